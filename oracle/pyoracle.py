@@ -1,0 +1,270 @@
+"""ctypes binding of the CPU oracle (oracle/build/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (ergo_uvo_amd) never imports this module.
+PARITY UNPINNED vs OpenCV (see oracle/uvo_oracle.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "build", "liboracle.so")
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+class KeyPoint(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("size", C.c_float), ("angle", C.c_float),
+                ("response", C.c_float), ("octave", C.c_int), ("class_id", C.c_int)]
+
+
+class DMatch(C.Structure):
+    _fields_ = [("queryIdx", C.c_int), ("trainIdx", C.c_int), ("imgIdx", C.c_int), ("distance", C.c_float)]
+
+
+class SurfParams(C.Structure):
+    _fields_ = [("hessianThreshold", C.c_double), ("nOctaves", C.c_int), ("nOctaveLayers", C.c_int),
+                ("extended", C.c_int), ("upright", C.c_int)]
+
+
+class VoParams(C.Structure):
+    _fields_ = [("DISTANCE", C.c_int), ("LOWE_RATIO_THRESHOLD", C.c_double),
+                ("ESSENTIAL_OUTLIER_METHOD", C.c_int), ("ESSENTIAL_MAX_ITERS", C.c_double),
+                ("ESSENTIAL_CONFIDENCE", C.c_double), ("ESSENTIAL_THRESHOLD", C.c_double),
+                ("HOMOGRAPHY_OUTLIER_METHOD", C.c_int), ("HOMOGRAPHY_MAX_ITERS", C.c_double),
+                ("HOMOGRAPHY_CONFIDENCE", C.c_double), ("HOMOGRAPHY_THRESHOLD", C.c_double),
+                ("HOMOGRAPHY_DISTANCE", C.c_double), ("VPF_THRESHOLD", C.c_double),
+                ("REPROJECTION_TOLERANCE", C.c_double), ("MIN_NUM_FEATURES", C.c_int),
+                ("MIN_NUM_3DPOINTS", C.c_int), ("MIN_NUM_INLIERS", C.c_int), ("ITERATIONS_COUNT", C.c_int),
+                ("REPROJECTION_ERROR_THRESHOLD", C.c_double), ("CONFIDENCE", C.c_double),
+                ("USE_EXTRINSIC_GUESS", C.c_int), ("PNP_METHOD_FLAG", C.c_int),
+                ("SURF_MIN_HESSIAN", C.c_int), ("SURF_OCTAVES_NUMBER", C.c_int), ("SURF_OCTAVES_LAYERS", C.c_int),
+                ("SURF_EXTENDED", C.c_int), ("SURF_UPRIGHT", C.c_int)]
+
+
+class StereoResult(C.Structure):
+    _fields_ = [("valid", C.c_int), ("initialized", C.c_int), ("n_left", C.c_int), ("n_right", C.c_int),
+                ("n_stereo_matches", C.c_int), ("n_tri_matches", C.c_int), ("n_good3d", C.c_int),
+                ("n_inliers", C.c_int), ("rvec", C.c_double * 3), ("tvec", C.c_double * 3),
+                ("t_prev_curr", C.c_double * 3), ("velocity", C.c_double * 3)]
+
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"),
+                     ("octave", "i4"), ("class_id", "i4")])
+DM_DTYPE = np.dtype([("queryIdx", "i4"), ("trainIdx", "i4"), ("imgIdx", "i4"), ("distance", "f4")])
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_l2_distance_f32.restype = C.c_float
+        _lib.orc_hypot.restype = C.c_double
+        _lib.orc_hypot.argtypes = [C.c_double, C.c_double]
+        _lib.orc_acos.restype = C.c_double
+        _lib.orc_acos.argtypes = [C.c_double]
+        _lib.orc_sincos.argtypes = [C.c_double, C.c_void_p, C.c_void_p]
+        _lib.orc_compute_median.restype = C.c_double
+        _lib.orc_stereo_create.restype = C.c_void_p
+        _lib.orc_stereo_destroy.argtypes = [C.c_void_p]
+        _lib.orc_stereo_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        _lib.orc_stereo_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+        _lib.orc_rng_init.argtypes = [C.c_void_p, C.c_uint64]
+        _lib.orc_rng_next.restype = C.c_uint32
+        _lib.orc_ransac_update_num_iters.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def stereo_params(min_hessian=1500) -> VoParams:
+    """stereo_VO_parameters.yaml:20-47."""
+    p = VoParams()
+    p.LOWE_RATIO_THRESHOLD = 0.8
+    p.REPROJECTION_TOLERANCE = 3.0
+    p.MIN_NUM_FEATURES = 5
+    p.MIN_NUM_3DPOINTS = 5
+    p.MIN_NUM_INLIERS = 5
+    p.ITERATIONS_COUNT = 1000
+    p.REPROJECTION_ERROR_THRESHOLD = 1.0
+    p.CONFIDENCE = 0.99
+    p.USE_EXTRINSIC_GUESS = 0
+    p.PNP_METHOD_FLAG = 1
+    p.SURF_MIN_HESSIAN = int(min_hessian)
+    p.SURF_OCTAVES_NUMBER = 4
+    p.SURF_OCTAVES_LAYERS = 3
+    p.SURF_EXTENDED = 0
+    p.SURF_UPRIGHT = 1
+    return p
+
+
+# ------------------------------------------------------------------ SURF
+def integral(img: np.ndarray) -> np.ndarray:
+    img = _c(img, np.uint8)
+    h, w = img.shape
+    out = np.empty((h + 1, w + 1), np.int32)
+    lib().orc_integral_u8(_p(img), w, h, w, _p(out))
+    return out
+
+
+def surf_layer(sum_: np.ndarray, size: int, step: int):
+    h, w = sum_.shape[0] - 1, sum_.shape[1] - 1
+    det = np.zeros((h // step, w // step), np.float32)
+    tr = np.zeros_like(det)
+    s = _c(sum_, np.int32)
+    lib().orc_surf_layer(_p(s), w, h, size, step, _p(det), _p(tr))
+    return det, tr
+
+
+def surf(img: np.ndarray, hessian=1500.0, n_octaves=4, n_layers=3, cap=20000):
+    img = _c(img, np.uint8)
+    h, w = img.shape
+    sp = SurfParams(float(hessian), n_octaves, n_layers, 0, 1)
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 64), np.float32)
+    n = lib().orc_surf_detect_and_compute(_p(img), w, h, w, C.byref(sp), _p(kps), _p(desc), cap)
+    if n < 0:
+        raise RuntimeError(f"oracle SURF: capacity {cap} too small ({-n} keypoints)")
+    return kps[:n].copy(), desc[:n].copy()
+
+
+def resize_area(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = _c(src, np.uint8)
+    out = np.empty((dh, dw), np.uint8)
+    lib().orc_resize_area_u8(_p(src), src.shape[1], src.shape[0], _p(out), dw, dh)
+    return out
+
+
+# ------------------------------------------------------------------ matching
+def knn2(d1: np.ndarray, d2: np.ndarray):
+    d1 = _c(d1, np.float32)
+    d2 = _c(d2, np.float32)
+    idx = np.empty((len(d1), 2), np.int32)
+    dist = np.empty((len(d1), 2), np.float32)
+    lib().orc_knn2(_p(d1), len(d1), _p(d2), len(d2), d1.shape[1] if d1.ndim == 2 else 64, _p(idx), _p(dist))
+    return idx, dist
+
+
+def match(d1: np.ndarray, d2: np.ndarray, ratio: float) -> np.ndarray:
+    d1 = _c(d1, np.float32)
+    d2 = _c(d2, np.float32)
+    out = np.zeros(max(len(d1), 1), DM_DTYPE)
+    m = C.c_int(0)
+    lib().orc_match_knn2_ratio(_p(d1), len(d1), _p(d2), len(d2), 64, C.c_float(ratio), _p(out), len(out), C.byref(m))
+    return out[:m.value].copy()
+
+
+# ------------------------------------------------------------------ geometry
+def triangulate(P1, P2, x1, x2) -> np.ndarray:
+    P1 = _c(P1, np.float64); P2 = _c(P2, np.float64)
+    x1 = _c(x1, np.float32); x2 = _c(x2, np.float32)
+    n = len(x1)
+    out = np.empty((4, n), np.float32)
+    lib().orc_triangulate_points(_p(P1), _p(P2), _p(x1), _p(x2), n, _p(out))
+    return out
+
+
+def rodrigues_vec2mat(r):
+    r = _c(r, np.float64); R = np.empty((3, 3))
+    lib().orc_rodrigues_vec2mat(_p(r), _p(R))
+    return R
+
+
+def rodrigues_mat2vec(R):
+    R = _c(R, np.float64); r = np.empty(3)
+    lib().orc_rodrigues_mat2vec(_p(R), _p(r))
+    return r
+
+
+def extract_3d_points(k1, k2, R1, t1, R2, t2, K1, K2, points4d, min_pts=5, tol=3.0):
+    k1 = _c(k1, np.float32); k2 = _c(k2, np.float32)
+    n = len(k1)
+    p4 = _c(points4d, np.float32)
+    pts = np.empty((max(n, 1), 3)); idx = np.empty(max(n, 1), np.int32)
+    a = [_c(x, np.float64) for x in (R1, t1, R2, t2, K1, K2)]
+    g = lib().orc_extract_3Dpoints(_p(k1), _p(k2), n, *[_p(x) for x in a], _p(p4), min_pts, C.c_double(tol), _p(pts), _p(idx))
+    return pts[:g].copy(), idx[:g].copy()
+
+
+def solve_pnp_ransac(obj, img, K, iters=1000, reproj=1.0, conf=0.99):
+    obj = _c(obj, np.float64); img = _c(img, np.float32); K = _c(K, np.float64)
+    n = len(obj)
+    rvec = np.zeros(3); tvec = np.zeros(3); inl = np.empty(max(n, 1), np.int32); ni = C.c_int(0)
+    ok = lib().orc_solve_pnp_ransac(_p(obj), _p(img), n, _p(K), iters, C.c_float(reproj), C.c_double(conf),
+                                    _p(rvec), _p(tvec), _p(inl), C.byref(ni))
+    return bool(ok), rvec, tvec, inl[:ni.value].copy()
+
+
+def epnp(pws, us, fu, fv, uc, vc):
+    pws = _c(pws, np.float64); us = _c(us, np.float64)
+    R = np.empty((3, 3)); t = np.empty(3)
+    lib().orc_epnp(_p(pws), _p(us), len(pws), C.c_double(fu), C.c_double(fv), C.c_double(uc), C.c_double(vc), _p(R), _p(t))
+    return R, t
+
+
+def svd(A):
+    A = _c(A, np.float64); m, n = A.shape; k = min(m, n)
+    w = np.empty(k); u = np.empty((m, k)); vt = np.empty((k, n))
+    lib().orc_svd(_p(A), m, n, _p(w), _p(u), _p(vt))
+    return u, w, vt
+
+
+# ------------------------------------------------------------------ stereo VO
+class StereoVO:
+    def __init__(self, params: VoParams, K_left, K_right, R_right, t_right, max_kpts=20000):
+        self._keep = [_c(x, np.float64) for x in (K_left, K_right, R_right, t_right)]
+        self.cap = max_kpts
+        self.h = lib().orc_stereo_create(C.byref(params), *[_p(x) for x in self._keep], max_kpts)
+
+    def step(self, left, right, dt=0.05) -> StereoResult:
+        left = _c(left, np.uint8); right = _c(right, np.uint8)
+        h, w = left.shape
+        r = StereoResult()
+        lib().orc_stereo_step(self.h, _p(left), _p(right), w, h, w, dt, C.byref(r))
+        return r
+
+    def get(self, what: str):
+        spec = {"kps_left": KP_DTYPE, "kps_right": KP_DTYPE, "desc_left": np.dtype(("f4", 64)),
+                "desc_right": np.dtype(("f4", 64)), "matches_stereo": DM_DTYPE, "matches_tri": DM_DTYPE,
+                "points4d": np.dtype(("f4", 4)), "good_pts": np.dtype(("f8", 3)), "good_idx": np.dtype("i4"),
+                "inliers": np.dtype("i4")}[what]
+        buf = np.zeros(self.cap * 4, spec)
+        n = lib().orc_stereo_get(self.h, what.encode(), _p(buf), buf.nbytes)
+        if n < 0:
+            raise RuntimeError("buffer too small")
+        out = buf[:n].copy()
+        if what == "points4d":  # stored 4 x T
+            raw = np.frombuffer(buf.tobytes(), np.float32)[:4 * n]
+            out = raw.reshape(4, n).copy()
+        return out
+
+    def close(self):
+        if self.h:
+            lib().orc_stereo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,162 @@
+/*
+ * uvo_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the UVO feature-match + relative-pose hot path
+ * (reference: team-ergo-unipi/ergo_uvo, uvo_libraries/src/VO_utility.cpp,
+ * uvo/include/visual_odometry.h) and of the OpenCV 4.5.x / opencv_contrib
+ * routines those files call.  OpenCV is an un-vendored third-party dependency
+ * of the reference ("OpenCV 4.5" + contrib xfeatures2d, README.md:60,70-72;
+ * find_package(OpenCV 4 REQUIRED), uvo_libraries/CMakeLists.txt:15) and is not
+ * available in this environment, and the reference ships no tests, golden
+ * vectors or data.
+ *
+ *   >>> PARITY UNPINNED vs OpenCV: nothing here could be checked against a
+ *   >>> run of the reference.  What pins this oracle is analytic known-answer
+ *   >>> tests (tests/test_oracle_*.py) and self-generated fixtures
+ *   >>> (tests/golden/).  Parity shown elsewhere is HIP <-> this restatement.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (ergo_uvo_amd/) never includes, links or
+ * calls anything in oracle/.
+ *
+ * Every function cites the reference line(s) it follows (VOU = VO_utility.cpp,
+ * VO = visual_odometry.h, MU = math_utility.cpp) and/or the upstream OpenCV
+ * routine it restates ([UPSTREAM], recalled behaviour).
+ */
+#ifndef UVO_ORACLE_H
+#define UVO_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- boundary PODs (same memory layout as cv::KeyPoint / cv::DMatch / cv::Point2f) ---- */
+typedef struct { float x, y, size, angle, response; int octave, class_id; } orc_keypoint; /* 28 B */
+typedef struct { int queryIdx, trainIdx, imgIdx; float distance; } orc_dmatch;           /* 16 B */
+typedef struct { float x, y; } orc_point2f;
+
+/* ---- scalar helpers ([UPSTREAM] core/fast_math.hpp, core/operations.hpp) ---- */
+int      orc_cvRound(double v);          /* lrint, round-half-even */
+int      orc_cvRoundf(float v);
+int      orc_cvFloor(double v);
+int      orc_cvCeil(double v);
+typedef struct { uint64_t state; } orc_rng;
+void     orc_rng_init(orc_rng* r, uint64_t seed);
+uint32_t orc_rng_next(orc_rng* r);
+int      orc_rng_uniform(orc_rng* r, int a, int b);
+
+/* deterministic elementary functions shared (operation for operation) with the
+ * HIP path: plain IEEE double arithmetic, no libm, so host and device agree
+ * bit for bit.  <= 2 ulp from libm (documented departure). */
+double orc_hypot(double a, double b);
+void   orc_sincos(double x, double* s, double* c);
+double orc_acos(double c);
+
+/* ---- dense linear algebra ([UPSTREAM] core/src/lapack.cpp, matmul) ---- */
+/* One-sided Jacobi SVD exactly as JacobiSVDImpl_<double>: At is n rows of m
+ * (rows = columns of A), W n values, Vt n x n (may be NULL), n1 rows of U^T
+ * completed.  Strides in elements. */
+void orc_jacobi_svd(double* At, int astep, double* W, double* Vt, int vstep, int m, int n, int n1);
+/* cv::SVD::compute(A[m x n]) -> w[min], u[m x min], vt[min x n] (row-major, tight) */
+void orc_svd(const double* A, int m, int n, double* w, double* u, double* vt);
+/* cv::solve(A[m x n], b[m], DECOMP_SVD) -> x[n] */
+void orc_solve_svd(const double* A, int m, int n, const double* b, double* x);
+/* cv::invert(A[3x3], DECOMP_SVD) */
+void orc_invert3_svd(const double* A, double* Ainv);
+/* cv::mulTransposed(src[rows x cols], aTa=true) -> dst[cols x cols] */
+void orc_mul_transposed(const double* src, int rows, int cols, double* dst);
+
+/* ---- SURF ([UPSTREAM] opencv_contrib xfeatures2d/src/surf.cpp; VOU:114-119) ---- */
+typedef struct {
+    double hessianThreshold; int nOctaves, nOctaveLayers, extended, upright;
+} orc_surf_params;
+void orc_integral_u8(const uint8_t* img, int w, int h, int stride, int32_t* sum /* (h+1)*(w+1) */);
+/* one det/trace layer: planes are (h/step) x (w/step), caller-zeroed */
+void orc_surf_layer(const int32_t* sum, int w, int h, int size, int step, float* det, float* trace);
+/* full detectAndCompute; returns number of keypoints (<= cap, or -needed if cap too small) */
+int  orc_surf_detect_and_compute(const uint8_t* img, int w, int h, int stride, const orc_surf_params* p,
+                                 orc_keypoint* kps, float* desc, int cap);
+/* cv::resize(u8 src sw x sh -> dst dw x dh, INTER_AREA), downscale only */
+void orc_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh);
+void orc_gaussian_kernel_f32(int n, double sigma, float* out);
+
+/* ---- matching ([UPSTREAM] features2d BFMatcher / core batchDistance; VOU:515-573) ---- */
+float orc_l2_distance_f32(const float* a, const float* b, int n);
+/* knnMatch k=2 + Lowe ratio; appends to out starting at *m (VOU:533-540 appends). */
+int  orc_match_knn2_ratio(const float* d1, int n1, const float* d2, int n2, int dim, float ratio,
+                          orc_dmatch* out, int cap, int* m);
+/* raw knn (for tests): idx[2*n1], dist[2*n1]; idx=-1 when absent */
+void orc_knn2(const float* d1, int n1, const float* d2, int n2, int dim, int* idx, float* dist);
+
+/* ---- geometry ([UPSTREAM] calib3d triangulate.cpp, calibration.cpp) ---- */
+void orc_triangulate_points(const double* P1, const double* P2, const orc_point2f* x1, const orc_point2f* x2,
+                            int n, float* out4xN);
+void orc_rodrigues_vec2mat(const double* r, double* R);
+void orc_rodrigues_mat2vec(const double* R, double* r);
+/* cv::projectPoints, no distortion; R is a 3x3 matrix */
+void orc_project_points_f64(const double* X, int n, const double* R, const double* t, const double* K, double* out2n);
+void orc_project_points_f32(const float* X, int n, const double* R, const double* t, const double* K, float* out2n);
+
+/* ---- uvo_libraries functions (VOU / MU) ---- */
+typedef struct {
+    /* vo_params */
+    int    DISTANCE;
+    double LOWE_RATIO_THRESHOLD;
+    int    ESSENTIAL_OUTLIER_METHOD; double ESSENTIAL_MAX_ITERS, ESSENTIAL_CONFIDENCE, ESSENTIAL_THRESHOLD;
+    int    HOMOGRAPHY_OUTLIER_METHOD; double HOMOGRAPHY_MAX_ITERS, HOMOGRAPHY_CONFIDENCE, HOMOGRAPHY_THRESHOLD, HOMOGRAPHY_DISTANCE;
+    double VPF_THRESHOLD, REPROJECTION_TOLERANCE;
+    int    MIN_NUM_FEATURES, MIN_NUM_3DPOINTS, MIN_NUM_INLIERS;
+    int    ITERATIONS_COUNT; double REPROJECTION_ERROR_THRESHOLD, CONFIDENCE; int USE_EXTRINSIC_GUESS, PNP_METHOD_FLAG;
+    int    SURF_MIN_HESSIAN, SURF_OCTAVES_NUMBER, SURF_OCTAVES_LAYERS, SURF_EXTENDED, SURF_UPRIGHT;
+} orc_vo_params;
+
+double orc_compute_median(const double* v, int n);                        /* MU:65-86 */
+void   orc_compute_mean_and_variance(const double* v, int n, double* mv); /* MU:35-56 */
+/* VOU:632-651 */
+void   orc_reproject_errors(const double* world, int n, const double* R, const double* t, const double* K,
+                            const orc_point2f* img, double* err);
+/* VOU:188-237; returns G, fills pts[G*3] (f64) and idx[G] */
+int    orc_extract_3Dpoints(const orc_point2f* k1, const orc_point2f* k2, int n,
+                            const double* R1, const double* t1, const double* R2, const double* t2,
+                            const double* K1, const double* K2, const float* points4D /* 4 x n */,
+                            int min_num_3dpoints, double reproj_tol, double* pts, int* idx);
+
+/* cv::solvePnPRansac(..., flags = SOLVEPNP_EPNP) as called at VO:647-648.
+ * obj: n x 3 f64, img: n Point2f.  Returns 1/0 (OpenCV bool); inliers ascending. */
+int    orc_solve_pnp_ransac(const double* obj, const orc_point2f* img, int n, const double* K,
+                            int iterationsCount, float reprojectionError, double confidence,
+                            double* rvec, double* tvec, int* inliers, int* n_inliers);
+/* one EPnP solve on double points (normalised image coords xn,yn given as us = x*fu+uc) */
+void   orc_epnp(const double* pws, const double* us, int n, double fu, double fv, double uc, double vc,
+                double* R, double* t);
+int    orc_ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters);
+
+/* ---- stereo VO state machine (VO:406-741), ROS-free ---- */
+typedef struct orc_stereo orc_stereo;
+typedef struct {
+    int    valid;                 /* successful_estimate.data */
+    int    initialized;           /* 0 while in the init loop (VO:474-506) */
+    int    n_left, n_right;       /* keypoints per image */
+    int    n_stereo_matches;      /* results_match_curr.size() */
+    int    n_tri_matches;         /* results_match_prev_curr.size() */
+    int    n_good3d;              /* good_prevCam_points.rows */
+    int    n_inliers;             /* inliers_idx.rows */
+    double rvec[3], tvec[3];      /* R_currCam_prevCam_Vec, t_currCam_prevCam */
+    double t_prev_curr[3];        /* t_prevCam_currCam (kept on failure) */
+    double velocity[3];           /* t_prevCam_currCam / dt  (VO:148-159) */
+} orc_stereo_result;
+orc_stereo* orc_stereo_create(const orc_vo_params* p, const double* K_left, const double* K_right,
+                              const double* R_right, const double* t_right, int max_kpts);
+void        orc_stereo_destroy(orc_stereo* s);
+int         orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
+                            double dt, orc_stereo_result* out);
+/* introspection for parity tests: last step's intermediate arrays */
+int         orc_stereo_get(orc_stereo* s, const char* what, void* out, int cap_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
