@@ -1,0 +1,271 @@
+"""ergo_uvo_amd -- MI355X-native hot path of UVO (team-ergo-unipi/ergo_uvo): upright SURF-64,
+brute-force L2 2-NN + ratio test, triangulation and EPnP PnP-RANSAC, behind the C ABI of
+include/uvo_hip.h (hand-written HIP for gfx950 in csrc/).
+
+This module is the Python-side mirror of the reference's `uvo_libraries` function surface
+(uvo_libraries/include/uvo_libraries/VO_utility.h:96-117): same function names and argument
+meaning, numpy in / numpy out, every call going through libuvo_hip.so.  Images and descriptors
+may also be torch CUDA(ROCm) tensors, in which case they are used in place (no host copy).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+__all__ = ["Params", "Context", "StereoResult", "UvoError", "KP_DTYPE", "DM_DTYPE", "build"]
+
+build = _lib.build
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"),
+                     ("octave", "i4"), ("class_id", "i4")])          # cv::KeyPoint, 28 B
+DM_DTYPE = np.dtype([("queryIdx", "i4"), ("trainIdx", "i4"), ("imgIdx", "i4"), ("distance", "f4")])  # cv::DMatch
+
+MEM_HOST, MEM_DEVICE = 0, 1
+_STATUS = {1: "UVO_INVALID_ARG", 2: "UVO_TOO_FEW_POINTS", 3: "UVO_CAPACITY", 4: "UVO_HIP_ERROR", 5: "UVO_NO_DEVICE"}
+
+
+class UvoError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"{_STATUS.get(status, status)}: {msg}")
+        self.status = status
+
+
+class Params(C.Structure):
+    """uvo_params: the globals of VO_utility.h:25-89 read by the hot path."""
+    _fields_ = [("DISTANCE", C.c_int), ("LOWE_RATIO_THRESHOLD", C.c_double),
+                ("ESSENTIAL_OUTLIER_METHOD", C.c_int), ("ESSENTIAL_MAX_ITERS", C.c_double),
+                ("ESSENTIAL_CONFIDENCE", C.c_double), ("ESSENTIAL_THRESHOLD", C.c_double),
+                ("HOMOGRAPHY_OUTLIER_METHOD", C.c_int), ("HOMOGRAPHY_MAX_ITERS", C.c_double),
+                ("HOMOGRAPHY_CONFIDENCE", C.c_double), ("HOMOGRAPHY_THRESHOLD", C.c_double),
+                ("HOMOGRAPHY_DISTANCE", C.c_double), ("VPF_THRESHOLD", C.c_double),
+                ("REPROJECTION_TOLERANCE", C.c_double), ("MIN_NUM_FEATURES", C.c_int),
+                ("MIN_NUM_3DPOINTS", C.c_int), ("MIN_NUM_INLIERS", C.c_int), ("ITERATIONS_COUNT", C.c_int),
+                ("REPROJECTION_ERROR_THRESHOLD", C.c_double), ("CONFIDENCE", C.c_double),
+                ("USE_EXTRINSIC_GUESS", C.c_int), ("PNP_METHOD_FLAG", C.c_int),
+                ("SURF_MIN_HESSIAN", C.c_int), ("SURF_OCTAVES_NUMBER", C.c_int), ("SURF_OCTAVES_LAYERS", C.c_int),
+                ("SURF_EXTENDED", C.c_int), ("SURF_UPRIGHT", C.c_int)]
+
+    @classmethod
+    def stereo(cls, **kw) -> "Params":
+        p = cls()
+        _lib.lib().uvo_params_default_stereo(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    @classmethod
+    def mono(cls, **kw) -> "Params":
+        p = cls()
+        _lib.lib().uvo_params_default_mono(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+
+class StereoResult(C.Structure):
+    _fields_ = [("valid", C.c_int), ("initialized", C.c_int), ("n_left", C.c_int), ("n_right", C.c_int),
+                ("n_stereo_matches", C.c_int), ("n_tri_matches", C.c_int), ("n_good3d", C.c_int),
+                ("n_inliers", C.c_int), ("rvec", C.c_double * 3), ("tvec", C.c_double * 3),
+                ("t_prev_curr", C.c_double * 3), ("velocity", C.c_double * 3)]
+
+
+def _is_device(a) -> bool:
+    return hasattr(a, "data_ptr") and getattr(a, "is_cuda", False)
+
+
+def _ptr_mem(a, dtype):
+    """(pointer, mem, keepalive) of a numpy array or a torch CUDA tensor."""
+    if _is_device(a):
+        if not a.is_contiguous():
+            raise ValueError("device tensors must be contiguous")
+        return C.c_void_p(a.data_ptr()), MEM_DEVICE, a
+    arr = np.ascontiguousarray(a, dtype=dtype)
+    return arr.ctypes.data_as(C.c_void_p), MEM_HOST, arr
+
+
+def _np(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One uvo_ctx: one GPU, one HIP stream, all device workspaces."""
+
+    def __init__(self, params: Params, device: int = 0, max_w: int = 1920, max_h: int = 1080, max_kpts: int = 8192):
+        self._lib = _lib.lib()
+        self.params = params
+        self.max_kpts = max_kpts
+        h = C.c_void_p()
+        st = self._lib.uvo_ctx_create(C.byref(params), device, max_w, max_h, max_kpts, C.byref(h))
+        if st != 0:
+            raise UvoError(st, "uvo_ctx_create failed (no usable HIP device?)" if st == 5 else "uvo_ctx_create failed")
+        self._h = h
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, st):
+        if st != 0:
+            raise UvoError(st, (self._lib.uvo_last_error(self._h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.uvo_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self) -> int:
+        return self._lib.uvo_ctx_stream(self._h)
+
+    def set_params(self, params: Params):
+        self.params = params
+        self._check(self._lib.uvo_ctx_set_params(self._h, C.byref(params)))
+
+    # ------------------------------------------------------------------ uvo_libraries mirror
+    def detect_features(self, img):
+        """detect_features(img, keypoints, descriptors), SURF branch (VO_utility.cpp:114-119)."""
+        h, w = img.shape[-2], img.shape[-1]
+        p, mem, keep = _ptr_mem(img, np.uint8)
+        n = C.c_int(0)
+        kps = np.zeros(self.max_kpts, KP_DTYPE)
+        desc = np.zeros((self.max_kpts, 64), np.float32)
+        self._check(self._lib.uvo_surf_detect(self._h, p, w, h, w, mem, _p(kps), _p(desc), self.max_kpts, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def integral(self, img):
+        h, w = img.shape
+        p, mem, keep = _ptr_mem(img, np.uint8)
+        out = np.empty((h + 1, w + 1), np.int32)
+        self._check(self._lib.uvo_integral(self._h, p, w, h, w, mem, _p(out)))
+        return out
+
+    def hessian_layer(self, shape, octave: int, layer: int):
+        h, w = shape
+        step = 1 << octave
+        det = np.empty((h // step, w // step), np.float32)
+        tr = np.empty_like(det)
+        self._check(self._lib.uvo_hessian_layer(self._h, octave, layer, _p(det), _p(tr)))
+        return det, tr
+
+    def match_features(self, descriptors1, descriptors2, ratio=None, matches=None):
+        """match_features (VO_utility.cpp:515-543); appends to `matches` like the reference."""
+        ratio = float(self.params.LOWE_RATIO_THRESHOLD if ratio is None else ratio)
+        n1, n2 = int(descriptors1.shape[0]), int(descriptors2.shape[0])
+        p1, m1, k1 = _ptr_mem(descriptors1, np.float32)
+        p2, m2, k2 = _ptr_mem(descriptors2, np.float32)
+        if m1 != m2:
+            raise ValueError("descriptors1 and descriptors2 must live in the same memory space")
+        prev = 0 if matches is None else len(matches)
+        out = np.zeros(prev + max(n1, 1), DM_DTYPE)
+        if prev:
+            out[:prev] = matches
+        m = C.c_int(prev)
+        self._check(self._lib.uvo_match_knn2_ratio(self._h, p1, n1, p2, n2, m1, C.c_float(ratio), _p(out), len(out), C.byref(m)))
+        return out[:m.value].copy()
+
+    def knn_match(self, descriptors1, descriptors2):
+        n1, n2 = int(descriptors1.shape[0]), int(descriptors2.shape[0])
+        p1, m1, k1 = _ptr_mem(descriptors1, np.float32)
+        p2, m2, k2 = _ptr_mem(descriptors2, np.float32)
+        idx = np.empty((n1, 2), np.int32)
+        dist = np.empty((n1, 2), np.float32)
+        self._check(self._lib.uvo_match_knn2(self._h, p1, n1, p2, n2, m1, _p(idx), _p(dist)))
+        return idx, dist
+
+    def triangulatePoints(self, P1, P2, pts1, pts2):
+        P1, P2 = _np(P1, np.float64), _np(P2, np.float64)
+        x1, x2 = _np(pts1, np.float32), _np(pts2, np.float32)
+        n = len(x1)
+        out = np.empty((4, n), np.float32)
+        self._check(self._lib.uvo_triangulate_points(self._h, _p(P1), _p(P2), _p(x1), _p(x2), n, _p(out)))
+        return out
+
+    def extract_3Dpoints(self, k1, k2, R1, t1, R2, t2, K1, K2, points4D):
+        k1, k2 = _np(k1, np.float32), _np(k2, np.float32)
+        n = len(k1)
+        p4 = _np(points4D, np.float32)
+        a = [_np(x, np.float64) for x in (R1, t1, R2, t2, K1, K2)]
+        pts = np.empty((max(n, 1), 3))
+        idx = np.empty(max(n, 1), np.int32)
+        g = C.c_int(0)
+        self._check(self._lib.uvo_extract_3d_points(self._h, _p(k1), _p(k2), n, *[_p(x) for x in a], _p(p4), _p(pts), _p(idx), C.byref(g)))
+        return pts[:g.value].copy(), idx[:g.value].copy()
+
+    def solvePnPRansac(self, object_points, image_points, K, iterations_count=None, reprojection_error=None, confidence=None):
+        p = self.params
+        it = int(p.ITERATIONS_COUNT if iterations_count is None else iterations_count)
+        re_ = float(p.REPROJECTION_ERROR_THRESHOLD if reprojection_error is None else reprojection_error)
+        cf = float(p.CONFIDENCE if confidence is None else confidence)
+        obj, img, K = _np(object_points, np.float64), _np(image_points, np.float32), _np(K, np.float64)
+        n = len(obj)
+        rvec, tvec = np.zeros(3), np.zeros(3)
+        inl = np.empty(max(n, 1), np.int32)
+        ni, ok = C.c_int(0), C.c_int(0)
+        self._check(self._lib.uvo_solve_pnp_ransac(self._h, _p(obj), _p(img), n, _p(K), it, C.c_float(re_), C.c_double(cf),
+                                                   _p(rvec), _p(tvec), _p(inl), C.byref(ni), C.byref(ok)))
+        return bool(ok.value), rvec, tvec, inl[:ni.value].copy()
+
+    def Rodrigues(self, x):
+        x = _np(x, np.float64).ravel()
+        out = np.empty(9 if x.size == 3 else 3)
+        st = self._lib.uvo_rodrigues(_p(x), int(x.size), _p(out))
+        if st != 0:
+            raise UvoError(st, "uvo_rodrigues: input must have 3 or 9 elements")
+        return out.reshape(3, 3) if x.size == 3 else out
+
+    # ------------------------------------------------------------------ stereo loop (visual_odometry.h:406-741)
+    def stereo_set_rig(self, K_left, K_right, R_right, t_right):
+        a = [_np(x, np.float64) for x in (K_left, K_right, R_right, t_right)]
+        self._check(self._lib.uvo_stereo_set_rig(self._h, *[_p(x) for x in a]))
+
+    def stereo_reset(self):
+        self._check(self._lib.uvo_stereo_reset(self._h))
+
+    def stereo_step(self, left, right, dt: float = 0.05) -> StereoResult:
+        h, w = left.shape[-2], left.shape[-1]
+        pl, ml, kl = _ptr_mem(left, np.uint8)
+        pr, mr, kr = _ptr_mem(right, np.uint8)
+        if ml != mr:
+            raise ValueError("left and right must live in the same memory space")
+        r = StereoResult()
+        self._check(self._lib.uvo_stereo_step(self._h, pl, pr, w, h, w, ml, C.c_double(dt), C.byref(r)))
+        return r
+
+    def stereo_get(self, what: str):
+        spec = {"kps_left": KP_DTYPE, "kps_right": KP_DTYPE, "desc_left": np.dtype(("f4", 64)),
+                "desc_right": np.dtype(("f4", 64)), "matches_stereo": DM_DTYPE, "matches_tri": DM_DTYPE,
+                "points4d": np.dtype(("f4", 4)), "good_pts": np.dtype(("f8", 3)), "good_idx": np.dtype("i4"),
+                "inliers": np.dtype("i4")}[what]
+        buf = np.zeros(self.max_kpts, spec)
+        n = self._lib.uvo_stereo_get(self._h, what.encode(), _p(buf), buf.nbytes)
+        if n < 0:
+            raise UvoError(3, "stereo_get buffer too small")
+        out = buf[:n].copy()
+        if what == "points4d":
+            out = np.ascontiguousarray(out.T)       # 4 x T like cv::triangulatePoints
+        return out
+
+    # ------------------------------------------------------------------ timing
+    def timing_enable(self, on: bool = True):
+        self._check(self._lib.uvo_timing_enable(self._h, int(on)))
+
+    def timing_reset(self):
+        self._check(self._lib.uvo_timing_reset(self._h))
+
+    def timing(self) -> dict:
+        out = {}
+        for i in range(self._lib.uvo_timing_count(self._h)):
+            ms, n = C.c_double(0), C.c_longlong(0)
+            self._lib.uvo_timing_get(self._h, i, C.byref(ms), C.byref(n))
+            out[self._lib.uvo_timing_name(self._h, i).decode()] = (ms.value, n.value)
+        return out

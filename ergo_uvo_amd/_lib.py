@@ -1,0 +1,54 @@
+"""Loader for libuvo_hip.so (the C ABI declared in include/uvo_hip.h).
+
+There is no CPU fallback: if the HIP library is missing it is (re)built with hipcc, and if that
+fails -- or no GPU is present when a context is created -- the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "lib", "libuvo_hip.so")
+
+EXPORTS = [
+    "uvo_params_default_stereo", "uvo_params_default_mono", "uvo_ctx_create", "uvo_ctx_destroy", "uvo_last_error",
+    "uvo_ctx_stream", "uvo_ctx_set_params", "uvo_surf_detect", "uvo_integral", "uvo_hessian_layer",
+    "uvo_match_knn2_ratio", "uvo_match_knn2", "uvo_triangulate_points", "uvo_extract_3d_points",
+    "uvo_solve_pnp_ransac", "uvo_rodrigues", "uvo_stereo_set_rig", "uvo_stereo_reset", "uvo_stereo_step",
+    "uvo_stereo_get", "uvo_timing_enable", "uvo_timing_count", "uvo_timing_name", "uvo_timing_get", "uvo_timing_reset",
+]
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into lib/libuvo_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "uvo_hip.h"))
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j4"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.uvo_last_error.restype = C.c_char_p
+        _lib.uvo_last_error.argtypes = [C.c_void_p]
+        _lib.uvo_ctx_stream.restype = C.c_void_p
+        _lib.uvo_ctx_stream.argtypes = [C.c_void_p]
+        _lib.uvo_ctx_destroy.argtypes = [C.c_void_p]
+        _lib.uvo_ctx_destroy.restype = None
+        _lib.uvo_timing_name.restype = C.c_char_p
+        _lib.uvo_timing_name.argtypes = [C.c_void_p, C.c_int]
+        for name in EXPORTS:
+            getattr(_lib, name)  # fail loudly if the ABI and the header drift apart
+    return _lib

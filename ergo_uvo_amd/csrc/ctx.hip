@@ -1,0 +1,573 @@
+// ctx.hip -- the C ABI of libuvo_hip.so (include/uvo_hip.h): context, standalone operators and the
+// fused stereo step (visual_odometry_node::stereo_VO, visual_odometry.h:474-739) with every
+// intermediate kept in HBM.
+#include "uvo_ctx.h"
+#include "uvo_epnp.h"
+#include <string.h>
+#include <math.h>
+#include <new>
+
+using namespace uvo;
+
+struct uvo_ctx : public uvo::Ctx {};
+
+// fixed slots of Ctx::d_counts / h_counts
+enum { CN_T = 0, CN_G = 1, CN_NINL = 2, CN_NQA = 3, CN_NQB = 4, CN_MEFF = 5, CN_NL = 6, CN_NR = 7,
+       CN_CAND0 = 8, CN_CAND1 = 9, CN_M = 10, CN_TRAW = 11, CN_AS0 = 12, CN_AS1 = 13, CN_TOTAL = 16 };
+
+extern "C" void uvo_params_default_stereo(uvo_params* p)
+{   // uvo/config/stereo_VO_parameters.yaml:20-47 (keys absent from that file stay zero, as the globals do)
+    memset(p, 0, sizeof(*p));
+    p->LOWE_RATIO_THRESHOLD = 0.8; p->REPROJECTION_TOLERANCE = 3.0;
+    p->MIN_NUM_FEATURES = 5; p->MIN_NUM_3DPOINTS = 5; p->MIN_NUM_INLIERS = 5;
+    p->ITERATIONS_COUNT = 1000; p->REPROJECTION_ERROR_THRESHOLD = 1.0; p->CONFIDENCE = 0.99;
+    p->USE_EXTRINSIC_GUESS = 0; p->PNP_METHOD_FLAG = 1;
+    p->SURF_MIN_HESSIAN = 1500; p->SURF_OCTAVES_NUMBER = 4; p->SURF_OCTAVES_LAYERS = 3; p->SURF_EXTENDED = 0; p->SURF_UPRIGHT = 1;
+}
+extern "C" void uvo_params_default_mono(uvo_params* p)
+{   // uvo/config/mono_VO_parameters.yaml:13-49
+    memset(p, 0, sizeof(*p));
+    p->DISTANCE = 10; p->LOWE_RATIO_THRESHOLD = 0.7;
+    p->ESSENTIAL_OUTLIER_METHOD = 4; p->ESSENTIAL_MAX_ITERS = 2000; p->ESSENTIAL_CONFIDENCE = 0.99; p->ESSENTIAL_THRESHOLD = 0.1;
+    p->HOMOGRAPHY_OUTLIER_METHOD = 4; p->HOMOGRAPHY_MAX_ITERS = 2000; p->HOMOGRAPHY_CONFIDENCE = 0.99; p->HOMOGRAPHY_THRESHOLD = 0.1;
+    p->HOMOGRAPHY_DISTANCE = 50.0; p->VPF_THRESHOLD = 0.4; p->REPROJECTION_TOLERANCE = 0.1;
+    p->MIN_NUM_FEATURES = 20; p->MIN_NUM_INLIERS = 10; p->MIN_NUM_3DPOINTS = 5;
+    p->SURF_MIN_HESSIAN = 50; p->SURF_OCTAVES_NUMBER = 4; p->SURF_OCTAVES_LAYERS = 3; p->SURF_EXTENDED = 0; p->SURF_UPRIGHT = 1;
+}
+
+template <class T>
+static hipError_t dalloc(T** p, size_t count) { return hipMalloc(reinterpret_cast<void**>(p), sizeof(T) * (count ? count : 1)); }
+
+// getGaussianKernel(20, 3.3, CV_32F) outer product (surf.cpp SURFInvoker ctor: DW)
+static void make_desc_weights(float* DW)
+{
+    double t[20], sum = 0; float G[20];
+    const double sigma = 3.3f;
+    double scale2X = -0.5 / (sigma * sigma);
+    for (int i = 0; i < 20; i++) { double x = i - 19 * 0.5; t[i] = exp(scale2X * x * x); sum += t[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < 20; i++) G[i] = (float)(t[i] * sum);
+    for (int i = 0; i < 20; i++) for (int j = 0; j < 20; j++) DW[i * 20 + j] = G[i] * G[j];
+}
+
+extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w, int max_h, int max_kpts, uvo_ctx** out)
+{
+    if (!out) return UVO_INVALID_ARG;
+    *out = nullptr;
+    if (!p || max_w < 16 || max_h < 16 || max_kpts < 16) return UVO_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return UVO_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return UVO_HIP_ERROR;
+    uvo_ctx* c = new (std::nothrow) uvo_ctx();
+    if (!c) return UVO_HIP_ERROR;
+    c->p = *p; c->device = device; c->max_w = max_w; c->max_h = max_h; c->cap = max_kpts;
+    const size_t cap = (size_t)max_kpts;
+    const size_t npx = (size_t)max_w * max_h, nsum = (size_t)(max_w + 1) * (max_h + 1);
+    const int nseg = (max_h + 31) / 32;
+    const size_t nchunks = (cap + kMatchChunk - 1) / kMatchChunk;
+    hipError_t e = hipSuccess;
+#define A(expr) do { if (e == hipSuccess) e = (expr); } while (0)
+    A(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    A(hipEventCreate(&c->ev0)); A(hipEventCreate(&c->ev1));
+    for (int i = 0; i < 2; i++) {
+        A(dalloc(&c->d_img[i], npx)); A(dalloc(&c->d_sum[i], nsum));
+        A(dalloc(&c->d_cand[i], cap)); A(dalloc(&c->det[i].kps, cap)); A(dalloc(&c->det[i].desc, cap * 64));
+        A(dalloc(&c->d_tmp_desc[i], cap * 64)); A(dalloc(&c->d_matches[i], cap));
+        A(dalloc(&c->d_as_kpsL[i], cap)); A(dalloc(&c->d_as_kpsR[i], cap)); A(dalloc(&c->d_as_descL[i], cap * 64));
+    }
+    A(dalloc(&c->d_colpart, (size_t)2 * nseg * (max_w + 1)));
+    A(dalloc(&c->d_DW, 400));
+    A(dalloc(&c->d_mpart, nchunks * cap)); A(dalloc(&c->d_knn_idx, cap * 2)); A(dalloc(&c->d_knn_dist, cap * 2));
+    A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
+    A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_good_pts, cap * 3)); A(dalloc(&c->d_good_idx, cap));
+    A(dalloc(&c->d_opts, cap * 3)); A(dalloc(&c->d_ipts, cap)); A(dalloc(&c->d_counts, (size_t)CN_TOTAL));
+    A(dalloc(&c->d_subsets, (size_t)kMaxHyp * 5)); A(dalloc(&c->d_models, (size_t)kMaxHyp * 6)); A(dalloc(&c->d_hcount, (size_t)kMaxHyp));
+    A(dalloc(&c->d_inliers, cap)); A(dalloc(&c->d_refit, cap * 37)); A(dalloc(&c->d_pose, (size_t)6));
+    A(hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), sizeof(int) * CN_TOTAL));
+    A(hipHostMalloc(reinterpret_cast<void**>(&c->h_subsets), sizeof(int) * kMaxHyp * 5));
+    A(hipHostMalloc(reinterpret_cast<void**>(&c->h_hcount), sizeof(int) * kMaxHyp));
+    A(hipHostMalloc(reinterpret_cast<void**>(&c->h_pose), sizeof(double) * 6));
+#undef A
+    if (e != hipSuccess) { uvo_ctx_destroy(c); return UVO_HIP_ERROR; }
+    c->d_cand_n = c->d_counts + CN_CAND0;
+    c->det[0].n = c->d_counts + CN_NL; c->det[1].n = c->d_counts + CN_NR;
+    c->d_nmatch = c->d_counts + CN_M;
+    c->d_as_n = c->d_counts + CN_AS0;
+    make_desc_weights(c->h_DW);
+    if (hipMemcpy(c->d_DW, c->h_DW, sizeof(float) * 400, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(c->d_counts, 0, sizeof(int) * CN_TOTAL) != hipSuccess) { uvo_ctx_destroy(c); return UVO_HIP_ERROR; }
+    *out = c;
+    return UVO_OK;
+}
+
+extern "C" void uvo_ctx_destroy(uvo_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 2; i++) {
+        (void)hipFree(c->d_img[i]); (void)hipFree(c->d_sum[i]); (void)hipFree(c->d_cand[i]); (void)hipFree(c->det[i].kps);
+        (void)hipFree(c->det[i].desc); (void)hipFree(c->d_tmp_desc[i]); (void)hipFree(c->d_matches[i]);
+        (void)hipFree(c->d_as_kpsL[i]); (void)hipFree(c->d_as_kpsR[i]); (void)hipFree(c->d_as_descL[i]);
+    }
+    void* ptrs[] = { c->d_colpart, c->d_DW, c->d_mpart, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
+                     c->d_flag, c->d_good_pts, c->d_good_idx, c->d_opts, c->d_ipts, c->d_counts, c->d_subsets, c->d_models,
+                     c->d_hcount, c->d_inliers, c->d_refit, c->d_pose };
+    for (void* p : ptrs) (void)hipFree(p);
+    (void)hipHostFree(c->h_counts); (void)hipHostFree(c->h_subsets); (void)hipHostFree(c->h_hcount); (void)hipHostFree(c->h_pose);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* uvo_last_error(const uvo_ctx* c) { return c ? c->err.c_str() : "null context"; }
+extern "C" void* uvo_ctx_stream(uvo_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" uvo_status uvo_ctx_set_params(uvo_ctx* c, const uvo_params* p)
+{
+    if (!c || !p) return UVO_INVALID_ARG;
+    c->p = *p;
+    return UVO_OK;
+}
+
+static uvo_status fail(uvo_ctx* c, uvo_status s, const char* msg) { c->err = msg; return s; }
+
+// ------------------------------------------------------------------------------------------ SURF
+static uvo_status read_counts(uvo_ctx* c)
+{
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(int) * CN_TOTAL, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return UVO_OK;
+}
+
+static uvo_status check_cand_overflow(uvo_ctx* c, int nimg)
+{
+    for (int i = 0; i < nimg; i++)
+        if (c->h_counts[CN_CAND0 + i] > c->cap)
+            return fail(c, UVO_CAPACITY, "SURF found more keypoints than the context's max_kpts; results would be order-dependent");
+    return UVO_OK;
+}
+
+extern "C" uvo_status uvo_surf_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem,
+                                      uvo_keypoint* kps, float* desc, int cap, int* n)
+{
+    if (!c || !n) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    UVO_TRY(surf_upload(c, 0, gray, w, h, stride, mem));
+    UVO_TRY(surf_detect(c, 1));
+    UVO_TRY(read_counts(c));
+    UVO_TRY(check_cand_overflow(c, 1));
+    int cnt = c->h_counts[CN_NL];
+    *n = cnt;
+    if ((kps || desc) && cnt > cap) return fail(c, UVO_CAPACITY, "uvo_surf_detect: output capacity too small");
+    if (kps && cnt) UVO_HIP_TRY(c, hipMemcpyAsync(kps, c->det[0].kps, sizeof(uvo_keypoint) * cnt, hipMemcpyDeviceToHost, c->stream));
+    if (desc && cnt) UVO_HIP_TRY(c, hipMemcpyAsync(desc, c->det[0].desc, sizeof(float) * 64 * cnt, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return UVO_OK;
+}
+
+extern "C" uvo_status uvo_integral(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int32_t* sum)
+{
+    if (!c || !sum) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    UVO_TRY(surf_upload(c, 0, gray, w, h, stride, mem));
+    UVO_TRY(surf_integral(c, 1));
+    UVO_HIP_TRY(c, hipMemcpyAsync(sum, c->d_sum[0], sizeof(int32_t) * (size_t)(w + 1) * (h + 1), hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return UVO_OK;
+}
+
+extern "C" uvo_status uvo_hessian_layer(uvo_ctx* c, int octave, int layer, float* det, float* trace)
+{
+    if (!c || !det || !trace) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    return surf_hessian_layer_debug(c, octave, layer, det, trace);
+}
+
+// ------------------------------------------------------------------------------------------ matching
+static uvo_status stage_desc(uvo_ctx* c, int slot, const float* d, int n, int mem, const float** out)
+{
+    if (n > c->cap) return fail(c, UVO_CAPACITY, "descriptor count exceeds the context's max_kpts");
+    if (mem == UVO_MEM_DEVICE) { *out = d; return UVO_OK; }
+    if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->d_tmp_desc[slot], d, sizeof(float) * 64 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    *out = c->d_tmp_desc[slot];
+    return UVO_OK;
+}
+
+extern "C" uvo_status uvo_match_knn2(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int mem, int* idx, float* dist)
+{
+    if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !idx || !dist) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n1 == 0) return UVO_OK;
+    if (n2 == 0) { for (int i = 0; i < 2 * n1; i++) { idx[i] = -1; dist[i] = FLT_MAX; } return UVO_OK; }
+    const float *q, *t;
+    UVO_TRY(stage_desc(c, 0, d1, n1, mem, &q));
+    UVO_TRY(stage_desc(c, 1, d2, n2, mem, &t));
+    UVO_TRY(match_knn2(c, q, nullptr, n1, t, nullptr, n2));
+    UVO_HIP_TRY(c, hipMemcpyAsync(idx, c->d_knn_idx, sizeof(int) * 2 * n1, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipMemcpyAsync(dist, c->d_knn_dist, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return UVO_OK;
+}
+
+extern "C" uvo_status uvo_match_knn2_ratio(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int mem,
+                                           float ratio, uvo_dmatch* out, int cap, int* m)
+{
+    if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !out || !m || *m < 0) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n1 == 0 || n2 == 0) return UVO_OK;          // knnMatch on an empty query/train set yields no matches
+    const float *q, *t;
+    UVO_TRY(stage_desc(c, 0, d1, n1, mem, &q));
+    UVO_TRY(stage_desc(c, 1, d2, n2, mem, &t));
+    UVO_TRY(match_knn2(c, q, nullptr, n1, t, nullptr, n2));
+    UVO_TRY(match_ratio_compact(c, nullptr, n1, ratio, c->d_matches[0], c->d_nmatch, c->cap));
+    UVO_TRY(read_counts(c));
+    int cnt = c->h_counts[CN_M];
+    if (*m + cnt > cap) return fail(c, UVO_CAPACITY, "uvo_match_knn2_ratio: output capacity too small");
+    if (cnt) UVO_HIP_TRY(c, hipMemcpyAsync(out + *m, c->d_matches[0], sizeof(uvo_dmatch) * cnt, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *m += cnt;                                       // appended, as VOU:538
+    return UVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------ geometry operators
+extern "C" uvo_status uvo_triangulate_points(uvo_ctx* c, const double* P1, const double* P2,
+                                             const uvo_point2f* x1, const uvo_point2f* x2, int n, float* out4xn)
+{
+    if (!c || !P1 || !P2 || n < 0 || (n && (!x1 || !x2 || !out4xn))) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n == 0) return UVO_OK;
+    if (n > c->cap) return fail(c, UVO_CAPACITY, "point count exceeds the context's max_kpts");
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x1, x1, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x2, x2, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
+    UVO_TRY(pose_triangulate(c, P1, P2, nullptr, n));
+    std::vector<float4> tmp(n);
+    UVO_HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->d_pts4, sizeof(float4) * n, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < n; i++) { out4xn[i] = tmp[i].x; out4xn[n + i] = tmp[i].y; out4xn[2*n + i] = tmp[i].z; out4xn[3*n + i] = tmp[i].w; }
+    return UVO_OK;
+}
+
+extern "C" uvo_status uvo_extract_3d_points(uvo_ctx* c, const uvo_point2f* k1, const uvo_point2f* k2, int n,
+                                            const double* R1, const double* t1, const double* R2, const double* t2,
+                                            const double* K1, const double* K2, const float* points4d,
+                                            double* pts, int* idx, int* g)
+{
+    if (!c || n < 0 || !g || !R1 || !t1 || !R2 || !t2 || !K1 || !K2 || (n && (!k1 || !k2 || !points4d || !pts || !idx))) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    *g = 0;
+    if (n == 0) return UVO_OK;
+    if (n > c->cap) return fail(c, UVO_CAPACITY, "point count exceeds the context's max_kpts");
+    std::vector<float4> tmp(n);
+    for (int i = 0; i < n; i++) tmp[i] = make_float4(points4d[i], points4d[n + i], points4d[2*n + i], points4d[3*n + i]);
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->d_pts4, tmp.data(), sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x1, k1, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x2, k2, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->d_xc, k1, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
+    UVO_TRY(pose_extract3d(c, R1, t1, R2, t2, K1, K2, nullptr, n));
+    UVO_TRY(read_counts(c));
+    int G = c->h_counts[CN_G];
+    if (G) {
+        UVO_HIP_TRY(c, hipMemcpyAsync(pts, c->d_good_pts, sizeof(double) * 3 * G, hipMemcpyDeviceToHost, c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(idx, c->d_good_idx, sizeof(int) * G, hipMemcpyDeviceToHost, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    *g = G;
+    return UVO_OK;
+}
+
+extern "C" uvo_status uvo_solve_pnp_ransac(uvo_ctx* c, const double* obj, const uvo_point2f* img, int n, const double* K,
+                                           int iterations_count, float reprojection_error, double confidence,
+                                           double* rvec, double* tvec, int* inliers, int* n_inliers, int* ok)
+{
+    if (!c || !obj || !img || !K || !rvec || !tvec || !n_inliers || !ok || n < 0) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n > c->cap) return fail(c, UVO_CAPACITY, "point count exceeds the context's max_kpts");
+    std::vector<float> of((size_t)3 * n);
+    for (int i = 0; i < 3 * n; i++) of[i] = (float)obj[i];                     // opoints0.convertTo(opoints, CV_32F)
+    if (n) {
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_opts, of.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_ipts, img, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    int ni = 0;
+    UVO_TRY(pose_pnp_ransac(c, n, K, iterations_count, reprojection_error, confidence, rvec, tvec, &ni, ok));
+    *n_inliers = ni;
+    if (inliers && ni) {
+        UVO_HIP_TRY(c, hipMemcpyAsync(inliers, c->d_inliers, sizeof(int) * ni, hipMemcpyDeviceToHost, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return UVO_OK;
+}
+
+// host fp64; the matrix -> vector direction needs the 3x3 Jacobi SVD
+extern "C" uvo_status uvo_rodrigues(const double* in, int n_in, double* out)
+{
+    if (!in || !out) return UVO_INVALID_ARG;
+    if (n_in == 3) { rodrigues_vec2mat(in, out); return UVO_OK; }
+    if (n_in == 9) {
+        double Rm[9], sc[33];
+        memcpy(Rm, in, sizeof(Rm));
+        rodrigues_mat2vec(SArr<1>{Rm}, SArr<1>{sc}, out);
+        return UVO_OK;
+    }
+    return UVO_INVALID_ARG;
+}
+
+// ------------------------------------------------------------------------------------------ stereo step
+__global__ void k_ctl_gate_a(int* cn, int min_features)
+{   // VO:556: both images need >= MIN_NUM_FEATURES keypoints, else no stereo matching
+    int nL = cn[CN_NL], nR = cn[CN_NR];
+    cn[CN_NQA] = (nL >= min_features && nR >= min_features) ? nL : 0;
+}
+__global__ void k_ctl_gate_b(int* cn, int min_features, int cap, int as_curr_slot, int as_prev_slot, int nq_a_was_zero_clears)
+{   // VO:567: results_match_curr.size() > MIN_NUM_FEATURES, else the "after stereo match" sets stay empty
+    int M = cn[CN_NQA] > 0 ? cn[CN_M] : 0;
+    if (cn[CN_NQA] == 0) cn[CN_M] = 0;
+    int meff = (M > min_features) ? min(M, cap) : 0;
+    cn[CN_MEFF] = meff;
+    cn[as_curr_slot] = meff;
+    cn[CN_NQB] = meff > 0 ? cn[as_prev_slot] : 0;     // triangular matching only runs inside that branch
+}
+__global__ void k_ctl_gate_c(int* cn, int min_features, int cap)
+{   // VO:626: results_match_prev_curr.size() > MIN_NUM_FEATURES
+    int T = cn[CN_NQB] > 0 ? cn[CN_TRAW] : 0;
+    if (cn[CN_NQB] == 0) cn[CN_TRAW] = 0;
+    cn[CN_T] = (T > min_features) ? min(T, cap) : 0;
+    cn[CN_G] = 0;
+}
+
+// VO:569-579: curr_{left,right}_{descr,keypoints}_after_stereo_match by the stereo matches' indices
+__global__ __launch_bounds__(256) void k_gather_after_stereo(const uvo_dmatch* m, const int* cn, const uvo_keypoint* kL, const uvo_keypoint* kR,
+                                                             const float* dL, uvo_keypoint* okL, uvo_keypoint* okR, float* odL)
+{
+    const int meff = cn[CN_MEFF];
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (row >= meff) return;
+    const int q = m[row].queryIdx, t = m[row].trainIdx;
+    reinterpret_cast<float4*>(odL + (size_t)row * 64)[sub] = reinterpret_cast<const float4*>(dL + (size_t)q * 64)[sub];
+    if (sub == 0) { okL[row] = kL[q]; okR[row] = kR[t]; }
+}
+// VO:601-617, 637-640: points of the triangular matches (prev left / prev right by queryIdx, curr left by trainIdx)
+__global__ __launch_bounds__(256) void k_gather_triangular(const uvo_dmatch* m, const int* cn, const uvo_keypoint* pL, const uvo_keypoint* pR,
+                                                           const uvo_keypoint* cL, uvo_point2f* x1, uvo_point2f* x2, uvo_point2f* xc)
+{
+    const int T = cn[CN_T];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= T) return;
+    const int q = m[i].queryIdx, t = m[i].trainIdx;
+    x1[i] = uvo_point2f{pL[q].x, pL[q].y};
+    x2[i] = uvo_point2f{pR[q].x, pR[q].y};
+    xc[i] = uvo_point2f{cL[t].x, cL[t].y};
+}
+__global__ void k_gather_kps_idx(const uvo_keypoint* src, const int* idx, int n, uvo_keypoint* dst)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+__global__ void k_gather_desc_idx(const float* src, int nsrc, const int* idx, int n, float* dst)
+{
+    int row = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (row >= n) return;
+    int q = idx[row];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // the reference leaves an out-of-range row uninitialised (VOU:690)
+    if (q >= 0 && q < nsrc) v = reinterpret_cast<const float4*>(src + (size_t)q * 64)[sub];
+    reinterpret_cast<float4*>(dst + (size_t)row * 64)[sub] = v;
+}
+
+// compute_projection_matrix (VOU:9-15): K * [R|t]
+static void projection_matrix(const double* R, const double* t, const double* K, double* P)
+{
+    double Rt[12];
+    for (int i = 0; i < 3; i++) { Rt[i*4] = R[i*3]; Rt[i*4+1] = R[i*3+1]; Rt[i*4+2] = R[i*3+2]; Rt[i*4+3] = t[i]; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++)
+        P[i*4 + j] = K[i*3]*Rt[j] + K[i*3+1]*Rt[4 + j] + K[i*3+2]*Rt[8 + j];
+}
+
+extern "C" uvo_status uvo_stereo_set_rig(uvo_ctx* c, const double* K_left, const double* K_right, const double* R_right, const double* t_right)
+{
+    if (!c || !K_left || !K_right || !R_right || !t_right) return UVO_INVALID_ARG;
+    memcpy(c->K_left, K_left, sizeof(double) * 9); memcpy(c->K_right, K_right, sizeof(double) * 9);
+    memcpy(c->R_right, R_right, sizeof(double) * 9); memcpy(c->t_right, t_right, sizeof(double) * 3);
+    const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
+    projection_matrix(I, z, K_left, c->P_eye_left);               // VO:460
+    projection_matrix(R_right, t_right, K_right, c->P_right);     // VO:462
+    c->rig_set = true;
+    return uvo_stereo_reset(c);
+}
+
+extern "C" uvo_status uvo_stereo_reset(uvo_ctx* c)
+{
+    if (!c) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    c->vo_initialized = false; c->init_matches.clear(); c->as_prev = 0;
+    for (int i = 0; i < 3; i++) c->t_prev_curr[i] = c->rvec[i] = c->tvec[i] = 0;
+    UVO_HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(int) * CN_TOTAL, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return UVO_OK;
+}
+
+// init phase VO:474-520 (first pairs only; host-assisted because results_match_prev accumulates)
+static uvo_status stereo_init_step(uvo_ctx* c, uvo_stereo_result* out)
+{
+    const uvo_params& p = c->p;
+    UVO_TRY(read_counts(c));
+    UVO_TRY(check_cand_overflow(c, 2));
+    const int nL = c->h_counts[CN_NL], nR = c->h_counts[CN_NR];
+    out->n_left = nL; out->n_right = nR;
+    c->last_nL = nL; c->last_nR = nR; c->last_M = c->last_T = c->last_G = c->last_ninl = 0;
+    if (nL >= p.MIN_NUM_FEATURES && nR >= p.MIN_NUM_FEATURES) {                         // VO:489
+        UVO_TRY(match_knn2(c, c->det[0].desc, nullptr, nL, c->det[1].desc, nullptr, nR));
+        UVO_TRY(match_ratio_compact(c, nullptr, nL, (float)p.LOWE_RATIO_THRESHOLD, c->d_matches[0], c->d_nmatch, c->cap));
+        UVO_TRY(read_counts(c));
+        int m = c->h_counts[CN_M];
+        if (m > c->cap) return fail(c, UVO_CAPACITY, "stereo matches exceed max_kpts");
+        size_t old = c->init_matches.size();
+        c->init_matches.resize(old + m);                                                  // VOU:538 appends
+        if (m) UVO_HIP_TRY(c, hipMemcpyAsync(c->init_matches.data() + old, c->d_matches[0], sizeof(uvo_dmatch) * m, hipMemcpyDeviceToHost, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if ((int)c->init_matches.size() > p.MIN_NUM_FEATURES) c->vo_initialized = true;  // VO:500
+    }
+    const int total = (int)c->init_matches.size();
+    out->n_stereo_matches = total; c->last_M = total;
+    if (c->vo_initialized) {
+        if (total > c->cap) return fail(c, UVO_CAPACITY, "accumulated init matches exceed max_kpts");
+        // VO:508-520 with the reference's bounds checks (stale indices from failed attempts)
+        std::vector<int> iL(total), iR(total), vL, vR;
+        for (int i = 0; i < total; i++) { iL[i] = c->init_matches[i].queryIdx; iR[i] = c->init_matches[i].trainIdx; }
+        for (int i = 0; i < total; i++) { if (iL[i] >= 0 && iL[i] < nL) vL.push_back(iL[i]); if (iR[i] >= 0 && iR[i] < nR) vR.push_back(iR[i]); }
+        if ((int)vL.size() != total || (int)vR.size() != total)
+            return fail(c, UVO_INVALID_ARG, "stale stereo-init matches index past the current keypoints; the reference's "
+                                            "keypoint/descriptor sets would go out of step (OpenCV asserts downstream)");
+        const int b = c->as_prev;
+        int* d_idx = c->d_good_idx;    // scratch
+        UVO_HIP_TRY(c, hipMemcpyAsync(d_idx, iL.data(), sizeof(int) * total, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_gather_desc_idx, dim3((total + 15) / 16), dim3(256), 0, c->stream, c->det[0].desc, nL, d_idx, total, c->d_as_descL[b]);
+        hipLaunchKernelGGL(k_gather_kps_idx, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->det[0].kps, d_idx, total, c->d_as_kpsL[b]);
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(d_idx, iR.data(), sizeof(int) * total, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_gather_kps_idx, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->det[1].kps, d_idx, total, c->d_as_kpsR[b]);
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_as_n + b, &total, sizeof(int), hipMemcpyHostToDevice, c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_matches[0], c->init_matches.data(), sizeof(uvo_dmatch) * total, hipMemcpyHostToDevice, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        UVO_HIP_TRY(c, hipGetLastError());
+    }
+    out->initialized = 0; out->valid = 0;
+    return UVO_OK;
+}
+
+extern "C" uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
+                                      int mem, double dt, uvo_stereo_result* out)
+{
+    if (!c || !left || !right || !out) return UVO_INVALID_ARG;
+    if (!c->rig_set) return fail(c, UVO_INVALID_ARG, "uvo_stereo_set_rig has not been called");
+    (void)hipSetDevice(c->device);
+    const uvo_params& p = c->p;
+    memset(out, 0, sizeof(*out));
+    UVO_TRY(surf_upload(c, 0, left, w, h, stride, mem));
+    UVO_TRY(surf_upload(c, 1, right, w, h, stride, mem));
+    UVO_TRY(surf_detect(c, 2));                                                            // VO:548-549
+    if (!c->vo_initialized) return stereo_init_step(c, out);
+
+    out->initialized = 1;
+    const int cap = c->cap, prev = c->as_prev, curr = 1 - prev;
+    int* cn = c->d_counts;
+    const float ratio = (float)p.LOWE_RATIO_THRESHOLD;
+    // stereo matching L -> R (VO:558), gated on device by VO:556
+    hipLaunchKernelGGL(k_ctl_gate_a, dim3(1), dim3(1), 0, c->stream, cn, p.MIN_NUM_FEATURES);
+    UVO_TRY(match_knn2(c, c->det[0].desc, cn + CN_NQA, cap, c->det[1].desc, cn + CN_NR, cap));
+    UVO_TRY(match_ratio_compact(c, cn + CN_NQA, cap, ratio, c->d_matches[0], cn + CN_M, cap));
+    hipLaunchKernelGGL(k_ctl_gate_b, dim3(1), dim3(1), 0, c->stream, cn, p.MIN_NUM_FEATURES, cap, CN_AS0 + curr, CN_AS0 + prev, 0);
+    {
+        StageTimer t(c, ST_GATHER);
+        hipLaunchKernelGGL(k_gather_after_stereo, dim3((cap + 15) / 16), dim3(256), 0, c->stream, c->d_matches[0], cn,
+                           c->det[0].kps, c->det[1].kps, c->det[0].desc, c->d_as_kpsL[curr], c->d_as_kpsR[curr], c->d_as_descL[curr]);
+    }
+    // triangular matching prev-left-after-stereo -> curr-left (VO:592)
+    UVO_TRY(match_knn2(c, c->d_as_descL[prev], cn + CN_NQB, cap, c->det[0].desc, cn + CN_NL, cap));
+    UVO_TRY(match_ratio_compact(c, cn + CN_NQB, cap, ratio, c->d_matches[1], cn + CN_TRAW, cap));
+    hipLaunchKernelGGL(k_ctl_gate_c, dim3(1), dim3(1), 0, c->stream, cn, p.MIN_NUM_FEATURES, cap);
+    {
+        StageTimer t(c, ST_GATHER);
+        hipLaunchKernelGGL(k_gather_triangular, dim3((cap + 255) / 256), dim3(256), 0, c->stream, c->d_matches[1], cn,
+                           c->d_as_kpsL[prev], c->d_as_kpsR[prev], c->det[0].kps, c->d_x1, c->d_x2, c->d_xc);
+    }
+    UVO_HIP_TRY(c, hipGetLastError());
+    // triangulation + extract_3Dpoints (VO:631-632)
+    UVO_TRY(pose_triangulate(c, c->P_eye_left, c->P_right, cn + CN_T, cap));
+    const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
+    UVO_TRY(pose_extract3d(c, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap));
+    UVO_TRY(read_counts(c));
+    UVO_TRY(check_cand_overflow(c, 2));
+    const int* hc = c->h_counts;
+    if (hc[CN_M] > cap || hc[CN_TRAW] > cap) return fail(c, UVO_CAPACITY, "match count exceeds max_kpts");
+    const int nL = hc[CN_NL], nR = hc[CN_NR], M = hc[CN_M], T = hc[CN_TRAW], G = hc[CN_G];
+    out->n_left = nL; out->n_right = nR; out->n_stereo_matches = M; out->n_tri_matches = T; out->n_good3d = G;
+    c->last_nL = nL; c->last_nR = nR; c->last_M = M; c->last_T = hc[CN_T]; c->last_G = G; c->last_ninl = 0;
+    int valid = 0;
+    if (G > p.MIN_NUM_3DPOINTS) {                                                          // VO:634
+        int ninl = 0, ok = 0;
+        UVO_TRY(pose_pnp_ransac(c, G, c->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE,
+                                c->rvec, c->tvec, &ninl, &ok));                            // VO:647-648
+        c->last_ninl = ninl; out->n_inliers = ninl;
+        if (ninl >= p.MIN_NUM_INLIERS) {                                                   // VO:665
+            double R[9];
+            rodrigues_vec2mat(c->rvec, R);                                                 // VO:673
+            for (int i = 0; i < 3; i++) {                                                  // VO:675: -R^T t
+                double acc = 0;
+                for (int k = 0; k < 3; k++) acc += R[k*3 + i] * c->tvec[k];
+                c->t_prev_curr[i] = acc * -1.0;
+            }
+            valid = 1;
+        }
+    }
+    out->valid = valid;
+    for (int i = 0; i < 3; i++) {
+        out->rvec[i] = c->rvec[i]; out->tvec[i] = c->tvec[i]; out->t_prev_curr[i] = c->t_prev_curr[i];
+        out->velocity[i] = c->t_prev_curr[i] / dt;                                         // VO:152
+    }
+    c->as_prev = curr;                                                                     // VO:727-733
+    return UVO_OK;
+}
+
+extern "C" int uvo_stereo_get(uvo_ctx* c, const char* what, void* out, int cap_bytes)
+{
+    if (!c || !what || !out) return 0;
+    (void)hipSetDevice(c->device);
+    const void* src = nullptr; int count = 0; size_t esz = 0;
+    std::string w(what);
+    if (w == "kps_left") { src = c->det[0].kps; count = c->last_nL; esz = sizeof(uvo_keypoint); }
+    else if (w == "kps_right") { src = c->det[1].kps; count = c->last_nR; esz = sizeof(uvo_keypoint); }
+    else if (w == "desc_left") { src = c->det[0].desc; count = c->last_nL; esz = 64 * sizeof(float); }
+    else if (w == "desc_right") { src = c->det[1].desc; count = c->last_nR; esz = 64 * sizeof(float); }
+    else if (w == "matches_stereo") { src = c->d_matches[0]; count = c->last_M; esz = sizeof(uvo_dmatch); }
+    else if (w == "matches_tri") { src = c->d_matches[1]; count = c->last_T > 0 ? c->h_counts[CN_TRAW] : c->h_counts[CN_TRAW]; esz = sizeof(uvo_dmatch); }
+    else if (w == "points4d") { src = c->d_pts4; count = c->last_T; esz = sizeof(float4); }
+    else if (w == "good_pts") { src = c->d_good_pts; count = c->last_G; esz = 3 * sizeof(double); }
+    else if (w == "good_idx") { src = c->d_good_idx; count = c->last_G; esz = sizeof(int); }
+    else if (w == "inliers") { src = c->d_inliers; count = c->last_ninl; esz = sizeof(int); }
+    else return 0;
+    if ((size_t)count * esz > (size_t)cap_bytes) return -count;
+    if (count) {
+        if (hipMemcpy(out, src, (size_t)count * esz, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    }
+    return count;
+}
+
+// ------------------------------------------------------------------------------------------ timing
+extern "C" uvo_status uvo_timing_enable(uvo_ctx* c, int on) { if (!c) return UVO_INVALID_ARG; c->timing = on != 0; return UVO_OK; }
+extern "C" int uvo_timing_count(uvo_ctx*) { return ST_COUNT; }
+extern "C" const char* uvo_timing_name(uvo_ctx*, int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+extern "C" uvo_status uvo_timing_get(uvo_ctx* c, int i, double* ms, long long* launches)
+{
+    if (!c || i < 0 || i >= ST_COUNT) return UVO_INVALID_ARG;
+    if (ms) *ms = c->stage_ms[i];
+    if (launches) *launches = c->stage_n[i];
+    return UVO_OK;
+}
+extern "C" uvo_status uvo_timing_reset(uvo_ctx* c)
+{
+    if (!c) return UVO_INVALID_ARG;
+    for (int i = 0; i < ST_COUNT; i++) { c->stage_ms[i] = 0; c->stage_n[i] = 0; }
+    return UVO_OK;
+}

@@ -1,0 +1,404 @@
+// pose.hip -- triangulation, extract_3Dpoints and EPnP PnP-RANSAC on gfx950 (replaces the calls at
+// visual_odometry.h:631-648: cv::triangulatePoints, extract_3Dpoints (VO_utility.cpp:188-237),
+// cv::solvePnPRansac(SOLVEPNP_EPNP)).
+//
+// These stages are tiny (<= a few thousand points) and latency-bound, not bandwidth-bound; what
+// matters is that the sequential OpenCV semantics survive parallel execution unchanged:
+//   * every fp64 solver runs one problem per thread (4x4 / 12x12 Jacobi SVD in LDS, [elem][lane]
+//     interleaved) in the reference's operation order;
+//   * RANSAC: the host replays cv::RNG to produce the exact 5-point subsets, ALL hypotheses are
+//     solved (k_pnp_hyp) and scored (k_pnp_score) in parallel, then the host replays OpenCV's
+//     sequential "better than best => shrink niters" scan over the counts to pick the identical
+//     winner; the winner's mask is recomputed and the inlier refit runs block-cooperatively with
+//     each floating-point sum kept in its sequential order.
+#include "uvo_ctx.h"
+#include "uvo_epnp.h"
+#include <string.h>
+
+namespace uvo {
+
+// RANSACUpdateNumIters (ptsetreg.cpp); host libm, as the reference
+int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters)
+{
+    p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : cv_round_d(num / denom);
+}
+
+struct Mat34 { double v[12]; };
+struct Cam { double R[9], t[3], fx, fy, cx, cy; };
+
+// ---------------------------------------------------------------- triangulatePoints
+static const int kTriThreads = 64;
+__global__ __launch_bounds__(kTriThreads) void k_triangulate(Mat34 P1, Mat34 P2, const uvo_point2f* x1, const uvo_point2f* x2,
+                                                             const int* n_p, int n_imm, float4* out)
+{
+    const int n = n_p ? *n_p : n_imm;
+    const int i = blockIdx.x * kTriThreads + threadIdx.x;
+    __shared__ double lds[(16 + 16 + 16 + 4 + 4) * kTriThreads];
+    if (i >= n) return;
+    using A = SArr<kTriThreads>;
+    A Am{lds + threadIdx.x}, At = Am + 16, Vt = Am + 32, W = Am + 48, Wt = Am + 52;
+    const double xa = x1[i].x, ya = x1[i].y, xb = x2[i].x, yb = x2[i].y;
+    for (int k = 0; k < 4; k++) {
+        Am[0*4 + k] = xa * P1.v[2*4 + k] - P1.v[0*4 + k];
+        Am[1*4 + k] = ya * P1.v[2*4 + k] - P1.v[1*4 + k];
+        Am[2*4 + k] = xb * P2.v[2*4 + k] - P2.v[0*4 + k];
+        Am[3*4 + k] = yb * P2.v[2*4 + k] - P2.v[1*4 + k];
+    }
+    svd_square(Am, At, W, Vt, Wt, 4);
+    out[i] = make_float4((float)Vt[12], (float)Vt[13], (float)Vt[14], (float)Vt[15]);
+}
+
+// ---------------------------------------------------------------- extract_3Dpoints
+// stage A: convertPointsFromHomogeneous (float) + mean reprojection error in both views + z > 0
+__global__ __launch_bounds__(256) void k_extract3d_a(const float4* pts4, const uvo_point2f* k1, const uvo_point2f* k2,
+                                                     Cam c1, Cam c2, double tol, const int* n_p, int n_imm,
+                                                     double* cam1, int* flag)
+{
+    const int n = n_p ? *n_p : n_imm;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pts4[i];
+    float scale = p.w != 0.f ? 1.f / p.w : 1.f;
+    double X = (double)(p.x * scale), Y = (double)(p.y * scale), Z = (double)(p.z * scale);
+    cam1[3*i] = X; cam1[3*i + 1] = Y; cam1[3*i + 2] = Z;
+    double u, v;
+    project_point(X, Y, Z, c1.R, c1.t, c1.fx, c1.fy, c1.cx, c1.cy, &u, &v);
+    double dx = k1[i].x - u, dy = k1[i].y - v;
+    double e1 = sqrt(dx * dx + dy * dy);
+    project_point(X, Y, Z, c2.R, c2.t, c2.fx, c2.fy, c2.cx, c2.cy, &u, &v);
+    dx = k2[i].x - u; dy = k2[i].y - v;
+    double e2 = sqrt(dx * dx + dy * dy);
+    double mean = (e1 + e2) / 2.0;
+    flag[i] = ((mean < tol) && (Z > 0)) ? 1 : 0;
+}
+
+// block-wide ordered compaction helper: returns the exclusive position of a kept element and
+// advances *s_base (shared) by the number kept in this pass.  1024 threads.
+__device__ __forceinline__ int block_compact_pos(bool keep, int* wtot, int* s_base)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned long long bal = __ballot(keep);
+    int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[wv] = __popcll(bal);
+    __syncthreads();
+    int off = *s_base;
+    for (int k = 0; k < wv; k++) off += wtot[k];
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int k = 0; k < (int)(blockDim.x >> 6); k++) t += wtot[k]; *s_base += t; }
+    __syncthreads();
+    return off + before;
+}
+
+// stage B (one workgroup): first compaction, mean/variance of z in index order, +-3 sigma filter,
+// second compaction; also gathers the PnP inputs (float object points, current-image points).
+__global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const int* flag, const uvo_point2f* xc,
+                                                      const int* n_p, int n_imm, int min_pts,
+                                                      int* tmp_idx, double* good_pts, int* good_idx, float* opts, uvo_point2f* ipts,
+                                                      int* counts /* [1] = G */)
+{
+    const int n = n_p ? *n_p : n_imm;
+    const int tid = threadIdx.x;
+    __shared__ int wtot[16];
+    __shared__ int s_base;
+    __shared__ double s_mean, s_sd3;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    const bool enough = n >= min_pts;                       // VOU:203
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + tid;
+        bool keep = enough && i < n && flag[i] != 0;
+        int pos = block_compact_pos(keep, wtot, &s_base);
+        if (keep) tmp_idx[pos] = i;
+    }
+    __syncthreads();
+    const int ngood = s_base;
+    if (ngood < min_pts || ngood == 0) {                    // VOU:222
+        if (tid == 0) counts[1] = 0;
+        return;
+    }
+    if (tid == 0) {                                          // MU:35-56, sequential sums
+        double sum = 0.0, sumsq = 0.0;
+        for (int i = 0; i < ngood; i++) { double z = cam1[3 * tmp_idx[i] + 2]; sum += z; sumsq += z * z; }
+        double mean = sum / ngood;
+        double variance = (sumsq / ngood) - (mean * mean);
+        s_mean = mean; s_sd3 = 3.0 * sqrt(variance);
+        s_base = 0;
+    }
+    __syncthreads();
+    const double mean = s_mean, sd3 = s_sd3;
+    for (int base = 0; base < ngood; base += 1024) {
+        int i = base + tid;
+        bool keep = false; int src = 0; double z = 0;
+        if (i < ngood) { src = tmp_idx[i]; z = cam1[3*src + 2]; keep = (z <= mean + sd3) && (z >= mean - sd3); }
+        int pos = block_compact_pos(keep, wtot, &s_base);
+        if (keep) {
+            double X = cam1[3*src], Y = cam1[3*src + 1];
+            good_idx[pos] = src;
+            good_pts[3*pos] = X; good_pts[3*pos + 1] = Y; good_pts[3*pos + 2] = z;
+            opts[3*pos] = (float)X; opts[3*pos + 1] = (float)Y; opts[3*pos + 2] = (float)z;   // solvePnPRansac: opoints -> CV_32F
+            if (xc) ipts[pos] = xc[src];
+        }
+    }
+    __syncthreads();
+    if (tid == 0) counts[1] = s_base;
+}
+
+// ---------------------------------------------------------------- PnP RANSAC
+static const int kHypThreads = 32;       // hypotheses per workgroup; LDS = 32 * (EPNP_SMALL + 65) doubles
+static const int kHypPerThread = EPNP_SMALL + 15 + 10 + 20 + 15 + 5;
+
+__global__ __launch_bounds__(kHypThreads) void k_pnp_hyp(const float* opts, const uvo_point2f* ipts, const int* subsets, int nhyp,
+                                                         double fx, double fy, double cx, double cy, double* models)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    const int hyp = blockIdx.x * kHypThreads + threadIdx.x;
+    if (hyp >= nhyp) return;
+    using P = ThreadPolicy<kHypThreads>;
+    using A = P::Arr;
+    A base{lds + threadIdx.x};
+    Epnp<P> e;
+    e.uc = cx; e.vc = cy; e.fu = fx; e.fv = fy; e.n = 5;
+    e.s = base; e.pws = base + EPNP_SMALL; e.us = e.pws + 15; e.alphas = e.us + 10; e.pcs = e.alphas + 20; e.tmp = e.pcs + 15;
+    e.M = e.tmp;    // unused (kStoreM = false)
+    const double ifx = 1. / fx, ify = 1. / fy;
+    for (int i = 0; i < 5; i++) {
+        int id = subsets[hyp * 5 + i];
+        e.pws[3*i] = opts[3*id]; e.pws[3*i + 1] = opts[3*id + 1]; e.pws[3*i + 2] = opts[3*id + 2];
+        // undistortPoints with zero distortion, stored CV_32FC2, then epnp::init_points
+        double x = (double)(float)((ipts[id].x - cx) * ifx), y = (double)(float)((ipts[id].y - cy) * ify);
+        e.us[2*i] = x * fx + cx; e.us[2*i + 1] = y * fy + cy;
+    }
+    double rvec[3], tvec[3];
+    e.compute_pose(rvec, tvec);
+    double* m = models + (size_t)hyp * 6;
+    m[0] = rvec[0]; m[1] = rvec[1]; m[2] = rvec[2]; m[3] = tvec[0]; m[4] = tvec[1]; m[5] = tvec[2];
+}
+
+// PnPRansacCallback::computeError + findInliers for one model: projectPoints (double, stored float),
+// err = |ipt - proj|^2 in float, inlier iff err <= (float)(thr*thr)
+__device__ __forceinline__ bool pnp_is_inlier(const float* opts, const uvo_point2f* ipts, int i, const double* R, const double* t,
+                                              double fx, double fy, double cx, double cy, float thr2)
+{
+    double u, v;
+    project_point((double)opts[3*i], (double)opts[3*i + 1], (double)opts[3*i + 2], R, t, fx, fy, cx, cy, &u, &v);
+    float dx = ipts[i].x - (float)u, dy = ipts[i].y - (float)v;
+    float err = dx * dx + dy * dy;
+    return err <= thr2;
+}
+
+__global__ __launch_bounds__(256) void k_pnp_score(const float* opts, const uvo_point2f* ipts, int n, const double* models, int nhyp,
+                                                   double fx, double fy, double cx, double cy, float thr2, int* hcount)
+{
+    const int hyp = blockIdx.x, tid = threadIdx.x;
+    __shared__ double sR[9], st[3];
+    __shared__ int s_cnt;
+    if (tid == 0) {
+        const double* m = models + (size_t)hyp * 6;
+        double R[9]; rodrigues_vec2mat(m, R);
+        for (int k = 0; k < 9; k++) sR[k] = R[k];
+        st[0] = m[3]; st[1] = m[4]; st[2] = m[5];
+        s_cnt = 0;
+    }
+    __syncthreads();
+    double R[9], t[3];
+    for (int k = 0; k < 9; k++) R[k] = sR[k];
+    t[0] = st[0]; t[1] = st[1]; t[2] = st[2];
+    int cnt = 0;
+    for (int i = tid; i < n; i += 256) cnt += pnp_is_inlier(opts, ipts, i, R, t, fx, fy, cx, cy, thr2) ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((tid & 63) == 0) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (tid == 0) hcount[hyp] = s_cnt;
+}
+
+// winner's mask -> ascending inlier list + refit inputs (double points; undistort in double)
+__global__ __launch_bounds__(1024) void k_pnp_mask(const float* opts, const uvo_point2f* ipts, int n, const double* model,
+                                                   double fx, double fy, double cx, double cy, float thr2,
+                                                   int* inliers, double* pws, double* us, int* counts /* [2] = n_inliers */)
+{
+    const int tid = threadIdx.x;
+    __shared__ int wtot[16];
+    __shared__ int s_base;
+    double R[9], t[3];
+    rodrigues_vec2mat(model, R);
+    t[0] = model[3]; t[1] = model[4]; t[2] = model[5];
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    const double ifx = 1. / fx, ify = 1. / fy;
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + tid;
+        bool keep = i < n && pnp_is_inlier(opts, ipts, i, R, t, fx, fy, cx, cy, thr2);
+        int pos = block_compact_pos(keep, wtot, &s_base);
+        if (keep) {
+            inliers[pos] = i;
+            pws[3*pos] = opts[3*i]; pws[3*pos + 1] = opts[3*i + 1]; pws[3*pos + 2] = opts[3*i + 2];
+            double x = ((double)ipts[i].x - cx) * ifx, y = ((double)ipts[i].y - cy) * ify;     // undistortPoints, CV_64FC2
+            us[2*pos] = x * fx + cx; us[2*pos + 1] = y * fy + cy;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) counts[2] = s_base;
+}
+
+// inlier refit: one workgroup, block-cooperative EPnP.  ws: pws 3n | us 2n | alphas 4n | pcs 3n | tmp n | M 24n
+__global__ __launch_bounds__(256) void k_pnp_refit(double* ws, int cap, const int* n_p, double fx, double fy, double cx, double cy, double* pose)
+{
+    __shared__ double small[EPNP_SMALL];
+    const int n = *n_p;
+    using P = BlockPolicy;
+    Epnp<P> e;
+    e.uc = cx; e.vc = cy; e.fu = fx; e.fv = fy; e.n = n;
+    e.s = P::Arr{small};
+    e.pws = P::Arr{ws}; e.us = P::Arr{ws + 3 * (size_t)cap}; e.alphas = P::Arr{ws + 5 * (size_t)cap};
+    e.pcs = P::Arr{ws + 9 * (size_t)cap}; e.tmp = P::Arr{ws + 12 * (size_t)cap}; e.M = P::Arr{ws + 13 * (size_t)cap};
+    double rvec[3], tvec[3];
+    e.compute_pose(rvec, tvec);
+    if (threadIdx.x == 0) { pose[0] = rvec[0]; pose[1] = rvec[1]; pose[2] = rvec[2]; pose[3] = tvec[0]; pose[4] = tvec[1]; pose[5] = tvec[2]; }
+}
+
+// single 5-point solve when npoints == model_points (solvePnPRansac short-cut): reuse k_pnp_hyp with
+// the identity subset.
+
+// ---------------------------------------------------------------- host orchestration
+uvo_status pose_triangulate(Ctx* c, const double* P1, const double* P2, const int* d_n, int n_max)
+{
+    if (n_max <= 0) return UVO_OK;
+    Mat34 a, b; memcpy(a.v, P1, sizeof(a.v)); memcpy(b.v, P2, sizeof(b.v));
+    StageTimer t(c, ST_TRIANGULATE);
+    hipLaunchKernelGGL(k_triangulate, dim3((n_max + kTriThreads - 1) / kTriThreads), dim3(kTriThreads), 0, c->stream,
+                       a, b, c->d_x1, c->d_x2, d_n, n_max, c->d_pts4);
+    UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+
+static Cam make_cam(const double* R, const double* t, const double* K)
+{
+    Cam cm; memcpy(cm.R, R, sizeof(cm.R)); memcpy(cm.t, t, sizeof(cm.t));
+    cm.fx = K[0]; cm.fy = K[4]; cm.cx = K[2]; cm.cy = K[5];
+    return cm;
+}
+
+uvo_status pose_extract3d(Ctx* c, const double* R1, const double* t1, const double* R2, const double* t2,
+                          const double* K1, const double* K2, const int* d_n, int n_max)
+{
+    StageTimer t(c, ST_EXTRACT3D);
+    if (n_max > 0) {
+        hipLaunchKernelGGL(k_extract3d_a, dim3((n_max + 255) / 256), dim3(256), 0, c->stream, c->d_pts4, c->d_x1, c->d_x2,
+                           make_cam(R1, t1, K1), make_cam(R2, t2, K2), c->p.REPROJECTION_TOLERANCE, d_n, n_max, c->d_cam1, c->d_flag);
+    }
+    hipLaunchKernelGGL(k_extract3d_b, dim3(1), dim3(1024), 0, c->stream, c->d_cam1, c->d_flag, c->d_xc, d_n, n_max,
+                       c->p.MIN_NUM_3DPOINTS, c->d_inliers /* scratch: tmp_idx */, c->d_good_pts, c->d_good_idx, c->d_opts, c->d_ipts,
+                       c->d_counts);
+    UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+
+// solvePnPRansac on the G points already in c->d_opts / c->d_ipts.
+uvo_status pose_pnp_ransac(Ctx* c, int G, const double* K, int iterationsCount, float reprojectionError, double confidence,
+                           double* rvec, double* tvec, int* n_inliers, int* ok)
+{
+    const int modelPoints = 5;
+    *n_inliers = 0; *ok = 0;
+    if (G < 4) { c->err = "solvePnPRansac needs at least 4 points (OpenCV asserts)"; return UVO_TOO_FEW_POINTS; }
+    if (G == 4) { c->err = "solvePnPRansac with exactly 4 points takes OpenCV's P3P path, which the reference never reaches; not implemented"; return UVO_TOO_FEW_POINTS; }
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const size_t hyp_lds = sizeof(double) * kHypThreads * kHypPerThread;
+    static bool attr_set = false;
+    if (!attr_set) {
+        UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_hyp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds));
+        attr_set = true;
+    }
+    int niters = iterationsCount > 1 ? iterationsCount : 1;
+    if (niters > kMaxHyp) { c->err = "iterations_count exceeds the compiled hypothesis capacity (2048)"; return UVO_CAPACITY; }
+    int nhyp;
+    if (G == modelPoints) {
+        for (int i = 0; i < 5; i++) c->h_subsets[i] = i;
+        nhyp = 1;
+    } else {
+        // getSubset (ptsetreg.cpp): cv::RNG((uint64)-1), uniform(0, count), redraw while duplicate
+        uint64_t state = (uint64_t)-1;
+        for (int it = 0; it < niters; it++) {
+            int* idx = c->h_subsets + it * 5;
+            for (int i = 0; i < modelPoints; i++) {
+                int idx_i;
+                for (;;) {
+                    idx_i = (int)(rng_next(state) % (uint32_t)G);
+                    bool dup = false;
+                    for (int q = 0; q < i; q++) dup = dup || idx[q] == idx_i;
+                    if (!dup) break;
+                }
+                idx[i] = idx_i;
+            }
+        }
+        nhyp = niters;
+    }
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->d_subsets, c->h_subsets, sizeof(int) * 5 * nhyp, hipMemcpyHostToDevice, c->stream));
+    {
+        StageTimer t(c, ST_PNP_HYP);
+        hipLaunchKernelGGL(k_pnp_hyp, dim3((nhyp + kHypThreads - 1) / kHypThreads), dim3(kHypThreads), hyp_lds, c->stream,
+                           c->d_opts, c->d_ipts, c->d_subsets, nhyp, fx, fy, cx, cy, c->d_models);
+        UVO_HIP_TRY(c, hipGetLastError());
+    }
+    if (G == modelPoints) {
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->h_pose, c->d_models, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        memcpy(rvec, c->h_pose, sizeof(double) * 3); memcpy(tvec, c->h_pose + 3, sizeof(double) * 3);
+        int ids[5] = {0, 1, 2, 3, 4};
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_inliers, ids, sizeof(ids), hipMemcpyHostToDevice, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        *n_inliers = 5; *ok = 1;
+        return UVO_OK;
+    }
+    const double threshold = reprojectionError;
+    const float thr2 = (float)(threshold * threshold);
+    {
+        StageTimer t(c, ST_PNP_SCORE);
+        hipLaunchKernelGGL(k_pnp_score, dim3(nhyp), dim3(256), 0, c->stream, c->d_opts, c->d_ipts, G, c->d_models, nhyp,
+                           fx, fy, cx, cy, thr2, c->d_hcount);
+        UVO_HIP_TRY(c, hipGetLastError());
+    }
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_hcount, c->d_hcount, sizeof(int) * nhyp, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // replay of RANSACPointSetRegistrator::run's sequential scan
+    int maxGoodCount = 0, best = -1, last = 0;
+    for (int iter = 0; iter < niters; iter++) {
+        last = iter;
+        int goodCount = c->h_hcount[iter];
+        if (goodCount > (maxGoodCount > modelPoints - 1 ? maxGoodCount : modelPoints - 1)) {
+            best = iter; maxGoodCount = goodCount;
+            niters = ransac_update_num_iters(confidence, (double)(G - goodCount) / G, modelPoints, niters);
+        }
+    }
+    if (best < 0) {
+        // RANSAC failed: OpenCV hands back the last hypothesis' rvec/tvec and no inliers
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->h_pose, c->d_models + (size_t)last * 6, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        memcpy(rvec, c->h_pose, sizeof(double) * 3); memcpy(tvec, c->h_pose + 3, sizeof(double) * 3);
+        return UVO_OK;
+    }
+    {
+        StageTimer t(c, ST_PNP_REFIT);
+        double* ws = c->d_refit;
+        hipLaunchKernelGGL(k_pnp_mask, dim3(1), dim3(1024), 0, c->stream, c->d_opts, c->d_ipts, G, c->d_models + (size_t)best * 6,
+                           fx, fy, cx, cy, thr2, c->d_inliers, ws, ws + 3 * (size_t)c->cap, c->d_counts);
+        hipLaunchKernelGGL(k_pnp_refit, dim3(1), dim3(256), 0, c->stream, ws, c->cap, c->d_counts + 2, fx, fy, cx, cy, c->d_pose);
+        UVO_HIP_TRY(c, hipGetLastError());
+    }
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_pose, c->d_pose, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_counts + 2, c->d_counts + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(rvec, c->h_pose, sizeof(double) * 3); memcpy(tvec, c->h_pose + 3, sizeof(double) * 3);
+    *n_inliers = c->h_counts[2];
+    *ok = 1;
+    return UVO_OK;
+}
+
+}  // namespace uvo

@@ -1,0 +1,600 @@
+// surf.hip -- upright SURF-64 detect + describe on gfx950 (replaces detect_features' SURF branch,
+// VO_utility.cpp:114-119 -> OpenCV xfeatures2d::SURF::detectAndCompute).
+//
+// Pipeline per image (both images of a stereo pair go through every launch together, blockIdx.z):
+//   integral_rows / integral_colsum / integral_colfinal : u8 -> s32 integral image (HBM-bound)
+//   hessian_nms<STEP, LDS>  : per octave, fused box-filter Hessian (5 layers) + 3x3x3 NMS +
+//                             quadratic interpolation; the integral tile is staged in LDS for
+//                             octaves 0-1, det planes never leave LDS; candidates are appended
+//                             with one atomic per keypoint
+//   rank_sort               : deterministic ordering (OpenCV's KeypointGreater) by counting rank
+//   descriptor64            : INTER_AREA window resample + Haar gradients + 4x4x4 sums
+// All float arithmetic keeps OpenCV's operation order (int box sum * float weight accumulated in
+// double; no FMA contraction) so results are bit-identical to the CPU restatement.
+#include "uvo_ctx.h"
+#include "uvo_math.h"
+
+namespace uvo {
+
+// ------------------------------------------------------------------------------------------
+// integral image
+// ------------------------------------------------------------------------------------------
+struct ImgPair { const uint8_t* img[2]; int32_t* sum[2]; };
+static const int kSegRows = 32;
+
+__global__ __launch_bounds__(256) void k_integral_rows(ImgPair ip, int w, int h)
+{
+    const int y = blockIdx.x, im = blockIdx.z, tid = threadIdx.x;
+    const int sw = w + 1;
+    const uint8_t* src = ip.img[im] + (size_t)y * w;
+    int32_t* dst = ip.sum[im] + (size_t)(y + 1) * sw;
+    const int chunk = (w + 255) / 256;
+    const int x0 = tid * chunk;
+    int local = 0;
+    for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) local += src[x]; }
+    // block exclusive scan of `local`
+    __shared__ int wsum[4];
+    int lane = tid & 63, wv = tid >> 6;
+    int inc = local;
+    for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wv; k++) base += wsum[k];
+    int run = base + inc - local;
+    for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) { run += src[x]; dst[x + 1] = run; } }
+    if (tid == 0) dst[0] = 0;
+    if (y == 0) { int32_t* r0 = ip.sum[im]; for (int x = tid; x < sw; x += 256) r0[x] = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_integral_colsum(ImgPair ip, int w, int h, int32_t* part, int nseg)
+{
+    const int sw = w + 1, x = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y, im = blockIdx.z;
+    if (x >= sw) return;
+    const int32_t* s = ip.sum[im];
+    int y0 = 1 + seg * kSegRows, y1 = min(h + 1, y0 + kSegRows);
+    int acc = 0;
+    for (int y = y0; y < y1; y++) acc += s[(size_t)y * sw + x];
+    part[((size_t)im * nseg + seg) * sw + x] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_integral_colfinal(ImgPair ip, int w, int h, const int32_t* part, int nseg)
+{
+    const int sw = w + 1, x = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y, im = blockIdx.z;
+    if (x >= sw) return;
+    int32_t* s = ip.sum[im];
+    int acc = 0;
+    for (int k = 0; k < seg; k++) acc += part[((size_t)im * nseg + k) * sw + x];
+    int y0 = 1 + seg * kSegRows, y1 = min(h + 1, y0 + kSegRows);
+    for (int y = y0; y < y1; y++) { acc += s[(size_t)y * sw + x]; s[(size_t)y * sw + x] = acc; }
+}
+
+// ------------------------------------------------------------------------------------------
+// Hessian layers
+// ------------------------------------------------------------------------------------------
+struct LayerPat {
+    int dx1[10], dy1[10], dx2[10], dy2[10];   // boxes: 0-2 Dx, 3-5 Dy, 6-9 Dxy
+    float w[10];
+    int size, margin, samples_i, samples_j;   // samples = 0 when the layer does not fit the image
+};
+struct OctavePat {
+    LayerPat L[5];
+    int step, rows, cols;
+    int lo, hi;                // sum-coordinate extent of all boxes relative to plane_coord*step
+    int nms_margin[3];         // for middle layers 1..3
+    int octave;
+};
+
+// resizeHaarPattern (surf.cpp): coordinates cvRound(ratio*c), weight w/((float)(dx2-dx1)*(dy2-dy1))
+static void make_pattern(int size, LayerPat* lp)
+{
+    static const int dx_s[3][5]  = { {0, 2, 3, 7, 1}, {3, 2, 6, 7, -2}, {6, 2, 9, 7, 1} };
+    static const int dy_s[3][5]  = { {2, 0, 7, 3, 1}, {2, 3, 7, 6, -2}, {2, 6, 7, 9, 1} };
+    static const int dxy_s[4][5] = { {1, 1, 4, 4, 1}, {5, 1, 8, 4, -1}, {1, 5, 4, 8, -1}, {5, 5, 8, 8, 1} };
+    float ratio = (float)size / 9;
+    for (int k = 0; k < 10; k++) {
+        const int* s = k < 3 ? dx_s[k] : k < 6 ? dy_s[k - 3] : dxy_s[k - 6];
+        int dx1 = cv_round_f(ratio * s[0]), dy1 = cv_round_f(ratio * s[1]);
+        int dx2 = cv_round_f(ratio * s[2]), dy2 = cv_round_f(ratio * s[3]);
+        lp->dx1[k] = dx1; lp->dy1[k] = dy1; lp->dx2[k] = dx2; lp->dy2[k] = dy2;
+        lp->w[k] = s[4] / ((float)(dx2 - dx1) * (dy2 - dy1));
+    }
+    lp->size = size;
+}
+
+static void make_octave(int octave, int nOctaveLayers, int w, int h, OctavePat* op)
+{
+    int step = 1 << octave;
+    op->step = step; op->rows = h / step; op->cols = w / step; op->octave = octave;
+    op->lo = 0; op->hi = 0;
+    for (int l = 0; l < 5; l++) {
+        int size = (9 + 6 * l) << octave;
+        LayerPat* lp = &op->L[l];
+        make_pattern(size, lp);
+        lp->margin = (size / 2) / step;
+        bool fits = l < nOctaveLayers + 2 && size <= h && size <= w;
+        lp->samples_i = fits ? 1 + (h - size) / step : 0;
+        lp->samples_j = fits ? 1 + (w - size) / step : 0;
+        int lo = -lp->margin * step, hi = lo + size;
+        if (lo < op->lo) op->lo = lo;
+        if (hi > op->hi) op->hi = hi;
+    }
+    for (int m = 0; m < 3; m++) op->nms_margin[m] = (op->L[m + 2].size / 2) / step + 1;
+}
+
+// calcHaarPattern x3 -> dx, dy, dxy for the template whose top-left integral sample is S(0,0)
+template <class SumAt>
+__device__ __forceinline__ void haar_response(const LayerPat& lp, SumAt S, float* pdx, float* pdy, float* pdxy)
+{
+    double d = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int v = S(lp.dy1[k], lp.dx1[k]) + S(lp.dy2[k], lp.dx2[k]) - S(lp.dy2[k], lp.dx1[k]) - S(lp.dy1[k], lp.dx2[k]);
+        d += (float)v * lp.w[k];
+    }
+    *pdx = (float)d;
+    d = 0;
+#pragma unroll
+    for (int k = 3; k < 6; k++) {
+        int v = S(lp.dy1[k], lp.dx1[k]) + S(lp.dy2[k], lp.dx2[k]) - S(lp.dy2[k], lp.dx1[k]) - S(lp.dy1[k], lp.dx2[k]);
+        d += (float)v * lp.w[k];
+    }
+    *pdy = (float)d;
+    d = 0;
+#pragma unroll
+    for (int k = 6; k < 10; k++) {
+        int v = S(lp.dy1[k], lp.dx1[k]) + S(lp.dy2[k], lp.dx2[k]) - S(lp.dy2[k], lp.dx1[k]) - S(lp.dy1[k], lp.dx2[k]);
+        d += (float)v * lp.w[k];
+    }
+    *pdxy = (float)d;
+}
+
+// Matx33f::solve(b, DECOMP_LU) == Cramer's rule in float (Matx_FastSolveOp<float,3,3,1>)
+__device__ __forceinline__ void solve3f(const float a[3][3], const float b[3], float x[3])
+{
+    float d = (float)(double)(a[0][0]*(a[1][1]*a[2][2] - a[2][1]*a[1][2]) -
+                              a[0][1]*(a[1][0]*a[2][2] - a[2][0]*a[1][2]) +
+                              a[0][2]*(a[1][0]*a[2][1] - a[2][0]*a[1][1]));
+    if (d == 0) { x[0] = x[1] = x[2] = 0; return; }
+    d = 1/d;
+    x[0] = d*(b[0]*(a[1][1]*a[2][2] - a[1][2]*a[2][1]) -
+              a[0][1]*(b[1]*a[2][2] - a[1][2]*b[2]) +
+              a[0][2]*(b[1]*a[2][1] - a[1][1]*b[2]));
+    x[1] = d*(a[0][0]*(b[1]*a[2][2] - a[1][2]*b[2]) -
+              b[0]*(a[1][0]*a[2][2] - a[1][2]*a[2][0]) +
+              a[0][2]*(a[1][0]*b[2] - b[1]*a[2][0]));
+    x[2] = d*(a[0][0]*(a[1][1]*b[2] - b[1]*a[2][1]) -
+              a[0][1]*(a[1][0]*b[2] - b[1]*a[2][0]) +
+              b[0]*(a[1][0]*a[2][1] - a[1][1]*a[2][0]));
+}
+
+struct CandOut { uvo_keypoint* cand[2]; int* count; int cap; };
+
+// TW x TH plane samples per workgroup including a 1-sample halo; (TW-2) x (TH-2) NMS outputs.
+template <int STEP, bool USE_LDS, int TW, int TH>
+__global__ __launch_bounds__(256) void k_hessian_nms(ImgPair ip, int w, int h, OctavePat op, float thr, CandOut out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, im = blockIdx.z;
+    const int sw = w + 1;
+    const int32_t* __restrict__ gsum = ip.sum[im];
+    float* sdet = reinterpret_cast<float*>(smem);                    // [5][TH][TW]
+    int32_t* stile = reinterpret_cast<int32_t*>(smem + sizeof(float) * 5 * TH * TW);
+
+    const int px0 = blockIdx.x * (TW - 2) - 1, py0 = blockIdx.y * (TH - 2) - 1;   // plane coords of region (0,0)
+    // integral tile: sum coords [sx0, sx0 + tw) x [sy0, sy0 + th)
+    const int sx0 = px0 * STEP + op.lo, sy0 = py0 * STEP + op.lo;
+    const int tw = (TW - 1) * STEP + (op.hi - op.lo) + 1;
+    const int th = (TH - 1) * STEP + (op.hi - op.lo) + 1;
+    if (USE_LDS) {
+        for (int idx = tid; idx < tw * th; idx += 256) {
+            int ty = idx / tw, tx = idx - ty * tw;
+            int gy = sy0 + ty, gx = sx0 + tx;
+            int v = 0;
+            if (gy >= 0 && gy <= h && gx >= 0 && gx <= w) v = gsum[(size_t)gy * sw + gx];
+            stile[idx] = v;
+        }
+        __syncthreads();
+    }
+
+    // ---- det for 5 layers over the TW x TH region ----
+#pragma unroll 1
+    for (int l = 0; l < 5; l++) {
+        const LayerPat& lp = op.L[l];
+        for (int idx = tid; idx < TW * TH; idx += 256) {
+            int ry = idx / TW, rx = idx - ry * TW;
+            int oi = py0 + ry - lp.margin, oj = px0 + rx - lp.margin;
+            float det = 0.f;
+            if (oi >= 0 && oi < lp.samples_i && oj >= 0 && oj < lp.samples_j) {
+                float dx, dy, dxy;
+                if (USE_LDS) {
+                    const int32_t* o = stile + (oi * STEP - sy0) * tw + (oj * STEP - sx0);
+                    haar_response(lp, [&](int yy, int xx) { return o[yy * tw + xx]; }, &dx, &dy, &dxy);
+                } else {
+                    const int32_t* o = gsum + (size_t)(oi * STEP) * sw + oj * STEP;
+                    haar_response(lp, [&](int yy, int xx) { return o[(size_t)yy * sw + xx]; }, &dx, &dy, &dxy);
+                }
+                det = dx * dy - 0.81f * dxy * dxy;
+            }
+            sdet[(l * TH + ry) * TW + rx] = det;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3x3x3 non-maximum suppression + interpolation on the three middle layers ----
+#pragma unroll 1
+    for (int L = 1; L <= 3; L++) {
+        const LayerPat& lp = op.L[L];
+        if (lp.samples_i == 0 || op.L[L + 1].samples_i == 0) continue;
+        const int m = op.nms_margin[L - 1];
+        for (int idx = tid; idx < (TW - 2) * (TH - 2); idx += 256) {
+            int ry = idx / (TW - 2) + 1, rx = idx - (ry - 1) * (TW - 2) + 1;
+            int i = py0 + ry, j = px0 + rx;
+            if (i < m || i >= op.rows - m || j < m || j >= op.cols - m) continue;
+            const float* d2 = sdet + (L * TH + ry) * TW + rx;
+            float val0 = d2[0];
+            if (!(val0 > thr)) continue;
+            const float* d1 = d2 - TH * TW;
+            const float* d3 = d2 + TH * TW;
+            float N9[3][9] = {
+                { d1[-TW-1], d1[-TW], d1[-TW+1], d1[-1], d1[0], d1[1], d1[TW-1], d1[TW], d1[TW+1] },
+                { d2[-TW-1], d2[-TW], d2[-TW+1], d2[-1], d2[0], d2[1], d2[TW-1], d2[TW], d2[TW+1] },
+                { d3[-TW-1], d3[-TW], d3[-TW+1], d3[-1], d3[0], d3[1], d3[TW-1], d3[TW], d3[TW+1] } };
+            bool is_max = true;
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 9; b++)
+                    if (!(a == 1 && b == 4)) is_max = is_max && (val0 > N9[a][b]);
+            if (!is_max) continue;
+
+            const int size = lp.size;
+            int sum_i = STEP * (i - (size / 2) / STEP);
+            int sum_j = STEP * (j - (size / 2) / STEP);
+            float center_i = sum_i + (size - 1) * 0.5f;
+            float center_j = sum_j + (size - 1) * 0.5f;
+            // sign of the trace (dx + dy) at the maximum
+            float dx, dy, dxy;
+            {
+                int oi = i - lp.margin, oj = j - lp.margin;
+                if (USE_LDS) {
+                    const int32_t* o = stile + (oi * STEP - sy0) * tw + (oj * STEP - sx0);
+                    haar_response(lp, [&](int yy, int xx) { return o[yy * tw + xx]; }, &dx, &dy, &dxy);
+                } else {
+                    const int32_t* o = gsum + (size_t)(oi * STEP) * sw + oj * STEP;
+                    haar_response(lp, [&](int yy, int xx) { return o[(size_t)yy * sw + xx]; }, &dx, &dy, &dxy);
+                }
+            }
+            float trace = dx + dy;
+            // interpolateKeypoint
+            float bb[3] = { -(N9[1][5]-N9[1][3])/2, -(N9[1][7]-N9[1][1])/2, -(N9[2][4]-N9[0][4])/2 };
+            float A[3][3] = {
+                { N9[1][3]-2*N9[1][4]+N9[1][5], (N9[1][8]-N9[1][6]-N9[1][2]+N9[1][0])/4, (N9[2][5]-N9[2][3]-N9[0][5]+N9[0][3])/4 },
+                { (N9[1][8]-N9[1][6]-N9[1][2]+N9[1][0])/4, N9[1][1]-2*N9[1][4]+N9[1][7], (N9[2][7]-N9[2][1]-N9[0][7]+N9[0][1])/4 },
+                { (N9[2][5]-N9[2][3]-N9[0][5]+N9[0][3])/4, (N9[2][7]-N9[2][1]-N9[0][7]+N9[0][1])/4, N9[0][4]-2*N9[1][4]+N9[2][4] } };
+            float x[3];
+            solve3f(A, bb, x);
+            bool ok = (x[0] != 0 || x[1] != 0 || x[2] != 0) &&
+                      fabsf(x[0]) <= 1 && fabsf(x[1]) <= 1 && fabsf(x[2]) <= 1;
+            if (!ok) continue;
+            int ds = size - op.L[L - 1].size;
+            uvo_keypoint kp;
+            kp.x = center_j + x[0] * STEP;
+            kp.y = center_i + x[1] * STEP;
+            kp.size = (float)cv_round_f((float)size + x[2] * ds);
+            kp.angle = 360.f - 90.f;            // upright: descriptor_dir
+            kp.response = val0;
+            kp.octave = op.octave;
+            kp.class_id = (trace > 0) - (trace < 0);
+            // SURFInvoker: keypoints whose gradient wavelet exceeds the integral image are dropped
+            float s = kp.size * 1.2f / 9.0f;
+            int grad_wav_size = 2 * cv_round_f(2 * s);
+            if (h + 1 < grad_wav_size || w + 1 < grad_wav_size) continue;
+            int slot = atomicAdd(&out.count[im], 1);
+            if (slot < out.cap) out.cand[im][slot] = kp;
+        }
+    }
+}
+
+// debug / parity hook: one det+trace layer written to global planes (rows x cols)
+__global__ void k_hessian_layer_debug(const int32_t* gsum, int w, int h, LayerPat lp, int step, int rows, int cols,
+                                      float* det, float* trace)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= lp.samples_j || i >= lp.samples_i) return;
+    const int sw = w + 1;
+    const int32_t* o = gsum + (size_t)(i * step) * sw + j * step;
+    float dx, dy, dxy;
+    haar_response(lp, [&](int yy, int xx) { return o[(size_t)yy * sw + xx]; }, &dx, &dy, &dxy);
+    size_t pos = (size_t)(i + lp.margin) * cols + (j + lp.margin);
+    det[pos] = dx * dy - 0.81f * dxy * dxy;
+    trace[pos] = dx + dy;
+}
+
+// ------------------------------------------------------------------------------------------
+// deterministic ordering: rank = number of keypoints that sort before this one (KeypointGreater)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool kp_greater(const uvo_keypoint& a, const uvo_keypoint& b)
+{
+    if (a.response > b.response) return true;
+    if (a.response < b.response) return false;
+    if (a.size > b.size) return true;
+    if (a.size < b.size) return false;
+    if (a.octave > b.octave) return true;
+    if (a.octave < b.octave) return false;
+    if (a.y < b.y) return false;
+    if (a.y > b.y) return true;
+    return a.x < b.x;
+}
+
+struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* out[2]; int* out_n[2]; int cap; };
+
+__global__ __launch_bounds__(256) void k_rank_sort(SortArgs a)
+{
+    const int im = blockIdx.y, tid = threadIdx.x;
+    const int n = min(a.cand_n[im], a.cap);
+    const int me = blockIdx.x * 256 + tid;
+    if (blockIdx.x * 256 >= n && !(blockIdx.x == 0)) return;
+    __shared__ uvo_keypoint tile[256];
+    uvo_keypoint mine;
+    if (me < n) mine = a.cand[im][me];
+    int rank = 0;
+    for (int base = 0; base < n; base += 256) {
+        if (base + tid < n) tile[tid] = a.cand[im][base + tid];
+        __syncthreads();
+        if (me < n) {
+            int cnt = min(256, n - base);
+            for (int k = 0; k < cnt; k++) {
+                const uvo_keypoint& o = tile[k];
+                bool before = kp_greater(o, mine);
+                if (!before && !kp_greater(mine, o)) {        // identical sort key: class_id, then slot
+                    int oi = base + k;
+                    before = o.class_id < mine.class_id || (o.class_id == mine.class_id && oi < me);
+                }
+                rank += before ? 1 : 0;
+            }
+        }
+        __syncthreads();
+    }
+    if (me < n) a.out[im][rank] = mine;
+    if (blockIdx.x == 0 && tid == 0) *a.out_n[im] = n;
+}
+
+// ------------------------------------------------------------------------------------------
+// descriptor: one workgroup per keypoint
+// ------------------------------------------------------------------------------------------
+struct AreaTab { int sx1, sx2; float a_first, a_mid, a_last; bool has_first, has_last; };
+
+// computeResizeAreaTab (resize.cpp) for one destination index
+__device__ __forceinline__ AreaTab area_tab(int dx, int ssize, double scale)
+{
+    AreaTab t;
+    double fsx1 = dx * scale;
+    double fsx2 = fsx1 + scale;
+    double cellWidth = scale < ssize - fsx1 ? scale : ssize - fsx1;
+    int sx1 = cv_ceil_d(fsx1), sx2 = cv_floor_d(fsx2);
+    sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+    sx1 = sx1 < sx2 ? sx1 : sx2;
+    t.sx1 = sx1; t.sx2 = sx2;
+    t.has_first = sx1 - fsx1 > 1e-3;
+    t.a_first = (float)((sx1 - fsx1) / cellWidth);
+    t.a_mid = (float)(1.0 / cellWidth);
+    t.has_last = fsx2 - sx2 > 1e-3;
+    double a = fsx2 - sx2; if (a > 1.) a = 1.; if (a > cellWidth) a = cellWidth;
+    t.a_last = (float)(a / cellWidth);
+    return t;
+}
+
+__device__ __forceinline__ uint8_t sat_u8(float v) { int iv = cv_round_f(v); return (uint8_t)(iv < 0 ? 0 : iv > 255 ? 255 : iv); }
+
+struct DescArgs { const uint8_t* img[2]; uvo_keypoint* kps[2]; float* desc[2]; const int* n[2]; const float* DW; };
+
+__global__ __launch_bounds__(256) void k_descriptor64(DescArgs a, int w, int h)
+{
+    const int k = blockIdx.x, im = blockIdx.y, tid = threadIdx.x;
+    if (k >= *a.n[im]) return;
+    __shared__ int PATCH[21][21];
+    __shared__ float DX[20][20], DY[20][20];
+    __shared__ float vec[64];
+    __shared__ float s_scale;
+    const uint8_t* __restrict__ img = a.img[im];
+    const uvo_keypoint kp = a.kps[im][k];
+    const float size = kp.size;
+    const float s = size * 1.2f / 9.0f;
+    const int win_size = (int)((20 + 1) * s);
+    const float win_offset = -(float)(win_size - 1) / 2;
+    const int start_x = cv_round_f(kp.x + win_offset);
+    const int start_y = cv_round_f(kp.y - win_offset);
+    // WIN[i][j] = img(clamp(start_y - j), clamp(start_x + i)); PATCH = resize(WIN, 21x21, INTER_AREA)
+    const double inv_scale = (double)21 / win_size;
+    const double scale = 1. / inv_scale;
+    const int iscale = cv_round_d(scale);
+    const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
+
+    for (int o = tid; o < 441; o += 256) {
+        int dy = o / 21, dx = o - dy * 21;
+        int result;
+        if (area_fast) {
+            int sum = 0;
+            for (int sy = 0; sy < iscale; sy++) {
+                int x = start_x + dy * iscale + sy; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
+                for (int sx = 0; sx < iscale; sx++) {
+                    int y = start_y - (dx * iscale + sx); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                    sum += img[(size_t)y * w + x];
+                }
+            }
+            if (iscale == 2) result = (sum + 2) >> 2;
+            else { float sc = 1.f / (iscale * iscale); result = sat_u8(sum * sc); }
+        } else {
+            AreaTab ty = area_tab(dy, win_size, scale);
+            AreaTab tx = area_tab(dx, win_size, scale);
+            float sum = 0.f;
+            const int r_begin = ty.has_first ? ty.sx1 - 1 : ty.sx1;
+            const int r_end = ty.has_last ? ty.sx2 + 1 : ty.sx2;          // exclusive
+            const int c_begin = tx.has_first ? tx.sx1 - 1 : tx.sx1;
+            const int c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
+            for (int r = r_begin; r < r_end; r++) {
+                float beta = r < ty.sx1 ? ty.a_first : (r < ty.sx2 ? ty.a_mid : ty.a_last);
+                int x = start_x + r; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
+                float buf = 0.f;
+                for (int cc = c_begin; cc < c_end; cc++) {
+                    float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
+                    int y = start_y - cc; y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                    buf += img[(size_t)y * w + x] * alpha;
+                }
+                sum += beta * buf;
+            }
+            result = sat_u8(sum);
+        }
+        PATCH[dy][dx] = result;
+    }
+    __syncthreads();
+    for (int o = tid; o < 400; o += 256) {
+        int i = o / 20, j = o - i * 20;
+        float dw = a.DW[o];
+        float vx = (PATCH[i][j+1] - PATCH[i][j] + PATCH[i+1][j+1] - PATCH[i+1][j]) * dw;
+        float vy = (PATCH[i+1][j] - PATCH[i][j] + PATCH[i+1][j+1] - PATCH[i][j+1]) * dw;
+        DX[i][j] = vx; DY[i][j] = vy;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        int cell = tid >> 2, comp = tid & 3, ci = cell >> 2, cj = cell & 3;
+        float acc = 0.f;
+        for (int y = ci * 5; y < ci * 5 + 5; y++)
+            for (int x = cj * 5; x < cj * 5 + 5; x++) {
+                float t = (comp & 1) ? DY[y][x] : DX[y][x];
+                acc += (comp & 2) ? (float)fabs(t) : t;
+            }
+        vec[tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double square_mag = 0;
+        for (int kk = 0; kk < 64; kk++) square_mag += vec[kk] * vec[kk];
+        s_scale = (float)(1. / (sqrt(square_mag) + FLT_EPSILON));
+    }
+    __syncthreads();
+    if (tid < 64) a.desc[im][(size_t)k * 64 + tid] = vec[tid] * s_scale;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int stride, int mem)
+{
+    if (!gray || w <= 0 || h <= 0 || w > c->max_w || h > c->max_h || stride < w || slot < 0 || slot > 1) {
+        c->err = "surf_upload: bad image geometry (w/h exceed the context's max_w/max_h?)";
+        return UVO_INVALID_ARG;
+    }
+    if (slot == 1 && (w != c->img_w || h != c->img_h)) { c->err = "left/right image sizes differ"; return UVO_INVALID_ARG; }
+    c->img_w = w; c->img_h = h;
+    UVO_HIP_TRY(c, hipMemcpy2DAsync(c->d_img[slot], w, gray, stride, w, h,
+                                    mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    return UVO_OK;
+}
+
+uvo_status surf_integral(Ctx* c, int nimg)
+{
+    const int w = c->img_w, h = c->img_h, sw = w + 1;
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] } };
+    int nseg = (h + kSegRows - 1) / kSegRows;
+    StageTimer t(c, ST_INTEGRAL);
+    hipLaunchKernelGGL(k_integral_rows, dim3(h, 1, nimg), dim3(256), 0, c->stream, ip, w, h);
+    dim3 g((sw + 255) / 256, nseg, nimg);
+    hipLaunchKernelGGL(k_integral_colsum, g, dim3(256), 0, c->stream, ip, w, h, c->d_colpart, nseg);
+    hipLaunchKernelGGL(k_integral_colfinal, g, dim3(256), 0, c->stream, ip, w, h, c->d_colpart, nseg);
+    UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+
+template <int STEP, bool USE_LDS, int TW, int TH>
+static hipError_t launch_hessian(Ctx* c, int nimg, const OctavePat& op, float thr)
+{
+    const int w = c->img_w, h = c->img_h;
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] } };
+    CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
+    size_t lds = sizeof(float) * 5 * TW * TH;
+    if (USE_LDS) {
+        int tw = (TW - 1) * STEP + (op.hi - op.lo) + 1, th = (TH - 1) * STEP + (op.hi - op.lo) + 1;
+        lds += sizeof(int32_t) * (size_t)tw * th;
+    }
+    dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
+    auto kern = k_hessian_nms<STEP, USE_LDS, TW, TH>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, ip, w, h, op, thr, out);
+    return hipGetLastError();
+}
+
+uvo_status surf_detect(Ctx* c, int nimg)
+{
+    const int w = c->img_w, h = c->img_h;
+    if (c->p.SURF_EXTENDED || !c->p.SURF_UPRIGHT) {
+        c->err = "only the reference's configured SURF branch (extended=false, upright=true) is implemented";
+        return UVO_INVALID_ARG;
+    }
+    if (c->p.SURF_OCTAVES_NUMBER < 1 || c->p.SURF_OCTAVES_NUMBER > 4 || c->p.SURF_OCTAVES_LAYERS != 3) {
+        c->err = "SURF: supported nOctaves 1..4, nOctaveLayers 3";
+        return UVO_INVALID_ARG;
+    }
+    UVO_TRY(surf_integral(c, nimg));
+    UVO_HIP_TRY(c, hipMemsetAsync(c->d_cand_n, 0, sizeof(int) * 2, c->stream));
+    const float thr = (float)c->p.SURF_MIN_HESSIAN;
+    {
+        StageTimer t(c, ST_HESSIAN);
+        for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER; o++) {
+            OctavePat op;
+            make_octave(o, c->p.SURF_OCTAVES_LAYERS, w, h, &op);
+            hipError_t e;
+            if (o == 0)      e = launch_hessian<1, true, 64, 32>(c, nimg, op, thr);
+            else if (o == 1) e = launch_hessian<2, true, 32, 32>(c, nimg, op, thr);
+            else if (o == 2) e = launch_hessian<4, false, 32, 16>(c, nimg, op, thr);
+            else             e = launch_hessian<8, false, 32, 16>(c, nimg, op, thr);
+            UVO_HIP_TRY(c, e);
+        }
+    }
+    {
+        StageTimer t(c, ST_SORT);
+        SortArgs sa = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, { c->det[0].kps, c->det[1].kps },
+                        { c->det[0].n, c->det[1].n }, c->cap };
+        hipLaunchKernelGGL(k_rank_sort, dim3((c->cap + 255) / 256, nimg), dim3(256), 0, c->stream, sa);
+        UVO_HIP_TRY(c, hipGetLastError());
+    }
+    {
+        StageTimer t(c, ST_DESCRIPTOR);
+        DescArgs da = { { c->d_img[0], c->d_img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
+                        { c->det[0].n, c->det[1].n }, c->d_DW };
+        hipLaunchKernelGGL(k_descriptor64, dim3(c->cap, nimg), dim3(256), 0, c->stream, da, w, h);
+        UVO_HIP_TRY(c, hipGetLastError());
+    }
+    return UVO_OK;
+}
+
+uvo_status surf_hessian_layer_debug(Ctx* c, int octave, int layer, float* det, float* trace)
+{
+    const int w = c->img_w, h = c->img_h;
+    if (octave < 0 || octave > 3 || layer < 0 || layer > 4 || w <= 0) { c->err = "hessian_layer: bad octave/layer or no image"; return UVO_INVALID_ARG; }
+    OctavePat op;
+    make_octave(octave, 3, w, h, &op);
+    size_t n = (size_t)op.rows * op.cols;
+    float *d_det = nullptr, *d_tr = nullptr;
+    UVO_HIP_TRY(c, hipMalloc(&d_det, sizeof(float) * n * 2));
+    d_tr = d_det + n;
+    UVO_HIP_TRY(c, hipMemsetAsync(d_det, 0, sizeof(float) * n * 2, c->stream));
+    const LayerPat& lp = op.L[layer];
+    if (lp.samples_i > 0) {
+        dim3 g((lp.samples_j + 255) / 256, lp.samples_i);
+        hipLaunchKernelGGL(k_hessian_layer_debug, g, dim3(256), 0, c->stream, c->d_sum[0], w, h, lp, op.step, op.rows, op.cols, d_det, d_tr);
+    }
+    UVO_HIP_TRY(c, hipMemcpyAsync(det, d_det, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipMemcpyAsync(trace, d_tr, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(d_det);
+    return UVO_OK;
+}
+
+}  // namespace uvo

@@ -1,0 +1,140 @@
+// uvo_ctx.h -- internal context of libuvo_hip: device workspaces, stream, stage timers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include <stdint.h>
+#include "../../include/uvo_hip.h"
+
+namespace uvo {
+
+#define UVO_HIP_TRY(c, expr)                                                                  \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            (c)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                     \
+            return UVO_HIP_ERROR;                                                             \
+        }                                                                                     \
+    } while (0)
+
+#define UVO_TRY(expr)                                                                         \
+    do { uvo_status _s = (expr); if (_s != UVO_OK) return _s; } while (0)
+
+enum Stage {
+    ST_INTEGRAL = 0, ST_HESSIAN, ST_SORT, ST_DESCRIPTOR, ST_MATCH, ST_MATCH_MERGE, ST_GATHER,
+    ST_TRIANGULATE, ST_EXTRACT3D, ST_PNP_HYP, ST_PNP_SCORE, ST_PNP_REFIT, ST_COUNT
+};
+static const char* const kStageNames[ST_COUNT] = {
+    "integral", "hessian_nms", "kp_sort", "descriptor64", "match_top2", "match_merge", "gather",
+    "triangulate", "extract3d", "pnp_epnp5", "pnp_score", "pnp_refit"
+};
+
+static const int kMaxHyp = 2048;      // RANSAC hypotheses evaluated per call (>= ITERATIONS_COUNT)
+static const int kMatchChunk = 64;    // train rows per matcher workgroup
+
+struct DetectSet {                    // one image's detector outputs (device)
+    uvo_keypoint* kps;                // sorted, cap
+    float* desc;                      // cap x 64
+    int* n;                           // device count (clamped to cap)
+};
+
+struct Ctx {
+    uvo_params p;
+    int device = 0, max_w = 0, max_h = 0, cap = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- SURF ----
+    uint8_t* d_img[2] = {nullptr, nullptr};
+    int32_t* d_sum[2] = {nullptr, nullptr};      // (max_h+1) x (max_w+1)
+    int32_t* d_colpart = nullptr;                // [2][nseg][max_w+1]
+    uvo_keypoint* d_cand[2] = {nullptr, nullptr};// unsorted candidates
+    int* d_cand_n = nullptr;                     // [2] raw atomic counters
+    DetectSet det[2];                            // current left/right
+    int img_w = 0, img_h = 0;
+    float h_DW[400];                             // descriptor Gaussian weights (host copy)
+    float* d_DW = nullptr;
+
+    // ---- matcher ----
+    float4* d_mpart = nullptr;                   // partial top-2 per (chunk, query): (d0, i0, d1, i1)
+    int* d_knn_idx = nullptr;  float* d_knn_dist = nullptr;   // [cap][2]
+    float* d_tmp_desc[2] = {nullptr, nullptr};   // staging for the standalone match API
+    uvo_dmatch* d_matches[2] = {nullptr, nullptr};            // [0] stereo (L-R), [1] triangular (prev-curr)
+    int* d_nmatch = nullptr;                     // [2]
+
+    // ---- stereo state: "after stereo match" sets, double-buffered (prev / curr) ----
+    uvo_keypoint* d_as_kpsL[2] = {nullptr, nullptr};
+    uvo_keypoint* d_as_kpsR[2] = {nullptr, nullptr};
+    float* d_as_descL[2] = {nullptr, nullptr};
+    int* d_as_n = nullptr;                       // [2] counts (device)
+    int as_prev = 0;                             // index of the prev buffer
+    bool vo_initialized = false;
+    std::vector<uvo_dmatch> init_matches;        // results_match_prev (VO:468): survives failed init attempts
+    double K_left[9], K_right[9], R_right[9], t_right[3], P_eye_left[12], P_right[12];
+    bool rig_set = false;
+    double t_prev_curr[3] = {0, 0, 0}, rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0};
+
+    // ---- triangulation / extract_3Dpoints ----
+    uvo_point2f *d_x1 = nullptr, *d_x2 = nullptr, *d_xc = nullptr;   // prevL, prevR, currL points of the T matches
+    float4* d_pts4 = nullptr;                    // T homogeneous points
+    double* d_cam1 = nullptr;                    // T x 3
+    int* d_flag = nullptr;                       // T
+    double* d_good_pts = nullptr;  int* d_good_idx = nullptr;        // G x 3, G
+    float* d_opts = nullptr;  uvo_point2f* d_ipts = nullptr;         // G x 3 f32 object points, G image points
+    int* d_counts = nullptr;                     // misc device counters: [0]=T, [1]=G, [2]=n_inliers, ...
+    int* h_counts = nullptr;                     // pinned mirror
+
+    // ---- PnP RANSAC ----
+    int* d_subsets = nullptr;                    // kMaxHyp x 5
+    int* h_subsets = nullptr;                    // pinned
+    double* d_models = nullptr;                  // kMaxHyp x 6 (rvec | tvec)
+    int* d_hcount = nullptr;  int* h_hcount = nullptr;               // inlier count per hypothesis
+    int* d_inliers = nullptr;                    // cap
+    double* d_refit = nullptr;                   // refit workspace: pws 3n, us 2n, alphas 4n, pcs 3n, tmp n, M 24n, small
+    double* d_pose = nullptr;  double* h_pose = nullptr;             // rvec(3) tvec(3)
+
+    // pinned staging for results
+    void* h_stage = nullptr;  size_t h_stage_bytes = 0;
+
+    // last-step bookkeeping for uvo_stereo_get
+    int last_nL = 0, last_nR = 0, last_M = 0, last_T = 0, last_G = 0, last_ninl = 0;
+
+    // ---- timing ----
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double stage_ms[ST_COUNT] = {0};
+    long long stage_n[ST_COUNT] = {0};
+};
+
+// RAII-less stage timer: records events around a launch when timing is on (and synchronises, so
+// timing mode serialises the stream -- bench.py uses it only in its roofline leg).
+struct StageTimer {
+    Ctx* c; int st;
+    StageTimer(Ctx* c_, int st_) : c(c_), st(st_) { if (c->timing) (void)hipEventRecord(c->ev0, c->stream); }
+    ~StageTimer()
+    {
+        if (!c->timing) return;
+        (void)hipEventRecord(c->ev1, c->stream);
+        (void)hipEventSynchronize(c->ev1);
+        float ms = 0; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        c->stage_ms[st] += ms; c->stage_n[st] += 1;
+    }
+};
+
+// surf.hip
+uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int stride, int mem);
+uvo_status surf_integral(Ctx* c, int nimg);
+uvo_status surf_detect(Ctx* c, int nimg);          // integral -> ... -> sorted kps + descriptors in c->det[]
+uvo_status surf_hessian_layer_debug(Ctx* c, int octave, int layer, float* det, float* trace);
+// match.hip
+uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, const float* d_t, const int* d_nt, int nt_max);
+uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio, uvo_dmatch* d_out, int* d_nout, int out_cap);
+// pose.hip
+uvo_status pose_triangulate(Ctx* c, const double* P1, const double* P2, const int* d_n, int n_max);
+uvo_status pose_extract3d(Ctx* c, const double* R1, const double* t1, const double* R2, const double* t2,
+                          const double* K1, const double* K2, const int* d_n, int n_max);
+uvo_status pose_pnp_ransac(Ctx* c, int G, const double* K, int iters, float reproj, double conf,
+                           double* rvec, double* tvec, int* n_inliers, int* ok);
+int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters);
+
+}  // namespace uvo

@@ -1,0 +1,541 @@
+// uvo_epnp.h -- EPnP pose solver + Rodrigues for the PnP-RANSAC kernels (device side), in the
+// operation order of OpenCV 4.5 calib3d (epnp.cpp compute_pose and helpers, calibration.cpp
+// cvRodrigues2), as reached by cv::solvePnPRansac(flags = SOLVEPNP_EPNP) at
+// visual_odometry.h:647-648.  One source, two execution policies:
+//   ThreadPolicy<S>: one 5-point hypothesis per thread, all arrays in LDS interleaved by lane.
+//   BlockPolicy    : one n-point refit per workgroup; O(n) loops are spread over the threads,
+//                    every floating-point SUM keeps the reference's sequential order (one thread
+//                    per independent accumulator), so results are identical to the serial form.
+#pragma once
+#include "uvo_linalg.h"
+
+namespace uvo {
+
+template <int S>
+struct ThreadPolicy {
+    using Arr = SArr<S>;
+    static constexpr bool kStoreM = false;
+    __device__ static __forceinline__ int tid() { return 0; }
+    __device__ static __forceinline__ int nth() { return 1; }
+    __device__ static __forceinline__ void sync() {}
+};
+struct BlockPolicy {
+    using Arr = SArr<1>;
+    static constexpr bool kStoreM = true;
+    __device__ static __forceinline__ int tid() { return threadIdx.x; }
+    __device__ static __forceinline__ int nth() { return blockDim.x; }
+    __device__ static __forceinline__ void sync() { __syncthreads(); }
+};
+
+// jacobi_svd variant used for the 12x12 M^T M: OpenCV runs it with Vt present (so the rows of At
+// are sorted and normalised into U^T) but only U is consumed; the V rotations do not feed back
+// into At or W, so they are skipped.
+template <class A>
+__device__ void jacobi_svd_u_only(A At, int astep, A W_out, int m, int n, A W)
+{
+    const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
+    int i, j, k, iter, max_iter = m > 30 ? m : 30;
+    double c, s, sd;
+    for (i = 0; i < n; i++) {
+        for (k = 0, sd = 0; k < m; k++) { double t = At[i*astep + k]; sd += t*t; }
+        W[i] = sd;
+    }
+#pragma unroll 1
+    for (iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+#pragma unroll 1
+        for (i = 0; i < n-1; i++)
+#pragma unroll 1
+            for (j = i+1; j < n; j++) {
+                A Ai = At + i*astep, Aj = At + j*astep;
+                double a = W[i], p = 0, b = W[j];
+                for (k = 0; k < m; k++) p += Ai[k]*Aj[k];
+                if (fabs(p) <= eps*sqrt(a*b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = det_hypot(p, beta);
+                if (beta < 0) {
+                    double delta = (gamma - beta)*0.5;
+                    s = sqrt(delta/gamma);
+                    c = p/(gamma*s*2);
+                } else {
+                    c = sqrt((gamma + beta)/(gamma*2));
+                    s = p/(gamma*c*2);
+                }
+                a = b = 0;
+                for (k = 0; k < m; k++) {
+                    double x = Ai[k], y = Aj[k];
+                    double t0 = c*x + s*y;
+                    double t1 = -s*x + c*y;
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += t0*t0; b += t1*t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = true;
+            }
+        if (!changed) break;
+    }
+    for (i = 0; i < n; i++) {
+        for (k = 0, sd = 0; k < m; k++) { double t = At[i*astep + k]; sd += t*t; }
+        W[i] = sqrt(sd);
+    }
+    for (i = 0; i < n-1; i++) {
+        j = i;
+        for (k = i+1; k < n; k++) if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double t = W[i]; W[i] = W[j]; W[j] = t;
+            for (k = 0; k < m; k++) { t = At[i*astep+k]; At[i*astep+k] = At[j*astep+k]; At[j*astep+k] = t; }
+        }
+    }
+    for (i = 0; i < n; i++) W_out[i] = W[i];
+    uint64_t rng = 0x12345678ULL;
+    for (i = 0; i < n; i++) {
+        sd = W[i];
+        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+            const double val0 = 1./m;
+            for (k = 0; k < m; k++) {
+                double val = (rng_next(rng) & 256) != 0 ? val0 : -val0;
+                At[i*astep + k] = val;
+            }
+            for (iter = 0; iter < 2; iter++) {
+                for (j = 0; j < i; j++) {
+                    sd = 0;
+                    for (k = 0; k < m; k++) sd += At[i*astep + k]*At[j*astep + k];
+                    double asum = 0;
+                    for (k = 0; k < m; k++) {
+                        double t = At[i*astep + k] - sd*At[j*astep + k];
+                        At[i*astep + k] = t;
+                        asum += fabs(t);
+                    }
+                    asum = asum > eps*100 ? 1/asum : 0;
+                    for (k = 0; k < m; k++) At[i*astep + k] *= asum;
+                }
+            }
+            sd = 0;
+            for (k = 0; k < m; k++) { double t = At[i*astep + k]; sd += t*t; }
+            sd = sqrt(sd);
+        }
+        s = sd > minval ? 1/sd : 0.;
+        for (k = 0; k < m; k++) At[i*astep + k] *= s;
+    }
+}
+
+// ---- cvRodrigues2 (calibration.cpp) ----
+// vector -> matrix; R is 9 plain doubles
+__host__ __device__ inline void rodrigues_vec2mat(const double* rv, double* R)
+{
+    double rx = rv[0], ry = rv[1], rz = rv[2];
+    double theta = sqrt(rx*rx + ry*ry + rz*rz);
+    if (theta < DBL_EPSILON) {
+        for (int i = 0; i < 9; i++) R[i] = 0;
+        R[0] = R[4] = R[8] = 1;
+        return;
+    }
+    double s, c; det_sincos(theta, &s, &c);
+    double c1 = 1. - c;
+    double itheta = theta ? 1./theta : 0.;
+    rx *= itheta; ry *= itheta; rz *= itheta;
+    const double rrt[9] = { rx*rx, rx*ry, rx*rz, rx*ry, ry*ry, ry*rz, rx*rz, ry*rz, rz*rz };
+    const double r_x[9] = { 0, -rz, ry, rz, 0, -rx, -ry, rx, 0 };
+    const double eye[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    for (int k = 0; k < 9; k++) R[k] = c*eye[k] + c1*rrt[k] + s*r_x[k];
+}
+
+// matrix -> vector.  Rin: 9 values (accessor), sc: 33 doubles of scratch (a9 v9 w3 wt3 R9)
+template <class A>
+__host__ __device__ void rodrigues_mat2vec(A Rin, A sc, double* rv)
+{
+    for (int i = 0; i < 9; i++) {
+        double v = Rin[i];
+        if (!(v >= -100 && v < 100)) { rv[0] = rv[1] = rv[2] = 0; return; }
+    }
+    A a = sc, v = sc + 9, w = sc + 18, wt = sc + 21, R = sc + 24;
+    svd_square(Rin, a, w, v, wt, 3);
+    // R = U * Vt ; U(i,k) = a[k*3+i]
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double s = 0;
+        for (int k = 0; k < 3; k++) s += a[k*3 + i]*v[k*3 + j];
+        R[i*3 + j] = s;
+    }
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    double s = sqrt((rx*rx + ry*ry + rz*rz)*0.25);
+    double c = (R[0] + R[4] + R[8] - 1)*0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = det_acos(c);
+    if (s < 1e-5) {
+        double t;
+        if (c > 0) rx = ry = rz = 0;
+        else {
+            t = (R[0] + 1)*0.5; rx = sqrt(t > 0. ? t : 0.);
+            t = (R[4] + 1)*0.5; ry = sqrt(t > 0. ? t : 0.)*(R[1] < 0 ? -1. : 1.);
+            t = (R[8] + 1)*0.5; rz = sqrt(t > 0. ? t : 0.)*(R[2] < 0 ? -1. : 1.);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry*rz > 0)) rz = -rz;
+            theta /= sqrt(rx*rx + ry*ry + rz*rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        double vth = 1/(2*s);
+        vth *= theta;
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    rv[0] = rx; rv[1] = ry; rv[2] = rz;
+}
+
+// cvProjectPoints2 with zero distortion: u = ((R X + t).x * (1/z)) * fx + cx
+__host__ __device__ __forceinline__ void project_point(double X, double Y, double Z, const double* R, const double* t,
+                                                       double fx, double fy, double cx, double cy, double* u, double* v)
+{
+    double x = R[0]*X + R[1]*Y + R[2]*Z + t[0];
+    double y = R[3]*X + R[4]*Y + R[5]*Z + t[1];
+    double z = R[6]*X + R[7]*Y + R[8]*Z + t[2];
+    z = z ? 1./z : 1;
+    x *= z; y *= z;
+    *u = x*fx + cx;
+    *v = y*fy + cy;
+}
+
+// ------------------------------------------------------------------------------------------
+// EPnP.  Small fixed-size state lives in `s` (EPNP_SMALL doubles); per-point arrays are
+// pws(3n) us(2n) alphas(4n) pcs(3n) tmp(n) and, for the block policy, M(24n).
+// ------------------------------------------------------------------------------------------
+enum {
+    EP_CWS = 0, EP_CCS = 12, EP_MTM = 24, EP_D = 168, EP_WT = 180, EP_L = 192, EP_RHO = 252,
+    EP_BETAS = 258, EP_REP = 274, EP_RS = 278, EP_TS = 314, EP_PC0 = 326, EP_PW0 = 329, EP_ABT = 332,
+    EP_SC = 341,              // scratch: 140 doubles
+    EPNP_SMALL = 341 + 140
+};
+
+template <class P>
+struct Epnp {
+    using Arr = typename P::Arr;
+    double uc, vc, fu, fv;
+    int n;
+    Arr pws, us, alphas, pcs, tmp, M, s;
+
+    __device__ __forceinline__ double dot3(Arr a, Arr b) const { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
+    __device__ __forceinline__ double dist2(Arr p1, Arr p2) const
+    {
+        return (p1[0]-p2[0])*(p1[0]-p2[0]) + (p1[1]-p2[1])*(p1[1]-p2[1]) + (p1[2]-p2[2])*(p1[2]-p2[2]);
+    }
+    // element (k, c) of the 2n x 12 matrix M of fill_M
+    __device__ __forceinline__ double Mval(int k, int c) const
+    {
+        if (P::kStoreM) return M[k*12 + c];
+        int p = k >> 1, r = k & 1, a = c / 3, q = c - 3*a;
+        double as = alphas[4*p + a];
+        if (r == 0) return q == 0 ? as * fu : q == 1 ? 0.0 : as * (uc - us[2*p]);
+        return q == 0 ? 0.0 : q == 1 ? as * fv : as * (vc - us[2*p + 1]);
+    }
+
+    __device__ void choose_control_points()
+    {
+        Arr cws = s + EP_CWS, sc = s + EP_SC;
+        for (int j = P::tid(); j < 3; j += P::nth()) {
+            double acc = 0;
+            for (int i = 0; i < n; i++) acc += pws[3*i + j];
+            cws[j] = acc / n;
+        }
+        P::sync();
+        // PW0^T PW0 (upper triangle, sequential over points), then mirrored
+        Arr ptp = sc;                         // 9
+        for (int e = P::tid(); e < 6; e += P::nth()) {
+            int a = e < 3 ? 0 : e < 5 ? 1 : 2;
+            int b = e < 3 ? e : e < 5 ? e - 2 : 2;
+            double ca = cws[a], cb = cws[b], s0 = 0;
+            for (int k = 0; k < n; k++) s0 += (pws[3*k + a] - ca) * (pws[3*k + b] - cb);
+            ptp[a*3 + b] = s0;
+            ptp[b*3 + a] = s0;
+        }
+        P::sync();
+        if (P::tid() == 0) {
+            Arr at = sc + 9, dc = sc + 18, vt = sc + 21, wt = sc + 30;
+            svd_square(ptp, at, dc, vt, wt, 3);       // rows of `at` = U^T = uct
+            for (int i = 1; i < 4; i++) {
+                double k = sqrt(dc[i-1] / n);
+                for (int j = 0; j < 3; j++) cws[3*i + j] = cws[j] + k * at[3*(i-1) + j];
+            }
+        }
+        P::sync();
+    }
+
+    __device__ void compute_barycentric_coordinates()
+    {
+        Arr cws = s + EP_CWS, sc = s + EP_SC;
+        Arr cc = sc, ci = sc + 9;
+        if (P::tid() == 0) {
+            for (int i = 0; i < 3; i++) for (int j = 1; j < 4; j++) cc[3*i + j - 1] = cws[3*j + i] - cws[i];
+            invert3_svd(cc, ci, sc + 18, sc + 27, sc + 36, sc + 39);
+        }
+        P::sync();
+        for (int i = P::tid(); i < n; i += P::nth()) {
+            Arr pi = pws + 3*i, a = alphas + 4*i;
+            for (int j = 0; j < 3; j++)
+                a[1 + j] = ci[3*j] * (pi[0] - cws[0]) + ci[3*j + 1] * (pi[1] - cws[1]) + ci[3*j + 2] * (pi[2] - cws[2]);
+            a[0] = 1.0f - a[1] - a[2] - a[3];
+        }
+        P::sync();
+    }
+
+    __device__ void build_mtm()
+    {
+        if (P::kStoreM) {
+            for (int i = P::tid(); i < n; i += P::nth()) {
+                Arr M1 = M + (2*i)*12, M2 = M + (2*i + 1)*12, as = alphas + 4*i;
+                double u = us[2*i], v = us[2*i + 1];
+                for (int a = 0; a < 4; a++) {
+                    M1[3*a] = as[a] * fu; M1[3*a + 1] = 0.0; M1[3*a + 2] = as[a] * (uc - u);
+                    M2[3*a] = 0.0; M2[3*a + 1] = as[a] * fv; M2[3*a + 2] = as[a] * (vc - v);
+                }
+            }
+            P::sync();
+        }
+        Arr mtm = s + EP_MTM;
+        // mulTransposed (MulTransposedR): upper triangle, each entry a sequential sum over the 2n rows
+        for (int e = P::tid(); e < 78; e += P::nth()) {
+            int i = 0, rem = e;
+            while (rem >= 12 - i) { rem -= 12 - i; i++; }
+            int j = i + rem;
+            double s0 = 0;
+            for (int k = 0; k < 2*n; k++) s0 += Mval(k, i) * Mval(k, j);
+            mtm[i*12 + j] = s0;
+            mtm[j*12 + i] = s0;
+        }
+        P::sync();
+    }
+
+    __device__ void compute_L_6x10(Arr ut, Arr l)
+    {
+        Arr dv = s + EP_SC;                   // dv[4][6][3] = 72
+        for (int i = 0; i < 4; i++) {
+            Arr v = ut + 12*(11 - i);
+            int a = 0, b = 1;
+            for (int j = 0; j < 6; j++) {
+                dv[(i*6 + j)*3 + 0] = v[3*a] - v[3*b];
+                dv[(i*6 + j)*3 + 1] = v[3*a + 1] - v[3*b + 1];
+                dv[(i*6 + j)*3 + 2] = v[3*a + 2] - v[3*b + 2];
+                b++;
+                if (b > 3) { a++; b = a + 1; }
+            }
+        }
+#define UVO_DV(i, j) (dv + ((i)*6 + (j))*3)
+        for (int i = 0; i < 6; i++) {
+            Arr row = l + 10*i;
+            row[0] =        dot3(UVO_DV(0, i), UVO_DV(0, i));
+            row[1] = 2.0f * dot3(UVO_DV(0, i), UVO_DV(1, i));
+            row[2] =        dot3(UVO_DV(1, i), UVO_DV(1, i));
+            row[3] = 2.0f * dot3(UVO_DV(0, i), UVO_DV(2, i));
+            row[4] = 2.0f * dot3(UVO_DV(1, i), UVO_DV(2, i));
+            row[5] =        dot3(UVO_DV(2, i), UVO_DV(2, i));
+            row[6] = 2.0f * dot3(UVO_DV(0, i), UVO_DV(3, i));
+            row[7] = 2.0f * dot3(UVO_DV(1, i), UVO_DV(3, i));
+            row[8] = 2.0f * dot3(UVO_DV(2, i), UVO_DV(3, i));
+            row[9] =        dot3(UVO_DV(3, i), UVO_DV(3, i));
+        }
+#undef UVO_DV
+    }
+
+    // scratch layout for the small solves: Ls(30) a(30) v(25) w(5) wt(5) b(5)
+    __device__ void find_betas(int which, Arr L, Arr rho, Arr betas)
+    {
+        Arr sc = s + EP_SC;
+        Arr Ls = sc, a = sc + 30, v = sc + 60, w = sc + 85, wt = sc + 90, b = sc + 95;
+        if (which == 1) {
+            for (int i = 0; i < 6; i++) { Ls[4*i] = L[10*i]; Ls[4*i+1] = L[10*i+1]; Ls[4*i+2] = L[10*i+3]; Ls[4*i+3] = L[10*i+6]; }
+            solve_svd(Ls, 6, 4, rho, b, a, v, w, wt);
+            if (b[0] < 0) { betas[0] = sqrt(-b[0]); betas[1] = -b[1] / betas[0]; betas[2] = -b[2] / betas[0]; betas[3] = -b[3] / betas[0]; }
+            else          { betas[0] = sqrt(b[0]);  betas[1] = b[1] / betas[0];  betas[2] = b[2] / betas[0];  betas[3] = b[3] / betas[0]; }
+        } else if (which == 2) {
+            for (int i = 0; i < 6; i++) { Ls[3*i] = L[10*i]; Ls[3*i+1] = L[10*i+1]; Ls[3*i+2] = L[10*i+2]; }
+            solve_svd(Ls, 6, 3, rho, b, a, v, w, wt);
+            if (b[0] < 0) { betas[0] = sqrt(-b[0]); betas[1] = (b[2] < 0) ? sqrt(-b[2]) : 0.0; }
+            else          { betas[0] = sqrt(b[0]);  betas[1] = (b[2] > 0) ? sqrt(b[2]) : 0.0; }
+            if (b[1] < 0) betas[0] = -betas[0];
+            betas[2] = 0.0; betas[3] = 0.0;
+        } else {
+            for (int i = 0; i < 6; i++) for (int j = 0; j < 5; j++) Ls[5*i + j] = L[10*i + j];
+            solve_svd(Ls, 6, 5, rho, b, a, v, w, wt);
+            if (b[0] < 0) { betas[0] = sqrt(-b[0]); betas[1] = (b[2] < 0) ? sqrt(-b[2]) : 0.0; }
+            else          { betas[0] = sqrt(b[0]);  betas[1] = (b[2] > 0) ? sqrt(b[2]) : 0.0; }
+            if (b[1] < 0) betas[0] = -betas[0];
+            betas[2] = b[3] / betas[0];
+            betas[3] = 0.0;
+        }
+    }
+
+    // epnp.cpp qr_solve, nr = 6, nc = 4 (pA 24, pb 6, pX 4, A1 4, A2 4)
+    __device__ void qr_solve(Arr pA, Arr pb, Arr pX, Arr A1, Arr A2)
+    {
+        const int nr = 6, nc = 4;
+        int kk = 0;                                // index of A[k][k]
+        for (int k = 0; k < nc; k++) {
+            int p1 = kk; double eta = fabs(pA[p1]);
+            for (int i = k + 1; i < nr; i++) { double elt = fabs(pA[p1]); if (eta < elt) eta = elt; p1 += nc; }
+            if (eta == 0) { A1[k] = A2[k] = 0.0; return; }
+            else {
+                int p2 = kk; double sum2 = 0.0, inv_eta = 1. / eta;
+                for (int i = k; i < nr; i++) { double t = pA[p2] * inv_eta; pA[p2] = t; sum2 += t * t; p2 += nc; }
+                double sigma = sqrt(sum2);
+                if (pA[kk] < 0) sigma = -sigma;
+                pA[kk] += sigma;
+                A1[k] = sigma * pA[kk];
+                A2[k] = -eta * sigma;
+                for (int j = k + 1; j < nc; j++) {
+                    int p = kk; double sum = 0;
+                    for (int i = k; i < nr; i++) { sum += pA[p] * pA[p + j - k]; p += nc; }
+                    double tau = sum / A1[k];
+                    p = kk;
+                    for (int i = k; i < nr; i++) { pA[p + j - k] -= tau * pA[p]; p += nc; }
+                }
+            }
+            kk += nc + 1;
+        }
+        int jj = 0;
+        for (int j = 0; j < nc; j++) {
+            int p = jj; double tau = 0;
+            for (int i = j; i < nr; i++) { tau += pA[p] * pb[i]; p += nc; }
+            tau /= A1[j];
+            p = jj;
+            for (int i = j; i < nr; i++) { pb[i] -= tau * pA[p]; p += nc; }
+            jj += nc + 1;
+        }
+        pX[nc - 1] = pb[nc - 1] / A2[nc - 1];
+        for (int i = nc - 2; i >= 0; i--) {
+            int p = i*nc + (i + 1); double sum = 0;
+            for (int j = i + 1; j < nc; j++) { sum += pA[p] * pX[j]; p++; }
+            pX[i] = (pb[i] - sum) / A2[i];
+        }
+    }
+
+    __device__ void gauss_newton(Arr L, Arr rho, Arr betas)
+    {
+        Arr sc = s + EP_SC;
+        Arr A = sc, b = sc + 24, x = sc + 30, A1 = sc + 34, A2 = sc + 38;
+        for (int i = 0; i < 4; i++) x[i] = 0;
+        for (int it = 0; it < 5; it++) {
+            double b0 = betas[0], b1 = betas[1], b2 = betas[2], b3 = betas[3];
+            for (int i = 0; i < 6; i++) {
+                Arr rowL = L + i*10, rowA = A + i*4;
+                rowA[0] = 2*rowL[0]*b0 +   rowL[1]*b1 +   rowL[3]*b2 +   rowL[6]*b3;
+                rowA[1] =   rowL[1]*b0 + 2*rowL[2]*b1 +   rowL[4]*b2 +   rowL[7]*b3;
+                rowA[2] =   rowL[3]*b0 +   rowL[4]*b1 + 2*rowL[5]*b2 +   rowL[8]*b3;
+                rowA[3] =   rowL[6]*b0 +   rowL[7]*b1 +   rowL[8]*b2 + 2*rowL[9]*b3;
+                b[i] = rho[i] -
+                    (rowL[0]*b0*b0 + rowL[1]*b0*b1 + rowL[2]*b1*b1 +
+                     rowL[3]*b0*b2 + rowL[4]*b1*b2 + rowL[5]*b2*b2 +
+                     rowL[6]*b0*b3 + rowL[7]*b1*b3 + rowL[8]*b2*b3 +
+                     rowL[9]*b3*b3);
+            }
+            qr_solve(A, b, x, A1, A2);
+            for (int i = 0; i < 4; i++) betas[i] += x[i];
+        }
+    }
+
+    // compute_ccs + compute_pcs + solve_for_sign + estimate_R_and_t + reprojection_error
+    __device__ double compute_R_and_t(Arr ut, Arr betas, Arr R, Arr t)
+    {
+        Arr ccs = s + EP_CCS, pc0 = s + EP_PC0, pw0 = s + EP_PW0, abt = s + EP_ABT, sc = s + EP_SC;
+        if (P::tid() == 0) {
+            for (int i = 0; i < 12; i++) ccs[i] = 0.0f;
+            for (int i = 0; i < 4; i++) {
+                Arr v = ut + 12*(11 - i);
+                double bi = betas[i];
+                for (int j = 0; j < 4; j++) for (int k = 0; k < 3; k++) ccs[3*j + k] += bi * v[3*j + k];
+            }
+        }
+        P::sync();
+        for (int i = P::tid(); i < n; i += P::nth()) {
+            Arr a = alphas + 4*i, pc = pcs + 3*i;
+            for (int j = 0; j < 3; j++) pc[j] = a[0]*ccs[j] + a[1]*ccs[3 + j] + a[2]*ccs[6 + j] + a[3]*ccs[9 + j];
+        }
+        P::sync();
+        bool flip = pcs[2] < 0.0;
+        P::sync();
+        if (flip) {
+            if (P::tid() == 0) for (int i = 0; i < 12; i++) ccs[i] = -ccs[i];
+            for (int i = P::tid(); i < n; i += P::nth()) { pcs[3*i] = -pcs[3*i]; pcs[3*i+1] = -pcs[3*i+1]; pcs[3*i+2] = -pcs[3*i+2]; }
+            P::sync();
+        }
+        // estimate_R_and_t
+        for (int e = P::tid(); e < 6; e += P::nth()) {
+            int j = e % 3; double acc = 0;
+            if (e < 3) { for (int i = 0; i < n; i++) acc += pcs[3*i + j]; pc0[j] = acc / n; }
+            else       { for (int i = 0; i < n; i++) acc += pws[3*i + j]; pw0[j] = acc / n; }
+        }
+        P::sync();
+        for (int e = P::tid(); e < 9; e += P::nth()) {
+            int j = e / 3, q = e - 3*j;
+            double cj = pc0[j], wq = pw0[q], acc = 0;
+            for (int i = 0; i < n; i++) acc += (pcs[3*i + j] - cj) * (pws[3*i + q] - wq);
+            abt[e] = acc;
+        }
+        P::sync();
+        if (P::tid() == 0) {
+            Arr at = sc, w = sc + 9, vt = sc + 12, wt = sc + 21;
+            svd_square(abt, at, w, vt, wt, 3);
+            // R[i][j] = dot(U row i, V row j) = sum_k U(i,k) V(j,k) = sum_k at[k][i] * vt[k][j]
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+                R[3*i + j] = at[0*3 + i]*vt[0*3 + j] + at[1*3 + i]*vt[1*3 + j] + at[2*3 + i]*vt[2*3 + j];
+            const double det =
+                R[0]*R[4]*R[8] + R[1]*R[5]*R[6] + R[2]*R[3]*R[7] -
+                R[2]*R[4]*R[6] - R[1]*R[3]*R[8] - R[0]*R[5]*R[7];
+            if (det < 0) { R[6] = -R[6]; R[7] = -R[7]; R[8] = -R[8]; }
+            t[0] = pc0[0] - dot3(R, pw0);
+            t[1] = pc0[1] - dot3(R + 3, pw0);
+            t[2] = pc0[2] - dot3(R + 6, pw0);
+        }
+        P::sync();
+        // reprojection_error: per-point terms in parallel, summed in order by one thread
+        for (int i = P::tid(); i < n; i += P::nth()) {
+            Arr pw = pws + 3*i;
+            double Xc = dot3(R, pw) + t[0];
+            double Yc = dot3(R + 3, pw) + t[1];
+            double inv_Zc = 1.0 / (dot3(R + 6, pw) + t[2]);
+            double ue = uc + fu * Xc * inv_Zc;
+            double ve = vc + fv * Yc * inv_Zc;
+            double u = us[2*i], v = us[2*i + 1];
+            tmp[i] = sqrt((u - ue)*(u - ue) + (v - ve)*(v - ve));
+        }
+        P::sync();
+        double sum2 = 0.0;
+        if (P::tid() == 0) { for (int i = 0; i < n; i++) sum2 += tmp[i]; sum2 = sum2 / n; }
+        P::sync();
+        return sum2;     // meaningful on tid 0 only
+    }
+
+    // epnp::compute_pose followed by Rodrigues(R, rvec).  Outputs valid on tid 0.
+    __device__ void compute_pose(double* rvec, double* tvec)
+    {
+        choose_control_points();
+        compute_barycentric_coordinates();
+        build_mtm();
+        Arr mtm = s + EP_MTM, d = s + EP_D, wt = s + EP_WT, L = s + EP_L, rho = s + EP_RHO;
+        Arr betas = s + EP_BETAS, rep = s + EP_REP, Rs = s + EP_RS, ts = s + EP_TS, cws = s + EP_CWS;
+        if (P::tid() == 0) {
+            // cvSVD(MtM, D, Ut, 0, MODIFY_A | U_T): MtM is symmetric so At = MtM^T is MtM itself
+            jacobi_svd_u_only(mtm, 12, d, 12, 12, wt);
+            compute_L_6x10(mtm, L);
+            rho[0] = dist2(cws, cws + 3); rho[1] = dist2(cws, cws + 6); rho[2] = dist2(cws, cws + 9);
+            rho[3] = dist2(cws + 3, cws + 6); rho[4] = dist2(cws + 3, cws + 9); rho[5] = dist2(cws + 6, cws + 9);
+        }
+        P::sync();
+        for (int N = 1; N <= 3; N++) {
+            if (P::tid() == 0) {
+                find_betas(N, L, rho, betas + 4*N);
+                gauss_newton(L, rho, betas + 4*N);
+            }
+            P::sync();
+            double e = compute_R_and_t(mtm, betas + 4*N, Rs + 9*N, ts + 3*N);
+            if (P::tid() == 0) rep[N] = e;
+            P::sync();
+        }
+        if (P::tid() == 0) {
+            int N = 1;
+            if (rep[2] < rep[1]) N = 2;
+            if (rep[3] < rep[N]) N = 3;
+            tvec[0] = ts[3*N]; tvec[1] = ts[3*N + 1]; tvec[2] = ts[3*N + 2];
+            rodrigues_mat2vec(Rs + 9*N, s + EP_SC, rvec);
+        }
+        P::sync();
+    }
+};
+
+}  // namespace uvo

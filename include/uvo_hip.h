@@ -1,0 +1,147 @@
+/*
+ * uvo_hip.h -- C ABI of libuvo_hip.so: the MI355X (gfx950) implementation of UVO's per-frame
+ * feature-match + relative-pose hot path.
+ *
+ * The reference (team-ergo-unipi/ergo_uvo) has no FFI: its boundary is the C++ shared library
+ * `uvo_libraries` (free functions, uvo_libraries/include/uvo_libraries/VO_utility.h:96-117, with
+ * parameters in the mutable globals of VO_utility.h:25-89) plus the direct OpenCV calls in
+ * uvo/include/visual_odometry.h.  Each entry point below names the reference interface it
+ * replaces.  Everything is POD: plain pointers, sizes and status codes; nothing throws across
+ * this boundary (the reference lets cv::Exception kill the process and relies on roslaunch
+ * respawn, uvo/launch/UVO_node.launch:24,38).
+ *
+ * Memory: `mem` says where caller buffers live (UVO_MEM_HOST or UVO_MEM_DEVICE = HIP device
+ * memory of the context's GPU).  Outputs are caller-allocated with a capacity; counts come back
+ * through pointers.  A context is single-caller, owns one HIP stream and all device workspaces
+ * (no per-call allocation); distinct contexts are independent.
+ */
+#ifndef UVO_HIP_H
+#define UVO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct uvo_ctx uvo_ctx;
+
+typedef enum {
+    UVO_OK = 0,
+    UVO_INVALID_ARG = 1,
+    UVO_TOO_FEW_POINTS = 2,
+    UVO_CAPACITY = 3,          /* a caller buffer or the context's max_kpts was too small */
+    UVO_HIP_ERROR = 4,
+    UVO_NO_DEVICE = 5
+} uvo_status;
+
+enum { UVO_MEM_HOST = 0, UVO_MEM_DEVICE = 1 };
+
+/* cv::KeyPoint (28 B), cv::DMatch (16 B), cv::Point2f -- same field order and size */
+typedef struct { float x, y, size, angle, response; int octave, class_id; } uvo_keypoint;
+typedef struct { int queryIdx, trainIdx, imgIdx; float distance; } uvo_dmatch;
+typedef struct { float x, y; } uvo_point2f;
+
+/* The parameter globals of VO_utility.h:25-89 that the hot path reads (key names: SURVEY.md 5.6,
+ * loaded by get_VO_parameters, VO_utility.cpp:461-507). */
+typedef struct uvo_params {
+    int    DISTANCE;                                   /* VOH:47  /vo_params/distance */
+    double LOWE_RATIO_THRESHOLD;                       /* VOH:65 */
+    int    ESSENTIAL_OUTLIER_METHOD;                   /* VOH:52-55 */
+    double ESSENTIAL_MAX_ITERS, ESSENTIAL_CONFIDENCE, ESSENTIAL_THRESHOLD;
+    int    HOMOGRAPHY_OUTLIER_METHOD;                  /* VOH:57-61 */
+    double HOMOGRAPHY_MAX_ITERS, HOMOGRAPHY_CONFIDENCE, HOMOGRAPHY_THRESHOLD, HOMOGRAPHY_DISTANCE;
+    double VPF_THRESHOLD, REPROJECTION_TOLERANCE;      /* VOH:63-64 */
+    int    MIN_NUM_FEATURES, MIN_NUM_3DPOINTS, MIN_NUM_INLIERS;   /* VOH:67-69 */
+    int    ITERATIONS_COUNT;                           /* VOH:72-76 */
+    double REPROJECTION_ERROR_THRESHOLD, CONFIDENCE;
+    int    USE_EXTRINSIC_GUESS, PNP_METHOD_FLAG;
+    int    SURF_MIN_HESSIAN, SURF_OCTAVES_NUMBER, SURF_OCTAVES_LAYERS, SURF_EXTENDED, SURF_UPRIGHT; /* VOH:83-87 */
+} uvo_params;
+
+/* uvo/config/stereo_VO_parameters.yaml / mono_VO_parameters.yaml values */
+void uvo_params_default_stereo(uvo_params* p);
+void uvo_params_default_mono(uvo_params* p);
+
+/* ---- context ---- */
+uvo_status  uvo_ctx_create(const uvo_params* p, int device, int max_w, int max_h, int max_kpts, uvo_ctx** out);
+void        uvo_ctx_destroy(uvo_ctx* c);
+const char* uvo_last_error(const uvo_ctx* c);           /* message of the last non-OK status */
+void*       uvo_ctx_stream(uvo_ctx* c);                 /* the context's hipStream_t */
+uvo_status  uvo_ctx_set_params(uvo_ctx* c, const uvo_params* p);
+
+/* ---- detect_features, SURF branch (VO_utility.h:100 -> VO_utility.cpp:114-119) ----
+ * gray: 8-bit single channel, `stride` bytes per row.  kps/desc (n x 64 f32) are host buffers of
+ * capacity `cap`, either may be NULL.  Overwrites outputs (as detectAndCompute does). */
+uvo_status uvo_surf_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem,
+                           uvo_keypoint* kps, float* desc, int cap, int* n);
+/* test hooks into the detector's first stages (host outputs): integral image (h+1)x(w+1) s32 of the
+ * last image given to uvo_surf_detect / uvo_integral, and one Hessian det/trace layer of it */
+uvo_status uvo_integral(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int32_t* sum);
+uvo_status uvo_hessian_layer(uvo_ctx* c, int octave, int layer, float* det, float* trace);
+
+/* ---- match_features (VO_utility.h:109-110 -> VO_utility.cpp:515-573): BFMatcher(NORM_L2).knnMatch
+ * k=2 + Lowe ratio.  d1: n1 x 64, d2: n2 x 64 (f32, `mem`).  Matches are APPENDED at out[*m]
+ * (the reference's vector is appended to, VO_utility.cpp:538); out is a host buffer. */
+uvo_status uvo_match_knn2_ratio(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int mem,
+                                float ratio, uvo_dmatch* out, int cap, int* m);
+/* raw 2-NN (host outputs idx[2*n1], dist[2*n1]; idx = -1 when the train set is too small) */
+uvo_status uvo_match_knn2(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int mem,
+                          int* idx, float* dist);
+
+/* ---- cv::triangulatePoints as called at visual_odometry.h:355, 631 and VO_utility.cpp:595 ----
+ * P1, P2: 3x4 f64 row-major; x1, x2: n Point2f (host); out: 4 x n f32 (host). */
+uvo_status uvo_triangulate_points(uvo_ctx* c, const double* P1, const double* P2,
+                                  const uvo_point2f* x1, const uvo_point2f* x2, int n, float* out4xn);
+
+/* ---- extract_3Dpoints (VO_utility.h:102 -> VO_utility.cpp:188-237), thresholds from the params ----
+ * pts: g x 3 f64, idx: g s32 (host, capacity n). */
+uvo_status uvo_extract_3d_points(uvo_ctx* c, const uvo_point2f* k1, const uvo_point2f* k2, int n,
+                                 const double* R1, const double* t1, const double* R2, const double* t2,
+                                 const double* K1, const double* K2, const float* points4d,
+                                 double* pts, int* idx, int* g);
+
+/* ---- cv::solvePnPRansac(..., SOLVEPNP_EPNP) as called at visual_odometry.h:647-648 ----
+ * obj: n x 3 f64, img: n Point2f, K 3x3 f64 (host).  inliers: host, capacity n, ascending.
+ * *ok is OpenCV's bool return. */
+uvo_status uvo_solve_pnp_ransac(uvo_ctx* c, const double* obj, const uvo_point2f* img, int n, const double* K,
+                                int iterations_count, float reprojection_error, double confidence,
+                                double* rvec, double* tvec, int* inliers, int* n_inliers, int* ok);
+
+/* cv::Rodrigues (visual_odometry.h:673): n_in = 3 (vector -> 3x3) or 9 (3x3 -> vector) */
+uvo_status uvo_rodrigues(const double* in, int n_in, double* out);
+
+/* ---- stereo loop body, visual_odometry_node::stereo_VO (visual_odometry.h:474-520 init,
+ * 531-739 main loop, 148-159 output) with all intermediates kept on the device ---- */
+typedef struct {
+    int    valid;                 /* successful_estimate.data */
+    int    initialized;           /* 0 for steps consumed by the init loop */
+    int    n_left, n_right, n_stereo_matches, n_tri_matches, n_good3d, n_inliers;
+    double rvec[3], tvec[3];      /* R_currCam_prevCam_Vec, t_currCam_prevCam */
+    double t_prev_curr[3];        /* t_prevCam_currCam (kept from the last valid step on failure) */
+    double velocity[3];           /* t_prevCam_currCam / dt */
+} uvo_stereo_result;
+
+/* new_camera_matrix_left/right, R_right, t_right (visual_odometry.h:447-463) */
+uvo_status uvo_stereo_set_rig(uvo_ctx* c, const double* K_left, const double* K_right,
+                              const double* R_right, const double* t_right);
+uvo_status uvo_stereo_reset(uvo_ctx* c);
+uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
+                           int mem, double dt, uvo_stereo_result* out);
+/* last step's intermediates for parity tests: "kps_left", "kps_right", "desc_left", "desc_right",
+ * "matches_stereo", "matches_tri", "points4d", "good_pts", "good_idx", "inliers".
+ * Returns the element count, or -(count) if cap_bytes is too small. */
+int        uvo_stereo_get(uvo_ctx* c, const char* what, void* out, int cap_bytes);
+
+/* ---- per-stage device timing (HIP events on the context's stream) for bench.py ---- */
+uvo_status uvo_timing_enable(uvo_ctx* c, int on);
+int        uvo_timing_count(uvo_ctx* c);
+const char* uvo_timing_name(uvo_ctx* c, int i);
+/* accumulated milliseconds and number of launches of stage i since the last reset */
+uvo_status uvo_timing_get(uvo_ctx* c, int i, double* ms, long long* launches);
+uvo_status uvo_timing_reset(uvo_ctx* c);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def scene_small():
+    """640x360 stereo sequence (3 pairs), seeded."""
+    from ergo_uvo_amd import synth
+    sc = synth.Scene(123, 640)
+    return [synth.stereo_pair(sc, k, 640, 360) for k in range(3)]

@@ -1,0 +1,207 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+Bit-exact for integers, keypoints, descriptors, match pairs, masks; poses to 1e-4 rel. Frobenius
+(BASELINE.json north_star), in practice bit-equal.  PARITY vs OpenCV itself is UNPINNED (no OpenCV
+in this environment): what is shown is HIP <-> the oracle's restatement."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import ergo_uvo_amd as uvo
+    c = uvo.Context(uvo.Params.stereo(), 0, 1920, 1080, 20000)
+    yield c
+    c.close()
+
+
+def _rand_img(seed, h, w):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (h // 8 + 2, w // 8 + 2)).astype(np.float64)
+    from scipy import ndimage
+    img = ndimage.zoom(base, 8, order=1)[:h, :w] + rng.integers(-6, 7, (h, w))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (97, 131), (360, 640), (1080, 1920)])
+def test_integral_exact(ctx, oracle, shape):
+    img = np.random.default_rng(1).integers(0, 256, shape).astype(np.uint8)
+    got = ctx.integral(img)
+    assert np.array_equal(got, oracle.integral(img))
+    assert got[-1, -1] == int(img.astype(np.int64).sum())
+
+
+@pytest.mark.parametrize("octave,layer", [(0, 0), (0, 4), (1, 2), (2, 1), (3, 0), (3, 4)])
+def test_hessian_layer_bit_exact(ctx, oracle, octave, layer):
+    img = _rand_img(2, 360, 640)
+    s = ctx.integral(img)
+    det, tr = ctx.hessian_layer(img.shape, octave, layer)
+    size = (9 + 6 * layer) << octave
+    odet, otr = oracle.surf_layer(oracle.integral(img), size, 1 << octave)
+    assert np.array_equal(det.view(np.uint32), odet.view(np.uint32))
+    assert np.array_equal(tr.view(np.uint32), otr.view(np.uint32))
+
+
+def _assert_kps_equal(a, b):
+    assert len(a) == len(b)
+    for f in a.dtype.names:
+        av, bv = a[f], b[f]
+        if av.dtype.kind == "f":
+            assert np.array_equal(av.view(np.uint32), bv.view(np.uint32)), f
+        else:
+            assert np.array_equal(av, bv), f
+
+
+@pytest.mark.parametrize("shape,thr", [((120, 160), 50), ((360, 640), 400), ((240, 320), 1500), ((720, 1280), 1500)])
+def test_surf_detect_describe_bit_exact(ctx, oracle, shape, thr):
+    import ergo_uvo_amd as uvo
+    img = _rand_img(3, *shape)
+    ctx.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=thr))
+    kps, desc = ctx.detect_features(img)
+    okps, odesc = oracle.surf(img, thr)
+    assert len(okps) > 20
+    _assert_kps_equal(kps, okps)
+    assert np.array_equal(desc.view(np.uint32), odesc.view(np.uint32))
+
+
+def test_surf_empty_and_tiny(ctx, oracle):
+    import ergo_uvo_amd as uvo
+    ctx.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=100))
+    flat = np.full((64, 64), 77, np.uint8)
+    kps, desc = ctx.detect_features(flat)
+    assert len(kps) == 0 and desc.shape == (0, 64)
+    img = _rand_img(5, 40, 56)          # most layers do not fit
+    kps, desc = ctx.detect_features(img)
+    okps, odesc = oracle.surf(img, 100)
+    _assert_kps_equal(kps, okps)
+    assert np.array_equal(desc.view(np.uint32), odesc.view(np.uint32))
+
+
+def test_match_knn_and_ratio_bit_exact(ctx, oracle, scene_small):
+    L, R = scene_small[0]
+    _, dL = oracle.surf(L, 500)
+    _, dR = oracle.surf(R, 500)
+    idx, dist = ctx.knn_match(dL, dR)
+    oidx, odist = oracle.knn2(dL, dR)
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32))
+    for ratio in (0.7, 0.8):
+        m = ctx.match_features(dL, dR, ratio)
+        om = oracle.match(dL, dR, ratio)
+        assert len(om) > 50
+        assert np.array_equal(m["queryIdx"], om["queryIdx"]) and np.array_equal(m["trainIdx"], om["trainIdx"])
+        assert np.array_equal(m["distance"].view(np.uint32), om["distance"].view(np.uint32))
+
+
+def test_match_ties_and_edges(ctx, oracle):
+    rng = np.random.default_rng(7)
+    d2 = rng.normal(size=(300, 64)).astype(np.float32)
+    d2[17] = d2[5]; d2[200] = d2[5]; d2[250] = d2[100]          # exact duplicates -> distance ties
+    d1 = np.concatenate([d2[[5, 100, 250]], rng.normal(size=(70, 64)).astype(np.float32)])
+    idx, dist = ctx.knn_match(d1, d2)
+    oidx, odist = oracle.knn2(d1, d2)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist.view(np.uint32), odist.view(np.uint32))
+    assert list(idx[0]) == [5, 17]                               # ties keep the lower train index first
+    # train set with a single row: no second neighbour -> no matches (reference would index out of bounds)
+    assert len(ctx.match_features(d1, d2[:1], 0.8)) == 0
+    assert len(ctx.match_features(d1[:0], d2, 0.8)) == 0
+    # append semantics (VOU:538)
+    first = ctx.match_features(d1, d2, 0.9)
+    both = ctx.match_features(d1, d2, 0.9, matches=first)
+    assert len(both) == 2 * len(first) and np.array_equal(both[:len(first)], first)
+
+
+def _synthetic_stereo_points(n, seed, noise=0.3):
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(1280)
+    rng = np.random.default_rng(seed)
+    X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.2, 1.2, n), rng.uniform(2.5, 6, n)], 1)
+    def proj(K, R, t, X):
+        Y = X @ R.T + t
+        return (Y[:, :2] / Y[:, 2:]) * np.array([K[0, 0], K[1, 1]]) + np.array([K[0, 2], K[1, 2]])
+    x1 = proj(rig.K_left, np.eye(3), np.zeros(3), X) + rng.normal(0, noise, (n, 2))
+    x2 = proj(rig.K_right, rig.R_right, rig.t_right, X) + rng.normal(0, noise, (n, 2))
+    P1 = rig.K_left @ np.hstack([np.eye(3), np.zeros((3, 1))])
+    P2 = rig.K_right @ np.hstack([rig.R_right, rig.t_right[:, None]])
+    return rig, X, x1.astype(np.float32), x2.astype(np.float32), P1, P2
+
+
+@pytest.mark.parametrize("n", [1, 7, 500, 3000])
+def test_triangulate_bit_exact(ctx, oracle, n):
+    rig, X, x1, x2, P1, P2 = _synthetic_stereo_points(n, 11)
+    got = ctx.triangulatePoints(P1, P2, x1, x2)
+    want = oracle.triangulate(P1, P2, x1, x2)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    Xh = (got[:3] / got[3]).T
+    assert np.abs(Xh - X).max() < 0.5
+
+
+@pytest.mark.parametrize("n,noise", [(4, 0.2), (6, 0.2), (800, 0.2), (800, 3.0), (2500, 1.0)])
+def test_extract_3dpoints_bit_exact(ctx, oracle, n, noise):
+    rig, X, x1, x2, P1, P2 = _synthetic_stereo_points(n, 13, noise)
+    p4 = oracle.triangulate(P1, P2, x1, x2)
+    p4[:, ::17] *= -1.0 if n > 100 else 1.0          # some points behind the camera / flipped sign
+    args = (x1, x2, np.eye(3), np.zeros(3), rig.R_right, rig.t_right, rig.K_left, rig.K_right, p4)
+    pts, idx = ctx.extract_3Dpoints(*args)
+    opts, oidx = oracle.extract_3d_points(*args, min_pts=5, tol=3.0)
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(pts.view(np.uint64), opts.view(np.uint64))
+
+
+@pytest.mark.parametrize("n,outliers,noise", [(5, 0.0, 0.1), (6, 0.0, 0.1), (300, 0.2, 0.3), (1200, 0.5, 0.5), (900, 0.9, 0.3), (40, 1.0, 0.0)])
+def test_pnp_ransac_parity(ctx, oracle, n, outliers, noise):
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(1920)
+    rng = np.random.default_rng(17 + n)
+    X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.2, 1.2, n), rng.uniform(2.5, 6, n)], 1)
+    Rt, tt = synth.true_relative_motion()
+    Y = X @ Rt.T + tt
+    K = rig.K_left
+    x = (Y[:, :2] / Y[:, 2:]) * np.array([K[0, 0], K[1, 1]]) + np.array([K[0, 2], K[1, 2]]) + rng.normal(0, noise, (n, 2))
+    bad = rng.random(n) < outliers
+    x[bad] = rng.uniform(0, 1000, (int(bad.sum()), 2))
+    x = x.astype(np.float32)
+    ok, rvec, tvec, inl = ctx.solvePnPRansac(X, x, K, 1000, 1.0, 0.99)
+    ook, orvec, otvec, oinl = oracle.solve_pnp_ransac(X, x, K, 1000, 1.0, 0.99)
+    assert ok == ook
+    assert np.array_equal(inl, oinl)                    # bit-exact inlier set
+    def rel(a, b):
+        return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
+    assert rel(rvec, orvec) < 1e-4 and rel(tvec, otvec) < 1e-4
+    assert np.array_equal(rvec.view(np.uint64), orvec.view(np.uint64)), (rvec, orvec)
+    assert np.array_equal(tvec.view(np.uint64), otvec.view(np.uint64))
+    if outliers <= 0.5 and n > 5:
+        assert ok and rel(tvec, tt) < 0.05
+
+
+def test_stereo_sequence_parity(ctx, oracle, scene_small):
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    ctx.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=1500))
+    ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    ovo = oracle.StereoVO(oracle.stereo_params(1500), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    for k, (L, R) in enumerate(scene_small):
+        r = ctx.stereo_step(L, R, 0.05)
+        o = ovo.step(L, R, 0.05)
+        for f in ("valid", "initialized", "n_left", "n_right", "n_stereo_matches", "n_tri_matches", "n_good3d", "n_inliers"):
+            assert getattr(r, f) == getattr(o, f), (k, f, getattr(r, f), getattr(o, f))
+        _assert_kps_equal(ctx.stereo_get("kps_left"), ovo.get("kps_left"))
+        _assert_kps_equal(ctx.stereo_get("kps_right"), ovo.get("kps_right"))
+        assert np.array_equal(ctx.stereo_get("desc_left").view(np.uint32), ovo.get("desc_left").view(np.uint32))
+        ms, oms = ctx.stereo_get("matches_stereo"), ovo.get("matches_stereo")
+        assert np.array_equal(ms["queryIdx"], oms["queryIdx"]) and np.array_equal(ms["trainIdx"], oms["trainIdx"])
+        if k > 0:
+            mt, omt = ctx.stereo_get("matches_tri"), ovo.get("matches_tri")
+            assert np.array_equal(mt["queryIdx"], omt["queryIdx"]) and np.array_equal(mt["trainIdx"], omt["trainIdx"])
+            assert np.array_equal(ctx.stereo_get("points4d").view(np.uint32), ovo.get("points4d").view(np.uint32))
+            assert np.array_equal(ctx.stereo_get("good_idx"), ovo.get("good_idx"))
+            assert np.array_equal(ctx.stereo_get("inliers"), ovo.get("inliers"))
+            assert r.valid == 1
+            for a, b in ((r.rvec, o.rvec), (r.tvec, o.tvec), (r.t_prev_curr, o.t_prev_curr), (r.velocity, o.velocity)):
+                a, b = np.array(list(a)), np.array(list(b))
+                assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)
+                assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+    Rt, tt = synth.true_relative_motion()
+    assert np.linalg.norm(np.array(list(r.tvec)) - tt) < 0.01
