@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo frame-pairs/sec (detect + match + pose) of the HIP hot path.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one iteration body of stereo_VO (visual_odometry.h:531-739, minus get_image / decode /
+publish): 2x SURF detect+describe, L<->R match, prev<->curr match, gathers, triangulation,
+extract_3Dpoints, EPnP PnP-RANSAC + refit, pose inversion, on one synthetic 1920x1080 pair with
+~3000 keypoints per image (BASELINE.json configs[2], "C3"); images are resident in HBM before the
+timed region.  With N ranks every rank runs its own independent stream (configs[4]; weak scaling)
+and the per-step pose records are all-gathered over RCCL at the end of the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
+kernel (hessian_nms octave 0: algorithmic bytes of SURVEY.md 8(d) / HIP-event time measured here)
+and `cpu_baseline` (the CPU oracle, 1 thread, on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT = 1920, 1080
+MIN_HESSIAN_C3 = 6387            # frozen: frame 0 of seed 20250906 gives 3001 / 3008 keypoints
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes_hessian_o0(w: int, h: int, nimg: int) -> int:
+    """SURVEY.md 8(d) B_det restricted to octave 0 (the dominant launch): one read of the integral
+    image (4(W+1)(H+1)) + det and trace written (2*S0) + det read by the NMS (S0), S0 = 5 layers*4 B*H*W."""
+    s0 = 5 * 4 * h * w
+    return nimg * (4 * (w + 1) * (h + 1) + 3 * s0)
+
+
+def algorithmic_bytes_pair(w: int, h: int, n_kp: int) -> float:
+    """SURVEY.md 8(d) B_pair = 2*B_det + 2*B_desc + 2*B_match (descriptor term at its ~7.5 MB midpoint)."""
+    s = sum(5 * 4 * (h >> o) * (w >> o) for o in range(4))
+    b_det = w * h + 4 * (w + 1) * (h + 1) + 4 * 4 * (w + 1) * (h + 1) + 3 * s
+    b_desc = 7.5e6
+    b_match = (n_kp + n_kp) * 256 + n_kp * 16
+    return 2 * b_det + 2 * b_desc + 2 * b_match
+
+
+def ping_pong(n_frames: int):
+    k, d = 0, 1
+    while True:
+        yield k
+        if n_frames == 1:
+            continue
+        if k + d < 0 or k + d >= n_frames:
+            d = -d
+        k += d
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=4, help="distinct synthetic stereo pairs (ping-pong order)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-oracle baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    # ---- synthetic workload (seeded; one independent stream per rank) ----
+    seed = synth.SEEDS["C3"] if world == 1 else synth.SEEDS["C5"] + rank
+    min_hessian = MIN_HESSIAN_C3
+    scene = synth.Scene(seed, WIDTH)
+    host_frames = [synth.stereo_pair(scene, k, WIDTH, HEIGHT) for k in range(args.frames)]
+    dev_frames = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in host_frames]
+    rig = synth.stereo_rig(WIDTH)
+    params = uvo.Params.stereo(SURF_MIN_HESSIAN=min_hessian)
+    ctx = uvo.Context(params, local_rank, WIDTH, HEIGHT, 8192)
+    ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+
+    order = ping_pong(args.frames)
+    records = torch.zeros((max(args.steps, 1), 16), dtype=torch.float64)
+
+    def step():
+        k = next(order)
+        L, R = dev_frames[k]
+        return ctx.stereo_step(L, R, 0.05)
+
+    for _ in range(max(args.warmup, 2)):          # the first step is consumed by the VO init phase
+        r = step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    n_valid = 0
+    kp_sum = 0
+    for i in range(args.steps):
+        r = step()
+        n_valid += r.valid
+        kp_sum += r.n_left
+        records[i, 0] = rank; records[i, 1] = i; records[i, 2] = r.valid; records[i, 3] = r.n_inliers
+        records[i, 4:7] = torch.tensor(list(r.rvec)); records[i, 7:10] = torch.tensor(list(r.tvec))
+        records[i, 10:13] = torch.tensor(list(r.t_prev_curr))
+    if world > 1:                                  # pose records of all streams, one RCCL all-gather
+        mine = records.cuda()
+        allrec = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+        dist.all_gather_into_tensor(allrec, mine)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        assert int(allrec[:, 0, 0].sum().item()) == sum(range(world))
+    total_pairs = args.steps * world
+    value = total_pairs / dt
+
+    out = None
+    if rank == 0:
+        # ---- roofline leg: HIP events on the context's stream around each stage ----
+        ctx.timing_enable(True)
+        ctx.timing_reset()
+        for _ in range(10):
+            step()
+        tm = ctx.timing()
+        ctx.timing_enable(False)
+        ms, n = tm["hessian_nms_o0"]
+        avg_ms = ms / max(n, 1)
+        alg_bytes = algorithmic_bytes_hessian_o0(WIDTH, HEIGHT, 2)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_hessian_o0.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        stage_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in tm.items() if v[1]}
+        stage_calls = {k: v[1] // 10 for k, v in tm.items() if v[1]}
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import pyoracle as po
+            ovo = po.StereoVO(po.stereo_params(min_hessian), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+            o_order = ping_pong(args.frames)
+            k = next(o_order)
+            ovo.step(*host_frames[k], 0.05)                    # init pair, untimed
+            n_cpu, t_cpu = 0, 0.0
+            while t_cpu < args.cpu_seconds and n_cpu < 12:
+                k = next(o_order)
+                a = time.perf_counter()
+                ores = ovo.step(*host_frames[k], 0.05)
+                t_cpu += time.perf_counter() - a
+                n_cpu += 1
+            cpu = {"value": round(n_cpu / t_cpu, 4), "unit": "pairs/s", "cores": 1, "kind": "port",
+                   "sample": f"{n_cpu} consecutive pairs of the same 1920x1080 sequence through oracle/ (C restatement, "
+                             f"gcc -O2, 1 thread; not OpenCV)"}
+
+        out = {
+            "metric": "stereo frame-pairs/sec (detect+match+pose) @1920x1080, 3k kpts",
+            "value": round(value, 3), "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32+f64", "data": "synthetic",
+            "config": {"workload": "C3: stereo UVO synthetic 1920x1080 pair, ~3000 SURF kpts/image, EPnP PnP-RANSAC"
+                                   if world == 1 else "C5: one independent 1920x1080 stereo stream per GPU",
+                       "min_hessian": min_hessian, "kpts_per_image": round(kp_sum / max(args.steps, 1), 1),
+                       "valid_steps": n_valid, "frames": args.frames, "parallelism": f"streams{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_hessian_nms<octave 0> (2 images per launch)",
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5)},
+            "pair_hbm_frac": round(algorithmic_bytes_pair(WIDTH, HEIGHT, 3000) * value / world / 1e9 / HBM_PEAK_GBS, 5),
+            "stage_ms": stage_ms, "stage_launches_per_step": stage_calls,
+            "cpu_baseline": cpu,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -545,8 +545,8 @@ uvo_status surf_detect(Ctx* c, int nimg)
     UVO_HIP_TRY(c, hipMemsetAsync(c->d_cand_n, 0, sizeof(int) * 2, c->stream));
     const float thr = (float)c->p.SURF_MIN_HESSIAN;
     {
-        StageTimer t(c, ST_HESSIAN);
         for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER; o++) {
+            StageTimer t(c, ST_HESSIAN_O0 + o);
             OctavePat op;
             make_octave(o, c->p.SURF_OCTAVES_LAYERS, w, h, &op);
             hipError_t e;

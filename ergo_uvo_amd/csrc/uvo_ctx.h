@@ -21,11 +21,11 @@ namespace uvo {
     do { uvo_status _s = (expr); if (_s != UVO_OK) return _s; } while (0)
 
 enum Stage {
-    ST_INTEGRAL = 0, ST_HESSIAN, ST_SORT, ST_DESCRIPTOR, ST_MATCH, ST_MATCH_MERGE, ST_GATHER,
+    ST_INTEGRAL = 0, ST_HESSIAN_O0, ST_HESSIAN_O1, ST_HESSIAN_O2, ST_HESSIAN_O3, ST_SORT, ST_DESCRIPTOR, ST_MATCH, ST_MATCH_MERGE, ST_GATHER,
     ST_TRIANGULATE, ST_EXTRACT3D, ST_PNP_HYP, ST_PNP_SCORE, ST_PNP_REFIT, ST_COUNT
 };
 static const char* const kStageNames[ST_COUNT] = {
-    "integral", "hessian_nms", "kp_sort", "descriptor64", "match_top2", "match_merge", "gather",
+    "integral", "hessian_nms_o0", "hessian_nms_o1", "hessian_nms_o2", "hessian_nms_o3", "kp_sort", "descriptor64", "match_top2", "match_merge", "gather",
     "triangulate", "extract3d", "pnp_epnp5", "pnp_score", "pnp_refit"
 };
 
