@@ -76,13 +76,13 @@ extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w,
         A(dalloc(&c->d_as_kpsL[i], cap)); A(dalloc(&c->d_as_kpsR[i], cap)); A(dalloc(&c->d_as_descL[i], cap * 64));
     }
     A(dalloc(&c->d_colpart, (size_t)2 * nseg * (max_w + 1)));
-    A(dalloc(&c->d_DW, 400));
+    A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_list, cap * 2));
     A(dalloc(&c->d_mpart, nchunks * cap)); A(dalloc(&c->d_knn_idx, cap * 2)); A(dalloc(&c->d_knn_dist, cap * 2));
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
     A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_good_pts, cap * 3)); A(dalloc(&c->d_good_idx, cap));
     A(dalloc(&c->d_opts, cap * 3)); A(dalloc(&c->d_ipts, cap)); A(dalloc(&c->d_counts, (size_t)CN_TOTAL));
     A(dalloc(&c->d_subsets, (size_t)kMaxHyp * 5)); A(dalloc(&c->d_models, (size_t)kMaxHyp * 6)); A(dalloc(&c->d_hcount, (size_t)kMaxHyp));
-    A(dalloc(&c->d_inliers, cap)); A(dalloc(&c->d_refit, cap * 37)); A(dalloc(&c->d_pose, (size_t)6));
+    A(dalloc(&c->d_inliers, cap)); A(dalloc(&c->d_refit, cap * 45)); A(dalloc(&c->d_pose, (size_t)6));
     A(hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), sizeof(int) * CN_TOTAL));
     A(hipHostMalloc(reinterpret_cast<void**>(&c->h_subsets), sizeof(int) * kMaxHyp * 5));
     A(hipHostMalloc(reinterpret_cast<void**>(&c->h_hcount), sizeof(int) * kMaxHyp));
@@ -93,8 +93,10 @@ extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w,
     c->det[0].n = c->d_counts + CN_NL; c->det[1].n = c->d_counts + CN_NR;
     c->d_nmatch = c->d_counts + CN_M;
     c->d_as_n = c->d_counts + CN_AS0;
+    c->d_big_n = c->d_counts + 14;
     make_desc_weights(c->h_DW);
     if (hipMemcpy(c->d_DW, c->h_DW, sizeof(float) * 400, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(c->d_rank, 0, sizeof(int) * cap * 2) != hipSuccess ||
         hipMemset(c->d_counts, 0, sizeof(int) * CN_TOTAL) != hipSuccess) { uvo_ctx_destroy(c); return UVO_HIP_ERROR; }
     *out = c;
     return UVO_OK;
@@ -110,7 +112,7 @@ extern "C" void uvo_ctx_destroy(uvo_ctx* c)
         (void)hipFree(c->det[i].desc); (void)hipFree(c->d_tmp_desc[i]); (void)hipFree(c->d_matches[i]);
         (void)hipFree(c->d_as_kpsL[i]); (void)hipFree(c->d_as_kpsR[i]); (void)hipFree(c->d_as_descL[i]);
     }
-    void* ptrs[] = { c->d_colpart, c->d_DW, c->d_mpart, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
+    void* ptrs[] = { c->d_colpart, c->d_DW, c->d_rank, c->d_big_list, c->d_mpart, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
                      c->d_flag, c->d_good_pts, c->d_good_idx, c->d_opts, c->d_ipts, c->d_counts, c->d_subsets, c->d_models,
                      c->d_hcount, c->d_inliers, c->d_refit, c->d_pose };
     for (void* p : ptrs) (void)hipFree(p);

@@ -14,6 +14,7 @@
 #include "uvo_ctx.h"
 #include "uvo_epnp.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace uvo {
 
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(kTriThreads) void k_triangulate(Mat34 P1, Mat34 P2,
         Am[2*4 + k] = xb * P2.v[2*4 + k] - P2.v[0*4 + k];
         Am[3*4 + k] = yb * P2.v[2*4 + k] - P2.v[1*4 + k];
     }
-    svd_square(Am, At, W, Vt, Wt, 4);
+    svd_square<4>(Am, At, W, Vt, Wt);
     out[i] = make_float4((float)Vt[12], (float)Vt[13], (float)Vt[14], (float)Vt[15]);
 }
 
@@ -123,13 +124,32 @@ __global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const 
         if (tid == 0) counts[1] = 0;
         return;
     }
-    if (tid == 0) {                                          // MU:35-56, sequential sums
+    {   // MU:35-56: sum and sum of squares in index order; z values are staged through LDS in chunks
+        __shared__ double zbuf[2048];
         double sum = 0.0, sumsq = 0.0;
-        for (int i = 0; i < ngood; i++) { double z = cam1[3 * tmp_idx[i] + 2]; sum += z; sumsq += z * z; }
-        double mean = sum / ngood;
-        double variance = (sumsq / ngood) - (mean * mean);
-        s_mean = mean; s_sd3 = 3.0 * sqrt(variance);
-        s_base = 0;
+        for (int base = 0; base < ngood; base += 2048) {
+            const int cnt = min(2048, ngood - base);
+            for (int i = tid; i < cnt; i += 1024) zbuf[i] = cam1[3 * tmp_idx[base + i] + 2];
+            __syncthreads();
+            if (tid == 0) {
+                int i = 0;
+                for (; i + 8 <= cnt; i += 8) {
+                    double z[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) z[q] = zbuf[i + q];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { sum += z[q]; sumsq += z[q] * z[q]; }
+                }
+                for (; i < cnt; i++) { double z = zbuf[i]; sum += z; sumsq += z * z; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            double mean = sum / ngood;
+            double variance = (sumsq / ngood) - (mean * mean);
+            s_mean = mean; s_sd3 = 3.0 * sqrt(variance);
+            s_base = 0;
+        }
     }
     __syncthreads();
     const double mean = s_mean, sd3 = s_sd3;
@@ -151,35 +171,39 @@ __global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const 
 }
 
 // ---------------------------------------------------------------- PnP RANSAC
-static const int kHypThreads = 32;       // hypotheses per workgroup; LDS = 32 * (EPNP_SMALL + 65) doubles
-static const int kHypPerThread = EPNP_SMALL + 15 + 10 + 20 + 15 + 5;
+static const int kHypGroups = 8;         // hypotheses per workgroup (one wave): 8 lanes cooperate on each
+static const int kHypPerGroup = EPNP_SMALL + 15 + 10 + 20 + 45 + 15;   // doubles of LDS per hypothesis
 
-__global__ __launch_bounds__(kHypThreads) void k_pnp_hyp(const float* opts, const uvo_point2f* ipts, const int* subsets, int nhyp,
-                                                         double fx, double fy, double cx, double cy, double* models)
+__global__ __launch_bounds__(64) void k_pnp_hyp(const float* opts, const uvo_point2f* ipts, const int* subsets, int nhyp,
+                                                double fx, double fy, double cx, double cy, double* models)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     double* lds = reinterpret_cast<double*>(smem);
-    const int hyp = blockIdx.x * kHypThreads + threadIdx.x;
-    if (hyp >= nhyp) return;
-    using P = ThreadPolicy<kHypThreads>;
+    const int group = threadIdx.x >> 3, lane = threadIdx.x & 7;
+    const int hyp_raw = blockIdx.x * kHypGroups + group;
+    const int hyp = hyp_raw < nhyp ? hyp_raw : nhyp - 1;      // surplus groups redo the last one (they must reach every barrier)
+    using P = GroupPolicy<kHypGroups>;
     using A = P::Arr;
-    A base{lds + threadIdx.x};
+    A base{lds + group};
     Epnp<P> e;
     e.uc = cx; e.vc = cy; e.fu = fx; e.fv = fy; e.n = 5;
-    e.s = base; e.pws = base + EPNP_SMALL; e.us = e.pws + 15; e.alphas = e.us + 10; e.pcs = e.alphas + 20; e.tmp = e.pcs + 15;
+    e.s = base; e.pws = base + EPNP_SMALL; e.us = e.pws + 15; e.alphas = e.us + 10; e.pcs = e.alphas + 20; e.tmp = e.pcs + 45;
     e.M = e.tmp;    // unused (kStoreM = false)
     const double ifx = 1. / fx, ify = 1. / fy;
-    for (int i = 0; i < 5; i++) {
-        int id = subsets[hyp * 5 + i];
+    if (lane < 5) {
+        const int i = lane, id = subsets[hyp * 5 + i];
         e.pws[3*i] = opts[3*id]; e.pws[3*i + 1] = opts[3*id + 1]; e.pws[3*i + 2] = opts[3*id + 2];
         // undistortPoints with zero distortion, stored CV_32FC2, then epnp::init_points
         double x = (double)(float)((ipts[id].x - cx) * ifx), y = (double)(float)((ipts[id].y - cy) * ify);
         e.us[2*i] = x * fx + cx; e.us[2*i + 1] = y * fy + cy;
     }
+    __syncthreads();
     double rvec[3], tvec[3];
     e.compute_pose(rvec, tvec);
-    double* m = models + (size_t)hyp * 6;
-    m[0] = rvec[0]; m[1] = rvec[1]; m[2] = rvec[2]; m[3] = tvec[0]; m[4] = tvec[1]; m[5] = tvec[2];
+    if (lane == 0 && hyp_raw < nhyp) {
+        double* m = models + (size_t)hyp * 6;
+        m[0] = rvec[0]; m[1] = rvec[1]; m[2] = rvec[2]; m[3] = tvec[0]; m[4] = tvec[1]; m[5] = tvec[2];
+    }
 }
 
 // PnPRansacCallback::computeError + findInliers for one model: projectPoints (double, stored float),
@@ -248,7 +272,7 @@ __global__ __launch_bounds__(1024) void k_pnp_mask(const float* opts, const uvo_
     if (tid == 0) counts[2] = s_base;
 }
 
-// inlier refit: one workgroup, block-cooperative EPnP.  ws: pws 3n | us 2n | alphas 4n | pcs 3n | tmp n | M 24n
+// inlier refit: one workgroup, block-cooperative EPnP.  ws: pws 3c | us 2c | alphas 4c | pcs 9c | tmp 3c | M 24c (c = cap)
 __global__ __launch_bounds__(256) void k_pnp_refit(double* ws, int cap, const int* n_p, double fx, double fy, double cx, double cy, double* pose)
 {
     __shared__ double small[EPNP_SMALL];
@@ -258,7 +282,7 @@ __global__ __launch_bounds__(256) void k_pnp_refit(double* ws, int cap, const in
     e.uc = cx; e.vc = cy; e.fu = fx; e.fv = fy; e.n = n;
     e.s = P::Arr{small};
     e.pws = P::Arr{ws}; e.us = P::Arr{ws + 3 * (size_t)cap}; e.alphas = P::Arr{ws + 5 * (size_t)cap};
-    e.pcs = P::Arr{ws + 9 * (size_t)cap}; e.tmp = P::Arr{ws + 12 * (size_t)cap}; e.M = P::Arr{ws + 13 * (size_t)cap};
+    e.pcs = P::Arr{ws + 9 * (size_t)cap}; e.tmp = P::Arr{ws + 18 * (size_t)cap}; e.M = P::Arr{ws + 21 * (size_t)cap};
     double rvec[3], tvec[3];
     e.compute_pose(rvec, tvec);
     if (threadIdx.x == 0) { pose[0] = rvec[0]; pose[1] = rvec[1]; pose[2] = rvec[2]; pose[3] = tvec[0]; pose[4] = tvec[1]; pose[5] = tvec[2]; }
@@ -310,7 +334,7 @@ uvo_status pose_pnp_ransac(Ctx* c, int G, const double* K, int iterationsCount, 
     if (G < 4) { c->err = "solvePnPRansac needs at least 4 points (OpenCV asserts)"; return UVO_TOO_FEW_POINTS; }
     if (G == 4) { c->err = "solvePnPRansac with exactly 4 points takes OpenCV's P3P path, which the reference never reaches; not implemented"; return UVO_TOO_FEW_POINTS; }
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-    const size_t hyp_lds = sizeof(double) * kHypThreads * kHypPerThread;
+    const size_t hyp_lds = sizeof(double) * kHypGroups * kHypPerGroup;
     static bool attr_set = false;
     if (!attr_set) {
         UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_hyp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds));
@@ -343,7 +367,7 @@ uvo_status pose_pnp_ransac(Ctx* c, int G, const double* K, int iterationsCount, 
     UVO_HIP_TRY(c, hipMemcpyAsync(c->d_subsets, c->h_subsets, sizeof(int) * 5 * nhyp, hipMemcpyHostToDevice, c->stream));
     {
         StageTimer t(c, ST_PNP_HYP);
-        hipLaunchKernelGGL(k_pnp_hyp, dim3((nhyp + kHypThreads - 1) / kHypThreads), dim3(kHypThreads), hyp_lds, c->stream,
+        hipLaunchKernelGGL(k_pnp_hyp, dim3((nhyp + kHypGroups - 1) / kHypGroups), dim3(64), hyp_lds, c->stream,
                            c->d_opts, c->d_ipts, c->d_subsets, nhyp, fx, fy, cx, cy, c->d_models);
         UVO_HIP_TRY(c, hipGetLastError());
     }

@@ -312,52 +312,71 @@ __global__ void k_hessian_layer_debug(const int32_t* gsum, int w, int h, LayerPa
 }
 
 // ------------------------------------------------------------------------------------------
-// deterministic ordering: rank = number of keypoints that sort before this one (KeypointGreater)
+// deterministic ordering: rank = number of keypoints that sort before this one under OpenCV's
+// KeypointGreater (response desc, size desc, octave desc, y desc, x asc).  The five fields are
+// packed into order-preserving integer keys so a comparison is three 64-bit compares; ranks are
+// accumulated over (i-block, j-chunk) tiles with integer atomics (order-independent), then the
+// records are scattered to their rank.  Atomic-append order never reaches the output.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool kp_greater(const uvo_keypoint& a, const uvo_keypoint& b)
+__device__ __forceinline__ uint32_t ord_f32(float f)
 {
-    if (a.response > b.response) return true;
-    if (a.response < b.response) return false;
-    if (a.size > b.size) return true;
-    if (a.size < b.size) return false;
-    if (a.octave > b.octave) return true;
-    if (a.octave < b.octave) return false;
-    if (a.y < b.y) return false;
-    if (a.y > b.y) return true;
-    return a.x < b.x;
+    uint32_t b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+struct SortKey { unsigned long long k1, k2, k3; };
+__device__ __forceinline__ SortKey make_sort_key(const uvo_keypoint& kp)
+{
+    SortKey k;
+    k.k1 = ((unsigned long long)ord_f32(kp.response) << 32) | ord_f32(kp.size);
+    k.k2 = ((unsigned long long)(uint32_t)kp.octave << 32) | ord_f32(kp.y);
+    k.k3 = ((unsigned long long)(~ord_f32(kp.x)) << 32) | (uint32_t)(1 - kp.class_id);
+    return k;
 }
 
-struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* out[2]; int* out_n[2]; int cap; };
+struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* out[2]; int* out_n[2]; int* rank; int cap;
+                  int* big_list; int* big_n; };
+static const int kSmallWin = 128;       // descriptor windows up to this size use the small-LDS kernel
+static const int kSortChunk = 512;
 
-__global__ __launch_bounds__(256) void k_rank_sort(SortArgs a)
+__global__ __launch_bounds__(256) void k_rank_partial(SortArgs a)
 {
-    const int im = blockIdx.y, tid = threadIdx.x;
+    const int im = blockIdx.z, tid = threadIdx.x;
     const int n = min(a.cand_n[im], a.cap);
-    const int me = blockIdx.x * 256 + tid;
-    if (blockIdx.x * 256 >= n && !(blockIdx.x == 0)) return;
-    __shared__ uvo_keypoint tile[256];
-    uvo_keypoint mine;
-    if (me < n) mine = a.cand[im][me];
+    const int i0 = blockIdx.x * 256, j0 = blockIdx.y * kSortChunk;
+    if (i0 >= n || j0 >= n) return;
+    __shared__ SortKey tile[kSortChunk];
+    const int cnt = min(kSortChunk, n - j0);
+    for (int t = tid; t < cnt; t += 256) tile[t] = make_sort_key(a.cand[im][j0 + t]);
+    __syncthreads();
+    const int me = i0 + tid;
+    if (me >= n) return;
+    const SortKey mine = make_sort_key(a.cand[im][me]);
     int rank = 0;
-    for (int base = 0; base < n; base += 256) {
-        if (base + tid < n) tile[tid] = a.cand[im][base + tid];
-        __syncthreads();
-        if (me < n) {
-            int cnt = min(256, n - base);
-            for (int k = 0; k < cnt; k++) {
-                const uvo_keypoint& o = tile[k];
-                bool before = kp_greater(o, mine);
-                if (!before && !kp_greater(mine, o)) {        // identical sort key: class_id, then slot
-                    int oi = base + k;
-                    before = o.class_id < mine.class_id || (o.class_id == mine.class_id && oi < me);
-                }
-                rank += before ? 1 : 0;
-            }
-        }
-        __syncthreads();
+    for (int k = 0; k < cnt; k++) {
+        const SortKey o = tile[k];
+        bool before = o.k1 > mine.k1 ||
+                      (o.k1 == mine.k1 && (o.k2 > mine.k2 ||
+                                           (o.k2 == mine.k2 && (o.k3 > mine.k3 || (o.k3 == mine.k3 && j0 + k < me)))));
+        rank += before ? 1 : 0;
     }
-    if (me < n) a.out[im][rank] = mine;
-    if (blockIdx.x == 0 && tid == 0) *a.out_n[im] = n;
+    atomicAdd(&a.rank[im * a.cap + me], rank);
+}
+
+__global__ __launch_bounds__(256) void k_rank_scatter(SortArgs a)
+{
+    const int im = blockIdx.y;
+    const int n = min(a.cand_n[im], a.cap);
+    const int me = blockIdx.x * 256 + threadIdx.x;
+    if (me < n) {
+        int r = a.rank[im * a.cap + me];
+        a.rank[im * a.cap + me] = 0;                 // ready for the next frame
+        const uvo_keypoint kp = a.cand[im][me];
+        a.out[im][r] = kp;
+        // keypoints whose descriptor window exceeds kSmallWin go to the large-LDS descriptor launch
+        const float sc = kp.size * 1.2f / 9.0f;
+        if ((int)((20 + 1) * sc) > kSmallWin) { int e = atomicAdd(&a.big_n[im], 1); a.big_list[im * a.cap + e] = r; }
+    }
+    if (me == 0) *a.out_n[im] = n;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -387,66 +406,90 @@ __device__ __forceinline__ AreaTab area_tab(int dx, int ssize, double scale)
 
 __device__ __forceinline__ uint8_t sat_u8(float v) { int iv = cv_round_f(v); return (uint8_t)(iv < 0 ? 0 : iv > 255 ? 255 : iv); }
 
-struct DescArgs { const uint8_t* img[2]; uvo_keypoint* kps[2]; float* desc[2]; const int* n[2]; const float* DW; };
+struct DescArgs { const uint8_t* img[2]; uvo_keypoint* kps[2]; float* desc[2]; const int* n[2]; const float* DW;
+                  const int* big_list; const int* big_n; int cap; };
 
-__global__ __launch_bounds__(256) void k_descriptor64(DescArgs a, int w, int h)
+// One workgroup per keypoint.  PATCH = cv::resize(WIN, 21x21, INTER_AREA) with
+// WIN[i][j] = img(clamp(start_y - j), clamp(start_x + i)) is evaluated separably, exactly as
+// resizeArea_ does: buf[i][dx] = sum_j WIN[i][j]*alpha_j (lanes run along i = image x, coalesced),
+// then PATCH[dy][dx] = sum_i beta_i*buf[i][dx].  BIG selects the LDS budget: windows up to 128
+// samples (most keypoints) need 10.5 KB, the rare large ones up to 739 need 62 KB; each launch
+// skips the keypoints of the other class.
+template <bool BIG>
+__device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int h, int k, int im)
 {
-    const int k = blockIdx.x, im = blockIdx.y, tid = threadIdx.x;
-    if (k >= *a.n[im]) return;
+    const int tid = threadIdx.x;
+    const uvo_keypoint kp = a.kps[im][k];
+    const float size = kp.size;
+    const float s = size * 1.2f / 9.0f;
+    const int win_size = (int)((20 + 1) * s);
+    if ((win_size > kSmallWin) != BIG) return;
+    extern __shared__ __align__(16) unsigned char smem_desc[];
+    float* buf = reinterpret_cast<float*>(smem_desc);                 // [21][win_size]
+    __shared__ AreaTab tab[21];
     __shared__ int PATCH[21][21];
     __shared__ float DX[20][20], DY[20][20];
     __shared__ float vec[64];
     __shared__ float s_scale;
     const uint8_t* __restrict__ img = a.img[im];
-    const uvo_keypoint kp = a.kps[im][k];
-    const float size = kp.size;
-    const float s = size * 1.2f / 9.0f;
-    const int win_size = (int)((20 + 1) * s);
     const float win_offset = -(float)(win_size - 1) / 2;
     const int start_x = cv_round_f(kp.x + win_offset);
     const int start_y = cv_round_f(kp.y - win_offset);
-    // WIN[i][j] = img(clamp(start_y - j), clamp(start_x + i)); PATCH = resize(WIN, 21x21, INTER_AREA)
     const double inv_scale = (double)21 / win_size;
     const double scale = 1. / inv_scale;
     const int iscale = cv_round_d(scale);
     const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
 
-    for (int o = tid; o < 441; o += 256) {
-        int dy = o / 21, dx = o - dy * 21;
-        int result;
-        if (area_fast) {
+    if (area_fast) {
+        // resizeAreaFast_: integer block sums; 2x2 -> (sum+2)>>2, else saturate(sum * (1.f/area))
+        for (int o = tid; o < 441; o += 256) {
+            int dy = o / 21, dx = o - dy * 21;
             int sum = 0;
-            for (int sy = 0; sy < iscale; sy++) {
-                int x = start_x + dy * iscale + sy; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
-                for (int sx = 0; sx < iscale; sx++) {
-                    int y = start_y - (dx * iscale + sx); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+            for (int sx = 0; sx < iscale; sx++) {
+                int y = start_y - (dx * iscale + sx); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                for (int sy = 0; sy < iscale; sy++) {
+                    int x = start_x + dy * iscale + sy; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
                     sum += img[(size_t)y * w + x];
                 }
             }
+            int result;
             if (iscale == 2) result = (sum + 2) >> 2;
             else { float sc = 1.f / (iscale * iscale); result = sat_u8(sum * sc); }
-        } else {
-            AreaTab ty = area_tab(dy, win_size, scale);
-            AreaTab tx = area_tab(dx, win_size, scale);
-            float sum = 0.f;
-            const int r_begin = ty.has_first ? ty.sx1 - 1 : ty.sx1;
-            const int r_end = ty.has_last ? ty.sx2 + 1 : ty.sx2;          // exclusive
+            PATCH[dy][dx] = result;
+        }
+    } else {
+        if (tid < 21) tab[tid] = area_tab(tid, win_size, scale);
+        __syncthreads();
+        // horizontal pass of resizeArea_ (over WIN columns j = image rows), lanes along WIN rows i = image x
+        for (int it = tid; it < 21 * win_size; it += 256) {
+            int dx = it / win_size, i = it - dx * win_size;
+            const AreaTab tx = tab[dx];
             const int c_begin = tx.has_first ? tx.sx1 - 1 : tx.sx1;
             const int c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
+            int x = start_x + i; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
+            float b = 0.f;
+            for (int cc = c_begin; cc < c_end; cc++) {
+                float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
+                int y = start_y - cc; y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                b += img[(size_t)y * w + x] * alpha;
+            }
+            buf[it] = b;
+        }
+        __syncthreads();
+        // vertical pass (over WIN rows i)
+        for (int o = tid; o < 441; o += 256) {
+            int dy = o / 21, dx = o - dy * 21;
+            const AreaTab ty = tab[dy];
+            const int r_begin = ty.has_first ? ty.sx1 - 1 : ty.sx1;
+            const int r_end = ty.has_last ? ty.sx2 + 1 : ty.sx2;
+            const float* col = buf + dx * win_size;
+            float sum = 0.f;
             for (int r = r_begin; r < r_end; r++) {
                 float beta = r < ty.sx1 ? ty.a_first : (r < ty.sx2 ? ty.a_mid : ty.a_last);
-                int x = start_x + r; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
-                float buf = 0.f;
-                for (int cc = c_begin; cc < c_end; cc++) {
-                    float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
-                    int y = start_y - cc; y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
-                    buf += img[(size_t)y * w + x] * alpha;
-                }
-                sum += beta * buf;
+                sum += beta * col[r];
             }
-            result = sat_u8(sum);
+            PATCH[dy][dx] = sat_u8(sum);
         }
-        PATCH[dy][dx] = result;
     }
     __syncthreads();
     for (int o = tid; o < 400; o += 256) {
@@ -475,6 +518,24 @@ __global__ __launch_bounds__(256) void k_descriptor64(DescArgs a, int w, int h)
     }
     __syncthreads();
     if (tid < 64) a.desc[im][(size_t)k * 64 + tid] = vec[tid] * s_scale;
+}
+
+// small windows: one workgroup per keypoint
+__global__ __launch_bounds__(256) void k_descriptor64_small(DescArgs a, int w, int h)
+{
+    const int k = blockIdx.x, im = blockIdx.y;
+    if (k >= *a.n[im]) return;
+    describe_keypoint<false>(a, w, h, k, im);
+}
+// large windows (62 KB of LDS each): a fixed grid walks the list built by k_rank_scatter
+__global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int h)
+{
+    const int im = blockIdx.y;
+    const int nb = a.big_n[im];
+    for (int e = blockIdx.x; e < nb; e += gridDim.x) {
+        describe_keypoint<true>(a, w, h, a.big_list[im * a.cap + e], im);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -543,6 +604,7 @@ uvo_status surf_detect(Ctx* c, int nimg)
     }
     UVO_TRY(surf_integral(c, nimg));
     UVO_HIP_TRY(c, hipMemsetAsync(c->d_cand_n, 0, sizeof(int) * 2, c->stream));
+    UVO_HIP_TRY(c, hipMemsetAsync(c->d_big_n, 0, sizeof(int) * 2, c->stream));
     const float thr = (float)c->p.SURF_MIN_HESSIAN;
     {
         for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER; o++) {
@@ -560,15 +622,25 @@ uvo_status surf_detect(Ctx* c, int nimg)
     {
         StageTimer t(c, ST_SORT);
         SortArgs sa = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, { c->det[0].kps, c->det[1].kps },
-                        { c->det[0].n, c->det[1].n }, c->cap };
-        hipLaunchKernelGGL(k_rank_sort, dim3((c->cap + 255) / 256, nimg), dim3(256), 0, c->stream, sa);
+                        { c->det[0].n, c->det[1].n }, c->d_rank, c->cap, c->d_big_list, c->d_big_n };
+        dim3 g((c->cap + 255) / 256, (c->cap + kSortChunk - 1) / kSortChunk, nimg);
+        hipLaunchKernelGGL(k_rank_partial, g, dim3(256), 0, c->stream, sa);
+        hipLaunchKernelGGL(k_rank_scatter, dim3((c->cap + 255) / 256, nimg), dim3(256), 0, c->stream, sa);
         UVO_HIP_TRY(c, hipGetLastError());
     }
     {
         StageTimer t(c, ST_DESCRIPTOR);
         DescArgs da = { { c->d_img[0], c->d_img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
-                        { c->det[0].n, c->det[1].n }, c->d_DW };
-        hipLaunchKernelGGL(k_descriptor64, dim3(c->cap, nimg), dim3(256), 0, c->stream, da, w, h);
+                        { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_list, c->d_big_n, c->cap };
+        const size_t lds_small = sizeof(float) * 21 * 128, lds_big = sizeof(float) * 21 * 740;
+        static bool attr_set = false;
+        if (!attr_set) {
+            UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_descriptor64_big),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_descriptor64_big, dim3(256, nimg), dim3(256), lds_big, c->stream, da, w, h);
+        hipLaunchKernelGGL(k_descriptor64_small, dim3(c->cap, nimg), dim3(256), lds_small, c->stream, da, w, h);
         UVO_HIP_TRY(c, hipGetLastError());
     }
     return UVO_OK;

@@ -50,6 +50,8 @@ struct Ctx {
     int32_t* d_colpart = nullptr;                // [2][nseg][max_w+1]
     uvo_keypoint* d_cand[2] = {nullptr, nullptr};// unsorted candidates
     int* d_cand_n = nullptr;                     // [2] raw atomic counters
+    int* d_big_list = nullptr; int* d_big_n = nullptr;   // [2][cap] sorted indices of large-window keypoints, [2] counts
+    int* d_rank = nullptr;                       // [2][cap] sort ranks (zero between frames)
     DetectSet det[2];                            // current left/right
     int img_w = 0, img_h = 0;
     float h_DW[400];                             // descriptor Gaussian weights (host copy)

@@ -2,23 +2,28 @@
 // operation order of OpenCV 4.5 calib3d (epnp.cpp compute_pose and helpers, calibration.cpp
 // cvRodrigues2), as reached by cv::solvePnPRansac(flags = SOLVEPNP_EPNP) at
 // visual_odometry.h:647-648.  One source, two execution policies:
-//   ThreadPolicy<S>: one 5-point hypothesis per thread, all arrays in LDS interleaved by lane.
-//   BlockPolicy    : one n-point refit per workgroup; O(n) loops are spread over the threads,
-//                    every floating-point SUM keeps the reference's sequential order (one thread
-//                    per independent accumulator), so results are identical to the serial form.
+//   GroupPolicy<G>: G 5-point hypotheses per wave, 8 lanes each, arrays in LDS interleaved by group.
+//   BlockPolicy   : one n-point refit per workgroup.
+// Parallelism never changes a result: independent accumulators / matrix entries / the three beta
+// approximations go to different lanes, every floating-point SUM keeps the reference's sequential
+// order inside one lane, and the 12x12 Jacobi sweep runs its 66 rotations in 21 dependency levels
+// (rotations on disjoint row pairs commute exactly).
 #pragma once
 #include "uvo_linalg.h"
 
 namespace uvo {
 
-template <int S>
-struct ThreadPolicy {
-    using Arr = SArr<S>;
+// GroupPolicy<G>: G problems per workgroup, 8 consecutive lanes cooperate on each (blockDim = 8*G,
+// which must be ONE wave so that sync() is cheap).  Arrays live in LDS interleaved by group.
+template <int G>
+struct GroupPolicy {
+    using Arr = SArr<G>;
     static constexpr bool kStoreM = false;
-    __device__ static __forceinline__ int tid() { return 0; }
-    __device__ static __forceinline__ int nth() { return 1; }
-    __device__ static __forceinline__ void sync() {}
+    __device__ static __forceinline__ int tid() { return threadIdx.x & 7; }
+    __device__ static __forceinline__ int nth() { return 8; }
+    __device__ static __forceinline__ void sync() { __syncthreads(); }
 };
+// BlockPolicy: one problem per workgroup, plain (stride-1) arrays.
 struct BlockPolicy {
     using Arr = SArr<1>;
     static constexpr bool kStoreM = true;
@@ -27,96 +32,23 @@ struct BlockPolicy {
     __device__ static __forceinline__ void sync() { __syncthreads(); }
 };
 
-// jacobi_svd variant used for the 12x12 M^T M: OpenCV runs it with Vt present (so the rows of At
-// are sorted and normalised into U^T) but only U is consumed; the V rotations do not feed back
-// into At or W, so they are skipped.
-template <class A>
-__device__ void jacobi_svd_u_only(A At, int astep, A W_out, int m, int n, A W)
+// Sequential floating-point sum acc = (((0 + f(0)) + f(1)) + ...) with the terms fetched eight at a
+// time, so the (independent) loads and products of a batch overlap while the additions keep the
+// reference's order exactly.
+template <class F>
+__device__ __forceinline__ double seq_sum(int n, F f)
 {
-    const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
-    int i, j, k, iter, max_iter = m > 30 ? m : 30;
-    double c, s, sd;
-    for (i = 0; i < n; i++) {
-        for (k = 0, sd = 0; k < m; k++) { double t = At[i*astep + k]; sd += t*t; }
-        W[i] = sd;
+    double acc = 0;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        double t[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) t[q] = f(i + q);
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc += t[q];
     }
-#pragma unroll 1
-    for (iter = 0; iter < max_iter; iter++) {
-        bool changed = false;
-#pragma unroll 1
-        for (i = 0; i < n-1; i++)
-#pragma unroll 1
-            for (j = i+1; j < n; j++) {
-                A Ai = At + i*astep, Aj = At + j*astep;
-                double a = W[i], p = 0, b = W[j];
-                for (k = 0; k < m; k++) p += Ai[k]*Aj[k];
-                if (fabs(p) <= eps*sqrt(a*b)) continue;
-                p *= 2;
-                double beta = a - b, gamma = det_hypot(p, beta);
-                if (beta < 0) {
-                    double delta = (gamma - beta)*0.5;
-                    s = sqrt(delta/gamma);
-                    c = p/(gamma*s*2);
-                } else {
-                    c = sqrt((gamma + beta)/(gamma*2));
-                    s = p/(gamma*c*2);
-                }
-                a = b = 0;
-                for (k = 0; k < m; k++) {
-                    double x = Ai[k], y = Aj[k];
-                    double t0 = c*x + s*y;
-                    double t1 = -s*x + c*y;
-                    Ai[k] = t0; Aj[k] = t1;
-                    a += t0*t0; b += t1*t1;
-                }
-                W[i] = a; W[j] = b;
-                changed = true;
-            }
-        if (!changed) break;
-    }
-    for (i = 0; i < n; i++) {
-        for (k = 0, sd = 0; k < m; k++) { double t = At[i*astep + k]; sd += t*t; }
-        W[i] = sqrt(sd);
-    }
-    for (i = 0; i < n-1; i++) {
-        j = i;
-        for (k = i+1; k < n; k++) if (W[j] < W[k]) j = k;
-        if (i != j) {
-            double t = W[i]; W[i] = W[j]; W[j] = t;
-            for (k = 0; k < m; k++) { t = At[i*astep+k]; At[i*astep+k] = At[j*astep+k]; At[j*astep+k] = t; }
-        }
-    }
-    for (i = 0; i < n; i++) W_out[i] = W[i];
-    uint64_t rng = 0x12345678ULL;
-    for (i = 0; i < n; i++) {
-        sd = W[i];
-        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
-            const double val0 = 1./m;
-            for (k = 0; k < m; k++) {
-                double val = (rng_next(rng) & 256) != 0 ? val0 : -val0;
-                At[i*astep + k] = val;
-            }
-            for (iter = 0; iter < 2; iter++) {
-                for (j = 0; j < i; j++) {
-                    sd = 0;
-                    for (k = 0; k < m; k++) sd += At[i*astep + k]*At[j*astep + k];
-                    double asum = 0;
-                    for (k = 0; k < m; k++) {
-                        double t = At[i*astep + k] - sd*At[j*astep + k];
-                        At[i*astep + k] = t;
-                        asum += fabs(t);
-                    }
-                    asum = asum > eps*100 ? 1/asum : 0;
-                    for (k = 0; k < m; k++) At[i*astep + k] *= asum;
-                }
-            }
-            sd = 0;
-            for (k = 0; k < m; k++) { double t = At[i*astep + k]; sd += t*t; }
-            sd = sqrt(sd);
-        }
-        s = sd > minval ? 1/sd : 0.;
-        for (k = 0; k < m; k++) At[i*astep + k] *= s;
-    }
+    for (; i < n; i++) acc += f(i);
+    return acc;
 }
 
 // ---- cvRodrigues2 (calibration.cpp) ----
@@ -149,7 +81,7 @@ __host__ __device__ void rodrigues_mat2vec(A Rin, A sc, double* rv)
         if (!(v >= -100 && v < 100)) { rv[0] = rv[1] = rv[2] = 0; return; }
     }
     A a = sc, v = sc + 9, w = sc + 18, wt = sc + 21, R = sc + 24;
-    svd_square(Rin, a, w, v, wt, 3);
+    svd_square<3>(Rin, a, w, v, wt);
     // R = U * Vt ; U(i,k) = a[k*3+i]
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
         double s = 0;
@@ -194,14 +126,223 @@ __host__ __device__ __forceinline__ void project_point(double X, double Y, doubl
 }
 
 // ------------------------------------------------------------------------------------------
-// EPnP.  Small fixed-size state lives in `s` (EPNP_SMALL doubles); per-point arrays are
-// pws(3n) us(2n) alphas(4n) pcs(3n) tmp(n) and, for the block policy, M(24n).
+// Runtime-sized one-sided Jacobi (same operations as jacobi_svd<M,N,true>); used where several
+// lanes run differently-shaped solves at once (the three beta approximations).
+// ------------------------------------------------------------------------------------------
+template <class A>
+__device__ void jacobi_svd_rt(A At, A W_out, A Vt, A W, int m, int n)
+{
+    const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
+    int i, j, k, iter, max_iter = m > 30 ? m : 30;
+    double c, s, sd;
+    for (i = 0; i < n; i++) {
+        for (k = 0, sd = 0; k < m; k++) { double t = At[i*m + k]; sd += t*t; }
+        W[i] = sd;
+        for (k = 0; k < n; k++) Vt[i*n + k] = 0;
+        Vt[i*n + i] = 1;
+    }
+#pragma unroll 1
+    for (iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+#pragma unroll 1
+        for (i = 0; i < n-1; i++)
+#pragma unroll 1
+            for (j = i+1; j < n; j++) {
+                A Ai = At + i*m, Aj = At + j*m;
+                double a = W[i], p = 0, b = W[j];
+                for (k = 0; k < m; k++) p += Ai[k]*Aj[k];
+                if (fabs(p) <= eps*sqrt(a*b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = det_hypot(p, beta);
+                if (beta < 0) {
+                    double delta = (gamma - beta)*0.5;
+                    s = sqrt(delta/gamma);
+                    c = p/(gamma*s*2);
+                } else {
+                    c = sqrt((gamma + beta)/(gamma*2));
+                    s = p/(gamma*c*2);
+                }
+                a = b = 0;
+                for (k = 0; k < m; k++) {
+                    double x = Ai[k], y = Aj[k];
+                    double t0 = c*x + s*y;
+                    double t1 = -s*x + c*y;
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += t0*t0; b += t1*t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = true;
+                A Vi = Vt + i*n, Vj = Vt + j*n;
+                for (k = 0; k < n; k++) {
+                    double x = Vi[k], y = Vj[k];
+                    double t0 = c*x + s*y;
+                    double t1 = -s*x + c*y;
+                    Vi[k] = t0; Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (i = 0; i < n; i++) {
+        for (k = 0, sd = 0; k < m; k++) { double t = At[i*m + k]; sd += t*t; }
+        W[i] = sqrt(sd);
+    }
+    for (i = 0; i < n-1; i++) {
+        j = i;
+        for (k = i+1; k < n; k++) if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double t = W[i]; W[i] = W[j]; W[j] = t;
+            for (k = 0; k < m; k++) { t = At[i*m+k]; At[i*m+k] = At[j*m+k]; At[j*m+k] = t; }
+            for (k = 0; k < n; k++) { t = Vt[i*n+k]; Vt[i*n+k] = Vt[j*n+k]; Vt[j*n+k] = t; }
+        }
+    }
+    for (i = 0; i < n; i++) W_out[i] = W[i];
+    uint64_t rng = 0x12345678ULL;
+    for (i = 0; i < n; i++) {
+        sd = W[i];
+        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+            const double val0 = 1./m;
+            for (k = 0; k < m; k++) { double val = (rng_next(rng) & 256) != 0 ? val0 : -val0; At[i*m + k] = val; }
+            for (iter = 0; iter < 2; iter++)
+                for (j = 0; j < i; j++) {
+                    sd = 0;
+                    for (k = 0; k < m; k++) sd += At[i*m + k]*At[j*m + k];
+                    double asum = 0;
+                    for (k = 0; k < m; k++) { double t = At[i*m + k] - sd*At[j*m + k]; At[i*m + k] = t; asum += fabs(t); }
+                    asum = asum > eps*100 ? 1/asum : 0;
+                    for (k = 0; k < m; k++) At[i*m + k] *= asum;
+                }
+            sd = 0;
+            for (k = 0; k < m; k++) { double t = At[i*m + k]; sd += t*t; }
+            sd = sqrt(sd);
+        }
+        s = sd > minval ? 1/sd : 0.;
+        for (k = 0; k < m; k++) At[i*m + k] *= s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 12x12 (generally MxN) Jacobi with U only, rotations scheduled by dependency level.
+// In OpenCV's cyclic order (0,1),(0,2)..(0,N-1),(1,2).. rotation (i,j) depends only on the previous
+// rotation that touched row i and the previous one that touched row j, which are (i,j-1)/(i-1,i) and
+// (i-1,j): level(i,j) = i + j.  All rotations of one level touch disjoint rows, so they run on
+// different lanes; levels run in order, which reproduces the sequential result bit for bit.
+// `flag` is one double of shared scratch.  Needs P::nth() >= N/2 lanes.
+// ------------------------------------------------------------------------------------------
+template <class P, int M, int N>
+__device__ void jacobi_svd_u_levels(typename P::Arr At, typename P::Arr W_out, typename P::Arr W, typename P::Arr flag)
+{
+    using A = typename P::Arr;
+    const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
+    const int lane = P::tid();
+    const int max_iter = M > 30 ? M : 30;
+    for (int i = lane; i < N; i += P::nth()) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) { double t = At[i*M + k]; sd += t*t; }
+        W[i] = sd;
+    }
+    P::sync();
+#pragma unroll 1
+    for (int iter = 0; iter < max_iter; iter++) {
+        if (lane == 0) flag[0] = 0;
+        P::sync();
+#pragma unroll 1
+        for (int t = 1; t <= 2*N - 3; t++) {
+            const int i_lo = t - (N - 1) > 0 ? t - (N - 1) : 0, i_hi = (t - 1) / 2;
+            const int i = i_lo + lane, j = t - i;
+            if (i <= i_hi) {
+                A Ai = At + i*M, Aj = At + j*M;
+                double ai[M], aj[M];
+#pragma unroll
+                for (int k = 0; k < M; k++) { ai[k] = Ai[k]; aj[k] = Aj[k]; }
+                double a = W[i], p = 0, b = W[j];
+#pragma unroll
+                for (int k = 0; k < M; k++) p += ai[k]*aj[k];
+                if (!(fabs(p) <= eps*sqrt(a*b))) {
+                    double c, s;
+                    p *= 2;
+                    double beta = a - b, gamma = det_hypot(p, beta);
+                    if (beta < 0) {
+                        double delta = (gamma - beta)*0.5;
+                        s = sqrt(delta/gamma);
+                        c = p/(gamma*s*2);
+                    } else {
+                        c = sqrt((gamma + beta)/(gamma*2));
+                        s = p/(gamma*c*2);
+                    }
+                    a = b = 0;
+#pragma unroll
+                    for (int k = 0; k < M; k++) {
+                        double t0 = c*ai[k] + s*aj[k];
+                        double t1 = -s*ai[k] + c*aj[k];
+                        Ai[k] = t0; Aj[k] = t1;
+                        a += t0*t0; b += t1*t1;
+                    }
+                    W[i] = a; W[j] = b;
+                    flag[0] = 1;
+                }
+            }
+            P::sync();
+        }
+        const bool changed = flag[0] != 0;
+        P::sync();
+        if (!changed) break;
+    }
+    for (int i = lane; i < N; i += P::nth()) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < M; k++) { double t = At[i*M + k]; sd += t*t; }
+        W[i] = sqrt(sd);
+    }
+    P::sync();
+    if (lane == 0) {
+        for (int i = 0; i < N-1; i++) {
+            int j = i;
+            for (int k = i+1; k < N; k++) if (W[j] < W[k]) j = k;
+            if (i != j) {
+                double t = W[i]; W[i] = W[j]; W[j] = t;
+                for (int k = 0; k < M; k++) { t = At[i*M+k]; At[i*M+k] = At[j*M+k]; At[j*M+k] = t; }
+            }
+        }
+        for (int i = 0; i < N; i++) W_out[i] = W[i];
+        uint64_t rng = 0x12345678ULL;
+        for (int i = 0; i < N; i++) {
+            double sd = W[i];
+            for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+                const double val0 = 1./M;
+                for (int k = 0; k < M; k++) { double val = (rng_next(rng) & 256) != 0 ? val0 : -val0; At[i*M + k] = val; }
+                for (int it = 0; it < 2; it++)
+                    for (int j = 0; j < i; j++) {
+                        sd = 0;
+                        for (int k = 0; k < M; k++) sd += At[i*M + k]*At[j*M + k];
+                        double asum = 0;
+                        for (int k = 0; k < M; k++) { double t = At[i*M + k] - sd*At[j*M + k]; At[i*M + k] = t; asum += fabs(t); }
+                        asum = asum > eps*100 ? 1/asum : 0;
+                        for (int k = 0; k < M; k++) At[i*M + k] *= asum;
+                    }
+                sd = 0;
+                for (int k = 0; k < M; k++) { double t = At[i*M + k]; sd += t*t; }
+                sd = sqrt(sd);
+            }
+            double s = sd > minval ? 1/sd : 0.;
+            for (int k = 0; k < M; k++) At[i*M + k] *= s;
+        }
+    }
+    P::sync();
+}
+
+// ------------------------------------------------------------------------------------------
+// EPnP.  Fixed-size state lives in `s` (EPNP_SMALL doubles): a common part and one block per beta
+// approximation N = 1..3 (the three run on lanes 0..2 concurrently).  Per-point arrays: pws(3n)
+// us(2n) alphas(4n) pcs(3 x 3n) tmp(3 x n) and, for the block policy, M(24n).
 // ------------------------------------------------------------------------------------------
 enum {
-    EP_CWS = 0, EP_CCS = 12, EP_MTM = 24, EP_D = 168, EP_WT = 180, EP_L = 192, EP_RHO = 252,
-    EP_BETAS = 258, EP_REP = 274, EP_RS = 278, EP_TS = 314, EP_PC0 = 326, EP_PW0 = 329, EP_ABT = 332,
-    EP_SC = 341,              // scratch: 140 doubles
-    EPNP_SMALL = 341 + 140
+    EP_CWS = 0, EP_MTM = 12, EP_D = 156, EP_WT = 168, EP_FLAG = 180, EP_L = 181, EP_RHO = 241,
+    EP_PW0 = 247, EP_SC = 250,      // common scratch: 72 doubles
+    EP_BR = 322,                    // per-branch blocks start here
+    EPB_CCS = 0, EPB_BETAS = 12, EPB_REP = 16, EPB_RS = 17, EPB_TS = 26, EPB_PC0 = 29, EPB_ABT = 32, EPB_SC = 41,  // scratch: 100
+    EPB_SIZE = 141,
+    EPNP_SMALL = EP_BR + 3 * EPB_SIZE
 };
 
 template <class P>
@@ -209,8 +350,9 @@ struct Epnp {
     using Arr = typename P::Arr;
     double uc, vc, fu, fv;
     int n;
-    Arr pws, us, alphas, pcs, tmp, M, s;
+    Arr pws, us, alphas, pcs, tmp, M, s;      // pcs: 3 branches x 3n, tmp: 3 branches x n
 
+    __device__ __forceinline__ Arr br(int b) const { return s + (EP_BR + b * EPB_SIZE); }
     __device__ __forceinline__ double dot3(Arr a, Arr b) const { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
     __device__ __forceinline__ double dist2(Arr p1, Arr p2) const
     {
@@ -230,8 +372,7 @@ struct Epnp {
     {
         Arr cws = s + EP_CWS, sc = s + EP_SC;
         for (int j = P::tid(); j < 3; j += P::nth()) {
-            double acc = 0;
-            for (int i = 0; i < n; i++) acc += pws[3*i + j];
+            double acc = seq_sum(n, [&](int i) { return pws[3*i + j]; });
             cws[j] = acc / n;
         }
         P::sync();
@@ -240,15 +381,15 @@ struct Epnp {
         for (int e = P::tid(); e < 6; e += P::nth()) {
             int a = e < 3 ? 0 : e < 5 ? 1 : 2;
             int b = e < 3 ? e : e < 5 ? e - 2 : 2;
-            double ca = cws[a], cb = cws[b], s0 = 0;
-            for (int k = 0; k < n; k++) s0 += (pws[3*k + a] - ca) * (pws[3*k + b] - cb);
+            double ca = cws[a], cb = cws[b];
+            double s0 = seq_sum(n, [&](int k) { return (pws[3*k + a] - ca) * (pws[3*k + b] - cb); });
             ptp[a*3 + b] = s0;
             ptp[b*3 + a] = s0;
         }
         P::sync();
         if (P::tid() == 0) {
             Arr at = sc + 9, dc = sc + 18, vt = sc + 21, wt = sc + 30;
-            svd_square(ptp, at, dc, vt, wt, 3);       // rows of `at` = U^T = uct
+            svd_square<3>(ptp, at, dc, vt, wt);       // rows of `at` = U^T = uct
             for (int i = 1; i < 4; i++) {
                 double k = sqrt(dc[i-1] / n);
                 for (int j = 0; j < 3; j++) cws[3*i + j] = cws[j] + k * at[3*(i-1) + j];
@@ -294,8 +435,7 @@ struct Epnp {
             int i = 0, rem = e;
             while (rem >= 12 - i) { rem -= 12 - i; i++; }
             int j = i + rem;
-            double s0 = 0;
-            for (int k = 0; k < 2*n; k++) s0 += Mval(k, i) * Mval(k, j);
+            double s0 = seq_sum(2*n, [&](int k) { return Mval(k, i) * Mval(k, j); });
             mtm[i*12 + j] = s0;
             mtm[j*12 + i] = s0;
         }
@@ -333,30 +473,30 @@ struct Epnp {
 #undef UVO_DV
     }
 
-    // scratch layout for the small solves: Ls(30) a(30) v(25) w(5) wt(5) b(5)
-    __device__ void find_betas(int which, Arr L, Arr rho, Arr betas)
+    // find_betas_approx_{1,2,3}: cvSolve(L_6xK, Rho, B, CV_SVD) with K = 4, 3, 5 columns picked from L_6x10.
+    // Written shape-generic so that lanes 0..2 run the three approximations in one instruction stream.
+    // scratch: Ls(30) a(30) v(25) w(5) wt(5) b(5)
+    __device__ void find_betas(int which, Arr L, Arr rho, Arr betas, Arr sc)
     {
-        Arr sc = s + EP_SC;
         Arr Ls = sc, a = sc + 30, v = sc + 60, w = sc + 85, wt = sc + 90, b = sc + 95;
+        const int K = which == 1 ? 4 : which == 2 ? 3 : 5;
+        for (int i = 0; i < 6; i++)
+            for (int j = 0; j < K; j++) {
+                int col = which == 1 ? (j == 0 ? 0 : j == 1 ? 1 : j == 2 ? 3 : 6) : j;
+                Ls[K*i + j] = L[10*i + col];
+            }
+        // cv::solve(DECOMP_SVD): a = Ls^T, JacobiSVD, back-substitution
+        for (int i = 0; i < 6; i++) for (int j = 0; j < K; j++) a[j*6 + i] = Ls[i*K + j];
+        jacobi_svd_rt(a, w, v, wt, 6, K);
+        svbksb_vec(6, K, w, a, 6, v, K, rho, b);
         if (which == 1) {
-            for (int i = 0; i < 6; i++) { Ls[4*i] = L[10*i]; Ls[4*i+1] = L[10*i+1]; Ls[4*i+2] = L[10*i+3]; Ls[4*i+3] = L[10*i+6]; }
-            solve_svd(Ls, 6, 4, rho, b, a, v, w, wt);
             if (b[0] < 0) { betas[0] = sqrt(-b[0]); betas[1] = -b[1] / betas[0]; betas[2] = -b[2] / betas[0]; betas[3] = -b[3] / betas[0]; }
             else          { betas[0] = sqrt(b[0]);  betas[1] = b[1] / betas[0];  betas[2] = b[2] / betas[0];  betas[3] = b[3] / betas[0]; }
-        } else if (which == 2) {
-            for (int i = 0; i < 6; i++) { Ls[3*i] = L[10*i]; Ls[3*i+1] = L[10*i+1]; Ls[3*i+2] = L[10*i+2]; }
-            solve_svd(Ls, 6, 3, rho, b, a, v, w, wt);
-            if (b[0] < 0) { betas[0] = sqrt(-b[0]); betas[1] = (b[2] < 0) ? sqrt(-b[2]) : 0.0; }
-            else          { betas[0] = sqrt(b[0]);  betas[1] = (b[2] > 0) ? sqrt(b[2]) : 0.0; }
-            if (b[1] < 0) betas[0] = -betas[0];
-            betas[2] = 0.0; betas[3] = 0.0;
         } else {
-            for (int i = 0; i < 6; i++) for (int j = 0; j < 5; j++) Ls[5*i + j] = L[10*i + j];
-            solve_svd(Ls, 6, 5, rho, b, a, v, w, wt);
             if (b[0] < 0) { betas[0] = sqrt(-b[0]); betas[1] = (b[2] < 0) ? sqrt(-b[2]) : 0.0; }
             else          { betas[0] = sqrt(b[0]);  betas[1] = (b[2] > 0) ? sqrt(b[2]) : 0.0; }
             if (b[1] < 0) betas[0] = -betas[0];
-            betas[2] = b[3] / betas[0];
+            betas[2] = which == 2 ? 0.0 : b[3] / betas[0];
             betas[3] = 0.0;
         }
     }
@@ -405,9 +545,8 @@ struct Epnp {
         }
     }
 
-    __device__ void gauss_newton(Arr L, Arr rho, Arr betas)
+    __device__ void gauss_newton(Arr L, Arr rho, Arr betas, Arr sc)
     {
-        Arr sc = s + EP_SC;
         Arr A = sc, b = sc + 24, x = sc + 30, A1 = sc + 34, A2 = sc + 38;
         for (int i = 0; i < 4; i++) x[i] = 0;
         for (int it = 0; it < 5; it++) {
@@ -429,48 +568,76 @@ struct Epnp {
         }
     }
 
-    // compute_ccs + compute_pcs + solve_for_sign + estimate_R_and_t + reprojection_error
-    __device__ double compute_R_and_t(Arr ut, Arr betas, Arr R, Arr t)
+    // epnp::compute_pose followed by Rodrigues(R, rvec).  Outputs valid on tid 0.
+    __device__ void compute_pose(double* rvec, double* tvec)
     {
-        Arr ccs = s + EP_CCS, pc0 = s + EP_PC0, pw0 = s + EP_PW0, abt = s + EP_ABT, sc = s + EP_SC;
-        if (P::tid() == 0) {
+        choose_control_points();
+        compute_barycentric_coordinates();
+        build_mtm();
+        Arr mtm = s + EP_MTM, L = s + EP_L, rho = s + EP_RHO, cws = s + EP_CWS, pw0 = s + EP_PW0;
+        // cvSVD(MtM, D, Ut, 0, MODIFY_A | U_T): MtM is symmetric so At = MtM^T is MtM itself; rows -> U^T
+        jacobi_svd_u_levels<P, 12, 12>(mtm, s + EP_D, s + EP_WT, s + EP_FLAG);
+        const int tid = P::tid();
+        if (tid == 0) {
+            compute_L_6x10(mtm, L);
+            rho[0] = dist2(cws, cws + 3); rho[1] = dist2(cws, cws + 6); rho[2] = dist2(cws, cws + 9);
+            rho[3] = dist2(cws + 3, cws + 6); rho[4] = dist2(cws + 3, cws + 9); rho[5] = dist2(cws + 6, cws + 9);
+        }
+        P::sync();
+        // ---- the three beta approximations, one per lane: find_betas + gauss_newton + compute_ccs ----
+        if (tid < 3) {
+            Arr B = br(tid), betas = B + EPB_BETAS, ccs = B + EPB_CCS;
+            find_betas(tid + 1, L, rho, betas, B + EPB_SC);
+            gauss_newton(L, rho, betas, B + EPB_SC);
             for (int i = 0; i < 12; i++) ccs[i] = 0.0f;
             for (int i = 0; i < 4; i++) {
-                Arr v = ut + 12*(11 - i);
+                Arr v = mtm + 12*(11 - i);
                 double bi = betas[i];
                 for (int j = 0; j < 4; j++) for (int k = 0; k < 3; k++) ccs[3*j + k] += bi * v[3*j + k];
             }
         }
         P::sync();
-        for (int i = P::tid(); i < n; i += P::nth()) {
-            Arr a = alphas + 4*i, pc = pcs + 3*i;
+        // compute_pcs for the three branches
+        for (int it = tid; it < 3*n; it += P::nth()) {
+            int b = it / n, i = it - b*n;
+            Arr ccs = br(b) + EPB_CCS, a = alphas + 4*i, pc = pcs + 3*(b*n + i);
             for (int j = 0; j < 3; j++) pc[j] = a[0]*ccs[j] + a[1]*ccs[3 + j] + a[2]*ccs[6 + j] + a[3]*ccs[9 + j];
         }
         P::sync();
-        bool flip = pcs[2] < 0.0;
+        // solve_for_sign
+        bool flip[3];
+        for (int b = 0; b < 3; b++) flip[b] = pcs[3*(b*n) + 2] < 0.0;
         P::sync();
-        if (flip) {
-            if (P::tid() == 0) for (int i = 0; i < 12; i++) ccs[i] = -ccs[i];
-            for (int i = P::tid(); i < n; i += P::nth()) { pcs[3*i] = -pcs[3*i]; pcs[3*i+1] = -pcs[3*i+1]; pcs[3*i+2] = -pcs[3*i+2]; }
+        if (flip[0] || flip[1] || flip[2]) {
+            if (tid < 3 && flip[tid]) { Arr ccs = br(tid) + EPB_CCS; for (int i = 0; i < 12; i++) ccs[i] = -ccs[i]; }
+            for (int it = tid; it < 3*n; it += P::nth()) {
+                int b = it / n;
+                if (flip[b]) { Arr pc = pcs + 3*it; pc[0] = -pc[0]; pc[1] = -pc[1]; pc[2] = -pc[2]; }
+            }
             P::sync();
         }
-        // estimate_R_and_t
-        for (int e = P::tid(); e < 6; e += P::nth()) {
-            int j = e % 3; double acc = 0;
-            if (e < 3) { for (int i = 0; i < n; i++) acc += pcs[3*i + j]; pc0[j] = acc / n; }
-            else       { for (int i = 0; i < n; i++) acc += pws[3*i + j]; pw0[j] = acc / n; }
+        // estimate_R_and_t: centroids (pw0 does not depend on the branch), 3x3 covariances
+        for (int e = tid; e < 12; e += P::nth()) {
+            if (e < 3) { double acc = seq_sum(n, [&](int i) { return pws[3*i + e]; }); pw0[e] = acc / n; }
+            else {
+                int b = (e - 3) / 3, j = (e - 3) - 3*b;
+                Arr pc = pcs + 3*(b*n);
+                double acc = seq_sum(n, [&](int i) { return pc[3*i + j]; });
+                (br(b) + EPB_PC0)[j] = acc / n;
+            }
         }
         P::sync();
-        for (int e = P::tid(); e < 9; e += P::nth()) {
-            int j = e / 3, q = e - 3*j;
-            double cj = pc0[j], wq = pw0[q], acc = 0;
-            for (int i = 0; i < n; i++) acc += (pcs[3*i + j] - cj) * (pws[3*i + q] - wq);
-            abt[e] = acc;
+        for (int e = tid; e < 27; e += P::nth()) {
+            int b = e / 9, r = e - 9*b, j = r / 3, q = r - 3*j;
+            Arr pc = pcs + 3*(b*n);
+            double cj = (br(b) + EPB_PC0)[j], wq = pw0[q];
+            (br(b) + EPB_ABT)[r] = seq_sum(n, [&](int i) { return (pc[3*i + j] - cj) * (pws[3*i + q] - wq); });
         }
         P::sync();
-        if (P::tid() == 0) {
+        if (tid < 3) {
+            Arr B = br(tid), abt = B + EPB_ABT, R = B + EPB_RS, t = B + EPB_TS, pc0 = B + EPB_PC0, sc = B + EPB_SC;
             Arr at = sc, w = sc + 9, vt = sc + 12, wt = sc + 21;
-            svd_square(abt, at, w, vt, wt, 3);
+            svd_square<3>(abt, at, w, vt, wt);
             // R[i][j] = dot(U row i, V row j) = sum_k U(i,k) V(j,k) = sum_k at[k][i] * vt[k][j]
             for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
                 R[3*i + j] = at[0*3 + i]*vt[0*3 + j] + at[1*3 + i]*vt[1*3 + j] + at[2*3 + i]*vt[2*3 + j];
@@ -483,56 +650,33 @@ struct Epnp {
             t[2] = pc0[2] - dot3(R + 6, pw0);
         }
         P::sync();
-        // reprojection_error: per-point terms in parallel, summed in order by one thread
-        for (int i = P::tid(); i < n; i += P::nth()) {
-            Arr pw = pws + 3*i;
+        // reprojection_error: per-point terms in parallel, summed in order by one lane per branch
+        for (int it = tid; it < 3*n; it += P::nth()) {
+            int b = it / n, i = it - b*n;
+            Arr R = br(b) + EPB_RS, t = br(b) + EPB_TS, pw = pws + 3*i;
             double Xc = dot3(R, pw) + t[0];
             double Yc = dot3(R + 3, pw) + t[1];
             double inv_Zc = 1.0 / (dot3(R + 6, pw) + t[2]);
             double ue = uc + fu * Xc * inv_Zc;
             double ve = vc + fv * Yc * inv_Zc;
             double u = us[2*i], v = us[2*i + 1];
-            tmp[i] = sqrt((u - ue)*(u - ue) + (v - ve)*(v - ve));
+            tmp[it] = sqrt((u - ue)*(u - ue) + (v - ve)*(v - ve));
         }
         P::sync();
-        double sum2 = 0.0;
-        if (P::tid() == 0) { for (int i = 0; i < n; i++) sum2 += tmp[i]; sum2 = sum2 / n; }
-        P::sync();
-        return sum2;     // meaningful on tid 0 only
-    }
-
-    // epnp::compute_pose followed by Rodrigues(R, rvec).  Outputs valid on tid 0.
-    __device__ void compute_pose(double* rvec, double* tvec)
-    {
-        choose_control_points();
-        compute_barycentric_coordinates();
-        build_mtm();
-        Arr mtm = s + EP_MTM, d = s + EP_D, wt = s + EP_WT, L = s + EP_L, rho = s + EP_RHO;
-        Arr betas = s + EP_BETAS, rep = s + EP_REP, Rs = s + EP_RS, ts = s + EP_TS, cws = s + EP_CWS;
-        if (P::tid() == 0) {
-            // cvSVD(MtM, D, Ut, 0, MODIFY_A | U_T): MtM is symmetric so At = MtM^T is MtM itself
-            jacobi_svd_u_only(mtm, 12, d, 12, 12, wt);
-            compute_L_6x10(mtm, L);
-            rho[0] = dist2(cws, cws + 3); rho[1] = dist2(cws, cws + 6); rho[2] = dist2(cws, cws + 9);
-            rho[3] = dist2(cws + 3, cws + 6); rho[4] = dist2(cws + 3, cws + 9); rho[5] = dist2(cws + 6, cws + 9);
+        if (tid < 3) {
+            Arr tb = tmp + tid*n;
+            double sum2 = seq_sum(n, [&](int i) { return tb[i]; });
+            (br(tid) + EPB_REP)[0] = sum2 / n;
         }
         P::sync();
-        for (int N = 1; N <= 3; N++) {
-            if (P::tid() == 0) {
-                find_betas(N, L, rho, betas + 4*N);
-                gauss_newton(L, rho, betas + 4*N);
-            }
-            P::sync();
-            double e = compute_R_and_t(mtm, betas + 4*N, Rs + 9*N, ts + 3*N);
-            if (P::tid() == 0) rep[N] = e;
-            P::sync();
-        }
-        if (P::tid() == 0) {
-            int N = 1;
-            if (rep[2] < rep[1]) N = 2;
-            if (rep[3] < rep[N]) N = 3;
-            tvec[0] = ts[3*N]; tvec[1] = ts[3*N + 1]; tvec[2] = ts[3*N + 2];
-            rodrigues_mat2vec(Rs + 9*N, s + EP_SC, rvec);
+        if (tid == 0) {
+            double rep1 = (br(0) + EPB_REP)[0], rep2 = (br(1) + EPB_REP)[0], rep3 = (br(2) + EPB_REP)[0];
+            int N = 1; double repN = rep1;
+            if (rep2 < rep1) { N = 2; repN = rep2; }
+            if (rep3 < repN) N = 3;
+            Arr B = br(N - 1), ts = B + EPB_TS;
+            tvec[0] = ts[0]; tvec[1] = ts[1]; tvec[2] = ts[2];
+            rodrigues_mat2vec(B + EPB_RS, B + EPB_SC, rvec);
         }
         P::sync();
     }

@@ -17,31 +17,46 @@ struct SArr {
     __host__ __device__ __forceinline__ SArr operator+(int o) const { return SArr{p + o * S}; }
 };
 
-// JacobiSVDImpl_<double>(At, astep, W, Vt, vstep, m, n, n1, DBL_MIN, DBL_EPSILON*10).
-// At: n rows of m (row i at At[i*astep..]); Vt (n x n) optional; Wt: n doubles of scratch.
-template <class A>
-__host__ __device__ void jacobi_svd(A At, int astep, A W_out, A Vt, int vstep, bool hasV, int m, int n, int n1, A W)
+// JacobiSVDImpl_<double>(At, astep = M, W, Vt, vstep = N, m = M, n = N, n1 = N, DBL_MIN, DBL_EPSILON*10)
+// with Vt present (OpenCV always passes it on the paths used here).  At: N rows of M (row i =
+// column i of A); afterwards row i of At = i-th left singular vector, row i of Vt = i-th right
+// singular vector.  M, N are compile-time so the two rows of a rotation live in registers and the
+// k-loops unroll (same operations, same order as the reference loop).  ACCUM_V = false skips the
+// V rotations (they never feed back into At or W) for callers that only consume U and W.
+template <int M, int N, bool ACCUM_V, class A>
+__host__ __device__ void jacobi_svd(A At, A W_out, A Vt, A W)
 {
     const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
-    int i, j, k, iter, max_iter = m > 30 ? m : 30;
+    int i, j, k, iter;
+    const int max_iter = M > 30 ? M : 30;
     double c, s, sd;
-    if (!hasV) n1 = 0;
 
-    for (i = 0; i < n; i++) {
-        for (k = 0, sd = 0; k < m; k++) { double t = At[i*astep + k]; sd += t*t; }
+#pragma unroll 1
+    for (i = 0; i < N; i++) {
+        sd = 0;
+#pragma unroll
+        for (k = 0; k < M; k++) { double t = At[i*M + k]; sd += t*t; }
         W[i] = sd;
-        if (hasV) { for (k = 0; k < n; k++) Vt[i*vstep + k] = 0; Vt[i*vstep + i] = 1; }
+        if (ACCUM_V) {
+#pragma unroll
+            for (k = 0; k < N; k++) Vt[i*N + k] = 0;
+            Vt[i*N + i] = 1;
+        }
     }
 #pragma unroll 1
     for (iter = 0; iter < max_iter; iter++) {
         bool changed = false;
 #pragma unroll 1
-        for (i = 0; i < n-1; i++)
+        for (i = 0; i < N-1; i++)
 #pragma unroll 1
-            for (j = i+1; j < n; j++) {
-                A Ai = At + i*astep, Aj = At + j*astep;
+            for (j = i+1; j < N; j++) {
+                A Ai = At + i*M, Aj = At + j*M;
+                double ai[M], aj[M];
+#pragma unroll
+                for (k = 0; k < M; k++) { ai[k] = Ai[k]; aj[k] = Aj[k]; }
                 double a = W[i], p = 0, b = W[j];
-                for (k = 0; k < m; k++) p += Ai[k]*Aj[k];
+#pragma unroll
+                for (k = 0; k < M; k++) p += ai[k]*aj[k];
                 if (fabs(p) <= eps*sqrt(a*b)) continue;
                 p *= 2;
                 double beta = a - b, gamma = det_hypot(p, beta);
@@ -54,18 +69,19 @@ __host__ __device__ void jacobi_svd(A At, int astep, A W_out, A Vt, int vstep, b
                     s = p/(gamma*c*2);
                 }
                 a = b = 0;
-                for (k = 0; k < m; k++) {
-                    double x = Ai[k], y = Aj[k];
-                    double t0 = c*x + s*y;
-                    double t1 = -s*x + c*y;
+#pragma unroll
+                for (k = 0; k < M; k++) {
+                    double t0 = c*ai[k] + s*aj[k];
+                    double t1 = -s*ai[k] + c*aj[k];
                     Ai[k] = t0; Aj[k] = t1;
                     a += t0*t0; b += t1*t1;
                 }
                 W[i] = a; W[j] = b;
                 changed = true;
-                if (hasV) {
-                    A Vi = Vt + i*vstep, Vj = Vt + j*vstep;
-                    for (k = 0; k < n; k++) {
+                if (ACCUM_V) {
+                    A Vi = Vt + i*N, Vj = Vt + j*N;
+#pragma unroll
+                    for (k = 0; k < N; k++) {
                         double x = Vi[k], y = Vj[k];
                         double t0 = c*x + s*y;
                         double t1 = -s*x + c*y;
@@ -75,64 +91,69 @@ __host__ __device__ void jacobi_svd(A At, int astep, A W_out, A Vt, int vstep, b
             }
         if (!changed) break;
     }
-    for (i = 0; i < n; i++) {
-        for (k = 0, sd = 0; k < m; k++) { double t = At[i*astep + k]; sd += t*t; }
+#pragma unroll 1
+    for (i = 0; i < N; i++) {
+        sd = 0;
+#pragma unroll
+        for (k = 0; k < M; k++) { double t = At[i*M + k]; sd += t*t; }
         W[i] = sqrt(sd);
     }
-    for (i = 0; i < n-1; i++) {
+#pragma unroll 1
+    for (i = 0; i < N-1; i++) {
         j = i;
-        for (k = i+1; k < n; k++) if (W[j] < W[k]) j = k;
+        for (k = i+1; k < N; k++) if (W[j] < W[k]) j = k;
         if (i != j) {
             double t = W[i]; W[i] = W[j]; W[j] = t;
-            if (hasV) {
-                for (k = 0; k < m; k++) { t = At[i*astep+k]; At[i*astep+k] = At[j*astep+k]; At[j*astep+k] = t; }
-                for (k = 0; k < n; k++) { t = Vt[i*vstep+k]; Vt[i*vstep+k] = Vt[j*vstep+k]; Vt[j*vstep+k] = t; }
-            }
+            for (k = 0; k < M; k++) { t = At[i*M+k]; At[i*M+k] = At[j*M+k]; At[j*M+k] = t; }
+            if (ACCUM_V) for (k = 0; k < N; k++) { t = Vt[i*N+k]; Vt[i*N+k] = Vt[j*N+k]; Vt[j*N+k] = t; }
         }
     }
-    for (i = 0; i < n; i++) W_out[i] = W[i];
-    if (!hasV) return;
+    for (i = 0; i < N; i++) W_out[i] = W[i];
 
     uint64_t rng = 0x12345678ULL;
-    for (i = 0; i < n1; i++) {
-        sd = i < n ? W[i] : 0;
+#pragma unroll 1
+    for (i = 0; i < N; i++) {
+        sd = W[i];
+#pragma unroll 1
         for (int ii = 0; ii < 100 && sd <= minval; ii++) {
-            const double val0 = 1./m;
-            for (k = 0; k < m; k++) {
+            // zero singular value: random +-1/m vector orthogonalised against the previous rows
+            const double val0 = 1./M;
+            for (k = 0; k < M; k++) {
                 double val = (rng_next(rng) & 256) != 0 ? val0 : -val0;
-                At[i*astep + k] = val;
+                At[i*M + k] = val;
             }
             for (iter = 0; iter < 2; iter++) {
                 for (j = 0; j < i; j++) {
                     sd = 0;
-                    for (k = 0; k < m; k++) sd += At[i*astep + k]*At[j*astep + k];
+                    for (k = 0; k < M; k++) sd += At[i*M + k]*At[j*M + k];
                     double asum = 0;
-                    for (k = 0; k < m; k++) {
-                        double t = At[i*astep + k] - sd*At[j*astep + k];
-                        At[i*astep + k] = t;
+                    for (k = 0; k < M; k++) {
+                        double t = At[i*M + k] - sd*At[j*M + k];
+                        At[i*M + k] = t;
                         asum += fabs(t);
                     }
                     asum = asum > eps*100 ? 1/asum : 0;
-                    for (k = 0; k < m; k++) At[i*astep + k] *= asum;
+                    for (k = 0; k < M; k++) At[i*M + k] *= asum;
                 }
             }
             sd = 0;
-            for (k = 0; k < m; k++) { double t = At[i*astep + k]; sd += t*t; }
+            for (k = 0; k < M; k++) { double t = At[i*M + k]; sd += t*t; }
             sd = sqrt(sd);
         }
         s = sd > minval ? 1/sd : 0.;
-        for (k = 0; k < m; k++) At[i*astep + k] *= s;
+#pragma unroll
+        for (k = 0; k < M; k++) At[i*M + k] *= s;
     }
 }
 
-// cv::SVD::compute of a square n x n matrix A (row-major, tight, element (i,j) at A[i*n+j]):
-// writes At = A^T in place of `At`, runs Jacobi; afterwards row i of At is the i-th LEFT
-// singular vector (U^T), row i of Vt the i-th right singular vector.  W, Wt: n doubles each.
-template <class A>
-__host__ __device__ void svd_square(A Ain, A At, A W, A Vt, A Wt, int n)
+// cv::SVD::compute of a square N x N matrix A (row-major, tight): writes At = A^T into `At`, runs
+// Jacobi; afterwards row i of At is the i-th LEFT singular vector (U^T), row i of Vt the i-th right
+// singular vector.  W, Wt: N doubles each.
+template <int N, class A>
+__host__ __device__ void svd_square(A Ain, A At, A W, A Vt, A Wt)
 {
-    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) At[j*n + i] = Ain[i*n + j];
-    jacobi_svd(At, n, W, Vt, n, true, n, n, n, Wt);
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) At[j*N + i] = Ain[i*N + j];
+    jacobi_svd<N, N, true>(At, W, Vt, Wt);
 }
 
 // SVBkSbImpl_<double>, nb == 1 with right-hand side b: x = V diag(1/w) U^T b.
@@ -156,12 +177,12 @@ __host__ __device__ void svbksb_vec(int m, int n, A w, A ut, int ldu, A vt, int 
 }
 
 // cv::solve(A[m x n], b, DECOMP_SVD).  scratch: a (n*m), v (n*n), w (n), wt (n)
-template <class A>
-__host__ __device__ void solve_svd(A Amat, int m, int n, A b, A x, A a, A v, A w, A wt)
+template <int M, int N, class A>
+__host__ __device__ void solve_svd(A Amat, A b, A x, A a, A v, A w, A wt)
 {
-    for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) a[j*m + i] = Amat[i*n + j];
-    jacobi_svd(a, m, w, v, n, true, m, n, n, wt);
-    svbksb_vec(m, n, w, a, m, v, n, b, x);
+    for (int i = 0; i < M; i++) for (int j = 0; j < N; j++) a[j*M + i] = Amat[i*N + j];
+    jacobi_svd<M, N, true>(a, w, v, wt);
+    svbksb_vec(M, N, w, a, M, v, N, b, x);
 }
 
 // cv::invert(A[3x3], DECOMP_SVD) = SVD::compute + SVD::backSubst(rhs = empty).
@@ -170,7 +191,7 @@ template <class A>
 __host__ __device__ void invert3_svd(A Amat, A Ainv, A a, A v, A w, A wt)
 {
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a[j*3 + i] = Amat[i*3 + j];
-    jacobi_svd(a, 3, w, v, 3, true, 3, 3, 3, wt);
+    jacobi_svd<3, 3, true>(a, w, v, wt);
     double threshold = 0;
     for (int i = 0; i < 9; i++) Ainv[i] = 0;
     for (int i = 0; i < 3; i++) threshold += w[i];
