@@ -241,6 +241,21 @@ class Context:
         self._check(self._lib.uvo_stereo_step(self._h, pl, pr, w, h, w, ml, C.c_double(dt), C.byref(r)))
         return r
 
+    def stereo_submit(self, left, right):
+        """Enqueue detect..extract_3Dpoints of a pair (no host sync); at most two pairs in flight."""
+        h, w = left.shape[-2], left.shape[-1]
+        pl, ml, kl = _ptr_mem(left, np.uint8)
+        pr, mr, kr = _ptr_mem(right, np.uint8)
+        if ml != mr:
+            raise ValueError("left and right must live in the same memory space")
+        self._check(self._lib.uvo_stereo_submit(self._h, pl, pr, w, h, w, ml))
+
+    def stereo_collect(self, dt: float = 0.05) -> StereoResult:
+        """Finish the oldest submitted pair (PnP-RANSAC + pose); same result as stereo_step."""
+        r = StereoResult()
+        self._check(self._lib.uvo_stereo_collect(self._h, C.c_double(dt), C.byref(r)))
+        return r
+
     def stereo_get(self, what: str):
         spec = {"kps_left": KP_DTYPE, "kps_right": KP_DTYPE, "desc_left": np.dtype(("f4", 64)),
                 "desc_right": np.dtype(("f4", 64)), "matches_stereo": DM_DTYPE, "matches_tri": DM_DTYPE,

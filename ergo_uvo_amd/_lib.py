@@ -18,6 +18,7 @@ EXPORTS = [
     "uvo_ctx_stream", "uvo_ctx_set_params", "uvo_surf_detect", "uvo_integral", "uvo_hessian_layer",
     "uvo_match_knn2_ratio", "uvo_match_knn2", "uvo_triangulate_points", "uvo_extract_3d_points",
     "uvo_solve_pnp_ransac", "uvo_rodrigues", "uvo_stereo_set_rig", "uvo_stereo_reset", "uvo_stereo_step",
+    "uvo_stereo_submit", "uvo_stereo_collect",
     "uvo_stereo_get", "uvo_timing_enable", "uvo_timing_count", "uvo_timing_name", "uvo_timing_get", "uvo_timing_reset",
 ]
 

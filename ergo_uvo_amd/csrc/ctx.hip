@@ -79,10 +79,18 @@ extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w,
     A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_list, cap * 2));
     A(dalloc(&c->d_mpart, nchunks * cap)); A(dalloc(&c->d_knn_idx, cap * 2)); A(dalloc(&c->d_knn_dist, cap * 2));
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
-    A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_good_pts, cap * 3)); A(dalloc(&c->d_good_idx, cap));
-    A(dalloc(&c->d_opts, cap * 3)); A(dalloc(&c->d_ipts, cap)); A(dalloc(&c->d_counts, (size_t)CN_TOTAL));
+    A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_tmp_idx, cap));
+    for (int i = 0; i < 2; i++) {
+        A(dalloc(&c->d_good_pts[i], cap * 3)); A(dalloc(&c->d_good_idx[i], cap));
+        A(dalloc(&c->d_opts[i], cap * 3)); A(dalloc(&c->d_ipts[i], cap));
+        A(hipEventCreateWithFlags(&c->evA[i], hipEventDisableTiming));
+        A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsA[i]), sizeof(int) * CN_TOTAL));
+    }
+    A(hipStreamCreateWithFlags(&c->pnp_stream, hipStreamNonBlocking));
+    A(dalloc(&c->d_countsB, (size_t)4)); A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsB), sizeof(int) * 4));
+    A(dalloc(&c->d_counts, (size_t)CN_TOTAL));
     A(dalloc(&c->d_subsets, (size_t)kMaxHyp * 5)); A(dalloc(&c->d_models, (size_t)kMaxHyp * 6)); A(dalloc(&c->d_hcount, (size_t)kMaxHyp));
-    A(dalloc(&c->d_inliers, cap)); A(dalloc(&c->d_refit, cap * 45)); A(dalloc(&c->d_pose, (size_t)6));
+    A(dalloc(&c->d_inliers, cap)); A(dalloc(&c->d_refit, cap * 21)); A(dalloc(&c->d_pose, (size_t)6));
     A(hipHostMalloc(reinterpret_cast<void**>(&c->h_counts), sizeof(int) * CN_TOTAL));
     A(hipHostMalloc(reinterpret_cast<void**>(&c->h_subsets), sizeof(int) * kMaxHyp * 5));
     A(hipHostMalloc(reinterpret_cast<void**>(&c->h_hcount), sizeof(int) * kMaxHyp));
@@ -112,11 +120,16 @@ extern "C" void uvo_ctx_destroy(uvo_ctx* c)
         (void)hipFree(c->det[i].desc); (void)hipFree(c->d_tmp_desc[i]); (void)hipFree(c->d_matches[i]);
         (void)hipFree(c->d_as_kpsL[i]); (void)hipFree(c->d_as_kpsR[i]); (void)hipFree(c->d_as_descL[i]);
     }
+    if (c->pnp_stream) (void)hipStreamSynchronize(c->pnp_stream);
     void* ptrs[] = { c->d_colpart, c->d_DW, c->d_rank, c->d_big_list, c->d_mpart, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
-                     c->d_flag, c->d_good_pts, c->d_good_idx, c->d_opts, c->d_ipts, c->d_counts, c->d_subsets, c->d_models,
+                     c->d_flag, c->d_tmp_idx, c->d_good_pts[0], c->d_good_pts[1], c->d_good_idx[0], c->d_good_idx[1], c->d_opts[0], c->d_opts[1],
+                     c->d_ipts[0], c->d_ipts[1], c->d_counts, c->d_countsB, c->d_subsets, c->d_models,
                      c->d_hcount, c->d_inliers, c->d_refit, c->d_pose };
     for (void* p : ptrs) (void)hipFree(p);
     (void)hipHostFree(c->h_counts); (void)hipHostFree(c->h_subsets); (void)hipHostFree(c->h_hcount); (void)hipHostFree(c->h_pose);
+    (void)hipHostFree(c->h_countsB);
+    for (int i = 0; i < 2; i++) { (void)hipHostFree(c->h_countsA[i]); if (c->evA[i]) (void)hipEventDestroy(c->evA[i]); }
+    if (c->pnp_stream) (void)hipStreamDestroy(c->pnp_stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -266,12 +279,12 @@ extern "C" uvo_status uvo_extract_3d_points(uvo_ctx* c, const uvo_point2f* k1, c
     UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x1, k1, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
     UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x2, k2, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
     UVO_HIP_TRY(c, hipMemcpyAsync(c->d_xc, k1, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
-    UVO_TRY(pose_extract3d(c, R1, t1, R2, t2, K1, K2, nullptr, n));
+    UVO_TRY(pose_extract3d(c, 0, R1, t1, R2, t2, K1, K2, nullptr, n));
     UVO_TRY(read_counts(c));
     int G = c->h_counts[CN_G];
     if (G) {
-        UVO_HIP_TRY(c, hipMemcpyAsync(pts, c->d_good_pts, sizeof(double) * 3 * G, hipMemcpyDeviceToHost, c->stream));
-        UVO_HIP_TRY(c, hipMemcpyAsync(idx, c->d_good_idx, sizeof(int) * G, hipMemcpyDeviceToHost, c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(pts, c->d_good_pts[0], sizeof(double) * 3 * G, hipMemcpyDeviceToHost, c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(idx, c->d_good_idx[0], sizeof(int) * G, hipMemcpyDeviceToHost, c->stream));
         UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     *g = G;
@@ -288,16 +301,16 @@ extern "C" uvo_status uvo_solve_pnp_ransac(uvo_ctx* c, const double* obj, const 
     std::vector<float> of((size_t)3 * n);
     for (int i = 0; i < 3 * n; i++) of[i] = (float)obj[i];                     // opoints0.convertTo(opoints, CV_32F)
     if (n) {
-        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_opts, of.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
-        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_ipts, img, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_opts[0], of.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_ipts[0], img, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
         UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     int ni = 0;
-    UVO_TRY(pose_pnp_ransac(c, n, K, iterations_count, reprojection_error, confidence, rvec, tvec, &ni, ok));
+    UVO_TRY(pose_pnp_ransac(c, 0, n, K, iterations_count, reprojection_error, confidence, rvec, tvec, &ni, ok));
     *n_inliers = ni;
     if (inliers && ni) {
-        UVO_HIP_TRY(c, hipMemcpyAsync(inliers, c->d_inliers, sizeof(int) * ni, hipMemcpyDeviceToHost, c->stream));
-        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(inliers, c->d_inliers, sizeof(int) * ni, hipMemcpyDeviceToHost, c->pnp_stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->pnp_stream));
     }
     return UVO_OK;
 }
@@ -402,7 +415,9 @@ extern "C" uvo_status uvo_stereo_reset(uvo_ctx* c)
 {
     if (!c) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
+    if (c->pnp_stream) (void)hipStreamSynchronize(c->pnp_stream);
     c->vo_initialized = false; c->init_matches.clear(); c->as_prev = 0;
+    c->n_pending = 0; c->n_submitted = c->n_collected = 0; c->pending[0].used = c->pending[1].used = false;
     for (int i = 0; i < 3; i++) c->t_prev_curr[i] = c->rvec[i] = c->tvec[i] = 0;
     UVO_HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(int) * CN_TOTAL, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -442,7 +457,7 @@ static uvo_status stereo_init_step(uvo_ctx* c, uvo_stereo_result* out)
             return fail(c, UVO_INVALID_ARG, "stale stereo-init matches index past the current keypoints; the reference's "
                                             "keypoint/descriptor sets would go out of step (OpenCV asserts downstream)");
         const int b = c->as_prev;
-        int* d_idx = c->d_good_idx;    // scratch
+        int* d_idx = c->d_tmp_idx;     // scratch
         UVO_HIP_TRY(c, hipMemcpyAsync(d_idx, iL.data(), sizeof(int) * total, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_gather_desc_idx, dim3((total + 15) / 16), dim3(256), 0, c->stream, c->det[0].desc, nL, d_idx, total, c->d_as_descL[b]);
         hipLaunchKernelGGL(k_gather_kps_idx, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->det[0].kps, d_idx, total, c->d_as_kpsL[b]);
@@ -458,20 +473,31 @@ static uvo_status stereo_init_step(uvo_ctx* c, uvo_stereo_result* out)
     return UVO_OK;
 }
 
-extern "C" uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
-                                      int mem, double dt, uvo_stereo_result* out)
+// Stage A of one pair (VO:548-632): detect, stereo match, triangular match, triangulation,
+// extract_3Dpoints -- all enqueued on c->stream without a host sync; the counters are copied to the
+// slot's pinned mirror and an event marks completion.
+extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, int mem)
 {
-    if (!c || !left || !right || !out) return UVO_INVALID_ARG;
+    if (!c || !left || !right) return UVO_INVALID_ARG;
     if (!c->rig_set) return fail(c, UVO_INVALID_ARG, "uvo_stereo_set_rig has not been called");
+    if (c->n_pending >= 2) return fail(c, UVO_INVALID_ARG, "uvo_stereo_submit: two pairs are already in flight; collect one first");
     (void)hipSetDevice(c->device);
     const uvo_params& p = c->p;
-    memset(out, 0, sizeof(*out));
+    const int slot = (int)(c->n_submitted & 1);
+    uvo_ctx::Pending& pd = c->pending[slot];
+    pd = uvo_ctx::Pending();
+    pd.used = true; pd.slot = slot;
+    memset(&pd.res, 0, sizeof(pd.res));
     UVO_TRY(surf_upload(c, 0, left, w, h, stride, mem));
     UVO_TRY(surf_upload(c, 1, right, w, h, stride, mem));
     UVO_TRY(surf_detect(c, 2));                                                            // VO:548-549
-    if (!c->vo_initialized) return stereo_init_step(c, out);
-
-    out->initialized = 1;
+    if (!c->vo_initialized) {
+        if (c->n_pending != 0) return fail(c, UVO_INVALID_ARG, "uvo_stereo_submit: the init phase cannot be pipelined");
+        UVO_TRY(stereo_init_step(c, &pd.res));
+        pd.init_done = true;
+        c->n_submitted++; c->n_pending++;
+        return UVO_OK;
+    }
     const int cap = c->cap, prev = c->as_prev, curr = 1 - prev;
     int* cn = c->d_counts;
     const float ratio = (float)p.LOWE_RATIO_THRESHOLD;
@@ -498,10 +524,33 @@ extern "C" uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uin
     // triangulation + extract_3Dpoints (VO:631-632)
     UVO_TRY(pose_triangulate(c, c->P_eye_left, c->P_right, cn + CN_T, cap));
     const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
-    UVO_TRY(pose_extract3d(c, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap));
-    UVO_TRY(read_counts(c));
+    UVO_TRY(pose_extract3d(c, slot, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap));
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_countsA[slot], c->d_counts, sizeof(int) * CN_TOTAL, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipEventRecord(c->evA[slot], c->stream));
+    c->as_prev = curr;                                                                     // VO:727-733
+    c->n_submitted++; c->n_pending++;
+    return UVO_OK;
+}
+
+// Stage B of the oldest submitted pair (VO:634-717): gates, PnP-RANSAC on c->pnp_stream, pose inversion.
+extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_result* out)
+{
+    if (!c || !out) return UVO_INVALID_ARG;
+    if (c->n_pending <= 0) return fail(c, UVO_INVALID_ARG, "uvo_stereo_collect: nothing submitted");
+    (void)hipSetDevice(c->device);
+    const uvo_params& p = c->p;
+    const int slot = (int)(c->n_collected & 1);
+    uvo_ctx::Pending& pd = c->pending[slot];
+    c->n_collected++; c->n_pending--; pd.used = false;
+    c->last_slot = slot;
+    if (pd.init_done) { *out = pd.res; return UVO_OK; }
+    memset(out, 0, sizeof(*out));
+    out->initialized = 1;
+    UVO_HIP_TRY(c, hipEventSynchronize(c->evA[slot]));
+    const int* hc = c->h_countsA[slot];
+    memcpy(c->h_counts, hc, sizeof(int) * CN_TOTAL);
     UVO_TRY(check_cand_overflow(c, 2));
-    const int* hc = c->h_counts;
+    const int cap = c->cap;
     if (hc[CN_M] > cap || hc[CN_TRAW] > cap) return fail(c, UVO_CAPACITY, "match count exceeds max_kpts");
     const int nL = hc[CN_NL], nR = hc[CN_NR], M = hc[CN_M], T = hc[CN_TRAW], G = hc[CN_G];
     out->n_left = nL; out->n_right = nR; out->n_stereo_matches = M; out->n_tri_matches = T; out->n_good3d = G;
@@ -509,7 +558,7 @@ extern "C" uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uin
     int valid = 0;
     if (G > p.MIN_NUM_3DPOINTS) {                                                          // VO:634
         int ninl = 0, ok = 0;
-        UVO_TRY(pose_pnp_ransac(c, G, c->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE,
+        UVO_TRY(pose_pnp_ransac(c, slot, G, c->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE,
                                 c->rvec, c->tvec, &ninl, &ok));                            // VO:647-648
         c->last_ninl = ninl; out->n_inliers = ninl;
         if (ninl >= p.MIN_NUM_INLIERS) {                                                   // VO:665
@@ -528,8 +577,16 @@ extern "C" uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uin
         out->rvec[i] = c->rvec[i]; out->tvec[i] = c->tvec[i]; out->t_prev_curr[i] = c->t_prev_curr[i];
         out->velocity[i] = c->t_prev_curr[i] / dt;                                         // VO:152
     }
-    c->as_prev = curr;                                                                     // VO:727-733
     return UVO_OK;
+}
+
+extern "C" uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
+                                      int mem, double dt, uvo_stereo_result* out)
+{
+    if (!c || !out) return UVO_INVALID_ARG;
+    if (c->n_pending != 0) return fail(c, UVO_INVALID_ARG, "uvo_stereo_step: pairs submitted with uvo_stereo_submit are still in flight");
+    UVO_TRY(uvo_stereo_submit(c, left, right, w, h, stride, mem));
+    return uvo_stereo_collect(c, dt, out);
 }
 
 extern "C" int uvo_stereo_get(uvo_ctx* c, const char* what, void* out, int cap_bytes)
@@ -545,8 +602,8 @@ extern "C" int uvo_stereo_get(uvo_ctx* c, const char* what, void* out, int cap_b
     else if (w == "matches_stereo") { src = c->d_matches[0]; count = c->last_M; esz = sizeof(uvo_dmatch); }
     else if (w == "matches_tri") { src = c->d_matches[1]; count = c->last_T > 0 ? c->h_counts[CN_TRAW] : c->h_counts[CN_TRAW]; esz = sizeof(uvo_dmatch); }
     else if (w == "points4d") { src = c->d_pts4; count = c->last_T; esz = sizeof(float4); }
-    else if (w == "good_pts") { src = c->d_good_pts; count = c->last_G; esz = 3 * sizeof(double); }
-    else if (w == "good_idx") { src = c->d_good_idx; count = c->last_G; esz = sizeof(int); }
+    else if (w == "good_pts") { src = c->d_good_pts[c->last_slot]; count = c->last_G; esz = 3 * sizeof(double); }
+    else if (w == "good_idx") { src = c->d_good_idx[c->last_slot]; count = c->last_G; esz = sizeof(int); }
     else if (w == "inliers") { src = c->d_inliers; count = c->last_ninl; esz = sizeof(int); }
     else return 0;
     if ((size_t)count * esz > (size_t)cap_bytes) return -count;

@@ -188,7 +188,6 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* opts, const uvo_poi
     Epnp<P> e;
     e.uc = cx; e.vc = cy; e.fu = fx; e.fv = fy; e.n = 5;
     e.s = base; e.pws = base + EPNP_SMALL; e.us = e.pws + 15; e.alphas = e.us + 10; e.pcs = e.alphas + 20; e.tmp = e.pcs + 45;
-    e.M = e.tmp;    // unused (kStoreM = false)
     const double ifx = 1. / fx, ify = 1. / fy;
     if (lane < 5) {
         const int i = lane, id = subsets[hyp * 5 + i];
@@ -246,7 +245,7 @@ __global__ __launch_bounds__(256) void k_pnp_score(const float* opts, const uvo_
 // winner's mask -> ascending inlier list + refit inputs (double points; undistort in double)
 __global__ __launch_bounds__(1024) void k_pnp_mask(const float* opts, const uvo_point2f* ipts, int n, const double* model,
                                                    double fx, double fy, double cx, double cy, float thr2,
-                                                   int* inliers, double* pws, double* us, int* counts /* [2] = n_inliers */)
+                                                   int* inliers, double* pws, double* us, int* counts /* [0] = n_inliers */)
 {
     const int tid = threadIdx.x;
     __shared__ int wtot[16];
@@ -269,20 +268,21 @@ __global__ __launch_bounds__(1024) void k_pnp_mask(const float* opts, const uvo_
         }
     }
     __syncthreads();
-    if (tid == 0) counts[2] = s_base;
+    if (tid == 0) counts[0] = s_base;
 }
 
-// inlier refit: one workgroup, block-cooperative EPnP.  ws: pws 3c | us 2c | alphas 4c | pcs 9c | tmp 3c | M 24c (c = cap)
+// inlier refit: one workgroup, block-cooperative EPnP.  ws: pws 3c | us 2c | alphas 4c | pcs 9c | tmp 3c (c = cap)
 __global__ __launch_bounds__(256) void k_pnp_refit(double* ws, int cap, const int* n_p, double fx, double fy, double cx, double cy, double* pose)
 {
     __shared__ double small[EPNP_SMALL];
+    __shared__ double stage_buf[Epnp<BlockPolicy>::kStageDoubles];
     const int n = *n_p;
     using P = BlockPolicy;
     Epnp<P> e;
     e.uc = cx; e.vc = cy; e.fu = fx; e.fv = fy; e.n = n;
-    e.s = P::Arr{small};
+    e.s = P::Arr{small}; e.stage = stage_buf;
     e.pws = P::Arr{ws}; e.us = P::Arr{ws + 3 * (size_t)cap}; e.alphas = P::Arr{ws + 5 * (size_t)cap};
-    e.pcs = P::Arr{ws + 9 * (size_t)cap}; e.tmp = P::Arr{ws + 18 * (size_t)cap}; e.M = P::Arr{ws + 21 * (size_t)cap};
+    e.pcs = P::Arr{ws + 9 * (size_t)cap}; e.tmp = P::Arr{ws + 18 * (size_t)cap};
     double rvec[3], tvec[3];
     e.compute_pose(rvec, tvec);
     if (threadIdx.x == 0) { pose[0] = rvec[0]; pose[1] = rvec[1]; pose[2] = rvec[2]; pose[3] = tvec[0]; pose[4] = tvec[1]; pose[5] = tvec[2]; }
@@ -310,7 +310,7 @@ static Cam make_cam(const double* R, const double* t, const double* K)
     return cm;
 }
 
-uvo_status pose_extract3d(Ctx* c, const double* R1, const double* t1, const double* R2, const double* t2,
+uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, const double* R2, const double* t2,
                           const double* K1, const double* K2, const int* d_n, int n_max)
 {
     StageTimer t(c, ST_EXTRACT3D);
@@ -319,18 +319,20 @@ uvo_status pose_extract3d(Ctx* c, const double* R1, const double* t1, const doub
                            make_cam(R1, t1, K1), make_cam(R2, t2, K2), c->p.REPROJECTION_TOLERANCE, d_n, n_max, c->d_cam1, c->d_flag);
     }
     hipLaunchKernelGGL(k_extract3d_b, dim3(1), dim3(1024), 0, c->stream, c->d_cam1, c->d_flag, c->d_xc, d_n, n_max,
-                       c->p.MIN_NUM_3DPOINTS, c->d_inliers /* scratch: tmp_idx */, c->d_good_pts, c->d_good_idx, c->d_opts, c->d_ipts,
+                       c->p.MIN_NUM_3DPOINTS, c->d_tmp_idx, c->d_good_pts[slot], c->d_good_idx[slot], c->d_opts[slot], c->d_ipts[slot],
                        c->d_counts);
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }
 
-// solvePnPRansac on the G points already in c->d_opts / c->d_ipts.
-uvo_status pose_pnp_ransac(Ctx* c, int G, const double* K, int iterationsCount, float reprojectionError, double confidence,
+// solvePnPRansac on the G points already in c->d_opts[slot] / c->d_ipts[slot]; runs on c->pnp_stream.
+uvo_status pose_pnp_ransac(Ctx* c, int slot, int G, const double* K, int iterationsCount, float reprojectionError, double confidence,
                            double* rvec, double* tvec, int* n_inliers, int* ok)
 {
     const int modelPoints = 5;
     *n_inliers = 0; *ok = 0;
+    hipStream_t st = c->pnp_stream;
+    const float* d_opts = c->d_opts[slot]; const uvo_point2f* d_ipts = c->d_ipts[slot];
     if (G < 4) { c->err = "solvePnPRansac needs at least 4 points (OpenCV asserts)"; return UVO_TOO_FEW_POINTS; }
     if (G == 4) { c->err = "solvePnPRansac with exactly 4 points takes OpenCV's P3P path, which the reference never reaches; not implemented"; return UVO_TOO_FEW_POINTS; }
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
@@ -364,33 +366,33 @@ uvo_status pose_pnp_ransac(Ctx* c, int G, const double* K, int iterationsCount, 
         }
         nhyp = niters;
     }
-    UVO_HIP_TRY(c, hipMemcpyAsync(c->d_subsets, c->h_subsets, sizeof(int) * 5 * nhyp, hipMemcpyHostToDevice, c->stream));
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->d_subsets, c->h_subsets, sizeof(int) * 5 * nhyp, hipMemcpyHostToDevice, st));
     {
-        StageTimer t(c, ST_PNP_HYP);
-        hipLaunchKernelGGL(k_pnp_hyp, dim3((nhyp + kHypGroups - 1) / kHypGroups), dim3(64), hyp_lds, c->stream,
-                           c->d_opts, c->d_ipts, c->d_subsets, nhyp, fx, fy, cx, cy, c->d_models);
+        StageTimer t(c, ST_PNP_HYP, st);
+        hipLaunchKernelGGL(k_pnp_hyp, dim3((nhyp + kHypGroups - 1) / kHypGroups), dim3(64), hyp_lds, st,
+                           d_opts, d_ipts, c->d_subsets, nhyp, fx, fy, cx, cy, c->d_models);
         UVO_HIP_TRY(c, hipGetLastError());
     }
     if (G == modelPoints) {
-        UVO_HIP_TRY(c, hipMemcpyAsync(c->h_pose, c->d_models, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
-        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->h_pose, c->d_models, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
+        UVO_HIP_TRY(c, hipStreamSynchronize(st));
         memcpy(rvec, c->h_pose, sizeof(double) * 3); memcpy(tvec, c->h_pose + 3, sizeof(double) * 3);
         int ids[5] = {0, 1, 2, 3, 4};
-        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_inliers, ids, sizeof(ids), hipMemcpyHostToDevice, c->stream));
-        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_inliers, ids, sizeof(ids), hipMemcpyHostToDevice, st));
+        UVO_HIP_TRY(c, hipStreamSynchronize(st));
         *n_inliers = 5; *ok = 1;
         return UVO_OK;
     }
     const double threshold = reprojectionError;
     const float thr2 = (float)(threshold * threshold);
     {
-        StageTimer t(c, ST_PNP_SCORE);
-        hipLaunchKernelGGL(k_pnp_score, dim3(nhyp), dim3(256), 0, c->stream, c->d_opts, c->d_ipts, G, c->d_models, nhyp,
+        StageTimer t(c, ST_PNP_SCORE, st);
+        hipLaunchKernelGGL(k_pnp_score, dim3(nhyp), dim3(256), 0, st, d_opts, d_ipts, G, c->d_models, nhyp,
                            fx, fy, cx, cy, thr2, c->d_hcount);
         UVO_HIP_TRY(c, hipGetLastError());
     }
-    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_hcount, c->d_hcount, sizeof(int) * nhyp, hipMemcpyDeviceToHost, c->stream));
-    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_hcount, c->d_hcount, sizeof(int) * nhyp, hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipStreamSynchronize(st));
     // replay of RANSACPointSetRegistrator::run's sequential scan
     int maxGoodCount = 0, best = -1, last = 0;
     for (int iter = 0; iter < niters; iter++) {
@@ -403,24 +405,24 @@ uvo_status pose_pnp_ransac(Ctx* c, int G, const double* K, int iterationsCount, 
     }
     if (best < 0) {
         // RANSAC failed: OpenCV hands back the last hypothesis' rvec/tvec and no inliers
-        UVO_HIP_TRY(c, hipMemcpyAsync(c->h_pose, c->d_models + (size_t)last * 6, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
-        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->h_pose, c->d_models + (size_t)last * 6, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
+        UVO_HIP_TRY(c, hipStreamSynchronize(st));
         memcpy(rvec, c->h_pose, sizeof(double) * 3); memcpy(tvec, c->h_pose + 3, sizeof(double) * 3);
         return UVO_OK;
     }
     {
-        StageTimer t(c, ST_PNP_REFIT);
+        StageTimer t(c, ST_PNP_REFIT, st);
         double* ws = c->d_refit;
-        hipLaunchKernelGGL(k_pnp_mask, dim3(1), dim3(1024), 0, c->stream, c->d_opts, c->d_ipts, G, c->d_models + (size_t)best * 6,
-                           fx, fy, cx, cy, thr2, c->d_inliers, ws, ws + 3 * (size_t)c->cap, c->d_counts);
-        hipLaunchKernelGGL(k_pnp_refit, dim3(1), dim3(256), 0, c->stream, ws, c->cap, c->d_counts + 2, fx, fy, cx, cy, c->d_pose);
+        hipLaunchKernelGGL(k_pnp_mask, dim3(1), dim3(1024), 0, st, d_opts, d_ipts, G, c->d_models + (size_t)best * 6,
+                           fx, fy, cx, cy, thr2, c->d_inliers, ws, ws + 3 * (size_t)c->cap, c->d_countsB);
+        hipLaunchKernelGGL(k_pnp_refit, dim3(1), dim3(256), 0, st, ws, c->cap, c->d_countsB, fx, fy, cx, cy, c->d_pose);
         UVO_HIP_TRY(c, hipGetLastError());
     }
-    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_pose, c->d_pose, sizeof(double) * 6, hipMemcpyDeviceToHost, c->stream));
-    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_counts + 2, c->d_counts + 2, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_pose, c->d_pose, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_countsB, c->d_countsB, sizeof(int), hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipStreamSynchronize(st));
     memcpy(rvec, c->h_pose, sizeof(double) * 3); memcpy(tvec, c->h_pose + 3, sizeof(double) * 3);
-    *n_inliers = c->h_counts[2];
+    *n_inliers = c->h_countsB[0];
     *ok = 1;
     return UVO_OK;
 }

@@ -170,6 +170,42 @@ __device__ __forceinline__ void solve3f(const float a[3][3], const float b[3], f
 
 struct CandOut { uvo_keypoint* cand[2]; int* count; int cap; };
 
+// findMaximaInLayer's tail for one 3x3x3 maximum: centre, interpolateKeypoint, SURFInvoker's size check,
+// append.  `trace` is dx + dy of the centre sample.
+template <int STEP>
+__device__ __forceinline__ void emit_keypoint(float N9[3][9], float val0, float trace, int i, int j, int size, int ds, int octave,
+                                              int w, int h, int im, const CandOut& out)
+{
+    int sum_i = STEP * (i - (size / 2) / STEP);
+    int sum_j = STEP * (j - (size / 2) / STEP);
+    float center_i = sum_i + (size - 1) * 0.5f;
+    float center_j = sum_j + (size - 1) * 0.5f;
+    float bb[3] = { -(N9[1][5]-N9[1][3])/2, -(N9[1][7]-N9[1][1])/2, -(N9[2][4]-N9[0][4])/2 };
+    float A[3][3] = {
+        { N9[1][3]-2*N9[1][4]+N9[1][5], (N9[1][8]-N9[1][6]-N9[1][2]+N9[1][0])/4, (N9[2][5]-N9[2][3]-N9[0][5]+N9[0][3])/4 },
+        { (N9[1][8]-N9[1][6]-N9[1][2]+N9[1][0])/4, N9[1][1]-2*N9[1][4]+N9[1][7], (N9[2][7]-N9[2][1]-N9[0][7]+N9[0][1])/4 },
+        { (N9[2][5]-N9[2][3]-N9[0][5]+N9[0][3])/4, (N9[2][7]-N9[2][1]-N9[0][7]+N9[0][1])/4, N9[0][4]-2*N9[1][4]+N9[2][4] } };
+    float x[3];
+    solve3f(A, bb, x);
+    bool ok = (x[0] != 0 || x[1] != 0 || x[2] != 0) &&
+              fabsf(x[0]) <= 1 && fabsf(x[1]) <= 1 && fabsf(x[2]) <= 1;
+    if (!ok) return;
+    uvo_keypoint kp;
+    kp.x = center_j + x[0] * STEP;
+    kp.y = center_i + x[1] * STEP;
+    kp.size = (float)cv_round_f((float)size + x[2] * ds);
+    kp.angle = 360.f - 90.f;            // upright: descriptor_dir
+    kp.response = val0;
+    kp.octave = octave;
+    kp.class_id = (trace > 0) - (trace < 0);
+    // SURFInvoker: keypoints whose gradient wavelet exceeds the integral image are dropped
+    float s = kp.size * 1.2f / 9.0f;
+    int grad_wav_size = 2 * cv_round_f(2 * s);
+    if (h + 1 < grad_wav_size || w + 1 < grad_wav_size) return;
+    int slot = atomicAdd(&out.count[im], 1);
+    if (slot < out.cap) out.cand[im][slot] = kp;
+}
+
 // TW x TH plane samples per workgroup including a 1-sample halo; (TW-2) x (TH-2) NMS outputs.
 template <int STEP, bool USE_LDS, int TW, int TH>
 __global__ __launch_bounds__(256) void k_hessian_nms(ImgPair ip, int w, int h, OctavePat op, float thr, CandOut out)
@@ -248,12 +284,6 @@ __global__ __launch_bounds__(256) void k_hessian_nms(ImgPair ip, int w, int h, O
                     if (!(a == 1 && b == 4)) is_max = is_max && (val0 > N9[a][b]);
             if (!is_max) continue;
 
-            const int size = lp.size;
-            int sum_i = STEP * (i - (size / 2) / STEP);
-            int sum_j = STEP * (j - (size / 2) / STEP);
-            float center_i = sum_i + (size - 1) * 0.5f;
-            float center_j = sum_j + (size - 1) * 0.5f;
-            // sign of the trace (dx + dy) at the maximum
             float dx, dy, dxy;
             {
                 int oi = i - lp.margin, oj = j - lp.margin;
@@ -265,33 +295,168 @@ __global__ __launch_bounds__(256) void k_hessian_nms(ImgPair ip, int w, int h, O
                     haar_response(lp, [&](int yy, int xx) { return o[(size_t)yy * sw + xx]; }, &dx, &dy, &dxy);
                 }
             }
-            float trace = dx + dy;
-            // interpolateKeypoint
-            float bb[3] = { -(N9[1][5]-N9[1][3])/2, -(N9[1][7]-N9[1][1])/2, -(N9[2][4]-N9[0][4])/2 };
-            float A[3][3] = {
-                { N9[1][3]-2*N9[1][4]+N9[1][5], (N9[1][8]-N9[1][6]-N9[1][2]+N9[1][0])/4, (N9[2][5]-N9[2][3]-N9[0][5]+N9[0][3])/4 },
-                { (N9[1][8]-N9[1][6]-N9[1][2]+N9[1][0])/4, N9[1][1]-2*N9[1][4]+N9[1][7], (N9[2][7]-N9[2][1]-N9[0][7]+N9[0][1])/4 },
-                { (N9[2][5]-N9[2][3]-N9[0][5]+N9[0][3])/4, (N9[2][7]-N9[2][1]-N9[0][7]+N9[0][1])/4, N9[0][4]-2*N9[1][4]+N9[2][4] } };
-            float x[3];
-            solve3f(A, bb, x);
-            bool ok = (x[0] != 0 || x[1] != 0 || x[2] != 0) &&
-                      fabsf(x[0]) <= 1 && fabsf(x[1]) <= 1 && fabsf(x[2]) <= 1;
-            if (!ok) continue;
-            int ds = size - op.L[L - 1].size;
-            uvo_keypoint kp;
-            kp.x = center_j + x[0] * STEP;
-            kp.y = center_i + x[1] * STEP;
-            kp.size = (float)cv_round_f((float)size + x[2] * ds);
-            kp.angle = 360.f - 90.f;            // upright: descriptor_dir
-            kp.response = val0;
-            kp.octave = op.octave;
-            kp.class_id = (trace > 0) - (trace < 0);
-            // SURFInvoker: keypoints whose gradient wavelet exceeds the integral image are dropped
-            float s = kp.size * 1.2f / 9.0f;
-            int grad_wav_size = 2 * cv_round_f(2 * s);
-            if (h + 1 < grad_wav_size || w + 1 < grad_wav_size) continue;
-            int slot = atomicAdd(&out.count[im], 1);
-            if (slot < out.cap) out.cand[im][slot] = kp;
+            emit_keypoint<STEP>(N9, val0, dx + dy, i, j, lp.size, lp.size - op.L[L - 1].size, op.octave, w, h, im, out);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Octaves 0 and 1: the same fused kernel with the box patterns, weights and every LDS offset
+// resolved at compile time (sizes (9+6l)<<O are fixed by the octave), so one box corner is one
+// ds_read_b32 with an immediate offset and corners shared between the boxes of a filter are read
+// once (32 reads per sample instead of 40, no address arithmetic).  For STEP > 1 the integral tile
+// is stored de-interleaved by column residue, which turns the stride-STEP sample walk into
+// unit-stride (conflict-free) LDS reads.
+// ------------------------------------------------------------------------------------------
+constexpr int cround_pos(float v)      // cvRound for v >= 0 (round half to even), usable in constant expressions
+{
+    int i = (int)v;
+    float f = v - (float)i;
+    return f > 0.5f ? i + 1 : (f < 0.5f ? i : ((i & 1) ? i + 1 : i));
+}
+template <int SIZE>
+struct LayerC {
+    static constexpr float ratio = (float)SIZE / 9;
+    static constexpr int r(int c) { return cround_pos(ratio * (float)c); }
+    static constexpr float wt(int wgt, int x1, int y1, int x2, int y2)
+    {
+        return (float)wgt / ((float)(r(x2) - r(x1)) * (float)(r(y2) - r(y1)));
+    }
+};
+template <int O>
+struct OctC {
+    static constexpr int STEP = 1 << O;
+    static constexpr int size(int l) { return (9 + 6 * l) << O; }
+    static constexpr int margin(int l) { return (size(l) / 2) / STEP; }
+    static constexpr int LO = -margin(4) * STEP;                  // the largest layer reaches furthest left/up ...
+    static constexpr int HI = -margin(4) * STEP + size(4);        // ... and furthest right/down
+};
+
+template <int O, int L, int TW, int TH, int NT>
+__device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, float* __restrict__ sdet, const OctavePat& op,
+                                            int px0, int py0)
+{
+    using OC = OctC<O>;
+    constexpr int STEP = OC::STEP, SIZE = OC::size(L);
+    using LC = LayerC<SIZE>;
+    constexpr int TWs = (TW - 1) * STEP + (OC::HI - OC::LO) + 1;
+    constexpr int PW = (TWs + STEP - 1) / STEP;
+    constexpr int OFFL = -OC::margin(L) * STEP - OC::LO;          // tile offset of this layer's template origin
+    static_assert(OFFL >= 0, "layer origin outside the tile");
+    // tile index of corner (dy, dx) relative to base = &stile[ry*STEP*STEP*PW + rx]
+#define SV(dy, dx) base[((OFFL + (dy)) * STEP + ((OFFL + (dx)) % STEP)) * PW + (OFFL + (dx)) / STEP]
+    constexpr int c0 = LC::r(0), c1 = LC::r(1), c2 = LC::r(2), c3 = LC::r(3), c4 = LC::r(4), c5 = LC::r(5),
+                  c6 = LC::r(6), c7 = LC::r(7), c8 = LC::r(8), c9 = LC::r(9);
+    constexpr float wx0 = LC::wt(1, 0, 2, 3, 7), wx1 = LC::wt(-2, 3, 2, 6, 7), wx2 = LC::wt(1, 6, 2, 9, 7);
+    constexpr float wy0 = LC::wt(1, 2, 0, 7, 3), wy1 = LC::wt(-2, 2, 3, 7, 6), wy2 = LC::wt(1, 2, 6, 7, 9);
+    constexpr float wd0 = LC::wt(1, 1, 1, 4, 4), wd1 = LC::wt(-1, 5, 1, 8, 4), wd2 = LC::wt(-1, 1, 5, 4, 8), wd3 = LC::wt(1, 5, 5, 8, 8);
+    const LayerPat& lp = op.L[L];
+    const int tid = threadIdx.x;
+#pragma unroll 2
+    for (int sidx = tid; sidx < TW * TH; sidx += NT) {
+        const int ry = sidx / TW, rx = sidx - ry * TW;
+        const int oi = py0 + ry - OC::margin(L), oj = px0 + rx - OC::margin(L);
+        float det = 0.f;
+        if (oi >= 0 && oi < lp.samples_i && oj >= 0 && oj < lp.samples_j) {
+            const int32_t* base = stile + ry * (STEP * STEP * PW) + rx;
+            // Dx: boxes (0,2,3,7,+1) (3,2,6,7,-2) (6,2,9,7,+1)
+            int a0 = SV(c2, c0), a3 = SV(c2, c3), a6 = SV(c2, c6), a9 = SV(c2, c9);
+            int b0 = SV(c7, c0), b3 = SV(c7, c3), b6 = SV(c7, c6), b9 = SV(c7, c9);
+            double d = 0;
+            d += (float)(a0 + b3 - b0 - a3) * wx0;
+            d += (float)(a3 + b6 - b3 - a6) * wx1;
+            d += (float)(a6 + b9 - b6 - a9) * wx2;
+            const float dx = (float)d;
+            // Dy: boxes (2,0,7,3,+1) (2,3,7,6,-2) (2,6,7,9,+1)
+            int e0 = SV(c0, c2), e3 = SV(c3, c2), e6 = SV(c6, c2), e9 = SV(c9, c2);
+            int f0 = SV(c0, c7), f3 = SV(c3, c7), f6 = SV(c6, c7), f9 = SV(c9, c7);
+            d = 0;
+            d += (float)(e0 + f3 - e3 - f0) * wy0;
+            d += (float)(e3 + f6 - e6 - f3) * wy1;
+            d += (float)(e6 + f9 - e9 - f6) * wy2;
+            const float dy = (float)d;
+            // Dxy: boxes (1,1,4,4,+1) (5,1,8,4,-1) (1,5,4,8,-1) (5,5,8,8,+1)
+            int g11 = SV(c1, c1), g14 = SV(c1, c4), g15 = SV(c1, c5), g18 = SV(c1, c8);
+            int g41 = SV(c4, c1), g44 = SV(c4, c4), g45 = SV(c4, c5), g48 = SV(c4, c8);
+            int g51 = SV(c5, c1), g54 = SV(c5, c4), g55 = SV(c5, c5), g58 = SV(c5, c8);
+            int g81 = SV(c8, c1), g84 = SV(c8, c4), g85 = SV(c8, c5), g88 = SV(c8, c8);
+            d = 0;
+            d += (float)(g11 + g44 - g41 - g14) * wd0;
+            d += (float)(g15 + g48 - g45 - g18) * wd1;
+            d += (float)(g51 + g84 - g81 - g54) * wd2;
+            d += (float)(g55 + g88 - g85 - g58) * wd3;
+            const float dxy = (float)d;
+            det = dx * dy - 0.81f * dxy * dxy;
+        }
+        sdet[(L * TH + ry) * TW + rx] = det;
+    }
+#undef SV
+}
+
+template <int O, int TW, int TH, int NT>
+__global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, OctavePat op, float thr, CandOut out)
+{
+    using OC = OctC<O>;
+    constexpr int STEP = OC::STEP;
+    constexpr int TWs = (TW - 1) * STEP + (OC::HI - OC::LO) + 1;
+    constexpr int THs = (TH - 1) * STEP + (OC::HI - OC::LO) + 1;
+    constexpr int PW = (TWs + STEP - 1) / STEP;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, im = blockIdx.z;
+    const int sw = w + 1;
+    const int32_t* __restrict__ gsum = ip.sum[im];
+    float* sdet = reinterpret_cast<float*>(smem);                    // [5][TH][TW]
+    int32_t* stile = reinterpret_cast<int32_t*>(smem + sizeof(float) * 5 * TH * TW);   // [THs][STEP][PW]
+
+    const int px0 = blockIdx.x * (TW - 2) - 1, py0 = blockIdx.y * (TH - 2) - 1;
+    const int sx0 = px0 * STEP + OC::LO, sy0 = py0 * STEP + OC::LO;
+    for (int idx = tid; idx < THs * TWs; idx += NT) {
+        int ty = idx / TWs, tx = idx - ty * TWs;
+        int gy = sy0 + ty, gx = sx0 + tx;
+        int v = 0;
+        if (gy >= 0 && gy <= h && gx >= 0 && gx <= w) v = gsum[(size_t)gy * sw + gx];
+        stile[(ty * STEP + tx % STEP) * PW + tx / STEP] = v;
+    }
+    __syncthreads();
+    det_layer_c<O, 0, TW, TH, NT>(stile, sdet, op, px0, py0);
+    det_layer_c<O, 1, TW, TH, NT>(stile, sdet, op, px0, py0);
+    det_layer_c<O, 2, TW, TH, NT>(stile, sdet, op, px0, py0);
+    det_layer_c<O, 3, TW, TH, NT>(stile, sdet, op, px0, py0);
+    det_layer_c<O, 4, TW, TH, NT>(stile, sdet, op, px0, py0);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int L = 1; L <= 3; L++) {
+        const LayerPat& lp = op.L[L];
+        if (lp.samples_i == 0 || op.L[L + 1].samples_i == 0) continue;
+        const int m = op.nms_margin[L - 1];
+        for (int idx = tid; idx < (TW - 2) * (TH - 2); idx += NT) {
+            int ry = idx / (TW - 2) + 1, rx = idx - (ry - 1) * (TW - 2) + 1;
+            int i = py0 + ry, j = px0 + rx;
+            if (i < m || i >= op.rows - m || j < m || j >= op.cols - m) continue;
+            const float* d2 = sdet + (L * TH + ry) * TW + rx;
+            float val0 = d2[0];
+            if (!(val0 > thr)) continue;
+            const float* d1 = d2 - TH * TW;
+            const float* d3 = d2 + TH * TW;
+            float N9[3][9] = {
+                { d1[-TW-1], d1[-TW], d1[-TW+1], d1[-1], d1[0], d1[1], d1[TW-1], d1[TW], d1[TW+1] },
+                { d2[-TW-1], d2[-TW], d2[-TW+1], d2[-1], d2[0], d2[1], d2[TW-1], d2[TW], d2[TW+1] },
+                { d3[-TW-1], d3[-TW], d3[-TW+1], d3[-1], d3[0], d3[1], d3[TW-1], d3[TW], d3[TW+1] } };
+            bool is_max = true;
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 9; b++)
+                    if (!(a == 1 && b == 4)) is_max = is_max && (val0 > N9[a][b]);
+            if (!is_max) continue;
+            float dx, dy, dxy;
+            {
+                const int ty0 = (i - lp.margin) * STEP - sy0, tx0 = (j - lp.margin) * STEP - sx0;
+                haar_response(lp, [&](int yy, int xx) { int ty = ty0 + yy, tx = tx0 + xx; return stile[(ty * STEP + tx % STEP) * PW + tx / STEP]; },
+                              &dx, &dy, &dxy);
+            }
+            emit_keypoint<STEP>(N9, val0, dx + dy, i, j, lp.size, lp.size - op.L[L - 1].size, op.octave, w, h, im, out);
         }
     }
 }
@@ -468,10 +633,20 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
             const int c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
             int x = start_x + i; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
             float b = 0.f;
-            for (int cc = c_begin; cc < c_end; cc++) {
-                float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
-                int y = start_y - cc; y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
-                b += img[(size_t)y * w + x] * alpha;
+            // taps fetched eight at a time (independent loads in flight), accumulated in order
+            for (int c0 = c_begin; c0 < c_end; c0 += 8) {
+                int v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                    v[q] = img[(size_t)y * w + x];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    int cc = c0 + q;
+                    float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
+                    if (cc < c_end) b += v[q] * alpha;
+                }
             }
             buf[it] = b;
         }
@@ -591,6 +766,29 @@ static hipError_t launch_hessian(Ctx* c, int nimg, const OctavePat& op, float th
     return hipGetLastError();
 }
 
+template <int O, int TW, int TH, int NT>
+static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float thr)
+{
+    using OC = OctC<O>;
+    constexpr int STEP = OC::STEP;
+    constexpr int TWs = (TW - 1) * STEP + (OC::HI - OC::LO) + 1, THs = (TH - 1) * STEP + (OC::HI - OC::LO) + 1;
+    constexpr int PW = (TWs + STEP - 1) / STEP;
+    const int w = c->img_w, h = c->img_h;
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] } };
+    CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
+    const size_t lds = sizeof(float) * 5 * TW * TH + sizeof(int32_t) * (size_t)THs * STEP * PW;
+    dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
+    auto kern = k_hessian_nms_c<O, TW, TH, NT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, c->stream, ip, w, h, op, thr, out);
+    return hipGetLastError();
+}
+
 uvo_status surf_detect(Ctx* c, int nimg)
 {
     const int w = c->img_w, h = c->img_h;
@@ -612,8 +810,8 @@ uvo_status surf_detect(Ctx* c, int nimg)
             OctavePat op;
             make_octave(o, c->p.SURF_OCTAVES_LAYERS, w, h, &op);
             hipError_t e;
-            if (o == 0)      e = launch_hessian<1, true, 64, 32>(c, nimg, op, thr);
-            else if (o == 1) e = launch_hessian<2, true, 32, 32>(c, nimg, op, thr);
+            if (o == 0)      e = launch_hessian_c<0, 64, 32, 512>(c, nimg, op, thr);
+            else if (o == 1) e = launch_hessian_c<1, 32, 16, 512>(c, nimg, op, thr);
             else if (o == 2) e = launch_hessian<4, false, 32, 16>(c, nimg, op, thr);
             else             e = launch_hessian<8, false, 32, 16>(c, nimg, op, thr);
             UVO_HIP_TRY(c, e);

@@ -81,8 +81,10 @@ struct Ctx {
     float4* d_pts4 = nullptr;                    // T homogeneous points
     double* d_cam1 = nullptr;                    // T x 3
     int* d_flag = nullptr;                       // T
-    double* d_good_pts = nullptr;  int* d_good_idx = nullptr;        // G x 3, G
-    float* d_opts = nullptr;  uvo_point2f* d_ipts = nullptr;         // G x 3 f32 object points, G image points
+    // outputs of extract_3Dpoints = inputs of PnP, double-buffered by pipeline slot (pair index & 1)
+    double* d_good_pts[2] = {nullptr, nullptr};  int* d_good_idx[2] = {nullptr, nullptr};     // G x 3, G
+    float* d_opts[2] = {nullptr, nullptr};  uvo_point2f* d_ipts[2] = {nullptr, nullptr};      // G x 3 f32 object points, G image points
+    int* d_tmp_idx = nullptr;                    // extract_3Dpoints scratch
     int* d_counts = nullptr;                     // misc device counters: [0]=T, [1]=G, [2]=n_inliers, ...
     int* h_counts = nullptr;                     // pinned mirror
 
@@ -95,8 +97,16 @@ struct Ctx {
     double* d_refit = nullptr;                   // refit workspace: pws 3n, us 2n, alphas 4n, pcs 3n, tmp n, M 24n, small
     double* d_pose = nullptr;  double* h_pose = nullptr;             // rvec(3) tvec(3)
 
-    // pinned staging for results
-    void* h_stage = nullptr;  size_t h_stage_bytes = 0;
+    // ---- two-stage pipeline: stage A (detect .. extract_3Dpoints) on `stream`, stage B (PnP) on `pnp_stream` ----
+    hipStream_t pnp_stream = nullptr;
+    int* d_countsB = nullptr;  int* h_countsB = nullptr;             // [0] = n_inliers
+    hipEvent_t evA[2] = {nullptr, nullptr};      // stage A of slot s finished (its counts are in h_countsA[s])
+    int* h_countsA[2] = {nullptr, nullptr};      // pinned copies of d_counts per slot
+    struct Pending { bool used = false; bool init_done = false; int slot = 0; uvo_stereo_result res; };
+    Pending pending[2];
+    int n_pending = 0;                           // submitted, not yet collected
+    long long n_submitted = 0, n_collected = 0;
+    int last_slot = 0;
 
     // last-step bookkeeping for uvo_stereo_get
     int last_nL = 0, last_nR = 0, last_M = 0, last_T = 0, last_G = 0, last_ninl = 0;
@@ -111,12 +121,12 @@ struct Ctx {
 // RAII-less stage timer: records events around a launch when timing is on (and synchronises, so
 // timing mode serialises the stream -- bench.py uses it only in its roofline leg).
 struct StageTimer {
-    Ctx* c; int st;
-    StageTimer(Ctx* c_, int st_) : c(c_), st(st_) { if (c->timing) (void)hipEventRecord(c->ev0, c->stream); }
+    Ctx* c; int st; hipStream_t s;
+    StageTimer(Ctx* c_, int st_, hipStream_t s_ = nullptr) : c(c_), st(st_), s(s_ ? s_ : c_->stream) { if (c->timing) (void)hipEventRecord(c->ev0, s); }
     ~StageTimer()
     {
         if (!c->timing) return;
-        (void)hipEventRecord(c->ev1, c->stream);
+        (void)hipEventRecord(c->ev1, s);
         (void)hipEventSynchronize(c->ev1);
         float ms = 0; (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
         c->stage_ms[st] += ms; c->stage_n[st] += 1;
@@ -133,9 +143,9 @@ uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, con
 uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio, uvo_dmatch* d_out, int* d_nout, int out_cap);
 // pose.hip
 uvo_status pose_triangulate(Ctx* c, const double* P1, const double* P2, const int* d_n, int n_max);
-uvo_status pose_extract3d(Ctx* c, const double* R1, const double* t1, const double* R2, const double* t2,
+uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, const double* R2, const double* t2,
                           const double* K1, const double* K2, const int* d_n, int n_max);
-uvo_status pose_pnp_ransac(Ctx* c, int G, const double* K, int iters, float reproj, double conf,
+uvo_status pose_pnp_ransac(Ctx* c, int slot, int G, const double* K, int iters, float reproj, double conf,
                            double* rvec, double* tvec, int* n_inliers, int* ok);
 int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters);
 

@@ -18,7 +18,7 @@ namespace uvo {
 template <int G>
 struct GroupPolicy {
     using Arr = SArr<G>;
-    static constexpr bool kStoreM = false;
+    static constexpr bool kStaged = false;
     __device__ static __forceinline__ int tid() { return threadIdx.x & 7; }
     __device__ static __forceinline__ int nth() { return 8; }
     __device__ static __forceinline__ void sync() { __syncthreads(); }
@@ -26,7 +26,7 @@ struct GroupPolicy {
 // BlockPolicy: one problem per workgroup, plain (stride-1) arrays.
 struct BlockPolicy {
     using Arr = SArr<1>;
-    static constexpr bool kStoreM = true;
+    static constexpr bool kStaged = true;     // long sums are staged through LDS (Epnp::stage)
     __device__ static __forceinline__ int tid() { return threadIdx.x; }
     __device__ static __forceinline__ int nth() { return blockDim.x; }
     __device__ static __forceinline__ void sync() { __syncthreads(); }
@@ -334,7 +334,7 @@ __device__ void jacobi_svd_u_levels(typename P::Arr At, typename P::Arr W_out, t
 // ------------------------------------------------------------------------------------------
 // EPnP.  Fixed-size state lives in `s` (EPNP_SMALL doubles): a common part and one block per beta
 // approximation N = 1..3 (the three run on lanes 0..2 concurrently).  Per-point arrays: pws(3n)
-// us(2n) alphas(4n) pcs(3 x 3n) tmp(3 x n) and, for the block policy, M(24n).
+// us(2n) alphas(4n) pcs(3 x 3n) tmp(3 x n).
 // ------------------------------------------------------------------------------------------
 enum {
     EP_CWS = 0, EP_MTM = 12, EP_D = 156, EP_WT = 168, EP_FLAG = 180, EP_L = 181, EP_RHO = 241,
@@ -350,7 +350,52 @@ struct Epnp {
     using Arr = typename P::Arr;
     double uc, vc, fu, fv;
     int n;
-    Arr pws, us, alphas, pcs, tmp, M, s;      // pcs: 3 branches x 3n, tmp: 3 branches x n
+    Arr pws, us, alphas, pcs, tmp, s;         // pcs: 3 branches x 3n, tmp: 3 branches x n
+    double* stage = nullptr;                  // BlockPolicy: LDS staging buffer of kStageDoubles
+    static constexpr int kStageDoubles = 5120;
+
+    // E independent sequential sums out[e] = (((0 + term(e,0)) + term(e,1)) + ...) over i < n.
+    // Group policy: chain e runs on lane e (mod 8).  Block policy: all threads evaluate the terms of a
+    // chunk in parallel into LDS (coalesced loads), then lane e adds its chunk in index order; the
+    // running sums stay in the lanes' registers across chunks, so the order of additions is the
+    // reference's.
+    template <class TermF, class StoreF>
+    __device__ __forceinline__ void multi_sum(int E, int n_terms, TermF term, StoreF store)
+    {
+        if (!P::kStaged) {
+            for (int ch = P::tid(); ch < E; ch += P::nth()) store(ch, seq_sum(n_terms, [&](int i) { return term(ch, i); }));
+            P::sync();
+        } else {
+            int CH = (kStageDoubles / E - 1) & ~7;
+            if (CH > 512) CH = 512;
+            const int CHS = CH + 1;
+            const int tid = P::tid();
+            double acc = 0;
+            for (int base = 0; base < n_terms; base += CH) {
+                const int cnt = n_terms - base < CH ? n_terms - base : CH;
+                for (int idx = tid; idx < E * cnt; idx += P::nth()) {
+                    int ch = idx / cnt, i = idx - ch * cnt;
+                    stage[ch * CHS + i] = term(ch, base + i);
+                }
+                P::sync();
+                if (tid < E) {
+                    const double* row = stage + tid * CHS;
+                    int i = 0;
+                    for (; i + 8 <= cnt; i += 8) {
+                        double t[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) t[q] = row[i + q];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) acc += t[q];
+                    }
+                    for (; i < cnt; i++) acc += row[i];
+                }
+                P::sync();
+            }
+            if (tid < E) store(tid, acc);
+            P::sync();
+        }
+    }
 
     __device__ __forceinline__ Arr br(int b) const { return s + (EP_BR + b * EPB_SIZE); }
     __device__ __forceinline__ double dot3(Arr a, Arr b) const { return a[0]*b[0] + a[1]*b[1] + a[2]*b[2]; }
@@ -361,7 +406,6 @@ struct Epnp {
     // element (k, c) of the 2n x 12 matrix M of fill_M
     __device__ __forceinline__ double Mval(int k, int c) const
     {
-        if (P::kStoreM) return M[k*12 + c];
         int p = k >> 1, r = k & 1, a = c / 3, q = c - 3*a;
         double as = alphas[4*p + a];
         if (r == 0) return q == 0 ? as * fu : q == 1 ? 0.0 : as * (uc - us[2*p]);
@@ -371,22 +415,18 @@ struct Epnp {
     __device__ void choose_control_points()
     {
         Arr cws = s + EP_CWS, sc = s + EP_SC;
-        for (int j = P::tid(); j < 3; j += P::nth()) {
-            double acc = seq_sum(n, [&](int i) { return pws[3*i + j]; });
-            cws[j] = acc / n;
-        }
-        P::sync();
+        multi_sum(3, n, [&](int j, int i) { return pws[3*i + j]; }, [&](int j, double acc) { cws[j] = acc / n; });
         // PW0^T PW0 (upper triangle, sequential over points), then mirrored
         Arr ptp = sc;                         // 9
-        for (int e = P::tid(); e < 6; e += P::nth()) {
-            int a = e < 3 ? 0 : e < 5 ? 1 : 2;
-            int b = e < 3 ? e : e < 5 ? e - 2 : 2;
-            double ca = cws[a], cb = cws[b];
-            double s0 = seq_sum(n, [&](int k) { return (pws[3*k + a] - ca) * (pws[3*k + b] - cb); });
-            ptp[a*3 + b] = s0;
-            ptp[b*3 + a] = s0;
-        }
-        P::sync();
+        multi_sum(6, n,
+                  [&](int e, int k) {
+                      int a = e < 3 ? 0 : e < 5 ? 1 : 2, b = e < 3 ? e : e < 5 ? e - 2 : 2;
+                      return (pws[3*k + a] - cws[a]) * (pws[3*k + b] - cws[b]);
+                  },
+                  [&](int e, double s0) {
+                      int a = e < 3 ? 0 : e < 5 ? 1 : 2, b = e < 3 ? e : e < 5 ? e - 2 : 2;
+                      ptp[a*3 + b] = s0; ptp[b*3 + a] = s0;
+                  });
         if (P::tid() == 0) {
             Arr at = sc + 9, dc = sc + 18, vt = sc + 21, wt = sc + 30;
             svd_square<3>(ptp, at, dc, vt, wt);       // rows of `at` = U^T = uct
@@ -418,28 +458,56 @@ struct Epnp {
 
     __device__ void build_mtm()
     {
-        if (P::kStoreM) {
-            for (int i = P::tid(); i < n; i += P::nth()) {
-                Arr M1 = M + (2*i)*12, M2 = M + (2*i + 1)*12, as = alphas + 4*i;
-                double u = us[2*i], v = us[2*i + 1];
-                for (int a = 0; a < 4; a++) {
-                    M1[3*a] = as[a] * fu; M1[3*a + 1] = 0.0; M1[3*a + 2] = as[a] * (uc - u);
-                    M2[3*a] = 0.0; M2[3*a + 1] = as[a] * fv; M2[3*a + 2] = as[a] * (vc - v);
-                }
-            }
-            P::sync();
-        }
         Arr mtm = s + EP_MTM;
-        // mulTransposed (MulTransposedR): upper triangle, each entry a sequential sum over the 2n rows
-        for (int e = P::tid(); e < 78; e += P::nth()) {
+        auto entry = [](int e, int* pi, int* pj) {
             int i = 0, rem = e;
             while (rem >= 12 - i) { rem -= 12 - i; i++; }
-            int j = i + rem;
-            double s0 = seq_sum(2*n, [&](int k) { return Mval(k, i) * Mval(k, j); });
-            mtm[i*12 + j] = s0;
-            mtm[j*12 + i] = s0;
+            *pi = i; *pj = i + rem;
+        };
+        // mulTransposed (MulTransposedR): upper triangle, each entry a sequential sum over the 2n rows of M
+        if (!P::kStaged) {
+            multi_sum(78, 2*n,
+                      [&](int e, int k) { int i, j; entry(e, &i, &j); return Mval(k, i) * Mval(k, j); },
+                      [&](int e, double s0) { int i, j; entry(e, &i, &j); mtm[i*12 + j] = s0; mtm[j*12 + i] = s0; });
+        } else {
+            // rows of M (fill_M) are produced chunk-wise into LDS by all threads; lane e < 78 owns entry (i,j)
+            // and walks the rows in order
+            constexpr int PTS = kStageDoubles / 24;            // points per chunk (2 rows of 12 each)
+            const int tid = P::tid();
+            int ei = 0, ej = 0;
+            if (tid < 78) entry(tid, &ei, &ej);
+            double acc = 0;
+            for (int base = 0; base < n; base += PTS) {
+                const int cnt = n - base < PTS ? n - base : PTS;
+                for (int p = tid; p < cnt; p += P::nth()) {
+                    double* M1 = stage + (2*p)*12; double* M2 = M1 + 12;
+                    Arr as = alphas + 4*(base + p);
+                    double u = us[2*(base + p)], v = us[2*(base + p) + 1];
+                    for (int a = 0; a < 4; a++) {
+                        double al = as[a];
+                        M1[3*a] = al * fu; M1[3*a + 1] = 0.0; M1[3*a + 2] = al * (uc - u);
+                        M2[3*a] = 0.0; M2[3*a + 1] = al * fv; M2[3*a + 2] = al * (vc - v);
+                    }
+                }
+                P::sync();
+                if (tid < 78) {
+                    const double* ri = stage + ei; const double* rj = stage + ej;
+                    const int rows = 2*cnt;
+                    int k = 0;
+                    for (; k + 8 <= rows; k += 8) {
+                        double t[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) t[q] = ri[(k + q)*12] * rj[(k + q)*12];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) acc += t[q];
+                    }
+                    for (; k < rows; k++) acc += ri[k*12] * rj[k*12];
+                }
+                P::sync();
+            }
+            if (tid < 78) { mtm[ei*12 + ej] = acc; mtm[ej*12 + ei] = acc; }
+            P::sync();
         }
-        P::sync();
     }
 
     __device__ void compute_L_6x10(Arr ut, Arr l)
@@ -617,23 +685,22 @@ struct Epnp {
             P::sync();
         }
         // estimate_R_and_t: centroids (pw0 does not depend on the branch), 3x3 covariances
-        for (int e = tid; e < 12; e += P::nth()) {
-            if (e < 3) { double acc = seq_sum(n, [&](int i) { return pws[3*i + e]; }); pw0[e] = acc / n; }
-            else {
-                int b = (e - 3) / 3, j = (e - 3) - 3*b;
-                Arr pc = pcs + 3*(b*n);
-                double acc = seq_sum(n, [&](int i) { return pc[3*i + j]; });
-                (br(b) + EPB_PC0)[j] = acc / n;
-            }
-        }
-        P::sync();
-        for (int e = tid; e < 27; e += P::nth()) {
-            int b = e / 9, r = e - 9*b, j = r / 3, q = r - 3*j;
-            Arr pc = pcs + 3*(b*n);
-            double cj = (br(b) + EPB_PC0)[j], wq = pw0[q];
-            (br(b) + EPB_ABT)[r] = seq_sum(n, [&](int i) { return (pc[3*i + j] - cj) * (pws[3*i + q] - wq); });
-        }
-        P::sync();
+        multi_sum(12, n,
+                  [&](int e, int i) {
+                      if (e < 3) return pws[3*i + e];
+                      int b = (e - 3) / 3, j = (e - 3) - 3*b;
+                      return pcs[3*(b*n + i) + j];
+                  },
+                  [&](int e, double acc) {
+                      if (e < 3) pw0[e] = acc / n;
+                      else { int b = (e - 3) / 3, j = (e - 3) - 3*b; (br(b) + EPB_PC0)[j] = acc / n; }
+                  });
+        multi_sum(27, n,
+                  [&](int e, int i) {
+                      int b = e / 9, r = e - 9*b, j = r / 3, q = r - 3*j;
+                      return (pcs[3*(b*n + i) + j] - (br(b) + EPB_PC0)[j]) * (pws[3*i + q] - pw0[q]);
+                  },
+                  [&](int e, double acc) { int b = e / 9, r = e - 9*b; (br(b) + EPB_ABT)[r] = acc; });
         if (tid < 3) {
             Arr B = br(tid), abt = B + EPB_ABT, R = B + EPB_RS, t = B + EPB_TS, pc0 = B + EPB_PC0, sc = B + EPB_SC;
             Arr at = sc, w = sc + 9, vt = sc + 12, wt = sc + 21;
@@ -663,12 +730,7 @@ struct Epnp {
             tmp[it] = sqrt((u - ue)*(u - ue) + (v - ve)*(v - ve));
         }
         P::sync();
-        if (tid < 3) {
-            Arr tb = tmp + tid*n;
-            double sum2 = seq_sum(n, [&](int i) { return tb[i]; });
-            (br(tid) + EPB_REP)[0] = sum2 / n;
-        }
-        P::sync();
+        multi_sum(3, n, [&](int b, int i) { return tmp[b*n + i]; }, [&](int b, double sum2) { (br(b) + EPB_REP)[0] = sum2 / n; });
         if (tid == 0) {
             double rep1 = (br(0) + EPB_REP)[0], rep2 = (br(1) + EPB_REP)[0], rep3 = (br(2) + EPB_REP)[0];
             int N = 1; double repN = rep1;

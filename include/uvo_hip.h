@@ -128,7 +128,13 @@ uvo_status uvo_stereo_set_rig(uvo_ctx* c, const double* K_left, const double* K_
 uvo_status uvo_stereo_reset(uvo_ctx* c);
 uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
                            int mem, double dt, uvo_stereo_result* out);
-/* last step's intermediates for parity tests: "kps_left", "kps_right", "desc_left", "desc_right",
+/* The same step split for throughput: uvo_stereo_submit enqueues the device work of a pair up to
+ * extract_3Dpoints and returns at once; uvo_stereo_collect finishes the OLDEST submitted pair
+ * (PnP-RANSAC, pose) on a second HIP stream.  Up to two pairs may be in flight, so the detector of
+ * pair k+1 overlaps the pose solve of pair k; results are identical to uvo_stereo_step's. */
+uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, int mem);
+uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_result* out);
+/* last step's intermediates for parity tests (only meaningful after a non-pipelined uvo_stereo_step): "kps_left", "kps_right", "desc_left", "desc_right",
  * "matches_stereo", "matches_tri", "points4d", "good_pts", "good_idx", "inliers".
  * Returns the element count, or -(count) if cap_bytes is too small. */
 int        uvo_stereo_get(uvo_ctx* c, const char* what, void* out, int cap_bytes);

@@ -205,3 +205,31 @@ def test_stereo_sequence_parity(ctx, oracle, scene_small):
                 assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
     Rt, tt = synth.true_relative_motion()
     assert np.linalg.norm(np.array(list(r.tvec)) - tt) < 0.01
+
+
+def test_pipelined_submit_collect_equals_step(ctx, scene_small):
+    """uvo_stereo_submit/collect (two pairs in flight on two HIP streams) must give exactly the
+    results of the synchronous uvo_stereo_step."""
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    ctx.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=1500))
+    seq = [scene_small[k] for k in (0, 1, 2, 1, 0, 1, 2)]
+
+    def fields(r):
+        return (r.valid, r.initialized, r.n_left, r.n_right, r.n_stereo_matches, r.n_tri_matches, r.n_good3d, r.n_inliers,
+                tuple(r.rvec), tuple(r.tvec), tuple(r.t_prev_curr), tuple(r.velocity))
+
+    ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    sync = [fields(ctx.stereo_step(L, R, 0.05)) for L, R in seq]
+    ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)      # resets the VO state
+    piped = []
+    ctx.stereo_submit(*seq[0])
+    for i in range(len(seq)):
+        if i + 1 < len(seq):
+            ctx.stereo_submit(*seq[i + 1])
+        piped.append(fields(ctx.stereo_collect(0.05)))
+    assert piped == sync
+    assert sum(f[0] for f in sync) == len(seq) - 1
+    with pytest.raises(uvo.UvoError):
+        ctx.stereo_collect(0.05)                     # nothing in flight

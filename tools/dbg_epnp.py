@@ -21,6 +21,6 @@ for _ in range(5): c.solvePnPRansac(X, x, K)
 t = c.timing()
 print(os.environ.get("UVO_DBG_PHASE"), {k: round(v[0]/max(v[1],1),4) for k,v in t.items() if v[1]})
 '''
-for ph in [0,1,2,3,4,5,6,7,99]:
+for ph in [0,1,2,3,4,5,6,99]:
     env = dict(os.environ, UVO_DBG_PHASE=str(ph))
     subprocess.run([sys.executable, "-c", code], env=env)
