@@ -73,21 +73,18 @@ def main():
     import torch
     import torch.distributed as dist
     import ergo_uvo_amd as uvo
-    from ergo_uvo_amd import synth
+    from ergo_uvo_amd import synth, multirank
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    rank, world = multirank.init("nccl", local_rank)          # "nccl" is RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local_rank)
 
     # ---- synthetic workload (seeded; one independent stream per rank) ----
-    seed = synth.SEEDS["C3"] if world == 1 else synth.SEEDS["C5"] + rank
+    seed = synth.SEEDS["C3"] if world == 1 else multirank.stream_seed(synth.SEEDS["C5"], rank)
     min_hessian = MIN_HESSIAN_C3
     scene = synth.Scene(seed, WIDTH)
     host_frames = [synth.stereo_pair(scene, k, WIDTH, HEIGHT) for k in range(args.frames)]
@@ -98,7 +95,7 @@ def main():
     ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
 
     order = ping_pong(args.frames)
-    records = torch.zeros((max(args.steps, 1), 16), dtype=torch.float64)
+    records = torch.zeros((max(args.steps, 1), multirank.RECORD_WIDTH), dtype=torch.float64)
 
     def step():
         k = next(order)
@@ -115,8 +112,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        multirank.barrier()
         torch.cuda.synchronize()
 
     fence()
@@ -132,20 +128,11 @@ def main():
         r = ctx.stereo_collect(0.05)
         n_valid += r.valid
         kp_sum += r.n_left
-        records[i, 0] = rank; records[i, 1] = i; records[i, 2] = r.valid; records[i, 3] = r.n_inliers
-        records[i, 4:7] = torch.tensor(list(r.rvec)); records[i, 7:10] = torch.tensor(list(r.tvec))
-        records[i, 10:13] = torch.tensor(list(r.t_prev_curr))
-    if world > 1:                                  # pose records of all streams, one RCCL all-gather
-        mine = records.cuda()
-        allrec = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-        dist.all_gather_into_tensor(allrec, mine)
+        records[i] = multirank.make_record(rank, i, r)
+    allrec = multirank.gather_records(records, dev)  # pose records of all streams: one RCCL all-gather (N > 1)
     fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        assert int(allrec[:, 0, 0].sum().item()) == sum(range(world))
+    dt = multirank.max_over_ranks(time.perf_counter() - t0, dev)
+    assert [int(v) for v in allrec[:, 0, 0].tolist()] == list(range(world))
     total_pairs = args.steps * world
     value = total_pairs / dt
 
@@ -208,7 +195,7 @@ def main():
             "cpu_baseline": cpu,
         }
     if world > 1:
-        dist.barrier()
+        multirank.barrier()
         dist.destroy_process_group()
     ctx.close()
     if out is not None:
