@@ -268,3 +268,129 @@ class StereoVO:
             self.close()
         except Exception:
             pass
+
+
+# ------------------------------------------------------------------ mono path
+class MonoResult(C.Structure):
+    _fields_ = [("published", C.c_int), ("valid", C.c_int), ("initialized", C.c_int), ("used_essential", C.c_int),
+                ("success", C.c_int), ("n_kps", C.c_int), ("n_matches", C.c_int), ("n_inliers", C.c_int),
+                ("n_good3d", C.c_int), ("n_front", C.c_int), ("R", C.c_double * 9), ("t", C.c_double * 3),
+                ("SF", C.c_double), ("velocity", C.c_double * 3)]
+
+
+def mono_params(min_hessian=50, method=4) -> VoParams:
+    """mono_VO_parameters.yaml:13-49 (method 4 = LMEDS as shipped, 8 = RANSAC for BASELINE config 4)."""
+    p = VoParams()
+    p.DISTANCE = 10
+    p.LOWE_RATIO_THRESHOLD = 0.7
+    p.ESSENTIAL_OUTLIER_METHOD = method; p.ESSENTIAL_MAX_ITERS = 2000; p.ESSENTIAL_CONFIDENCE = 0.99; p.ESSENTIAL_THRESHOLD = 0.1
+    p.HOMOGRAPHY_OUTLIER_METHOD = method; p.HOMOGRAPHY_MAX_ITERS = 2000; p.HOMOGRAPHY_CONFIDENCE = 0.99
+    p.HOMOGRAPHY_THRESHOLD = 0.1; p.HOMOGRAPHY_DISTANCE = 50.0
+    p.VPF_THRESHOLD = 0.4; p.REPROJECTION_TOLERANCE = 0.1
+    p.MIN_NUM_FEATURES = 20; p.MIN_NUM_INLIERS = 10; p.MIN_NUM_3DPOINTS = 5
+    p.SURF_MIN_HESSIAN = int(min_hessian); p.SURF_OCTAVES_NUMBER = 4; p.SURF_OCTAVES_LAYERS = 3
+    p.SURF_EXTENDED = 0; p.SURF_UPRIGHT = 1
+    return p
+
+
+def solve_poly(coeffs):
+    c = _c(coeffs, np.float64); n = len(c) - 1
+    re = np.empty(n); im = np.empty(n)
+    lib().orc_solve_poly(_p(c), n, _p(re), _p(im))
+    return re + 1j * im
+
+
+def jacobi_eigen(A):
+    A = _c(A, np.float64).copy(); n = A.shape[0]
+    w = np.empty(n); v = np.empty((n, n))
+    lib().orc_jacobi_eigen(_p(A), n, _p(w), _p(v))
+    return w, v
+
+
+def five_point(q1, q2):
+    q1 = _c(q1, np.float64); q2 = _c(q2, np.float64)
+    out = np.empty((10, 9))
+    n = lib().orc_five_point(_p(q1), _p(q2), _p(out))
+    return out[:n].reshape(n, 3, 3).copy()
+
+
+def find_essential_mat(p1, p2, K, method=8, prob=0.99, thr=0.1, max_iters=2000):
+    p1 = _c(p1, np.float32); p2 = _c(p2, np.float32); K = _c(K, np.float64)
+    E = np.zeros((3, 3)); mask = np.zeros(max(len(p1), 1), np.uint8)
+    ok = lib().orc_find_essential_mat(_p(p1), _p(p2), len(p1), _p(K), method, C.c_double(prob), C.c_double(thr), max_iters, _p(E), _p(mask))
+    return bool(ok), E, mask[:len(p1)].copy()
+
+
+def recover_pose(E, p1, p2, K, mask):
+    E = _c(E, np.float64); p1 = _c(p1, np.float32); p2 = _c(p2, np.float32); K = _c(K, np.float64)
+    m = _c(mask, np.uint8).copy(); R = np.empty((3, 3)); t = np.empty(3)
+    g = lib().orc_recover_pose(_p(E), _p(p1), _p(p2), len(p1), _p(K), _p(R), _p(t), _p(m))
+    return g, R, t, m
+
+
+def find_homography(p1, p2, method=8, thr=0.1, max_iters=2000, conf=0.99):
+    p1 = _c(p1, np.float32); p2 = _c(p2, np.float32)
+    H = np.zeros((3, 3)); mask = np.zeros(max(len(p1), 1), np.uint8)
+    ok = lib().orc_find_homography(_p(p1), _p(p2), len(p1), method, C.c_double(thr), max_iters, C.c_double(conf), _p(H), _p(mask))
+    return bool(ok), H, mask[:len(p1)].copy()
+
+
+def decompose_homography(H, K):
+    H = _c(H, np.float64); K = _c(K, np.float64)
+    Rs = np.empty((4, 3, 3)); ts = np.empty((4, 3)); ns = np.empty((4, 3))
+    n = lib().orc_decompose_homography_mat(_p(H), _p(K), _p(Rs), _p(ts), _p(ns))
+    return Rs[:n].copy(), ts[:n].copy(), ns[:n].copy()
+
+
+def recover_pose_homography(H, p1, p2, K, dist=50.0):
+    H = _c(H, np.float64); p1 = _c(p1, np.float32); p2 = _c(p2, np.float32); K = _c(K, np.float64)
+    R = np.full((3, 3), np.nan); t = np.full(3, np.nan)
+    g = lib().orc_recover_pose_homography(_p(H), _p(p1), _p(p2), len(p1), _p(K), C.c_double(dist), _p(R), _p(t))
+    return g, R, t
+
+
+def estimate_relative_pose(params: VoParams, use_essential: bool, p1, p2, K, R0=None, t0=None):
+    p1 = _c(p1, np.float32); p2 = _c(p2, np.float32); K = _c(K, np.float64)
+    n = len(p1)
+    R = np.eye(3) if R0 is None else _c(R0, np.float64).copy()
+    t = np.zeros(3) if t0 is None else _c(t0, np.float64).copy()
+    in1 = np.empty((max(n, 1), 2), np.float32); in2 = np.empty((max(n, 1), 2), np.float32)
+    ue = C.c_int(int(use_essential)); nin = C.c_int(0); mask = np.zeros(max(n, 1), np.uint8)
+    ok = lib().orc_estimate_relative_pose(C.byref(params), C.byref(ue), _p(p1), _p(p2), n, _p(K), _p(R), _p(t), _p(in1), _p(in2),
+                                          C.byref(nin), _p(mask))
+    return bool(ok), bool(ue.value), R, t, in1[:nin.value].copy(), in2[:nin.value].copy(), mask[:n].copy()
+
+
+class MonoVO:
+    def __init__(self, params: VoParams, K, max_kpts=20000):
+        self._K = _c(K, np.float64)
+        self.cap = max_kpts
+        lib().orc_mono_create.restype = C.c_void_p
+        self.h = C.c_void_p(lib().orc_mono_create(C.byref(params), _p(self._K), max_kpts))
+
+    def step(self, img, rng=1.0, dt=0.05) -> MonoResult:
+        img = _c(img, np.uint8)
+        h, w = img.shape
+        r = MonoResult()
+        lib().orc_mono_step.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        lib().orc_mono_step(self.h, _p(img), w, h, w, float(rng), float(dt), C.byref(r))
+        return r
+
+    def get(self, what):
+        spec = {"kps": KP_DTYPE, "matches": DM_DTYPE, "mask": np.dtype("u1"), "good_pts": np.dtype(("f8", 3))}[what]
+        buf = np.zeros(self.cap, spec)
+        lib().orc_mono_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+        n = lib().orc_mono_get(self.h, what.encode(), _p(buf), buf.nbytes)
+        return buf[:max(n, 0)].copy()
+
+    def close(self):
+        if self.h:
+            lib().orc_mono_destroy.argtypes = [C.c_void_p]
+            lib().orc_mono_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -156,6 +156,41 @@ int         orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* r
 /* introspection for parity tests: last step's intermediate arrays */
 int         orc_stereo_get(orc_stereo* s, const char* what, void* out, int cap_bytes);
 
+/* ---- mono path ([UPSTREAM] five-point.cpp, fundam.cpp, levmarq.cpp, homography_decomp.cpp; VOU / VO mono) ---- */
+int    orc_solve_poly(const double* coeffs, int degree, double* roots_re, double* roots_im);
+void   orc_jacobi_eigen(double* A, int n, double* W, double* V);
+int    orc_five_point(const double* q1, const double* q2, double* models /* <= 10 x 9 */);
+void   orc_sampson_error(const double* p1, const double* p2, int n, const double* E, float* err);
+int    orc_find_essential_mat(const orc_point2f* p1, const orc_point2f* p2, int n, const double* K, int method,
+                              double prob, double threshold, int maxIters, double* E, uint8_t* mask);
+void   orc_decompose_essential_mat(const double* E, double* R1, double* R2, double* t);
+int    orc_recover_pose(const double* E, const orc_point2f* p1, const orc_point2f* p2, int n, const double* K,
+                        double* R, double* t, uint8_t* mask);
+int    orc_homography_kernel(const float* M, const float* m, int count, double* H);
+void   orc_homography_error(const float* M, const float* m, int count, const double* H, float* err);
+int    orc_homography_check_subset(const float* ms1, const float* ms2, int count);
+int    orc_find_homography(const orc_point2f* p1, const orc_point2f* p2, int n, int method, double thr, int maxIters,
+                           double confidence, double* H, uint8_t* mask);
+int    orc_decompose_homography_mat(const double* H, const double* K, double* Rs, double* ts, double* ns);
+int    orc_select_estimation_method(const orc_point2f* k1, const orc_point2f* k2, int n, int DISTANCE);
+int    orc_extract_inliers(const orc_point2f* k1, const orc_point2f* k2, const uint8_t* mask, int n, orc_point2f* in1, orc_point2f* in2);
+int    orc_recover_pose_homography(const double* H, const orc_point2f* p1, const orc_point2f* p2, int n, const double* K,
+                                   double HOMOGRAPHY_DISTANCE, double* R, double* t);
+int    orc_estimate_relative_pose(const orc_vo_params* p, int* use_essential, const orc_point2f* k1, const orc_point2f* k2, int n,
+                                  const double* K, double* R, double* t, orc_point2f* in1, orc_point2f* in2, int* n_in, uint8_t* mask_out);
+int    orc_convert_3Dpoints_camera(const double* pts, int n, const double* R, const double* t, double* out);
+double orc_compute_scale_factor(float distance, const double* pts_nx3, int n);
+typedef struct orc_mono orc_mono;
+typedef struct {
+    int published, valid, initialized, used_essential, success;
+    int n_kps, n_matches, n_inliers, n_good3d, n_front;
+    double R[9], t[3], SF, velocity[3];
+} orc_mono_result;
+orc_mono* orc_mono_create(const orc_vo_params* p, const double* K, int max_kpts);
+void      orc_mono_destroy(orc_mono* s);
+int       orc_mono_step(orc_mono* s, const uint8_t* img, int w, int h, int stride, double range, double dt, orc_mono_result* out);
+int       orc_mono_get(orc_mono* s, const char* what, void* out, int cap_bytes);
+
 #ifdef __cplusplus
 }
 #endif

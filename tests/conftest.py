@@ -25,3 +25,12 @@ def scene_small():
     from ergo_uvo_amd import synth
     sc = synth.Scene(123, 640)
     return [synth.stereo_pair(sc, k, 640, 360) for k in range(3)]
+
+
+@pytest.fixture(scope="session")
+def mono_small():
+    """640x360 mono sequence: left views at frames 0, 4, 8 (0.24 m baseline per step so that depth/baseline
+    stays below recoverPose's distance threshold of 50), seeded."""
+    from ergo_uvo_amd import synth
+    sc = synth.Scene(123, 640)
+    return [synth.stereo_pair(sc, k, 640, 360)[0] for k in (0, 4, 8)]
