@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["Params", "Context", "StereoResult", "UvoError", "KP_DTYPE", "DM_DTYPE", "build"]
+__all__ = ["Params", "Context", "StereoResult", "MonoResult", "UvoError", "KP_DTYPE", "DM_DTYPE", "build"]
 
 build = _lib.build
 
@@ -70,6 +70,13 @@ class StereoResult(C.Structure):
                 ("n_stereo_matches", C.c_int), ("n_tri_matches", C.c_int), ("n_good3d", C.c_int),
                 ("n_inliers", C.c_int), ("rvec", C.c_double * 3), ("tvec", C.c_double * 3),
                 ("t_prev_curr", C.c_double * 3), ("velocity", C.c_double * 3)]
+
+
+class MonoResult(C.Structure):
+    _fields_ = [("published", C.c_int), ("valid", C.c_int), ("initialized", C.c_int), ("used_essential", C.c_int),
+                ("success", C.c_int), ("n_kps", C.c_int), ("n_matches", C.c_int), ("n_inliers", C.c_int),
+                ("n_good3d", C.c_int), ("n_front", C.c_int), ("R", C.c_double * 9), ("t", C.c_double * 3),
+                ("SF", C.c_double), ("velocity", C.c_double * 3)]
 
 
 def _is_device(a) -> bool:
@@ -269,6 +276,78 @@ class Context:
         if what == "points4d":
             out = np.ascontiguousarray(out.T)       # 4 x T like cv::triangulatePoints
         return out
+
+    # ------------------------------------------------------------------ mono relative pose (VO_utility.cpp:134-180)
+    def findEssentialMat(self, pts1, pts2, K, method=8, prob=0.99, threshold=1.0, max_iters=1000):
+        p1, p2, K = _np(pts1, np.float32), _np(pts2, np.float32), _np(K, np.float64)
+        n = len(p1)
+        E = np.zeros((3, 3)); mask = np.zeros(max(n, 1), np.uint8); ok = C.c_int(0)
+        self._check(self._lib.uvo_find_essential_mat(self._h, _p(p1), _p(p2), n, _p(K), int(method), C.c_double(prob), C.c_double(threshold),
+                                                     int(max_iters), _p(E), _p(mask), C.byref(ok)))
+        return bool(ok.value), E, mask[:n].copy()
+
+    def recoverPose(self, E, pts1, pts2, K, mask):
+        E, p1, p2, K = _np(E, np.float64), _np(pts1, np.float32), _np(pts2, np.float32), _np(K, np.float64)
+        m = _np(mask, np.uint8).copy(); R = np.empty((3, 3)); t = np.empty(3); good = C.c_int(0)
+        self._check(self._lib.uvo_recover_pose(self._h, _p(E), _p(p1), _p(p2), len(p1), _p(K), _p(R), _p(t), _p(m), C.byref(good)))
+        return good.value, R, t, m
+
+    def findHomography(self, pts1, pts2, method=8, threshold=3.0, max_iters=2000, confidence=0.995):
+        p1, p2 = _np(pts1, np.float32), _np(pts2, np.float32)
+        n = len(p1)
+        H = np.zeros((3, 3)); mask = np.zeros(max(n, 1), np.uint8); ok = C.c_int(0)
+        self._check(self._lib.uvo_find_homography(self._h, _p(p1), _p(p2), n, int(method), C.c_double(threshold), int(max_iters),
+                                                  C.c_double(confidence), _p(H), _p(mask), C.byref(ok)))
+        return bool(ok.value), H, mask[:n].copy()
+
+    def decomposeHomographyMat(self, H, K):
+        H, K = _np(H, np.float64), _np(K, np.float64)
+        Rs = np.empty((4, 3, 3)); ts = np.empty((4, 3)); ns = np.empty((4, 3)); n = C.c_int(0)
+        st = self._lib.uvo_decompose_homography_mat(_p(H), _p(K), _p(Rs), _p(ts), _p(ns), C.byref(n))
+        if st != 0:
+            raise UvoError(st, "uvo_decompose_homography_mat")
+        return Rs[:n.value].copy(), ts[:n.value].copy(), ns[:n.value].copy()
+
+    def recover_pose_homography(self, H, pts1, pts2, K):
+        H, p1, p2, K = _np(H, np.float64), _np(pts1, np.float32), _np(pts2, np.float32), _np(K, np.float64)
+        R = np.full((3, 3), np.nan); t = np.full(3, np.nan); g = C.c_int(0)
+        self._check(self._lib.uvo_recover_pose_homography(self._h, _p(H), _p(p1), _p(p2), len(p1), _p(K), _p(R), _p(t), C.byref(g)))
+        return g.value, R, t
+
+    def select_estimation_method(self, pts1, pts2, distance=None) -> bool:
+        p1, p2 = _np(pts1, np.float32), _np(pts2, np.float32)
+        d = int(self.params.DISTANCE if distance is None else distance)
+        return bool(self._lib.uvo_select_estimation_method(_p(p1), _p(p2), len(p1), d))
+
+    def estimate_relative_pose(self, pts1, pts2, K, use_essential=True, R0=None, t0=None):
+        p1, p2, K = _np(pts1, np.float32), _np(pts2, np.float32), _np(K, np.float64)
+        n = len(p1)
+        R = np.eye(3) if R0 is None else _np(R0, np.float64).copy()
+        t = np.zeros(3) if t0 is None else _np(t0, np.float64).copy()
+        in1 = np.empty((max(n, 1), 2), np.float32); in2 = np.empty((max(n, 1), 2), np.float32)
+        ue, nin, succ = C.c_int(int(use_essential)), C.c_int(0), C.c_int(0)
+        mask = np.zeros(max(n, 1), np.uint8)
+        self._check(self._lib.uvo_estimate_relative_pose(self._h, _p(p1), _p(p2), n, _p(K), C.byref(ue), _p(R), _p(t), _p(in1), _p(in2),
+                                                         C.byref(nin), _p(mask), C.byref(succ)))
+        return bool(succ.value), bool(ue.value), R, t, in1[:nin.value].copy(), in2[:nin.value].copy(), mask[:n].copy()
+
+    # ------------------------------------------------------------------ mono loop (visual_odometry.h:167-398)
+    def mono_set_camera(self, K):
+        K = _np(K, np.float64)
+        self._check(self._lib.uvo_mono_set_camera(self._h, _p(K)))
+
+    def mono_step(self, img, range_=1.0, dt: float = 0.05) -> MonoResult:
+        h, w = img.shape[-2], img.shape[-1]
+        p, mem, keep = _ptr_mem(img, np.uint8)
+        r = MonoResult()
+        self._check(self._lib.uvo_mono_step(self._h, p, w, h, w, mem, C.c_double(range_), C.c_double(dt), C.byref(r)))
+        return r
+
+    def mono_get(self, what: str):
+        spec = {"kps": KP_DTYPE, "matches": DM_DTYPE, "mask": np.dtype("u1"), "good_pts": np.dtype(("f8", 3))}[what]
+        buf = np.zeros(self.max_kpts, spec)
+        n = self._lib.uvo_mono_get(self._h, what.encode(), _p(buf), buf.nbytes)
+        return buf[:max(n, 0)].copy()
 
     # ------------------------------------------------------------------ timing
     def timing_enable(self, on: bool = True):

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <math.h>
 #include <new>
+#include <algorithm>
 
 using namespace uvo;
 
@@ -121,6 +122,7 @@ extern "C" void uvo_ctx_destroy(uvo_ctx* c)
         (void)hipFree(c->d_as_kpsL[i]); (void)hipFree(c->d_as_kpsR[i]); (void)hipFree(c->d_as_descL[i]);
     }
     if (c->pnp_stream) (void)hipStreamSynchronize(c->pnp_stream);
+    mono_ws_free(c);
     void* ptrs[] = { c->d_colpart, c->d_DW, c->d_rank, c->d_big_list, c->d_mpart, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
                      c->d_flag, c->d_tmp_idx, c->d_good_pts[0], c->d_good_pts[1], c->d_good_idx[0], c->d_good_idx[1], c->d_opts[0], c->d_opts[1],
                      c->d_ipts[0], c->d_ipts[1], c->d_counts, c->d_countsB, c->d_subsets, c->d_models,
@@ -390,15 +392,6 @@ __global__ void k_gather_desc_idx(const float* src, int nsrc, const int* idx, in
     reinterpret_cast<float4*>(dst + (size_t)row * 64)[sub] = v;
 }
 
-// compute_projection_matrix (VOU:9-15): K * [R|t]
-static void projection_matrix(const double* R, const double* t, const double* K, double* P)
-{
-    double Rt[12];
-    for (int i = 0; i < 3; i++) { Rt[i*4] = R[i*3]; Rt[i*4+1] = R[i*3+1]; Rt[i*4+2] = R[i*3+2]; Rt[i*4+3] = t[i]; }
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++)
-        P[i*4 + j] = K[i*3]*Rt[j] + K[i*3+1]*Rt[4 + j] + K[i*3+2]*Rt[8 + j];
-}
-
 extern "C" uvo_status uvo_stereo_set_rig(uvo_ctx* c, const double* K_left, const double* K_right, const double* R_right, const double* t_right)
 {
     if (!c || !K_left || !K_right || !R_right || !t_right) return UVO_INVALID_ARG;
@@ -610,6 +603,245 @@ extern "C" int uvo_stereo_get(uvo_ctx* c, const char* what, void* out, int cap_b
     if (count) {
         if (hipMemcpy(out, src, (size_t)count * esz, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     }
+    return count;
+}
+
+
+// ------------------------------------------------------------------------------------------ mono path
+extern "C" uvo_status uvo_find_essential_mat(uvo_ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K, int method,
+                                             double prob, double threshold, int max_iters, double* E, uint8_t* mask, int* ok)
+{
+    if (!c || !p1 || !p2 || !K || !E || !mask || !ok || n < 0 || (method != 4 && method != 8)) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    return mono_find_essential(c, p1, p2, n, K, method, prob, threshold, max_iters, E, mask, ok);
+}
+extern "C" uvo_status uvo_recover_pose(uvo_ctx* c, const double* E, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K,
+                                       double* R, double* t, uint8_t* mask, int* good)
+{
+    if (!c || !E || !p1 || !p2 || !K || !R || !t || !mask || !good || n < 0) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    return mono_recover_pose(c, E, p1, p2, n, K, R, t, mask, good);
+}
+extern "C" uvo_status uvo_find_homography(uvo_ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, int method, double threshold,
+                                          int max_iters, double confidence, double* H, uint8_t* mask, int* ok)
+{
+    if (!c || !p1 || !p2 || !H || !mask || !ok || n < 0 || (method != 4 && method != 8)) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    return mono_find_homography(c, p1, p2, n, method, threshold, max_iters, confidence, H, mask, ok);
+}
+extern "C" uvo_status uvo_decompose_homography_mat(const double* H, const double* K, double* Rs, double* ts, double* ns, int* n_solutions)
+{
+    if (!H || !K || !Rs || !ts || !ns || !n_solutions) return UVO_INVALID_ARG;
+    *n_solutions = decompose_homography_mat(H, K, Rs, ts, ns);
+    return UVO_OK;
+}
+extern "C" uvo_status uvo_recover_pose_homography(uvo_ctx* c, const double* H, const uvo_point2f* p1, const uvo_point2f* p2, int n,
+                                                  const double* K, double* R, double* t, int* max_good)
+{
+    if (!c || !H || !p1 || !p2 || !K || !R || !t || !max_good || n < 0) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    return mono_recover_pose_homography(c, H, p1, p2, n, K, c->p.HOMOGRAPHY_DISTANCE, R, t, max_good);
+}
+
+// MU:65-86 compute_median
+static double compute_median(std::vector<double> v)
+{
+    size_t size = v.size();
+    if (size == 0) return 0.0;
+    std::sort(v.begin(), v.end());
+    if (size % 2 == 0) { size_t mid = size / 2; return (v[mid - 1] + v[mid]) / 2.0; }
+    return v[size / 2];
+}
+// select_estimation_method (VOU:725-748): 1 = essential, 0 = homography
+extern "C" int uvo_select_estimation_method(const uvo_point2f* k1, const uvo_point2f* k2, int n, int distance)
+{
+    std::vector<double> d(n > 0 ? n : 0);
+    for (int i = 0; i < n; i++) { double dx = k1[i].x - k2[i].x, dy = k1[i].y - k2[i].y; d[i] = sqrt(dx * dx + dy * dy); }
+    return compute_median(d) < distance ? 0 : 1;
+}
+// extract_inliers (VOU:306-329)
+static int extract_inliers(const uvo_point2f* k1, const uvo_point2f* k2, const uint8_t* mask, int n, uvo_point2f* in1, uvo_point2f* in2)
+{
+    int k = 0;
+    for (int i = 0; i < n; i++) if (mask[i] != 0) { in1[k] = k1[i]; in2[k] = k2[i]; k++; }
+    return k;
+}
+// estimate_relative_pose (VOU:134-180).  use_essential is the reference's global (in/out); R, t are in/out.
+extern "C" uvo_status uvo_estimate_relative_pose(uvo_ctx* c, const uvo_point2f* k1, const uvo_point2f* k2, int n, const double* K,
+                                                 int* use_essential, double* R, double* t, uvo_point2f* in1, uvo_point2f* in2, int* n_in,
+                                                 uint8_t* mask, int* success)
+{
+    if (!c || !k1 || !k2 || !K || !use_essential || !R || !t || !in1 || !in2 || !n_in || !mask || !success || n <= 0) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    const uvo_params& p = c->p;
+    if ((p.ESSENTIAL_OUTLIER_METHOD != 4 && p.ESSENTIAL_OUTLIER_METHOD != 8) || (p.HOMOGRAPHY_OUTLIER_METHOD != 4 && p.HOMOGRAPHY_OUTLIER_METHOD != 8))
+        return fail(c, UVO_INVALID_ARG, "outlier methods must be 4 (LMEDS) or 8 (RANSAC)");
+    bool estimate_completed = false, switch_method = false;
+    *success = 0;
+    while (!estimate_completed) {
+        int valid_inliers = 0, ok = 0;
+        memset(mask, 0, n);
+        if (*use_essential) {
+            double E[9];
+            UVO_TRY(mono_find_essential(c, k1, k2, n, K, p.ESSENTIAL_OUTLIER_METHOD, p.ESSENTIAL_CONFIDENCE, p.ESSENTIAL_THRESHOLD,
+                                        (int)p.ESSENTIAL_MAX_ITERS, E, mask, &ok));
+            *n_in = extract_inliers(k1, k2, mask, n, in1, in2);
+            int good = 0;
+            if (ok) UVO_TRY(mono_recover_pose(c, E, k1, k2, n, K, R, t, mask, &good));
+            else memset(mask, 0, n);          // OpenCV would throw on the empty E; the attempt simply fails here
+        } else {
+            double H[9];
+            UVO_TRY(mono_find_homography(c, k1, k2, n, p.HOMOGRAPHY_OUTLIER_METHOD, p.HOMOGRAPHY_THRESHOLD, (int)p.HOMOGRAPHY_MAX_ITERS,
+                                         p.HOMOGRAPHY_CONFIDENCE, H, mask, &ok));
+            *n_in = extract_inliers(k1, k2, mask, n, in1, in2);
+            int good = 0;
+            if (ok) UVO_TRY(mono_recover_pose_homography(c, H, k1, k2, n, K, p.HOMOGRAPHY_DISTANCE, R, t, &good));
+        }
+        for (int i = 0; i < n; i++) valid_inliers += mask[i] != 0;
+        double valid_point_fraction = (double)valid_inliers / n;
+        if (valid_point_fraction >= p.VPF_THRESHOLD && valid_inliers >= p.MIN_NUM_INLIERS) { *success = 1; estimate_completed = true; }
+        else {
+            if (switch_method) break;
+            switch_method = true;
+            *use_essential = !*use_essential;
+        }
+    }
+    return UVO_OK;
+}
+
+extern "C" uvo_status uvo_mono_set_camera(uvo_ctx* c, const double* K)
+{
+    if (!c || !K) return UVO_INVALID_ARG;
+    memcpy(c->mono_K, K, sizeof(c->mono_K));
+    c->mono_cam_set = true;
+    return uvo_mono_reset(c);
+}
+extern "C" uvo_status uvo_mono_reset(uvo_ctx* c)
+{
+    if (!c) return UVO_INVALID_ARG;
+    c->mono_initialized = false; c->mono_use_essential = 1; c->mono_SF = 1.0; c->mono_n_prev = 0;
+    const double I[9] = {1,0,0,0,1,0,0,0,1};
+    memcpy(c->mono_R, I, sizeof(I)); c->mono_t[0] = c->mono_t[1] = c->mono_t[2] = 0;
+    c->mono_prev_kps.clear(); c->mono_kps.clear(); c->mono_matches.clear(); c->mono_mask.clear(); c->mono_good_pts.clear();
+    return UVO_OK;
+}
+
+// mono loop body, visual_odometry_node::mono_VO (visual_odometry.h:227-245 init, 247-397 main loop, 126-140 output)
+extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h, int stride, int mem, double range, double dt,
+                                    uvo_mono_result* out)
+{
+    if (!c || !img || !out) return UVO_INVALID_ARG;
+    if (!c->mono_cam_set) return fail(c, UVO_INVALID_ARG, "uvo_mono_set_camera has not been called");
+    (void)hipSetDevice(c->device);
+    const uvo_params& p = c->p;
+    memset(out, 0, sizeof(*out));
+    c->mono_matches.clear(); c->mono_mask.clear(); c->mono_good_pts.clear();
+    UVO_TRY(surf_upload(c, 0, img, w, h, stride, mem));
+    UVO_TRY(surf_detect(c, 1));                                                            // VO:238 / VO:274
+    UVO_TRY(read_counts(c));
+    UVO_TRY(check_cand_overflow(c, 1));
+    const int n = c->h_counts[CN_NL];
+    out->n_kps = n;
+    c->mono_kps.resize(n);
+    if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->mono_kps.data(), c->det[0].kps, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    auto roll_state = [&]() -> uvo_status {                                                // VO:279-282 / VO:392-395
+        if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->d_as_descL[0], c->det[0].desc, sizeof(float) * 64 * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->mono_prev_kps = c->mono_kps; c->mono_n_prev = n;
+        return UVO_OK;
+    };
+    if (!c->mono_initialized) {                                                            // VO:227-245
+        UVO_TRY(roll_state());
+        if (n >= p.MIN_NUM_FEATURES) c->mono_initialized = true;
+        return UVO_OK;
+    }
+    out->initialized = 1;
+    if (n < p.MIN_NUM_FEATURES) return roll_state();                                       // VO:276-284
+    // match_features 7-arg (VO:287 -> VOU:551-573)
+    int M = 0;
+    if (c->mono_n_prev > 0 && n > 0) {
+        UVO_TRY(match_knn2(c, c->d_as_descL[0], nullptr, c->mono_n_prev, c->det[0].desc, nullptr, n));
+        UVO_TRY(match_ratio_compact(c, nullptr, c->mono_n_prev, (float)p.LOWE_RATIO_THRESHOLD, c->d_matches[0], c->d_nmatch, c->cap));
+        UVO_TRY(read_counts(c));
+        M = c->h_counts[CN_M];
+        if (M > c->cap) return fail(c, UVO_CAPACITY, "match count exceeds max_kpts");
+        c->mono_matches.resize(M);
+        if (M) UVO_HIP_TRY(c, hipMemcpyAsync(c->mono_matches.data(), c->d_matches[0], sizeof(uvo_dmatch) * M, hipMemcpyDeviceToHost, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    out->n_matches = M;
+    if (M < p.MIN_NUM_FEATURES) return roll_state();                                       // VO:299-307
+    std::vector<uvo_point2f> k1(M), k2(M), in1(M), in2(M);
+    for (int i = 0; i < M; i++) {                                                          // VOU:567-568
+        const uvo_keypoint& a = c->mono_prev_kps[c->mono_matches[i].queryIdx]; const uvo_keypoint& b = c->mono_kps[c->mono_matches[i].trainIdx];
+        k1[i] = uvo_point2f{a.x, a.y}; k2[i] = uvo_point2f{b.x, b.y};
+    }
+    c->mono_use_essential = uvo_select_estimation_method(k1.data(), k2.data(), M, p.DISTANCE);   // VO:310-317
+    int n_in = 0, success = 0;
+    c->mono_mask.assign(M, 0);
+    UVO_TRY(uvo_estimate_relative_pose(c, k1.data(), k2.data(), M, c->mono_K, &c->mono_use_essential, c->mono_R, c->mono_t,
+                                       in1.data(), in2.data(), &n_in, c->mono_mask.data(), &success));             // VO:323
+    out->success = success; out->used_essential = c->mono_use_essential; out->n_inliers = n_in;
+    int valid = success ? 1 : 0;                                                           // VO:335-344
+    if (success) {                                                                         // VO:351-376
+        const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
+        double P_prev[12], P_curr[12];
+        projection_matrix(I, z, c->mono_K, P_prev);
+        projection_matrix(c->mono_R, c->mono_t, c->mono_K, P_curr);
+        int G = 0;
+        if (n_in > 0) {
+            UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x1, in1.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, c->stream));
+            UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x2, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, c->stream));
+            UVO_HIP_TRY(c, hipMemcpyAsync(c->d_xc, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, c->stream));
+            UVO_TRY(pose_triangulate(c, P_prev, P_curr, nullptr, n_in));                   // VO:355
+            UVO_TRY(pose_extract3d(c, 0, I, z, c->mono_R, c->mono_t, c->mono_K, c->mono_K, nullptr, n_in));   // VO:356
+            UVO_TRY(read_counts(c));
+            G = c->h_counts[CN_G];
+            c->mono_good_pts.resize((size_t)3 * G);
+            if (G) UVO_HIP_TRY(c, hipMemcpyAsync(c->mono_good_pts.data(), c->d_good_pts[0], sizeof(double) * 3 * G, hipMemcpyDeviceToHost, c->stream));
+            UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        out->n_good3d = G;
+        if (G < p.MIN_NUM_3DPOINTS) valid = 0;                                             // VO:358
+        else {
+            // convert_3Dpoints_camera (VOU:46-63): the ORIGINAL rows whose transformed z is positive
+            std::vector<double> zs;
+            const double* R = c->mono_R; const double* t = c->mono_t;
+            for (int i = 0; i < G; i++) {
+                const double* q = &c->mono_good_pts[3 * (size_t)i];
+                double zt = (R[6]*q[0] + R[7]*q[1] + R[8]*q[2]) * 1.0 + t[2] * 1.0;
+                if (zt > 0) zs.push_back(q[2]);
+            }
+            out->n_front = (int)zs.size();
+            if (!zs.empty()) c->mono_SF = (float)range / compute_median(zs);               // compute_scale_factor (VOU:23-38)
+            else valid = 0;
+        }
+    }
+    // mono_output_computation (VO:126-140): -SF * R^T * t / dt as one gemm with alpha = (-SF) * (1/dt)
+    double alpha = (-c->mono_SF) * (1.0 / dt);
+    for (int i = 0; i < 3; i++) {
+        double acc = 0;
+        for (int k = 0; k < 3; k++) acc += c->mono_R[k*3 + i] * c->mono_t[k];
+        out->velocity[i] = acc * alpha;
+    }
+    out->published = 1; out->valid = valid; out->SF = c->mono_SF;
+    memcpy(out->R, c->mono_R, sizeof(out->R)); memcpy(out->t, c->mono_t, sizeof(out->t));
+    return roll_state();
+}
+
+extern "C" int uvo_mono_get(uvo_ctx* c, const char* what, void* out, int cap_bytes)
+{
+    if (!c || !what || !out) return 0;
+    const void* src = nullptr; size_t nb = 0; int count = 0;
+    std::string w(what);
+    if (w == "kps") { src = c->mono_kps.data(); count = (int)c->mono_kps.size(); nb = (size_t)count * sizeof(uvo_keypoint); }
+    else if (w == "matches") { src = c->mono_matches.data(); count = (int)c->mono_matches.size(); nb = (size_t)count * sizeof(uvo_dmatch); }
+    else if (w == "mask") { src = c->mono_mask.data(); count = (int)c->mono_mask.size(); nb = (size_t)count; }
+    else if (w == "good_pts") { src = c->mono_good_pts.data(); count = (int)c->mono_good_pts.size() / 3; nb = (size_t)count * 3 * sizeof(double); }
+    else return 0;
+    if (nb > (size_t)cap_bytes) return -count;
+    if (nb) memcpy(out, src, nb);
     return count;
 }
 

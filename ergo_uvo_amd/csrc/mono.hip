@@ -1,0 +1,1080 @@
+// mono.hip -- the mono node's relative-pose stage on gfx950 (replaces estimate_relative_pose and what it
+// calls, VO_utility.cpp:134-180: cv::findEssentialMat + cv::recoverPose, cv::findHomography +
+// recover_pose_homography (cv::decomposeHomographyMat, cv::triangulatePoints), VO_utility.cpp:581-624).
+//
+// Same scheme as the PnP stage: the host replays cv::RNG to produce OpenCV's exact sample subsets
+// (including HomographyEstimatorCallback::checkSubset), ALL hypotheses are solved and scored on the
+// device in parallel, and the host replays the sequential RANSAC ("better than best => shrink niters")
+// or LMedS ("smaller median wins") scan to pick the identical winner.  Small sequential fp64 pieces
+// (homography refit + Levenberg-Marquardt polish, decomposeHomographyMat) stay on the host as
+// SURVEY.md 2.3 (K5, K6) plans.
+//   k_fivepoint_hyp : one 5-point hypothesis per wave (Nister/Stewenius as in OpenCV's five-point.cpp)
+//   k_e_score       : Sampson error of every (hypothesis, model) over all matches -> inlier count or median
+//   k_h_hyp         : one normalised-DLT homography per thread (9x9 Jacobi eigen in LDS)
+//   k_h_score       : reprojection error -> inlier count or median
+//   k_model_mask    : mask of the winning model
+//   k_recover_pose  : cheirality test of the 4 (R,t) candidates
+#include "uvo_ctx.h"
+#include "uvo_mono.h"
+#include "uvo_epnp.h"
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <algorithm>
+
+namespace uvo {
+
+// ------------------------------------------------------------------------------------------
+// five-point solver (device)
+// ------------------------------------------------------------------------------------------
+// monomial order of the 20 columns: x^3 y^3 x^2y xy^2 x^2z x^2 y^2z y^2 xyz xy | xz^2 xz x yz^2 yz y z^3 z^2 z 1
+__device__ const signed char kMono[20][3] = {
+    {3,0,0},{0,3,0},{2,1,0},{1,2,0},{2,0,1},{2,0,0},{0,2,1},{0,2,0},{1,1,1},{1,1,0},
+    {1,0,2},{1,0,1},{1,0,0},{0,1,2},{0,1,1},{0,1,0},{0,0,3},{0,0,2},{0,0,1},{0,0,0} };
+__device__ __forceinline__ int mono_index(int a, int b, int c)
+{
+    for (int i = 0; i < 20; i++) if (kMono[i][0] == a && kMono[i][1] == b && kMono[i][2] == c) return i;
+    return 19;
+}
+__device__ void p_zero(double* p) { for (int i = 0; i < 20; i++) p[i] = 0; }
+// out = a * b (out must not alias a or b); products of total degree > 3 never occur
+__device__ void p_mul(const double* a, const double* b, double* out)
+{
+    p_zero(out);
+    for (int i = 0; i < 20; i++) {
+        double ai = a[i];
+        if (ai == 0) continue;
+        for (int j = 0; j < 20; j++) {
+            double bj = b[j];
+            if (bj == 0) continue;
+            int e0 = kMono[i][0] + kMono[j][0], e1 = kMono[i][1] + kMono[j][1], e2 = kMono[i][2] + kMono[j][2];
+            if (e0 + e1 + e2 > 3) continue;
+            out[mono_index(e0, e1, e2)] += ai * bj;
+        }
+    }
+}
+__device__ void p_axpy(double* y, double a, const double* x) { for (int i = 0; i < 20; i++) y[i] += a * x[i]; }
+
+struct cplx { double re, im; };
+__device__ __forceinline__ cplx c_mul(cplx a, cplx b) { return cplx{ a.re*b.re - a.im*b.im, a.re*b.im + a.im*b.re }; }
+__device__ __forceinline__ cplx c_sub(cplx a, cplx b) { return cplx{ a.re - b.re, a.im - b.im }; }
+__device__ __forceinline__ cplx c_add(cplx a, cplx b) { return cplx{ a.re + b.re, a.im + b.im }; }
+__device__ __forceinline__ cplx c_div(cplx a, cplx b)
+{
+    double t = 1./(b.re*b.re + b.im*b.im);
+    return cplx{ (a.re*b.re + a.im*b.im)*t, (-a.re*b.im + a.im*b.re)*t };
+}
+// cv::solvePoly, real coefficients c[0..10] (increasing powers), 300 Durand-Kerner iterations
+__device__ void solve_poly10(const double* c0, double* rre, double* rim)
+{
+    const int n0 = 10;
+    cplx coeffs[11], roots[10];
+    int n = n0, i, j, iter;
+    for (i = 0; i <= n; i++) { coeffs[i].re = c0[i]; coeffs[i].im = 0; }
+    for (; n > 1; n--) if (fabs(coeffs[n].re) + fabs(coeffs[n].im) > DBL_EPSILON) break;
+    cplx p{1, 0}, r{1, 1};
+    for (i = 0; i < n; i++) { roots[i] = p; p = c_mul(p, r); }
+#pragma unroll 1
+    for (iter = 0; iter < 300; iter++) {
+        double maxDiff = 0;
+#pragma unroll 1
+        for (i = 0; i < n; i++) {
+            p = roots[i];
+            cplx num = coeffs[n], denom = coeffs[n];
+#pragma unroll 1
+            for (j = 0; j < n; j++) {
+                num = c_add(c_mul(num, p), coeffs[n-j-1]);
+                if (j != i) {
+                    cplx df = c_sub(p, roots[j]);
+                    if (df.re != 0 || df.im != 0) denom = c_mul(denom, df);
+                }
+            }
+            num = c_div(num, denom);
+            roots[i] = c_sub(p, num);
+            double a = sqrt(num.re*num.re + num.im*num.im);
+            if (a > maxDiff) maxDiff = a;
+        }
+        if (maxDiff <= 0) break;
+    }
+    for (i = 0; i < n; i++) if (fabs(roots[i].im) < 1e-100) roots[i].im = 0;
+    for (; n < n0; n++) roots[n] = roots[n-1];
+    for (i = 0; i < n0; i++) { rre[i] = roots[i].re; rim[i] = roots[i].im; }
+}
+__device__ void pz_mul(const double* a, int da, const double* b, int db, double* out)
+{
+    for (int i = 0; i <= da + db; i++) out[i] = 0;
+    for (int i = 0; i <= da; i++) for (int j = 0; j <= db; j++) out[i + j] += a[i] * b[j];
+}
+
+// LDS layout of one hypothesis (doubles)
+enum { FP_AT = 0, FP_W = 81, FP_WT = 90, FP_V5 = 99, FP_E = 124, FP_EET = 304, FP_TR = 484, FP_A = 504, FP_LANE = 704,
+       FP_AL = 1904, FP_AINV = 2004, FP_AR = 2104, FP_AP = 2204, FP_B = 2304, FP_C = 2343, FP_ROOTS = 2354, FP_RT = 2374,
+       FP_CAND = 2704, FP_FLAG = 2794, FP_TOTAL = 2808 };
+
+__global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const double* q2, const int* subsets, int nhyp,
+                                                      double* models /* nhyp x 10 x 9 */, int* nmodels)
+{
+    __shared__ double S[FP_TOTAL];
+    __shared__ int s_piv, s_sing;
+    const int hyp = blockIdx.x, lane = threadIdx.x;
+    using A1 = SArr<1>;
+    double* At = S + FP_AT;
+    // ---- Q (5 x 9) in the first five rows of the 9 x 9 buffer, rest zero ----
+    for (int i = lane; i < 81; i += 64) At[i] = 0;
+    __syncthreads();
+    if (lane < 5) {
+        int id = subsets[hyp * 5 + lane];
+        double x1 = q1[2*id], y1 = q1[2*id+1], x2 = q2[2*id], y2 = q2[2*id+1];
+        double* r = At + lane * 9;
+        r[0] = x2*x1; r[1] = x2*y1; r[2] = x2; r[3] = y2*x1; r[4] = y2*y1; r[5] = y2; r[6] = x1; r[7] = y1; r[8] = 1.0;
+    }
+    __syncthreads();
+    // SVD::compute(Q, FULL_UV): rows 5..8 of Vt = JacobiSVD's completion = null-space basis
+    if (lane == 0) jacobi_svd_rt(A1{At}, A1{S + FP_W}, A1{S + FP_V5}, A1{S + FP_WT}, 9, 5, 9);
+    __syncthreads();
+    const double* EE = At + 45;                                   // 4 x 9
+    double* Ep = S + FP_E;                                         // E[9][20]
+    double* EEt = S + FP_EET;                                      // [9][20]
+    double* tr = S + FP_TR;
+    double* Amat = S + FP_A;                                       // 10 x 20
+    double* L = S + FP_LANE + (lane < 10 ? lane : 0) * 120;        // private: 6 polys
+    if (lane < 9) {                                                // p_lin
+        double* p = Ep + lane * 20;
+        p_zero(p);
+        p[12] = EE[0*9 + lane]; p[15] = EE[1*9 + lane]; p[18] = EE[2*9 + lane]; p[19] = EE[3*9 + lane];
+    }
+    __syncthreads();
+#define EPOLY(i, j) (Ep + ((i)*3 + (j)) * 20)
+    if (lane < 9) {                                                // (E E^T)(i,j)
+        int i = lane / 3, j = lane - 3*i;
+        double* acc = EEt + lane * 20; double* t = L;
+        p_zero(acc);
+        for (int k = 0; k < 3; k++) { p_mul(EPOLY(i, k), EPOLY(j, k), t); p_axpy(acc, 1.0, t); }
+    } else if (lane == 9) {                                        // det(E) -> row 0
+        double *m0 = L, *m1 = L + 20, *m2 = L + 40, *t = L + 60, *d = L + 80;
+        p_mul(EPOLY(1,1), EPOLY(2,2), m0); p_mul(EPOLY(1,2), EPOLY(2,1), t); p_axpy(m0, -1.0, t);
+        p_mul(EPOLY(1,0), EPOLY(2,2), m1); p_mul(EPOLY(1,2), EPOLY(2,0), t); p_axpy(m1, -1.0, t);
+        p_mul(EPOLY(1,0), EPOLY(2,1), m2); p_mul(EPOLY(1,1), EPOLY(2,0), t); p_axpy(m2, -1.0, t);
+        p_mul(EPOLY(0,0), m0, d);
+        p_mul(EPOLY(0,1), m1, t); p_axpy(d, -1.0, t);
+        p_mul(EPOLY(0,2), m2, t); p_axpy(d, 1.0, t);
+        for (int k = 0; k < 20; k++) Amat[k] = d[k];
+    }
+    __syncthreads();
+    if (lane == 0) { p_zero(tr); for (int i = 0; i < 3; i++) p_axpy(tr, 1.0, EEt + (i*3 + i) * 20); }
+    __syncthreads();
+    if (lane < 9) {                                                // 2 E E^T E - trace(E E^T) E
+        int i = lane / 3, j = lane - 3*i;
+        double* acc = L + 20; double* t = L;
+        p_zero(acc);
+        for (int k = 0; k < 3; k++) { p_mul(EEt + (i*3 + k) * 20, EPOLY(k, j), t); p_axpy(acc, 2.0, t); }
+        p_mul(tr, EPOLY(i, j), t); p_axpy(acc, -1.0, t);
+        for (int k = 0; k < 20; k++) Amat[(1 + lane) * 20 + k] = acc[k];
+    }
+#undef EPOLY
+    __syncthreads();
+    // ---- A = inv(A[:, :10]) * A[:, 10:]  (LU with partial pivoting, eps = 100*DBL_EPSILON, then gemm) ----
+    double *Al = S + FP_AL, *Ainv = S + FP_AINV, *Ar = S + FP_AR, *Ap = S + FP_AP;
+    for (int e = lane; e < 100; e += 64) { int i = e / 10, j = e - 10*i; Al[e] = Amat[i*20 + j]; Ar[e] = Amat[i*20 + 10 + j]; Ainv[e] = i == j; }
+    if (lane == 0) s_sing = 0;
+    __syncthreads();
+    for (int i = 0; i < 10; i++) {
+        if (lane == 0) {
+            int k = i;
+            for (int j = i+1; j < 10; j++) if (fabs(Al[j*10 + i]) > fabs(Al[k*10 + i])) k = j;
+            s_piv = k;
+            if (fabs(Al[k*10 + i]) < DBL_EPSILON * 100) s_sing = 1;
+        }
+        __syncthreads();
+        if (s_sing) break;
+        int k = s_piv;
+        if (k != i && lane < 10) {
+            if (lane >= i) { double t = Al[i*10 + lane]; Al[i*10 + lane] = Al[k*10 + lane]; Al[k*10 + lane] = t; }
+            double t = Ainv[i*10 + lane]; Ainv[i*10 + lane] = Ainv[k*10 + lane]; Ainv[k*10 + lane] = t;
+        }
+        __syncthreads();
+        double d = -1/Al[i*10 + i];
+        int j = i + 1 + lane;
+        if (j < 10) {
+            double alpha = Al[j*10 + i]*d;
+            for (int kk = i+1; kk < 10; kk++) Al[j*10 + kk] += alpha*Al[i*10 + kk];
+            for (int kk = 0; kk < 10; kk++) Ainv[j*10 + kk] += alpha*Ainv[i*10 + kk];
+        }
+        __syncthreads();
+    }
+    if (!s_sing) {
+        for (int i = 9; i >= 0; i--) {
+            if (lane < 10) {
+                double s = Ainv[i*10 + lane];
+                for (int k = i+1; k < 10; k++) s -= Al[i*10 + k]*Ainv[k*10 + lane];
+                Ainv[i*10 + lane] = s/Al[i*10 + i];
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int e = lane; e < 100; e += 64) Ainv[e] = 0;            // invert() of a singular matrix yields zeros
+        __syncthreads();
+    }
+    for (int e = lane; e < 100; e += 64) {
+        int i = e / 10, j = e - 10*i;
+        double s = 0;
+        for (int k = 0; k < 10; k++) s += Ainv[i*10 + k] * Ar[k*10 + j];
+        Ap[e] = s;
+    }
+    __syncthreads();
+    double* b = S + FP_B;                                           // 3 x 13
+    if (lane < 3) {
+        const double* a1 = Ap + (lane*2 + 4) * 10; const double* a2 = Ap + (lane*2 + 5) * 10;
+        double row1[13], row2[13];
+        for (int k = 0; k < 13; k++) row1[k] = row2[k] = 0;
+        for (int k = 0; k < 3; k++) { row1[1 + k] = a1[k]; row1[5 + k] = a1[3 + k]; }
+        for (int k = 0; k < 4; k++) row1[9 + k] = a1[6 + k];
+        for (int k = 0; k < 3; k++) { row2[k] = a2[k]; row2[4 + k] = a2[3 + k]; }
+        for (int k = 0; k < 4; k++) row2[8 + k] = a2[6 + k];
+        for (int k = 0; k < 13; k++) b[lane*13 + k] = row1[k] - row2[k];
+    }
+    __syncthreads();
+    double* rre = S + FP_ROOTS; double* rim = rre + 10;
+    if (lane == 0) {                                                // det B(z) and its roots
+        double e[3][3][5], c[11], t1[12], t2[12], m[12];
+        for (int r = 0; r < 3; r++) {
+            for (int k = 0; k < 4; k++) { e[r][0][k] = b[r*13 + 3 - k]; e[r][1][k] = b[r*13 + 7 - k]; }
+            e[r][0][4] = e[r][1][4] = 0;
+            for (int k = 0; k < 5; k++) e[r][2][k] = b[r*13 + 12 - k];
+        }
+        for (int k = 0; k < 11; k++) c[k] = 0;
+        pz_mul(e[1][1], 3, e[2][2], 4, t1); pz_mul(e[1][2], 4, e[2][1], 3, t2);
+        for (int k = 0; k <= 7; k++) m[k] = t1[k] - t2[k];
+        pz_mul(e[0][0], 3, m, 7, t1); for (int k = 0; k <= 10; k++) c[k] += t1[k];
+        pz_mul(e[1][0], 3, e[2][2], 4, t1); pz_mul(e[1][2], 4, e[2][0], 3, t2);
+        for (int k = 0; k <= 7; k++) m[k] = t1[k] - t2[k];
+        pz_mul(e[0][1], 3, m, 7, t1); for (int k = 0; k <= 10; k++) c[k] -= t1[k];
+        pz_mul(e[1][0], 3, e[2][1], 3, t1); pz_mul(e[1][1], 3, e[2][0], 3, t2);
+        for (int k = 0; k <= 6; k++) m[k] = t1[k] - t2[k];
+        pz_mul(e[0][2], 4, m, 6, t1); for (int k = 0; k <= 10; k++) c[k] += t1[k];
+        solve_poly10(c, rre, rim);
+    }
+    __syncthreads();
+    double* cand = S + FP_CAND; double* flag = S + FP_FLAG;
+    if (lane < 10) {                                                // one real root per lane
+        flag[lane] = 0;
+        if (!(fabs(rim[lane]) > 1e-10)) {
+            double z1 = rre[lane], z2 = z1*z1, z3 = z2*z1, z4 = z3*z1;
+            double* R = S + FP_RT + lane * 33;                      // bz 9 | at 9 | w 3 | vt 9 | wt 3
+            for (int j = 0; j < 3; j++) {
+                const double* br = b + j*13;
+                R[j*3 + 0] = br[0]*z3 + br[1]*z2 + br[2]*z1 + br[3];
+                R[j*3 + 1] = br[4]*z3 + br[5]*z2 + br[6]*z1 + br[7];
+                R[j*3 + 2] = br[8]*z4 + br[9]*z3 + br[10]*z2 + br[11]*z1 + br[12];
+            }
+            svd_square<3>(A1{R}, A1{R + 9}, A1{R + 18}, A1{R + 21}, A1{R + 30});
+            const double* vt = R + 21;
+            if (!(fabs(vt[8]) < 1e-10)) {
+                double xs = vt[6] / vt[8], ys = vt[7] / vt[8];
+                double Ev[9], nrm = 0;
+                for (int k = 0; k < 9; k++) Ev[k] = EE[0*9 + k]*xs + EE[1*9 + k]*ys + EE[2*9 + k]*z1 + EE[3*9 + k];
+                for (int k = 0; k < 9; k++) nrm += Ev[k]*Ev[k];
+                nrm = sqrt(nrm);
+                for (int k = 0; k < 9; k++) cand[lane*9 + k] = Ev[k] / nrm;
+                flag[lane] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int count = 0;
+        double* out = models + (size_t)hyp * 90;
+        for (int i = 0; i < 10; i++) if (flag[i] != 0) { for (int k = 0; k < 9; k++) out[count*9 + k] = cand[i*9 + k]; count++; }
+        nmodels[hyp] = count;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// scoring: one workgroup per (hypothesis, model); mode 0 = inlier count (RANSAC), 1 = median (LMedS)
+// ------------------------------------------------------------------------------------------
+__device__ void block_sort_median(float* s_err, int n, int npow2, double* out)
+{
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int k = 2; k <= npow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow2; i += nt) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    float a = s_err[i], b = s_err[ixj];
+                    bool up = (i & k) == 0;
+                    if ((a > b) == up) { s_err[i] = b; s_err[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) *out = n % 2 != 0 ? (double)s_err[n/2] : (s_err[n/2 - 1] + s_err[n/2]) * 0.5;
+}
+
+__global__ __launch_bounds__(256) void k_e_score(const double* q1, const double* q2, int n, const double* models, const int* nmodels,
+                                                 int mode, float thr2, int npow2, int* counts, double* medians)
+{
+    extern __shared__ float s_err[];
+    __shared__ int s_cnt;
+    const int m = blockIdx.x, hyp = blockIdx.y, tid = threadIdx.x;
+    if (m >= nmodels[hyp]) return;
+    double E[9];
+    for (int k = 0; k < 9; k++) E[k] = models[(size_t)hyp * 90 + m * 9 + k];
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = tid; i < (mode ? npow2 : n); i += 256) {
+        float e = INFINITY;
+        if (i < n) e = sampson_error1(E, q1[2*i], q1[2*i+1], q2[2*i], q2[2*i+1]);
+        if (mode) s_err[i] = e; else cnt += (i < n && e <= thr2) ? 1 : 0;
+    }
+    if (mode == 0) {
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+        if ((tid & 63) == 0) atomicAdd(&s_cnt, cnt);
+        __syncthreads();
+        if (tid == 0) counts[hyp * 10 + m] = s_cnt;
+    } else {
+        __syncthreads();
+        block_sort_median(s_err, n, npow2, &medians[hyp * 10 + m]);
+    }
+}
+
+static const int kHHypThreads = 32;
+__global__ __launch_bounds__(kHHypThreads) void k_h_hyp(const float* src, const float* dst, const int* subsets, int nhyp,
+                                                        double* models /* nhyp x 9 */, int* nmodels)
+{
+    __shared__ double lds[171 * kHHypThreads];
+    __shared__ int ilds[18 * kHHypThreads];
+    const int hyp = blockIdx.x * kHHypThreads + threadIdx.x;
+    if (hyp >= nhyp) return;
+    float M[8], m[8];
+    for (int i = 0; i < 4; i++) {
+        int id = subsets[hyp * 4 + i];
+        M[2*i] = src[2*id]; M[2*i+1] = src[2*id+1]; m[2*i] = dst[2*id]; m[2*i+1] = dst[2*id+1];
+    }
+    using A = SArr<kHHypThreads>;
+    struct IArr { int* p; __device__ int& operator[](int i) const { return p[i * kHHypThreads]; } __device__ IArr operator+(int o) const { return IArr{p + o * kHHypThreads}; } };
+    A base{lds + threadIdx.x};
+    double H[9];
+    int ok = homography_kernel(M, m, 4, H, base, base + 81, base + 90, IArr{ilds + threadIdx.x});
+    nmodels[hyp] = ok;
+    if (ok) for (int k = 0; k < 9; k++) models[(size_t)hyp * 9 + k] = H[k];
+}
+
+__global__ __launch_bounds__(256) void k_h_score(const float* src, const float* dst, int n, const double* models, const int* nmodels,
+                                                 int mode, float thr2, int npow2, int* counts, double* medians)
+{
+    extern __shared__ float s_err[];
+    __shared__ int s_cnt;
+    const int hyp = blockIdx.x, tid = threadIdx.x;
+    if (nmodels[hyp] <= 0) return;
+    float Hf[8];
+    for (int k = 0; k < 8; k++) Hf[k] = (float)models[(size_t)hyp * 9 + k];
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (int i = tid; i < (mode ? npow2 : n); i += 256) {
+        float e = INFINITY;
+        if (i < n) e = homography_error1(Hf, src[2*i], src[2*i+1], dst[2*i], dst[2*i+1]);
+        if (mode) s_err[i] = e; else cnt += (i < n && e <= thr2) ? 1 : 0;
+    }
+    if (mode == 0) {
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+        if ((tid & 63) == 0) atomicAdd(&s_cnt, cnt);
+        __syncthreads();
+        if (tid == 0) counts[hyp] = s_cnt;
+    } else {
+        __syncthreads();
+        block_sort_median(s_err, n, npow2, &medians[hyp]);
+    }
+}
+
+// findInliers for one model: kind 0 = essential (q1,q2 doubles), 1 = homography (floats)
+__global__ void k_model_mask(int kind, const double* q1, const double* q2, const float* src, const float* dst, int n,
+                             const double* model, float thr2, uint8_t* mask)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float e;
+    if (kind == 0) e = sampson_error1(model, q1[2*i], q1[2*i+1], q2[2*i], q2[2*i+1]);
+    else { float Hf[8]; for (int k = 0; k < 8; k++) Hf[k] = (float)model[k]; e = homography_error1(Hf, src[2*i], src[2*i+1], dst[2*i], dst[2*i+1]); }
+    mask[i] = (uint8_t)(e <= thr2);
+}
+
+// recoverPose: candidate c = blockIdx.y, triangulatePoints (double points) + the cheirality / distance tests
+struct PoseCands { double P[4][12]; };
+static const int kRpThreads = 64;
+__global__ __launch_bounds__(kRpThreads) void k_recover_pose(const double* q1, const double* q2, int n, PoseCands pc, const uint8_t* mask_in,
+                                                             uint8_t* masks /* 4 x n */, int* good /* 4 */)
+{
+    __shared__ double lds[(16 + 16 + 16 + 4 + 4) * kRpThreads];
+    const int c = blockIdx.y, i = blockIdx.x * kRpThreads + threadIdx.x;
+    if (i >= n) return;
+    using A = SArr<kRpThreads>;
+    A Am{lds + threadIdx.x}, At = Am + 16, Vt = Am + 32, W = Am + 48, Wt = Am + 52;
+    const double* P = pc.P[c];
+    const double xa = q1[2*i], ya = q1[2*i+1], xb = q2[2*i], yb = q2[2*i+1];
+    // P0 = [I | 0]
+    Am[0] = xa*0. - 1.; Am[1] = xa*0. - 0.; Am[2] = xa*1. - 0.; Am[3] = xa*0. - 0.;
+    Am[4] = ya*0. - 0.; Am[5] = ya*0. - 1.; Am[6] = ya*1. - 0.; Am[7] = ya*0. - 0.;
+    for (int k = 0; k < 4; k++) { Am[8 + k] = xb * P[8 + k] - P[k]; Am[12 + k] = yb * P[8 + k] - P[4 + k]; }
+    svd_square<4>(Am, At, W, Vt, Wt);
+    double X = Vt[12], Y = Vt[13], Z = Vt[14], Wv = Vt[15];
+    const double distanceThresh = 50;
+    bool m = Z * Wv > 0;
+    X /= Wv; Y /= Wv; Z /= Wv; Wv /= Wv;
+    m = (Z < distanceThresh) && m;
+    double z2 = P[8]*X + P[9]*Y + P[10]*Z + P[11]*Wv;
+    m = (z2 > 0) && m;
+    m = (z2 < distanceThresh) && m;
+    m = m && mask_in[i];
+    masks[(size_t)c * n + i] = m ? 1 : 0;
+    if (m) atomicAdd(&good[c], 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct MonoWs {                       // device workspace of the mono stage, owned by the context
+    double *q1 = nullptr, *q2 = nullptr;           // normalised points (cap x 2)
+    float *src = nullptr, *dst = nullptr;          // pixel points (cap x 2)
+    int* subsets = nullptr;                        // kMaxHyp x 5
+    double* models = nullptr;                      // kMaxHyp x 10 x 9
+    int* nmodels = nullptr;                        // kMaxHyp
+    int* counts = nullptr;  double* medians = nullptr;   // kMaxHyp x 10
+    uint8_t* masks = nullptr;                      // 5 x cap
+    int* good = nullptr;                           // 4
+    double* best = nullptr;                        // 9
+    std::vector<int> h_subsets, h_nmodels, h_counts;
+    std::vector<double> h_medians, h_models;
+};
+
+static MonoWs* mono_ws(Ctx* c)
+{
+    if (c->mono_ws) return static_cast<MonoWs*>(c->mono_ws);
+    MonoWs* w = new MonoWs();
+    size_t cap = (size_t)c->cap;
+    bool ok = hipMalloc((void**)&w->q1, sizeof(double) * 2 * cap) == hipSuccess && hipMalloc((void**)&w->q2, sizeof(double) * 2 * cap) == hipSuccess &&
+              hipMalloc((void**)&w->src, sizeof(float) * 2 * cap) == hipSuccess && hipMalloc((void**)&w->dst, sizeof(float) * 2 * cap) == hipSuccess &&
+              hipMalloc((void**)&w->subsets, sizeof(int) * kMaxHyp * 5) == hipSuccess &&
+              hipMalloc((void**)&w->models, sizeof(double) * kMaxHyp * 90) == hipSuccess &&
+              hipMalloc((void**)&w->nmodels, sizeof(int) * kMaxHyp) == hipSuccess &&
+              hipMalloc((void**)&w->counts, sizeof(int) * kMaxHyp * 10) == hipSuccess &&
+              hipMalloc((void**)&w->medians, sizeof(double) * kMaxHyp * 10) == hipSuccess &&
+              hipMalloc((void**)&w->masks, 5 * cap) == hipSuccess && hipMalloc((void**)&w->good, sizeof(int) * 4) == hipSuccess &&
+              hipMalloc((void**)&w->best, sizeof(double) * 9) == hipSuccess;
+    if (!ok) { delete w; return nullptr; }
+    w->h_subsets.resize(kMaxHyp * 5); w->h_nmodels.resize(kMaxHyp); w->h_counts.resize(kMaxHyp * 10);
+    w->h_medians.resize(kMaxHyp * 10); w->h_models.resize((size_t)kMaxHyp * 90);
+    c->mono_ws = w;
+    return w;
+}
+void mono_ws_free(Ctx* c)
+{
+    MonoWs* w = static_cast<MonoWs*>(c->mono_ws);
+    if (!w) return;
+    void* ptrs[] = { w->q1, w->q2, w->src, w->dst, w->subsets, w->models, w->nmodels, w->counts, w->medians, w->masks, w->good, w->best };
+    for (void* p : ptrs) (void)hipFree(p);
+    delete w;
+    c->mono_ws = nullptr;
+}
+
+static int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+
+// HomographyEstimatorCallback::checkSubset (host, on the sampled points)
+static bool have_collinear_points(const float* m, int count)
+{
+    int j, k, i = count - 1;
+    for (j = 0; j < i; j++) {
+        double dx1 = m[2*j] - m[2*i], dy1 = m[2*j+1] - m[2*i+1];
+        for (k = 0; k < j; k++) {
+            double dx2 = m[2*k] - m[2*i], dy2 = m[2*k+1] - m[2*i+1];
+            if (fabs(dx2*dy1 - dy2*dx1) <= FLT_EPSILON*(fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2))) return true;
+        }
+    }
+    return false;
+}
+static double det3d(double a0, double a1, double a2, double a3, double a4, double a5, double a6, double a7, double a8)
+{
+    return a0*(a4*a8 - a5*a7) - a1*(a3*a8 - a5*a6) + a2*(a3*a7 - a4*a6);
+}
+static bool h_check_subset(const float* ms1, const float* ms2, int count)
+{
+    if (have_collinear_points(ms1, count) || have_collinear_points(ms2, count)) return false;
+    if (count == 4) {
+        static const int tt[4][3] = {{0, 1, 2}, {1, 2, 3}, {0, 2, 3}, {0, 1, 3}};
+        int negative = 0;
+        for (int i = 0; i < 4; i++) {
+            const int* t = tt[i];
+            double dA = det3d(ms1[2*t[0]], ms1[2*t[0]+1], 1., ms1[2*t[1]], ms1[2*t[1]+1], 1., ms1[2*t[2]], ms1[2*t[2]+1], 1.);
+            double dB = det3d(ms2[2*t[0]], ms2[2*t[0]+1], 1., ms2[2*t[1]], ms2[2*t[1]+1], 1., ms2[2*t[2]], ms2[2*t[2]+1], 1.);
+            negative += dA*dB < 0;
+        }
+        if (negative != 0 && negative != 4) return false;
+    }
+    return true;
+}
+
+// getSubset replay for `niters` iterations.  Returns the number of subsets produced (< niters only when an
+// attempt budget ran out; *failed_first tells whether that happened on the first iteration).
+static int make_subsets(int* out, int niters, int model_points, int count, int maxAttempts,
+                        const float* src, const float* dst, bool* failed_first)
+{
+    uint64_t state = (uint64_t)-1;
+    *failed_first = false;
+    for (int it = 0; it < niters; it++) {
+        int* idx = out + it * model_points;
+        bool found = false;
+        for (int iters = 0; iters < maxAttempts && !found; ++iters) {
+            float ms1[8], ms2[8];
+            for (int i = 0; i < model_points; ++i) {
+                int idx_i;
+                for (;;) {
+                    idx_i = (int)(rng_next(state) % (uint32_t)count);
+                    bool dup = false;
+                    for (int q = 0; q < i; q++) dup = dup || idx[q] == idx_i;
+                    if (!dup) break;
+                }
+                idx[i] = idx_i;
+                if (src) { ms1[2*i] = src[2*idx_i]; ms1[2*i+1] = src[2*idx_i+1]; ms2[2*i] = dst[2*idx_i]; ms2[2*i+1] = dst[2*idx_i+1]; }
+            }
+            found = !src || h_check_subset(ms1, ms2, model_points);
+        }
+        if (!found) { if (it == 0) *failed_first = true; return it; }
+    }
+    return niters;
+}
+
+// sequential replays over the device scores
+struct Winner { int hyp = -1, model = 0; double min_median = DBL_MAX; int max_good = 0; };
+static Winner replay_ransac(const int* nmodels, const int* counts, int stride, int nsub, int niters0, int count, int modelPoints, double confidence)
+{
+    Winner w; int niters = niters0;
+    for (int iter = 0; iter < niters && iter < nsub; iter++) {
+        for (int i = 0; i < nmodels[iter]; i++) {
+            int goodCount = counts[iter * stride + i];
+            if (goodCount > (w.max_good > modelPoints - 1 ? w.max_good : modelPoints - 1)) {
+                w.hyp = iter; w.model = i; w.max_good = goodCount;
+                niters = ransac_update_num_iters(confidence, (double)(count - goodCount) / count, modelPoints, niters);
+            }
+        }
+    }
+    return w;
+}
+static Winner replay_lmeds(const int* nmodels, const double* medians, int stride, int nsub)
+{
+    Winner w;
+    for (int iter = 0; iter < nsub; iter++)
+        for (int i = 0; i < nmodels[iter]; i++) {
+            double median = medians[iter * stride + i];
+            if (median < w.min_median) { w.min_median = median; w.hyp = iter; w.model = i; }
+        }
+    return w;
+}
+
+// cv::findEssentialMat on host points (VOU:147)
+uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K, int method,
+                               double prob, double threshold, int maxIters, double* E, uint8_t* mask, int* ok)
+{
+    *ok = 0;
+    memset(mask, 0, n);
+    if (n > c->cap) { c->err = "point count exceeds the context's max_kpts"; return UVO_CAPACITY; }
+    MonoWs* w = mono_ws(c);
+    if (!w) { c->err = "mono workspace allocation failed"; return UVO_HIP_ERROR; }
+    const int modelPoints = 5;
+    if (n < modelPoints) return UVO_OK;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double ax = 1. / fx, bx = -cx * ax, ay = 1. / fy, by = -cy * ay;
+    std::vector<double> q1(2 * (size_t)n), q2(2 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        q1[2*i] = p1[i].x * ax + bx; q1[2*i+1] = p1[i].y * ay + by;
+        q2[2*i] = p2[i].x * ax + bx; q2[2*i+1] = p2[i].y * ay + by;
+    }
+    threshold /= (fx + fy) / 2;
+    hipStream_t st = c->stream;
+    UVO_HIP_TRY(c, hipMemcpyAsync(w->q1, q1.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
+    UVO_HIP_TRY(c, hipMemcpyAsync(w->q2, q2.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
+    const bool lmeds = method != 8;
+    int niters;
+    if (n == modelPoints) niters = 1;
+    else if (lmeds) { niters = ransac_update_num_iters(prob, 0.45, modelPoints, maxIters); niters = niters > 3 ? niters : 3; }
+    else niters = maxIters > 1 ? maxIters : 1;
+    if (niters > kMaxHyp) { c->err = "max_iters exceeds the compiled hypothesis capacity (2048)"; return UVO_CAPACITY; }
+    bool failed_first = false;
+    int nsub;
+    if (n == modelPoints) { for (int i = 0; i < 5; i++) w->h_subsets[i] = i; nsub = 1; }
+    else nsub = make_subsets(w->h_subsets.data(), niters, modelPoints, n, lmeds ? 1000 : 10000, nullptr, nullptr, &failed_first);
+    UVO_HIP_TRY(c, hipMemcpyAsync(w->subsets, w->h_subsets.data(), sizeof(int) * 5 * nsub, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_fivepoint_hyp, dim3(nsub), dim3(64), 0, st, w->q1, w->q2, w->subsets, nsub, w->models, w->nmodels);
+    UVO_HIP_TRY(c, hipGetLastError());
+    if (n == modelPoints) {
+        UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data(), w->nmodels, sizeof(int), hipMemcpyDeviceToHost, st));
+        UVO_HIP_TRY(c, hipMemcpyAsync(E, w->models, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
+        UVO_HIP_TRY(c, hipStreamSynchronize(st));
+        if (w->h_nmodels[0] <= 0) return UVO_OK;
+        memset(mask, 1, n); *ok = 1;
+        return UVO_OK;
+    }
+    const int npow2 = next_pow2(n);
+    const float thr2 = (float)(threshold * threshold);
+    hipLaunchKernelGGL(k_e_score, dim3(10, nsub), dim3(256), lmeds ? sizeof(float) * npow2 : 0, st, w->q1, w->q2, n, w->models, w->nmodels,
+                       lmeds ? 1 : 0, thr2, npow2, w->counts, w->medians);
+    UVO_HIP_TRY(c, hipGetLastError());
+    UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data(), w->nmodels, sizeof(int) * nsub, hipMemcpyDeviceToHost, st));
+    if (lmeds) UVO_HIP_TRY(c, hipMemcpyAsync(w->h_medians.data(), w->medians, sizeof(double) * 10 * nsub, hipMemcpyDeviceToHost, st));
+    else UVO_HIP_TRY(c, hipMemcpyAsync(w->h_counts.data(), w->counts, sizeof(int) * 10 * nsub, hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipStreamSynchronize(st));
+    Winner win = lmeds ? replay_lmeds(w->h_nmodels.data(), w->h_medians.data(), 10, nsub)
+                       : replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 10, nsub, niters, n, modelPoints, prob);
+    if (win.hyp < 0) return UVO_OK;
+    double final_thr = threshold;
+    if (lmeds) {
+        double sigma = 2.5 * 1.4826 * (1 + 5. / (n - modelPoints)) * sqrt(win.min_median);
+        final_thr = sigma > 0.001 ? sigma : 0.001;
+    }
+    const double* best = w->models + (size_t)win.hyp * 90 + win.model * 9;
+    hipLaunchKernelGGL(k_model_mask, dim3((n + 255) / 256), dim3(256), 0, st, 0, w->q1, w->q2, nullptr, nullptr, n, best,
+                       (float)(final_thr * final_thr), w->masks);
+    UVO_HIP_TRY(c, hipGetLastError());
+    UVO_HIP_TRY(c, hipMemcpyAsync(mask, w->masks, n, hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipMemcpyAsync(E, best, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipStreamSynchronize(st));
+    if (lmeds) { int good = 0; for (int i = 0; i < n; i++) good += mask[i]; *ok = good >= modelPoints; }
+    else *ok = 1;
+    return UVO_OK;
+}
+
+// decomposeEssentialMat (host; 3x3 Jacobi SVD)
+static void decompose_essential(const double* E, double* R1, double* R2, double* t)
+{
+    double Ein[9], at[9], w[3], vt[9], wt[3], U[9], Vt[9];
+    memcpy(Ein, E, sizeof(Ein));
+    svd_square<3>(SArr<1>{Ein}, SArr<1>{at}, SArr<1>{w}, SArr<1>{vt}, SArr<1>{wt});
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { U[i*3 + j] = at[j*3 + i]; Vt[i*3 + j] = vt[i*3 + j]; }
+    if (det3(U) < 0) for (int i = 0; i < 9; i++) U[i] *= -1.;
+    if (det3(Vt) < 0) for (int i = 0; i < 9; i++) Vt[i] *= -1.;
+    const double W[9] = { 0, 1, 0, -1, 0, 0, 0, 0, 1 }, Wt[9] = { 0, -1, 0, 1, 0, 0, 0, 0, 1 };
+    double UW[9];
+    mat3_mul(U, W, UW); mat3_mul(UW, Vt, R1);
+    mat3_mul(U, Wt, UW); mat3_mul(UW, Vt, R2);
+    t[0] = U[2]; t[1] = U[5]; t[2] = U[8];
+}
+
+// cv::recoverPose(E, p1, p2, K, R, t, mask), distanceThresh = 50 (VOU:149)
+uvo_status mono_recover_pose(Ctx* c, const double* E, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K,
+                             double* R, double* t, uint8_t* mask, int* good_out)
+{
+    *good_out = 0;
+    if (n > c->cap) { c->err = "point count exceeds the context's max_kpts"; return UVO_CAPACITY; }
+    MonoWs* w = mono_ws(c);
+    if (!w) { c->err = "mono workspace allocation failed"; return UVO_HIP_ERROR; }
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double ax = 1. / fx, bx = -cx * ax, ay = 1. / fy, by = -cy * ay;
+    std::vector<double> q1(2 * (size_t)n + 2), q2(2 * (size_t)n + 2);
+    for (int i = 0; i < n; i++) {
+        q1[2*i] = p1[i].x * ax + bx; q1[2*i+1] = p1[i].y * ay + by;
+        q2[2*i] = p2[i].x * ax + bx; q2[2*i+1] = p2[i].y * ay + by;
+    }
+    double R1[9], R2[9], tt[3];
+    decompose_essential(E, R1, R2, tt);
+    const double* Rc[4] = { R1, R2, R1, R2 };
+    const double sg[4] = { 1, 1, -1, -1 };
+    PoseCands pc;
+    for (int cnd = 0; cnd < 4; cnd++)
+        for (int i = 0; i < 3; i++) { pc.P[cnd][i*4] = Rc[cnd][i*3]; pc.P[cnd][i*4+1] = Rc[cnd][i*3+1]; pc.P[cnd][i*4+2] = Rc[cnd][i*3+2]; pc.P[cnd][i*4+3] = sg[cnd] * tt[i]; }
+    int good[4] = {0, 0, 0, 0};
+    if (n > 0) {
+        hipStream_t st = c->stream;
+        UVO_HIP_TRY(c, hipMemcpyAsync(w->q1, q1.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
+        UVO_HIP_TRY(c, hipMemcpyAsync(w->q2, q2.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
+        UVO_HIP_TRY(c, hipMemcpyAsync(w->masks + 4 * (size_t)c->cap, mask, n, hipMemcpyHostToDevice, st));
+        UVO_HIP_TRY(c, hipMemsetAsync(w->good, 0, sizeof(int) * 4, st));
+        hipLaunchKernelGGL(k_recover_pose, dim3((n + kRpThreads - 1) / kRpThreads, 4), dim3(kRpThreads), 0, st, w->q1, w->q2, n, pc,
+                           w->masks + 4 * (size_t)c->cap, w->masks, w->good);
+        UVO_HIP_TRY(c, hipGetLastError());
+        UVO_HIP_TRY(c, hipMemcpyAsync(good, w->good, sizeof(good), hipMemcpyDeviceToHost, st));
+        UVO_HIP_TRY(c, hipStreamSynchronize(st));
+    }
+    int best;
+    if (good[0] >= good[1] && good[0] >= good[2] && good[0] >= good[3]) best = 0;
+    else if (good[1] >= good[0] && good[1] >= good[2] && good[1] >= good[3]) best = 1;
+    else if (good[2] >= good[0] && good[2] >= good[1] && good[2] >= good[3]) best = 2;
+    else best = 3;
+    memcpy(R, Rc[best], sizeof(double) * 9);
+    for (int i = 0; i < 3; i++) t[i] = sg[best] * tt[i];
+    if (n > 0) {
+        UVO_HIP_TRY(c, hipMemcpy(mask, w->masks + (size_t)best * n, n, hipMemcpyDeviceToHost));
+    }
+    *good_out = good[best];
+    return UVO_OK;
+}
+
+// ---- homography: refit + LM polish (host, fundam.cpp / levmarq.cpp order) ----
+static void refine_compute(const float* M, const float* m, int count, const double* h, double* err, double* J)
+{
+    for (int i = 0; i < count; i++) {
+        double Mx = M[2*i], My = M[2*i+1];
+        double ww = h[6]*Mx + h[7]*My + 1.;
+        ww = fabs(ww) > DBL_EPSILON ? 1./ww : 0;
+        double xi = (h[0]*Mx + h[1]*My + h[2])*ww;
+        double yi = (h[3]*Mx + h[4]*My + h[5])*ww;
+        err[i*2] = xi - m[2*i];
+        err[i*2+1] = yi - m[2*i+1];
+        if (J) {
+            double* Jp = J + (size_t)i*16;
+            Jp[0] = Mx*ww; Jp[1] = My*ww; Jp[2] = ww;
+            Jp[3] = Jp[4] = Jp[5] = 0.;
+            Jp[6] = -Mx*ww*xi; Jp[7] = -My*ww*xi;
+            Jp[8] = Jp[9] = Jp[10] = 0.;
+            Jp[11] = Mx*ww; Jp[12] = My*ww; Jp[13] = ww;
+            Jp[14] = -Mx*ww*yi; Jp[15] = -My*ww*yi;
+        }
+    }
+}
+static double norm_l2sqr(const double* a, int n)
+{
+    double s = 0; int i = 0;
+    for (; i <= n - 4; i += 4) { double v0 = a[i], v1 = a[i+1], v2 = a[i+2], v3 = a[i+3]; s += v0*v0 + v1*v1 + v2*v2 + v3*v3; }
+    for (; i < n; i++) { double v = a[i]; s += v*v; }
+    return s;
+}
+static double dot_n(const double* a, const double* b, int n)
+{
+    double r = 0; int i = 0;
+    for (; i <= n - 4; i += 4) r += a[i]*b[i] + a[i+1]*b[i+1] + a[i+2]*b[i+2] + a[i+3]*b[i+3];
+    for (; i < n; i++) r += a[i]*b[i];
+    return r;
+}
+static double norm_inf(const double* a, int n) { double s = 0; for (int i = 0; i < n; i++) { double v = fabs(a[i]); if (s < v) s = v; } return s; }
+static void jtj_jtr(const double* J, const double* r, int rows, double* A, double* v)
+{
+    for (int i = 0; i < 8; i++) {
+        for (int j = i; j < 8; j++) { double s = 0; for (int k = 0; k < rows; k++) s += J[k*8 + i]*J[k*8 + j]; A[i*8 + j] = s; }
+        double s = 0; for (int k = 0; k < rows; k++) s += J[k*8 + i]*r[k];
+        v[i] = s * 1.0;
+    }
+    for (int i = 0; i < 8; i++) for (int j = 0; j < i; j++) A[i*8 + j] = A[j*8 + i];
+}
+static void eig8(const double* A, double* w, double* v)
+{
+    double a[64]; int ind[16];
+    memcpy(a, A, sizeof(a));
+    jacobi_eigen(SArr<1>{a}, 8, SArr<1>{w}, SArr<1>{v}, ind, ind + 8);
+}
+static void solve_eig8(const double* A, const double* b, double* x)
+{
+    double w[8], v[64];
+    eig8(A, w, v);
+    double threshold = 0;
+    for (int i = 0; i < 8; i++) { x[i] = 0; threshold += w[i]; }
+    threshold *= DBL_EPSILON * 2;
+    for (int i = 0; i < 8; i++) {
+        double wi = w[i];
+        if (fabs(wi) <= threshold) continue;
+        wi = 1/wi;
+        double s = 0;
+        for (int j = 0; j < 8; j++) s += v[i*8 + j]*b[j];
+        s *= wi;
+        for (int j = 0; j < 8; j++) x[j] = x[j] + s*v[i*8 + j];
+    }
+}
+static void invert_eig8(const double* A, double* Ainv)
+{
+    double w[8], v[64];
+    eig8(A, w, v);
+    double threshold = 0;
+    for (int i = 0; i < 64; i++) Ainv[i] = 0;
+    for (int i = 0; i < 8; i++) threshold += w[i];
+    threshold *= DBL_EPSILON * 2;
+    for (int i = 0; i < 8; i++) {
+        double wi = w[i];
+        if (fabs(wi) <= threshold) continue;
+        wi = 1/wi;
+        double buffer[8];
+        for (int j = 0; j < 8; j++) buffer[j] = v[i*8 + j]*wi;
+        for (int k = 0; k < 8; k++) { double sv = v[i*8 + k]; for (int j = 0; j < 8; j++) Ainv[k*8 + j] = Ainv[k*8 + j] + sv*buffer[j]; }
+    }
+}
+static void lm_refine_homography(const float* M, const float* m, int count, double* h)
+{
+    const int lx = 8, maxIters = 10; const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
+    int rows = 2*count;
+    std::vector<double> r(rows), rd(rows), J((size_t)rows*8);
+    double x[8], xd[8], d[8], v[8], A[64], Ap[64], D[8], temp_d[8];
+    memcpy(x, h, sizeof(x));
+    refine_compute(M, m, count, x, r.data(), J.data());
+    double S = norm_l2sqr(r.data(), rows);
+    jtj_jtr(J.data(), r.data(), rows, A, v);
+    for (int i = 0; i < lx; i++) D[i] = A[i*8 + i];
+    const double Rlo = 0.25, Rhi = 0.75;
+    double lambda = 1, lc = 0.75;
+    int iter = 0;
+    for (;;) {
+        memcpy(Ap, A, sizeof(Ap));
+        for (int i = 0; i < lx; i++) Ap[i*8 + i] += lambda*D[i];
+        solve_eig8(Ap, v, d);
+        for (int i = 0; i < lx; i++) xd[i] = x[i] - d[i];
+        refine_compute(M, m, count, xd, rd.data(), nullptr);
+        double Sd = norm_l2sqr(rd.data(), rows);
+        for (int i = 0; i < lx; i++) { double s0 = 0; for (int k = 0; k < lx; k++) s0 += A[i*8 + k]*d[k]; temp_d[i] = s0*-1 + v[i]*2; }
+        double dS = dot_n(d, temp_d, lx);
+        double R = (S - Sd)/(fabs(dS) > DBL_EPSILON ? dS : 1);
+        if (R > Rhi) { lambda *= 0.5; if (lambda < lc) lambda = 0; }
+        else if (R < Rlo) {
+            double t = dot_n(d, v, lx);
+            double nu = (Sd - S)/(fabs(t) > DBL_EPSILON ? t : 1) + 2;
+            nu = nu > 2. ? nu : 2.; nu = nu < 10. ? nu : 10.;
+            if (lambda == 0) {
+                invert_eig8(A, Ap);
+                double maxval = DBL_EPSILON;
+                for (int i = 0; i < lx; i++) { double a = fabs(Ap[i*8 + i]); if (maxval < a) maxval = a; }
+                lambda = lc = 1./maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+            memcpy(x, xd, sizeof(x));
+            refine_compute(M, m, count, x, r.data(), J.data());
+            jtj_jtr(J.data(), r.data(), rows, A, v);
+        }
+        iter++;
+        bool proceed = iter < maxIters && norm_inf(d, lx) >= epsx && norm_inf(r.data(), rows) >= epsf;
+        if (!proceed) break;
+    }
+    memcpy(h, x, sizeof(x));
+}
+
+// cv::findHomography (VOU:152)
+uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, int method, double thr, int maxIters,
+                                double confidence, double* H, uint8_t* mask, int* ok)
+{
+    *ok = 0;
+    memset(mask, 0, n);
+    if (n > c->cap) { c->err = "point count exceeds the context's max_kpts"; return UVO_CAPACITY; }
+    MonoWs* w = mono_ws(c);
+    if (!w) { c->err = "mono workspace allocation failed"; return UVO_HIP_ERROR; }
+    if (thr <= 0) thr = 3;
+    const int modelPoints = 4;
+    if (n < modelPoints) return UVO_OK;
+    std::vector<float> src(2 * (size_t)n), dst(2 * (size_t)n);
+    for (int i = 0; i < n; i++) { src[2*i] = p1[i].x; src[2*i+1] = p1[i].y; dst[2*i] = p2[i].x; dst[2*i+1] = p2[i].y; }
+    double scratch[171]; int iscratch[18];
+    int result = 0;
+    if (n == 4) {
+        memset(mask, 1, n);
+        result = homography_kernel(src.data(), dst.data(), n, H, SArr<1>{scratch}, SArr<1>{scratch + 81}, SArr<1>{scratch + 90}, iscratch) > 0;
+    } else {
+        hipStream_t st = c->stream;
+        const bool lmeds = method != 8;
+        int niters;
+        if (lmeds) { niters = ransac_update_num_iters(confidence, 0.45, modelPoints, maxIters); niters = niters > 3 ? niters : 3; }
+        else niters = maxIters > 1 ? maxIters : 1;
+        if (niters > kMaxHyp) { c->err = "max_iters exceeds the compiled hypothesis capacity (2048)"; return UVO_CAPACITY; }
+        bool failed_first = false;
+        int nsub = make_subsets(w->h_subsets.data(), niters, modelPoints, n, lmeds ? 1000 : 10000, src.data(), dst.data(), &failed_first);
+        if (nsub > 0) {
+            UVO_HIP_TRY(c, hipMemcpyAsync(w->src, src.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+            UVO_HIP_TRY(c, hipMemcpyAsync(w->dst, dst.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+            UVO_HIP_TRY(c, hipMemcpyAsync(w->subsets, w->h_subsets.data(), sizeof(int) * 4 * nsub, hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_h_hyp, dim3((nsub + kHHypThreads - 1) / kHHypThreads), dim3(kHHypThreads), 0, st, w->src, w->dst, w->subsets, nsub,
+                               w->models, w->nmodels);
+            const int npow2 = next_pow2(n);
+            const float thr2 = (float)(thr * thr);
+            hipLaunchKernelGGL(k_h_score, dim3(nsub), dim3(256), lmeds ? sizeof(float) * npow2 : 0, st, w->src, w->dst, n, w->models, w->nmodels,
+                               lmeds ? 1 : 0, thr2, npow2, w->counts, w->medians);
+            UVO_HIP_TRY(c, hipGetLastError());
+            UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data(), w->nmodels, sizeof(int) * nsub, hipMemcpyDeviceToHost, st));
+            if (lmeds) UVO_HIP_TRY(c, hipMemcpyAsync(w->h_medians.data(), w->medians, sizeof(double) * nsub, hipMemcpyDeviceToHost, st));
+            else UVO_HIP_TRY(c, hipMemcpyAsync(w->h_counts.data(), w->counts, sizeof(int) * nsub, hipMemcpyDeviceToHost, st));
+            UVO_HIP_TRY(c, hipStreamSynchronize(st));
+            Winner win = lmeds ? replay_lmeds(w->h_nmodels.data(), w->h_medians.data(), 1, nsub)
+                               : replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 1, nsub, niters, n, modelPoints, confidence);
+            if (win.hyp >= 0) {
+                double final_thr = thr;
+                if (lmeds) {
+                    double sigma = 2.5 * 1.4826 * (1 + 5. / (n - modelPoints)) * sqrt(win.min_median);
+                    final_thr = sigma > 0.001 ? sigma : 0.001;
+                }
+                const double* best = w->models + (size_t)win.hyp * 9;
+                hipLaunchKernelGGL(k_model_mask, dim3((n + 255) / 256), dim3(256), 0, st, 1, nullptr, nullptr, w->src, w->dst, n, best,
+                                   (float)(final_thr * final_thr), w->masks);
+                UVO_HIP_TRY(c, hipGetLastError());
+                UVO_HIP_TRY(c, hipMemcpyAsync(mask, w->masks, n, hipMemcpyDeviceToHost, st));
+                UVO_HIP_TRY(c, hipMemcpyAsync(H, best, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
+                UVO_HIP_TRY(c, hipStreamSynchronize(st));
+                if (lmeds) { int good = 0; for (int i = 0; i < n; i++) good += mask[i]; result = good >= modelPoints; }
+                else result = 1;
+            }
+        }
+    }
+    if (result && n > 4) {
+        int k = 0;                                                       // compressElems
+        for (int i = 0; i < n; i++) if (mask[i]) { src[2*k] = src[2*i]; src[2*k+1] = src[2*i+1]; dst[2*k] = dst[2*i]; dst[2*k+1] = dst[2*i+1]; k++; }
+        if (k > 0) {
+            homography_kernel(src.data(), dst.data(), k, H, SArr<1>{scratch}, SArr<1>{scratch + 81}, SArr<1>{scratch + 90}, iscratch);
+            lm_refine_homography(src.data(), dst.data(), k, H);
+        }
+    }
+    if (!result) memset(mask, 0, n);
+    *ok = result;
+    return UVO_OK;
+}
+
+// ---- cv::decomposeHomographyMat (HomographyDecompInria), host ----
+static void m3inv(const double* a, double* b)
+{
+    double d = det3(a);
+    if (d == 0) { memset(b, 0, sizeof(double)*9); return; }
+    d = 1./d;
+    b[0] = (a[4]*a[8] - a[5]*a[7])*d; b[1] = (a[2]*a[7] - a[1]*a[8])*d; b[2] = (a[1]*a[5] - a[2]*a[4])*d;
+    b[3] = (a[5]*a[6] - a[3]*a[8])*d; b[4] = (a[0]*a[8] - a[2]*a[6])*d; b[5] = (a[2]*a[3] - a[0]*a[5])*d;
+    b[6] = (a[3]*a[7] - a[4]*a[6])*d; b[7] = (a[1]*a[6] - a[0]*a[7])*d; b[8] = (a[0]*a[4] - a[1]*a[3])*d;
+}
+static double opposite_of_minor(const double* M, int row, int col)
+{
+    int x1 = col == 0 ? 1 : 0, x2 = col == 2 ? 1 : 2, y1 = row == 0 ? 1 : 0, y2 = row == 2 ? 1 : 2;
+    return M[y1*3 + x2]*M[y2*3 + x1] - M[y1*3 + x1]*M[y2*3 + x2];
+}
+static int signd(double x) { return x >= 0 ? 1 : -1; }
+static void find_rmat(const double* Hn, const double* tstar, const double* n, double v, double* R)
+{
+    double T[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) T[i*3 + j] = (i == j ? 1.0 : 0.0) - (2/v)*tstar[i]*n[j];
+    mat3_mul(Hn, T, R);
+    if (det3(R) < 0) for (int i = 0; i < 9; i++) R[i] *= -1;
+}
+int decompose_homography_mat(const double* H, const double* K, double* Rs, double* ts, double* ns)
+{
+    double Kinv[9], Hn[9], tmp[9];
+    m3inv(K, Kinv);
+    mat3_mul(Kinv, H, tmp); mat3_mul(tmp, K, Hn);
+    { double Hc[9], at[9], w[3], vt[9], wt[3]; memcpy(Hc, Hn, sizeof(Hc));
+      svd_square<3>(SArr<1>{Hc}, SArr<1>{at}, SArr<1>{w}, SArr<1>{vt}, SArr<1>{wt});
+      double s = 1.0/w[1]; for (int i = 0; i < 9; i++) Hn[i] = Hn[i]*s; }
+    const double epsilon = 0.001;
+    double S[9], Ht[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Ht[i*3 + j] = Hn[j*3 + i];
+    mat3_mul(Ht, Hn, S);
+    S[0] -= 1.0; S[4] -= 1.0; S[8] -= 1.0;
+    double ninf = 0;
+    for (int i = 0; i < 9; i++) { double a = fabs(S[i]); if (ninf < a) ninf = a; }
+    if (ninf < epsilon) {
+        memcpy(Rs, Hn, sizeof(double)*9);
+        for (int i = 0; i < 3; i++) { ts[i] = 0; ns[i] = 0; }
+        return 1;
+    }
+    double npa[3], npb[3];
+    double M00 = opposite_of_minor(S, 0, 0), M11 = opposite_of_minor(S, 1, 1), M22 = opposite_of_minor(S, 2, 2);
+    double rtM00 = sqrt(M00), rtM11 = sqrt(M11), rtM22 = sqrt(M22);
+    double M01 = opposite_of_minor(S, 0, 1), M12 = opposite_of_minor(S, 1, 2), M02 = opposite_of_minor(S, 0, 2);
+    int e12 = signd(M12), e02 = signd(M02), e01 = signd(M01);
+    double nS00 = fabs(S[0]), nS11 = fabs(S[4]), nS22 = fabs(S[8]);
+    int indx = 0;
+    if (nS00 < nS11) { indx = 1; if (nS11 < nS22) indx = 2; }
+    else { if (nS00 < nS22) indx = 2; }
+    switch (indx) {
+    case 0:
+        npa[0] = S[0];               npb[0] = S[0];
+        npa[1] = S[1] + rtM22;       npb[1] = S[1] - rtM22;
+        npa[2] = S[2] + e12*rtM11;   npb[2] = S[2] - e12*rtM11;
+        break;
+    case 1:
+        npa[0] = S[1] + rtM22;       npb[0] = S[1] - rtM22;
+        npa[1] = S[4];               npb[1] = S[4];
+        npa[2] = S[5] - e02*rtM00;   npb[2] = S[5] + e02*rtM00;
+        break;
+    default:
+        npa[0] = S[2] + e01*rtM11;   npb[0] = S[2] - e01*rtM11;
+        npa[1] = S[5] + rtM00;       npb[1] = S[5] - rtM00;
+        npa[2] = S[8];               npb[2] = S[8];
+        break;
+    }
+    double traceS = S[0] + S[4] + S[8];
+    double v = 2.0 * sqrtf((float)(1 + traceS - M00 - M11 - M22));
+    double ESii = signd(S[indx*3 + indx]);
+    double r_2 = 2 + traceS + v, nt_2 = 2 + traceS - v;
+    double r = sqrt(r_2), n_t = sqrt(nt_2);
+    double na[3], nb[3];
+    { double nn = sqrt(npa[0]*npa[0] + npa[1]*npa[1] + npa[2]*npa[2]); for (int i = 0; i < 3; i++) na[i] = npa[i] / nn; }
+    { double nn = sqrt(npb[0]*npb[0] + npb[1]*npb[1] + npb[2]*npb[2]); for (int i = 0; i < 3; i++) nb[i] = npb[i] / nn; }
+    double half_nt = 0.5*n_t, esii_t_r = ESii*r;
+    double ta_star[3], tb_star[3];
+    for (int i = 0; i < 3; i++) { ta_star[i] = half_nt*(esii_t_r*nb[i] - n_t*na[i]); tb_star[i] = half_nt*(esii_t_r*na[i] - n_t*nb[i]); }
+    double Ra[9], Rb[9], ta[3], tb[3];
+    find_rmat(Hn, ta_star, na, v, Ra);
+    find_rmat(Hn, tb_star, nb, v, Rb);
+    for (int i = 0; i < 3; i++) {
+        ta[i] = Ra[i*3]*ta_star[0] + Ra[i*3+1]*ta_star[1] + Ra[i*3+2]*ta_star[2];
+        tb[i] = Rb[i*3]*tb_star[0] + Rb[i*3+1]*tb_star[1] + Rb[i*3+2]*tb_star[2];
+    }
+    memcpy(Rs, Ra, 72); memcpy(Rs + 9, Ra, 72); memcpy(Rs + 18, Rb, 72); memcpy(Rs + 27, Rb, 72);
+    for (int i = 0; i < 3; i++) {
+        ts[i] = ta[i]; ns[i] = na[i];
+        ts[3 + i] = -ta[i]; ns[3 + i] = -na[i];
+        ts[6 + i] = tb[i]; ns[6 + i] = nb[i];
+        ts[9 + i] = -tb[i]; ns[9 + i] = -nb[i];
+    }
+    return 4;
+}
+
+void projection_matrix(const double* R, const double* t, const double* K, double* P)      // VOU:9-15
+{
+    double Rt[12];
+    for (int i = 0; i < 3; i++) { Rt[i*4] = R[i*3]; Rt[i*4+1] = R[i*3+1]; Rt[i*4+2] = R[i*3+2]; Rt[i*4+3] = t[i]; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) P[i*4 + j] = K[i*3]*Rt[j] + K[i*3+1]*Rt[4 + j] + K[i*3+2]*Rt[8 + j];
+}
+
+// recover_pose_homography (VOU:581-624), including the reference's reinterpretation of two neighbouring
+// floats as one double at VOU:601-602 (the last column, read past the buffer there, is not counted).
+uvo_status mono_recover_pose_homography(Ctx* c, const double* H, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K,
+                                        double HOMOGRAPHY_DISTANCE, double* R, double* t, int* max_good_out)
+{
+    *max_good_out = 0;
+    if (n > c->cap) { c->err = "point count exceeds the context's max_kpts"; return UVO_CAPACITY; }
+    double Rs[36], ts[12], ns[12];
+    int solutions = decompose_homography_mat(H, K, Rs, ts, ns);
+    const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
+    double proj_std[12];
+    projection_matrix(I, z, K, proj_std);
+    int best = -1, max_good = 0;
+    std::vector<float4> p4(n > 0 ? n : 1);
+    std::vector<float> zrow(n + 1);
+    hipStream_t st = c->stream;
+    if (n > 0) {
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x1, p1, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, st));
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x2, p2, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, st));
+    }
+    for (int i = 0; i < solutions; i++) {
+        double P[12];
+        projection_matrix(Rs + 9*i, ts + 3*i, K, P);
+        if (n > 0) {
+            UVO_TRY(pose_triangulate(c, proj_std, P, nullptr, n));
+            UVO_HIP_TRY(c, hipMemcpyAsync(p4.data(), c->d_pts4, sizeof(float4) * n, hipMemcpyDeviceToHost, st));
+            UVO_HIP_TRY(c, hipStreamSynchronize(st));
+        }
+        for (int j = 0; j < n; j++) {                       // convert_from_homogeneous_coords (VOU:71-83): col / w in float
+            float inv = (float)(1.0 / (double)p4[j].w);
+            zrow[j] = p4[j].z * inv + 0.f;
+        }
+        int good = 0;
+        for (int j = 0; j + 1 < n; j++) {
+            uint32_t lo, hi; memcpy(&lo, &zrow[j], 4); memcpy(&hi, &zrow[j + 1], 4);
+            uint64_t bits = ((uint64_t)hi << 32) | lo;
+            double v; memcpy(&v, &bits, 8);
+            if (v > 0 && v < HOMOGRAPHY_DISTANCE) good++;
+        }
+        if (good > max_good) { best = i; max_good = good; }
+    }
+    if (best != -1) {
+        const double* tb = ts + 3*best;
+        double nrm = sqrt(tb[0]*tb[0] + tb[1]*tb[1] + tb[2]*tb[2]);
+        double inv = 1.0 / nrm;
+        memcpy(R, Rs + 9*best, sizeof(double)*9);
+        for (int k = 0; k < 3; k++) t[k] = tb[k] * inv;
+    }
+    *max_good_out = max_good;
+    return UVO_OK;
+}
+
+}  // namespace uvo

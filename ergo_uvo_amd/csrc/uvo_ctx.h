@@ -111,6 +111,15 @@ struct Ctx {
     // last-step bookkeeping for uvo_stereo_get
     int last_nL = 0, last_nR = 0, last_M = 0, last_T = 0, last_G = 0, last_ninl = 0;
 
+    // ---- mono stage (mono.hip) ----
+    void* mono_ws = nullptr;                     // MonoWs*, allocated on first use
+    double mono_K[9]; bool mono_cam_set = false, mono_initialized = false;
+    int mono_use_essential = 1;                  // the reference's global `use_essential` (VOH:89)
+    double mono_R[9] = {1,0,0,0,1,0,0,0,1}, mono_t[3] = {0,0,0}, mono_SF = 1.0;
+    std::vector<uvo_keypoint> mono_prev_kps, mono_kps;   // host copies (prev frame / last frame)
+    int mono_n_prev = 0;                         // rows of the prev descriptors kept in d_as_descL[0]
+    std::vector<uvo_dmatch> mono_matches; std::vector<uint8_t> mono_mask; std::vector<double> mono_good_pts;
+
     // ---- timing ----
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -148,5 +157,17 @@ uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, 
 uvo_status pose_pnp_ransac(Ctx* c, int slot, int G, const double* K, int iters, float reproj, double conf,
                            double* rvec, double* tvec, int* n_inliers, int* ok);
 int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters);
+// mono.hip
+void mono_ws_free(Ctx* c);
+uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K, int method,
+                               double prob, double threshold, int maxIters, double* E, uint8_t* mask, int* ok);
+uvo_status mono_recover_pose(Ctx* c, const double* E, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K,
+                             double* R, double* t, uint8_t* mask, int* good);
+uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, int method, double thr, int maxIters,
+                                double confidence, double* H, uint8_t* mask, int* ok);
+int decompose_homography_mat(const double* H, const double* K, double* Rs, double* ts, double* ns);
+uvo_status mono_recover_pose_homography(Ctx* c, const double* H, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K,
+                                        double HOMOGRAPHY_DISTANCE, double* R, double* t, int* max_good);
+void projection_matrix(const double* R, const double* t, const double* K, double* P);
 
 }  // namespace uvo

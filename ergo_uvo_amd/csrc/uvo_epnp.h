@@ -126,101 +126,6 @@ __host__ __device__ __forceinline__ void project_point(double X, double Y, doubl
 }
 
 // ------------------------------------------------------------------------------------------
-// Runtime-sized one-sided Jacobi (same operations as jacobi_svd<M,N,true>); used where several
-// lanes run differently-shaped solves at once (the three beta approximations).
-// ------------------------------------------------------------------------------------------
-template <class A>
-__device__ void jacobi_svd_rt(A At, A W_out, A Vt, A W, int m, int n)
-{
-    const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
-    int i, j, k, iter, max_iter = m > 30 ? m : 30;
-    double c, s, sd;
-    for (i = 0; i < n; i++) {
-        for (k = 0, sd = 0; k < m; k++) { double t = At[i*m + k]; sd += t*t; }
-        W[i] = sd;
-        for (k = 0; k < n; k++) Vt[i*n + k] = 0;
-        Vt[i*n + i] = 1;
-    }
-#pragma unroll 1
-    for (iter = 0; iter < max_iter; iter++) {
-        bool changed = false;
-#pragma unroll 1
-        for (i = 0; i < n-1; i++)
-#pragma unroll 1
-            for (j = i+1; j < n; j++) {
-                A Ai = At + i*m, Aj = At + j*m;
-                double a = W[i], p = 0, b = W[j];
-                for (k = 0; k < m; k++) p += Ai[k]*Aj[k];
-                if (fabs(p) <= eps*sqrt(a*b)) continue;
-                p *= 2;
-                double beta = a - b, gamma = det_hypot(p, beta);
-                if (beta < 0) {
-                    double delta = (gamma - beta)*0.5;
-                    s = sqrt(delta/gamma);
-                    c = p/(gamma*s*2);
-                } else {
-                    c = sqrt((gamma + beta)/(gamma*2));
-                    s = p/(gamma*c*2);
-                }
-                a = b = 0;
-                for (k = 0; k < m; k++) {
-                    double x = Ai[k], y = Aj[k];
-                    double t0 = c*x + s*y;
-                    double t1 = -s*x + c*y;
-                    Ai[k] = t0; Aj[k] = t1;
-                    a += t0*t0; b += t1*t1;
-                }
-                W[i] = a; W[j] = b;
-                changed = true;
-                A Vi = Vt + i*n, Vj = Vt + j*n;
-                for (k = 0; k < n; k++) {
-                    double x = Vi[k], y = Vj[k];
-                    double t0 = c*x + s*y;
-                    double t1 = -s*x + c*y;
-                    Vi[k] = t0; Vj[k] = t1;
-                }
-            }
-        if (!changed) break;
-    }
-    for (i = 0; i < n; i++) {
-        for (k = 0, sd = 0; k < m; k++) { double t = At[i*m + k]; sd += t*t; }
-        W[i] = sqrt(sd);
-    }
-    for (i = 0; i < n-1; i++) {
-        j = i;
-        for (k = i+1; k < n; k++) if (W[j] < W[k]) j = k;
-        if (i != j) {
-            double t = W[i]; W[i] = W[j]; W[j] = t;
-            for (k = 0; k < m; k++) { t = At[i*m+k]; At[i*m+k] = At[j*m+k]; At[j*m+k] = t; }
-            for (k = 0; k < n; k++) { t = Vt[i*n+k]; Vt[i*n+k] = Vt[j*n+k]; Vt[j*n+k] = t; }
-        }
-    }
-    for (i = 0; i < n; i++) W_out[i] = W[i];
-    uint64_t rng = 0x12345678ULL;
-    for (i = 0; i < n; i++) {
-        sd = W[i];
-        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
-            const double val0 = 1./m;
-            for (k = 0; k < m; k++) { double val = (rng_next(rng) & 256) != 0 ? val0 : -val0; At[i*m + k] = val; }
-            for (iter = 0; iter < 2; iter++)
-                for (j = 0; j < i; j++) {
-                    sd = 0;
-                    for (k = 0; k < m; k++) sd += At[i*m + k]*At[j*m + k];
-                    double asum = 0;
-                    for (k = 0; k < m; k++) { double t = At[i*m + k] - sd*At[j*m + k]; At[i*m + k] = t; asum += fabs(t); }
-                    asum = asum > eps*100 ? 1/asum : 0;
-                    for (k = 0; k < m; k++) At[i*m + k] *= asum;
-                }
-            sd = 0;
-            for (k = 0; k < m; k++) { double t = At[i*m + k]; sd += t*t; }
-            sd = sqrt(sd);
-        }
-        s = sd > minval ? 1/sd : 0.;
-        for (k = 0; k < m; k++) At[i*m + k] *= s;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // 12x12 (generally MxN) Jacobi with U only, rotations scheduled by dependency level.
 // In OpenCV's cyclic order (0,1),(0,2)..(0,N-1),(1,2).. rotation (i,j) depends only on the previous
 // rotation that touched row i and the previous one that touched row j, which are (i,j-1)/(i-1,i) and

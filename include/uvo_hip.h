@@ -139,6 +139,44 @@ uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_result* out);
  * Returns the element count, or -(count) if cap_bytes is too small. */
 int        uvo_stereo_get(uvo_ctx* c, const char* what, void* out, int cap_bytes);
 
+/* ---- mono relative pose: estimate_relative_pose (VO_utility.h:101 -> VO_utility.cpp:134-180) and the OpenCV calls
+ * it makes.  Points are host Point2f arrays, K 3x3 f64, masks n bytes (0/1), methods 4 = LMEDS, 8 = RANSAC. ---- */
+/* cv::findEssentialMat(p1, p2, K, method, prob, threshold, maxIters, mask)  (VO_utility.cpp:147); *ok = 0: OpenCV's empty E */
+uvo_status uvo_find_essential_mat(uvo_ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K, int method,
+                                  double prob, double threshold, int max_iters, double* E, uint8_t* mask, int* ok);
+/* cv::recoverPose(E, p1, p2, K, R, t, mask), distance threshold 50 (VO_utility.cpp:149); mask is in/out */
+uvo_status uvo_recover_pose(uvo_ctx* c, const double* E, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K,
+                            double* R, double* t, uint8_t* mask, int* good);
+/* cv::findHomography(p1, p2, method, threshold, mask, maxIters, confidence)  (VO_utility.cpp:152) */
+uvo_status uvo_find_homography(uvo_ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, int method, double threshold,
+                               int max_iters, double confidence, double* H, uint8_t* mask, int* ok);
+/* cv::decomposeHomographyMat(H, K, Rs, ts, ns)  (VO_utility.cpp:585): up to 4 solutions, Rs 4x9, ts 4x3, ns 4x3 (host) */
+uvo_status uvo_decompose_homography_mat(const double* H, const double* K, double* Rs, double* ts, double* ns, int* n_solutions);
+/* recover_pose_homography (VO_utility.h:111 -> VO_utility.cpp:581-624); R, t written only when a candidate wins */
+uvo_status uvo_recover_pose_homography(uvo_ctx* c, const double* H, const uvo_point2f* p1, const uvo_point2f* p2, int n,
+                                       const double* K, double* R, double* t, int* max_good);
+/* select_estimation_method (VO_utility.h:116 -> VO_utility.cpp:725-748): 1 = essential, 0 = homography */
+int        uvo_select_estimation_method(const uvo_point2f* k1, const uvo_point2f* k2, int n, int distance);
+/* estimate_relative_pose: *use_essential is the reference's global of that name (in/out), R and t are in/out,
+ * in1/in2 (capacity n) receive extract_inliers' output, mask the final mask (VO_utility.cpp:157) */
+uvo_status uvo_estimate_relative_pose(uvo_ctx* c, const uvo_point2f* k1, const uvo_point2f* k2, int n, const double* K,
+                                      int* use_essential, double* R, double* t, uvo_point2f* in1, uvo_point2f* in2, int* n_in,
+                                      uint8_t* mask, int* success);
+
+/* ---- mono loop body, visual_odometry_node::mono_VO (visual_odometry.h:227-245 init, 247-397 main loop, 126-140 output) ---- */
+typedef struct {
+    int    published;             /* 0: frame skipped with `continue` (visual_odometry.h:276-307) -- nothing is published */
+    int    valid, initialized, used_essential, success;
+    int    n_kps, n_matches, n_inliers, n_good3d, n_front;
+    double R[9], t[3], SF, velocity[3];
+} uvo_mono_result;
+uvo_status uvo_mono_set_camera(uvo_ctx* c, const double* K);     /* new_camera_matrix (visual_odometry.h:221-222) */
+uvo_status uvo_mono_reset(uvo_ctx* c);
+uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h, int stride, int mem, double range, double dt,
+                         uvo_mono_result* out);
+/* last step's intermediates: "kps", "matches", "mask", "good_pts" */
+int        uvo_mono_get(uvo_ctx* c, const char* what, void* out, int cap_bytes);
+
 /* ---- per-stage device timing (HIP events on the context's stream) for bench.py ---- */
 uvo_status uvo_timing_enable(uvo_ctx* c, int on);
 int        uvo_timing_count(uvo_ctx* c);

@@ -233,3 +233,118 @@ def test_pipelined_submit_collect_equals_step(ctx, scene_small):
     assert sum(f[0] for f in sync) == len(seq) - 1
     with pytest.raises(uvo.UvoError):
         ctx.stereo_collect(0.05)                     # nothing in flight
+
+
+# ------------------------------------------------------------------ mono path
+def _mono_scene(n, seed, planar=False, noise=0.0, outliers=0.0):
+    from scipy.spatial.transform import Rotation
+    K = np.array([[800.0, 0, 320.0], [0, 790.0, 240.0], [0, 0, 1.0]])
+    rng = np.random.default_rng(seed)
+    R = Rotation.from_rotvec([0.02, -0.03, 0.015]).as_matrix()
+    t = np.array([0.30, -0.08, 0.12])
+    X = np.stack([rng.uniform(-1.5, 1.5, n), rng.uniform(-1.0, 1.0, n), rng.uniform(3.0, 7.0, n)], 1)
+    if planar:
+        nrm = np.array([0.1, -0.05, 1.0]); nrm /= np.linalg.norm(nrm)
+        X[:, 2] = (5.0 - X[:, 0] * nrm[0] - X[:, 1] * nrm[1]) / nrm[2]
+    def proj(Y):
+        return (Y[:, :2] / Y[:, 2:]) * np.array([K[0, 0], K[1, 1]]) + np.array([K[0, 2], K[1, 2]])
+    x1 = proj(X) + rng.normal(0, noise, (n, 2))
+    x2 = proj(X @ R.T + t) + rng.normal(0, noise, (n, 2))
+    bad = rng.random(n) < outliers
+    x2[bad] = rng.uniform(0, 600, (int(bad.sum()), 2))
+    return K, x1.astype(np.float32), x2.astype(np.float32), R, t
+
+
+def _beq(a, b):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+@pytest.mark.parametrize("n,method,thr,outl", [(5, 8, 1.0, 0.0), (6, 8, 1.0, 0.0), (300, 8, 1.0, 0.25), (300, 4, 0.1, 0.25),
+                                               (1500, 8, 0.5, 0.5), (1500, 4, 0.1, 0.4), (40, 8, 1.0, 1.0)])
+def test_find_essential_and_recover_pose_parity(ctx, oracle, n, method, thr, outl):
+    K, x1, x2, R, t = _mono_scene(n, 100 + n + method, noise=0.15, outliers=outl)
+    ok, E, mask = ctx.findEssentialMat(x1, x2, K, method, 0.99, thr, 2000)
+    ook, oE, omask = oracle.find_essential_mat(x1, x2, K, method, 0.99, thr, 2000)
+    assert ok == ook and np.array_equal(mask, omask)                       # bit-exact inlier mask
+    if ok:
+        assert np.linalg.norm(E - oE) <= 1e-4 * np.linalg.norm(oE) and _beq(E, oE)
+        g, Rr, tr, m2 = ctx.recoverPose(E, x1, x2, K, mask)
+        og, oR, ot, om2 = oracle.recover_pose(oE, x1, x2, K, omask)
+        assert g == og and np.array_equal(m2, om2) and _beq(Rr, oR) and _beq(tr, ot)
+
+
+@pytest.mark.parametrize("n,method,thr,outl", [(4, 8, 1.0, 0.0), (5, 8, 1.0, 0.0), (250, 8, 1.0, 0.2), (250, 4, 0.1, 0.2),
+                                               (1500, 8, 0.5, 0.5), (1500, 4, 0.1, 0.4)])
+def test_find_homography_parity(ctx, oracle, n, method, thr, outl):
+    import ergo_uvo_amd as uvo
+    ctx.set_params(uvo.Params.mono())                       # HOMOGRAPHY_DISTANCE = 50 (mono_VO_parameters.yaml:28)
+    K, x1, x2, R, t = _mono_scene(n, 200 + n + method, planar=True, noise=0.1, outliers=outl)
+    ok, H, mask = ctx.findHomography(x1, x2, method, thr, 2000, 0.99)
+    ook, oH, omask = oracle.find_homography(x1, x2, method, thr, 2000, 0.99)
+    assert ok == ook and np.array_equal(mask, omask)
+    if ok:
+        assert np.linalg.norm(H - oH) <= 1e-4 * np.linalg.norm(oH) and _beq(H, oH)      # includes the refit + LM polish
+        Rs, ts, ns = ctx.decomposeHomographyMat(H, K)
+        oRs, ots, ons = oracle.decompose_homography(oH, K)
+        assert _beq(Rs, oRs) and _beq(ts, ots) and _beq(ns, ons)
+        g, Rr, tr = ctx.recover_pose_homography(H, x1, x2, K)
+        og, oR, ot = oracle.recover_pose_homography(oH, x1, x2, K, 50.0)
+        assert g == og
+        if g > 0:
+            assert _beq(Rr, oR) and _beq(tr, ot)
+
+
+def test_estimate_relative_pose_parity(ctx, oracle):
+    import ergo_uvo_amd as uvo
+    for method, planar, start_e in [(8, False, True), (4, False, True), (8, True, False), (4, True, True), (8, False, False)]:
+        K, x1, x2, R, t = _mono_scene(400, 300 + method + planar, planar=planar, noise=0.15, outliers=0.2)
+        kw = dict(ESSENTIAL_OUTLIER_METHOD=method, HOMOGRAPHY_OUTLIER_METHOD=method)
+        if method == 8:
+            kw.update(ESSENTIAL_THRESHOLD=1.0, HOMOGRAPHY_THRESHOLD=1.0)
+        ctx.set_params(uvo.Params.mono(**kw))
+        op = oracle.mono_params(method=method)
+        if method == 8:
+            op.ESSENTIAL_THRESHOLD = 1.0; op.HOMOGRAPHY_THRESHOLD = 1.0
+        import ctypes as C
+        assert ctx.select_estimation_method(x1, x2) == bool(oracle.lib().orc_select_estimation_method(
+            x1.ctypes.data_as(C.c_void_p), x2.ctypes.data_as(C.c_void_p), len(x1), 10))
+        got = ctx.estimate_relative_pose(x1, x2, K, start_e)
+        want = oracle.estimate_relative_pose(op, start_e, x1, x2, K)
+        assert got[0] == want[0] and got[1] == want[1]
+        assert _beq(got[2], want[2]) and _beq(got[3], want[3])
+        assert np.array_equal(got[4], want[4]) and np.array_equal(got[5], want[5]) and np.array_equal(got[6], want[6])
+
+
+def test_mono_sequence_parity(ctx, oracle, mono_small):
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    for method in (8, 4):
+        kw = dict(SURF_MIN_HESSIAN=400, ESSENTIAL_OUTLIER_METHOD=method, HOMOGRAPHY_OUTLIER_METHOD=method, REPROJECTION_TOLERANCE=3.0)
+        op = oracle.mono_params(400, method=method); op.REPROJECTION_TOLERANCE = 3.0
+        if method == 8:
+            kw.update(ESSENTIAL_THRESHOLD=1.0, HOMOGRAPHY_THRESHOLD=1.0)
+            op.ESSENTIAL_THRESHOLD = 1.0; op.HOMOGRAPHY_THRESHOLD = 1.0
+        ctx.set_params(uvo.Params.mono(**kw))
+        ctx.mono_set_camera(rig.K_left)
+        ovo = oracle.MonoVO(op, rig.K_left)
+        blank = np.full((360, 640), 90, np.uint8)
+        seq = [blank, mono_small[0], mono_small[1], mono_small[2], blank, mono_small[1], mono_small[0]]
+        n_pub = 0
+        for k, img in enumerate(seq):
+            r = ctx.mono_step(img, 4.0, 0.2)
+            o = ovo.step(img, 4.0, 0.2)
+            for f in ("published", "valid", "initialized", "used_essential", "success", "n_kps", "n_matches", "n_inliers", "n_good3d", "n_front"):
+                assert getattr(r, f) == getattr(o, f), (method, k, f, getattr(r, f), getattr(o, f))
+            n_pub += r.published
+            if r.published:
+                for a, b in ((r.R, o.R), (r.t, o.t), (r.velocity, o.velocity), ([r.SF], [o.SF])):
+                    a, b = np.array(list(a)), np.array(list(b))
+                    assert np.linalg.norm(a - b) <= 1e-4 * max(np.linalg.norm(b), 1e-12)      # north_star tolerance
+                    assert _beq(a, b)
+                assert np.array_equal(ctx.mono_get("mask"), ovo.get("mask"))
+                m, om = ctx.mono_get("matches"), ovo.get("matches")
+                assert np.array_equal(m["queryIdx"], om["queryIdx"]) and np.array_equal(m["trainIdx"], om["trainIdx"])
+                assert _beq(ctx.mono_get("good_pts"), ovo.get("good_pts"))
+        assert n_pub >= 3
