@@ -31,11 +31,13 @@ namespace uvo {
 __device__ const signed char kMono[20][3] = {
     {3,0,0},{0,3,0},{2,1,0},{1,2,0},{2,0,1},{2,0,0},{0,2,1},{0,2,0},{1,1,1},{1,1,0},
     {1,0,2},{1,0,1},{1,0,0},{0,1,2},{0,1,1},{0,1,0},{0,0,3},{0,0,2},{0,0,1},{0,0,0} };
-__device__ __forceinline__ int mono_index(int a, int b, int c)
-{
-    for (int i = 0; i < 20; i++) if (kMono[i][0] == a && kMono[i][1] == b && kMono[i][2] == c) return i;
-    return 19;
-}
+// index of x^a y^b z^c in kMono (a + b + c <= 3), as a lookup table
+__device__ const signed char kMonoIdx[64] = {
+    /* a=0 */ 19, 18, 17, 16,  15, 14, 13, -1,   7,  6, -1, -1,   1, -1, -1, -1,
+    /* a=1 */ 12, 11, 10, -1,   9,  8, -1, -1,   3, -1, -1, -1,  -1, -1, -1, -1,
+    /* a=2 */  5,  4, -1, -1,   2, -1, -1, -1,  -1, -1, -1, -1,  -1, -1, -1, -1,
+    /* a=3 */  0, -1, -1, -1,  -1, -1, -1, -1,  -1, -1, -1, -1,  -1, -1, -1, -1 };
+__device__ __forceinline__ int mono_index(int a, int b, int c) { return kMonoIdx[a * 16 + b * 4 + c]; }
 __device__ void p_zero(double* p) { for (int i = 0; i < 20; i++) p[i] = 0; }
 // out = a * b (out must not alias a or b); products of total degree > 3 never occur
 __device__ void p_mul(const double* a, const double* b, double* out)
@@ -64,41 +66,49 @@ __device__ __forceinline__ cplx c_div(cplx a, cplx b)
     double t = 1./(b.re*b.re + b.im*b.im);
     return cplx{ (a.re*b.re + a.im*b.im)*t, (-a.re*b.im + a.im*b.re)*t };
 }
-// cv::solvePoly, real coefficients c[0..10] (increasing powers), 300 Durand-Kerner iterations
-__device__ void solve_poly10(const double* c0, double* rre, double* rim)
+// cv::solvePoly, real coefficients c[0..10] (increasing powers), 300 Durand-Kerner iterations.
+// coeffs/roots live in LDS (`work`, 42 doubles: dynamic indexing would push private arrays to scratch).
+// Exact shortcut: once a full sweep leaves every root bitwise unchanged, all later sweeps recompute the
+// same corrections from the same roots, so stopping there gives the result of the full 300 iterations.
+__device__ void solve_poly10(const double* c0, double* rre, double* rim, double* work)
 {
     const int n0 = 10;
-    cplx coeffs[11], roots[10];
+    double* cre = work;            // coeffs are real: imaginary parts are zero
+    double* zre = work + 11; double* zim = work + 21;
     int n = n0, i, j, iter;
-    for (i = 0; i <= n; i++) { coeffs[i].re = c0[i]; coeffs[i].im = 0; }
-    for (; n > 1; n--) if (fabs(coeffs[n].re) + fabs(coeffs[n].im) > DBL_EPSILON) break;
+    for (i = 0; i <= n; i++) cre[i] = c0[i];
+    for (; n > 1; n--) if (fabs(cre[n]) + fabs(0.0) > DBL_EPSILON) break;
     cplx p{1, 0}, r{1, 1};
-    for (i = 0; i < n; i++) { roots[i] = p; p = c_mul(p, r); }
+    for (i = 0; i < n; i++) { zre[i] = p.re; zim[i] = p.im; p = c_mul(p, r); }
 #pragma unroll 1
     for (iter = 0; iter < 300; iter++) {
         double maxDiff = 0;
+        bool changed = false;
 #pragma unroll 1
         for (i = 0; i < n; i++) {
-            p = roots[i];
-            cplx num = coeffs[n], denom = coeffs[n];
+            p = cplx{zre[i], zim[i]};
+            cplx num{cre[n], 0}, denom{cre[n], 0};
 #pragma unroll 1
             for (j = 0; j < n; j++) {
-                num = c_add(c_mul(num, p), coeffs[n-j-1]);
+                num = c_add(c_mul(num, p), cplx{cre[n-j-1], 0});
                 if (j != i) {
-                    cplx df = c_sub(p, roots[j]);
+                    cplx df = c_sub(p, cplx{zre[j], zim[j]});
                     if (df.re != 0 || df.im != 0) denom = c_mul(denom, df);
                 }
             }
             num = c_div(num, denom);
-            roots[i] = c_sub(p, num);
+            cplx nr = c_sub(p, num);
+            changed = changed || nr.re != p.re || nr.im != p.im;
+            zre[i] = nr.re; zim[i] = nr.im;
             double a = sqrt(num.re*num.re + num.im*num.im);
             if (a > maxDiff) maxDiff = a;
         }
         if (maxDiff <= 0) break;
+        if (!changed) break;
     }
-    for (i = 0; i < n; i++) if (fabs(roots[i].im) < 1e-100) roots[i].im = 0;
-    for (; n < n0; n++) roots[n] = roots[n-1];
-    for (i = 0; i < n0; i++) { rre[i] = roots[i].re; rim[i] = roots[i].im; }
+    for (i = 0; i < n; i++) if (fabs(zim[i]) < 1e-100) zim[i] = 0;
+    for (; n < n0; n++) { zre[n] = zre[n-1]; zim[n] = zim[n-1]; }
+    for (i = 0; i < n0; i++) { rre[i] = zre[i]; rim[i] = zim[i]; }
 }
 __device__ void pz_mul(const double* a, int da, const double* b, int db, double* out)
 {
@@ -109,7 +119,7 @@ __device__ void pz_mul(const double* a, int da, const double* b, int db, double*
 // LDS layout of one hypothesis (doubles)
 enum { FP_AT = 0, FP_W = 81, FP_WT = 90, FP_V5 = 99, FP_E = 124, FP_EET = 304, FP_TR = 484, FP_A = 504, FP_LANE = 704,
        FP_AL = 1904, FP_AINV = 2004, FP_AR = 2104, FP_AP = 2204, FP_B = 2304, FP_C = 2343, FP_ROOTS = 2354, FP_RT = 2374,
-       FP_CAND = 2704, FP_FLAG = 2794, FP_TOTAL = 2808 };
+       FP_CAND = 2704, FP_FLAG = 2794, FP_POLY = 2808, FP_TOTAL = 2852 };
 
 __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const double* q2, const int* subsets, int nhyp,
                                                       double* models /* nhyp x 10 x 9 */, int* nmodels)
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
         pz_mul(e[1][0], 3, e[2][1], 3, t1); pz_mul(e[1][1], 3, e[2][0], 3, t2);
         for (int k = 0; k <= 6; k++) m[k] = t1[k] - t2[k];
         pz_mul(e[0][2], 4, m, 6, t1); for (int k = 0; k <= 10; k++) c[k] += t1[k];
-        solve_poly10(c, rre, rim);
+        solve_poly10(c, rre, rim, S + FP_POLY);
     }
     __syncthreads();
     double* cand = S + FP_CAND; double* flag = S + FP_FLAG;

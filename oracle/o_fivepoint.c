@@ -167,6 +167,9 @@ static void pz_mul(const double* a, int da, const double* b, int db, double* out
     for (int i = 0; i <= da; i++) for (int j = 0; j <= db; j++) out[i + j] += a[i] * b[j];
 }
 
+static double g_last_poly[11];
+void orc_five_point_last_poly(double* c) { memcpy(c, g_last_poly, sizeof(g_last_poly)); }   /* test/debug hook */
+
 /* [UPSTREAM] EMEstimatorCallback::runKernel for 5 normalised correspondences (q1, q2: 5 x 2 doubles).
  * models: up to 10 matrices of 9 doubles (row-major, x2^T E x1 = 0).  Returns their number. */
 int orc_five_point(const double* q1, const double* q2, double* models)
@@ -227,6 +230,7 @@ int orc_five_point(const double* q1, const double* q2, double* models)
     for (int k = 0; k <= 6; k++) m[k] = t1[k] - t2[k];
     pz_mul(e[0][2], 4, m, 6, t1); for (int k = 0; k <= 10; k++) c[k] += t1[k];
 
+    memcpy(g_last_poly, c, sizeof(g_last_poly));
     double rre[10], rim[10];
     orc_solve_poly(c, 10, rre, rim);
     int count = 0;

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Secondary measurements for the other BASELINE.json configs (the headline C3 line comes from bench.py):
+  C2  stereo 1280x720, ~1500 kpts (min_hessian 5685), pipelined submit/collect and synchronous step
+  C4  mono 1920x1080 + range, ~3000 kpts, RANSAC for both E and H (frames 0,4,8,.. so depth/baseline < 50)
+Prints one JSON object; run on the GPU box:  python tools/bench_configs.py"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    out = {}
+    # ---------------- C2 ----------------
+    W, H = 1280, 720
+    scene = synth.Scene(synth.SEEDS["C2"], W)
+    frames = [synth.stereo_pair(scene, k, W, H) for k in range(4)]
+    dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+    rig = synth.stereo_rig(W)
+    ctx = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=5685), 0, W, H, 8192)
+    ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    order = [0, 1, 2, 3, 2, 1]
+    for i in range(12):
+        r = ctx.stereo_step(*dev[order[i % 6]], 0.05)
+    steps = 300
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    nv = 0
+    for i in range(steps):
+        nv += ctx.stereo_step(*dev[order[i % 6]], 0.05).valid
+    t_sync = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ctx.stereo_submit(*dev[order[0]])
+    for i in range(steps):
+        if i + 1 < steps:
+            ctx.stereo_submit(*dev[order[(i + 1) % 6]])
+        r = ctx.stereo_collect(0.05)
+    t_pipe = time.perf_counter() - t0
+    out["C2_stereo_1280x720"] = {"kpts": r.n_left, "valid": nv, "pairs_per_s_sync": round(steps / t_sync, 1),
+                                 "pairs_per_s_pipelined": round(steps / t_pipe, 1)}
+    ctx.close()
+    # ---------------- C3 synchronous latency ----------------
+    W, H = 1920, 1080
+    scene = synth.Scene(synth.SEEDS["C3"], W)
+    frames = [synth.stereo_pair(scene, k, W, H) for k in range(4)]
+    dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+    rig = synth.stereo_rig(W)
+    ctx = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=6387), 0, W, H, 8192)
+    ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    for i in range(12):
+        ctx.stereo_step(*dev[order[i % 6]], 0.05)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(steps):
+        ctx.stereo_step(*dev[order[i % 6]], 0.05)
+    out["C3_stereo_1920x1080_sync"] = {"pairs_per_s_sync": round(steps / (time.perf_counter() - t0), 1)}
+    # host images (PCIe-inclusive)
+    t0 = time.perf_counter()
+    ctx.stereo_submit(*frames[order[0]])
+    for i in range(steps):
+        if i + 1 < steps:
+            ctx.stereo_submit(*frames[order[(i + 1) % 6]])
+        ctx.stereo_collect(0.05)
+    out["C3_stereo_1920x1080_host_images"] = {"pairs_per_s_pipelined_pcie_inclusive": round(steps / (time.perf_counter() - t0), 1)}
+    ctx.close()
+    # ---------------- C4 ----------------
+    scene = synth.Scene(synth.SEEDS["C4"], W)
+    ks = [0, 4, 8, 12]
+    mono = [synth.stereo_pair(scene, k, W, H)[0] for k in ks]
+    dmono = [torch.from_numpy(m).cuda() for m in mono]
+    R0, C0 = synth.camera_pose(0)
+    rng = scene.depth_at_center(C0, R0)
+    p = uvo.Params.mono(SURF_MIN_HESSIAN=6387, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8,
+                        ESSENTIAL_THRESHOLD=1.0, HOMOGRAPHY_THRESHOLD=1.0, REPROJECTION_TOLERANCE=3.0)
+    ctx = uvo.Context(p, 0, W, H, 8192)
+    ctx.mono_set_camera(rig.K_left)
+    for i in range(8):
+        r = ctx.mono_step(dmono[order[i % 6]], rng, 0.2)
+    steps = 100
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    nv = ne = 0
+    for i in range(steps):
+        r = ctx.mono_step(dmono[order[i % 6]], rng, 0.2)
+        nv += r.valid; ne += r.used_essential
+    out["C4_mono_1920x1080_ransac"] = {"kpts": r.n_kps, "matches": r.n_matches, "valid": nv, "essential_used": ne,
+                                       "frames_per_s": round(steps / (time.perf_counter() - t0), 1)}
+    ctx.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
