@@ -66,49 +66,106 @@ __device__ __forceinline__ cplx c_div(cplx a, cplx b)
     double t = 1./(b.re*b.re + b.im*b.im);
     return cplx{ (a.re*b.re + a.im*b.im)*t, (-a.re*b.im + a.im*b.re)*t };
 }
-// cv::solvePoly, real coefficients c[0..10] (increasing powers), 300 Durand-Kerner iterations.
-// coeffs/roots live in LDS (`work`, 42 doubles: dynamic indexing would push private arrays to scratch).
+// cv::solvePoly, real coefficients c[0..10] (increasing powers) in LDS at `cw`, 300 Durand-Kerner sweeps,
+// run by the whole wave: lane i owns root i in registers.
+//   * the Horner numerators of a sweep depend only on each root's own old value -> all lanes at once;
+//   * the denominators are Gauss-Seidel (root i uses the NEW roots j < i) and OpenCV multiplies the
+//     factors in the order j = 0..n-1, so after root k is final every lane i > k takes the factor
+//     (p_i - z_k) in one SIMD step, and lane k alone finishes its chain over the old roots j > k.
+// Every operation and its order are those of the scalar loop; only independent work moves to other lanes.
 // Exact shortcut: once a full sweep leaves every root bitwise unchanged, all later sweeps recompute the
 // same corrections from the same roots, so stopping there gives the result of the full 300 iterations.
-__device__ void solve_poly10(const double* c0, double* rre, double* rim, double* work)
+__device__ __forceinline__ double lane_bcast(double v, int k)      // value of lane k (k compile-time after unrolling) as a scalar
 {
-    const int n0 = 10;
-    double* cre = work;            // coeffs are real: imaginary parts are zero
-    double* zre = work + 11; double* zim = work + 21;
-    int n = n0, i, j, iter;
-    for (i = 0; i <= n; i++) cre[i] = c0[i];
-    for (; n > 1; n--) if (fabs(cre[n]) + fabs(0.0) > DBL_EPSILON) break;
-    cplx p{1, 0}, r{1, 1};
-    for (i = 0; i < n; i++) { zre[i] = p.re; zim[i] = p.im; p = c_mul(p, r); }
-#pragma unroll 1
-    for (iter = 0; iter < 300; iter++) {
-        double maxDiff = 0;
-        bool changed = false;
-#pragma unroll 1
-        for (i = 0; i < n; i++) {
-            p = cplx{zre[i], zim[i]};
-            cplx num{cre[n], 0}, denom{cre[n], 0};
-#pragma unroll 1
-            for (j = 0; j < n; j++) {
-                num = c_add(c_mul(num, p), cplx{cre[n-j-1], 0});
-                if (j != i) {
-                    cplx df = c_sub(p, cplx{zre[j], zim[j]});
-                    if (df.re != 0 || df.im != 0) denom = c_mul(denom, df);
-                }
-            }
-            num = c_div(num, denom);
-            cplx nr = c_sub(p, num);
-            changed = changed || nr.re != p.re || nr.im != p.im;
-            zre[i] = nr.re; zim[i] = nr.im;
-            double a = sqrt(num.re*num.re + num.im*num.im);
-            if (a > maxDiff) maxDiff = a;
-        }
-        if (maxDiff <= 0) break;
-        if (!changed) break;
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], k); u.i[1] = __builtin_amdgcn_readlane(u.i[1], k);
+    return u.d;
+}
+// denom *= df unless df == 0 (OpenCV skips coincident roots), branch-free
+__device__ __forceinline__ cplx dk_factor(cplx denom, cplx df)
+{
+    cplx pr = c_mul(denom, df);
+    bool nz = df.re != 0 || df.im != 0;
+    return cplx{ nz ? pr.re : denom.re, nz ? pr.im : denom.im };
+}
+// One Durand-Kerner sweep.  NC = 10: the degree is 10 at compile time (the general case); NC = 0: runtime
+// degree n < 10.  CHECKED = false multiplies every factor without OpenCV's "skip a zero difference" test and
+// reports in `sawzero` whether any factor that counts was zero; the caller then redoes the sweep CHECKED.
+template <int NC, bool CHECKED>
+__device__ __forceinline__ cplx dk_sweep(const cplx p, const double* cr, double cn, int n, cplx& q, bool& sawzero)
+{
+    constexpr int n0 = 10;
+    const int lane = threadIdx.x;
+#define DK_ON(j) (NC != 0 || (j) < n)
+    cplx z = p;
+    cplx num{cn, 0};
+#pragma unroll
+    for (int j = 0; j < n0; j++) if (DK_ON(j)) num = c_add(c_mul(num, p), cplx{cr[j], 0});
+    cplx dfo[n0];                                // p - (old root j): the factors lane k multiplies after its own turn
+    bool zero = false;
+#pragma unroll
+    for (int j = 1; j < n0; j++) {
+        dfo[j] = c_sub(p, cplx{ lane_bcast(p.re, j), lane_bcast(p.im, j) });
+        if (!CHECKED) zero = zero || (lane < j && DK_ON(j) && dfo[j].re == 0 && dfo[j].im == 0);
     }
-    for (i = 0; i < n; i++) if (fabs(zim[i]) < 1e-100) zim[i] = 0;
-    for (; n < n0; n++) { zre[n] = zre[n-1]; zim[n] = zim[n-1]; }
-    for (i = 0; i < n0; i++) { rre[i] = zre[i]; rim[i] = zim[i]; }
+    cplx denom{cn, 0};
+    q = cplx{0, 0};
+#pragma unroll
+    for (int k = 0; k < n0; k++) {
+        if (DK_ON(k)) {
+            if (lane == k) {
+#pragma unroll
+                for (int j = k + 1; j < n0; j++) if (DK_ON(j)) denom = CHECKED ? dk_factor(denom, dfo[j]) : c_mul(denom, dfo[j]);
+                q = c_div(num, denom);
+                z = c_sub(p, q);
+            }
+            if (k + 1 < n0) {                    // lanes > k take the factor of the new root k (other lanes: dead value)
+                cplx df = c_sub(p, cplx{ lane_bcast(z.re, k), lane_bcast(z.im, k) });
+                if (!CHECKED) zero = zero || (lane > k && df.re == 0 && df.im == 0);
+                denom = CHECKED ? dk_factor(denom, df) : c_mul(denom, df);
+            }
+        }
+    }
+#undef DK_ON
+    sawzero = zero;
+    return z;
+}
+template <int NC>
+__device__ __forceinline__ cplx dk_sweeps(cplx z, const double* cr, double cn, int n)
+{
+#pragma unroll 1
+    for (int iter = 0; iter < 300; iter++) {
+        cplx q; bool sawzero;
+        cplx zn = dk_sweep<NC, false>(z, cr, cn, n, q, sawzero);
+        if (__any(sawzero)) zn = dk_sweep<NC, true>(z, cr, cn, n, q, sawzero);
+        bool moved = zn.re != z.re || zn.im != z.im;
+        bool nonzero = q.re*q.re + q.im*q.im > 0;                   // sqrt(s) > 0  <=>  s > 0
+        z = zn;
+        if (!__any(nonzero)) break;              // maxDiff <= 0
+        if (!__any(moved)) break;
+    }
+    return z;
+}
+__device__ void solve_poly10(const double* cw, double* rre, double* rim)
+{
+    const int n0 = 10, lane = threadIdx.x;
+    int n = n0;
+    for (; n > 1; n--) if (fabs(cw[n]) + fabs(0.0) > DBL_EPSILON) break;
+    double cr[n0];                               // cr[j] = c[n-1-j]: the coefficient Horner step j adds
+#pragma unroll
+    for (int j = 0; j < n0; j++) cr[j] = j < n ? cw[n - 1 - j] : 0.0;
+    const double cn = cw[n];
+    cplx z{0, 0};
+    {
+        cplx p{1, 0}; const cplx r{1, 1};
+#pragma unroll 1
+        for (int i = 0; i < n; i++) { if (i == lane) z = p; p = c_mul(p, r); }
+    }
+    z = n == n0 ? dk_sweeps<10>(z, cr, cn, n) : dk_sweeps<0>(z, cr, cn, n);
+    if (lane < n && fabs(z.im) < 1e-100) z.im = 0;
+    int src = lane < n ? lane : n - 1;
+    double ore = __shfl(z.re, src), oim = __shfl(z.im, src);
+    if (lane < n0) { rre[lane] = ore; rim[lane] = oim; }
 }
 __device__ void pz_mul(const double* a, int da, const double* b, int db, double* out)
 {
@@ -117,9 +174,17 @@ __device__ void pz_mul(const double* a, int da, const double* b, int db, double*
 }
 
 // LDS layout of one hypothesis (doubles)
+// (everything from FP_AL on reuses the per-lane polynomial scratch, dead once A is assembled: 15.2 KB per
+// workgroup, so the 2000 hypotheses of a RANSAC run are resident in one round on 256 CUs)
 enum { FP_AT = 0, FP_W = 81, FP_WT = 90, FP_V5 = 99, FP_E = 124, FP_EET = 304, FP_TR = 484, FP_A = 504, FP_LANE = 704,
-       FP_AL = 1904, FP_AINV = 2004, FP_AR = 2104, FP_AP = 2204, FP_B = 2304, FP_C = 2343, FP_ROOTS = 2354, FP_RT = 2374,
-       FP_CAND = 2704, FP_FLAG = 2794, FP_POLY = 2808, FP_TOTAL = 2852 };
+       FP_AL = FP_LANE, FP_AINV = FP_AL + 100, FP_AR = FP_AINV + 100, FP_AP = FP_AR + 100, FP_B = FP_AP + 100, FP_C = FP_B + 39,
+       FP_ROOTS = FP_C + 11, FP_RT = FP_ROOTS + 20, FP_CAND = FP_RT + 330, FP_FLAG = FP_CAND + 90, FP_POLY = FP_FLAG + 14,
+       FP_TOTAL = FP_LANE + 1200 };
+static_assert(FP_POLY + 44 <= FP_TOTAL, "five-point LDS overlay");
+
+// diagnostic: 100 MHz wall-clock stamps of hypothesis 0's phases (printed by the host when UVO_DBG_PHASE is set)
+__device__ long long g_fp_clk[8];
+#define FP_STAMP(i) do { if (hyp == 0 && lane == 0) g_fp_clk[i] = wall_clock64(); } while (0)
 
 __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const double* q2, const int* subsets, int nhyp,
                                                       double* models /* nhyp x 10 x 9 */, int* nmodels)
@@ -129,6 +194,7 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
     const int hyp = blockIdx.x, lane = threadIdx.x;
     using A1 = SArr<1>;
     double* At = S + FP_AT;
+    FP_STAMP(0);
     // ---- Q (5 x 9) in the first five rows of the 9 x 9 buffer, rest zero ----
     for (int i = lane; i < 81; i += 64) At[i] = 0;
     __syncthreads();
@@ -142,6 +208,7 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
     // SVD::compute(Q, FULL_UV): rows 5..8 of Vt = JacobiSVD's completion = null-space basis
     if (lane == 0) jacobi_svd_rt(A1{At}, A1{S + FP_W}, A1{S + FP_V5}, A1{S + FP_WT}, 9, 5, 9);
     __syncthreads();
+    FP_STAMP(1);
     const double* EE = At + 45;                                   // 4 x 9
     double* Ep = S + FP_E;                                         // E[9][20]
     double* EEt = S + FP_EET;                                      // [9][20]
@@ -183,6 +250,7 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
     }
 #undef EPOLY
     __syncthreads();
+    FP_STAMP(2);
     // ---- A = inv(A[:, :10]) * A[:, 10:]  (LU with partial pivoting, eps = 100*DBL_EPSILON, then gemm) ----
     double *Al = S + FP_AL, *Ainv = S + FP_AINV, *Ar = S + FP_AR, *Ap = S + FP_AP;
     for (int e = lane; e < 100; e += 64) { int i = e / 10, j = e - 10*i; Al[e] = Amat[i*20 + j]; Ar[e] = Amat[i*20 + 10 + j]; Ainv[e] = i == j; }
@@ -232,6 +300,7 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
         Ap[e] = s;
     }
     __syncthreads();
+    FP_STAMP(3);
     double* b = S + FP_B;                                           // 3 x 13
     if (lane < 3) {
         const double* a1 = Ap + (lane*2 + 4) * 10; const double* a2 = Ap + (lane*2 + 5) * 10;
@@ -245,8 +314,9 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
     }
     __syncthreads();
     double* rre = S + FP_ROOTS; double* rim = rre + 10;
-    if (lane == 0) {                                                // det B(z) and its roots
-        double e[3][3][5], c[11], t1[12], t2[12], m[12];
+    if (lane == 0) {                                                // det B(z)
+        double e[3][3][5], t1[12], t2[12], m[12];
+        double* c = S + FP_POLY;
         for (int r = 0; r < 3; r++) {
             for (int k = 0; k < 4; k++) { e[r][0][k] = b[r*13 + 3 - k]; e[r][1][k] = b[r*13 + 7 - k]; }
             e[r][0][4] = e[r][1][4] = 0;
@@ -262,9 +332,12 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
         pz_mul(e[1][0], 3, e[2][1], 3, t1); pz_mul(e[1][1], 3, e[2][0], 3, t2);
         for (int k = 0; k <= 6; k++) m[k] = t1[k] - t2[k];
         pz_mul(e[0][2], 4, m, 6, t1); for (int k = 0; k <= 10; k++) c[k] += t1[k];
-        solve_poly10(c, rre, rim, S + FP_POLY);
     }
     __syncthreads();
+    FP_STAMP(4);
+    solve_poly10(S + FP_POLY, rre, rim);                           // its roots, whole wave
+    __syncthreads();
+    FP_STAMP(5);
     double* cand = S + FP_CAND; double* flag = S + FP_FLAG;
     if (lane < 10) {                                                // one real root per lane
         flag[lane] = 0;
@@ -297,6 +370,7 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
         for (int i = 0; i < 10; i++) if (flag[i] != 0) { for (int k = 0; k < 9; k++) out[count*9 + k] = cand[i*9 + k]; count++; }
         nmodels[hyp] = count;
     }
+    FP_STAMP(6);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -616,6 +690,14 @@ uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f*
     UVO_HIP_TRY(c, hipMemcpyAsync(w->subsets, w->h_subsets.data(), sizeof(int) * 5 * nsub, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_fivepoint_hyp, dim3(nsub), dim3(64), 0, st, w->q1, w->q2, w->subsets, nsub, w->models, w->nmodels);
     UVO_HIP_TRY(c, hipGetLastError());
+    if (getenv("UVO_DBG_PHASE")) {
+        long long clk[8];
+        UVO_HIP_TRY(c, hipStreamSynchronize(st));
+        UVO_HIP_TRY(c, hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_fp_clk), sizeof(clk)));
+        fprintf(stderr, "[uvo] five-point phases (us): svd %.1f polys %.1f lu %.1f detB %.1f roots %.1f solveZ %.1f | nsub %d\n",
+                (clk[1]-clk[0])*0.01, (clk[2]-clk[1])*0.01, (clk[3]-clk[2])*0.01, (clk[4]-clk[3])*0.01, (clk[5]-clk[4])*0.01,
+                (clk[6]-clk[5])*0.01, nsub);
+    }
     if (n == modelPoints) {
         UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data(), w->nmodels, sizeof(int), hipMemcpyDeviceToHost, st));
         UVO_HIP_TRY(c, hipMemcpyAsync(E, w->models, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
