@@ -8,7 +8,7 @@
 // or LMedS ("smaller median wins") scan to pick the identical winner.  Small sequential fp64 pieces
 // (homography refit + Levenberg-Marquardt polish, decomposeHomographyMat) stay on the host as
 // SURVEY.md 2.3 (K5, K6) plans.
-//   k_fivepoint_hyp : one 5-point hypothesis per wave (Nister/Stewenius as in OpenCV's five-point.cpp)
+//   k_fivepoint_hyp : four 5-point hypotheses per wave (Nister/Stewenius as in OpenCV's five-point.cpp)
 //   k_e_score       : Sampson error of every (hypothesis, model) over all matches -> inlier count or median
 //   k_h_hyp         : one normalised-DLT homography per thread (9x9 Jacobi eigen in LDS)
 //   k_h_score       : reprojection error -> inlier count or median
@@ -75,11 +75,20 @@ __device__ __forceinline__ cplx c_div(cplx a, cplx b)
 // Every operation and its order are those of the scalar loop; only independent work moves to other lanes.
 // Exact shortcut: once a full sweep leaves every root bitwise unchanged, all later sweeps recompute the
 // same corrections from the same roots, so stopping there gives the result of the full 300 iterations.
-__device__ __forceinline__ double lane_bcast(double v, int k)      // value of lane k (k compile-time after unrolling) as a scalar
+// Four hypotheses share a wave, one per DPP row of 16 lanes.  row_bcast<K>(v) = v of lane K of the caller's own
+// row: one full-rate VALU move per 32 bits (row_newbcast), no LDS round trip on the critical path.
+template <int K>
+__device__ __forceinline__ double row_bcast(double v)
 {
     union { double d; int i[2]; } u; u.d = v;
-    u.i[0] = __builtin_amdgcn_readlane(u.i[0], k); u.i[1] = __builtin_amdgcn_readlane(u.i[1], k);
+    u.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x150 + K, 0xf, 0xf, false);
+    u.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x150 + K, 0xf, 0xf, false);
     return u.d;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 // denom *= df unless df == 0 (OpenCV skips coincident roots), branch-free
 __device__ __forceinline__ cplx dk_factor(cplx denom, cplx df)
@@ -88,14 +97,20 @@ __device__ __forceinline__ cplx dk_factor(cplx denom, cplx df)
     bool nz = df.re != 0 || df.im != 0;
     return cplx{ nz ? pr.re : denom.re, nz ? pr.im : denom.im };
 }
-// One Durand-Kerner sweep.  NC = 10: the degree is 10 at compile time (the general case); NC = 0: runtime
-// degree n < 10.  CHECKED = false multiplies every factor without OpenCV's "skip a zero difference" test and
-// reports in `sawzero` whether any factor that counts was zero; the caller then redoes the sweep CHECKED.
+// One Durand-Kerner sweep of cv::solvePoly for the hypothesis of this row; lane l (0..9) of the row owns root l
+// in registers.
+//   * the Horner numerators of a sweep depend only on each root's own old value -> all lanes at once;
+//   * the denominators are Gauss-Seidel (root i uses the NEW roots j < i) and OpenCV multiplies the factors in
+//     the order j = 0..n-1, so after root k is final every lane i > k takes the factor (p_i - z_k) in one SIMD
+//     step, and lane k alone finishes its chain over the old roots j > k.
+// Every operation and its order are those of the scalar loop; only independent work moves to other lanes.
+// NC = 10: the degree is 10 at compile time (the general case); NC = 0: runtime degree n < 10 (may differ per
+// row).  CHECKED = false multiplies every factor without OpenCV's "skip a zero difference" test and reports in
+// `sawzero` whether any factor that counts was zero; the caller then redoes the sweep CHECKED.
 template <int NC, bool CHECKED>
-__device__ __forceinline__ cplx dk_sweep(const cplx p, const double* cr, double cn, int n, cplx& q, bool& sawzero)
+__device__ __forceinline__ cplx dk_sweep(const cplx p, const double* cr, double cn, int n, int l, cplx& q, bool& sawzero)
 {
     constexpr int n0 = 10;
-    const int lane = threadIdx.x;
 #define DK_ON(j) (NC != 0 || (j) < n)
     cplx z = p;
     cplx num{cn, 0};
@@ -103,52 +118,57 @@ __device__ __forceinline__ cplx dk_sweep(const cplx p, const double* cr, double 
     for (int j = 0; j < n0; j++) if (DK_ON(j)) num = c_add(c_mul(num, p), cplx{cr[j], 0});
     cplx dfo[n0];                                // p - (old root j): the factors lane k multiplies after its own turn
     bool zero = false;
-#pragma unroll
-    for (int j = 1; j < n0; j++) {
-        dfo[j] = c_sub(p, cplx{ lane_bcast(p.re, j), lane_bcast(p.im, j) });
-        if (!CHECKED) zero = zero || (lane < j && DK_ON(j) && dfo[j].re == 0 && dfo[j].im == 0);
-    }
+    static_for<1, n0>([&](auto J) {
+        constexpr int j = decltype(J)::value;
+        dfo[j] = c_sub(p, cplx{ row_bcast<j>(p.re), row_bcast<j>(p.im) });
+        if (!CHECKED) zero = zero || (l < j && DK_ON(j) && dfo[j].re == 0 && dfo[j].im == 0);
+    });
     cplx denom{cn, 0};
     q = cplx{0, 0};
+    static_for<0, n0>([&](auto K) {
+        constexpr int k = decltype(K)::value;
+        if (l == k && DK_ON(k)) {
 #pragma unroll
-    for (int k = 0; k < n0; k++) {
-        if (DK_ON(k)) {
-            if (lane == k) {
-#pragma unroll
-                for (int j = k + 1; j < n0; j++) if (DK_ON(j)) denom = CHECKED ? dk_factor(denom, dfo[j]) : c_mul(denom, dfo[j]);
-                q = c_div(num, denom);
-                z = c_sub(p, q);
-            }
-            if (k + 1 < n0) {                    // lanes > k take the factor of the new root k (other lanes: dead value)
-                cplx df = c_sub(p, cplx{ lane_bcast(z.re, k), lane_bcast(z.im, k) });
-                if (!CHECKED) zero = zero || (lane > k && df.re == 0 && df.im == 0);
-                denom = CHECKED ? dk_factor(denom, df) : c_mul(denom, df);
-            }
+            for (int j = k + 1; j < n0; j++) if (DK_ON(j)) denom = CHECKED ? dk_factor(denom, dfo[j]) : c_mul(denom, dfo[j]);
+            q = c_div(num, denom);
+            z = c_sub(p, q);
         }
-    }
+        if constexpr (k + 1 < n0) {              // lanes > k take the factor of the new root k (other lanes: dead value)
+            cplx df = c_sub(p, cplx{ row_bcast<k>(z.re), row_bcast<k>(z.im) });
+            if (!CHECKED) zero = zero || (l > k && l < n && df.re == 0 && df.im == 0);
+            denom = CHECKED ? dk_factor(denom, df) : c_mul(denom, df);
+        }
+    });
 #undef DK_ON
     sawzero = zero;
     return z;
 }
+// 300 sweeps, or fewer when exact: OpenCV stops when the largest correction is <= 0; and once a full sweep leaves
+// every root bitwise unchanged all later sweeps recompute the same corrections, so stopping there gives the
+// result of the full 300 iterations.  The four rows of the wave stop independently (`live`).
 template <int NC>
-__device__ __forceinline__ cplx dk_sweeps(cplx z, const double* cr, double cn, int n)
+__device__ __forceinline__ cplx dk_sweeps(cplx z, const double* cr, double cn, int n, int l, int row)
 {
+    bool live = true;
 #pragma unroll 1
     for (int iter = 0; iter < 300; iter++) {
         cplx q; bool sawzero;
-        cplx zn = dk_sweep<NC, false>(z, cr, cn, n, q, sawzero);
-        if (__any(sawzero)) zn = dk_sweep<NC, true>(z, cr, cn, n, q, sawzero);
+        cplx zn = dk_sweep<NC, false>(z, cr, cn, n, l, q, sawzero);
+        if (__any(sawzero)) zn = dk_sweep<NC, true>(z, cr, cn, n, l, q, sawzero);
         bool moved = zn.re != z.re || zn.im != z.im;
         bool nonzero = q.re*q.re + q.im*q.im > 0;                   // sqrt(s) > 0  <=>  s > 0
-        z = zn;
-        if (!__any(nonzero)) break;              // maxDiff <= 0
-        if (!__any(moved)) break;
+        unsigned long long bn = __ballot(nonzero && l < n), bm = __ballot(moved && l < n);
+        if (live) z = zn;
+        bool go = ((bn >> (16 * row)) & 0xffffull) != 0 && ((bm >> (16 * row)) & 0xffffull) != 0;
+        live = live && go;
+        if (!__any(live)) break;
     }
     return z;
 }
-__device__ void solve_poly10(const double* cw, double* rre, double* rim)
+// cv::solvePoly, real coefficients c[0..10] (increasing powers) in LDS at `cw`; roots to rre/rim.
+__device__ void solve_poly10(const double* cw, double* rre, double* rim, int l, int row)
 {
-    const int n0 = 10, lane = threadIdx.x;
+    const int n0 = 10;
     int n = n0;
     for (; n > 1; n--) if (fabs(cw[n]) + fabs(0.0) > DBL_EPSILON) break;
     double cr[n0];                               // cr[j] = c[n-1-j]: the coefficient Horner step j adds
@@ -159,13 +179,13 @@ __device__ void solve_poly10(const double* cw, double* rre, double* rim)
     {
         cplx p{1, 0}; const cplx r{1, 1};
 #pragma unroll 1
-        for (int i = 0; i < n; i++) { if (i == lane) z = p; p = c_mul(p, r); }
+        for (int i = 0; i < n0; i++) { if (i == l && i < n) z = p; p = c_mul(p, r); }
     }
-    z = n == n0 ? dk_sweeps<10>(z, cr, cn, n) : dk_sweeps<0>(z, cr, cn, n);
-    if (lane < n && fabs(z.im) < 1e-100) z.im = 0;
-    int src = lane < n ? lane : n - 1;
+    z = __all(n == n0) ? dk_sweeps<10>(z, cr, cn, n, l, row) : dk_sweeps<0>(z, cr, cn, n, l, row);
+    if (l < n && fabs(z.im) < 1e-100) z.im = 0;
+    int src = (l < n ? l : n - 1) + 16 * row;
     double ore = __shfl(z.re, src), oim = __shfl(z.im, src);
-    if (lane < n0) { rre[lane] = ore; rim[lane] = oim; }
+    if (l < n0) { rre[l] = ore; rim[l] = oim; }
 }
 __device__ void pz_mul(const double* a, int da, const double* b, int db, double* out)
 {
@@ -184,29 +204,37 @@ static_assert(FP_POLY + 44 <= FP_TOTAL, "five-point LDS overlay");
 
 // diagnostic: 100 MHz wall-clock stamps of hypothesis 0's phases (printed by the host when UVO_DBG_PHASE is set)
 __device__ long long g_fp_clk[8];
-#define FP_STAMP(i) do { if (hyp == 0 && lane == 0) g_fp_clk[i] = wall_clock64(); } while (0)
+#define FP_STAMP(i) do { if (hyp == 0 && l == 0) g_fp_clk[i] = wall_clock64(); } while (0)
 
+// Four hypotheses per 64-thread workgroup (one per DPP row of 16 lanes, `l` = lane within the row): the
+// Durand-Kerner stage is VALU-issue bound, so sharing every instruction between four hypotheses quarters its
+// cost, and the 500 single-wave workgroups of a 2000-iteration RANSAC run all start at once (2 per CU by LDS).
+constexpr int kFpPerWg = 4;
 __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const double* q2, const int* subsets, int nhyp,
                                                       double* models /* nhyp x 10 x 9 */, int* nmodels)
 {
-    __shared__ double S[FP_TOTAL];
-    __shared__ int s_piv, s_sing;
-    const int hyp = blockIdx.x, lane = threadIdx.x;
+    __shared__ double S2[kFpPerWg * FP_TOTAL];
+    __shared__ int s_piv[kFpPerWg], s_sing[kFpPerWg];
+    const int row = threadIdx.x >> 4, l = threadIdx.x & 15;       // DPP row 0..3 = hypothesis slot
+    const int hyp_raw = blockIdx.x * kFpPerWg + row;
+    const bool real = hyp_raw < nhyp;                              // a ragged tail recomputes the last hypothesis, writes nothing
+    const int hyp = real ? hyp_raw : nhyp - 1;
+    double* S = S2 + row * FP_TOTAL;
     using A1 = SArr<1>;
     double* At = S + FP_AT;
     FP_STAMP(0);
     // ---- Q (5 x 9) in the first five rows of the 9 x 9 buffer, rest zero ----
-    for (int i = lane; i < 81; i += 64) At[i] = 0;
+    for (int i = l; i < 81; i += 16) At[i] = 0;
     __syncthreads();
-    if (lane < 5) {
-        int id = subsets[hyp * 5 + lane];
+    if (l < 5) {
+        int id = subsets[hyp * 5 + l];
         double x1 = q1[2*id], y1 = q1[2*id+1], x2 = q2[2*id], y2 = q2[2*id+1];
-        double* r = At + lane * 9;
+        double* r = At + l * 9;
         r[0] = x2*x1; r[1] = x2*y1; r[2] = x2; r[3] = y2*x1; r[4] = y2*y1; r[5] = y2; r[6] = x1; r[7] = y1; r[8] = 1.0;
     }
     __syncthreads();
     // SVD::compute(Q, FULL_UV): rows 5..8 of Vt = JacobiSVD's completion = null-space basis
-    if (lane == 0) jacobi_svd_rt(A1{At}, A1{S + FP_W}, A1{S + FP_V5}, A1{S + FP_WT}, 9, 5, 9);
+    if (l == 0) jacobi_svd_rt(A1{At}, A1{S + FP_W}, A1{S + FP_V5}, A1{S + FP_WT}, 9, 5, 9);
     __syncthreads();
     FP_STAMP(1);
     const double* EE = At + 45;                                   // 4 x 9
@@ -214,20 +242,20 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
     double* EEt = S + FP_EET;                                      // [9][20]
     double* tr = S + FP_TR;
     double* Amat = S + FP_A;                                       // 10 x 20
-    double* L = S + FP_LANE + (lane < 10 ? lane : 0) * 120;        // private: 6 polys
-    if (lane < 9) {                                                // p_lin
-        double* p = Ep + lane * 20;
+    double* L = S + FP_LANE + (l < 10 ? l : 0) * 120;              // private: 6 polys
+    if (l < 9) {                                                   // p_lin
+        double* p = Ep + l * 20;
         p_zero(p);
-        p[12] = EE[0*9 + lane]; p[15] = EE[1*9 + lane]; p[18] = EE[2*9 + lane]; p[19] = EE[3*9 + lane];
+        p[12] = EE[0*9 + l]; p[15] = EE[1*9 + l]; p[18] = EE[2*9 + l]; p[19] = EE[3*9 + l];
     }
     __syncthreads();
 #define EPOLY(i, j) (Ep + ((i)*3 + (j)) * 20)
-    if (lane < 9) {                                                // (E E^T)(i,j)
-        int i = lane / 3, j = lane - 3*i;
-        double* acc = EEt + lane * 20; double* t = L;
+    if (l < 9) {                                                   // (E E^T)(i,j)
+        int i = l / 3, j = l - 3*i;
+        double* acc = EEt + l * 20; double* t = L;
         p_zero(acc);
         for (int k = 0; k < 3; k++) { p_mul(EPOLY(i, k), EPOLY(j, k), t); p_axpy(acc, 1.0, t); }
-    } else if (lane == 9) {                                        // det(E) -> row 0
+    } else if (l == 9) {                                           // det(E) -> row 0
         double *m0 = L, *m1 = L + 20, *m2 = L + 40, *t = L + 60, *d = L + 80;
         p_mul(EPOLY(1,1), EPOLY(2,2), m0); p_mul(EPOLY(1,2), EPOLY(2,1), t); p_axpy(m0, -1.0, t);
         p_mul(EPOLY(1,0), EPOLY(2,2), m1); p_mul(EPOLY(1,2), EPOLY(2,0), t); p_axpy(m1, -1.0, t);
@@ -238,62 +266,60 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
         for (int k = 0; k < 20; k++) Amat[k] = d[k];
     }
     __syncthreads();
-    if (lane == 0) { p_zero(tr); for (int i = 0; i < 3; i++) p_axpy(tr, 1.0, EEt + (i*3 + i) * 20); }
+    if (l == 0) { p_zero(tr); for (int i = 0; i < 3; i++) p_axpy(tr, 1.0, EEt + (i*3 + i) * 20); }
     __syncthreads();
-    if (lane < 9) {                                                // 2 E E^T E - trace(E E^T) E
-        int i = lane / 3, j = lane - 3*i;
+    if (l < 9) {                                                   // 2 E E^T E - trace(E E^T) E
+        int i = l / 3, j = l - 3*i;
         double* acc = L + 20; double* t = L;
         p_zero(acc);
         for (int k = 0; k < 3; k++) { p_mul(EEt + (i*3 + k) * 20, EPOLY(k, j), t); p_axpy(acc, 2.0, t); }
         p_mul(tr, EPOLY(i, j), t); p_axpy(acc, -1.0, t);
-        for (int k = 0; k < 20; k++) Amat[(1 + lane) * 20 + k] = acc[k];
+        for (int k = 0; k < 20; k++) Amat[(1 + l) * 20 + k] = acc[k];
     }
 #undef EPOLY
     __syncthreads();
     FP_STAMP(2);
     // ---- A = inv(A[:, :10]) * A[:, 10:]  (LU with partial pivoting, eps = 100*DBL_EPSILON, then gemm) ----
     double *Al = S + FP_AL, *Ainv = S + FP_AINV, *Ar = S + FP_AR, *Ap = S + FP_AP;
-    for (int e = lane; e < 100; e += 64) { int i = e / 10, j = e - 10*i; Al[e] = Amat[i*20 + j]; Ar[e] = Amat[i*20 + 10 + j]; Ainv[e] = i == j; }
-    if (lane == 0) s_sing = 0;
+    for (int e = l; e < 100; e += 16) { int i = e / 10, j = e - 10*i; Al[e] = Amat[i*20 + j]; Ar[e] = Amat[i*20 + 10 + j]; Ainv[e] = i == j; }
+    if (l == 0) s_sing[row] = 0;
     __syncthreads();
-    for (int i = 0; i < 10; i++) {
-        if (lane == 0) {
+    for (int i = 0; i < 10; i++) {                                 // (a singular hypothesis idles through the remaining steps)
+        if (l == 0 && !s_sing[row]) {
             int k = i;
             for (int j = i+1; j < 10; j++) if (fabs(Al[j*10 + i]) > fabs(Al[k*10 + i])) k = j;
-            s_piv = k;
-            if (fabs(Al[k*10 + i]) < DBL_EPSILON * 100) s_sing = 1;
+            s_piv[row] = k;
+            if (fabs(Al[k*10 + i]) < DBL_EPSILON * 100) s_sing[row] = 1;
         }
         __syncthreads();
-        if (s_sing) break;
-        int k = s_piv;
-        if (k != i && lane < 10) {
-            if (lane >= i) { double t = Al[i*10 + lane]; Al[i*10 + lane] = Al[k*10 + lane]; Al[k*10 + lane] = t; }
-            double t = Ainv[i*10 + lane]; Ainv[i*10 + lane] = Ainv[k*10 + lane]; Ainv[k*10 + lane] = t;
+        const bool on = !s_sing[row];
+        int k = s_piv[row];
+        if (on && k != i && l < 10) {
+            if (l >= i) { double t = Al[i*10 + l]; Al[i*10 + l] = Al[k*10 + l]; Al[k*10 + l] = t; }
+            double t = Ainv[i*10 + l]; Ainv[i*10 + l] = Ainv[k*10 + l]; Ainv[k*10 + l] = t;
         }
         __syncthreads();
-        double d = -1/Al[i*10 + i];
-        int j = i + 1 + lane;
-        if (j < 10) {
+        int j = i + 1 + l;
+        if (on && j < 10) {
+            double d = -1/Al[i*10 + i];
             double alpha = Al[j*10 + i]*d;
             for (int kk = i+1; kk < 10; kk++) Al[j*10 + kk] += alpha*Al[i*10 + kk];
             for (int kk = 0; kk < 10; kk++) Ainv[j*10 + kk] += alpha*Ainv[i*10 + kk];
         }
         __syncthreads();
     }
-    if (!s_sing) {
-        for (int i = 9; i >= 0; i--) {
-            if (lane < 10) {
-                double s = Ainv[i*10 + lane];
-                for (int k = i+1; k < 10; k++) s -= Al[i*10 + k]*Ainv[k*10 + lane];
-                Ainv[i*10 + lane] = s/Al[i*10 + i];
-            }
-            __syncthreads();
+    const bool sing = s_sing[row] != 0;
+    for (int i = 9; i >= 0; i--) {
+        if (!sing && l < 10) {
+            double s = Ainv[i*10 + l];
+            for (int k = i+1; k < 10; k++) s -= Al[i*10 + k]*Ainv[k*10 + l];
+            Ainv[i*10 + l] = s/Al[i*10 + i];
         }
-    } else {
-        for (int e = lane; e < 100; e += 64) Ainv[e] = 0;            // invert() of a singular matrix yields zeros
         __syncthreads();
     }
-    for (int e = lane; e < 100; e += 64) {
+    if (sing) for (int e = l; e < 100; e += 16) Ainv[e] = 0;        // invert() of a singular matrix yields zeros
+    __syncthreads();
+    for (int e = l; e < 100; e += 16) {
         int i = e / 10, j = e - 10*i;
         double s = 0;
         for (int k = 0; k < 10; k++) s += Ainv[i*10 + k] * Ar[k*10 + j];
@@ -302,19 +328,19 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
     __syncthreads();
     FP_STAMP(3);
     double* b = S + FP_B;                                           // 3 x 13
-    if (lane < 3) {
-        const double* a1 = Ap + (lane*2 + 4) * 10; const double* a2 = Ap + (lane*2 + 5) * 10;
+    if (l < 3) {
+        const double* a1 = Ap + (l*2 + 4) * 10; const double* a2 = Ap + (l*2 + 5) * 10;
         double row1[13], row2[13];
         for (int k = 0; k < 13; k++) row1[k] = row2[k] = 0;
         for (int k = 0; k < 3; k++) { row1[1 + k] = a1[k]; row1[5 + k] = a1[3 + k]; }
         for (int k = 0; k < 4; k++) row1[9 + k] = a1[6 + k];
         for (int k = 0; k < 3; k++) { row2[k] = a2[k]; row2[4 + k] = a2[3 + k]; }
         for (int k = 0; k < 4; k++) row2[8 + k] = a2[6 + k];
-        for (int k = 0; k < 13; k++) b[lane*13 + k] = row1[k] - row2[k];
+        for (int k = 0; k < 13; k++) b[l*13 + k] = row1[k] - row2[k];
     }
     __syncthreads();
     double* rre = S + FP_ROOTS; double* rim = rre + 10;
-    if (lane == 0) {                                                // det B(z)
+    if (l == 0) {                                                   // det B(z)
         double e[3][3][5], t1[12], t2[12], m[12];
         double* c = S + FP_POLY;
         for (int r = 0; r < 3; r++) {
@@ -335,15 +361,15 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
     }
     __syncthreads();
     FP_STAMP(4);
-    solve_poly10(S + FP_POLY, rre, rim);                           // its roots, whole wave
+    solve_poly10(S + FP_POLY, rre, rim, l, row);                  // its roots
     __syncthreads();
     FP_STAMP(5);
     double* cand = S + FP_CAND; double* flag = S + FP_FLAG;
-    if (lane < 10) {                                                // one real root per lane
-        flag[lane] = 0;
-        if (!(fabs(rim[lane]) > 1e-10)) {
-            double z1 = rre[lane], z2 = z1*z1, z3 = z2*z1, z4 = z3*z1;
-            double* R = S + FP_RT + lane * 33;                      // bz 9 | at 9 | w 3 | vt 9 | wt 3
+    if (l < 10) {                                                   // one real root per lane
+        flag[l] = 0;
+        if (!(fabs(rim[l]) > 1e-10)) {
+            double z1 = rre[l], z2 = z1*z1, z3 = z2*z1, z4 = z3*z1;
+            double* R = S + FP_RT + l * 33;                         // bz 9 | at 9 | w 3 | vt 9 | wt 3
             for (int j = 0; j < 3; j++) {
                 const double* br = b + j*13;
                 R[j*3 + 0] = br[0]*z3 + br[1]*z2 + br[2]*z1 + br[3];
@@ -358,13 +384,13 @@ __global__ __launch_bounds__(64) void k_fivepoint_hyp(const double* q1, const do
                 for (int k = 0; k < 9; k++) Ev[k] = EE[0*9 + k]*xs + EE[1*9 + k]*ys + EE[2*9 + k]*z1 + EE[3*9 + k];
                 for (int k = 0; k < 9; k++) nrm += Ev[k]*Ev[k];
                 nrm = sqrt(nrm);
-                for (int k = 0; k < 9; k++) cand[lane*9 + k] = Ev[k] / nrm;
-                flag[lane] = 1;
+                for (int k = 0; k < 9; k++) cand[l*9 + k] = Ev[k] / nrm;
+                flag[l] = 1;
             }
         }
     }
     __syncthreads();
-    if (lane == 0) {
+    if (l == 0 && real) {
         int count = 0;
         double* out = models + (size_t)hyp * 90;
         for (int i = 0; i < 10; i++) if (flag[i] != 0) { for (int k = 0; k < 9; k++) out[count*9 + k] = cand[i*9 + k]; count++; }
@@ -688,7 +714,7 @@ uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f*
     if (n == modelPoints) { for (int i = 0; i < 5; i++) w->h_subsets[i] = i; nsub = 1; }
     else nsub = make_subsets(w->h_subsets.data(), niters, modelPoints, n, lmeds ? 1000 : 10000, nullptr, nullptr, &failed_first);
     UVO_HIP_TRY(c, hipMemcpyAsync(w->subsets, w->h_subsets.data(), sizeof(int) * 5 * nsub, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_fivepoint_hyp, dim3(nsub), dim3(64), 0, st, w->q1, w->q2, w->subsets, nsub, w->models, w->nmodels);
+    hipLaunchKernelGGL(k_fivepoint_hyp, dim3((nsub + kFpPerWg - 1) / kFpPerWg), dim3(64), 0, st, w->q1, w->q2, w->subsets, nsub, w->models, w->nmodels);
     UVO_HIP_TRY(c, hipGetLastError());
     if (getenv("UVO_DBG_PHASE")) {
         long long clk[8];
