@@ -208,6 +208,14 @@ class Context:
         self._check(self._lib.uvo_extract_3d_points(self._h, _p(k1), _p(k2), n, *[_p(x) for x in a], _p(p4), _p(pts), _p(idx), C.byref(g)))
         return pts[:g.value].copy(), idx[:g.value].copy()
 
+    def reproject_errors(self, world_points, R, t, K, img_points):
+        w, img = _np(world_points, np.float64), _np(img_points, np.float32)
+        R, t, K = _np(R, np.float64), _np(t, np.float64), _np(K, np.float64)
+        n = len(w)
+        err = np.empty(max(n, 1))
+        self._check(self._lib.uvo_reproject_errors(self._h, _p(w), n, _p(R), _p(t), _p(K), _p(img), _p(err)))
+        return err[:n].copy()
+
     def solvePnPRansac(self, object_points, image_points, K, iterations_count=None, reprojection_error=None, confidence=None):
         p = self.params
         it = int(p.ITERATIONS_COUNT if iterations_count is None else iterations_count)

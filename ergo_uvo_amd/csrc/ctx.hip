@@ -293,6 +293,16 @@ extern "C" uvo_status uvo_extract_3d_points(uvo_ctx* c, const uvo_point2f* k1, c
     return UVO_OK;
 }
 
+extern "C" uvo_status uvo_reproject_errors(uvo_ctx* c, const double* world, int n, const double* R, const double* t,
+                                           const double* K, const uvo_point2f* img, double* err)
+{
+    if (!c || n < 0 || !R || !t || !K || (n && (!world || !img || !err))) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    if (n == 0) return UVO_OK;
+    if (n > c->cap) return fail(c, UVO_CAPACITY, "point count exceeds the context's max_kpts");
+    return pose_reproject_errors(c, world, n, R, t, K, img, err);
+}
+
 extern "C" uvo_status uvo_solve_pnp_ransac(uvo_ctx* c, const double* obj, const uvo_point2f* img, int n, const double* K,
                                            int iterations_count, float reprojection_error, double confidence,
                                            double* rvec, double* tvec, int* inliers, int* n_inliers, int* ok)

@@ -80,6 +80,17 @@ __global__ __launch_bounds__(256) void k_extract3d_a(const float4* pts4, const u
     flag[i] = ((mean < tol) && (Z > 0)) ? 1 : 0;
 }
 
+// reproject_errors (VOU:632-651) on caller-provided points
+__global__ __launch_bounds__(256) void k_reproject_errors(const double* world, const uvo_point2f* img, Cam cm, int n, double* err)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double u, v;
+    project_point(world[3*i], world[3*i + 1], world[3*i + 2], cm.R, cm.t, cm.fx, cm.fy, cm.cx, cm.cy, &u, &v);
+    double dx = img[i].x - u, dy = img[i].y - v;
+    err[i] = sqrt(dx * dx + dy * dy);
+}
+
 // block-wide ordered compaction helper: returns the exclusive position of a kept element and
 // advances *s_base (shared) by the number kept in this pass.  1024 threads.
 __device__ __forceinline__ int block_compact_pos(bool keep, int* wtot, int* s_base)
@@ -322,6 +333,20 @@ uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, 
                        c->p.MIN_NUM_3DPOINTS, c->d_tmp_idx, c->d_good_pts[slot], c->d_good_idx[slot], c->d_opts[slot], c->d_ipts[slot],
                        c->d_counts);
     UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+
+uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const double* R, const double* t, const double* K,
+                                 const uvo_point2f* img, double* err)
+{
+    // staging: d_cam1 (cap x 3 f64) for the points, d_x1 for the pixels, d_good_pts[0] for the result
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->d_cam1, world, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x1, img, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_reproject_errors, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->d_cam1, c->d_x1, make_cam(R, t, K), n,
+                       c->d_good_pts[0]);
+    UVO_HIP_TRY(c, hipGetLastError());
+    UVO_HIP_TRY(c, hipMemcpyAsync(err, c->d_good_pts[0], sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return UVO_OK;
 }
 

@@ -154,6 +154,8 @@ uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio,
 uvo_status pose_triangulate(Ctx* c, const double* P1, const double* P2, const int* d_n, int n_max);
 uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, const double* R2, const double* t2,
                           const double* K1, const double* K2, const int* d_n, int n_max);
+uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const double* R, const double* t, const double* K,
+                                 const uvo_point2f* img, double* err);
 uvo_status pose_pnp_ransac(Ctx* c, int slot, int G, const double* K, int iters, float reproj, double conf,
                            double* rvec, double* tvec, int* n_inliers, int* ok);
 int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters);

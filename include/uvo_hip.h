@@ -101,6 +101,11 @@ uvo_status uvo_extract_3d_points(uvo_ctx* c, const uvo_point2f* k1, const uvo_po
                                  const double* K1, const double* K2, const float* points4d,
                                  double* pts, int* idx, int* g);
 
+/* ---- reproject_errors (VO_utility.h:112 -> VO_utility.cpp:632-651): cv::projectPoints without distortion,
+ * then the pixel distance to img[i].  world: n x 3 f64, R: 3x3 f64, t: 3, K: 3x3 (host); err: n f64 (host). */
+uvo_status uvo_reproject_errors(uvo_ctx* c, const double* world, int n, const double* R, const double* t,
+                                const double* K, const uvo_point2f* img, double* err);
+
 /* ---- cv::solvePnPRansac(..., SOLVEPNP_EPNP) as called at visual_odometry.h:647-648 ----
  * obj: n x 3 f64, img: n Point2f, K 3x3 f64 (host).  inliers: host, capacity n, ascending.
  * *ok is OpenCV's bool return. */

@@ -206,6 +206,15 @@ def extract_3d_points(k1, k2, R1, t1, R2, t2, K1, K2, points4d, min_pts=5, tol=3
     return pts[:g].copy(), idx[:g].copy()
 
 
+def reproject_errors(world, R, t, K, img):
+    world = _c(world, np.float64); img = _c(img, np.float32)
+    R, t, K = _c(R, np.float64), _c(t, np.float64), _c(K, np.float64)
+    n = len(world)
+    err = np.empty(max(n, 1))
+    lib().orc_reproject_errors(_p(world), n, _p(R), _p(t), _p(K), _p(img), _p(err))
+    return err[:n].copy()
+
+
 def solve_pnp_ransac(obj, img, K, iters=1000, reproj=1.0, conf=0.99):
     obj = _c(obj, np.float64); img = _c(img, np.float32); K = _c(K, np.float64)
     n = len(obj)

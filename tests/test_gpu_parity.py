@@ -149,6 +149,14 @@ def test_extract_3dpoints_bit_exact(ctx, oracle, n, noise):
     assert np.array_equal(pts.view(np.uint64), opts.view(np.uint64))
 
 
+@pytest.mark.parametrize("n", [1, 257, 3000])
+def test_reproject_errors_bit_exact(ctx, oracle, n):
+    rig, X, x1, x2, P1, P2 = _synthetic_stereo_points(n, 29, 0.7)
+    err = ctx.reproject_errors(X, rig.R_right, rig.t_right, rig.K_right, x2)
+    oerr = oracle.reproject_errors(X, rig.R_right, rig.t_right, rig.K_right, x2)
+    assert np.array_equal(err.view(np.uint64), oerr.view(np.uint64))
+
+
 @pytest.mark.parametrize("n,outliers,noise", [(5, 0.0, 0.1), (6, 0.0, 0.1), (300, 0.2, 0.3), (1200, 0.5, 0.5), (900, 0.9, 0.3), (40, 1.0, 0.0)])
 def test_pnp_ransac_parity(ctx, oracle, n, outliers, noise):
     from ergo_uvo_amd import synth

@@ -1,0 +1,115 @@
+"""The C++ host-side mirror of the reference's uvo_libraries API (include/uvo_libraries_hip/, ergo_uvo_amd/shim/).
+
+CPU: the shim library builds, exports every function the reference's VO_utility.h declares for the path, and its
+header compiles stand-alone.  GPU: a C++ driver runs the stereo node's loop (visual_odometry.h:474-739) through the
+shim and every per-frame record must equal the CPU oracle's state machine bit for bit."""
+import os
+import shutil
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM_DIR = os.path.join(ROOT, "ergo_uvo_amd", "shim")
+SHIM_LIB = os.path.join(ROOT, "ergo_uvo_amd", "lib", "libuvo_libraries_hip.so")
+DRIVER = os.path.join(ROOT, "tests", "cpp", "build", "shim_stereo_node")
+
+# VO_utility.h:96-117, minus ROS parameter readers, get_image / resize_camera_matrix and show_matches
+REFERENCE_FUNCTIONS = [
+    "compute_projection_matrix", "compute_scale_factor", "convert_3Dpoints_camera", "convert_from_homogeneous_coords",
+    "detect_features", "estimate_relative_pose", "extract_3Dpoints", "extract_3Dpoints_and_reprojection", "extract_inliers",
+    "match_features", "recover_pose_homography", "reproject_errors", "select_desired_descriptors", "select_desired_keypoints",
+    "select_estimation_method",
+]
+REFERENCE_GLOBALS = [
+    "FEATURE_DETECTOR", "DISTANCE", "ESSENTIAL_OUTLIER_METHOD", "ESSENTIAL_MAX_ITERS", "ESSENTIAL_CONFIDENCE", "ESSENTIAL_THRESHOLD",
+    "HOMOGRAPHY_OUTLIER_METHOD", "HOMOGRAPHY_MAX_ITERS", "HOMOGRAPHY_CONFIDENCE", "HOMOGRAPHY_THRESHOLD", "HOMOGRAPHY_DISTANCE",
+    "VPF_THRESHOLD", "REPROJECTION_TOLERANCE", "LOWE_RATIO_THRESHOLD", "MIN_NUM_FEATURES", "MIN_NUM_3DPOINTS", "MIN_NUM_INLIERS",
+    "ITERATIONS_COUNT", "REPROJECTION_ERROR_THRESHOLD", "CONFIDENCE", "USE_EXTRINSIC_GUESS", "PNP_METHOD_FLAG",
+    "SURF_MIN_HESSIAN", "SURF_OCTAVES_NUMBER", "SURF_OCTAVES_LAYERS", "SURF_EXTENDED", "SURF_UPRIGHT", "use_essential",
+]
+
+
+def _build():
+    from ergo_uvo_amd import _lib
+    _lib.build()
+    subprocess.check_call(["make", "-C", SHIM_DIR, "-s"])
+
+
+def test_shim_builds_and_exports_reference_surface():
+    _build()
+    assert os.path.exists(SHIM_LIB) and os.path.exists(DRIVER)
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", "-C", SHIM_LIB], text=True)
+    for f in REFERENCE_FUNCTIONS:
+        assert any(line.split(" ", 2)[-1].startswith(f + "(") for line in syms.splitlines()), f
+    assert sum(1 for line in syms.splitlines() if line.split(" ", 2)[-1].startswith("match_features(")) == 2   # both overloads
+    for g in REFERENCE_GLOBALS:
+        assert any(line.split()[-1] == g or line.split(" ", 2)[-1].startswith(g + "[") for line in syms.splitlines()), g
+    for f in ("uvo_hip::triangulatePoints(", "uvo_hip::solvePnPRansac(", "uvo_hip::Rodrigues(", "uvo_hip::configure("):
+        assert f in syms, f
+    # the shim is marshalling only: it must not link or name the test oracle
+    blob = open(SHIM_LIB, "rb").read()
+    assert b"orc_" not in blob and b"liboracle" not in blob
+
+
+def test_shim_header_is_self_contained(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "uvo_libraries_hip/VO_utility_hip.h"\nint main() { uvocv::Mat m(2, 2, uvocv::CV_64FC1); return m.rows - 2; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-DUVO_NO_OPENCV", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "include"), str(src)])
+
+
+def test_cv_compat_mat_semantics(tmp_path):
+    """push_back / row / t / clone of the stand-in Mat behave like cv::Mat for the cases the API relies on."""
+    src = tmp_path / "m.cpp"
+    src.write_text(r'''
+#include "uvo_libraries_hip/cv_compat.h"
+#include <cstdio>
+using namespace uvocv;
+int main() {
+    Mat idx; for (int i = 0; i < 5; i++) idx.push_back(i * 3);
+    if (idx.rows != 5 || idx.cols != 1 || idx.type() != CV_32SC1 || idx.at<int>(4, 0) != 12) return 1;
+    Mat a(2, 3, CV_64FC1); for (int i = 0; i < 6; i++) a.at<double>(i / 3, i % 3) = i;
+    Mat alias = a; Mat b = a.clone(); a.push_back(b);                 // append must not disturb an aliasing header
+    if (a.rows != 4 || alias.rows != 2 || a.at<double>(3, 2) != 5 || alias.at<double>(1, 2) != 5) return 2;
+    Mat t = b.t(); if (t.rows != 3 || t.cols != 2 || t.at<double>(2, 1) != 5 || t.at<double>(1, 0) != 1) return 3;
+    Mat r = b.row(1); if (r.rows != 1 || r.at<double>(0, 0) != 3) return 4;
+    Mat e = Mat::eye(3, 3, CV_64FC1); if (e.at<double>(1, 1) != 1 || e.at<double>(1, 2) != 0) return 5;
+    if (sizeof(KeyPoint) != 28 || sizeof(DMatch) != 16 || sizeof(Point2f) != 8) return 6;
+    return 0;
+}
+''')
+    exe = tmp_path / "m"
+    subprocess.check_call(["g++", "-std=c++17", "-DUVO_NO_OPENCV", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
+
+
+@pytest.mark.gpu
+def test_stereo_node_loop_through_the_shim_matches_oracle(oracle, scene_small, tmp_path):
+    from ergo_uvo_amd import synth
+    _build()
+    rig = synth.stereo_rig(640)
+    seq = [scene_small[k] for k in (0, 1, 2, 1, 0)]
+    H, W = seq[0][0].shape
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<4i", W, H, len(seq), 1500))
+        for m in (rig.K_left, rig.K_right, rig.R_right, rig.t_right):
+            f.write(np.ascontiguousarray(m, np.float64).tobytes())
+        for L, R in seq:
+            f.write(np.ascontiguousarray(L).tobytes()); f.write(np.ascontiguousarray(R).tobytes())
+    res = subprocess.run([DRIVER, str(inp), str(outp)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    rec = np.fromfile(outp, np.dtype([("i", "<i4", 8), ("d", "<f8", 9)]))
+    assert len(rec) == len(seq)
+    ovo = oracle.StereoVO(oracle.stereo_params(1500), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    nvalid = 0
+    for k, (L, R) in enumerate(seq):
+        o = ovo.step(L, R, 0.05)
+        want = [o.valid, o.initialized, o.n_left, o.n_right, o.n_stereo_matches, o.n_tri_matches, o.n_good3d, o.n_inliers]
+        assert list(rec["i"][k]) == want, (k, list(rec["i"][k]), want)
+        d = np.array(list(o.rvec) + list(o.tvec) + list(o.t_prev_curr))
+        assert np.array_equal(rec["d"][k].view(np.uint64), d.view(np.uint64)), (k, rec["d"][k], d)
+        nvalid += o.valid
+    assert nvalid == len(seq) - 1
