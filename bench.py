@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic stereo pairs (ping-pong order)")
+    ap.add_argument("--depth", type=int, default=int(os.environ.get("UVO_PIPELINE_DEPTH", "4")),
+                    help="consecutive pairs in flight per image stream (uvo_stereo_set_depth)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-oracle baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -92,6 +94,7 @@ def main():
     rig = synth.stereo_rig(WIDTH)
     params = uvo.Params.stereo(SURF_MIN_HESSIAN=min_hessian)
     ctx = uvo.Context(params, local_rank, WIDTH, HEIGHT, 8192)
+    ctx.stereo_set_depth(args.depth)
     ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
 
     order = ping_pong(args.frames)
@@ -119,12 +122,13 @@ def main():
     t0 = time.perf_counter()
     n_valid = 0
     kp_sum = 0
-    # one stream, two pairs in flight: the detector/matcher of pair i+1 (stream A) overlaps the PnP of
-    # pair i (stream B); every pair's result is identical to the synchronous uvo_stereo_step's
-    submit()
+    # one image stream, `depth` consecutive pairs in flight on separate pipeline lanes (own buffers, HIP streams and
+    # PnP worker thread each); a pair only waits for the previous pair's "after stereo match" set.  Every pair's
+    # result is identical to the synchronous uvo_stereo_step's (tests/test_gpu_parity.py).
+    submitted = 0
     for i in range(args.steps):
-        if i + 1 < args.steps:
-            submit()
+        while submitted < args.steps and submitted - i < args.depth:
+            submit(); submitted += 1
         r = ctx.stereo_collect(0.05)
         n_valid += r.valid
         kp_sum += r.n_left
@@ -185,7 +189,7 @@ def main():
             "config": {"workload": "C3: stereo UVO synthetic 1920x1080 pair, ~3000 SURF kpts/image, EPnP PnP-RANSAC"
                                    if world == 1 else "C5: one independent 1920x1080 stereo stream per GPU",
                        "min_hessian": min_hessian, "kpts_per_image": round(kp_sum / max(args.steps, 1), 1),
-                       "valid_steps": n_valid, "frames": args.frames, "parallelism": f"streams{world}", "pipeline": "submit/collect, 2 pairs in flight per stream"},
+                       "valid_steps": n_valid, "frames": args.frames, "parallelism": f"streams{world}", "pipeline": f"submit/collect, {args.depth} pairs in flight per image stream"},
             "roofline": {"bound": "hbm", "kernel": "k_hessian_nms<octave 0> (2 images per launch)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

@@ -256,6 +256,10 @@ class Context:
         self._check(self._lib.uvo_stereo_step(self._h, pl, pr, w, h, w, ml, C.c_double(dt), C.byref(r)))
         return r
 
+    def stereo_set_depth(self, depth):
+        """Number of consecutive pairs that may be in flight between stereo_submit and stereo_collect (default 2)."""
+        self._check(self._lib.uvo_stereo_set_depth(self._h, int(depth)))
+
     def stereo_submit(self, left, right):
         """Enqueue detect..extract_3Dpoints of a pair (no host sync); at most two pairs in flight."""
         h, w = left.shape[-2], left.shape[-1]

@@ -18,7 +18,7 @@ EXPORTS = [
     "uvo_ctx_stream", "uvo_ctx_set_params", "uvo_surf_detect", "uvo_integral", "uvo_hessian_layer",
     "uvo_match_knn2_ratio", "uvo_match_knn2", "uvo_triangulate_points", "uvo_extract_3d_points",
     "uvo_solve_pnp_ransac", "uvo_reproject_errors", "uvo_rodrigues", "uvo_stereo_set_rig", "uvo_stereo_reset", "uvo_stereo_step",
-    "uvo_stereo_submit", "uvo_stereo_collect",
+    "uvo_stereo_set_depth", "uvo_stereo_submit", "uvo_stereo_collect",
     "uvo_stereo_get", "uvo_find_essential_mat", "uvo_recover_pose", "uvo_find_homography", "uvo_decompose_homography_mat",
     "uvo_recover_pose_homography", "uvo_select_estimation_method", "uvo_estimate_relative_pose", "uvo_mono_set_camera",
     "uvo_mono_reset", "uvo_mono_step", "uvo_mono_get", "uvo_timing_enable", "uvo_timing_count", "uvo_timing_name", "uvo_timing_get", "uvo_timing_reset",

@@ -51,7 +51,11 @@ static void make_desc_weights(float* DW)
     for (int i = 0; i < 20; i++) for (int j = 0; j < 20; j++) DW[i * 20 + j] = G[i] * G[j];
 }
 
-extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w, int max_h, int max_kpts, uvo_ctx** out)
+static void lane_worker(uvo_ctx* L);
+static void destroy_one(uvo_ctx* c);
+
+// one set of buffers, streams and a stage-B worker thread: the caller's context, or a further pipeline lane of it
+static uvo_status create_one(const uvo_params* p, int device, int max_w, int max_h, int max_kpts, uvo_ctx** out)
 {
     if (!out) return UVO_INVALID_ARG;
     *out = nullptr;
@@ -87,6 +91,7 @@ extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w,
         A(hipEventCreateWithFlags(&c->evA[i], hipEventDisableTiming));
         A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsA[i]), sizeof(int) * CN_TOTAL));
     }
+    A(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
     A(hipStreamCreateWithFlags(&c->pnp_stream, hipStreamNonBlocking));
     A(dalloc(&c->d_countsB, (size_t)4)); A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsB), sizeof(int) * 4));
     A(dalloc(&c->d_counts, (size_t)CN_TOTAL));
@@ -97,7 +102,7 @@ extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w,
     A(hipHostMalloc(reinterpret_cast<void**>(&c->h_hcount), sizeof(int) * kMaxHyp));
     A(hipHostMalloc(reinterpret_cast<void**>(&c->h_pose), sizeof(double) * 6));
 #undef A
-    if (e != hipSuccess) { uvo_ctx_destroy(c); return UVO_HIP_ERROR; }
+    if (e != hipSuccess) { destroy_one(c); return UVO_HIP_ERROR; }
     c->d_cand_n = c->d_counts + CN_CAND0;
     c->det[0].n = c->d_counts + CN_NL; c->det[1].n = c->d_counts + CN_NR;
     c->d_nmatch = c->d_counts + CN_M;
@@ -106,15 +111,63 @@ extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w,
     make_desc_weights(c->h_DW);
     if (hipMemcpy(c->d_DW, c->h_DW, sizeof(float) * 400, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->d_rank, 0, sizeof(int) * cap * 2) != hipSuccess ||
-        hipMemset(c->d_counts, 0, sizeof(int) * CN_TOTAL) != hipSuccess) { uvo_ctx_destroy(c); return UVO_HIP_ERROR; }
+        hipMemset(c->d_counts, 0, sizeof(int) * CN_TOTAL) != hipSuccess) { destroy_one(c); return UVO_HIP_ERROR; }
+    c->worker = std::thread(lane_worker, c);
     *out = c;
     return UVO_OK;
+}
+
+static uvo_status set_depth(uvo_ctx* c, int depth)
+{
+    if (depth < 1 || depth > 8) { c->err = "pipeline depth must be 1..8"; return UVO_INVALID_ARG; }
+    if (c->n_pending != 0) { c->err = "pipeline depth cannot change while pairs are in flight"; return UVO_INVALID_ARG; }
+    while ((int)c->lanes.size() > depth) { destroy_one(static_cast<uvo_ctx*>(c->lanes.back())); c->lanes.pop_back(); }
+    while ((int)c->lanes.size() < depth) {
+        uvo_ctx* l = nullptr;
+        uvo_status st = create_one(&c->p, c->device, c->max_w, c->max_h, c->cap, &l);
+        if (st != UVO_OK) { c->err = "could not allocate a further pipeline lane"; return st; }
+        l->master = c; l->lane_id = (int)c->lanes.size(); l->timing = c->timing;
+        c->lanes.push_back(l);
+    }
+    // the previous pair's "after stereo match" set may live in a lane that no longer exists: restart the sequence
+    if (c->prev_lane >= depth || c->next_lane >= depth) { c->vo_initialized = false; c->init_matches.clear(); c->prev_lane = 0; c->next_lane = 0; c->prev_sync = true; }
+    return UVO_OK;
+}
+
+extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w, int max_h, int max_kpts, uvo_ctx** out)
+{
+    uvo_status st = create_one(p, device, max_w, max_h, max_kpts, out);
+    if (st != UVO_OK) return st;
+    (*out)->lanes.push_back(*out);
+    st = set_depth(*out, 2);                      // two pairs in flight by default (uvo_stereo_set_depth changes it)
+    if (st != UVO_OK) { uvo_ctx_destroy(*out); *out = nullptr; }
+    return st;
+}
+
+extern "C" uvo_status uvo_stereo_set_depth(uvo_ctx* c, int depth)
+{
+    if (!c) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    return set_depth(c, depth);
 }
 
 extern "C" void uvo_ctx_destroy(uvo_ctx* c)
 {
     if (!c) return;
+    for (size_t i = c->lanes.size(); i > 1; i--) destroy_one(static_cast<uvo_ctx*>(c->lanes[i - 1]));
+    c->lanes.clear();
+    destroy_one(c);
+}
+
+static void destroy_one(uvo_ctx* c)
+{
+    if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->worker.joinable()) {
+        { std::lock_guard<std::mutex> lk(c->mu); c->quit = true; }
+        c->cv.notify_all();
+        c->worker.join();
+    }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 2; i++) {
         (void)hipFree(c->d_img[i]); (void)hipFree(c->d_sum[i]); (void)hipFree(c->d_cand[i]); (void)hipFree(c->det[i].kps);
@@ -132,6 +185,7 @@ extern "C" void uvo_ctx_destroy(uvo_ctx* c)
     (void)hipHostFree(c->h_countsB);
     for (int i = 0; i < 2; i++) { (void)hipHostFree(c->h_countsA[i]); if (c->evA[i]) (void)hipEventDestroy(c->evA[i]); }
     if (c->pnp_stream) (void)hipStreamDestroy(c->pnp_stream);
+    if (c->evAS) (void)hipEventDestroy(c->evAS);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -143,7 +197,8 @@ extern "C" void* uvo_ctx_stream(uvo_ctx* c) { return c ? (void*)c->stream : null
 extern "C" uvo_status uvo_ctx_set_params(uvo_ctx* c, const uvo_params* p)
 {
     if (!c || !p) return UVO_INVALID_ARG;
-    c->p = *p;
+    if (c->n_pending != 0) { c->err = "parameters cannot change while pairs are in flight"; return UVO_INVALID_ARG; }
+    for (Ctx* l : c->lanes) l->p = *p;
     return UVO_OK;
 }
 
@@ -347,14 +402,14 @@ __global__ void k_ctl_gate_a(int* cn, int min_features)
     int nL = cn[CN_NL], nR = cn[CN_NR];
     cn[CN_NQA] = (nL >= min_features && nR >= min_features) ? nL : 0;
 }
-__global__ void k_ctl_gate_b(int* cn, int min_features, int cap, int as_curr_slot, int as_prev_slot, int nq_a_was_zero_clears)
+__global__ void k_ctl_gate_b(int* cn, int min_features, int cap, int* as_curr_n, const int* as_prev_n)
 {   // VO:567: results_match_curr.size() > MIN_NUM_FEATURES, else the "after stereo match" sets stay empty
     int M = cn[CN_NQA] > 0 ? cn[CN_M] : 0;
     if (cn[CN_NQA] == 0) cn[CN_M] = 0;
     int meff = (M > min_features) ? min(M, cap) : 0;
     cn[CN_MEFF] = meff;
-    cn[as_curr_slot] = meff;
-    cn[CN_NQB] = meff > 0 ? cn[as_prev_slot] : 0;     // triangular matching only runs inside that branch
+    *as_curr_n = meff;
+    cn[CN_NQB] = meff > 0 ? *as_prev_n : 0;           // triangular matching only runs inside that branch
 }
 __global__ void k_ctl_gate_c(int* cn, int min_features, int cap)
 {   // VO:626: results_match_prev_curr.size() > MIN_NUM_FEATURES
@@ -418,12 +473,18 @@ extern "C" uvo_status uvo_stereo_reset(uvo_ctx* c)
 {
     if (!c) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
-    if (c->pnp_stream) (void)hipStreamSynchronize(c->pnp_stream);
-    c->vo_initialized = false; c->init_matches.clear(); c->as_prev = 0;
-    c->n_pending = 0; c->n_submitted = c->n_collected = 0; c->pending[0].used = c->pending[1].used = false;
+    // drain whatever is still in flight (results are dropped)
+    while (c->n_pending > 0) { uvo_stereo_result r; (void)uvo_stereo_collect(c, 1.0, &r); }
+    for (Ctx* l : c->lanes) {
+        if (l->pnp_stream) (void)hipStreamSynchronize(l->pnp_stream);
+        UVO_HIP_TRY(c, hipMemsetAsync(l->d_counts, 0, sizeof(int) * CN_TOTAL, l->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(l->stream));
+        l->as_w = 0; l->pending = Ctx::Pending();
+    }
+    c->vo_initialized = false; c->init_matches.clear();
+    c->prev_lane = 0; c->prev_buf = 0; c->prev_sync = true; c->next_lane = 0;
+    c->n_pending = 0; c->n_submitted = c->n_collected = 0;
     for (int i = 0; i < 3; i++) c->t_prev_curr[i] = c->rvec[i] = c->tvec[i] = 0;
-    UVO_HIP_TRY(c, hipMemsetAsync(c->d_counts, 0, sizeof(int) * CN_TOTAL, c->stream));
-    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return UVO_OK;
 }
 
@@ -459,7 +520,8 @@ static uvo_status stereo_init_step(uvo_ctx* c, uvo_stereo_result* out)
         if ((int)vL.size() != total || (int)vR.size() != total)
             return fail(c, UVO_INVALID_ARG, "stale stereo-init matches index past the current keypoints; the reference's "
                                             "keypoint/descriptor sets would go out of step (OpenCV asserts downstream)");
-        const int b = c->as_prev;
+        const int b = c->as_w;         // lane 0 writes the first "after stereo match" set, synchronously
+        c->as_w ^= 1; c->prev_lane = 0; c->prev_buf = b; c->prev_sync = true;
         int* d_idx = c->d_tmp_idx;     // scratch
         UVO_HIP_TRY(c, hipMemcpyAsync(d_idx, iL.data(), sizeof(int) * total, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_gather_desc_idx, dim3((total + 15) / 16), dim3(256), 0, c->stream, c->det[0].desc, nL, d_idx, total, c->d_as_descL[b]);
@@ -477,94 +539,160 @@ static uvo_status stereo_init_step(uvo_ctx* c, uvo_stereo_result* out)
 }
 
 // Stage A of one pair (VO:548-632): detect, stereo match, triangular match, triangulation,
-// extract_3Dpoints -- all enqueued on c->stream without a host sync; the counters are copied to the
-// slot's pinned mirror and an event marks completion.
+// extract_3Dpoints -- all enqueued on the lane's stream without a host sync; the counters are copied to the
+// lane's pinned mirror, an event marks completion and the lane's worker thread takes over for stage B.
 extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, int mem)
 {
     if (!c || !left || !right) return UVO_INVALID_ARG;
     if (!c->rig_set) return fail(c, UVO_INVALID_ARG, "uvo_stereo_set_rig has not been called");
-    if (c->n_pending >= 2) return fail(c, UVO_INVALID_ARG, "uvo_stereo_submit: two pairs are already in flight; collect one first");
+    const int depth = (int)c->lanes.size();
+    if (c->n_pending >= depth) return fail(c, UVO_INVALID_ARG, "uvo_stereo_submit: the pipeline is full; collect a pair first (uvo_stereo_set_depth)");
+    if (c->timing && c->n_pending > 0) return fail(c, UVO_INVALID_ARG, "timing mode measures one pair at a time: collect before submitting");
     (void)hipSetDevice(c->device);
     const uvo_params& p = c->p;
-    const int slot = (int)(c->n_submitted & 1);
-    uvo_ctx::Pending& pd = c->pending[slot];
-    pd = uvo_ctx::Pending();
-    pd.used = true; pd.slot = slot;
-    memset(&pd.res, 0, sizeof(pd.res));
-    UVO_TRY(surf_upload(c, 0, left, w, h, stride, mem));
-    UVO_TRY(surf_upload(c, 1, right, w, h, stride, mem));
-    UVO_TRY(surf_detect(c, 2));                                                            // VO:548-549
-    if (!c->vo_initialized) {
+    if (!c->vo_initialized) {                                                               // VO:474-520, on lane 0, synchronous
         if (c->n_pending != 0) return fail(c, UVO_INVALID_ARG, "uvo_stereo_submit: the init phase cannot be pipelined");
-        UVO_TRY(stereo_init_step(c, &pd.res));
-        pd.init_done = true;
-        c->n_submitted++; c->n_pending++;
+        c->pending = Ctx::Pending();
+        c->pending.used = true;
+        memset(&c->pending.res, 0, sizeof(c->pending.res));
+        UVO_TRY(surf_upload(c, 0, left, w, h, stride, mem));
+        UVO_TRY(surf_upload(c, 1, right, w, h, stride, mem));
+        UVO_TRY(surf_detect(c, 2));
+        UVO_TRY(stereo_init_step(c, &c->pending.res));
+        c->pending.init_done = true;
+        c->inflight[c->n_pending++] = 0; c->n_submitted++;
+        c->next_lane = 0;
         return UVO_OK;
     }
-    const int cap = c->cap, prev = c->as_prev, curr = 1 - prev;
-    int* cn = c->d_counts;
+    const int li = c->next_lane;
+    uvo_ctx* L = static_cast<uvo_ctx*>(c->lanes[li]);
+    Ctx* P = c->lanes[c->prev_lane];
+    L->pending = Ctx::Pending();
+    L->pending.used = true;
+    memset(&L->pending.res, 0, sizeof(L->pending.res));
+#define LANE_TRY(expr) do { uvo_status st_ = (expr); if (st_ != UVO_OK) { if (L != c) c->err = L->err; return st_; } } while (0)
+    LANE_TRY(surf_upload(L, 0, left, w, h, stride, mem));
+    LANE_TRY(surf_upload(L, 1, right, w, h, stride, mem));
+    LANE_TRY(surf_detect(L, 2));                                                           // VO:548-549
+    const int cap = c->cap, curr = L->as_w, prev = c->prev_buf;
+    int* cn = L->d_counts;
     const float ratio = (float)p.LOWE_RATIO_THRESHOLD;
+    hipStream_t st = L->stream;
     // stereo matching L -> R (VO:558), gated on device by VO:556
-    hipLaunchKernelGGL(k_ctl_gate_a, dim3(1), dim3(1), 0, c->stream, cn, p.MIN_NUM_FEATURES);
-    UVO_TRY(match_knn2(c, c->det[0].desc, cn + CN_NQA, cap, c->det[1].desc, cn + CN_NR, cap));
-    UVO_TRY(match_ratio_compact(c, cn + CN_NQA, cap, ratio, c->d_matches[0], cn + CN_M, cap));
-    hipLaunchKernelGGL(k_ctl_gate_b, dim3(1), dim3(1), 0, c->stream, cn, p.MIN_NUM_FEATURES, cap, CN_AS0 + curr, CN_AS0 + prev, 0);
+    hipLaunchKernelGGL(k_ctl_gate_a, dim3(1), dim3(1), 0, st, cn, p.MIN_NUM_FEATURES);
+    LANE_TRY(match_knn2(L, L->det[0].desc, cn + CN_NQA, cap, L->det[1].desc, cn + CN_NR, cap));
+    LANE_TRY(match_ratio_compact(L, cn + CN_NQA, cap, ratio, L->d_matches[0], cn + CN_M, cap));
+    // from here on the previous pair's "after stereo match" set (another lane's buffers) is needed
+    if (!c->prev_sync && P != L) UVO_HIP_TRY(c, hipStreamWaitEvent(st, P->evAS, 0));
+    hipLaunchKernelGGL(k_ctl_gate_b, dim3(1), dim3(1), 0, st, cn, p.MIN_NUM_FEATURES, cap, L->d_as_n + curr, P->d_as_n + prev);
     {
-        StageTimer t(c, ST_GATHER);
-        hipLaunchKernelGGL(k_gather_after_stereo, dim3((cap + 15) / 16), dim3(256), 0, c->stream, c->d_matches[0], cn,
-                           c->det[0].kps, c->det[1].kps, c->det[0].desc, c->d_as_kpsL[curr], c->d_as_kpsR[curr], c->d_as_descL[curr]);
+        StageTimer t(L, ST_GATHER);
+        hipLaunchKernelGGL(k_gather_after_stereo, dim3((cap + 15) / 16), dim3(256), 0, st, L->d_matches[0], cn,
+                           L->det[0].kps, L->det[1].kps, L->det[0].desc, L->d_as_kpsL[curr], L->d_as_kpsR[curr], L->d_as_descL[curr]);
     }
+    UVO_HIP_TRY(c, hipEventRecord(L->evAS, st));
     // triangular matching prev-left-after-stereo -> curr-left (VO:592)
-    UVO_TRY(match_knn2(c, c->d_as_descL[prev], cn + CN_NQB, cap, c->det[0].desc, cn + CN_NL, cap));
-    UVO_TRY(match_ratio_compact(c, cn + CN_NQB, cap, ratio, c->d_matches[1], cn + CN_TRAW, cap));
-    hipLaunchKernelGGL(k_ctl_gate_c, dim3(1), dim3(1), 0, c->stream, cn, p.MIN_NUM_FEATURES, cap);
+    LANE_TRY(match_knn2(L, P->d_as_descL[prev], cn + CN_NQB, cap, L->det[0].desc, cn + CN_NL, cap));
+    LANE_TRY(match_ratio_compact(L, cn + CN_NQB, cap, ratio, L->d_matches[1], cn + CN_TRAW, cap));
+    hipLaunchKernelGGL(k_ctl_gate_c, dim3(1), dim3(1), 0, st, cn, p.MIN_NUM_FEATURES, cap);
     {
-        StageTimer t(c, ST_GATHER);
-        hipLaunchKernelGGL(k_gather_triangular, dim3((cap + 255) / 256), dim3(256), 0, c->stream, c->d_matches[1], cn,
-                           c->d_as_kpsL[prev], c->d_as_kpsR[prev], c->det[0].kps, c->d_x1, c->d_x2, c->d_xc);
+        StageTimer t(L, ST_GATHER);
+        hipLaunchKernelGGL(k_gather_triangular, dim3((cap + 255) / 256), dim3(256), 0, st, L->d_matches[1], cn,
+                           P->d_as_kpsL[prev], P->d_as_kpsR[prev], L->det[0].kps, L->d_x1, L->d_x2, L->d_xc);
     }
     UVO_HIP_TRY(c, hipGetLastError());
     // triangulation + extract_3Dpoints (VO:631-632)
-    UVO_TRY(pose_triangulate(c, c->P_eye_left, c->P_right, cn + CN_T, cap));
+    LANE_TRY(pose_triangulate(L, c->P_eye_left, c->P_right, cn + CN_T, cap));
     const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
-    UVO_TRY(pose_extract3d(c, slot, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap));
-    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_countsA[slot], c->d_counts, sizeof(int) * CN_TOTAL, hipMemcpyDeviceToHost, c->stream));
-    UVO_HIP_TRY(c, hipEventRecord(c->evA[slot], c->stream));
-    c->as_prev = curr;                                                                     // VO:727-733
-    c->n_submitted++; c->n_pending++;
+    LANE_TRY(pose_extract3d(L, 0, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap));
+    UVO_HIP_TRY(c, hipMemcpyAsync(L->h_countsA[0], L->d_counts, sizeof(int) * CN_TOTAL, hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipEventRecord(L->evA[0], st));
+    // state carry VO:727-733: this pair's set is the next pair's "prev"
+    L->as_w = curr ^ 1;
+    c->prev_lane = li; c->prev_buf = curr; c->prev_sync = false;
+    c->next_lane = (li + 1) % depth;
+    c->inflight[c->n_pending++] = li; c->n_submitted++;
+    {   // hand stage B to the lane's worker
+        std::lock_guard<std::mutex> lk(L->mu);
+        L->job.state = 1;
+    }
+    L->cv.notify_all();
     return UVO_OK;
+#undef LANE_TRY
 }
 
-// Stage B of the oldest submitted pair (VO:634-717): gates, PnP-RANSAC on c->pnp_stream, pose inversion.
+// Stage B of one lane's pair (VO:634-648), on the lane's worker thread: wait for stage A, then solvePnPRansac.
+static void run_stage_b(uvo_ctx* L)
+{
+    Ctx::BJob& j = L->job;
+    const Ctx* m = L->master ? L->master : L;
+    j.st = UVO_OK; j.err.clear(); j.ran = j.ninl = j.ok = 0;
+    if (hipEventSynchronize(L->evA[0]) != hipSuccess) { j.st = UVO_HIP_ERROR; j.err = "stage A of the pair failed"; return; }
+    const int* hc = L->h_countsA[0];
+    const int cap = L->cap;
+    if (hc[CN_CAND0] > cap || hc[CN_CAND1] > cap || hc[CN_M] > cap || hc[CN_TRAW] > cap) return;    // reported by collect
+    const int G = hc[CN_G];
+    const uvo_params& p = L->p;
+    if (G > p.MIN_NUM_3DPOINTS) {                                                          // VO:634
+        j.ran = 1;
+        j.st = pose_pnp_ransac(L, 0, G, m->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE,
+                               j.rvec, j.tvec, &j.ninl, &j.ok);                            // VO:647-648
+        if (j.st != UVO_OK) j.err = L->err;
+    }
+}
+static void lane_worker(uvo_ctx* L)
+{
+    (void)hipSetDevice(L->device);
+    std::unique_lock<std::mutex> lk(L->mu);
+    for (;;) {
+        L->cv.wait(lk, [&] { return L->quit || L->job.state == 1; });
+        if (L->quit) return;
+        lk.unlock();
+        run_stage_b(L);
+        lk.lock();
+        L->job.state = 2;
+        L->cv.notify_all();
+    }
+}
+
+// Result of the oldest submitted pair: gates, pose inversion and output (VO:634-717, VO:148-159), in order.
 extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_result* out)
 {
     if (!c || !out) return UVO_INVALID_ARG;
     if (c->n_pending <= 0) return fail(c, UVO_INVALID_ARG, "uvo_stereo_collect: nothing submitted");
     (void)hipSetDevice(c->device);
     const uvo_params& p = c->p;
-    const int slot = (int)(c->n_collected & 1);
-    uvo_ctx::Pending& pd = c->pending[slot];
-    c->n_collected++; c->n_pending--; pd.used = false;
-    c->last_slot = slot;
+    const int li = c->inflight[0];
+    for (int i = 1; i < c->n_pending; i++) c->inflight[i - 1] = c->inflight[i];
+    c->n_pending--; c->n_collected++;
+    uvo_ctx* L = static_cast<uvo_ctx*>(c->lanes[li]);
+    c->last_lane = li;
+    Ctx::Pending& pd = L->pending;
+    pd.used = false;
     if (pd.init_done) { *out = pd.res; return UVO_OK; }
+    {
+        std::unique_lock<std::mutex> lk(L->mu);
+        L->cv.wait(lk, [&] { return L->job.state == 2; });
+        L->job.state = 0;
+    }
+    const Ctx::BJob& j = L->job;
     memset(out, 0, sizeof(*out));
     out->initialized = 1;
-    UVO_HIP_TRY(c, hipEventSynchronize(c->evA[slot]));
-    const int* hc = c->h_countsA[slot];
-    memcpy(c->h_counts, hc, sizeof(int) * CN_TOTAL);
-    UVO_TRY(check_cand_overflow(c, 2));
+    if (j.st != UVO_OK && !j.ran) return fail(c, j.st, j.err.c_str());
+    const int* hc = L->h_countsA[0];
+    memcpy(L->h_counts, hc, sizeof(int) * CN_TOTAL);
+    if (check_cand_overflow(L, 2) != UVO_OK) return fail(c, UVO_CAPACITY, L->err.c_str());
     const int cap = c->cap;
     if (hc[CN_M] > cap || hc[CN_TRAW] > cap) return fail(c, UVO_CAPACITY, "match count exceeds max_kpts");
     const int nL = hc[CN_NL], nR = hc[CN_NR], M = hc[CN_M], T = hc[CN_TRAW], G = hc[CN_G];
     out->n_left = nL; out->n_right = nR; out->n_stereo_matches = M; out->n_tri_matches = T; out->n_good3d = G;
-    c->last_nL = nL; c->last_nR = nR; c->last_M = M; c->last_T = hc[CN_T]; c->last_G = G; c->last_ninl = 0;
+    L->last_nL = nL; L->last_nR = nR; L->last_M = M; L->last_T = hc[CN_T]; L->last_G = G; L->last_ninl = 0;
     int valid = 0;
-    if (G > p.MIN_NUM_3DPOINTS) {                                                          // VO:634
-        int ninl = 0, ok = 0;
-        UVO_TRY(pose_pnp_ransac(c, slot, G, c->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE,
-                                c->rvec, c->tvec, &ninl, &ok));                            // VO:647-648
-        c->last_ninl = ninl; out->n_inliers = ninl;
-        if (ninl >= p.MIN_NUM_INLIERS) {                                                   // VO:665
+    if (j.ran) {                                                                           // VO:634
+        if (j.st != UVO_OK) return fail(c, j.st, j.err.c_str());
+        if (j.ok) { memcpy(c->rvec, j.rvec, sizeof(c->rvec)); memcpy(c->tvec, j.tvec, sizeof(c->tvec)); }
+        L->last_ninl = j.ninl; out->n_inliers = j.ninl;
+        if (j.ninl >= p.MIN_NUM_INLIERS) {                                                 // VO:665
             double R[9];
             rodrigues_vec2mat(c->rvec, R);                                                 // VO:673
             for (int i = 0; i < 3; i++) {                                                  // VO:675: -R^T t
@@ -592,10 +720,11 @@ extern "C" uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uin
     return uvo_stereo_collect(c, dt, out);
 }
 
-extern "C" int uvo_stereo_get(uvo_ctx* c, const char* what, void* out, int cap_bytes)
+extern "C" int uvo_stereo_get(uvo_ctx* m, const char* what, void* out, int cap_bytes)
 {
-    if (!c || !what || !out) return 0;
-    (void)hipSetDevice(c->device);
+    if (!m || !what || !out) return 0;
+    (void)hipSetDevice(m->device);
+    const Ctx* c = m->lanes.empty() ? m : m->lanes[m->last_lane];    // the lane of the last collected pair
     const void* src = nullptr; int count = 0; size_t esz = 0;
     std::string w(what);
     if (w == "kps_left") { src = c->det[0].kps; count = c->last_nL; esz = sizeof(uvo_keypoint); }
@@ -603,10 +732,10 @@ extern "C" int uvo_stereo_get(uvo_ctx* c, const char* what, void* out, int cap_b
     else if (w == "desc_left") { src = c->det[0].desc; count = c->last_nL; esz = 64 * sizeof(float); }
     else if (w == "desc_right") { src = c->det[1].desc; count = c->last_nR; esz = 64 * sizeof(float); }
     else if (w == "matches_stereo") { src = c->d_matches[0]; count = c->last_M; esz = sizeof(uvo_dmatch); }
-    else if (w == "matches_tri") { src = c->d_matches[1]; count = c->last_T > 0 ? c->h_counts[CN_TRAW] : c->h_counts[CN_TRAW]; esz = sizeof(uvo_dmatch); }
+    else if (w == "matches_tri") { src = c->d_matches[1]; count = c->h_counts[CN_TRAW]; esz = sizeof(uvo_dmatch); }
     else if (w == "points4d") { src = c->d_pts4; count = c->last_T; esz = sizeof(float4); }
-    else if (w == "good_pts") { src = c->d_good_pts[c->last_slot]; count = c->last_G; esz = 3 * sizeof(double); }
-    else if (w == "good_idx") { src = c->d_good_idx[c->last_slot]; count = c->last_G; esz = sizeof(int); }
+    else if (w == "good_pts") { src = c->d_good_pts[0]; count = c->last_G; esz = 3 * sizeof(double); }
+    else if (w == "good_idx") { src = c->d_good_idx[0]; count = c->last_G; esz = sizeof(int); }
     else if (w == "inliers") { src = c->d_inliers; count = c->last_ninl; esz = sizeof(int); }
     else return 0;
     if ((size_t)count * esz > (size_t)cap_bytes) return -count;
@@ -856,19 +985,27 @@ extern "C" int uvo_mono_get(uvo_ctx* c, const char* what, void* out, int cap_byt
 }
 
 // ------------------------------------------------------------------------------------------ timing
-extern "C" uvo_status uvo_timing_enable(uvo_ctx* c, int on) { if (!c) return UVO_INVALID_ARG; c->timing = on != 0; return UVO_OK; }
+extern "C" uvo_status uvo_timing_enable(uvo_ctx* c, int on)
+{
+    if (!c) return UVO_INVALID_ARG;
+    if (c->n_pending != 0) { c->err = "timing mode cannot change while pairs are in flight"; return UVO_INVALID_ARG; }
+    for (Ctx* l : c->lanes) l->timing = on != 0;
+    return UVO_OK;
+}
 extern "C" int uvo_timing_count(uvo_ctx*) { return ST_COUNT; }
 extern "C" const char* uvo_timing_name(uvo_ctx*, int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
 extern "C" uvo_status uvo_timing_get(uvo_ctx* c, int i, double* ms, long long* launches)
 {
     if (!c || i < 0 || i >= ST_COUNT) return UVO_INVALID_ARG;
-    if (ms) *ms = c->stage_ms[i];
-    if (launches) *launches = c->stage_n[i];
+    double t = 0; long long n = 0;
+    for (Ctx* l : c->lanes) { t += l->stage_ms[i]; n += l->stage_n[i]; }
+    if (ms) *ms = t;
+    if (launches) *launches = n;
     return UVO_OK;
 }
 extern "C" uvo_status uvo_timing_reset(uvo_ctx* c)
 {
     if (!c) return UVO_INVALID_ARG;
-    for (int i = 0; i < ST_COUNT; i++) { c->stage_ms[i] = 0; c->stage_n[i] = 0; }
+    for (Ctx* l : c->lanes) for (int i = 0; i < ST_COUNT; i++) { l->stage_ms[i] = 0; l->stage_n[i] = 0; }
     return UVO_OK;
 }

@@ -282,6 +282,7 @@ __global__ __launch_bounds__(1024) void k_pnp_mask(const float* opts, const uvo_
     if (tid == 0) counts[0] = s_base;
 }
 
+__device__ long long g_refit_clk[16];       // diagnostic: phase stamps of the last refit (printed when UVO_DBG_PHASE is set)
 // inlier refit: one workgroup, block-cooperative EPnP.  ws: pws 3c | us 2c | alphas 4c | pcs 9c | tmp 3c (c = cap)
 __global__ __launch_bounds__(256) void k_pnp_refit(double* ws, int cap, const int* n_p, double fx, double fy, double cx, double cy, double* pose)
 {
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void k_pnp_refit(double* ws, int cap, const in
     using P = BlockPolicy;
     Epnp<P> e;
     e.uc = cx; e.vc = cy; e.fu = fx; e.fv = fy; e.n = n;
-    e.s = P::Arr{small}; e.stage = stage_buf;
+    e.s = P::Arr{small}; e.stage = stage_buf; e.clk = g_refit_clk;
     e.pws = P::Arr{ws}; e.us = P::Arr{ws + 3 * (size_t)cap}; e.alphas = P::Arr{ws + 5 * (size_t)cap};
     e.pcs = P::Arr{ws + 9 * (size_t)cap}; e.tmp = P::Arr{ws + 18 * (size_t)cap};
     double rvec[3], tvec[3];
@@ -448,6 +449,13 @@ uvo_status pose_pnp_ransac(Ctx* c, int slot, int G, const double* K, int iterati
     UVO_HIP_TRY(c, hipStreamSynchronize(st));
     memcpy(rvec, c->h_pose, sizeof(double) * 3); memcpy(tvec, c->h_pose + 3, sizeof(double) * 3);
     *n_inliers = c->h_countsB[0];
+    if (getenv("UVO_DBG_PHASE")) {
+        long long k[16];
+        UVO_HIP_TRY(c, hipMemcpyFromSymbol(k, HIP_SYMBOL(g_refit_clk), sizeof(k)));
+        fprintf(stderr, "[uvo] pnp refit phases (us), %d inliers: ctrl %.1f bary %.1f mtm %.1f svd12 %.1f betas %.1f pcs %.1f sums %.1f svd3 %.1f reproj %.1f\n",
+                *n_inliers, (k[1]-k[0])*0.01, (k[2]-k[1])*0.01, (k[3]-k[2])*0.01, (k[4]-k[3])*0.01, (k[5]-k[4])*0.01, (k[6]-k[5])*0.01,
+                (k[7]-k[6])*0.01, (k[8]-k[7])*0.01, (k[9]-k[8])*0.01);
+    }
     *ok = 1;
     return UVO_OK;
 }

@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
+#include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <vector>
 #include <stdint.h>
 #include "../../include/uvo_hip.h"
@@ -69,7 +72,6 @@ struct Ctx {
     uvo_keypoint* d_as_kpsR[2] = {nullptr, nullptr};
     float* d_as_descL[2] = {nullptr, nullptr};
     int* d_as_n = nullptr;                       // [2] counts (device)
-    int as_prev = 0;                             // index of the prev buffer
     bool vo_initialized = false;
     std::vector<uvo_dmatch> init_matches;        // results_match_prev (VO:468): survives failed init attempts
     double K_left[9], K_right[9], R_right[9], t_right[3], P_eye_left[12], P_right[12];
@@ -97,16 +99,35 @@ struct Ctx {
     double* d_refit = nullptr;                   // refit workspace: pws 3n, us 2n, alphas 4n, pcs 3n, tmp n, M 24n, small
     double* d_pose = nullptr;  double* h_pose = nullptr;             // rvec(3) tvec(3)
 
-    // ---- two-stage pipeline: stage A (detect .. extract_3Dpoints) on `stream`, stage B (PnP) on `pnp_stream` ----
+    // ---- pipeline: stage A (detect .. extract_3Dpoints) on `stream`, stage B (PnP) on `pnp_stream` ----
+    // A context is also one LANE of the stereo pipeline.  Lane 0 is the context the caller holds; uvo_stereo_set_depth
+    // adds child contexts (own buffers, streams and stage-B worker thread) so that `depth` consecutive pairs are in
+    // flight at once: pair k runs on lane k mod depth.  The only data one pair takes from the previous one is its
+    // "after stereo match" set, read from the previous lane's buffers behind an event.
     hipStream_t pnp_stream = nullptr;
     int* d_countsB = nullptr;  int* h_countsB = nullptr;             // [0] = n_inliers
-    hipEvent_t evA[2] = {nullptr, nullptr};      // stage A of slot s finished (its counts are in h_countsA[s])
-    int* h_countsA[2] = {nullptr, nullptr};      // pinned copies of d_counts per slot
-    struct Pending { bool used = false; bool init_done = false; int slot = 0; uvo_stereo_result res; };
-    Pending pending[2];
-    int n_pending = 0;                           // submitted, not yet collected
+    hipEvent_t evA[2] = {nullptr, nullptr};      // [0]: stage A of this lane's pair finished (counts in h_countsA[0])
+    int* h_countsA[2] = {nullptr, nullptr};      // pinned copy of d_counts
+    hipEvent_t evAS = nullptr;                   // this lane's "after stereo match" set is written
+    std::vector<Ctx*> lanes;                     // master only: lanes[0] == this
+    Ctx* master = nullptr;                       // children only
+    int lane_id = 0;
+    int as_w = 0;                                // the as-buffer this lane writes next
+    int prev_lane = 0, prev_buf = 0;             // master: where the previous pair's as-set lives
+    bool prev_sync = true;                       // master: that set was written synchronously (init step), no event to wait for
+    int next_lane = 0;                           // master: lane of the next submitted pair
+    struct Pending { bool used = false; bool init_done = false; uvo_stereo_result res; };
+    Pending pending;                             // this lane's pair
+    int inflight[8]; int n_pending = 0;          // master: lanes of the submitted, not yet collected pairs (FIFO)
     long long n_submitted = 0, n_collected = 0;
-    int last_slot = 0;
+    int last_lane = 0;
+    // stage-B worker of this lane
+    struct BJob {
+        int state = 0;                           // 0 idle, 1 queued, 2 done
+        uvo_status st = UVO_OK; std::string err;
+        int ran = 0, ninl = 0, ok = 0; double rvec[3], tvec[3];
+    } job;
+    std::thread worker; std::mutex mu; std::condition_variable cv; bool quit = false;
 
     // last-step bookkeeping for uvo_stereo_get
     int last_nL = 0, last_nR = 0, last_M = 0, last_T = 0, last_G = 0, last_ninl = 0;

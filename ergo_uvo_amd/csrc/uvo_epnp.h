@@ -257,6 +257,8 @@ struct Epnp {
     int n;
     Arr pws, us, alphas, pcs, tmp, s;         // pcs: 3 branches x 3n, tmp: 3 branches x n
     double* stage = nullptr;                  // BlockPolicy: LDS staging buffer of kStageDoubles
+    long long* clk = nullptr;                 // diagnostic phase stamps (100 MHz), block policy only
+#define EP_STAMP(i) do { if (P::kStaged && clk && P::tid() == 0) clk[i] = wall_clock64(); } while (0)
     static constexpr int kStageDoubles = 5120;
 
     // E independent sequential sums out[e] = (((0 + term(e,0)) + term(e,1)) + ...) over i < n.
@@ -544,13 +546,18 @@ struct Epnp {
     // epnp::compute_pose followed by Rodrigues(R, rvec).  Outputs valid on tid 0.
     __device__ void compute_pose(double* rvec, double* tvec)
     {
+        EP_STAMP(0);
         choose_control_points();
+        EP_STAMP(1);
         compute_barycentric_coordinates();
+        EP_STAMP(2);
         build_mtm();
+        EP_STAMP(3);
         Arr mtm = s + EP_MTM, L = s + EP_L, rho = s + EP_RHO, cws = s + EP_CWS, pw0 = s + EP_PW0;
         // cvSVD(MtM, D, Ut, 0, MODIFY_A | U_T): MtM is symmetric so At = MtM^T is MtM itself; rows -> U^T
         jacobi_svd_u_levels<P, 12, 12>(mtm, s + EP_D, s + EP_WT, s + EP_FLAG);
         const int tid = P::tid();
+        EP_STAMP(4);
         if (tid == 0) {
             compute_L_6x10(mtm, L);
             rho[0] = dist2(cws, cws + 3); rho[1] = dist2(cws, cws + 6); rho[2] = dist2(cws, cws + 9);
@@ -570,6 +577,7 @@ struct Epnp {
             }
         }
         P::sync();
+        EP_STAMP(5);
         // compute_pcs for the three branches
         for (int it = tid; it < 3*n; it += P::nth()) {
             int b = it / n, i = it - b*n;
@@ -589,6 +597,7 @@ struct Epnp {
             }
             P::sync();
         }
+        EP_STAMP(6);
         // estimate_R_and_t: centroids (pw0 does not depend on the branch), 3x3 covariances
         multi_sum(12, n,
                   [&](int e, int i) {
@@ -606,6 +615,7 @@ struct Epnp {
                       return (pcs[3*(b*n + i) + j] - (br(b) + EPB_PC0)[j]) * (pws[3*i + q] - pw0[q]);
                   },
                   [&](int e, double acc) { int b = e / 9, r = e - 9*b; (br(b) + EPB_ABT)[r] = acc; });
+        EP_STAMP(7);
         if (tid < 3) {
             Arr B = br(tid), abt = B + EPB_ABT, R = B + EPB_RS, t = B + EPB_TS, pc0 = B + EPB_PC0, sc = B + EPB_SC;
             Arr at = sc, w = sc + 9, vt = sc + 12, wt = sc + 21;
@@ -622,6 +632,7 @@ struct Epnp {
             t[2] = pc0[2] - dot3(R + 6, pw0);
         }
         P::sync();
+        EP_STAMP(8);
         // reprojection_error: per-point terms in parallel, summed in order by one lane per branch
         for (int it = tid; it < 3*n; it += P::nth()) {
             int b = it / n, i = it - b*n;
@@ -646,7 +657,9 @@ struct Epnp {
             rodrigues_mat2vec(B + EPB_RS, B + EPB_SC, rvec);
         }
         P::sync();
+        EP_STAMP(9);
     }
+#undef EP_STAMP
 };
 
 }  // namespace uvo

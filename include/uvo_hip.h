@@ -134,9 +134,13 @@ uvo_status uvo_stereo_reset(uvo_ctx* c);
 uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
                            int mem, double dt, uvo_stereo_result* out);
 /* The same step split for throughput: uvo_stereo_submit enqueues the device work of a pair up to
- * extract_3Dpoints and returns at once; uvo_stereo_collect finishes the OLDEST submitted pair
- * (PnP-RANSAC, pose) on a second HIP stream.  Up to two pairs may be in flight, so the detector of
- * pair k+1 overlaps the pose solve of pair k; results are identical to uvo_stereo_step's. */
+ * extract_3Dpoints on its pipeline lane and returns at once; the lane's worker thread runs PnP-RANSAC as soon as
+ * that work finishes; uvo_stereo_collect returns the result of the OLDEST submitted pair.  Up to `depth` pairs may
+ * be in flight (uvo_stereo_set_depth), so the detector of pairs k+1.. overlaps the pose solve of pair k; results
+ * are identical to uvo_stereo_step's.
+ * Pipeline depth: 1..8, default 2.  Each unit of depth is one more set of device buffers, two more HIP streams and
+ * one more host worker thread; changing it restarts nothing unless the lane holding the previous pair is removed. */
+uvo_status uvo_stereo_set_depth(uvo_ctx* c, int depth);
 uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, int mem);
 uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_result* out);
 /* last step's intermediates for parity tests (only meaningful after a non-pipelined uvo_stereo_step): "kps_left", "kps_right", "desc_left", "desc_right",

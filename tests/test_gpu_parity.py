@@ -216,7 +216,7 @@ def test_stereo_sequence_parity(ctx, oracle, scene_small):
 
 
 def test_pipelined_submit_collect_equals_step(ctx, scene_small):
-    """uvo_stereo_submit/collect (two pairs in flight on two HIP streams) must give exactly the
+    """uvo_stereo_submit/collect (1..4 pairs in flight on separate lanes) must give exactly the
     results of the synchronous uvo_stereo_step."""
     import ergo_uvo_amd as uvo
     from ergo_uvo_amd import synth
@@ -230,17 +230,24 @@ def test_pipelined_submit_collect_equals_step(ctx, scene_small):
 
     ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
     sync = [fields(ctx.stereo_step(L, R, 0.05)) for L, R in seq]
-    ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)      # resets the VO state
-    piped = []
-    ctx.stereo_submit(*seq[0])
-    for i in range(len(seq)):
-        if i + 1 < len(seq):
-            ctx.stereo_submit(*seq[i + 1])
-        piped.append(fields(ctx.stereo_collect(0.05)))
-    assert piped == sync
     assert sum(f[0] for f in sync) == len(seq) - 1
-    with pytest.raises(uvo.UvoError):
-        ctx.stereo_collect(0.05)                     # nothing in flight
+    for depth in (2, 1, 4, 3):
+        ctx.stereo_set_depth(depth)
+        ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)      # resets the VO state
+        piped, sub = [], 0
+        ctx.stereo_submit(*seq[0]); sub += 1
+        piped.append(fields(ctx.stereo_collect(0.05)))                              # the init pair cannot be pipelined
+        while len(piped) < len(seq):
+            while sub < len(seq) and sub - len(piped) < depth:
+                ctx.stereo_submit(*seq[sub]); sub += 1
+            if depth > 1 and sub < len(seq):
+                with pytest.raises(uvo.UvoError):
+                    ctx.stereo_submit(*seq[sub])                                    # pipeline full
+            piped.append(fields(ctx.stereo_collect(0.05)))
+        assert piped == sync, depth
+        with pytest.raises(uvo.UvoError):
+            ctx.stereo_collect(0.05)                 # nothing in flight
+    ctx.stereo_set_depth(2)
 
 
 # ------------------------------------------------------------------ mono path
