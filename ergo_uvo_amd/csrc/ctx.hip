@@ -69,7 +69,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     const size_t cap = (size_t)max_kpts;
     const size_t npx = (size_t)max_w * max_h, nsum = (size_t)(max_w + 1) * (max_h + 1);
     const int nseg = (max_h + 31) / 32;
-    const size_t nchunks = (cap + kMatchChunk - 1) / kMatchChunk;
+    const size_t nchunks = (cap + 127) / 128;                   // matcher shortlist: (cap/128) x cap float4 (match.hip)
     hipError_t e = hipSuccess;
 #define A(expr) do { if (e == hipSuccess) e = (expr); } while (0)
     A(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -82,7 +82,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     }
     A(dalloc(&c->d_colpart, (size_t)2 * nseg * (max_w + 1)));
     A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_list, cap * 2));
-    A(dalloc(&c->d_mpart, nchunks * cap)); A(dalloc(&c->d_knn_idx, cap * 2)); A(dalloc(&c->d_knn_dist, cap * 2));
+    A(dalloc(&c->d_mpart, nchunks * cap)); A(dalloc(&c->d_mscratch, (size_t)4)); A(dalloc(&c->d_knn_idx, cap * 2)); A(dalloc(&c->d_knn_dist, cap * 2));
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
     A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_tmp_idx, cap));
     for (int i = 0; i < 2; i++) {
@@ -176,7 +176,7 @@ static void destroy_one(uvo_ctx* c)
     }
     if (c->pnp_stream) (void)hipStreamSynchronize(c->pnp_stream);
     mono_ws_free(c);
-    void* ptrs[] = { c->d_colpart, c->d_DW, c->d_rank, c->d_big_list, c->d_mpart, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
+    void* ptrs[] = { c->d_colpart, c->d_DW, c->d_rank, c->d_big_list, c->d_mpart, c->d_mscratch, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
                      c->d_flag, c->d_tmp_idx, c->d_good_pts[0], c->d_good_pts[1], c->d_good_idx[0], c->d_good_idx[1], c->d_opts[0], c->d_opts[1],
                      c->d_ipts[0], c->d_ipts[1], c->d_counts, c->d_countsB, c->d_subsets, c->d_models,
                      c->d_hcount, c->d_inliers, c->d_refit, c->d_pose };

@@ -1,19 +1,27 @@
 // match.hip -- brute-force L2 2-nearest-neighbour matching + Lowe ratio test on gfx950
 // (replaces match_features, VO_utility.cpp:515-573 -> BFMatcher(NORM_L2).knnMatch(k=2)).
 //
-// Parity needs the exact float value of every distance (nearest/second-nearest order and the
-// strict `d0 < ratio*d1` test turn on the last bit), so the contraction is done on the VALU in
-// OpenCV's own summation order (normL2Sqr_: 4 lanes x 4 accumulators, mul then add, SSE
-// horizontal reduce, sqrt) rather than as a |a|^2+|b|^2-2ab MFMA product, whose rounding differs.
-// The work is small next to the detector (3000^2 x 64 x 3 flop ~ 1.7 GFLOP ~ tens of us of VALU
-// time); see DESIGN.md for the MFMA-prefilter variant and why it is not the default.
+// Parity needs the exact float value of the two winning distances (nearest/second-nearest order and the
+// strict `d0 < ratio*d1` test turn on the last bit), and OpenCV's value comes from its own summation order
+// (normL2Sqr_: 4 lanes x 4 accumulators, mul then add, SSE horizontal reduce, sqrt).  An all-pairs contraction in
+// that order is ~190 VALU operations per pair.  So the all-pairs work is done on the matrix cores instead, as a
+// SHORTLIST, and the exact order is spent only on the survivors:
 //
-// k_match_top2 : grid (query tiles of 256, train chunks of kMatchChunk).  Each thread keeps one
-//                query row in registers, the chunk's train rows are staged in LDS and broadcast.
-//                Emits the chunk-local top-2 (ties: lower train index first).
-// k_match_merge: per query, merges the chunk results in ascending train order with BFMatcher's
-//                insertion rule, then applies the ratio test.
-// k_match_compact: ordered stream compaction of the surviving matches (single workgroup scan).
+// k_match_mfma    : S' = |t|^2 - 2 t.q for every (train, query) pair with v_mfma_f32_32x32x2_f32 (exact f32
+//                   products, 64 k-steps), grid (query tiles of 128, train chunks of 128).  Each lane owns one query
+//                   column and keeps the four smallest S' of its rows (the row index rides in the low mantissa
+//                   bits); per (query, chunk) it emits those four.
+// k_match_resolve : 16 lanes per query.  lim = (second-smallest S' over all candidates) + margin.  Every train row that can
+//                   be one of the exact two nearest has S' <= lim, so: a chunk whose fourth value is above lim
+//                   contributes only its (at most three) candidates below lim; a chunk whose fourth value is not
+//                   (near-duplicate descriptors) is scanned row by row.  Those rows are evaluated in OpenCV's
+//                   order (the 16 lanes hold the 16 accumulators of normL2Sqr_) and the two smallest by (distance,
+//                   train index) are kept -- exactly what BFMatcher's insertion rule leaves after the full scan.
+// k_match_compact : ratio test + ordered stream compaction of the surviving matches (single workgroup scan).
+//
+// Margin: the MFMA value and OpenCV's float sum both differ from the real squared distance by at most
+// ~64 ulp of (|q|^2 + |t|^2), and the index bits cost 2^-16 of |S'|; kMarginRel = 6e-5 of that scale covers all three
+// several times over.
 #include "uvo_ctx.h"
 #include "uvo_math.h"
 
@@ -46,54 +54,215 @@ __device__ __forceinline__ void top2_insert(float d, int j, float& d0, int& i0, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_match_top2(const float* __restrict__ dq, const int* nq_p, int nq_imm,
-                                                    const float* __restrict__ dt, const int* nt_p, int nt_imm,
-                                                    float4* part, int nq_stride)
+static const int kMfmaChunk = 128;             // train rows per workgroup of k_match_mfma (7 index bits, see shortlist_key)
+static const int kRowStride = 68;              // floats per staged row: 64 + 4 so that the lanes' b128 reads spread over the LDS banks
+static const float kMarginRel = 6e-5f;
+static const float kBig = 3.0e38f;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// Shortlist key: S' with the 7 low mantissa bits replaced by the row's index inside its chunk, so that the three
+// smallest candidates AND their indices are tracked with min/med3 alone.  The replaced bits change S' by less than
+// 2^-16 of its magnitude, which kMarginRel includes.
+__device__ __forceinline__ float shortlist_key(float s, int row_in_chunk)
 {
-    const int nq = nq_p ? *nq_p : nq_imm, nt = nt_p ? *nt_p : nt_imm;
-    const int q0 = blockIdx.x * 256, t0 = blockIdx.y * kMatchChunk;
-    if (q0 >= nq || t0 >= nt) return;
-    __shared__ __align__(16) float tile[kMatchChunk * 64];
-    const int tid = threadIdx.x;
-    const int cnt = min(kMatchChunk, nt - t0);
-    {
-        const float4* src = reinterpret_cast<const float4*>(dt + (size_t)t0 * 64);
-        float4* dst = reinterpret_cast<float4*>(tile);
-        for (int i = tid; i < cnt * 16; i += 256) dst[i] = src[i];
-    }
-    __syncthreads();
-    const int q = q0 + tid;
-    if (q >= nq) return;
-    float qr[64];
-    {
-        const float4* src = reinterpret_cast<const float4*>(dq + (size_t)q * 64);
-#pragma unroll
-        for (int i = 0; i < 16; i++) { float4 v = src[i]; qr[4*i] = v.x; qr[4*i+1] = v.y; qr[4*i+2] = v.z; qr[4*i+3] = v.w; }
-    }
-    float d0 = FLT_MAX, d1 = FLT_MAX; int i0 = -1, i1 = -1;
-    for (int j = 0; j < cnt; j++) {
-        float d = l2_distance64(qr, tile + j * 64);
-        top2_insert(d, t0 + j, d0, i0, d1, i1);
-    }
-    part[(size_t)blockIdx.y * nq_stride + q] = make_float4(d0, __int_as_float(i0), d1, __int_as_float(i1));
+    return __uint_as_float((__float_as_uint(s) & ~127u) | (unsigned)row_in_chunk);
+}
+__device__ __forceinline__ void top4_keys(float v, float& k0, float& k1, float& k2, float& k3)
+{
+    k3 = __builtin_amdgcn_fmed3f(k2, k3, v);
+    k2 = __builtin_amdgcn_fmed3f(k1, k2, v);
+    k1 = __builtin_amdgcn_fmed3f(k0, k1, v);
+    k0 = fminf(k0, v);
 }
 
-__global__ __launch_bounds__(256) void k_match_merge(const float4* part, const int* nq_p, int nq_imm, const int* nt_p, int nt_imm,
-                                                     int nq_stride, int* knn_idx, float* knn_dist)
+// rows past the end are clamped to the last row (an unconditional load keeps the code free of branches); the caller
+// masks them through |t|^2 = kBig / q < nq
+__device__ __forceinline__ void load_half_row(const float* base, int row, int nrows, int h, float* reg)
+{
+    const float4* src = reinterpret_cast<const float4*>(base + (size_t)min(row, nrows - 1) * 64 + 32 * h);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        float4 v = src[i];
+        reg[4*i] = v.x; reg[4*i+1] = v.y; reg[4*i+2] = v.z; reg[4*i+3] = v.w;
+    }
+}
+
+// one 32-row step: dots of the 32 train rows in `areg` with this lane's query, then the three smallest keys
+__device__ __forceinline__ void mfma_step(const float* areg, const float* breg, int tb, int t0, int nt, int n, int h, float* tn_lds,
+                                          float& wmax, float& k0, float& k1, float& k2, float& k3)
+{
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; j++) acc[j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[i], breg[i], acc, 0, 0, 0);
+    // |t|^2 of train row tb + n (any summation order will do: the margin absorbs it), handed to the lanes that hold
+    // that row's dots through the wave's LDS line
+    float tnr = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; i++) tnr = __builtin_fmaf(areg[i], areg[i], tnr);
+    tnr += __shfl_xor(tnr, 32);
+    const bool valid = tb + n < nt;
+    wmax = fmaxf(wmax, valid ? tnr : 0.f);
+    if (h == 0) tn_lds[n] = valid ? tnr : kBig;             // rows past the end never win
+    __builtin_amdgcn_wave_barrier();
+    // acc[j] = t.q for train row tb + (j&3) + 8(j>>2) + 4h and this lane's query
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int rl = 8*g + 4*h;
+        const float4 nn = *reinterpret_cast<const float4*>(tn_lds + rl);
+        const int rc = tb - t0 + rl;
+        top4_keys(shortlist_key(__builtin_fmaf(-2.f, acc[4*g + 0], nn.x), rc),     k0, k1, k2, k3);
+        top4_keys(shortlist_key(__builtin_fmaf(-2.f, acc[4*g + 1], nn.y), rc + 1), k0, k1, k2, k3);
+        top4_keys(shortlist_key(__builtin_fmaf(-2.f, acc[4*g + 2], nn.z), rc + 2), k0, k1, k2, k3);
+        top4_keys(shortlist_key(__builtin_fmaf(-2.f, acc[4*g + 3], nn.w), rc + 3), k0, k1, k2, k3);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// part: [chunk][cap] (k0, k1, k2, k3): the four smallest shortlist keys; tnmax: max |t|^2 (uint bits, zeroed by the host)
+__global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ dq, const int* nq_p, int nq_imm,
+                                                    const float* __restrict__ dt, const int* nt_p, int nt_imm,
+                                                    int cap, float4* part, unsigned* tnmax)
 {
     const int nq = nq_p ? *nq_p : nq_imm, nt = nt_p ? *nt_p : nt_imm;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= nq) return;
-    const int nchunks = (nt + kMatchChunk - 1) / kMatchChunk;
-    float d0 = FLT_MAX, d1 = FLT_MAX; int i0 = -1, i1 = -1;
-    for (int c = 0; c < nchunks; c++) {
-        float4 p = part[(size_t)c * nq_stride + q];
-        int a = __float_as_int(p.y), b = __float_as_int(p.w);
-        if (a >= 0) top2_insert(p.x, a, d0, i0, d1, i1);
-        if (b >= 0) top2_insert(p.z, b, d0, i0, d1, i1);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q0 = blockIdx.x * 128 + wave * 32, t0 = blockIdx.y * kMfmaChunk;
+    if (blockIdx.x * 128 >= nq || t0 >= nt) return;
+    __shared__ __align__(16) float s_tn[4][32];
+    __shared__ __align__(16) float s_rows[kMfmaChunk * kRowStride];      // the chunk's train rows, shared by the four waves
+    float* tn_lds = s_tn[wave];
+    const int n = lane & 31, h = lane >> 5;
+    // B operand: this lane's query, k = 32h .. 32h+31 (MFMA step i consumes k = 32h + i from both operands)
+    const int q = q0 + n;
+    float breg[32];
+    load_half_row(dq, q, nq, h, breg);
+    {   // stage the chunk once: 128 rows x 16 float4, coalesced; rows past the end repeat the last one (masked below)
+        const float4* src = reinterpret_cast<const float4*>(dt);
+        for (int e = threadIdx.x; e < kMfmaChunk * 16; e += 256) {
+            const int r = e >> 4, c4 = e & 15;
+            *reinterpret_cast<float4*>(s_rows + r * kRowStride + 4 * c4) = src[(size_t)min(t0 + r, nt - 1) * 16 + c4];
+        }
     }
-    knn_idx[2*q] = i0; knn_idx[2*q + 1] = i1;
-    knn_dist[2*q] = d0; knn_dist[2*q + 1] = d1;
+    __syncthreads();
+    float k0 = kBig, k1 = kBig, k2 = kBig, k3 = kBig;
+    const int tend = min(t0 + kMfmaChunk, nt);
+    float wmax = 0.f;
+    for (int tb = t0; tb < tend; tb += 32) {
+        float areg[32];                                    // A operand: train row tb + n, same k range
+        const float4* src = reinterpret_cast<const float4*>(s_rows + (tb - t0 + n) * kRowStride + 32 * h);
+#pragma unroll
+        for (int i = 0; i < 8; i++) { float4 v = src[i]; areg[4*i] = v.x; areg[4*i+1] = v.y; areg[4*i+2] = v.z; areg[4*i+3] = v.w; }
+        mfma_step(areg, breg, tb, t0, nt, n, h, tn_lds, wmax, k0, k1, k2, k3);
+    }
+    // the other half-wave saw the other rows of the same query: merge its four
+    {
+        float o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32), o3 = __shfl_xor(k3, 32);
+        top4_keys(o0, k0, k1, k2, k3); top4_keys(o1, k0, k1, k2, k3); top4_keys(o2, k0, k1, k2, k3); top4_keys(o3, k0, k1, k2, k3);
+    }
+    if (h == 0 && q < nq) part[(size_t)blockIdx.y * cap + q] = make_float4(k0, k1, k2, k3);
+    if (blockIdx.x == 0 && wave == 0) {                     // one wave per chunk reports the largest |t|^2
+        for (int o = 16; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+        if (lane == 0) atomicMax(tnmax, __float_as_uint(wmax));         // >= 0: uint order == float order
+    }
+}
+
+// two smallest of the union of two (lo <= hi) pairs
+__device__ __forceinline__ void merge_min2(float& b0, float& b1, float o0, float o1)
+{
+    float n0 = fminf(b0, o0);
+    float n1 = fminf(fmaxf(b0, o0), fminf(b1, o1));
+    b0 = n0; b1 = n1;
+}
+// (d, t) lexicographic top-2: what BatchDistInvoker's insertion leaves after visiting every row in index order
+__device__ __forceinline__ void top2_lex(float d, int t, float& d0, int& i0, float& d1, int& i1)
+{
+    if (t < 0) return;
+    if (d < d0 || (d == d0 && t < i0)) { d1 = d0; i1 = i0; d0 = d; i0 = t; }
+    else if (d < d1 || (d == d1 && t < i1)) { d1 = d; i1 = t; }
+}
+// normL2Sqr_ + sqrt with the 16 accumulators on the 16 lanes of a group: lane l holds q[4l..4l+3]; returns on every lane
+__device__ __forceinline__ float group_distance(const float4 qv, const float* __restrict__ trow, int sub)
+{
+    // accumulator a (= j mod 16) sums elements a, a+16, a+32, a+48 in that order; element e lives in lane e/4, slot e%4
+    // lane `sub` computes accumulator a = sub: it needs q/t elements sub + 16k, i.e. slot sub%4 of lane sub/4 + 4k
+    const float4 tv = reinterpret_cast<const float4*>(trow)[sub];
+    const float dx = qv.x - tv.x, dy = qv.y - tv.y, dz = qv.z - tv.z, dw = qv.w - tv.w;
+    const float px = dx * dx, py = dy * dy, pz = dz * dz, pw = dw * dw;       // squared differences of elements 4sub..4sub+3
+    const int base = (threadIdx.x & 63 & ~15);
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int src = base + (sub >> 2) + 4 * k;           // lane holding element sub + 16k
+        const float vx = __shfl(px, src), vy = __shfl(py, src), vz = __shfl(pz, src), vw = __shfl(pw, src);
+        const int slot = sub & 3;
+        const float term = slot == 0 ? vx : (slot == 1 ? vy : (slot == 2 ? vz : vw));
+        acc = term + acc;
+    }
+    // v[l] = ((acc[l] + acc[4+l]) + acc[8+l]) + acc[12+l], d = (v0 + v2) + (v1 + v3)
+    const int l = sub & 3;
+    const float a0 = __shfl(acc, base + l), a1 = __shfl(acc, base + 4 + l), a2 = __shfl(acc, base + 8 + l), a3 = __shfl(acc, base + 12 + l);
+    const float v = ((a0 + a1) + a2) + a3;                  // lanes with the same l hold the same v
+    const float v0 = __shfl(v, base + 0), v1 = __shfl(v, base + 1), v2 = __shfl(v, base + 2), v3 = __shfl(v, base + 3);
+    return sqrtf((v0 + v2) + (v1 + v3));
+}
+
+__global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__ dq, const int* nq_p, int nq_imm,
+                                                      const float* __restrict__ dt, const int* nt_p, int nt_imm,
+                                                      int cap, const float4* part, const unsigned* tnmax_p,
+                                                      int* knn_idx, float* knn_dist)
+{
+    const int nq = nq_p ? *nq_p : nq_imm, nt = nt_p ? *nt_p : nt_imm;
+    const int sub = threadIdx.x & 15;
+    const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (blockIdx.x * 16 >= nq) return;
+    const bool live = q < nq;                              // whole groups are live or not
+    const int qq = live ? q : nq - 1;
+    const float4 qv = reinterpret_cast<const float4*>(dq + (size_t)qq * 64)[sub];
+    float qn = qv.x*qv.x + qv.y*qv.y + qv.z*qv.z + qv.w*qv.w;
+    qn += __shfl_xor(qn, 8); qn += __shfl_xor(qn, 4); qn += __shfl_xor(qn, 2); qn += __shfl_xor(qn, 1);
+    const float tnmax = __uint_as_float(*tnmax_p);
+    const int nchunks = (nt + kMfmaChunk - 1) / kMfmaChunk;
+    // pass 1: two smallest S' over all candidates of this query (lanes stride the chunks)
+    float b0 = kBig, b1 = kBig;
+    for (int c = sub; c < nchunks; c += 16) {
+        float4 p = part[(size_t)c * cap + qq];
+        merge_min2(b0, b1, p.x, p.y);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) merge_min2(b0, b1, __shfl_xor(b0, o), __shfl_xor(b1, o));
+    const float lim = b1 + 2.f * kMarginRel * (qn + tnmax);
+    // pass 2: every row that can be among the exact two nearest, evaluated by the whole group
+    float d0 = FLT_MAX, d1 = FLT_MAX; int i0 = -1, i1 = -1;
+    for (int cb = 0; cb < nchunks; cb += 16) {
+        const int c = cb + sub;
+        int a = -1, b = -1, e3 = -1; bool scan = false;
+        if (c < nchunks) {
+            float4 p = part[(size_t)c * cap + qq];
+            scan = p.w <= lim;                             // a fourth row is this close: the shortlist may be incomplete
+            if (p.x <= lim) a = c * kMfmaChunk + (int)(__float_as_uint(p.x) & 127u);
+            if (p.y <= lim) b = c * kMfmaChunk + (int)(__float_as_uint(p.y) & 127u);
+            if (p.z <= lim) e3 = c * kMfmaChunk + (int)(__float_as_uint(p.z) & 127u);
+        }
+        for (int l = 0; l < 16; l++) {                     // the lanes' findings, one lane at a time, all 16 lanes working
+            const int base = threadIdx.x & 63 & ~15;
+            const bool sc = __shfl((int)scan, base + l) != 0;
+            if (sc) {
+                const int cc = cb + l, te = min((cc + 1) * kMfmaChunk, nt);
+                for (int t = cc * kMfmaChunk; t < te; t++) top2_lex(group_distance(qv, dt + (size_t)t * 64, sub), t, d0, i0, d1, i1);
+            } else {
+                const int ta = __shfl(a, base + l), tb2 = __shfl(b, base + l), tc = __shfl(e3, base + l);
+                if (ta >= 0) top2_lex(group_distance(qv, dt + (size_t)ta * 64, sub), ta, d0, i0, d1, i1);
+                if (tb2 >= 0) top2_lex(group_distance(qv, dt + (size_t)tb2 * 64, sub), tb2, d0, i0, d1, i1);
+                if (tc >= 0) top2_lex(group_distance(qv, dt + (size_t)tc * 64, sub), tc, d0, i0, d1, i1);
+            }
+        }
+    }
+    if (live && sub == 0) {
+        knn_idx[2*q] = i0; knn_idx[2*q + 1] = i1;
+        knn_dist[2*q] = d0; knn_dist[2*q + 1] = d1;
+    }
 }
 
 // ratio test + ordered compaction, one workgroup of 1024 threads
@@ -135,16 +304,18 @@ uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, con
 {
     if (nq_max <= 0 || nt_max <= 0) return UVO_OK;
     if (nq_max > c->cap || nt_max > c->cap) { c->err = "match: descriptor count exceeds the context's max_kpts"; return UVO_CAPACITY; }
+    unsigned* tnmax = reinterpret_cast<unsigned*>(c->d_mscratch);
     {
         StageTimer t(c, ST_MATCH);
-        dim3 grid((nq_max + 255) / 256, (nt_max + kMatchChunk - 1) / kMatchChunk);
-        hipLaunchKernelGGL(k_match_top2, grid, dim3(256), 0, c->stream, d_q, d_nq, nq_max, d_t, d_nt, nt_max, c->d_mpart, c->cap);
+        UVO_HIP_TRY(c, hipMemsetAsync(tnmax, 0, sizeof(unsigned), c->stream));
+        dim3 grid((nq_max + 127) / 128, (nt_max + kMfmaChunk - 1) / kMfmaChunk);
+        hipLaunchKernelGGL(k_match_mfma, grid, dim3(256), 0, c->stream, d_q, d_nq, nq_max, d_t, d_nt, nt_max, c->cap, c->d_mpart, tnmax);
         UVO_HIP_TRY(c, hipGetLastError());
     }
     {
         StageTimer t(c, ST_MATCH_MERGE);
-        hipLaunchKernelGGL(k_match_merge, dim3((nq_max + 255) / 256), dim3(256), 0, c->stream, c->d_mpart, d_nq, nq_max, d_nt, nt_max,
-                           c->cap, c->d_knn_idx, c->d_knn_dist);
+        hipLaunchKernelGGL(k_match_resolve, dim3((nq_max + 15) / 16), dim3(256), 0, c->stream, d_q, d_nq, nq_max, d_t, d_nt, nt_max,
+                           c->cap, c->d_mpart, tnmax, c->d_knn_idx, c->d_knn_dist);
         UVO_HIP_TRY(c, hipGetLastError());
     }
     return UVO_OK;

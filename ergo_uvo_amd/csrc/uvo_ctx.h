@@ -33,7 +33,6 @@ static const char* const kStageNames[ST_COUNT] = {
 };
 
 static const int kMaxHyp = 2048;      // RANSAC hypotheses evaluated per call (>= ITERATIONS_COUNT)
-static const int kMatchChunk = 64;    // train rows per matcher workgroup
 
 struct DetectSet {                    // one image's detector outputs (device)
     uvo_keypoint* kps;                // sorted, cap
@@ -61,7 +60,8 @@ struct Ctx {
     float* d_DW = nullptr;
 
     // ---- matcher ----
-    float4* d_mpart = nullptr;                   // partial top-2 per (chunk, query): (d0, i0, d1, i1)
+    float4* d_mpart = nullptr;                   // shortlist per (train chunk, query): (s0, i0, s1, i1)
+    float* d_mscratch = nullptr;                 // [0] = max |t|^2 of the train set (uint bits)
     int* d_knn_idx = nullptr;  float* d_knn_dist = nullptr;   // [cap][2]
     float* d_tmp_desc[2] = {nullptr, nullptr};   // staging for the standalone match API
     uvo_dmatch* d_matches[2] = {nullptr, nullptr};            // [0] stereo (L-R), [1] triangular (prev-curr)
