@@ -499,7 +499,7 @@ __device__ __forceinline__ SortKey make_sort_key(const uvo_keypoint& kp)
 }
 
 struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* out[2]; int* out_n[2]; int* rank; int cap;
-                  int* big_list; int* big_n; };
+                  int4* big_par; int* big_n; };
 static const int kSmallWin = 128;       // descriptor windows up to this size use the small-LDS kernel
 static const int kSortChunk = 512;
 
@@ -537,9 +537,15 @@ __global__ __launch_bounds__(256) void k_rank_scatter(SortArgs a)
         a.rank[im * a.cap + me] = 0;                 // ready for the next frame
         const uvo_keypoint kp = a.cand[im][me];
         a.out[im][r] = kp;
-        // keypoints whose descriptor window exceeds kSmallWin go to the large-LDS descriptor launch
+        // keypoints whose descriptor window exceeds kSmallWin go to the large-window descriptor launch, with the window
+        // geometry every task of theirs needs (SURFInvoker: win_size, win_offset, start_x/start_y)
         const float sc = kp.size * 1.2f / 9.0f;
-        if ((int)((20 + 1) * sc) > kSmallWin) { int e = atomicAdd(&a.big_n[im], 1); a.big_list[im * a.cap + e] = r; }
+        const int win_size = (int)((20 + 1) * sc);
+        if (win_size > kSmallWin) {
+            const float win_offset = -(float)(win_size - 1) / 2;
+            int e = atomicAdd(&a.big_n[im], 1);
+            a.big_par[im * a.cap + e] = make_int4(r, win_size, cv_round_f(kp.x + win_offset), cv_round_f(kp.y - win_offset));
+        }
     }
     if (me == 0) *a.out_n[im] = n;
 }
@@ -572,7 +578,42 @@ __device__ __forceinline__ AreaTab area_tab(int dx, int ssize, double scale)
 __device__ __forceinline__ uint8_t sat_u8(float v) { int iv = cv_round_f(v); return (uint8_t)(iv < 0 ? 0 : iv > 255 ? 255 : iv); }
 
 struct DescArgs { const uint8_t* img[2]; uvo_keypoint* kps[2]; float* desc[2]; const int* n[2]; const float* DW;
-                  const int* big_list; const int* big_n; int cap; };
+                  const int4* big_par; const int* big_n; int cap; };
+
+// PATCH (21 x 21, shared) -> gradients, 4x4x4 sums, normalisation -> a.desc[im][k]; 256 threads, PATCH already synchronised
+__device__ __forceinline__ void describe_tail(const DescArgs& a, int im, int k, const int (*PATCH)[21])
+{
+    const int tid = threadIdx.x;
+    __shared__ float DX[20][20], DY[20][20];
+    __shared__ float vec[64];
+    __shared__ float s_scale;
+    for (int o = tid; o < 400; o += 256) {
+        int i = o / 20, j = o - i * 20;
+        float dw = a.DW[o];
+        float vx = (PATCH[i][j+1] - PATCH[i][j] + PATCH[i+1][j+1] - PATCH[i+1][j]) * dw;
+        float vy = (PATCH[i+1][j] - PATCH[i][j] + PATCH[i+1][j+1] - PATCH[i][j+1]) * dw;
+        DX[i][j] = vx; DY[i][j] = vy;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        int cell = tid >> 2, comp = tid & 3, ci = cell >> 2, cj = cell & 3;
+        float acc = 0.f;
+        for (int y = ci * 5; y < ci * 5 + 5; y++)
+            for (int x = cj * 5; x < cj * 5 + 5; x++) {
+                float t = (comp & 1) ? DY[y][x] : DX[y][x];
+                acc += (comp & 2) ? (float)fabs(t) : t;
+            }
+        vec[tid] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double square_mag = 0;
+        for (int kk = 0; kk < 64; kk++) square_mag += vec[kk] * vec[kk];
+        s_scale = (float)(1. / (sqrt(square_mag) + FLT_EPSILON));
+    }
+    __syncthreads();
+    if (tid < 64) a.desc[im][(size_t)k * 64 + tid] = vec[tid] * s_scale;
+}
 
 // One workgroup per keypoint.  PATCH = cv::resize(WIN, 21x21, INTER_AREA) with
 // WIN[i][j] = img(clamp(start_y - j), clamp(start_x + i)) is evaluated separably, exactly as
@@ -593,9 +634,6 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
     float* buf = reinterpret_cast<float*>(smem_desc);                 // [21][win_size]
     __shared__ AreaTab tab[21];
     __shared__ int PATCH[21][21];
-    __shared__ float DX[20][20], DY[20][20];
-    __shared__ float vec[64];
-    __shared__ float s_scale;
     const uint8_t* __restrict__ img = a.img[im];
     const float win_offset = -(float)(win_size - 1) / 2;
     const int start_x = cv_round_f(kp.x + win_offset);
@@ -667,32 +705,7 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
         }
     }
     __syncthreads();
-    for (int o = tid; o < 400; o += 256) {
-        int i = o / 20, j = o - i * 20;
-        float dw = a.DW[o];
-        float vx = (PATCH[i][j+1] - PATCH[i][j] + PATCH[i+1][j+1] - PATCH[i+1][j]) * dw;
-        float vy = (PATCH[i+1][j] - PATCH[i][j] + PATCH[i+1][j+1] - PATCH[i][j+1]) * dw;
-        DX[i][j] = vx; DY[i][j] = vy;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        int cell = tid >> 2, comp = tid & 3, ci = cell >> 2, cj = cell & 3;
-        float acc = 0.f;
-        for (int y = ci * 5; y < ci * 5 + 5; y++)
-            for (int x = cj * 5; x < cj * 5 + 5; x++) {
-                float t = (comp & 1) ? DY[y][x] : DX[y][x];
-                acc += (comp & 2) ? (float)fabs(t) : t;
-            }
-        vec[tid] = acc;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double square_mag = 0;
-        for (int kk = 0; kk < 64; kk++) square_mag += vec[kk] * vec[kk];
-        s_scale = (float)(1. / (sqrt(square_mag) + FLT_EPSILON));
-    }
-    __syncthreads();
-    if (tid < 64) a.desc[im][(size_t)k * 64 + tid] = vec[tid] * s_scale;
+    describe_tail(a, im, k, PATCH);
 }
 
 // small windows: one workgroup per keypoint
@@ -702,13 +715,168 @@ __global__ __launch_bounds__(256) void k_descriptor64_small(DescArgs a, int w, i
     if (k >= *a.n[im]) return;
     describe_keypoint<false>(a, w, h, k, im);
 }
-// large windows (62 KB of LDS each): a fixed grid walks the list built by k_rank_scatter
-__global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int h)
+// Large windows (up to 739 samples: the keypoints of octaves 2 and 3).  One keypoint is 21 independent tasks, one per
+// destination column dx of the area resize: a task needs only the ~win/21 image rows of that column's taps, computes
+// buf[i][dx] for every window row i exactly as above, and finishes the 21 outputs PATCH[dy][dx] of its column.  A
+// fixed grid walks the (keypoint, dx) tasks of the list built by k_rank_scatter, so the largest window is spread over
+// 21 workgroups instead of serialising one; k_descriptor64_big_finish turns the patches into descriptors.
+static const int kPatchStride = 448;       // bytes of patch scratch per keypoint (441 used)
+// the 21 resize tables of every large-window keypoint (they depend on win_size only), once instead of once per task
+__global__ __launch_bounds__(256) void k_descriptor64_big_tabs(DescArgs a, AreaTab* __restrict__ tabs)
 {
     const int im = blockIdx.y;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int e = id / 21, d = id - e * 21;
+    if (e >= a.big_n[im]) return;
+    const int win_size = a.big_par[im * a.cap + e].y;
+    const double scale = 1. / ((double)21 / win_size);
+    tabs[((size_t)im * a.cap + e) * 21 + d] = area_tab(d, win_size, scale);
+}
+__device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// One task per WAVE (no workgroup barriers: four independent waves per workgroup, 8192 tasks in flight on the chip).
+__global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int h, uint8_t* __restrict__ patch, const AreaTab* __restrict__ tabs)
+{
+    const int im = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nb = a.big_n[im];
+    __shared__ float s_bufrow[4][740];
+    float* bufrow = s_bufrow[wv];
+    const uint8_t* __restrict__ img = a.img[im];
+    const int t_first = blockIdx.x * 4 + wv, t_stride = gridDim.x * 4;
+    int4 par_next = make_int4(0, 0, 0, 0);
+    if (t_first < nb * 21) par_next = a.big_par[im * a.cap + t_first / 21];
+    for (int t = t_first; t < nb * 21; t += t_stride) {
+        const int e = t / 21, dx = t - e * 21;
+        const int4 par = par_next;                            // (sorted index, win_size, start_x, start_y) from k_rank_scatter
+        if (t + t_stride < nb * 21) par_next = a.big_par[im * a.cap + (t + t_stride) / 21];      // next task's, in flight meanwhile
+        const int win_size = par.y, start_x = par.z, start_y = par.w;
+        const double inv_scale = (double)21 / win_size;
+        const double scale = 1. / inv_scale;
+        const int iscale = cv_round_d(scale);
+        const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
+        uint8_t* out = patch + ((size_t)im * a.cap + e) * kPatchStride;
+        int* colsum = reinterpret_cast<int*>(bufrow);
+        // window inside the image and rows 4-byte aligned: aligned 32-bit loads cover four columns at a time
+        const bool vec_ok = (w & 3) == 0 && start_x >= 0 && start_x + win_size <= w;
+        const int xa = start_x & ~3;
+        if (area_fast) {
+            // resizeAreaFast_: integer block sums (any order); column c = dy*iscale + sy of the window
+            if (vec_ok) {
+                for (int x4 = xa + 4 * lane; x4 < start_x + win_size; x4 += 256) {
+                    int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                    for (int sx = 0; sx < iscale; sx++) {
+                        int y = start_y - (dx * iscale + sx); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                        const unsigned v = *reinterpret_cast<const unsigned*>(img + (size_t)y * w + x4);
+                        s0 += v & 255u; s1 += (v >> 8) & 255u; s2 += (v >> 16) & 255u; s3 += v >> 24;
+                    }
+                    const int c = x4 - start_x;
+                    if (c >= 0) colsum[c] = s0;
+                    if (c + 1 >= 0 && c + 1 < win_size) colsum[c + 1] = s1;
+                    if (c + 2 >= 0 && c + 2 < win_size) colsum[c + 2] = s2;
+                    if (c + 3 >= 0 && c + 3 < win_size) colsum[c + 3] = s3;
+                }
+            } else
+            for (int c = lane; c < win_size; c += 64) {
+                int x = start_x + c; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
+                int sum = 0;
+                for (int sx = 0; sx < iscale; sx++) {
+                    int y = start_y - (dx * iscale + sx); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                    sum += img[(size_t)y * w + x];
+                }
+                colsum[c] = sum;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 21) {
+                int sum = 0;
+                for (int sy = 0; sy < iscale; sy++) sum += colsum[lane * iscale + sy];
+                int result;
+                if (iscale == 2) result = (sum + 2) >> 2;
+                else { float sc = 1.f / (iscale * iscale); result = sat_u8(sum * sc); }
+                out[lane * 21 + dx] = (uint8_t)result;
+            }
+        } else {
+            const AreaTab* tab = tabs + ((size_t)im * a.cap + e) * 21;
+            AreaTab tx = tab[dx];                           // the same for every lane: keep it in scalar registers
+            tx.sx1 = sgpr_i(tx.sx1); tx.sx2 = sgpr_i(tx.sx2);
+            tx.a_first = sgpr_f(tx.a_first); tx.a_mid = sgpr_f(tx.a_mid); tx.a_last = sgpr_f(tx.a_last);
+            tx.has_first = sgpr_i(tx.has_first) != 0; tx.has_last = sgpr_i(tx.has_last) != 0;
+            const int c_begin = tx.has_first ? tx.sx1 - 1 : tx.sx1;
+            const int c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
+            if (vec_ok) {
+                // four adjacent window rows (image columns) per lane from one aligned 32-bit load per tap
+                for (int x4 = xa + 4 * lane; x4 < start_x + win_size; x4 += 256) {
+                    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+                    for (int c0 = c_begin; c0 < c_end; c0 += 16) {         // sixteen taps in flight, accumulated in order
+                        unsigned v[16];
+#pragma unroll
+                        for (int q = 0; q < 16; q++) {
+                            int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                            v[q] = *reinterpret_cast<const unsigned*>(img + (size_t)y * w + x4);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 16; q++) {
+                            int cc = c0 + q;
+                            float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
+                            if (cc < c_end) {
+                                b0 += (int)(v[q] & 255u) * alpha; b1 += (int)((v[q] >> 8) & 255u) * alpha;
+                                b2 += (int)((v[q] >> 16) & 255u) * alpha; b3 += (int)(v[q] >> 24) * alpha;
+                            }
+                        }
+                    }
+                    const int i = x4 - start_x;
+                    if (i >= 0) bufrow[i] = b0;
+                    if (i + 1 >= 0 && i + 1 < win_size) bufrow[i + 1] = b1;
+                    if (i + 2 >= 0 && i + 2 < win_size) bufrow[i + 2] = b2;
+                    if (i + 3 >= 0 && i + 3 < win_size) bufrow[i + 3] = b3;
+                }
+            } else
+            for (int i = lane; i < win_size; i += 64) {
+                int x = start_x + i; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
+                float b = 0.f;
+                // taps fetched eight at a time (independent loads in flight), accumulated in order
+                for (int c0 = c_begin; c0 < c_end; c0 += 8) {
+                    int v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                        v[q] = img[(size_t)y * w + x];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        int cc = c0 + q;
+                        float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
+                        if (cc < c_end) b += v[q] * alpha;
+                    }
+                }
+                bufrow[i] = b;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 21) {                                // vertical pass of this column
+                const AreaTab ty = tab[lane];
+                const int r_begin = ty.has_first ? ty.sx1 - 1 : ty.sx1;
+                const int r_end = ty.has_last ? ty.sx2 + 1 : ty.sx2;
+                float sum = 0.f;
+                for (int r = r_begin; r < r_end; r++) {
+                    float beta = r < ty.sx1 ? ty.a_first : (r < ty.sx2 ? ty.a_mid : ty.a_last);
+                    sum += beta * bufrow[r];
+                }
+                out[lane * 21 + dx] = sat_u8(sum);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+__global__ __launch_bounds__(256) void k_descriptor64_big_finish(DescArgs a, const uint8_t* __restrict__ patch)
+{
+    const int im = blockIdx.y, tid = threadIdx.x;
+    const int nb = a.big_n[im];
+    __shared__ int PATCH[21][21];
     for (int e = blockIdx.x; e < nb; e += gridDim.x) {
-        describe_keypoint<true>(a, w, h, a.big_list[im * a.cap + e], im);
+        const uint8_t* src = patch + ((size_t)im * a.cap + e) * kPatchStride;
+        for (int o = tid; o < 441; o += 256) PATCH[o / 21][o % 21] = src[o];
+        __syncthreads();
+        describe_tail(a, im, a.big_par[im * a.cap + e].x, PATCH);
         __syncthreads();
     }
 }
@@ -820,7 +988,7 @@ uvo_status surf_detect(Ctx* c, int nimg)
     {
         StageTimer t(c, ST_SORT);
         SortArgs sa = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, { c->det[0].kps, c->det[1].kps },
-                        { c->det[0].n, c->det[1].n }, c->d_rank, c->cap, c->d_big_list, c->d_big_n };
+                        { c->det[0].n, c->det[1].n }, c->d_rank, c->cap, c->d_big_par, c->d_big_n };
         dim3 g((c->cap + 255) / 256, (c->cap + kSortChunk - 1) / kSortChunk, nimg);
         hipLaunchKernelGGL(k_rank_partial, g, dim3(256), 0, c->stream, sa);
         hipLaunchKernelGGL(k_rank_scatter, dim3((c->cap + 255) / 256, nimg), dim3(256), 0, c->stream, sa);
@@ -829,15 +997,11 @@ uvo_status surf_detect(Ctx* c, int nimg)
     {
         StageTimer t(c, ST_DESCRIPTOR);
         DescArgs da = { { c->d_img[0], c->d_img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
-                        { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_list, c->d_big_n, c->cap };
-        const size_t lds_small = sizeof(float) * 21 * 128, lds_big = sizeof(float) * 21 * 740;
-        static bool attr_set = false;
-        if (!attr_set) {
-            UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_descriptor64_big),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_big));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(k_descriptor64_big, dim3(256, nimg), dim3(256), lds_big, c->stream, da, w, h);
+                        { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par, c->d_big_n, c->cap };
+        const size_t lds_small = sizeof(float) * 21 * 128;
+        hipLaunchKernelGGL(k_descriptor64_big_tabs, dim3((c->cap * 21 + 255) / 256, nimg), dim3(256), 0, c->stream, da, c->d_big_tabs);
+        hipLaunchKernelGGL(k_descriptor64_big, dim3(1024, nimg), dim3(256), 0, c->stream, da, w, h, c->d_big_patch, c->d_big_tabs);
+        hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(256, nimg), dim3(256), 0, c->stream, da, c->d_big_patch);
         hipLaunchKernelGGL(k_descriptor64_small, dim3(c->cap, nimg), dim3(256), lds_small, c->stream, da, w, h);
         UVO_HIP_TRY(c, hipGetLastError());
     }

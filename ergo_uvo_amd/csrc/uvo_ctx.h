@@ -52,7 +52,9 @@ struct Ctx {
     int32_t* d_colpart = nullptr;                // [2][nseg][max_w+1]
     uvo_keypoint* d_cand[2] = {nullptr, nullptr};// unsorted candidates
     int* d_cand_n = nullptr;                     // [2] raw atomic counters
-    int* d_big_list = nullptr; int* d_big_n = nullptr;   // [2][cap] sorted indices of large-window keypoints, [2] counts
+    int4* d_big_par = nullptr; int* d_big_n = nullptr;   // [2][cap] (sorted index, win, start_x, start_y) of large-window keypoints, [2] counts
+    struct AreaTab* d_big_tabs = nullptr;        // [2][cap][21] resize tables of the large-window keypoints
+    uint8_t* d_big_patch = nullptr;              // [2][cap][448] 21x21 patches of the large-window keypoints
     int* d_rank = nullptr;                       // [2][cap] sort ranks (zero between frames)
     DetectSet det[2];                            // current left/right
     int img_w = 0, img_h = 0;

@@ -11,7 +11,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 scene = synth.Scene(synth.SEEDS["C3"], W)
 dev = [tuple(torch.from_numpy(x).cuda() for x in synth.stereo_pair(scene, k, W, H)) for k in range(4)]
 rig = synth.stereo_rig(W)
-ctx = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=6387), 0, W, H, 8192)
+ctx = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=6387, SURF_OCTAVES_NUMBER=int(os.environ.get("UVO_OCTAVES", "4"))), 0, W, H, 8192)
 ctx.stereo_set_depth(depth)
 ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
 order = [0, 1, 2, 3, 2, 1]
