@@ -20,6 +20,10 @@ from __future__ import annotations
 import argparse
 import json
 import os
+
+# one hardware queue per HIP stream of the pipeline lanes (the ROCm default of 4 makes lanes share queues and
+# serialises them); must be set before the HIP runtime starts
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import sys
 import time
 
@@ -66,7 +70,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic stereo pairs (ping-pong order)")
-    ap.add_argument("--depth", type=int, default=int(os.environ.get("UVO_PIPELINE_DEPTH", "4")),
+    ap.add_argument("--depth", type=int, default=int(os.environ.get("UVO_PIPELINE_DEPTH", "6")),
                     help="consecutive pairs in flight per image stream (uvo_stereo_set_depth)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU-oracle baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")

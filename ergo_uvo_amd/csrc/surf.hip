@@ -19,7 +19,10 @@ namespace uvo {
 // ------------------------------------------------------------------------------------------
 // integral image
 // ------------------------------------------------------------------------------------------
-struct ImgPair { const uint8_t* img[2]; int32_t* sum[2]; };
+// planes[im]: the integral image de-interleaved by (row & 3, column & 3): 16 planes of ph x pw, plane (ry, rx) holds
+// S[4i + ry][4j + rx] at [i][j].  The step-4 / step-8 sample walks of octaves 2 and 3 become unit / two-element
+// strides in them (coalesced), where the row-major image gives one useful word per 16 or 32 bytes.
+struct ImgPair { const uint8_t* img[2]; int32_t* sum[2]; int32_t* planes[2]; int pw, pstride; };
 static const int kSegRows = 32;
 
 __global__ __launch_bounds__(256) void k_integral_rows(ImgPair ip, int w, int h)
@@ -66,7 +69,11 @@ __global__ __launch_bounds__(256) void k_integral_colfinal(ImgPair ip, int w, in
     int acc = 0;
     for (int k = 0; k < seg; k++) acc += part[((size_t)im * nseg + k) * sw + x];
     int y0 = 1 + seg * kSegRows, y1 = min(h + 1, y0 + kSegRows);
-    for (int y = y0; y < y1; y++) { acc += s[(size_t)y * sw + x]; s[(size_t)y * sw + x] = acc; }
+    int32_t* pl = ip.planes[im] + (size_t)(x & 3) * ip.pstride + (x >> 2);
+    for (int y = y0; y < y1; y++) {
+        acc += s[(size_t)y * sw + x]; s[(size_t)y * sw + x] = acc;
+        pl[(size_t)((y & 3) * 4) * ip.pstride + (size_t)(y >> 2) * ip.pw] = acc;       // (row 0 is zero from allocation)
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -332,6 +339,47 @@ struct OctC {
     static constexpr int HI = -margin(4) * STEP + size(4);        // ... and furthest right/down
 };
 
+// dx, dy, dxy -> det of one sample; SV(dy, dx) fetches the integral value at compile-time offset (dy, dx) from the
+// template's top-left corner.  Corners shared between the boxes of a filter are read once (32 reads per sample).
+#define UVO_HESSIAN_DET(SV, det)                                                                          \
+    {                                                                                                     \
+        /* Dx: boxes (0,2,3,7,+1) (3,2,6,7,-2) (6,2,9,7,+1) */                                            \
+        int a0 = SV(c2, c0), a3 = SV(c2, c3), a6 = SV(c2, c6), a9 = SV(c2, c9);                           \
+        int b0 = SV(c7, c0), b3 = SV(c7, c3), b6 = SV(c7, c6), b9 = SV(c7, c9);                           \
+        double d = 0;                                                                                     \
+        d += (float)(a0 + b3 - b0 - a3) * wx0;                                                            \
+        d += (float)(a3 + b6 - b3 - a6) * wx1;                                                            \
+        d += (float)(a6 + b9 - b6 - a9) * wx2;                                                            \
+        const float dx = (float)d;                                                                        \
+        /* Dy: boxes (2,0,7,3,+1) (2,3,7,6,-2) (2,6,7,9,+1) */                                            \
+        int e0 = SV(c0, c2), e3 = SV(c3, c2), e6 = SV(c6, c2), e9 = SV(c9, c2);                           \
+        int f0 = SV(c0, c7), f3 = SV(c3, c7), f6 = SV(c6, c7), f9 = SV(c9, c7);                           \
+        d = 0;                                                                                            \
+        d += (float)(e0 + f3 - e3 - f0) * wy0;                                                            \
+        d += (float)(e3 + f6 - e6 - f3) * wy1;                                                            \
+        d += (float)(e6 + f9 - e9 - f6) * wy2;                                                            \
+        const float dy = (float)d;                                                                        \
+        /* Dxy: boxes (1,1,4,4,+1) (5,1,8,4,-1) (1,5,4,8,-1) (5,5,8,8,+1) */                              \
+        int g11 = SV(c1, c1), g14 = SV(c1, c4), g15 = SV(c1, c5), g18 = SV(c1, c8);                       \
+        int g41 = SV(c4, c1), g44 = SV(c4, c4), g45 = SV(c4, c5), g48 = SV(c4, c8);                       \
+        int g51 = SV(c5, c1), g54 = SV(c5, c4), g55 = SV(c5, c5), g58 = SV(c5, c8);                       \
+        int g81 = SV(c8, c1), g84 = SV(c8, c4), g85 = SV(c8, c5), g88 = SV(c8, c8);                       \
+        d = 0;                                                                                            \
+        d += (float)(g11 + g44 - g41 - g14) * wd0;                                                        \
+        d += (float)(g15 + g48 - g45 - g18) * wd1;                                                        \
+        d += (float)(g51 + g84 - g81 - g54) * wd2;                                                        \
+        d += (float)(g55 + g88 - g85 - g58) * wd3;                                                        \
+        const float dxy = (float)d;                                                                       \
+        det = dx * dy - 0.81f * dxy * dxy;                                                                \
+    }
+#define UVO_HESSIAN_CONSTS(LC)                                                                            \
+    constexpr int c0 = LC::r(0), c1 = LC::r(1), c2 = LC::r(2), c3 = LC::r(3), c4 = LC::r(4), c5 = LC::r(5), \
+                  c6 = LC::r(6), c7 = LC::r(7), c8 = LC::r(8), c9 = LC::r(9);                             \
+    constexpr float wx0 = LC::wt(1, 0, 2, 3, 7), wx1 = LC::wt(-2, 3, 2, 6, 7), wx2 = LC::wt(1, 6, 2, 9, 7); \
+    constexpr float wy0 = LC::wt(1, 2, 0, 7, 3), wy1 = LC::wt(-2, 2, 3, 7, 6), wy2 = LC::wt(1, 2, 6, 7, 9); \
+    constexpr float wd0 = LC::wt(1, 1, 1, 4, 4), wd1 = LC::wt(-1, 5, 1, 8, 4), wd2 = LC::wt(-1, 1, 5, 4, 8), wd3 = LC::wt(1, 5, 5, 8, 8); \
+    (void)c0; (void)c9
+
 template <int O, int L, int TW, int TH, int NT>
 __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, float* __restrict__ sdet, const OctavePat& op,
                                             int px0, int py0)
@@ -345,11 +393,7 @@ __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, f
     static_assert(OFFL >= 0, "layer origin outside the tile");
     // tile index of corner (dy, dx) relative to base = &stile[ry*STEP*STEP*PW + rx]
 #define SV(dy, dx) base[((OFFL + (dy)) * STEP + ((OFFL + (dx)) % STEP)) * PW + (OFFL + (dx)) / STEP]
-    constexpr int c0 = LC::r(0), c1 = LC::r(1), c2 = LC::r(2), c3 = LC::r(3), c4 = LC::r(4), c5 = LC::r(5),
-                  c6 = LC::r(6), c7 = LC::r(7), c8 = LC::r(8), c9 = LC::r(9);
-    constexpr float wx0 = LC::wt(1, 0, 2, 3, 7), wx1 = LC::wt(-2, 3, 2, 6, 7), wx2 = LC::wt(1, 6, 2, 9, 7);
-    constexpr float wy0 = LC::wt(1, 2, 0, 7, 3), wy1 = LC::wt(-2, 2, 3, 7, 6), wy2 = LC::wt(1, 2, 6, 7, 9);
-    constexpr float wd0 = LC::wt(1, 1, 1, 4, 4), wd1 = LC::wt(-1, 5, 1, 8, 4), wd2 = LC::wt(-1, 1, 5, 4, 8), wd3 = LC::wt(1, 5, 5, 8, 8);
+    UVO_HESSIAN_CONSTS(LC);
     const LayerPat& lp = op.L[L];
     const int tid = threadIdx.x;
 #pragma unroll 2
@@ -359,38 +403,39 @@ __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, f
         float det = 0.f;
         if (oi >= 0 && oi < lp.samples_i && oj >= 0 && oj < lp.samples_j) {
             const int32_t* base = stile + ry * (STEP * STEP * PW) + rx;
-            // Dx: boxes (0,2,3,7,+1) (3,2,6,7,-2) (6,2,9,7,+1)
-            int a0 = SV(c2, c0), a3 = SV(c2, c3), a6 = SV(c2, c6), a9 = SV(c2, c9);
-            int b0 = SV(c7, c0), b3 = SV(c7, c3), b6 = SV(c7, c6), b9 = SV(c7, c9);
-            double d = 0;
-            d += (float)(a0 + b3 - b0 - a3) * wx0;
-            d += (float)(a3 + b6 - b3 - a6) * wx1;
-            d += (float)(a6 + b9 - b6 - a9) * wx2;
-            const float dx = (float)d;
-            // Dy: boxes (2,0,7,3,+1) (2,3,7,6,-2) (2,6,7,9,+1)
-            int e0 = SV(c0, c2), e3 = SV(c3, c2), e6 = SV(c6, c2), e9 = SV(c9, c2);
-            int f0 = SV(c0, c7), f3 = SV(c3, c7), f6 = SV(c6, c7), f9 = SV(c9, c7);
-            d = 0;
-            d += (float)(e0 + f3 - e3 - f0) * wy0;
-            d += (float)(e3 + f6 - e6 - f3) * wy1;
-            d += (float)(e6 + f9 - e9 - f6) * wy2;
-            const float dy = (float)d;
-            // Dxy: boxes (1,1,4,4,+1) (5,1,8,4,-1) (1,5,4,8,-1) (5,5,8,8,+1)
-            int g11 = SV(c1, c1), g14 = SV(c1, c4), g15 = SV(c1, c5), g18 = SV(c1, c8);
-            int g41 = SV(c4, c1), g44 = SV(c4, c4), g45 = SV(c4, c5), g48 = SV(c4, c8);
-            int g51 = SV(c5, c1), g54 = SV(c5, c4), g55 = SV(c5, c5), g58 = SV(c5, c8);
-            int g81 = SV(c8, c1), g84 = SV(c8, c4), g85 = SV(c8, c5), g88 = SV(c8, c8);
-            d = 0;
-            d += (float)(g11 + g44 - g41 - g14) * wd0;
-            d += (float)(g15 + g48 - g45 - g18) * wd1;
-            d += (float)(g51 + g84 - g81 - g54) * wd2;
-            d += (float)(g55 + g88 - g85 - g58) * wd3;
-            const float dxy = (float)d;
-            det = dx * dy - 0.81f * dxy * dxy;
+            UVO_HESSIAN_DET(SV, det)
         }
         sdet[(L * TH + ry) * TW + rx] = det;
     }
 #undef SV
+}
+
+// The same layer from the de-interleaved planes in global memory (octaves 2 and 3: the integral tile of one
+// workgroup would not fit LDS).  Sample (oi, oj) has its top-left at pixel (STEP*oi, STEP*oj); corner (dy, dx) is in
+// plane (dy & 3, dx & 3) at [STEP/4*oi + dy/4][STEP/4*oj + dx/4]: plane and offsets are compile-time, lanes along oj.
+template <int O, int L, int TW, int TH, int NT>
+__device__ __forceinline__ void det_layer_p(const int32_t* __restrict__ planes, int pw, int pstride, float* __restrict__ sdet,
+                                            const OctavePat& op, int px0, int py0)
+{
+    using OC = OctC<O>;
+    constexpr int STEP = OC::STEP, SIZE = OC::size(L), Q = STEP / 4;
+    static_assert(STEP % 4 == 0, "plane variant needs a step that is a multiple of 4");
+    using LC = LayerC<SIZE>;
+#define SVP(dy, dx) base[(size_t)((((dy) & 3) * 4 + ((dx) & 3)) * pstride + ((dy) >> 2) * pw + ((dx) >> 2))]
+    UVO_HESSIAN_CONSTS(LC);
+    const LayerPat& lp = op.L[L];
+    const int tid = threadIdx.x;
+    for (int sidx = tid; sidx < TW * TH; sidx += NT) {
+        const int ry = sidx / TW, rx = sidx - ry * TW;
+        const int oi = py0 + ry - OC::margin(L), oj = px0 + rx - OC::margin(L);
+        float det = 0.f;
+        if (oi >= 0 && oi < lp.samples_i && oj >= 0 && oj < lp.samples_j) {
+            const int32_t* base = planes + (size_t)(oi * Q) * pw + oj * Q;
+            UVO_HESSIAN_DET(SVP, det)
+        }
+        sdet[(L * TH + ry) * TW + rx] = det;
+    }
+#undef SVP
 }
 
 template <int O, int TW, int TH, int NT>
@@ -461,6 +506,58 @@ __global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, 
     }
 }
 
+// Octaves 2 and 3: det layers from the de-interleaved planes, det planes in LDS, NMS as above.
+template <int O, int TW, int TH, int NT>
+__global__ __launch_bounds__(NT) void k_hessian_nms_p(ImgPair ip, int w, int h, OctavePat op, float thr, CandOut out)
+{
+    using OC = OctC<O>;
+    constexpr int STEP = OC::STEP;
+    __shared__ float sdet[5 * TH * TW];
+    const int tid = threadIdx.x, im = blockIdx.z;
+    const int sw = w + 1;
+    const int32_t* __restrict__ gsum = ip.sum[im];
+    const int px0 = blockIdx.x * (TW - 2) - 1, py0 = blockIdx.y * (TH - 2) - 1;
+    det_layer_p<O, 0, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
+    det_layer_p<O, 1, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
+    det_layer_p<O, 2, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
+    det_layer_p<O, 3, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
+    det_layer_p<O, 4, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
+    __syncthreads();
+#pragma unroll 1
+    for (int L = 1; L <= 3; L++) {
+        const LayerPat& lp = op.L[L];
+        if (lp.samples_i == 0 || op.L[L + 1].samples_i == 0) continue;
+        const int m = op.nms_margin[L - 1];
+        for (int idx = tid; idx < (TW - 2) * (TH - 2); idx += NT) {
+            int ry = idx / (TW - 2) + 1, rx = idx - (ry - 1) * (TW - 2) + 1;
+            int i = py0 + ry, j = px0 + rx;
+            if (i < m || i >= op.rows - m || j < m || j >= op.cols - m) continue;
+            const float* d2 = sdet + (L * TH + ry) * TW + rx;
+            float val0 = d2[0];
+            if (!(val0 > thr)) continue;
+            const float* d1 = d2 - TH * TW;
+            const float* d3 = d2 + TH * TW;
+            float N9[3][9] = {
+                { d1[-TW-1], d1[-TW], d1[-TW+1], d1[-1], d1[0], d1[1], d1[TW-1], d1[TW], d1[TW+1] },
+                { d2[-TW-1], d2[-TW], d2[-TW+1], d2[-1], d2[0], d2[1], d2[TW-1], d2[TW], d2[TW+1] },
+                { d3[-TW-1], d3[-TW], d3[-TW+1], d3[-1], d3[0], d3[1], d3[TW-1], d3[TW], d3[TW+1] } };
+            bool is_max = true;
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b = 0; b < 9; b++)
+                    if (!(a == 1 && b == 4)) is_max = is_max && (val0 > N9[a][b]);
+            if (!is_max) continue;
+            float dx, dy, dxy;
+            {
+                const int32_t* o = gsum + (size_t)((i - lp.margin) * STEP) * sw + (j - lp.margin) * STEP;
+                haar_response(lp, [&](int yy, int xx) { return o[(size_t)yy * sw + xx]; }, &dx, &dy, &dxy);
+            }
+            emit_keypoint<STEP>(N9, val0, dx + dy, i, j, lp.size, lp.size - op.L[L - 1].size, op.octave, w, h, im, out);
+        }
+    }
+}
+
 // debug / parity hook: one det+trace layer written to global planes (rows x cols)
 __global__ void k_hessian_layer_debug(const int32_t* gsum, int w, int h, LayerPat lp, int step, int rows, int cols,
                                       float* det, float* trace)
@@ -501,7 +598,7 @@ __device__ __forceinline__ SortKey make_sort_key(const uvo_keypoint& kp)
 struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* out[2]; int* out_n[2]; int* rank; int cap;
                   int4* big_par; int* big_n; };
 static const int kSmallWin = 128;       // descriptor windows up to this size use the small-LDS kernel
-static const int kSortChunk = 512;
+static const int kSortChunk = 128;     // compared-against keypoints per workgroup: small, so that ~600 workgroups share the work
 
 __global__ __launch_bounds__(256) void k_rank_partial(SortArgs a)
 {
@@ -517,6 +614,7 @@ __global__ __launch_bounds__(256) void k_rank_partial(SortArgs a)
     if (me >= n) return;
     const SortKey mine = make_sort_key(a.cand[im][me]);
     int rank = 0;
+#pragma unroll 8
     for (int k = 0; k < cnt; k++) {
         const SortKey o = tile[k];
         bool before = o.k1 > mine.k1 ||
@@ -900,7 +998,7 @@ uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int 
 uvo_status surf_integral(Ctx* c, int nimg)
 {
     const int w = c->img_w, h = c->img_h, sw = w + 1;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] } };
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride };
     int nseg = (h + kSegRows - 1) / kSegRows;
     StageTimer t(c, ST_INTEGRAL);
     hipLaunchKernelGGL(k_integral_rows, dim3(h, 1, nimg), dim3(256), 0, c->stream, ip, w, h);
@@ -915,7 +1013,7 @@ template <int STEP, bool USE_LDS, int TW, int TH>
 static hipError_t launch_hessian(Ctx* c, int nimg, const OctavePat& op, float thr)
 {
     const int w = c->img_w, h = c->img_h;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] } };
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride };
     CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
     size_t lds = sizeof(float) * 5 * TW * TH;
     if (USE_LDS) {
@@ -935,6 +1033,17 @@ static hipError_t launch_hessian(Ctx* c, int nimg, const OctavePat& op, float th
 }
 
 template <int O, int TW, int TH, int NT>
+static hipError_t launch_hessian_p(Ctx* c, int nimg, const OctavePat& op, float thr)
+{
+    const int w = c->img_w, h = c->img_h;
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride };
+    CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
+    dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
+    hipLaunchKernelGGL((k_hessian_nms_p<O, TW, TH, NT>), grid, dim3(NT), 0, c->stream, ip, w, h, op, thr, out);
+    return hipGetLastError();
+}
+
+template <int O, int TW, int TH, int NT>
 static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float thr)
 {
     using OC = OctC<O>;
@@ -942,7 +1051,7 @@ static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float 
     constexpr int TWs = (TW - 1) * STEP + (OC::HI - OC::LO) + 1, THs = (TH - 1) * STEP + (OC::HI - OC::LO) + 1;
     constexpr int PW = (TWs + STEP - 1) / STEP;
     const int w = c->img_w, h = c->img_h;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] } };
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride };
     CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
     const size_t lds = sizeof(float) * 5 * TW * TH + sizeof(int32_t) * (size_t)THs * STEP * PW;
     dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
@@ -980,8 +1089,8 @@ uvo_status surf_detect(Ctx* c, int nimg)
             hipError_t e;
             if (o == 0)      e = launch_hessian_c<0, 64, 32, 512>(c, nimg, op, thr);
             else if (o == 1) e = launch_hessian_c<1, 32, 16, 512>(c, nimg, op, thr);
-            else if (o == 2) e = launch_hessian<4, false, 32, 16>(c, nimg, op, thr);
-            else             e = launch_hessian<8, false, 32, 16>(c, nimg, op, thr);
+            else if (o == 2) e = launch_hessian_p<2, 32, 16, 512>(c, nimg, op, thr);
+            else             e = launch_hessian_p<3, 16, 16, 256>(c, nimg, op, thr);
             UVO_HIP_TRY(c, e);
         }
     }

@@ -50,6 +50,8 @@ struct Ctx {
     uint8_t* d_img[2] = {nullptr, nullptr};
     int32_t* d_sum[2] = {nullptr, nullptr};      // (max_h+1) x (max_w+1)
     int32_t* d_colpart = nullptr;                // [2][nseg][max_w+1]
+    int32_t* d_planes[2] = {nullptr, nullptr};   // integral de-interleaved by (row & 3, col & 3): 16 planes of plane_ph x plane_pw
+    int plane_pw = 0, plane_stride = 0;
     uvo_keypoint* d_cand[2] = {nullptr, nullptr};// unsorted candidates
     int* d_cand_n = nullptr;                     // [2] raw atomic counters
     int4* d_big_par = nullptr; int* d_big_n = nullptr;   // [2][cap] (sorted index, win, start_x, start_y) of large-window keypoints, [2] counts
