@@ -5,6 +5,8 @@
 Prints one JSON object; run on the GPU box:  python tools/bench_configs.py"""
 import json
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # one hardware queue per pipeline stream (see bench.py)
 import sys
 import time
 
@@ -36,11 +38,13 @@ def main():
     for i in range(steps):
         nv += ctx.stereo_step(*dev[order[i % 6]], 0.05).valid
     t_sync = time.perf_counter() - t0
+    DEPTH = 6
+    ctx.stereo_set_depth(DEPTH)
     t0 = time.perf_counter()
-    ctx.stereo_submit(*dev[order[0]])
+    sub = 0
     for i in range(steps):
-        if i + 1 < steps:
-            ctx.stereo_submit(*dev[order[(i + 1) % 6]])
+        while sub < steps and sub - i < DEPTH:
+            ctx.stereo_submit(*dev[order[sub % 6]]); sub += 1
         r = ctx.stereo_collect(0.05)
     t_pipe = time.perf_counter() - t0
     out["C2_stereo_1280x720"] = {"kpts": r.n_left, "valid": nv, "pairs_per_s_sync": round(steps / t_sync, 1),
@@ -62,10 +66,11 @@ def main():
     out["C3_stereo_1920x1080_sync"] = {"pairs_per_s_sync": round(steps / (time.perf_counter() - t0), 1)}
     # host images (PCIe-inclusive)
     t0 = time.perf_counter()
-    ctx.stereo_submit(*frames[order[0]])
+    ctx.stereo_set_depth(6)
+    sub = 0
     for i in range(steps):
-        if i + 1 < steps:
-            ctx.stereo_submit(*frames[order[(i + 1) % 6]])
+        while sub < steps and sub - i < 6:
+            ctx.stereo_submit(*frames[order[sub % 6]]); sub += 1
         ctx.stereo_collect(0.05)
     out["C3_stereo_1920x1080_host_images"] = {"pairs_per_s_pipelined_pcie_inclusive": round(steps / (time.perf_counter() - t0), 1)}
     ctx.close()

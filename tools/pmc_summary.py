@@ -15,7 +15,7 @@ KERNEL = "k_hessian_nms_c<0"
 
 
 def counter_avg(dirname, counter):
-    f = glob.glob(os.path.join(OUT, dirname, "*", "*_counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(OUT, dirname, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     if not f:
         return None, 0
     vals = []
@@ -37,7 +37,7 @@ def main(tag):
                        "tile rows, an uncalibrated width, so the true read traffic lies between raw and corrected")
     json.dump(res, open(os.path.join(ROOT, "profiles", "pmc_hessian_o0.json"), "w"), indent=1)
     print(json.dumps(res, indent=1))
-    ks = glob.glob(os.path.join(OUT, "prof_%s" % tag, "*", "*_kernel_stats.csv"))
+    ks = sorted(glob.glob(os.path.join(OUT, "prof_%s" % tag, "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime, reverse=True)
     if ks:
         rows = list(csv.DictReader(open(ks[0])))
         with open(os.path.join(ROOT, "profiles", "%s_kernel_stats.csv" % tag), "w") as g:
