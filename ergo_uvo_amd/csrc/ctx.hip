@@ -143,6 +143,7 @@ extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w,
     uvo_status st = create_one(p, device, max_w, max_h, max_kpts, out);
     if (st != UVO_OK) return st;
     (*out)->lanes.push_back(*out);
+    if (getenv("UVO_MAX_B")) (*out)->max_b = atoi(getenv("UVO_MAX_B"));
     st = set_depth(*out, 2);                      // two pairs in flight by default (uvo_stereo_set_depth changes it)
     if (st != UVO_OK) { uvo_ctx_destroy(*out); *out = nullptr; }
     return st;
@@ -368,6 +369,7 @@ extern "C" uvo_status uvo_solve_pnp_ransac(uvo_ctx* c, const double* obj, const 
 {
     if (!c || !obj || !img || !K || !rvec || !tvec || !n_inliers || !ok || n < 0) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
+    if (c->n_pending != 0) return fail(c, UVO_INVALID_ARG, "uvo_solve_pnp_ransac: collect the pairs in flight first (the PnP buffers are in use)");
     if (n > c->cap) return fail(c, UVO_CAPACITY, "point count exceeds the context's max_kpts");
     std::vector<float> of((size_t)3 * n);
     for (int i = 0; i < 3 * n; i++) of[i] = (float)obj[i];                     // opoints0.convertTo(opoints, CV_32F)
@@ -630,7 +632,7 @@ static void run_stage_b(uvo_ctx* L)
 {
     Ctx::BJob& j = L->job;
     const Ctx* m = L->master ? L->master : L;
-    j.st = UVO_OK; j.err.clear(); j.ran = j.ninl = j.ok = 0;
+    j.st = UVO_OK; j.err.clear(); j.ran = j.ninl = j.ok = j.wrote = 0;
     if (hipEventSynchronize(L->evA[0]) != hipSuccess) { j.st = UVO_HIP_ERROR; j.err = "stage A of the pair failed"; return; }
     const int* hc = L->h_countsA[0];
     const int cap = L->cap;
@@ -639,9 +641,12 @@ static void run_stage_b(uvo_ctx* L)
     const uvo_params& p = L->p;
     if (G > p.MIN_NUM_3DPOINTS) {                                                          // VO:634
         j.ran = 1;
-        j.st = pose_pnp_ransac(L, 0, G, m->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE,
-                               j.rvec, j.tvec, &j.ninl, &j.ok);                            // VO:647-648
+        PnpResult r;
+        Ctx* one[1] = { L };
+        j.st = pose_pnp_ransac_batch(L, 1, one, &G, m->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE, &r);   // VO:647-648
+        if (j.st == UVO_OK) j.st = r.st;
         if (j.st != UVO_OK) j.err = L->err;
+        else { j.wrote = r.wrote; j.ok = r.ok; j.ninl = r.ninl; memcpy(j.rvec, r.rvec, sizeof(j.rvec)); memcpy(j.tvec, r.tvec, sizeof(j.tvec)); }
     }
 }
 static void lane_worker(uvo_ctx* L)
@@ -652,7 +657,17 @@ static void lane_worker(uvo_ctx* L)
         L->cv.wait(lk, [&] { return L->quit || L->job.state == 1; });
         if (L->quit) return;
         lk.unlock();
-        run_stage_b(L);
+        {   // at most max_b PnP stages at a time over all lanes (the device runs only ~3 kernels concurrently: leave room for stage A)
+            Ctx* m = L->master ? L->master : L;
+            std::unique_lock<std::mutex> g(m->b_mu);
+            m->b_cv.wait(g, [&] { return m->b_running < m->max_b; });
+            m->b_running++;
+            g.unlock();
+            run_stage_b(L);
+            g.lock();
+            m->b_running--;
+            m->b_cv.notify_one();
+        }
         lk.lock();
         L->job.state = 2;
         L->cv.notify_all();
@@ -694,7 +709,7 @@ extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_resul
     int valid = 0;
     if (j.ran) {                                                                           // VO:634
         if (j.st != UVO_OK) return fail(c, j.st, j.err.c_str());
-        if (j.ok) { memcpy(c->rvec, j.rvec, sizeof(c->rvec)); memcpy(c->tvec, j.tvec, sizeof(c->tvec)); }
+        if (j.wrote) { memcpy(c->rvec, j.rvec, sizeof(c->rvec)); memcpy(c->tvec, j.tvec, sizeof(c->tvec)); }     // also the last hypothesis of a failed RANSAC, as OpenCV
         L->last_ninl = j.ninl; out->n_inliers = j.ninl;
         if (j.ninl >= p.MIN_NUM_INLIERS) {                                                 // VO:665
             double R[9];

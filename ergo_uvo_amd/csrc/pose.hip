@@ -15,6 +15,7 @@
 #include "uvo_epnp.h"
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
 
 namespace uvo {
 
@@ -185,9 +186,25 @@ __global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const 
 static const int kHypGroups = 8;         // hypotheses per workgroup (one wave): 8 lanes cooperate on each
 static const int kHypPerGroup = EPNP_SMALL + 15 + 10 + 20 + 45 + 15;   // doubles of LDS per hypothesis
 
-__global__ __launch_bounds__(64) void k_pnp_hyp(const float* opts, const uvo_point2f* ipts, const int* subsets, int nhyp,
-                                                double fx, double fy, double cx, double cy, double* models)
+__device__ long long g_hyp_clk[16];         // diagnostic: phase stamps of hypothesis 0 (printed when UVO_DBG_PHASE is set)
+// The PnP stage of up to kMaxPnpBatch pairs (pipeline lanes) shares every launch: blockIdx.y (or .x for the one-workgroup
+// kernels) selects the job.  The kernels are latency-bound and far too small to fill the chip, and the device runs
+// only a few kernels at a time, so batching the pairs that are ready divides the stage's share of that budget.
+static const int kMaxPnpBatch = 8;
+struct PnpJob {
+    const float* opts; const uvo_point2f* ipts; const int* subsets; double* models; int* hcount;
+    int* inliers; double* ws; int* countsB; double* pose;
+    int G, nhyp, best;
+};
+struct PnpBatch { int n, cap; double fx, fy, cx, cy; float thr2; PnpJob job[kMaxPnpBatch]; };
+
+__global__ __launch_bounds__(64) void k_pnp_hyp(PnpBatch b)
 {
+    const PnpJob& jb = b.job[blockIdx.y];
+    const float* opts = jb.opts; const uvo_point2f* ipts = jb.ipts; const int* subsets = jb.subsets; double* models = jb.models;
+    const int nhyp = jb.nhyp;
+    const double fx = b.fx, fy = b.fy, cx = b.cx, cy = b.cy;
+    if ((int)blockIdx.x * kHypGroups >= nhyp) return;
     extern __shared__ __align__(16) unsigned char smem[];
     double* lds = reinterpret_cast<double*>(smem);
     const int group = threadIdx.x >> 3, lane = threadIdx.x & 7;
@@ -198,6 +215,7 @@ __global__ __launch_bounds__(64) void k_pnp_hyp(const float* opts, const uvo_poi
     A base{lds + group};
     Epnp<P> e;
     e.uc = cx; e.vc = cy; e.fu = fx; e.fv = fy; e.n = 5;
+    e.clk = (blockIdx.x == 0 && blockIdx.y == 0 && group == 0) ? g_hyp_clk : nullptr;
     e.s = base; e.pws = base + EPNP_SMALL; e.us = e.pws + 15; e.alphas = e.us + 10; e.pcs = e.alphas + 20; e.tmp = e.pcs + 45;
     const double ifx = 1. / fx, ify = 1. / fy;
     if (lane < 5) {
@@ -228,10 +246,14 @@ __device__ __forceinline__ bool pnp_is_inlier(const float* opts, const uvo_point
     return err <= thr2;
 }
 
-__global__ __launch_bounds__(256) void k_pnp_score(const float* opts, const uvo_point2f* ipts, int n, const double* models, int nhyp,
-                                                   double fx, double fy, double cx, double cy, float thr2, int* hcount)
+__global__ __launch_bounds__(256) void k_pnp_score(PnpBatch b)
 {
+    const PnpJob& jb = b.job[blockIdx.y];
+    const float* opts = jb.opts; const uvo_point2f* ipts = jb.ipts; const double* models = jb.models; int* hcount = jb.hcount;
+    const int n = jb.G;
+    const double fx = b.fx, fy = b.fy, cx = b.cx, cy = b.cy; const float thr2 = b.thr2;
     const int hyp = blockIdx.x, tid = threadIdx.x;
+    if (hyp >= jb.nhyp) return;
     __shared__ double sR[9], st[3];
     __shared__ int s_cnt;
     if (tid == 0) {
@@ -254,10 +276,13 @@ __global__ __launch_bounds__(256) void k_pnp_score(const float* opts, const uvo_
 }
 
 // winner's mask -> ascending inlier list + refit inputs (double points; undistort in double)
-__global__ __launch_bounds__(1024) void k_pnp_mask(const float* opts, const uvo_point2f* ipts, int n, const double* model,
-                                                   double fx, double fy, double cx, double cy, float thr2,
-                                                   int* inliers, double* pws, double* us, int* counts /* [0] = n_inliers */)
+__global__ __launch_bounds__(1024) void k_pnp_mask(PnpBatch b)
 {
+    const PnpJob& jb = b.job[blockIdx.x];
+    const float* opts = jb.opts; const uvo_point2f* ipts = jb.ipts; const int n = jb.G;
+    const double* model = jb.models + (size_t)jb.best * 6;
+    const double fx = b.fx, fy = b.fy, cx = b.cx, cy = b.cy; const float thr2 = b.thr2;
+    int* inliers = jb.inliers; double* pws = jb.ws; double* us = jb.ws + 3 * (size_t)b.cap; int* counts = jb.countsB;   // [0] = n_inliers
     const int tid = threadIdx.x;
     __shared__ int wtot[16];
     __shared__ int s_base;
@@ -284,15 +309,18 @@ __global__ __launch_bounds__(1024) void k_pnp_mask(const float* opts, const uvo_
 
 __device__ long long g_refit_clk[16];       // diagnostic: phase stamps of the last refit (printed when UVO_DBG_PHASE is set)
 // inlier refit: one workgroup, block-cooperative EPnP.  ws: pws 3c | us 2c | alphas 4c | pcs 9c | tmp 3c (c = cap)
-__global__ __launch_bounds__(256) void k_pnp_refit(double* ws, int cap, const int* n_p, double fx, double fy, double cx, double cy, double* pose)
+__global__ __launch_bounds__(256) void k_pnp_refit(PnpBatch b)
 {
+    const PnpJob& jb = b.job[blockIdx.x];
+    double* ws = jb.ws; const int cap = b.cap; double* pose = jb.pose;
+    const double fx = b.fx, fy = b.fy, cx = b.cx, cy = b.cy;
     __shared__ double small[EPNP_SMALL];
     __shared__ double stage_buf[Epnp<BlockPolicy>::kStageDoubles];
-    const int n = *n_p;
+    const int n = jb.countsB[0];
     using P = BlockPolicy;
     Epnp<P> e;
     e.uc = cx; e.vc = cy; e.fu = fx; e.fv = fy; e.n = n;
-    e.s = P::Arr{small}; e.stage = stage_buf; e.clk = g_refit_clk;
+    e.s = P::Arr{small}; e.stage = stage_buf; e.clk = blockIdx.x == 0 ? g_refit_clk : nullptr;
     e.pws = P::Arr{ws}; e.us = P::Arr{ws + 3 * (size_t)cap}; e.alphas = P::Arr{ws + 5 * (size_t)cap};
     e.pcs = P::Arr{ws + 9 * (size_t)cap}; e.tmp = P::Arr{ws + 18 * (size_t)cap};
     double rvec[3], tvec[3];
@@ -351,112 +379,166 @@ uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const doubl
     return UVO_OK;
 }
 
-// solvePnPRansac on the G points already in c->d_opts[slot] / c->d_ipts[slot]; runs on c->pnp_stream.
+// solvePnPRansac for n jobs at once: job i works on the G[i] points already in lanes[i]->d_opts[0] / d_ipts[0] with
+// lanes[i]'s PnP buffers; every launch and both host syncs are shared.  Runs on m->pnp_stream.
+uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G, const double* K, int iterationsCount,
+                                 float reprojectionError, double confidence, PnpResult* res)
+{
+    const int modelPoints = 5;
+    hipStream_t st = m->pnp_stream;
+    if (n < 1 || n > kMaxPnpBatch) { m->err = "pnp batch size"; return UVO_INVALID_ARG; }
+    const size_t hyp_lds = sizeof(double) * kHypGroups * kHypPerGroup;
+    static std::once_flag attr_once;
+    std::call_once(attr_once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_hyp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds); });
+    int niters0 = iterationsCount > 1 ? iterationsCount : 1;
+    PnpBatch b;
+    memset(&b, 0, sizeof(b));
+    b.cap = m->cap; b.fx = K[0]; b.fy = K[4]; b.cx = K[2]; b.cy = K[5];
+    const double threshold = reprojectionError;
+    b.thr2 = (float)(threshold * threshold);
+    int idx[kMaxPnpBatch];                    // batch slot -> job
+    int nb = 0, max_hyp = 0;
+    for (int i = 0; i < n; i++) {
+        PnpResult& r = res[i];
+        r.st = UVO_OK; r.wrote = r.ok = r.ninl = 0;
+        Ctx* c = lanes[i];
+        if (G[i] < 4) { c->err = "solvePnPRansac needs at least 4 points (OpenCV asserts)"; r.st = UVO_TOO_FEW_POINTS; continue; }
+        if (G[i] == 4) { c->err = "solvePnPRansac with exactly 4 points takes OpenCV's P3P path, which the reference never reaches; not implemented"; r.st = UVO_TOO_FEW_POINTS; continue; }
+        if (niters0 > kMaxHyp) { c->err = "iterations_count exceeds the compiled hypothesis capacity (2048)"; r.st = UVO_CAPACITY; continue; }
+        int nhyp;
+        if (G[i] == modelPoints) {
+            for (int k = 0; k < 5; k++) c->h_subsets[k] = k;
+            nhyp = 1;
+        } else {
+            // getSubset (ptsetreg.cpp): cv::RNG((uint64)-1), uniform(0, count), redraw while duplicate
+            uint64_t state = (uint64_t)-1;
+            for (int it = 0; it < niters0; it++) {
+                int* sub = c->h_subsets + it * 5;
+                for (int k = 0; k < modelPoints; k++) {
+                    int idx_k;
+                    for (;;) {
+                        idx_k = (int)(rng_next(state) % (uint32_t)G[i]);
+                        bool dup = false;
+                        for (int q = 0; q < k; q++) dup = dup || sub[q] == idx_k;
+                        if (!dup) break;
+                    }
+                    sub[k] = idx_k;
+                }
+            }
+            nhyp = niters0;
+        }
+        UVO_HIP_TRY(m, hipMemcpyAsync(c->d_subsets, c->h_subsets, sizeof(int) * 5 * nhyp, hipMemcpyHostToDevice, st));
+        PnpJob& j = b.job[nb];
+        j.opts = c->d_opts[0]; j.ipts = c->d_ipts[0]; j.subsets = c->d_subsets; j.models = c->d_models; j.hcount = c->d_hcount;
+        j.inliers = c->d_inliers; j.ws = c->d_refit; j.countsB = c->d_countsB; j.pose = c->d_pose;
+        j.G = G[i]; j.nhyp = nhyp; j.best = 0;
+        if (nhyp > max_hyp) max_hyp = nhyp;
+        idx[nb++] = i;
+    }
+    if (nb == 0) return UVO_OK;
+    b.n = nb;
+    {
+        StageTimer t(m, ST_PNP_HYP, st);
+        hipLaunchKernelGGL(k_pnp_hyp, dim3((max_hyp + kHypGroups - 1) / kHypGroups, nb), dim3(64), hyp_lds, st, b);
+        UVO_HIP_TRY(m, hipGetLastError());
+    }
+    {
+        StageTimer t(m, ST_PNP_SCORE, st);
+        hipLaunchKernelGGL(k_pnp_score, dim3(max_hyp, nb), dim3(256), 0, st, b);
+        UVO_HIP_TRY(m, hipGetLastError());
+    }
+    for (int s = 0; s < nb; s++) {
+        Ctx* c = lanes[idx[s]];
+        if (b.job[s].G == modelPoints) UVO_HIP_TRY(m, hipMemcpyAsync(c->h_pose, c->d_models, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
+        else UVO_HIP_TRY(m, hipMemcpyAsync(c->h_hcount, c->d_hcount, sizeof(int) * b.job[s].nhyp, hipMemcpyDeviceToHost, st));
+    }
+    UVO_HIP_TRY(m, hipStreamSynchronize(st));
+    // replay of RANSACPointSetRegistrator::run's sequential scan, per job
+    PnpBatch b2 = b;
+    int idx2[kMaxPnpBatch], nb2 = 0;
+    bool need_sync = false;
+    for (int s = 0; s < nb; s++) {
+        Ctx* c = lanes[idx[s]];
+        PnpResult& r = res[idx[s]];
+        const int Gs = b.job[s].G;
+        if (Gs == modelPoints) {              // npoints == model_points: the single model, all five points inliers
+            memcpy(r.rvec, c->h_pose, sizeof(double) * 3); memcpy(r.tvec, c->h_pose + 3, sizeof(double) * 3);
+            int ids[5] = {0, 1, 2, 3, 4};
+            UVO_HIP_TRY(m, hipMemcpyAsync(c->d_inliers, ids, sizeof(ids), hipMemcpyHostToDevice, st));
+            UVO_HIP_TRY(m, hipStreamSynchronize(st));
+            r.wrote = 1; r.ok = 1; r.ninl = 5;
+            continue;
+        }
+        int niters = niters0, maxGoodCount = 0, best = -1, last = 0;
+        for (int iter = 0; iter < niters; iter++) {
+            last = iter;
+            int goodCount = c->h_hcount[iter];
+            if (goodCount > (maxGoodCount > modelPoints - 1 ? maxGoodCount : modelPoints - 1)) {
+                best = iter; maxGoodCount = goodCount;
+                niters = ransac_update_num_iters(confidence, (double)(Gs - goodCount) / Gs, modelPoints, niters);
+            }
+        }
+        if (best < 0) {
+            // RANSAC failed: OpenCV hands back the last hypothesis' rvec/tvec and no inliers
+            UVO_HIP_TRY(m, hipMemcpyAsync(c->h_pose, c->d_models + (size_t)last * 6, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
+            need_sync = true;
+            r.wrote = 2;                      // pose arrives with the final sync
+            continue;
+        }
+        b2.job[nb2] = b.job[s]; b2.job[nb2].best = best;
+        idx2[nb2++] = idx[s];
+    }
+    if (nb2 > 0) {
+        b2.n = nb2;
+        StageTimer t(m, ST_PNP_REFIT, st);
+        hipLaunchKernelGGL(k_pnp_mask, dim3(nb2), dim3(1024), 0, st, b2);
+        hipLaunchKernelGGL(k_pnp_refit, dim3(nb2), dim3(256), 0, st, b2);
+        UVO_HIP_TRY(m, hipGetLastError());
+    }
+    for (int s = 0; s < nb2; s++) {
+        Ctx* c = lanes[idx2[s]];
+        UVO_HIP_TRY(m, hipMemcpyAsync(c->h_pose, c->d_pose, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
+        UVO_HIP_TRY(m, hipMemcpyAsync(c->h_countsB, c->d_countsB, sizeof(int), hipMemcpyDeviceToHost, st));
+        need_sync = true;
+    }
+    if (need_sync) UVO_HIP_TRY(m, hipStreamSynchronize(st));
+    for (int s = 0; s < nb2; s++) {
+        Ctx* c = lanes[idx2[s]];
+        PnpResult& r = res[idx2[s]];
+        memcpy(r.rvec, c->h_pose, sizeof(double) * 3); memcpy(r.tvec, c->h_pose + 3, sizeof(double) * 3);
+        r.ninl = c->h_countsB[0]; r.ok = 1; r.wrote = 1;
+    }
+    for (int i = 0; i < n; i++) if (res[i].wrote == 2) {
+        Ctx* c = lanes[i];
+        memcpy(res[i].rvec, c->h_pose, sizeof(double) * 3); memcpy(res[i].tvec, c->h_pose + 3, sizeof(double) * 3);
+        res[i].wrote = 1;
+    }
+    if (getenv("UVO_DBG_PHASE")) {
+        long long k[16];
+        UVO_HIP_TRY(m, hipMemcpyFromSymbol(k, HIP_SYMBOL(g_hyp_clk), sizeof(k)));
+        fprintf(stderr, "[uvo] pnp batch %d; hyp phases (us): ctrl %.1f bary %.1f mtm %.1f svd12 %.1f betas %.1f pcs %.1f sums %.1f svd3 %.1f reproj %.1f\n", nb,
+                (k[1]-k[0])*0.01, (k[2]-k[1])*0.01, (k[3]-k[2])*0.01, (k[4]-k[3])*0.01, (k[5]-k[4])*0.01, (k[6]-k[5])*0.01,
+                (k[7]-k[6])*0.01, (k[8]-k[7])*0.01, (k[9]-k[8])*0.01);
+        UVO_HIP_TRY(m, hipMemcpyFromSymbol(k, HIP_SYMBOL(g_refit_clk), sizeof(k)));
+        fprintf(stderr, "[uvo] pnp refit phases (us): ctrl %.1f bary %.1f mtm %.1f svd12 %.1f betas %.1f pcs %.1f sums %.1f svd3 %.1f reproj %.1f\n",
+                (k[1]-k[0])*0.01, (k[2]-k[1])*0.01, (k[3]-k[2])*0.01, (k[4]-k[3])*0.01, (k[5]-k[4])*0.01, (k[6]-k[5])*0.01,
+                (k[7]-k[6])*0.01, (k[8]-k[7])*0.01, (k[9]-k[8])*0.01);
+    }
+    return UVO_OK;
+}
+
+// single problem (the standalone operator): a batch of one on c's own buffers
 uvo_status pose_pnp_ransac(Ctx* c, int slot, int G, const double* K, int iterationsCount, float reprojectionError, double confidence,
                            double* rvec, double* tvec, int* n_inliers, int* ok)
 {
-    const int modelPoints = 5;
+    (void)slot;
+    PnpResult r;
+    Ctx* lanes[1] = { c };
     *n_inliers = 0; *ok = 0;
-    hipStream_t st = c->pnp_stream;
-    const float* d_opts = c->d_opts[slot]; const uvo_point2f* d_ipts = c->d_ipts[slot];
-    if (G < 4) { c->err = "solvePnPRansac needs at least 4 points (OpenCV asserts)"; return UVO_TOO_FEW_POINTS; }
-    if (G == 4) { c->err = "solvePnPRansac with exactly 4 points takes OpenCV's P3P path, which the reference never reaches; not implemented"; return UVO_TOO_FEW_POINTS; }
-    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-    const size_t hyp_lds = sizeof(double) * kHypGroups * kHypPerGroup;
-    static bool attr_set = false;
-    if (!attr_set) {
-        UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_hyp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds));
-        attr_set = true;
-    }
-    int niters = iterationsCount > 1 ? iterationsCount : 1;
-    if (niters > kMaxHyp) { c->err = "iterations_count exceeds the compiled hypothesis capacity (2048)"; return UVO_CAPACITY; }
-    int nhyp;
-    if (G == modelPoints) {
-        for (int i = 0; i < 5; i++) c->h_subsets[i] = i;
-        nhyp = 1;
-    } else {
-        // getSubset (ptsetreg.cpp): cv::RNG((uint64)-1), uniform(0, count), redraw while duplicate
-        uint64_t state = (uint64_t)-1;
-        for (int it = 0; it < niters; it++) {
-            int* idx = c->h_subsets + it * 5;
-            for (int i = 0; i < modelPoints; i++) {
-                int idx_i;
-                for (;;) {
-                    idx_i = (int)(rng_next(state) % (uint32_t)G);
-                    bool dup = false;
-                    for (int q = 0; q < i; q++) dup = dup || idx[q] == idx_i;
-                    if (!dup) break;
-                }
-                idx[i] = idx_i;
-            }
-        }
-        nhyp = niters;
-    }
-    UVO_HIP_TRY(c, hipMemcpyAsync(c->d_subsets, c->h_subsets, sizeof(int) * 5 * nhyp, hipMemcpyHostToDevice, st));
-    {
-        StageTimer t(c, ST_PNP_HYP, st);
-        hipLaunchKernelGGL(k_pnp_hyp, dim3((nhyp + kHypGroups - 1) / kHypGroups), dim3(64), hyp_lds, st,
-                           d_opts, d_ipts, c->d_subsets, nhyp, fx, fy, cx, cy, c->d_models);
-        UVO_HIP_TRY(c, hipGetLastError());
-    }
-    if (G == modelPoints) {
-        UVO_HIP_TRY(c, hipMemcpyAsync(c->h_pose, c->d_models, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
-        UVO_HIP_TRY(c, hipStreamSynchronize(st));
-        memcpy(rvec, c->h_pose, sizeof(double) * 3); memcpy(tvec, c->h_pose + 3, sizeof(double) * 3);
-        int ids[5] = {0, 1, 2, 3, 4};
-        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_inliers, ids, sizeof(ids), hipMemcpyHostToDevice, st));
-        UVO_HIP_TRY(c, hipStreamSynchronize(st));
-        *n_inliers = 5; *ok = 1;
-        return UVO_OK;
-    }
-    const double threshold = reprojectionError;
-    const float thr2 = (float)(threshold * threshold);
-    {
-        StageTimer t(c, ST_PNP_SCORE, st);
-        hipLaunchKernelGGL(k_pnp_score, dim3(nhyp), dim3(256), 0, st, d_opts, d_ipts, G, c->d_models, nhyp,
-                           fx, fy, cx, cy, thr2, c->d_hcount);
-        UVO_HIP_TRY(c, hipGetLastError());
-    }
-    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_hcount, c->d_hcount, sizeof(int) * nhyp, hipMemcpyDeviceToHost, st));
-    UVO_HIP_TRY(c, hipStreamSynchronize(st));
-    // replay of RANSACPointSetRegistrator::run's sequential scan
-    int maxGoodCount = 0, best = -1, last = 0;
-    for (int iter = 0; iter < niters; iter++) {
-        last = iter;
-        int goodCount = c->h_hcount[iter];
-        if (goodCount > (maxGoodCount > modelPoints - 1 ? maxGoodCount : modelPoints - 1)) {
-            best = iter; maxGoodCount = goodCount;
-            niters = ransac_update_num_iters(confidence, (double)(G - goodCount) / G, modelPoints, niters);
-        }
-    }
-    if (best < 0) {
-        // RANSAC failed: OpenCV hands back the last hypothesis' rvec/tvec and no inliers
-        UVO_HIP_TRY(c, hipMemcpyAsync(c->h_pose, c->d_models + (size_t)last * 6, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
-        UVO_HIP_TRY(c, hipStreamSynchronize(st));
-        memcpy(rvec, c->h_pose, sizeof(double) * 3); memcpy(tvec, c->h_pose + 3, sizeof(double) * 3);
-        return UVO_OK;
-    }
-    {
-        StageTimer t(c, ST_PNP_REFIT, st);
-        double* ws = c->d_refit;
-        hipLaunchKernelGGL(k_pnp_mask, dim3(1), dim3(1024), 0, st, d_opts, d_ipts, G, c->d_models + (size_t)best * 6,
-                           fx, fy, cx, cy, thr2, c->d_inliers, ws, ws + 3 * (size_t)c->cap, c->d_countsB);
-        hipLaunchKernelGGL(k_pnp_refit, dim3(1), dim3(256), 0, st, ws, c->cap, c->d_countsB, fx, fy, cx, cy, c->d_pose);
-        UVO_HIP_TRY(c, hipGetLastError());
-    }
-    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_pose, c->d_pose, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
-    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_countsB, c->d_countsB, sizeof(int), hipMemcpyDeviceToHost, st));
-    UVO_HIP_TRY(c, hipStreamSynchronize(st));
-    memcpy(rvec, c->h_pose, sizeof(double) * 3); memcpy(tvec, c->h_pose + 3, sizeof(double) * 3);
-    *n_inliers = c->h_countsB[0];
-    if (getenv("UVO_DBG_PHASE")) {
-        long long k[16];
-        UVO_HIP_TRY(c, hipMemcpyFromSymbol(k, HIP_SYMBOL(g_refit_clk), sizeof(k)));
-        fprintf(stderr, "[uvo] pnp refit phases (us), %d inliers: ctrl %.1f bary %.1f mtm %.1f svd12 %.1f betas %.1f pcs %.1f sums %.1f svd3 %.1f reproj %.1f\n",
-                *n_inliers, (k[1]-k[0])*0.01, (k[2]-k[1])*0.01, (k[3]-k[2])*0.01, (k[4]-k[3])*0.01, (k[5]-k[4])*0.01, (k[6]-k[5])*0.01,
-                (k[7]-k[6])*0.01, (k[8]-k[7])*0.01, (k[9]-k[8])*0.01);
-    }
-    *ok = 1;
+    UVO_TRY(pose_pnp_ransac_batch(c, 1, lanes, &G, K, iterationsCount, reprojectionError, confidence, &r));
+    if (r.st != UVO_OK) return r.st;
+    if (r.wrote) { memcpy(rvec, r.rvec, sizeof(r.rvec)); memcpy(tvec, r.tvec, sizeof(r.tvec)); }
+    *n_inliers = r.ninl; *ok = r.ok;
     return UVO_OK;
 }
 

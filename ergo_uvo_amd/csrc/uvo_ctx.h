@@ -129,9 +129,10 @@ struct Ctx {
     struct BJob {
         int state = 0;                           // 0 idle, 1 queued, 2 done
         uvo_status st = UVO_OK; std::string err;
-        int ran = 0, ninl = 0, ok = 0; double rvec[3], tvec[3];
+        int ran = 0, ninl = 0, ok = 0, wrote = 0; double rvec[3], tvec[3];
     } job;
     std::thread worker; std::mutex mu; std::condition_variable cv; bool quit = false;
+    std::mutex b_mu; std::condition_variable b_cv; int b_running = 0, max_b = 2;   // master: PnP stages running / allowed at once
 
     // last-step bookkeeping for uvo_stereo_get
     int last_nL = 0, last_nR = 0, last_M = 0, last_T = 0, last_G = 0, last_ninl = 0;
@@ -181,6 +182,9 @@ uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, 
                           const double* K1, const double* K2, const int* d_n, int n_max);
 uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const double* R, const double* t, const double* K,
                                  const uvo_point2f* img, double* err);
+struct PnpResult { uvo_status st; int wrote, ok, ninl; double rvec[3], tvec[3]; };
+uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G, const double* K, int iters, float reproj, double conf,
+                                 PnpResult* res);
 uvo_status pose_pnp_ransac(Ctx* c, int slot, int G, const double* K, int iters, float reproj, double conf,
                            double* rvec, double* tvec, int* n_inliers, int* ok);
 int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters);

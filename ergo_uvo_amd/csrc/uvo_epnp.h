@@ -257,8 +257,8 @@ struct Epnp {
     int n;
     Arr pws, us, alphas, pcs, tmp, s;         // pcs: 3 branches x 3n, tmp: 3 branches x n
     double* stage = nullptr;                  // BlockPolicy: LDS staging buffer of kStageDoubles
-    long long* clk = nullptr;                 // diagnostic phase stamps (100 MHz), block policy only
-#define EP_STAMP(i) do { if (P::kStaged && clk && P::tid() == 0) clk[i] = wall_clock64(); } while (0)
+    long long* clk = nullptr;                 // diagnostic phase stamps (100 MHz); null = off
+#define EP_STAMP(i) do { if (clk && P::tid() == 0) clk[i] = wall_clock64(); } while (0)
     static constexpr int kStageDoubles = 5120;
 
     // E independent sequential sums out[e] = (((0 + term(e,0)) + term(e,1)) + ...) over i < n.
