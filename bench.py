@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT = 1920, 1080
 MIN_HESSIAN_C3 = 6387            # frozen: frame 0 of seed 20250906 gives 3001 / 3008 keypoints
+MFMA_F32_PEAK_TFLOPS = 157.3    # dense f32-input MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -146,6 +147,15 @@ def main():
 
     out = None
     if rank == 0:
+        # ---- latency leg: synchronous uvo_stereo_step, one pair in flight, wall clock per call ----
+        lat = []
+        for _ in range(60):
+            a = time.perf_counter()
+            rl = step()
+            lat.append((time.perf_counter() - a) * 1e3)
+        lat.sort()
+        latency = {"median": round(lat[len(lat) // 2], 4), "p95": round(lat[int(len(lat) * 0.95)], 4), "samples": len(lat),
+                   "what": "uvo_stereo_step, synchronous (one pair in flight), images resident in HBM"}
         # ---- roofline leg: HIP events on the context's stream around each stage ----
         ctx.timing_enable(True)
         ctx.timing_reset()
@@ -164,6 +174,10 @@ def main():
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # the all-pairs contraction of the matcher against the f32 MFMA peak (F = 2 Nq Nt 64 per call)
+        mm_ms, mm_n = tm["match_top2"]
+        f_pair = 2.0 * 64 * (rl.n_left * rl.n_right + rl.n_stereo_matches * rl.n_left)
+        mm_tflops = f_pair / max(mm_ms / max(mm_n, 1) * 2 * 1e-3, 1e-12) / 1e12
         stage_ms = {k: round(v[0] / max(v[1], 1), 4) for k, v in tm.items() if v[1]}
         stage_calls = {k: v[1] // 10 for k, v in tm.items() if v[1]}
 
@@ -198,6 +212,10 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5)},
+            "roofline_match": {"bound": "mfma", "kernel": "k_match_mfma (v_mfma_f32_32x32x2_f32), two calls per pair",
+                               "achieved": round(mm_tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(mm_tflops / MFMA_F32_PEAK_TFLOPS, 5), "flops_per_pair": f_pair},
+            "step_latency_ms": latency,
             "pair_hbm_frac": round(algorithmic_bytes_pair(WIDTH, HEIGHT, 3000) * value / world / 1e9 / HBM_PEAK_GBS, 5),
             "stage_ms": stage_ms, "stage_launches_per_step": stage_calls,
             "cpu_baseline": cpu,
