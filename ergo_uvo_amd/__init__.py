@@ -256,6 +256,31 @@ class Context:
         self._check(self._lib.uvo_stereo_step(self._h, pl, pr, w, h, w, ml, C.c_double(dt), C.byref(r)))
         return r
 
+    def get_image(self, rgb, desired_width, K, dist4, newK, clahe=True, clip_limit=3, device_out=False):
+        """get_image (VO_utility.cpp:337-379): resize INTER_AREA -> RGB2GRAY -> undistort -> optional CLAHE.
+        rgb: HxWx3 uint8 numpy array, or a CUDA torch tensor of that shape.  Returns a numpy array, or a CUDA tensor
+        when device_out is set."""
+        K, dist4, newK = _np(K, np.float64), _np(dist4, np.float64), _np(newK, np.float64)
+        if hasattr(rgb, "data_ptr"):
+            h, w, _ = rgb.shape
+            src, mem, stride = C.c_void_p(rgb.data_ptr()), 1, int(rgb.stride(0))
+        else:
+            rgb = _np(rgb, np.uint8); h, w, _ = rgb.shape
+            src, mem, stride = _p(rgb), 0, w * 3
+        dh = int(h / (w / desired_width))
+        ow, oh = C.c_int(0), C.c_int(0)
+        if device_out:
+            import torch
+            out = torch.empty((dh, desired_width), dtype=torch.uint8, device="cuda")
+            dst, omem = C.c_void_p(out.data_ptr()), 1
+        else:
+            out = np.empty((dh, desired_width), np.uint8)
+            dst, omem = _p(out), 0
+        self._check(self._lib.uvo_get_image(self._h, src, w, h, stride, mem, _p(K), _p(dist4), _p(newK), int(desired_width),
+                                            int(bool(clahe)), int(clip_limit), dst, omem, C.byref(ow), C.byref(oh)))
+        assert (ow.value, oh.value) == (desired_width, dh)
+        return out
+
     def stereo_set_depth(self, depth):
         """Number of consecutive pairs that may be in flight between stereo_submit and stereo_collect (default 2)."""
         self._check(self._lib.uvo_stereo_set_depth(self._h, int(depth)))

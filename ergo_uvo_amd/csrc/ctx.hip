@@ -181,6 +181,7 @@ static void destroy_one(uvo_ctx* c)
     }
     if (c->pnp_stream) (void)hipStreamSynchronize(c->pnp_stream);
     mono_ws_free(c);
+    pre_ws_free(c);
     void* ptrs[] = { c->d_colpart, c->d_DW, c->d_rank, c->d_big_par, c->d_big_patch, c->d_big_tabs, c->d_mpart, c->d_mscratch, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
                      c->d_flag, c->d_tmp_idx, c->d_good_pts[0], c->d_good_pts[1], c->d_good_idx[0], c->d_good_idx[1], c->d_opts[0], c->d_opts[1],
                      c->d_ipts[0], c->d_ipts[1], c->d_counts, c->d_countsB, c->d_subsets, c->d_models,
@@ -764,6 +765,21 @@ extern "C" int uvo_stereo_get(uvo_ctx* m, const char* what, void* out, int cap_b
     return count;
 }
 
+
+// ------------------------------------------------------------------------------------------ get_image
+extern "C" uvo_status uvo_get_image(uvo_ctx* c, const uint8_t* rgb, int w, int h, int stride, int mem, const double* K, const double* dist4,
+                                    const double* newK, int desired_width, int clahe, int clip_limit, uint8_t* out, int out_mem,
+                                    int* out_w, int* out_h)
+{
+    if (!c || !rgb || !K || !dist4 || !newK || !out || !out_w || !out_h) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    const uint8_t* d_res = nullptr;
+    UVO_TRY(pre_get_image(c, rgb, w, h, stride, mem, K, dist4, newK, desired_width, clahe, clip_limit, &d_res, out_w, out_h));
+    const size_t n = (size_t)*out_w * *out_h;
+    UVO_HIP_TRY(c, hipMemcpyAsync(out, d_res, n, out_mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return UVO_OK;
+}
 
 // ------------------------------------------------------------------------------------------ mono path
 extern "C" uvo_status uvo_find_essential_mat(uvo_ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K, int method,

@@ -139,6 +139,7 @@ struct Ctx {
 
     // ---- mono stage (mono.hip) ----
     void* mono_ws = nullptr;                     // MonoWs*, allocated on first use
+    void* pre_ws = nullptr;                      // PreWs* (get_image), allocated on first use
     double mono_K[9]; bool mono_cam_set = false, mono_initialized = false;
     int mono_use_essential = 1;                  // the reference's global `use_essential` (VOH:89)
     double mono_R[9] = {1,0,0,0,1,0,0,0,1}, mono_t[3] = {0,0,0}, mono_SF = 1.0;
@@ -188,6 +189,10 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
 uvo_status pose_pnp_ransac(Ctx* c, int slot, int G, const double* K, int iters, float reproj, double conf,
                            double* rvec, double* tvec, int* n_inliers, int* ok);
 int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters);
+// preproc.hip
+void pre_ws_free(Ctx* c);
+uvo_status pre_get_image(Ctx* c, const uint8_t* rgb, int w, int h, int stride, int mem, const double* K, const double* dist4, const double* newK,
+                         int desired_width, int clahe_on, int clip_limit, const uint8_t** d_out, int* out_w, int* out_h);
 // mono.hip
 void mono_ws_free(Ctx* c);
 uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K, int method,

@@ -15,6 +15,7 @@ using std::vector;
 
 // ---- parameter globals; defaults are the stereo launch file's values (uvo_params_default_stereo) ---------------
 std::string FEATURE_DETECTOR = "SURF";
+int    DESIRED_WIDTH = 640;        bool CLAHE_CORRECTION = true;   int CLIP_LIMIT = 8;          // uvo/config/stereo_VO_parameters.yaml
 int    DISTANCE;
 int    ESSENTIAL_OUTLIER_METHOD;   double ESSENTIAL_MAX_ITERS, ESSENTIAL_CONFIDENCE, ESSENTIAL_THRESHOLD;
 int    HOMOGRAPHY_OUTLIER_METHOD;  double HOMOGRAPHY_MAX_ITERS, HOMOGRAPHY_CONFIDENCE, HOMOGRAPHY_THRESHOLD, HOMOGRAPHY_DISTANCE;
@@ -252,6 +253,29 @@ Mat convert_from_homogeneous_coords(const Mat& points4d)
         float w = points4d.at<float>(3, j);
         for (int r = 0; r < 3; r++) out.at<float>(r, j) = points4d.at<float>(r, j) / w;
     }
+    return out;
+}
+
+// VOU:337-379: resize INTER_AREA to DESIRED_WIDTH -> RGB2GRAY -> undistort -> CLAHE(CLIP_LIMIT) when CLAHE_CORRECTION
+Mat get_image(const Mat& current_img, const Mat& cameraMatrix, const Mat& distortionCoeff, const Mat& newCamMatrix)
+{
+    require(!current_img.empty() && current_img.type() == CV_8UC3, "get_image: CV_8UC3 image expected");
+    double K[9], newK[9], d4[4] = {0, 0, 0, 0};
+    doubles_of(cameraMatrix, 3, 3, K, "get_image: cameraMatrix must be 3x3 CV_64F");
+    doubles_of(newCamMatrix, 3, 3, newK, "get_image: newCamMatrix must be 3x3 CV_64F");
+    require(!distortionCoeff.empty() && distortionCoeff.type() == CV_64FC1 && distortionCoeff.rows * distortionCoeff.cols == 4,
+            "get_image: distortion must be (k1, k2, p1, p2) CV_64F");
+    for (int i = 0, k = 0; i < distortionCoeff.rows; i++) for (int j = 0; j < distortionCoeff.cols; j++) d4[k++] = distortionCoeff.at<double>(i, j);
+    const int w = current_img.cols, h = current_img.rows;
+    const int stride = h > 1 ? (int)(current_img.ptr<uint8_t>(1) - current_img.ptr<uint8_t>(0)) : w * 3;
+    const int dh = (int)(h / ((double)w / (double)DESIRED_WIDTH));
+    require(dh > 0, "get_image: DESIRED_WIDTH");
+    Mat out(dh, DESIRED_WIDTH, CV_8UC1);
+    std::vector<uint8_t> tight((size_t)dh * DESIRED_WIDTH);
+    int ow = 0, oh = 0;
+    SHIM_TRY(uvo_get_image(ctx_now(), current_img.ptr<uint8_t>(0), w, h, stride, UVO_MEM_HOST, K, d4, newK, DESIRED_WIDTH, CLAHE_CORRECTION ? 1 : 0,
+                           CLIP_LIMIT, tight.data(), UVO_MEM_HOST, &ow, &oh), "uvo_get_image");
+    for (int y = 0; y < oh; y++) memcpy(out.ptr<uint8_t>(y), tight.data() + (size_t)y * ow, (size_t)ow);
     return out;
 }
 

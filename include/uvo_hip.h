@@ -35,6 +35,8 @@ typedef enum {
     UVO_NO_DEVICE = 5
 } uvo_status;
 
+/* UVO_MEM_DEVICE buffers are read/written on the context's own (non-blocking) streams: the caller makes sure the
+ * data is complete before the call (e.g. synchronises the stream that produced it). */
 enum { UVO_MEM_HOST = 0, UVO_MEM_DEVICE = 1 };
 
 /* cv::KeyPoint (28 B), cv::DMatch (16 B), cv::Point2f -- same field order and size */
@@ -185,6 +187,17 @@ uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h, int strid
                          uvo_mono_result* out);
 /* last step's intermediates: "kps", "matches", "mask", "good_pts" */
 int        uvo_mono_get(uvo_ctx* c, const char* what, void* out, int cap_bytes);
+
+/* ---- get_image (VO_utility.h:105 -> VO_utility.cpp:337-379), the preprocessing in front of detect_features:
+ * cv::resize(INTER_AREA) to desired_width x (int)(h / (w / desired_width)) (skipped when the size already matches),
+ * cv::cvtColor(COLOR_RGB2GRAY), cv::undistort(K, dist, newK), and cv::CLAHE(clip_limit, 8x8 tiles) when `clahe` != 0
+ * (the reference's globals DESIRED_WIDTH, CLAHE_CORRECTION, CLIP_LIMIT, VO_utility.h:41-44).
+ * rgb: h x w x 3 interleaved u8, `stride` bytes per row, host or device per `mem`; dist4 = (k1, k2, p1, p2);
+ * out: tight-pitch u8 written to host or device memory per `out_mem` (feed it to uvo_surf_detect / uvo_stereo_submit with
+ * UVO_MEM_DEVICE to keep the frame in HBM).  The undistortion maps are cached per (K, dist, newK, size). */
+uvo_status uvo_get_image(uvo_ctx* c, const uint8_t* rgb, int w, int h, int stride, int mem, const double* K, const double* dist4,
+                         const double* newK, int desired_width, int clahe, int clip_limit, uint8_t* out, int out_mem,
+                         int* out_w, int* out_h);
 
 /* ---- per-stage device timing (HIP events on the context's stream) for bench.py ---- */
 uvo_status uvo_timing_enable(uvo_ctx* c, int on);

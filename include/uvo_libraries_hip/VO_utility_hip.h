@@ -21,6 +21,7 @@
 
 // ---- parameter globals (VOH:25-89), defined in VO_utility_hip.cpp ---------------------------------------------
 extern std::string FEATURE_DETECTOR;
+extern int    DESIRED_WIDTH;              extern bool CLAHE_CORRECTION;   extern int CLIP_LIMIT;      // VOH:41-44
 extern int    DISTANCE;
 extern int    ESSENTIAL_OUTLIER_METHOD;   extern double ESSENTIAL_MAX_ITERS, ESSENTIAL_CONFIDENCE, ESSENTIAL_THRESHOLD;
 extern int    HOMOGRAPHY_OUTLIER_METHOD;  extern double HOMOGRAPHY_MAX_ITERS, HOMOGRAPHY_CONFIDENCE, HOMOGRAPHY_THRESHOLD, HOMOGRAPHY_DISTANCE;
@@ -37,6 +38,8 @@ uvocv::Mat compute_projection_matrix(const uvocv::Mat& R, const uvocv::Mat& t, c
 double     compute_scale_factor(float distance, const uvocv::Mat& world_points);                                        // VOU:23-38
 uvocv::Mat convert_3Dpoints_camera(const uvocv::Mat& points_to_convert, const uvocv::Mat& R_to_from, const uvocv::Mat& t_to_from); // VOU:46-63
 uvocv::Mat convert_from_homogeneous_coords(const uvocv::Mat& points4d);                                                 // VOU:71-83
+uvocv::Mat get_image(const uvocv::Mat& current_img, const uvocv::Mat& cameraMatrix, const uvocv::Mat& distortionCoeff,
+                     const uvocv::Mat& newCamMatrix);                                                                  // VOU:337-379
 void detect_features(uvocv::Mat img, std::vector<uvocv::KeyPoint>& keypoints, uvocv::Mat& descriptors);                 // VOU:91-126
 void estimate_relative_pose(std::vector<uvocv::Point2f> keypoints1_conv, std::vector<uvocv::Point2f> keypoints2_conv,
                             uvocv::Mat cameraMatrix, uvocv::Mat& R_currCam_prevCam, uvocv::Mat& t_currCam_prevCam,

@@ -403,3 +403,46 @@ class MonoVO:
             self.close()
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------- get_image preprocessing
+def rgb2gray(rgb):
+    rgb = _c(rgb, np.uint8); h, w, _ = rgb.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_rgb2gray_u8(_p(rgb), w, h, w * 3, _p(out))
+    return out
+
+
+def resize_area_c3(rgb, dw, dh):
+    rgb = _c(rgb, np.uint8); h, w, _ = rgb.shape
+    out = np.empty((dh, dw, 3), np.uint8)
+    if lib().orc_resize_area_u8c3(_p(rgb), w, h, w * 3, _p(out), dw, dh) != 0:
+        raise ValueError("resize_area_c3: enlarging is outside the restatement")
+    return out
+
+
+def undistort(gray, K, dist4, newK):
+    gray = _c(gray, np.uint8); h, w = gray.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_undistort_u8(_p(gray), w, h, _p(_c(K, np.float64)), _p(_c(dist4, np.float64)), _p(_c(newK, np.float64)), _p(out))
+    return out
+
+
+def clahe(gray, clip_limit):
+    gray = _c(gray, np.uint8); h, w = gray.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_clahe_u8(_p(gray), w, h, C.c_double(clip_limit), _p(out))
+    return out
+
+
+def get_image(rgb, desired_width, K, dist4, newK, clahe_on=True, clip_limit=3):
+    rgb = _c(rgb, np.uint8); h, w, _ = rgb.shape
+    dh = int(h / (w / desired_width))
+    out = np.empty((dh, desired_width), np.uint8)
+    ow, oh = C.c_int(0), C.c_int(0)
+    rc = lib().orc_get_image(_p(rgb), w, h, w * 3, desired_width, _p(_c(K, np.float64)), _p(_c(dist4, np.float64)),
+                             _p(_c(newK, np.float64)), int(bool(clahe_on)), int(clip_limit), _p(out), C.byref(ow), C.byref(oh))
+    if rc != 0:
+        raise ValueError("get_image: enlarging is outside the restatement")
+    assert (ow.value, oh.value) == (desired_width, dh)
+    return out

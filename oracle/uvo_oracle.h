@@ -194,4 +194,15 @@ int       orc_mono_get(orc_mono* s, const char* what, void* out, int cap_bytes);
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- get_image preprocessing (o_preproc.c) ---- */
+void orc_rgb2gray_u8(const uint8_t* rgb, int w, int h, int stride, uint8_t* gray);
+int  orc_resize_area_u8c3(const uint8_t* src, int sw, int sh, int stride, uint8_t* dst, int dw, int dh);
+void orc_init_undistort_map(const double* A, const double* dist4, const double* Ar, int cols, int rows, int16_t* map1, uint16_t* map2);
+void orc_remap_bilinear_u8(const uint8_t* src, int sw, int sh, const int16_t* map1, const uint16_t* map2, uint8_t* dst, int dw, int dh);
+void orc_undistort_u8(const uint8_t* src, int w, int h, const double* K, const double* dist4, const double* newK, uint8_t* dst);
+void orc_clahe_u8(const uint8_t* src, int w, int h, double clip_limit, uint8_t* dst);
+int  orc_get_image(const uint8_t* rgb, int w, int h, int stride, int desired_width, const double* K, const double* dist4,
+                   const double* newK, int clahe_on, int clip_limit, uint8_t* out, int* out_w, int* out_h);
+
 #endif

@@ -95,3 +95,21 @@ def test_hip_reproduces_match_pnp_tri_fixtures(ctx):
     assert np.array_equal(_bits(p4), _bits(g["points4d"]))
     pts, idx = ctx.extract_3Dpoints(g["x1"], g["x2"], np.eye(3), np.zeros(3), g["R2"], g["t2"], g["K1"], g["K2"], p4)
     assert np.array_equal(idx, g["idx"]) and np.array_equal(_bits(pts), _bits(g["pts"]))
+
+
+def test_oracle_reproduces_preproc_fixture(oracle):
+    g = _load("preproc_96x160.npz")
+    dw = int(g["desired_width"][0]); dh = g["out"].shape[0]
+    assert np.array_equal(oracle.resize_area_c3(g["rgb"], dw, dh), g["small"])
+    assert np.array_equal(oracle.rgb2gray(g["small"]), g["gray"])
+    assert np.array_equal(oracle.undistort(g["gray"], g["K"], g["dist"], g["newK"]), g["undistorted"])
+    assert np.array_equal(oracle.clahe(g["undistorted"], float(g["clip_limit"][0])), g["out"])
+    assert np.array_equal(oracle.get_image(g["rgb"], dw, g["K"], g["dist"], g["newK"], True, int(g["clip_limit"][0])), g["out"])
+
+
+@pytest.mark.gpu
+def test_hip_reproduces_preproc_fixture(ctx):
+    g = _load("preproc_96x160.npz")
+    dw = int(g["desired_width"][0])
+    assert np.array_equal(ctx.get_image(g["rgb"], dw, g["K"], g["dist"], g["newK"], True, int(g["clip_limit"][0])), g["out"])
+    assert np.array_equal(ctx.get_image(g["rgb"], dw, g["K"], g["dist"], g["newK"], False, 0), g["undistorted"])

@@ -16,15 +16,15 @@ SHIM_DIR = os.path.join(ROOT, "ergo_uvo_amd", "shim")
 SHIM_LIB = os.path.join(ROOT, "ergo_uvo_amd", "lib", "libuvo_libraries_hip.so")
 DRIVER = os.path.join(ROOT, "tests", "cpp", "build", "shim_stereo_node")
 
-# VO_utility.h:96-117, minus ROS parameter readers, get_image / resize_camera_matrix and show_matches
+# VO_utility.h:96-117, minus ROS parameter readers, resize_camera_matrix (one-time setup) and show_matches
 REFERENCE_FUNCTIONS = [
     "compute_projection_matrix", "compute_scale_factor", "convert_3Dpoints_camera", "convert_from_homogeneous_coords",
-    "detect_features", "estimate_relative_pose", "extract_3Dpoints", "extract_3Dpoints_and_reprojection", "extract_inliers",
+    "detect_features", "get_image", "estimate_relative_pose", "extract_3Dpoints", "extract_3Dpoints_and_reprojection", "extract_inliers",
     "match_features", "recover_pose_homography", "reproject_errors", "select_desired_descriptors", "select_desired_keypoints",
     "select_estimation_method",
 ]
 REFERENCE_GLOBALS = [
-    "FEATURE_DETECTOR", "DISTANCE", "ESSENTIAL_OUTLIER_METHOD", "ESSENTIAL_MAX_ITERS", "ESSENTIAL_CONFIDENCE", "ESSENTIAL_THRESHOLD",
+    "FEATURE_DETECTOR", "DESIRED_WIDTH", "CLAHE_CORRECTION", "CLIP_LIMIT", "DISTANCE", "ESSENTIAL_OUTLIER_METHOD", "ESSENTIAL_MAX_ITERS", "ESSENTIAL_CONFIDENCE", "ESSENTIAL_THRESHOLD",
     "HOMOGRAPHY_OUTLIER_METHOD", "HOMOGRAPHY_MAX_ITERS", "HOMOGRAPHY_CONFIDENCE", "HOMOGRAPHY_THRESHOLD", "HOMOGRAPHY_DISTANCE",
     "VPF_THRESHOLD", "REPROJECTION_TOLERANCE", "LOWE_RATIO_THRESHOLD", "MIN_NUM_FEATURES", "MIN_NUM_3DPOINTS", "MIN_NUM_INLIERS",
     "ITERATIONS_COUNT", "REPROJECTION_ERROR_THRESHOLD", "CONFIDENCE", "USE_EXTRINSIC_GUESS", "PNP_METHOD_FLAG",
@@ -113,3 +113,29 @@ def test_stereo_node_loop_through_the_shim_matches_oracle(oracle, scene_small, t
         assert np.array_equal(rec["d"][k].view(np.uint64), d.view(np.uint64)), (k, rec["d"][k], d)
         nvalid += o.valid
     assert nvalid == len(seq) - 1
+
+
+@pytest.mark.gpu
+def test_get_image_through_the_shim_matches_oracle(oracle, tmp_path):
+    _build()
+    rng = np.random.default_rng(9)
+    H, W, DW = 180, 320, 240
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.clip((120 + 90 * np.sin(xx / 11.0) * np.cos(yy / 6.0))[..., None] + rng.normal(0, 10, (H, W, 3)), 0, 255).astype(np.uint8)
+    dh = int(H / (W / DW))
+    K = np.array([[200.0, 0, 121.0], [0, 205.0, 66.0], [0, 0, 1.0]])
+    newK = np.array([[190.0, 0, 120.0], [0, 195.0, 67.5], [0, 0, 1.0]])
+    dist = np.array([-0.25, 0.07, 0.001, -0.002])
+    inp, outp = tmp_path / "gi.bin", tmp_path / "go.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<5i", W, H, DW, 1, 8))
+        for m in (K, dist, newK):
+            f.write(np.ascontiguousarray(m, np.float64).tobytes())
+        f.write(img.tobytes())
+    res = subprocess.run([os.path.join(ROOT, "tests", "cpp", "build", "shim_get_image"), str(inp), str(outp)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    raw = open(outp, "rb").read()
+    ow, oh = struct.unpack("<2i", raw[:8])
+    assert (ow, oh) == (DW, dh)
+    got = np.frombuffer(raw[8:], np.uint8).reshape(oh, ow)
+    assert np.array_equal(got, oracle.get_image(img, DW, K, dist, newK, True, 8))
