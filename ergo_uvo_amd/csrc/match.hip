@@ -27,33 +27,6 @@
 
 namespace uvo {
 
-__device__ __forceinline__ float l2_distance64(const float* q /*registers*/, const float* t /*LDS, broadcast*/)
-{
-    float acc[16];
-#pragma unroll
-    for (int l = 0; l < 16; l++) acc[l] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 64; j += 16) {
-#pragma unroll
-        for (int l = 0; l < 16; l++) { float d = q[j + l] - t[j + l]; acc[l] = d * d + acc[l]; }
-    }
-    float v0 = ((acc[0] + acc[4]) + acc[8]) + acc[12];
-    float v1 = ((acc[1] + acc[5]) + acc[9]) + acc[13];
-    float v2 = ((acc[2] + acc[6]) + acc[10]) + acc[14];
-    float v3 = ((acc[3] + acc[7]) + acc[11]) + acc[15];
-    float d = (v0 + v2) + (v1 + v3);
-    return sqrtf(d);
-}
-
-// BatchDistInvoker K=2 insertion: enter iff d < worst; shift while prev > d
-__device__ __forceinline__ void top2_insert(float d, int j, float& d0, int& i0, float& d1, int& i1)
-{
-    if (d < d1) {
-        if (d0 > d) { d1 = d0; i1 = i0; d0 = d; i0 = j; }
-        else { d1 = d; i1 = j; }
-    }
-}
-
 static const int kMfmaChunk = 128;             // train rows per workgroup of k_match_mfma (7 index bits, see shortlist_key)
 static const int kRowStride = 68;              // floats per staged row: 64 + 4 so that the lanes' b128 reads spread over the LDS banks
 static const float kMarginRel = 6e-5f;

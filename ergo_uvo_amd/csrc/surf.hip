@@ -2,13 +2,14 @@
 // VO_utility.cpp:114-119 -> OpenCV xfeatures2d::SURF::detectAndCompute).
 //
 // Pipeline per image (both images of a stereo pair go through every launch together, blockIdx.z):
-//   integral_rows / integral_colsum / integral_colfinal : u8 -> s32 integral image (HBM-bound)
-//   hessian_nms<STEP, LDS>  : per octave, fused box-filter Hessian (5 layers) + 3x3x3 NMS +
-//                             quadratic interpolation; the integral tile is staged in LDS for
-//                             octaves 0-1, det planes never leave LDS; candidates are appended
-//                             with one atomic per keypoint
-//   rank_sort               : deterministic ordering (OpenCV's KeypointGreater) by counting rank
-//   descriptor64            : INTER_AREA window resample + Haar gradients + 4x4x4 sums
+//   integral_rows / integral_colsum / integral_colfinal : u8 -> s32 integral image (HBM-bound), row-major and
+//                             de-interleaved by (row & 3, col & 3) for the coarse octaves
+//   hessian_nms_c<O> (O = 0, 1) / hessian_nms_p<O> (O = 2, 3) : per octave, fused box-filter Hessian (5 layers) +
+//                             3x3x3 NMS + quadratic interpolation; box patterns compile-time; the integral tile is
+//                             staged in LDS (octaves 0-1) or read from the planes (2-3); det planes never leave LDS;
+//                             candidates are appended with one atomic per keypoint
+//   rank_partial / rank_scatter : deterministic ordering (OpenCV's KeypointGreater) by counting rank
+//   descriptor64_small / _big (+ _big_tabs, _big_finish) : INTER_AREA window resample + Haar gradients + 4x4x4 sums
 // All float arithmetic keeps OpenCV's operation order (int box sum * float weight accumulated in
 // double; no FMA contraction) so results are bit-identical to the CPU restatement.
 #include "uvo_ctx.h"
@@ -213,102 +214,9 @@ __device__ __forceinline__ void emit_keypoint(float N9[3][9], float val0, float 
     if (slot < out.cap) out.cand[im][slot] = kp;
 }
 
-// TW x TH plane samples per workgroup including a 1-sample halo; (TW-2) x (TH-2) NMS outputs.
-template <int STEP, bool USE_LDS, int TW, int TH>
-__global__ __launch_bounds__(256) void k_hessian_nms(ImgPair ip, int w, int h, OctavePat op, float thr, CandOut out)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, im = blockIdx.z;
-    const int sw = w + 1;
-    const int32_t* __restrict__ gsum = ip.sum[im];
-    float* sdet = reinterpret_cast<float*>(smem);                    // [5][TH][TW]
-    int32_t* stile = reinterpret_cast<int32_t*>(smem + sizeof(float) * 5 * TH * TW);
-
-    const int px0 = blockIdx.x * (TW - 2) - 1, py0 = blockIdx.y * (TH - 2) - 1;   // plane coords of region (0,0)
-    // integral tile: sum coords [sx0, sx0 + tw) x [sy0, sy0 + th)
-    const int sx0 = px0 * STEP + op.lo, sy0 = py0 * STEP + op.lo;
-    const int tw = (TW - 1) * STEP + (op.hi - op.lo) + 1;
-    const int th = (TH - 1) * STEP + (op.hi - op.lo) + 1;
-    if (USE_LDS) {
-        for (int idx = tid; idx < tw * th; idx += 256) {
-            int ty = idx / tw, tx = idx - ty * tw;
-            int gy = sy0 + ty, gx = sx0 + tx;
-            int v = 0;
-            if (gy >= 0 && gy <= h && gx >= 0 && gx <= w) v = gsum[(size_t)gy * sw + gx];
-            stile[idx] = v;
-        }
-        __syncthreads();
-    }
-
-    // ---- det for 5 layers over the TW x TH region ----
-#pragma unroll 1
-    for (int l = 0; l < 5; l++) {
-        const LayerPat& lp = op.L[l];
-        for (int idx = tid; idx < TW * TH; idx += 256) {
-            int ry = idx / TW, rx = idx - ry * TW;
-            int oi = py0 + ry - lp.margin, oj = px0 + rx - lp.margin;
-            float det = 0.f;
-            if (oi >= 0 && oi < lp.samples_i && oj >= 0 && oj < lp.samples_j) {
-                float dx, dy, dxy;
-                if (USE_LDS) {
-                    const int32_t* o = stile + (oi * STEP - sy0) * tw + (oj * STEP - sx0);
-                    haar_response(lp, [&](int yy, int xx) { return o[yy * tw + xx]; }, &dx, &dy, &dxy);
-                } else {
-                    const int32_t* o = gsum + (size_t)(oi * STEP) * sw + oj * STEP;
-                    haar_response(lp, [&](int yy, int xx) { return o[(size_t)yy * sw + xx]; }, &dx, &dy, &dxy);
-                }
-                det = dx * dy - 0.81f * dxy * dxy;
-            }
-            sdet[(l * TH + ry) * TW + rx] = det;
-        }
-    }
-    __syncthreads();
-
-    // ---- 3x3x3 non-maximum suppression + interpolation on the three middle layers ----
-#pragma unroll 1
-    for (int L = 1; L <= 3; L++) {
-        const LayerPat& lp = op.L[L];
-        if (lp.samples_i == 0 || op.L[L + 1].samples_i == 0) continue;
-        const int m = op.nms_margin[L - 1];
-        for (int idx = tid; idx < (TW - 2) * (TH - 2); idx += 256) {
-            int ry = idx / (TW - 2) + 1, rx = idx - (ry - 1) * (TW - 2) + 1;
-            int i = py0 + ry, j = px0 + rx;
-            if (i < m || i >= op.rows - m || j < m || j >= op.cols - m) continue;
-            const float* d2 = sdet + (L * TH + ry) * TW + rx;
-            float val0 = d2[0];
-            if (!(val0 > thr)) continue;
-            const float* d1 = d2 - TH * TW;
-            const float* d3 = d2 + TH * TW;
-            float N9[3][9] = {
-                { d1[-TW-1], d1[-TW], d1[-TW+1], d1[-1], d1[0], d1[1], d1[TW-1], d1[TW], d1[TW+1] },
-                { d2[-TW-1], d2[-TW], d2[-TW+1], d2[-1], d2[0], d2[1], d2[TW-1], d2[TW], d2[TW+1] },
-                { d3[-TW-1], d3[-TW], d3[-TW+1], d3[-1], d3[0], d3[1], d3[TW-1], d3[TW], d3[TW+1] } };
-            bool is_max = true;
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int b = 0; b < 9; b++)
-                    if (!(a == 1 && b == 4)) is_max = is_max && (val0 > N9[a][b]);
-            if (!is_max) continue;
-
-            float dx, dy, dxy;
-            {
-                int oi = i - lp.margin, oj = j - lp.margin;
-                if (USE_LDS) {
-                    const int32_t* o = stile + (oi * STEP - sy0) * tw + (oj * STEP - sx0);
-                    haar_response(lp, [&](int yy, int xx) { return o[yy * tw + xx]; }, &dx, &dy, &dxy);
-                } else {
-                    const int32_t* o = gsum + (size_t)(oi * STEP) * sw + oj * STEP;
-                    haar_response(lp, [&](int yy, int xx) { return o[(size_t)yy * sw + xx]; }, &dx, &dy, &dxy);
-                }
-            }
-            emit_keypoint<STEP>(N9, val0, dx + dy, i, j, lp.size, lp.size - op.L[L - 1].size, op.octave, w, h, im, out);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// Octaves 0 and 1: the same fused kernel with the box patterns, weights and every LDS offset
+// Octaves 0 and 1: one workgroup computes TW x TH plane samples (1-sample halo, (TW-2) x (TH-2) NMS outputs) of all five
+// layers from an integral tile in LDS, with the box patterns, weights and every LDS offset
 // resolved at compile time (sizes (9+6l)<<O are fixed by the octave), so one box corner is one
 // ds_read_b32 with an immediate offset and corners shared between the boxes of a filter are read
 // once (32 reads per sample instead of 40, no address arithmetic).  For STEP > 1 the integral tile
@@ -716,10 +624,8 @@ __device__ __forceinline__ void describe_tail(const DescArgs& a, int im, int k, 
 // One workgroup per keypoint.  PATCH = cv::resize(WIN, 21x21, INTER_AREA) with
 // WIN[i][j] = img(clamp(start_y - j), clamp(start_x + i)) is evaluated separably, exactly as
 // resizeArea_ does: buf[i][dx] = sum_j WIN[i][j]*alpha_j (lanes run along i = image x, coalesced),
-// then PATCH[dy][dx] = sum_i beta_i*buf[i][dx].  BIG selects the LDS budget: windows up to 128
-// samples (most keypoints) need 10.5 KB, the rare large ones up to 739 need 62 KB; each launch
-// skips the keypoints of the other class.
-template <bool BIG>
+// then PATCH[dy][dx] = sum_i beta_i*buf[i][dx].  Windows up to kSmallWin = 128 samples (10.5 KB of LDS); larger
+// ones are skipped here and handled by k_descriptor64_big.
 __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int h, int k, int im)
 {
     const int tid = threadIdx.x;
@@ -727,7 +633,7 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
     const float size = kp.size;
     const float s = size * 1.2f / 9.0f;
     const int win_size = (int)((20 + 1) * s);
-    if ((win_size > kSmallWin) != BIG) return;
+    if (win_size > kSmallWin) return;                  // large windows: k_descriptor64_big
     extern __shared__ __align__(16) unsigned char smem_desc[];
     float* buf = reinterpret_cast<float*>(smem_desc);                 // [21][win_size]
     __shared__ AreaTab tab[21];
@@ -811,7 +717,7 @@ __global__ __launch_bounds__(256) void k_descriptor64_small(DescArgs a, int w, i
 {
     const int k = blockIdx.x, im = blockIdx.y;
     if (k >= *a.n[im]) return;
-    describe_keypoint<false>(a, w, h, k, im);
+    describe_keypoint(a, w, h, k, im);
 }
 // Large windows (up to 739 samples: the keypoints of octaves 2 and 3).  One keypoint is 21 independent tasks, one per
 // destination column dx of the area resize: a task needs only the ~win/21 image rows of that column's taps, computes
@@ -1007,29 +913,6 @@ uvo_status surf_integral(Ctx* c, int nimg)
     hipLaunchKernelGGL(k_integral_colfinal, g, dim3(256), 0, c->stream, ip, w, h, c->d_colpart, nseg);
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
-}
-
-template <int STEP, bool USE_LDS, int TW, int TH>
-static hipError_t launch_hessian(Ctx* c, int nimg, const OctavePat& op, float thr)
-{
-    const int w = c->img_w, h = c->img_h;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride };
-    CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
-    size_t lds = sizeof(float) * 5 * TW * TH;
-    if (USE_LDS) {
-        int tw = (TW - 1) * STEP + (op.hi - op.lo) + 1, th = (TH - 1) * STEP + (op.hi - op.lo) + 1;
-        lds += sizeof(int32_t) * (size_t)tw * th;
-    }
-    dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
-    auto kern = k_hessian_nms<STEP, USE_LDS, TW, TH>;
-    static bool attr_set = false;
-    if (!attr_set && lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, c->stream, ip, w, h, op, thr, out);
-    return hipGetLastError();
 }
 
 template <int O, int TW, int TH, int NT>
