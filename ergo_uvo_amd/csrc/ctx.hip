@@ -12,9 +12,6 @@ using namespace uvo;
 
 struct uvo_ctx : public uvo::Ctx {};
 
-// fixed slots of Ctx::d_counts / h_counts
-enum { CN_T = 0, CN_G = 1, CN_NINL = 2, CN_NQA = 3, CN_NQB = 4, CN_MEFF = 5, CN_NL = 6, CN_NR = 7,
-       CN_CAND0 = 8, CN_CAND1 = 9, CN_M = 10, CN_TRAW = 11, CN_AS0 = 12, CN_AS1 = 13, CN_TOTAL = 16 };
 
 extern "C" void uvo_params_default_stereo(uvo_params* p)
 {   // uvo/config/stereo_VO_parameters.yaml:20-47 (keys absent from that file stay zero, as the globals do)
@@ -86,7 +83,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     }
     A(dalloc(&c->d_colpart, (size_t)2 * nseg * (max_w + 1)));
     A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_par, cap * 2)); A(dalloc(&c->d_big_patch, cap * 2 * 448)); A(hipMalloc(reinterpret_cast<void**>(&c->d_big_tabs), cap * 2 * 21 * 32));
-    A(dalloc(&c->d_mpart, nchunks * cap)); A(dalloc(&c->d_mscratch, (size_t)4)); A(dalloc(&c->d_knn_idx, cap * 2)); A(dalloc(&c->d_knn_dist, cap * 2));
+    A(dalloc(&c->d_mpart, nchunks * cap)); A(dalloc(&c->d_mscratch, nchunks + 4)); A(dalloc(&c->d_knn_idx, cap * 2)); A(dalloc(&c->d_knn_dist, cap * 2));
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
     A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_tmp_idx, cap));
     for (int i = 0; i < 2; i++) {
@@ -111,7 +108,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     c->det[0].n = c->d_counts + CN_NL; c->det[1].n = c->d_counts + CN_NR;
     c->d_nmatch = c->d_counts + CN_M;
     c->d_as_n = c->d_counts + CN_AS0;
-    c->d_big_n = c->d_counts + 14;
+    c->d_big_n = c->d_counts + CN_BIG0;
     make_desc_weights(c->h_DW);
     if (hipMemcpy(c->d_DW, c->h_DW, sizeof(float) * 400, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->d_rank, 0, sizeof(int) * cap * 2) != hipSuccess ||
@@ -404,28 +401,6 @@ extern "C" uvo_status uvo_rodrigues(const double* in, int n_in, double* out)
 }
 
 // ------------------------------------------------------------------------------------------ stereo step
-__global__ void k_ctl_gate_a(int* cn, int min_features)
-{   // VO:556: both images need >= MIN_NUM_FEATURES keypoints, else no stereo matching
-    int nL = cn[CN_NL], nR = cn[CN_NR];
-    cn[CN_NQA] = (nL >= min_features && nR >= min_features) ? nL : 0;
-}
-__global__ void k_ctl_gate_b(int* cn, int min_features, int cap, int* as_curr_n, const int* as_prev_n)
-{   // VO:567: results_match_curr.size() > MIN_NUM_FEATURES, else the "after stereo match" sets stay empty
-    int M = cn[CN_NQA] > 0 ? cn[CN_M] : 0;
-    if (cn[CN_NQA] == 0) cn[CN_M] = 0;
-    int meff = (M > min_features) ? min(M, cap) : 0;
-    cn[CN_MEFF] = meff;
-    *as_curr_n = meff;
-    cn[CN_NQB] = meff > 0 ? *as_prev_n : 0;           // triangular matching only runs inside that branch
-}
-__global__ void k_ctl_gate_c(int* cn, int min_features, int cap)
-{   // VO:626: results_match_prev_curr.size() > MIN_NUM_FEATURES
-    int T = cn[CN_NQB] > 0 ? cn[CN_TRAW] : 0;
-    if (cn[CN_NQB] == 0) cn[CN_TRAW] = 0;
-    cn[CN_T] = (T > min_features) ? min(T, cap) : 0;
-    cn[CN_G] = 0;
-}
-
 // VO:569-579: curr_{left,right}_{descr,keypoints}_after_stereo_match by the stereo matches' indices
 __global__ __launch_bounds__(256) void k_gather_after_stereo(const uvo_dmatch* m, const int* cn, const uvo_keypoint* kL, const uvo_keypoint* kR,
                                                              const float* dL, uvo_keypoint* okL, uvo_keypoint* okR, float* odL)
@@ -580,18 +555,17 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
 #define LANE_TRY(expr) do { uvo_status st_ = (expr); if (st_ != UVO_OK) { if (L != c) c->err = L->err; return st_; } } while (0)
     LANE_TRY(surf_upload(L, 0, left, w, h, stride, mem));
     LANE_TRY(surf_upload(L, 1, right, w, h, stride, mem));
-    LANE_TRY(surf_detect(L, 2));                                                           // VO:548-549
+    LANE_TRY(surf_detect(L, 2, p.MIN_NUM_FEATURES));                                       // VO:548-549, and the VO:556 gate
     const int cap = c->cap, curr = L->as_w, prev = c->prev_buf;
     int* cn = L->d_counts;
     const float ratio = (float)p.LOWE_RATIO_THRESHOLD;
     hipStream_t st = L->stream;
     // stereo matching L -> R (VO:558), gated on device by VO:556
-    hipLaunchKernelGGL(k_ctl_gate_a, dim3(1), dim3(1), 0, st, cn, p.MIN_NUM_FEATURES);
     LANE_TRY(match_knn2(L, L->det[0].desc, cn + CN_NQA, cap, L->det[1].desc, cn + CN_NR, cap));
-    LANE_TRY(match_ratio_compact(L, cn + CN_NQA, cap, ratio, L->d_matches[0], cn + CN_M, cap));
     // from here on the previous pair's "after stereo match" set (another lane's buffers) is needed
     if (!c->prev_sync && P != L) UVO_HIP_TRY(c, hipStreamWaitEvent(st, P->evAS, 0));
-    hipLaunchKernelGGL(k_ctl_gate_b, dim3(1), dim3(1), 0, st, cn, p.MIN_NUM_FEATURES, cap, L->d_as_n + curr, P->d_as_n + prev);
+    const GateArgs gate_b = { 1, cn, p.MIN_NUM_FEATURES, cap, L->d_as_n + curr, P->d_as_n + prev };       // VO:567
+    LANE_TRY(match_ratio_compact(L, cn + CN_NQA, cap, ratio, L->d_matches[0], cn + CN_M, cap, &gate_b));
     {
         StageTimer t(L, ST_GATHER);
         hipLaunchKernelGGL(k_gather_after_stereo, dim3((cap + 15) / 16), dim3(256), 0, st, L->d_matches[0], cn,
@@ -600,8 +574,8 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     UVO_HIP_TRY(c, hipEventRecord(L->evAS, st));
     // triangular matching prev-left-after-stereo -> curr-left (VO:592)
     LANE_TRY(match_knn2(L, P->d_as_descL[prev], cn + CN_NQB, cap, L->det[0].desc, cn + CN_NL, cap));
-    LANE_TRY(match_ratio_compact(L, cn + CN_NQB, cap, ratio, L->d_matches[1], cn + CN_TRAW, cap));
-    hipLaunchKernelGGL(k_ctl_gate_c, dim3(1), dim3(1), 0, st, cn, p.MIN_NUM_FEATURES, cap);
+    const GateArgs gate_c = { 2, cn, p.MIN_NUM_FEATURES, cap, nullptr, nullptr };                           // VO:626
+    LANE_TRY(match_ratio_compact(L, cn + CN_NQB, cap, ratio, L->d_matches[1], cn + CN_TRAW, cap, &gate_c));
     {
         StageTimer t(L, ST_GATHER);
         hipLaunchKernelGGL(k_gather_triangular, dim3((cap + 255) / 256), dim3(256), 0, st, L->d_matches[1], cn,

@@ -94,10 +94,10 @@ __device__ __forceinline__ void mfma_step(const float* areg, const float* breg, 
     __builtin_amdgcn_wave_barrier();
 }
 
-// part: [chunk][cap] (k0, k1, k2, k3): the four smallest shortlist keys; tnmax: max |t|^2 (uint bits, zeroed by the host)
+// part: [chunk][cap] (k0, k1, k2, k3): the four smallest shortlist keys; chunk_tnmax[chunk]: max |t|^2 of the chunk's rows
 __global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ dq, const int* nq_p, int nq_imm,
                                                     const float* __restrict__ dt, const int* nt_p, int nt_imm,
-                                                    int cap, float4* part, unsigned* tnmax)
+                                                    int cap, float4* part, float* chunk_tnmax)
 {
     const int nq = nq_p ? *nq_p : nq_imm, nt = nt_p ? *nt_p : nt_imm;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ dq
     if (h == 0 && q < nq) part[(size_t)blockIdx.y * cap + q] = make_float4(k0, k1, k2, k3);
     if (blockIdx.x == 0 && wave == 0) {                     // one wave per chunk reports the largest |t|^2
         for (int o = 16; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-        if (lane == 0) atomicMax(tnmax, __float_as_uint(wmax));         // >= 0: uint order == float order
+        if (lane == 0) chunk_tnmax[blockIdx.y] = wmax;
     }
 }
 
@@ -183,7 +183,7 @@ __device__ __forceinline__ float group_distance(const float4 qv, const float* __
 
 __global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__ dq, const int* nq_p, int nq_imm,
                                                       const float* __restrict__ dt, const int* nt_p, int nt_imm,
-                                                      int cap, const float4* part, const unsigned* tnmax_p,
+                                                      int cap, const float4* part, const float* chunk_tnmax,
                                                       int* knn_idx, float* knn_dist)
 {
     const int nq = nq_p ? *nq_p : nq_imm, nt = nt_p ? *nt_p : nt_imm;
@@ -195,16 +195,16 @@ __global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__
     const float4 qv = reinterpret_cast<const float4*>(dq + (size_t)qq * 64)[sub];
     float qn = qv.x*qv.x + qv.y*qv.y + qv.z*qv.z + qv.w*qv.w;
     qn += __shfl_xor(qn, 8); qn += __shfl_xor(qn, 4); qn += __shfl_xor(qn, 2); qn += __shfl_xor(qn, 1);
-    const float tnmax = __uint_as_float(*tnmax_p);
     const int nchunks = (nt + kMfmaChunk - 1) / kMfmaChunk;
     // pass 1: two smallest S' over all candidates of this query (lanes stride the chunks)
-    float b0 = kBig, b1 = kBig;
+    float b0 = kBig, b1 = kBig, tnmax = 0.f;
     for (int c = sub; c < nchunks; c += 16) {
         float4 p = part[(size_t)c * cap + qq];
         merge_min2(b0, b1, p.x, p.y);
+        tnmax = fmaxf(tnmax, chunk_tnmax[c]);
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) merge_min2(b0, b1, __shfl_xor(b0, o), __shfl_xor(b1, o));
+    for (int o = 8; o > 0; o >>= 1) { merge_min2(b0, b1, __shfl_xor(b0, o), __shfl_xor(b1, o)); tnmax = fmaxf(tnmax, __shfl_xor(tnmax, o)); }
     const float lim = b1 + 2.f * kMarginRel * (qn + tnmax);
     // pass 2: every row that can be among the exact two nearest, evaluated by the whole group
     float d0 = FLT_MAX, d1 = FLT_MAX; int i0 = -1, i1 = -1;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__
 
 // ratio test + ordered compaction, one workgroup of 1024 threads
 __global__ __launch_bounds__(1024) void k_match_compact(const int* knn_idx, const float* knn_dist, const int* nq_p, int nq_imm,
-                                                        float ratio, uvo_dmatch* out, int* nout, int out_cap)
+                                                        float ratio, uvo_dmatch* out, int* nout, int out_cap, GateArgs g)
 {
     const int nq = nq_p ? *nq_p : nq_imm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -270,17 +270,32 @@ __global__ __launch_bounds__(1024) void k_match_compact(const int* knn_idx, cons
         if (tid == 0) { int t = 0; for (int k = 0; k < 16; k++) t += wtot[k]; s_base += t; }
         __syncthreads();
     }
-    if (tid == 0) *nout = s_base;      // may exceed out_cap: the host reports UVO_CAPACITY
+    if (tid == 0) {
+        *nout = s_base;                // may exceed out_cap: the host reports UVO_CAPACITY
+        int* cn = g.cn;
+        if (g.mode == 1) {             // VO:567: results_match_curr.size() > MIN_NUM_FEATURES, else the "after stereo match" sets stay empty
+            int M = cn[CN_NQA] > 0 ? cn[CN_M] : 0;
+            if (cn[CN_NQA] == 0) cn[CN_M] = 0;
+            int meff = (M > g.min_features) ? min(M, g.cap) : 0;
+            cn[CN_MEFF] = meff;
+            *g.as_curr_n = meff;
+            cn[CN_NQB] = meff > 0 ? *g.as_prev_n : 0;      // triangular matching only runs inside that branch
+        } else if (g.mode == 2) {      // VO:626: results_match_prev_curr.size() > MIN_NUM_FEATURES
+            int T = cn[CN_NQB] > 0 ? cn[CN_TRAW] : 0;
+            if (cn[CN_NQB] == 0) cn[CN_TRAW] = 0;
+            cn[CN_T] = (T > g.min_features) ? min(T, g.cap) : 0;
+            cn[CN_G] = 0;
+        }
+    }
 }
 
 uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, const float* d_t, const int* d_nt, int nt_max)
 {
     if (nq_max <= 0 || nt_max <= 0) return UVO_OK;
     if (nq_max > c->cap || nt_max > c->cap) { c->err = "match: descriptor count exceeds the context's max_kpts"; return UVO_CAPACITY; }
-    unsigned* tnmax = reinterpret_cast<unsigned*>(c->d_mscratch);
+    float* tnmax = c->d_mscratch;                    // [chunk] max |t|^2
     {
         StageTimer t(c, ST_MATCH);
-        UVO_HIP_TRY(c, hipMemsetAsync(tnmax, 0, sizeof(unsigned), c->stream));
         dim3 grid((nq_max + 127) / 128, (nt_max + kMfmaChunk - 1) / kMfmaChunk);
         hipLaunchKernelGGL(k_match_mfma, grid, dim3(256), 0, c->stream, d_q, d_nq, nq_max, d_t, d_nt, nt_max, c->cap, c->d_mpart, tnmax);
         UVO_HIP_TRY(c, hipGetLastError());
@@ -294,11 +309,14 @@ uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, con
     return UVO_OK;
 }
 
-uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio, uvo_dmatch* d_out, int* d_nout, int out_cap)
+uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio, uvo_dmatch* d_out, int* d_nout, int out_cap,
+                               const GateArgs* gate)
 {
     StageTimer t(c, ST_MATCH_MERGE);
+    GateArgs g = { 0, nullptr, 0, 0, nullptr, nullptr };
+    if (gate) g = *gate;
     hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(1024), 0, c->stream, c->d_knn_idx, c->d_knn_dist, d_nq, nq_max, ratio,
-                       d_out, d_nout, out_cap);
+                       d_out, d_nout, out_cap, g);
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }

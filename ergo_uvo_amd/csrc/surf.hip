@@ -23,7 +23,7 @@ namespace uvo {
 // planes[im]: the integral image de-interleaved by (row & 3, column & 3): 16 planes of ph x pw, plane (ry, rx) holds
 // S[4i + ry][4j + rx] at [i][j].  The step-4 / step-8 sample walks of octaves 2 and 3 become unit / two-element
 // strides in them (coalesced), where the row-major image gives one useful word per 16 or 32 bytes.
-struct ImgPair { const uint8_t* img[2]; int32_t* sum[2]; int32_t* planes[2]; int pw, pstride; };
+struct ImgPair { const uint8_t* img[2]; int32_t* sum[2]; int32_t* planes[2]; int pw, pstride; int* cand_n; int* big_n; };
 static const int kSegRows = 32;
 
 __global__ __launch_bounds__(256) void k_integral_rows(ImgPair ip, int w, int h)
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void k_integral_rows(ImgPair ip, int w, int h)
     for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) { run += src[x]; dst[x + 1] = run; } }
     if (tid == 0) dst[0] = 0;
     if (y == 0) { int32_t* r0 = ip.sum[im]; for (int x = tid; x < sw; x += 256) r0[x] = 0; }
+    if (y == 0 && tid == 0) { ip.cand_n[im] = 0; ip.big_n[im] = 0; }       // the frame's candidate / large-window counters start at zero
 }
 
 __global__ __launch_bounds__(256) void k_integral_colsum(ImgPair ip, int w, int h, int32_t* part, int nseg)
@@ -504,7 +505,7 @@ __device__ __forceinline__ SortKey make_sort_key(const uvo_keypoint& kp)
 }
 
 struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* out[2]; int* out_n[2]; int* rank; int cap;
-                  int4* big_par; int* big_n; };
+                  int4* big_par; int* big_n; int* gate_nqa; int gate_min_features; };
 static const int kSmallWin = 128;       // descriptor windows up to this size use the small-LDS kernel
 static const int kSortChunk = 128;     // compared-against keypoints per workgroup: small, so that ~600 workgroups share the work
 
@@ -554,6 +555,10 @@ __global__ __launch_bounds__(256) void k_rank_scatter(SortArgs a)
         }
     }
     if (me == 0) *a.out_n[im] = n;
+    if (me == 0 && im == 0 && a.gate_nqa) {          // VO:556: both images need >= MIN_NUM_FEATURES keypoints, else no stereo matching
+        const int nL = n, nR = min(a.cand_n[1], a.cap);
+        *a.gate_nqa = (nL >= a.gate_min_features && nR >= a.gate_min_features) ? nL : 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -904,7 +909,7 @@ uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int 
 uvo_status surf_integral(Ctx* c, int nimg)
 {
     const int w = c->img_w, h = c->img_h, sw = w + 1;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride };
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n };
     int nseg = (h + kSegRows - 1) / kSegRows;
     StageTimer t(c, ST_INTEGRAL);
     hipLaunchKernelGGL(k_integral_rows, dim3(h, 1, nimg), dim3(256), 0, c->stream, ip, w, h);
@@ -919,7 +924,7 @@ template <int O, int TW, int TH, int NT>
 static hipError_t launch_hessian_p(Ctx* c, int nimg, const OctavePat& op, float thr)
 {
     const int w = c->img_w, h = c->img_h;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride };
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n };
     CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
     dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
     hipLaunchKernelGGL((k_hessian_nms_p<O, TW, TH, NT>), grid, dim3(NT), 0, c->stream, ip, w, h, op, thr, out);
@@ -934,7 +939,7 @@ static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float 
     constexpr int TWs = (TW - 1) * STEP + (OC::HI - OC::LO) + 1, THs = (TH - 1) * STEP + (OC::HI - OC::LO) + 1;
     constexpr int PW = (TWs + STEP - 1) / STEP;
     const int w = c->img_w, h = c->img_h;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride };
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n };
     CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
     const size_t lds = sizeof(float) * 5 * TW * TH + sizeof(int32_t) * (size_t)THs * STEP * PW;
     dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
@@ -949,7 +954,7 @@ static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float 
     return hipGetLastError();
 }
 
-uvo_status surf_detect(Ctx* c, int nimg)
+uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
 {
     const int w = c->img_w, h = c->img_h;
     if (c->p.SURF_EXTENDED || !c->p.SURF_UPRIGHT) {
@@ -961,8 +966,6 @@ uvo_status surf_detect(Ctx* c, int nimg)
         return UVO_INVALID_ARG;
     }
     UVO_TRY(surf_integral(c, nimg));
-    UVO_HIP_TRY(c, hipMemsetAsync(c->d_cand_n, 0, sizeof(int) * 2, c->stream));
-    UVO_HIP_TRY(c, hipMemsetAsync(c->d_big_n, 0, sizeof(int) * 2, c->stream));
     const float thr = (float)c->p.SURF_MIN_HESSIAN;
     {
         for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER; o++) {
@@ -980,7 +983,8 @@ uvo_status surf_detect(Ctx* c, int nimg)
     {
         StageTimer t(c, ST_SORT);
         SortArgs sa = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, { c->det[0].kps, c->det[1].kps },
-                        { c->det[0].n, c->det[1].n }, c->d_rank, c->cap, c->d_big_par, c->d_big_n };
+                        { c->det[0].n, c->det[1].n }, c->d_rank, c->cap, c->d_big_par, c->d_big_n,
+                        gate_min_features >= 0 && nimg == 2 ? c->d_counts + CN_NQA : nullptr, gate_min_features };
         dim3 g((c->cap + 255) / 256, (c->cap + kSortChunk - 1) / kSortChunk, nimg);
         hipLaunchKernelGGL(k_rank_partial, g, dim3(256), 0, c->stream, sa);
         hipLaunchKernelGGL(k_rank_scatter, dim3((c->cap + 255) / 256, nimg), dim3(256), 0, c->stream, sa);

@@ -32,6 +32,14 @@ static const char* const kStageNames[ST_COUNT] = {
     "triangulate", "extract3d", "pnp_epnp5", "pnp_score", "pnp_refit"
 };
 
+// fixed slots of Ctx::d_counts / h_counts
+enum { CN_T = 0, CN_G = 1, CN_NINL = 2, CN_NQA = 3, CN_NQB = 4, CN_MEFF = 5, CN_NL = 6, CN_NR = 7,
+       CN_CAND0 = 8, CN_CAND1 = 9, CN_M = 10, CN_TRAW = 11, CN_AS0 = 12, CN_AS1 = 13, CN_BIG0 = 14, CN_BIG1 = 15, CN_TOTAL = 16 };
+// The gate ladder of the stereo loop, evaluated on the device by the last thread of the kernel that produces the count it
+// tests (no launches of their own): mode 1 = VO:567 after the stereo matcher's compaction, mode 2 = VO:626 after the
+// triangular matcher's.
+struct GateArgs { int mode; int* cn; int min_features, cap; int* as_curr_n; const int* as_prev_n; };
+
 static const int kMaxHyp = 2048;      // RANSAC hypotheses evaluated per call (>= ITERATIONS_COUNT)
 
 struct DetectSet {                    // one image's detector outputs (device)
@@ -65,7 +73,7 @@ struct Ctx {
 
     // ---- matcher ----
     float4* d_mpart = nullptr;                   // shortlist per (train chunk, query): (s0, i0, s1, i1)
-    float* d_mscratch = nullptr;                 // [0] = max |t|^2 of the train set (uint bits)
+    float* d_mscratch = nullptr;                 // [train chunk] max |t|^2 of the chunk
     int* d_knn_idx = nullptr;  float* d_knn_dist = nullptr;   // [cap][2]
     float* d_tmp_desc[2] = {nullptr, nullptr};   // staging for the standalone match API
     uvo_dmatch* d_matches[2] = {nullptr, nullptr};            // [0] stereo (L-R), [1] triangular (prev-curr)
@@ -172,11 +180,13 @@ struct StageTimer {
 // surf.hip
 uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int stride, int mem);
 uvo_status surf_integral(Ctx* c, int nimg);
-uvo_status surf_detect(Ctx* c, int nimg);          // integral -> ... -> sorted kps + descriptors in c->det[]
+uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features = -1);   // integral -> ... -> sorted kps + descriptors in c->det[];
+                                                                        // gate_min_features >= 0: also evaluate VO:556 into d_counts[CN_NQA]
 uvo_status surf_hessian_layer_debug(Ctx* c, int octave, int layer, float* det, float* trace);
 // match.hip
 uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, const float* d_t, const int* d_nt, int nt_max);
-uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio, uvo_dmatch* d_out, int* d_nout, int out_cap);
+uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio, uvo_dmatch* d_out, int* d_nout, int out_cap,
+                               const GateArgs* gate = nullptr);
 // pose.hip
 uvo_status pose_triangulate(Ctx* c, const double* P1, const double* P2, const int* d_n, int n_max);
 uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, const double* R2, const double* t2,
