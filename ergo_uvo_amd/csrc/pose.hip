@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256) void k_pnp_refit(PnpBatch b)
     double* ws = jb.ws; const int cap = b.cap; double* pose = jb.pose;
     const double fx = b.fx, fy = b.fy, cx = b.cx, cy = b.cy;
     __shared__ double small[EPNP_SMALL];
-    __shared__ double stage_buf[Epnp<BlockPolicy>::kStageDoubles];
+    extern __shared__ __align__(16) unsigned char refit_smem[];
+    double* stage_buf = reinterpret_cast<double*>(refit_smem);       // Epnp<BlockPolicy>::kStageDoubles doubles (dynamic: > 64 KB)
     const int n = jb.countsB[0];
     using P = BlockPolicy;
     Epnp<P> e;
@@ -492,7 +493,10 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
         b2.n = nb2;
         StageTimer t(m, ST_PNP_REFIT, st);
         hipLaunchKernelGGL(k_pnp_mask, dim3(nb2), dim3(1024), 0, st, b2);
-        hipLaunchKernelGGL(k_pnp_refit, dim3(nb2), dim3(256), 0, st, b2);
+        const size_t refit_lds = sizeof(double) * Epnp<BlockPolicy>::kStageDoubles;
+        static std::once_flag refit_once;
+        std::call_once(refit_once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_refit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)refit_lds); });
+        hipLaunchKernelGGL(k_pnp_refit, dim3(nb2), dim3(256), refit_lds, st, b2);
         UVO_HIP_TRY(m, hipGetLastError());
     }
     for (int s = 0; s < nb2; s++) {

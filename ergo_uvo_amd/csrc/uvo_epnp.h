@@ -23,6 +23,15 @@ struct GroupPolicy {
     __device__ static __forceinline__ int nth() { return 8; }
     __device__ static __forceinline__ void sync() { __syncthreads(); }
 };
+// One wave of a workgroup working alone on stride-1 arrays (lanes exchange data through LDS in program order, so a
+// compiler-level barrier is all a "sync" needs): the 12 x 12 Jacobi sweeps of the block-cooperative refit.
+struct WavePolicy {
+    using Arr = SArr<1>;
+    static constexpr bool kStaged = false;
+    __device__ static __forceinline__ int tid() { return threadIdx.x & 63; }
+    __device__ static __forceinline__ int nth() { return 64; }
+    __device__ static __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+};
 // BlockPolicy: one problem per workgroup, plain (stride-1) arrays.
 struct BlockPolicy {
     using Arr = SArr<1>;
@@ -46,6 +55,32 @@ __device__ __forceinline__ double seq_sum(int n, F f)
         for (int q = 0; q < 8; q++) t[q] = f(i + q);
 #pragma unroll
         for (int q = 0; q < 8; q++) acc += t[q];
+    }
+    for (; i < n; i++) acc += f(i);
+    return acc;
+}
+
+// acc = ((acc + f(0)) + f(1)) + ... + f(n-1) with the operands fetched sixteen at a time, one batch ahead of the
+// additions, so that the LDS latency of batch k+1 hides behind the (dependent) additions of batch k.
+template <class F>
+__device__ __forceinline__ double seq_sum_pipelined(double acc, int n, F f)
+{
+    double cur[16], nxt[16];
+    int i = 0;
+    if (n >= 16) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) cur[q] = f(q);
+        for (; i + 32 <= n; i += 16) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) nxt[q] = f(i + 16 + q);
+#pragma unroll
+            for (int q = 0; q < 16; q++) acc += cur[q];
+#pragma unroll
+            for (int q = 0; q < 16; q++) cur[q] = nxt[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc += cur[q];
+        i += 16;
     }
     for (; i < n; i++) acc += f(i);
     return acc;
@@ -259,7 +294,7 @@ struct Epnp {
     double* stage = nullptr;                  // BlockPolicy: LDS staging buffer of kStageDoubles
     long long* clk = nullptr;                 // diagnostic phase stamps (100 MHz); null = off
 #define EP_STAMP(i) do { if (clk && P::tid() == 0) clk[i] = wall_clock64(); } while (0)
-    static constexpr int kStageDoubles = 5120;
+    static constexpr int kStageDoubles = 16384;          // 128 KB: few, large chunks (each costs a barrier and a memory round trip)
 
     // E independent sequential sums out[e] = (((0 + term(e,0)) + term(e,1)) + ...) over i < n.
     // Group policy: chain e runs on lane e (mod 8).  Block policy: all threads evaluate the terms of a
@@ -273,29 +308,44 @@ struct Epnp {
             for (int ch = P::tid(); ch < E; ch += P::nth()) store(ch, seq_sum(n_terms, [&](int i) { return term(ch, i); }));
             P::sync();
         } else {
-            int CH = (kStageDoubles / E - 1) & ~7;
+            // two half-size staging buffers: while the lanes of wave 0 add chunk c in order, the other waves evaluate the
+            // terms of chunk c + 1 (one barrier per chunk)
+            int CH = (kStageDoubles / 2 / E - 1) & ~7;
             if (CH > 512) CH = 512;
             const int CHS = CH + 1;
-            const int tid = P::tid();
+            const int tid = P::tid(), nth = P::nth();
+            const int ft = tid - 64, fnth = nth - 64;          // fill threads: waves 1.. (all threads for the first chunk)
             double acc = 0;
-            for (int base = 0; base < n_terms; base += CH) {
+            auto fill = [&](double* buf, int base, int t0, int tn) {
                 const int cnt = n_terms - base < CH ? n_terms - base : CH;
-                for (int idx = tid; idx < E * cnt; idx += P::nth()) {
-                    int ch = idx / cnt, i = idx - ch * cnt;
-                    stage[ch * CHS + i] = term(ch, base + i);
-                }
-                P::sync();
-                if (tid < E) {
-                    const double* row = stage + tid * CHS;
-                    int i = 0;
-                    for (; i + 8 <= cnt; i += 8) {
-                        double t[8];
+                const int total = E * cnt;
+                const float inv_cnt = 1.0f / cnt;                  // idx / cnt by multiplication: exact for idx < 2^20
+                for (int idx0 = t0; idx0 < total; idx0 += 16 * tn) {   // sixteen independent terms in flight per thread
+                    double t[16]; int off[16];
 #pragma unroll
-                        for (int q = 0; q < 8; q++) t[q] = row[i + q];
-#pragma unroll
-                        for (int q = 0; q < 8; q++) acc += t[q];
+                    for (int q = 0; q < 16; q++) {
+                        const int idx = idx0 + q * tn;
+                        int ch = (int)((idx + 0.5f) * inv_cnt);
+                        if (ch > E - 1) ch = E - 1;
+                        const int i = idx - ch * cnt;
+                        off[q] = idx < total ? ch * CHS + i : -1;
+                        t[q] = idx < total ? term(ch, base + i) : 0.0;
                     }
-                    for (; i < cnt; i++) acc += row[i];
+#pragma unroll
+                    for (int q = 0; q < 16; q++) if (off[q] >= 0) buf[off[q]] = t[q];
+                }
+            };
+            double* buf0 = stage; double* buf1 = stage + kStageDoubles / 2;
+            fill(buf0, 0, tid, nth);
+            P::sync();
+            int par = 0;
+            for (int base = 0; base < n_terms; base += CH, par ^= 1) {
+                double* cur = par ? buf1 : buf0; double* nxt = par ? buf0 : buf1;
+                const int cnt = n_terms - base < CH ? n_terms - base : CH;
+                if (tid >= 64) { if (base + CH < n_terms) fill(nxt, base + CH, ft, fnth); }
+                else if (tid < E) {
+                    const double* row = cur + tid * CHS;
+                    acc = seq_sum_pipelined(acc, cnt, [&](int i) { return row[i]; });
                 }
                 P::sync();
             }
@@ -373,9 +423,17 @@ struct Epnp {
         };
         // mulTransposed (MulTransposedR): upper triangle, each entry a sequential sum over the 2n rows of M
         if (!P::kStaged) {
-            multi_sum(78, 2*n,
-                      [&](int e, int k) { int i, j; entry(e, &i, &j); return Mval(k, i) * Mval(k, j); },
-                      [&](int e, double s0) { int i, j; entry(e, &i, &j); mtm[i*12 + j] = s0; mtm[j*12 + i] = s0; });
+            // M (2n x 12) once into the still unused per-branch blocks, then lane l owns entries l, l + nth, ...
+            Arr M = s + EP_BR;
+            const int rows = 2*n;                                 // <= 3*EPB_SIZE/12 = 35 rows: the 5-point hypotheses
+            for (int idx = P::tid(); idx < rows*12; idx += P::nth()) { int k = idx / 12; M[idx] = Mval(k, idx - 12*k); }
+            P::sync();
+            for (int e = P::tid(); e < 78; e += P::nth()) {
+                int i, j; entry(e, &i, &j);
+                const double s0 = seq_sum(rows, [&](int k) { return M[k*12 + i] * M[k*12 + j]; });
+                mtm[i*12 + j] = s0; mtm[j*12 + i] = s0;
+            }
+            P::sync();
         } else {
             // rows of M (fill_M) are produced chunk-wise into LDS by all threads; lane e < 78 owns entry (i,j)
             // and walks the rows in order
@@ -400,15 +458,7 @@ struct Epnp {
                 if (tid < 78) {
                     const double* ri = stage + ei; const double* rj = stage + ej;
                     const int rows = 2*cnt;
-                    int k = 0;
-                    for (; k + 8 <= rows; k += 8) {
-                        double t[8];
-#pragma unroll
-                        for (int q = 0; q < 8; q++) t[q] = ri[(k + q)*12] * rj[(k + q)*12];
-#pragma unroll
-                        for (int q = 0; q < 8; q++) acc += t[q];
-                    }
-                    for (; k < rows; k++) acc += ri[k*12] * rj[k*12];
+                    acc = seq_sum_pipelined(acc, rows, [&](int k) { return ri[k*12] * rj[k*12]; });
                 }
                 P::sync();
             }
@@ -555,7 +605,10 @@ struct Epnp {
         EP_STAMP(3);
         Arr mtm = s + EP_MTM, L = s + EP_L, rho = s + EP_RHO, cws = s + EP_CWS, pw0 = s + EP_PW0;
         // cvSVD(MtM, D, Ut, 0, MODIFY_A | U_T): MtM is symmetric so At = MtM^T is MtM itself; rows -> U^T
-        jacobi_svd_u_levels<P, 12, 12>(mtm, s + EP_D, s + EP_WT, s + EP_FLAG);
+        if constexpr (P::kStaged) {                   // block policy: 21 levels x ~8 sweeps of workgroup barriers cost more than they buy
+            if (P::tid() < 64) jacobi_svd_u_levels<WavePolicy, 12, 12>(mtm, s + EP_D, s + EP_WT, s + EP_FLAG);
+            P::sync();
+        } else jacobi_svd_u_levels<P, 12, 12>(mtm, s + EP_D, s + EP_WT, s + EP_FLAG);
         const int tid = P::tid();
         EP_STAMP(4);
         if (tid == 0) {
