@@ -250,6 +250,43 @@ def test_pipelined_submit_collect_equals_step(ctx, scene_small):
     ctx.stereo_set_depth(2)
 
 
+def test_failure_paths_through_the_pipeline(ctx, oracle, scene_small):
+    """Frames without features in the middle of a sequence: the gate ladder (VO:556/567/626/634/665), the state kept on
+    failure and the empty "after stereo match" sets handed to the next pair must behave as in the reference's loop --
+    synchronously, with several pairs in flight, and in the oracle."""
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    ctx.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=1500))
+    blank = (np.full_like(scene_small[0][0], 90), np.full_like(scene_small[0][1], 90))
+    half = (scene_small[1][0], blank[1])                      # features on the left only: VO:556 fails on the right count
+    seq = [scene_small[0], scene_small[1], blank, scene_small[2], scene_small[1], half, scene_small[0], scene_small[1], scene_small[2]]
+
+    def fields(r):
+        return (r.valid, r.initialized, r.n_left, r.n_right, r.n_stereo_matches, r.n_tri_matches, r.n_good3d, r.n_inliers,
+                tuple(r.rvec), tuple(r.tvec), tuple(r.t_prev_curr), tuple(r.velocity))
+
+    ovo = oracle.StereoVO(oracle.stereo_params(1500), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    want = [fields(ovo.step(L, R, 0.05)) for L, R in seq]
+    assert [w[0] for w in want] == [0, 1, 0, 0, 1, 0, 0, 1, 1]       # init, ok, blank, no prev set, ok, half-blank, no prev set, ok, ok
+    ctx.stereo_set_depth(1)
+    ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    sync = [fields(ctx.stereo_step(L, R, 0.05)) for L, R in seq]
+    assert sync == want
+    for depth in (2, 4):
+        ctx.stereo_set_depth(depth)
+        ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        piped, sub = [], 0
+        ctx.stereo_submit(*seq[0]); sub += 1
+        piped.append(fields(ctx.stereo_collect(0.05)))
+        while len(piped) < len(seq):
+            while sub < len(seq) and sub - len(piped) < depth:
+                ctx.stereo_submit(*seq[sub]); sub += 1
+            piped.append(fields(ctx.stereo_collect(0.05)))
+        assert piped == want, depth
+    ctx.stereo_set_depth(2)
+
+
 # ------------------------------------------------------------------ mono path (SURVEY.md 8(a) rows 3, 11-16)
 def _mono_scene(n, seed, planar=False, noise=0.0, outliers=0.0):
     from scipy.spatial.transform import Rotation
