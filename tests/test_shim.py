@@ -139,3 +139,33 @@ def test_get_image_through_the_shim_matches_oracle(oracle, tmp_path):
     assert (ow, oh) == (DW, dh)
     got = np.frombuffer(raw[8:], np.uint8).reshape(oh, ow)
     assert np.array_equal(got, oracle.get_image(img, DW, K, dist, newK, True, 8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,planar", [(8, False), (4, False), (8, True), (4, True)])
+def test_mono_relative_pose_through_the_shim_matches_oracle(oracle, tmp_path, method, planar):
+    from test_gpu_parity import _mono_scene
+    _build()
+    K, x1, x2, R, t = _mono_scene(400, 300 + method + planar, planar=planar, noise=0.15, outliers=0.2)
+    thr = 1.0 if method == 8 else 0.1
+    inp, outp = tmp_path / "mi.bin", tmp_path / "mo.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<3i", len(x1), method, method))
+        f.write(np.ascontiguousarray(K, np.float64).tobytes())
+        f.write(struct.pack("<2d", thr, thr))
+        f.write(np.ascontiguousarray(x1, np.float32).tobytes()); f.write(np.ascontiguousarray(x2, np.float32).tobytes())
+    res = subprocess.run([os.path.join(ROOT, "tests", "cpp", "build", "shim_mono_pose"), str(inp), str(outp)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    raw = open(outp, "rb").read()
+    ue_in, ue_out, success, nin = struct.unpack("<4i", raw[:16])
+    Rt = np.frombuffer(raw[16:16 + 96], np.float64)
+    pts = np.frombuffer(raw[16 + 96:], np.float32).reshape(nin, 4)
+    op = oracle.mono_params(method=method)
+    op.ESSENTIAL_THRESHOLD = thr; op.HOMOGRAPHY_THRESHOLD = thr
+    import ctypes as C
+    want_ue = bool(oracle.lib().orc_select_estimation_method(x1.ctypes.data_as(C.c_void_p), x2.ctypes.data_as(C.c_void_p), len(x1), 10))
+    assert bool(ue_in) == want_ue
+    ok, ue, Ro, to, in1, in2, mask = oracle.estimate_relative_pose(op, want_ue, x1, x2, K)
+    assert (bool(success), bool(ue_out), nin) == (ok, ue, len(in1))
+    assert np.array_equal(Rt[:9].view(np.uint64), Ro.ravel().view(np.uint64)) and np.array_equal(Rt[9:].view(np.uint64), to.view(np.uint64))
+    assert np.array_equal(pts[:, :2], in1) and np.array_equal(pts[:, 2:], in2)
