@@ -523,6 +523,8 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
         fprintf(stderr, "[uvo] pnp batch %d; hyp phases (us): ctrl %.1f bary %.1f mtm %.1f svd12 %.1f betas %.1f pcs %.1f sums %.1f svd3 %.1f reproj %.1f\n", nb,
                 (k[1]-k[0])*0.01, (k[2]-k[1])*0.01, (k[3]-k[2])*0.01, (k[4]-k[3])*0.01, (k[5]-k[4])*0.01, (k[6]-k[5])*0.01,
                 (k[7]-k[6])*0.01, (k[8]-k[7])*0.01, (k[9]-k[8])*0.01);
+        fprintf(stderr, "[uvo]   hyp betas split (us): L %.1f  find_betas %.1f  gauss_newton %.1f  ccs %.1f\n", (k[10]-k[4])*0.01, (k[11]-k[10])*0.01,
+                (k[12]-k[11])*0.01, (k[5]-k[12])*0.01);
         UVO_HIP_TRY(m, hipMemcpyFromSymbol(k, HIP_SYMBOL(g_refit_clk), sizeof(k)));
         fprintf(stderr, "[uvo] pnp refit phases (us): ctrl %.1f bary %.1f mtm %.1f svd12 %.1f betas %.1f pcs %.1f sums %.1f svd3 %.1f reproj %.1f\n",
                 (k[1]-k[0])*0.01, (k[2]-k[1])*0.01, (k[3]-k[2])*0.01, (k[4]-k[3])*0.01, (k[5]-k[4])*0.01, (k[6]-k[5])*0.01,

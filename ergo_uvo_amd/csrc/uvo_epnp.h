@@ -467,35 +467,32 @@ struct Epnp {
         }
     }
 
+    // compute_L_6x10: 24 difference vectors, then 60 independent dot products -- spread over the policy's lanes
+    // (every element is computed by one lane with the reference's expression; nothing is summed across lanes)
     __device__ void compute_L_6x10(Arr ut, Arr l)
     {
         Arr dv = s + EP_SC;                   // dv[4][6][3] = 72
-        for (int i = 0; i < 4; i++) {
+        for (int e = P::tid(); e < 24; e += P::nth()) {
+            const int i = e / 6, j = e - 6*i;
+            // pairs (a, b) in the order (0,1) (0,2) (0,3) (1,2) (1,3) (2,3)
+            const int a = j < 3 ? 0 : (j < 5 ? 1 : 2), b = j < 3 ? j + 1 : (j < 5 ? j - 1 : 3);
             Arr v = ut + 12*(11 - i);
-            int a = 0, b = 1;
-            for (int j = 0; j < 6; j++) {
-                dv[(i*6 + j)*3 + 0] = v[3*a] - v[3*b];
-                dv[(i*6 + j)*3 + 1] = v[3*a + 1] - v[3*b + 1];
-                dv[(i*6 + j)*3 + 2] = v[3*a + 2] - v[3*b + 2];
-                b++;
-                if (b > 3) { a++; b = a + 1; }
-            }
+            dv[e*3 + 0] = v[3*a] - v[3*b];
+            dv[e*3 + 1] = v[3*a + 1] - v[3*b + 1];
+            dv[e*3 + 2] = v[3*a + 2] - v[3*b + 2];
         }
+        P::sync();
 #define UVO_DV(i, j) (dv + ((i)*6 + (j))*3)
-        for (int i = 0; i < 6; i++) {
-            Arr row = l + 10*i;
-            row[0] =        dot3(UVO_DV(0, i), UVO_DV(0, i));
-            row[1] = 2.0f * dot3(UVO_DV(0, i), UVO_DV(1, i));
-            row[2] =        dot3(UVO_DV(1, i), UVO_DV(1, i));
-            row[3] = 2.0f * dot3(UVO_DV(0, i), UVO_DV(2, i));
-            row[4] = 2.0f * dot3(UVO_DV(1, i), UVO_DV(2, i));
-            row[5] =        dot3(UVO_DV(2, i), UVO_DV(2, i));
-            row[6] = 2.0f * dot3(UVO_DV(0, i), UVO_DV(3, i));
-            row[7] = 2.0f * dot3(UVO_DV(1, i), UVO_DV(3, i));
-            row[8] = 2.0f * dot3(UVO_DV(2, i), UVO_DV(3, i));
-            row[9] =        dot3(UVO_DV(3, i), UVO_DV(3, i));
+        for (int e = P::tid(); e < 60; e += P::nth()) {
+            const int i = e / 10, c = e - 10*i;
+            // column c <-> (p, q) with p <= q: 0:(0,0) 1:(0,1) 2:(1,1) 3:(0,2) 4:(1,2) 5:(2,2) 6:(0,3) 7:(1,3) 8:(2,3) 9:(3,3)
+            const int q = c < 1 ? 0 : (c < 3 ? 1 : (c < 6 ? 2 : 3));
+            const int p0 = c - (q*(q + 1))/2;
+            const double d = dot3(UVO_DV(p0, i), UVO_DV(q, i));
+            l[10*i + c] = p0 == q ? d : 2.0f * d;
         }
 #undef UVO_DV
+        P::sync();
     }
 
     // find_betas_approx_{1,2,3}: cvSolve(L_6xK, Rho, B, CV_SVD) with K = 4, 3, 5 columns picked from L_6x10.
@@ -512,7 +509,7 @@ struct Epnp {
             }
         // cv::solve(DECOMP_SVD): a = Ls^T, JacobiSVD, back-substitution
         for (int i = 0; i < 6; i++) for (int j = 0; j < K; j++) a[j*6 + i] = Ls[i*K + j];
-        jacobi_svd_rt(a, w, v, wt, 6, K);
+        jacobi_svd_rt6(a, w, v, wt, K);
         svbksb_vec(6, K, w, a, 6, v, K, rho, b);
         if (which == 1) {
             if (b[0] < 0) { betas[0] = sqrt(-b[0]); betas[1] = -b[1] / betas[0]; betas[2] = -b[2] / betas[0]; betas[3] = -b[3] / betas[0]; }
@@ -570,27 +567,94 @@ struct Epnp {
         }
     }
 
+    // epnp.cpp qr_solve (nr = 6, nc = 4) on register arrays: every index is a compile-time constant after unrolling, so
+    // the Householder steps run without a memory round trip per element.  Same operations, same order; X is left
+    // untouched when a column vanishes (the reference returns before writing it).
+    __device__ __forceinline__ void qr_solve_reg(double (&pA)[24], double (&pb)[6], double (&pX)[4])
+    {
+        constexpr int nr = 6, nc = 4;
+        double A1[nc], A2[nc];
+        bool singular = false;
+#pragma unroll
+        for (int k = 0; k < nc; k++) {
+            if (singular) break;
+            const int kk = k * (nc + 1);
+            double eta = fabs(pA[kk]);
+#pragma unroll
+            for (int i = k + 1; i < nr; i++) { double elt = fabs(pA[kk + (i - k - 1) * nc]); if (eta < elt) eta = elt; }   // epnp.cpp reads before it advances: rows k .. nr-2
+            if (eta == 0) { singular = true; break; }
+            double sum2 = 0.0; const double inv_eta = 1. / eta;
+#pragma unroll
+            for (int i = k; i < nr; i++) { double t = pA[kk + (i - k) * nc] * inv_eta; pA[kk + (i - k) * nc] = t; sum2 += t * t; }
+            double sigma = sqrt(sum2);
+            if (pA[kk] < 0) sigma = -sigma;
+            pA[kk] += sigma;
+            A1[k] = sigma * pA[kk];
+            A2[k] = -eta * sigma;
+#pragma unroll
+            for (int j = k + 1; j < nc; j++) {
+                double sum = 0;
+#pragma unroll
+                for (int i = k; i < nr; i++) sum += pA[kk + (i - k) * nc] * pA[kk + (i - k) * nc + j - k];
+                const double tau = sum / A1[k];
+#pragma unroll
+                for (int i = k; i < nr; i++) pA[kk + (i - k) * nc + j - k] -= tau * pA[kk + (i - k) * nc];
+            }
+        }
+        if (singular) return;
+#pragma unroll
+        for (int j = 0; j < nc; j++) {
+            const int jj = j * (nc + 1);
+            double tau = 0;
+#pragma unroll
+            for (int i = j; i < nr; i++) tau += pA[jj + (i - j) * nc] * pb[i];
+            tau /= A1[j];
+#pragma unroll
+            for (int i = j; i < nr; i++) pb[i] -= tau * pA[jj + (i - j) * nc];
+        }
+        pX[nc - 1] = pb[nc - 1] / A2[nc - 1];
+#pragma unroll
+        for (int i = nc - 2; i >= 0; i--) {
+            double sum = 0;
+#pragma unroll
+            for (int j = i + 1; j < nc; j++) sum += pA[i*nc + j] * pX[j];
+            pX[i] = (pb[i] - sum) / A2[i];
+        }
+    }
+
     __device__ void gauss_newton(Arr L, Arr rho, Arr betas, Arr sc)
     {
-        Arr A = sc, b = sc + 24, x = sc + 30, A1 = sc + 34, A2 = sc + 38;
-        for (int i = 0; i < 4; i++) x[i] = 0;
+        (void)sc;
+        double Lr[60], rh[6], be[4], x[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 60; i++) Lr[i] = L[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) rh[i] = rho[i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) be[i] = betas[i];
+#pragma unroll 1
         for (int it = 0; it < 5; it++) {
-            double b0 = betas[0], b1 = betas[1], b2 = betas[2], b3 = betas[3];
+            const double b0 = be[0], b1 = be[1], b2 = be[2], b3 = be[3];
+            double A[24], b[6];
+#pragma unroll
             for (int i = 0; i < 6; i++) {
-                Arr rowL = L + i*10, rowA = A + i*4;
-                rowA[0] = 2*rowL[0]*b0 +   rowL[1]*b1 +   rowL[3]*b2 +   rowL[6]*b3;
-                rowA[1] =   rowL[1]*b0 + 2*rowL[2]*b1 +   rowL[4]*b2 +   rowL[7]*b3;
-                rowA[2] =   rowL[3]*b0 +   rowL[4]*b1 + 2*rowL[5]*b2 +   rowL[8]*b3;
-                rowA[3] =   rowL[6]*b0 +   rowL[7]*b1 +   rowL[8]*b2 + 2*rowL[9]*b3;
-                b[i] = rho[i] -
+                const double* rowL = Lr + i*10;
+                A[i*4 + 0] = 2*rowL[0]*b0 +   rowL[1]*b1 +   rowL[3]*b2 +   rowL[6]*b3;
+                A[i*4 + 1] =   rowL[1]*b0 + 2*rowL[2]*b1 +   rowL[4]*b2 +   rowL[7]*b3;
+                A[i*4 + 2] =   rowL[3]*b0 +   rowL[4]*b1 + 2*rowL[5]*b2 +   rowL[8]*b3;
+                A[i*4 + 3] =   rowL[6]*b0 +   rowL[7]*b1 +   rowL[8]*b2 + 2*rowL[9]*b3;
+                b[i] = rh[i] -
                     (rowL[0]*b0*b0 + rowL[1]*b0*b1 + rowL[2]*b1*b1 +
                      rowL[3]*b0*b2 + rowL[4]*b1*b2 + rowL[5]*b2*b2 +
                      rowL[6]*b0*b3 + rowL[7]*b1*b3 + rowL[8]*b2*b3 +
                      rowL[9]*b3*b3);
             }
-            qr_solve(A, b, x, A1, A2);
-            for (int i = 0; i < 4; i++) betas[i] += x[i];
+            qr_solve_reg(A, b, x);
+#pragma unroll
+            for (int i = 0; i < 4; i++) be[i] += x[i];
         }
+#pragma unroll
+        for (int i = 0; i < 4; i++) betas[i] = be[i];
     }
 
     // epnp::compute_pose followed by Rodrigues(R, rvec).  Outputs valid on tid 0.
@@ -611,8 +675,9 @@ struct Epnp {
         } else jacobi_svd_u_levels<P, 12, 12>(mtm, s + EP_D, s + EP_WT, s + EP_FLAG);
         const int tid = P::tid();
         EP_STAMP(4);
+        compute_L_6x10(mtm, L);
+        EP_STAMP(10);
         if (tid == 0) {
-            compute_L_6x10(mtm, L);
             rho[0] = dist2(cws, cws + 3); rho[1] = dist2(cws, cws + 6); rho[2] = dist2(cws, cws + 9);
             rho[3] = dist2(cws + 3, cws + 6); rho[4] = dist2(cws + 3, cws + 9); rho[5] = dist2(cws + 6, cws + 9);
         }
@@ -621,7 +686,9 @@ struct Epnp {
         if (tid < 3) {
             Arr B = br(tid), betas = B + EPB_BETAS, ccs = B + EPB_CCS;
             find_betas(tid + 1, L, rho, betas, B + EPB_SC);
+            EP_STAMP(11);
             gauss_newton(L, rho, betas, B + EPB_SC);
+            EP_STAMP(12);
             for (int i = 0; i < 12; i++) ccs[i] = 0.0f;
             for (int i = 0; i < 4; i++) {
                 Arr v = mtm + 12*(11 - i);

@@ -253,6 +253,122 @@ __host__ __device__ void jacobi_svd_rt(A At, A W_out, A Vt, A W, int m, int n, i
     }
 }
 
+// jacobi_svd_rt for m == 6 rows and n <= 5 columns decided at run time (the three beta approximations of EPnP solve
+// 6 x 4, 6 x 3 and 6 x 5 systems side by side on three lanes): the same operations in the same order, but the loops
+// over m are unrolled and the two rows of a rotation are fetched in one batch, so a rotation waits for memory once
+// instead of once per element.
+template <class A>
+__host__ __device__ void jacobi_svd_rt6(A At, A W_out, A Vt, A W, int n)
+{
+    constexpr int m = 6, NMAX = 5;
+    const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
+    int i, j, k, iter;
+    const int max_iter = 30;
+    double c, s, sd;
+    for (i = 0; i < n; i++) {
+        double r[m];
+#pragma unroll
+        for (k = 0; k < m; k++) r[k] = At[i*m + k];
+        sd = 0;
+#pragma unroll
+        for (k = 0; k < m; k++) sd += r[k]*r[k];
+        W[i] = sd;
+#pragma unroll
+        for (k = 0; k < NMAX; k++) if (k < n) Vt[i*n + k] = 0;
+        Vt[i*n + i] = 1;
+    }
+#pragma unroll 1
+    for (iter = 0; iter < max_iter; iter++) {
+        bool changed = false;
+#pragma unroll 1
+        for (i = 0; i < n-1; i++)
+#pragma unroll 1
+            for (j = i+1; j < n; j++) {
+                A Ai = At + i*m, Aj = At + j*m;
+                double x[m], y[m];
+#pragma unroll
+                for (k = 0; k < m; k++) { x[k] = Ai[k]; y[k] = Aj[k]; }
+                double a = W[i], p = 0, b = W[j];
+#pragma unroll
+                for (k = 0; k < m; k++) p += x[k]*y[k];
+                if (fabs(p) <= eps*sqrt(a*b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = det_hypot(p, beta);
+                if (beta < 0) {
+                    double delta = (gamma - beta)*0.5;
+                    s = sqrt(delta/gamma);
+                    c = p/(gamma*s*2);
+                } else {
+                    c = sqrt((gamma + beta)/(gamma*2));
+                    s = p/(gamma*c*2);
+                }
+                a = b = 0;
+#pragma unroll
+                for (k = 0; k < m; k++) {
+                    double t0 = c*x[k] + s*y[k];
+                    double t1 = -s*x[k] + c*y[k];
+                    Ai[k] = t0; Aj[k] = t1;
+                    a += t0*t0; b += t1*t1;
+                }
+                W[i] = a; W[j] = b;
+                changed = true;
+                A Vi = Vt + i*n, Vj = Vt + j*n;
+                double vx[NMAX], vy[NMAX];
+#pragma unroll
+                for (k = 0; k < NMAX; k++) if (k < n) { vx[k] = Vi[k]; vy[k] = Vj[k]; }
+#pragma unroll
+                for (k = 0; k < NMAX; k++) if (k < n) {
+                    double t0 = c*vx[k] + s*vy[k];
+                    double t1 = -s*vx[k] + c*vy[k];
+                    Vi[k] = t0; Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (i = 0; i < n; i++) {
+        double r[m];
+#pragma unroll
+        for (k = 0; k < m; k++) r[k] = At[i*m + k];
+        sd = 0;
+#pragma unroll
+        for (k = 0; k < m; k++) sd += r[k]*r[k];
+        W[i] = sqrt(sd);
+    }
+    for (i = 0; i < n-1; i++) {
+        j = i;
+        for (k = i+1; k < n; k++) if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double t = W[i]; W[i] = W[j]; W[j] = t;
+            for (k = 0; k < m; k++) { t = At[i*m+k]; At[i*m+k] = At[j*m+k]; At[j*m+k] = t; }
+            for (k = 0; k < n; k++) { t = Vt[i*n+k]; Vt[i*n+k] = Vt[j*n+k]; Vt[j*n+k] = t; }
+        }
+    }
+    for (i = 0; i < n; i++) W_out[i] = W[i];
+    uint64_t rng = 0x12345678ULL;
+    for (i = 0; i < n; i++) {                  // (rows with a vanishing singular value are rebuilt exactly as in jacobi_svd_rt)
+        sd = W[i];
+        for (int ii = 0; ii < 100 && sd <= minval; ii++) {
+            const double val0 = 1./m;
+            for (k = 0; k < m; k++) { double val = (rng_next(rng) & 256) != 0 ? val0 : -val0; At[i*m + k] = val; }
+            for (iter = 0; iter < 2; iter++)
+                for (j = 0; j < i; j++) {
+                    sd = 0;
+                    for (k = 0; k < m; k++) sd += At[i*m + k]*At[j*m + k];
+                    double asum = 0;
+                    for (k = 0; k < m; k++) { double t = At[i*m + k] - sd*At[j*m + k]; At[i*m + k] = t; asum += fabs(t); }
+                    asum = asum > eps*100 ? 1/asum : 0;
+                    for (k = 0; k < m; k++) At[i*m + k] *= asum;
+                }
+            sd = 0;
+            for (k = 0; k < m; k++) { double t = At[i*m + k]; sd += t*t; }
+            sd = sqrt(sd);
+        }
+        s = sd > minval ? 1/sd : 0.;
+#pragma unroll
+        for (k = 0; k < m; k++) At[i*m + k] *= s;
+    }
+}
+
 // SVBkSbImpl_<double>, nb == 1 with right-hand side b: x = V diag(1/w) U^T b.
 // ut: row i = i-th left vector (length m), vt: row i = i-th right vector (length n).
 template <class A>
