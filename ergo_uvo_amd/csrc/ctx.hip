@@ -76,7 +76,8 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     for (int i = 0; i < 2; i++) {
         A(dalloc(&c->d_planes[i], (size_t)16 * c->plane_stride));
         if (e == hipSuccess) e = hipMemset(c->d_planes[i], 0, sizeof(int32_t) * 16 * c->plane_stride);       // row 0 / padding stay zero
-        A(dalloc(&c->d_img[i], npx)); A(dalloc(&c->d_sum[i], nsum));
+        A(dalloc(&c->d_img[i], npx)); A(dalloc(&c->d_sum_base[i], nsum + 2 * kSumPad));
+        if (e == hipSuccess) { e = hipMemset(c->d_sum_base[i], 0, sizeof(int32_t) * (nsum + 2 * kSumPad)); c->d_sum[i] = c->d_sum_base[i] + kSumPad; }
         A(dalloc(&c->d_cand[i], cap)); A(dalloc(&c->det[i].kps, cap)); A(dalloc(&c->det[i].desc, cap * 64));
         A(dalloc(&c->d_tmp_desc[i], cap * 64)); A(dalloc(&c->d_matches[i], cap));
         A(dalloc(&c->d_as_kpsL[i], cap)); A(dalloc(&c->d_as_kpsR[i], cap)); A(dalloc(&c->d_as_descL[i], cap * 64));
@@ -172,7 +173,7 @@ static void destroy_one(uvo_ctx* c)
     }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < 2; i++) {
-        (void)hipFree(c->d_img[i]); (void)hipFree(c->d_sum[i]); (void)hipFree(c->d_planes[i]); (void)hipFree(c->d_cand[i]); (void)hipFree(c->det[i].kps);
+        (void)hipFree(c->d_img[i]); (void)hipFree(c->d_sum_base[i]); (void)hipFree(c->d_planes[i]); (void)hipFree(c->d_cand[i]); (void)hipFree(c->det[i].kps);
         (void)hipFree(c->det[i].desc); (void)hipFree(c->d_tmp_desc[i]); (void)hipFree(c->d_matches[i]);
         (void)hipFree(c->d_as_kpsL[i]); (void)hipFree(c->d_as_kpsR[i]); (void)hipFree(c->d_as_descL[i]);
     }

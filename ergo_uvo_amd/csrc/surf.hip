@@ -248,6 +248,15 @@ struct OctC {
     static constexpr int HI = -margin(4) * STEP + size(4);        // ... and furthest right/down
 };
 
+// Integral tile of a TW-sample-wide workgroup: TWs columns, padded to whole quads (TWq), PW words per column-residue plane.
+template <int O, int TW>
+struct OctTile {
+    static constexpr int TWs = (TW - 1) * OctC<O>::STEP + (OctC<O>::HI - OctC<O>::LO) + 1;
+    static constexpr int TWq = (TWs + 3) & ~3;
+    static constexpr int PW = TWq / OctC<O>::STEP;
+};
+struct __attribute__((packed, aligned(4))) SumQuad { int32_t a, b, c, d; };     // four integral columns, 4-byte aligned
+
 // dx, dy, dxy -> det of one sample; SV(dy, dx) fetches the integral value at compile-time offset (dy, dx) from the
 // template's top-left corner.  Corners shared between the boxes of a filter are read once (32 reads per sample).
 #define UVO_HESSIAN_DET(SV, det)                                                                          \
@@ -296,8 +305,7 @@ __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, f
     using OC = OctC<O>;
     constexpr int STEP = OC::STEP, SIZE = OC::size(L);
     using LC = LayerC<SIZE>;
-    constexpr int TWs = (TW - 1) * STEP + (OC::HI - OC::LO) + 1;
-    constexpr int PW = (TWs + STEP - 1) / STEP;
+    constexpr int PW = OctTile<O, TW>::PW;
     constexpr int OFFL = -OC::margin(L) * STEP - OC::LO;          // tile offset of this layer's template origin
     static_assert(OFFL >= 0, "layer origin outside the tile");
     // tile index of corner (dy, dx) relative to base = &stile[ry*STEP*STEP*PW + rx]
@@ -352,9 +360,9 @@ __global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, 
 {
     using OC = OctC<O>;
     constexpr int STEP = OC::STEP;
-    constexpr int TWs = (TW - 1) * STEP + (OC::HI - OC::LO) + 1;
+    constexpr int TWs = OctTile<O, TW>::TWs;
     constexpr int THs = (TH - 1) * STEP + (OC::HI - OC::LO) + 1;
-    constexpr int PW = (TWs + STEP - 1) / STEP;
+    constexpr int PW = OctTile<O, TW>::PW;
     extern __shared__ __align__(16) unsigned char smem[];
     const int tid = threadIdx.x, im = blockIdx.z;
     const int sw = w + 1;
@@ -364,12 +372,38 @@ __global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, 
 
     const int px0 = blockIdx.x * (TW - 2) - 1, py0 = blockIdx.y * (TH - 2) - 1;
     const int sx0 = px0 * STEP + OC::LO, sy0 = py0 * STEP + OC::LO;
-    for (int idx = tid; idx < THs * TWs; idx += NT) {
-        int ty = idx / TWs, tx = idx - ty * TWs;
-        int gy = sy0 + ty, gx = sx0 + tx;
-        int v = 0;
-        if (gy >= 0 && gy <= h && gx >= 0 && gx <= w) v = gsum[(size_t)gy * sw + gx];
-        stile[(ty * STEP + tx % STEP) * PW + tx / STEP] = v;
+    // Tile fill: whole quads (global_load_dwordx4 at 4-byte alignment, ds_write_b128 / 2 x ds_write_b64), kFill of them in
+    // flight per thread before the first LDS store.  Rows are clamped to the image; columns are not: every corner a valid
+    // sample reads lies inside the image (samples_i/j are defined that way), out-of-image elements are only ever read by
+    // masked samples, and the integral buffers carry kSumPad ints of slack on both sides, so the overshoot of the first
+    // and last rows stays inside the allocation.
+    constexpr int QPR = OctTile<O, TW>::TWq / 4, kQuads = THs * QPR, kFill = 4, kQ = NT / QPR, kR = NT % QPR;
+    static_assert(STEP == 1 || STEP == 2, "tile fill handles octaves 0 and 1");
+    static_assert(OctTile<O, TW>::TWq < kSumPad && STEP - OC::LO < kSumPad, "integral slack too small for the tile overshoot");
+    int fidx = tid, fty = tid / QPR, fq = tid - fty * QPR;           // quad, tile row, quad in row: advanced by NT per step
+#pragma unroll 1
+    for (int i0 = 0; i0 < kQuads; i0 += NT * kFill) {
+        SumQuad v[kFill];
+        int dst[kFill];
+#pragma unroll
+        for (int u = 0; u < kFill; u++) {
+            const bool in = fidx < kQuads;
+            const int gy = min(max(sy0 + fty, 0), h), gx = sx0 + 4 * fq;
+            v[u] = *reinterpret_cast<const SumQuad*>(gsum + (in ? gy * sw + gx : 0));
+            dst[u] = in ? fty * STEP * PW + (4 / STEP) * fq : -1;
+            fidx += NT; fq += kR; fty += kQ;
+            if (fq >= QPR) { fq -= QPR; fty++; }
+        }
+#pragma unroll
+        for (int u = 0; u < kFill; u++) {
+            if (dst[u] < 0) continue;
+            if constexpr (STEP == 1) {
+                *reinterpret_cast<int4*>(stile + dst[u]) = make_int4(v[u].a, v[u].b, v[u].c, v[u].d);
+            } else {
+                *reinterpret_cast<int2*>(stile + dst[u]) = make_int2(v[u].a, v[u].c);          // even columns
+                *reinterpret_cast<int2*>(stile + dst[u] + PW) = make_int2(v[u].b, v[u].d);     // odd columns
+            }
+        }
     }
     __syncthreads();
     det_layer_c<O, 0, TW, TH, NT>(stile, sdet, op, px0, py0);
@@ -936,8 +970,8 @@ static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float 
 {
     using OC = OctC<O>;
     constexpr int STEP = OC::STEP;
-    constexpr int TWs = (TW - 1) * STEP + (OC::HI - OC::LO) + 1, THs = (TH - 1) * STEP + (OC::HI - OC::LO) + 1;
-    constexpr int PW = (TWs + STEP - 1) / STEP;
+    constexpr int THs = (TH - 1) * STEP + (OC::HI - OC::LO) + 1;
+    constexpr int PW = OctTile<O, TW>::PW;
     const int w = c->img_w, h = c->img_h;
     ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n };
     CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };

@@ -40,6 +40,7 @@ enum { CN_T = 0, CN_G = 1, CN_NINL = 2, CN_NQA = 3, CN_NQB = 4, CN_MEFF = 5, CN_
 // triangular matcher's.
 struct GateArgs { int mode; int* cn; int min_features, cap; int* as_curr_n; const int* as_prev_n; };
 
+static const int kSumPad = 256;      // ints of slack before and after each integral image (see Ctx::d_sum_base)
 static const int kMaxHyp = 2048;      // RANSAC hypotheses evaluated per call (>= ITERATIONS_COUNT)
 
 struct DetectSet {                    // one image's detector outputs (device)
@@ -56,7 +57,9 @@ struct Ctx {
 
     // ---- SURF ----
     uint8_t* d_img[2] = {nullptr, nullptr};
-    int32_t* d_sum[2] = {nullptr, nullptr};      // (max_h+1) x (max_w+1)
+    int32_t* d_sum[2] = {nullptr, nullptr};      // (max_h+1) x (max_w+1); = d_sum_base + kSumPad
+    int32_t* d_sum_base[2] = {nullptr, nullptr}; // allocation: kSumPad ints of slack on both sides, so the Hessian tile fill can
+                                                 // read whole quads of a clamped row without per-element bounds checks
     int32_t* d_colpart = nullptr;                // [2][nseg][max_w+1]
     int32_t* d_planes[2] = {nullptr, nullptr};   // integral de-interleaved by (row & 3, col & 3): 16 planes of plane_ph x plane_pw
     int plane_pw = 0, plane_stride = 0;
