@@ -4,9 +4,12 @@
 #include "uvo_ctx.h"
 #include "uvo_epnp.h"
 #include <string.h>
+#include <atomic>
 #include <math.h>
 #include <new>
 #include <algorithm>
+#include <atomic>
+namespace uvo { extern bool g_bdbg; extern std::atomic<double> g_bstat[8]; double now_us(); void operator+=(std::atomic<double>& a, double v); }
 
 using namespace uvo;
 
@@ -83,7 +86,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
         A(dalloc(&c->d_as_kpsL[i], cap)); A(dalloc(&c->d_as_kpsR[i], cap)); A(dalloc(&c->d_as_descL[i], cap * 64));
     }
     A(dalloc(&c->d_colpart, (size_t)2 * nseg * (max_w + 1)));
-    A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_par, cap * 2)); A(dalloc(&c->d_big_patch, cap * 2 * 448)); A(hipMalloc(reinterpret_cast<void**>(&c->d_big_tabs), cap * 2 * 21 * 32));
+    A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_par, cap * 8)); A(dalloc(&c->d_big_patch, cap * 2 * 448)); A(hipMalloc(reinterpret_cast<void**>(&c->d_big_tabs), cap * 2 * 21 * 32));
     A(dalloc(&c->d_mpart, nchunks * cap)); A(dalloc(&c->d_mscratch, nchunks + 4)); A(dalloc(&c->d_knn_idx, cap * 2)); A(dalloc(&c->d_knn_dist, cap * 2));
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
     A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_tmp_idx, cap));
@@ -157,6 +160,12 @@ extern "C" uvo_status uvo_stereo_set_depth(uvo_ctx* c, int depth)
 extern "C" void uvo_ctx_destroy(uvo_ctx* c)
 {
     if (!c) return;
+    if (uvo::g_bdbg && uvo::g_bstat[4].load() > 0) {
+        const double n = uvo::g_bstat[4].load();
+        fprintf(stderr, "[uvo] stage B over %.0f calls, host wall us per call: wait-for-A %.1f | hyp+score to sync %.1f | host scan + refit launch %.1f | refit to sync %.1f | semaphore wait %.1f\n",
+                n, uvo::g_bstat[0].load() / n, uvo::g_bstat[1].load() / n, uvo::g_bstat[2].load() / n, uvo::g_bstat[3].load() / n, uvo::g_bstat[5].load() / n);
+        fprintf(stderr, "[uvo] uvo_stereo_submit host wall: %.1f us per pair over %.0f pairs\n", uvo::g_bstat[6].load() / std::max(1.0, uvo::g_bstat[7].load()), uvo::g_bstat[7].load());
+    }
     for (size_t i = c->lanes.size(); i > 1; i--) destroy_one(static_cast<uvo_ctx*>(c->lanes[i - 1]));
     c->lanes.clear();
     destroy_one(c);
@@ -548,6 +557,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
         return UVO_OK;
     }
     const int li = c->next_lane;
+    const double t_sub = uvo::g_bdbg ? uvo::now_us() : 0;
     uvo_ctx* L = static_cast<uvo_ctx*>(c->lanes[li]);
     Ctx* P = c->lanes[c->prev_lane];
     L->pending = Ctx::Pending();
@@ -599,17 +609,21 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
         L->job.state = 1;
     }
     L->cv.notify_all();
+    if (uvo::g_bdbg) { uvo::g_bstat[6] += uvo::now_us() - t_sub; uvo::g_bstat[7] += 1; }
     return UVO_OK;
 #undef LANE_TRY
 }
 
 // Stage B of one lane's pair (VO:634-648), on the lane's worker thread: wait for stage A, then solvePnPRansac.
+namespace uvo { extern bool g_bdbg; extern std::atomic<double> g_bstat[8]; double now_us(); void operator+=(std::atomic<double>& a, double v); }
 static void run_stage_b(uvo_ctx* L)
 {
     Ctx::BJob& j = L->job;
     const Ctx* m = L->master ? L->master : L;
     j.st = UVO_OK; j.err.clear(); j.ran = j.ninl = j.ok = j.wrote = 0;
+    const double t0 = g_bdbg ? now_us() : 0;
     if (hipEventSynchronize(L->evA[0]) != hipSuccess) { j.st = UVO_HIP_ERROR; j.err = "stage A of the pair failed"; return; }
+    if (g_bdbg) g_bstat[0] += now_us() - t0;
     const int* hc = L->h_countsA[0];
     const int cap = L->cap;
     if (hc[CN_CAND0] > cap || hc[CN_CAND1] > cap || hc[CN_M] > cap || hc[CN_TRAW] > cap) return;    // reported by collect
@@ -636,7 +650,9 @@ static void lane_worker(uvo_ctx* L)
         {   // at most max_b PnP stages at a time over all lanes (the device runs only ~3 kernels concurrently: leave room for stage A)
             Ctx* m = L->master ? L->master : L;
             std::unique_lock<std::mutex> g(m->b_mu);
+            const double tw = g_bdbg ? now_us() : 0;
             m->b_cv.wait(g, [&] { return m->b_running < m->max_b; });
+            if (g_bdbg) g_bstat[5] += now_us() - tw;
             m->b_running++;
             g.unlock();
             run_stage_b(L);

@@ -12,6 +12,8 @@
 //     winner; the winner's mask is recomputed and the inlier refit runs block-cooperatively with
 //     each floating-point sum kept in its sequential order.
 #include "uvo_ctx.h"
+#include <atomic>
+#include <chrono>
 #include "uvo_epnp.h"
 #include <string.h>
 #include <stdlib.h>
@@ -380,6 +382,12 @@ uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const doubl
     return UVO_OK;
 }
 
+// UVO_DBG_BSTAGE=1: host wall time of the PnP stage's segments, summed over calls (printed by uvo_ctx_destroy)
+bool g_bdbg = getenv("UVO_DBG_BSTAGE") != nullptr;
+std::atomic<double> g_bstat[8];
+double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void operator+=(std::atomic<double>& a, double v) { double o = a.load(); while (!a.compare_exchange_weak(o, o + v)) {} }
+
 // solvePnPRansac for n jobs at once: job i works on the G[i] points already in lanes[i]->d_opts[0] / d_ipts[0] with
 // lanes[i]'s PnP buffers; every launch and both host syncs are shared.  Runs on m->pnp_stream.
 uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G, const double* K, int iterationsCount,
@@ -387,6 +395,7 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
 {
     const int modelPoints = 5;
     hipStream_t st = m->pnp_stream;
+    double t_b0 = g_bdbg ? now_us() : 0;
     if (n < 1 || n > kMaxPnpBatch) { m->err = "pnp batch size"; return UVO_INVALID_ARG; }
     const size_t hyp_lds = sizeof(double) * kHypGroups * kHypPerGroup;
     static std::once_flag attr_once;
@@ -454,6 +463,7 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
         else UVO_HIP_TRY(m, hipMemcpyAsync(c->h_hcount, c->d_hcount, sizeof(int) * b.job[s].nhyp, hipMemcpyDeviceToHost, st));
     }
     UVO_HIP_TRY(m, hipStreamSynchronize(st));
+    if (g_bdbg) { g_bstat[1] += now_us() - t_b0; t_b0 = now_us(); }
     // replay of RANSACPointSetRegistrator::run's sequential scan, per job
     PnpBatch b2 = b;
     int idx2[kMaxPnpBatch], nb2 = 0;
@@ -505,7 +515,9 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
         UVO_HIP_TRY(m, hipMemcpyAsync(c->h_countsB, c->d_countsB, sizeof(int), hipMemcpyDeviceToHost, st));
         need_sync = true;
     }
+    if (g_bdbg) { g_bstat[2] += now_us() - t_b0; t_b0 = now_us(); }
     if (need_sync) UVO_HIP_TRY(m, hipStreamSynchronize(st));
+    if (g_bdbg) { g_bstat[3] += now_us() - t_b0; g_bstat[4] += 1; }
     for (int s = 0; s < nb2; s++) {
         Ctx* c = lanes[idx2[s]];
         PnpResult& r = res[idx2[s]];

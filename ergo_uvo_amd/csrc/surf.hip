@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_integral_rows(ImgPair ip, int w, int h)
     for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) { run += src[x]; dst[x + 1] = run; } }
     if (tid == 0) dst[0] = 0;
     if (y == 0) { int32_t* r0 = ip.sum[im]; for (int x = tid; x < sw; x += 256) r0[x] = 0; }
-    if (y == 0 && tid == 0) { ip.cand_n[im] = 0; ip.big_n[im] = 0; }       // the frame's candidate / large-window counters start at zero
+    if (y == 0 && tid < 4) { if (tid == 0) ip.cand_n[im] = 0; ip.big_n[im * 4 + tid] = 0; }       // the frame's candidate / large-window counters start at zero
 }
 
 __global__ __launch_bounds__(256) void k_integral_colsum(ImgPair ip, int w, int h, int32_t* part, int nseg)
@@ -541,6 +541,23 @@ __device__ __forceinline__ SortKey make_sort_key(const uvo_keypoint& kp)
 struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* out[2]; int* out_n[2]; int* rank; int cap;
                   int4* big_par; int* big_n; int* gate_nqa; int gate_min_features; };
 static const int kSmallWin = 128;       // descriptor windows up to this size use the small-LDS kernel
+// Large windows are listed by cost class (a (keypoint, column) task of k_descriptor64_big costs about
+// ceil(win/256) lane passes x ceil((win/21 + 2)/16) tap batches): 0: > 512, 1: 295..512, 2: 257..294, 3: 129..256.
+// Walking the classes in this order gives a list sorted by descending cost, which the task dealing relies on.
+__device__ __forceinline__ int big_class(int win_size) { return win_size > 512 ? 0 : win_size > 294 ? 1 : win_size > 256 ? 2 : 3; }
+struct BigList { int p1, p2, p3, total; };                 // prefix counts of the four class lists
+__device__ __forceinline__ BigList big_list(const int* big_n, int im)
+{
+    const int n0 = big_n[im * 4], n1 = big_n[im * 4 + 1], n2 = big_n[im * 4 + 2], n3 = big_n[im * 4 + 3];
+    return BigList{ n0, n0 + n1, n0 + n1 + n2, n0 + n1 + n2 + n3 };
+}
+// entry e of the concatenated class lists -> index into big_par
+__device__ __forceinline__ int big_slot(const BigList& b, int im, int cap, int e)
+{
+    const int c = (e >= b.p1) + (e >= b.p2) + (e >= b.p3);
+    const int base = e >= b.p3 ? b.p3 : e >= b.p2 ? b.p2 : e >= b.p1 ? b.p1 : 0;
+    return (im * 4 + c) * cap + (e - base);
+}
 static const int kSortChunk = 128;     // compared-against keypoints per workgroup: small, so that ~600 workgroups share the work
 
 __global__ __launch_bounds__(256) void k_rank_partial(SortArgs a)
@@ -573,6 +590,8 @@ __global__ __launch_bounds__(256) void k_rank_scatter(SortArgs a)
     const int im = blockIdx.y;
     const int n = min(a.cand_n[im], a.cap);
     const int me = blockIdx.x * 256 + threadIdx.x;
+    int cls = -1;
+    int4 par = make_int4(0, 0, 0, 0);
     if (me < n) {
         int r = a.rank[im * a.cap + me];
         a.rank[im * a.cap + me] = 0;                 // ready for the next frame
@@ -584,9 +603,19 @@ __global__ __launch_bounds__(256) void k_rank_scatter(SortArgs a)
         const int win_size = (int)((20 + 1) * sc);
         if (win_size > kSmallWin) {
             const float win_offset = -(float)(win_size - 1) / 2;
-            int e = atomicAdd(&a.big_n[im], 1);
-            a.big_par[im * a.cap + e] = make_int4(r, win_size, cv_round_f(kp.x + win_offset), cv_round_f(kp.y - win_offset));
+            cls = big_class(win_size);
+            par = make_int4(r, win_size, cv_round_f(kp.x + win_offset), cv_round_f(kp.y - win_offset));
         }
+    }
+    // one atomic per wave and class (per-lane addresses would defeat the compiler's wave aggregation)
+    const int lane = threadIdx.x & 63;
+    for (int c = 0; c < 4; c++) {
+        const unsigned long long m = __ballot(cls == c);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&a.big_n[im * 4 + c], __popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (cls == c) a.big_par[(im * 4 + c) * a.cap + base + __popcll(m & ((1ull << lane) - 1))] = par;
     }
     if (me == 0) *a.out_n[im] = n;
     if (me == 0 && im == 0 && a.gate_nqa) {          // VO:556: both images need >= MIN_NUM_FEATURES keypoints, else no stereo matching
@@ -674,7 +703,8 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
     const int win_size = (int)((20 + 1) * s);
     if (win_size > kSmallWin) return;                  // large windows: k_descriptor64_big
     extern __shared__ __align__(16) unsigned char smem_desc[];
-    float* buf = reinterpret_cast<float*>(smem_desc);                 // [21][win_size]
+    float* buf = reinterpret_cast<float*>(smem_desc);                 // [21][bp]
+    const int bp = win_size | 1;                                      // odd pitch: the vertical pass walks 21 columns bank-conflict-free
     __shared__ AreaTab tab[21];
     __shared__ int PATCH[21][21];
     const uint8_t* __restrict__ img = a.img[im];
@@ -707,6 +737,48 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
         if (tid < 21) tab[tid] = area_tab(tid, win_size, scale);
         __syncthreads();
         // horizontal pass of resizeArea_ (over WIN columns j = image rows), lanes along WIN rows i = image x
+        const int xlo = start_x > 0 ? start_x : 0, xhi = start_x + win_size < w ? start_x + win_size : w;     // in-image columns
+        const bool vec_ok = (w & 3) == 0 && xlo < xhi;
+        if (vec_ok) {
+            // rows 4-byte aligned: one half-wave per destination column dx, four adjacent window
+            // rows (image columns) per lane from one aligned 32-bit load per tap; taps eight at a time, accumulated in order
+            // (a tap past c_end gets weight +0: b + v*0 == b exactly, the sums being non-negative)
+            const int half = tid >> 5, hl = tid & 31;
+            // window rows left or right of the image replicate the border column (WIN clamps x): copies of the first / last sum
+            const int xa = xlo & ~3, ilo = xlo - start_x, ihi = xhi - start_x;
+            for (int dx = half; dx < 21; dx += 8) {
+                const AreaTab tx = tab[dx];
+                const int c_begin = tx.has_first ? tx.sx1 - 1 : tx.sx1;
+                const int c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
+                float* brow = buf + dx * bp;
+                for (int x4 = xa + 4 * hl; x4 < xhi; x4 += 128) {
+                    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+                    for (int c0 = c_begin; c0 < c_end; c0 += 8) {
+                        unsigned v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                            v[q] = *reinterpret_cast<const unsigned*>(img + (unsigned)(y * w + x4));
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const int cc = c0 + q;
+                            float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
+                            alpha = cc < c_end ? alpha : 0.f;
+                            b0 += (int)(v[q] & 255u) * alpha; b1 += (int)((v[q] >> 8) & 255u) * alpha;
+                            b2 += (int)((v[q] >> 16) & 255u) * alpha; b3 += (int)(v[q] >> 24) * alpha;
+                        }
+                    }
+                    const int i = x4 - start_x;
+                    if (i >= ilo) brow[i] = b0;
+                    if (i + 1 >= ilo && i + 1 < ihi) brow[i + 1] = b1;
+                    if (i + 2 >= ilo && i + 2 < ihi) brow[i + 2] = b2;
+                    if (i + 3 >= ilo && i + 3 < ihi) brow[i + 3] = b3;
+                }
+                if (ilo > 0) { const float v = brow[ilo]; for (int i = hl; i < ilo; i += 32) brow[i] = v; }
+                if (ihi < win_size) { const float v = brow[ihi - 1]; for (int i = ihi + hl; i < win_size; i += 32) brow[i] = v; }
+            }
+        } else
         for (int it = tid; it < 21 * win_size; it += 256) {
             int dx = it / win_size, i = it - dx * win_size;
             const AreaTab tx = tab[dx];
@@ -729,7 +801,7 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
                     if (cc < c_end) b += v[q] * alpha;
                 }
             }
-            buf[it] = b;
+            buf[dx * bp + i] = b;
         }
         __syncthreads();
         // vertical pass (over WIN rows i)
@@ -738,7 +810,7 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
             const AreaTab ty = tab[dy];
             const int r_begin = ty.has_first ? ty.sx1 - 1 : ty.sx1;
             const int r_end = ty.has_last ? ty.sx2 + 1 : ty.sx2;
-            const float* col = buf + dx * win_size;
+            const float* col = buf + dx * bp;
             float sum = 0.f;
             for (int r = r_begin; r < r_end; r++) {
                 float beta = r < ty.sx1 ? ty.a_first : (r < ty.sx2 ? ty.a_mid : ty.a_last);
@@ -770,8 +842,9 @@ __global__ __launch_bounds__(256) void k_descriptor64_big_tabs(DescArgs a, AreaT
     const int im = blockIdx.y;
     const int id = blockIdx.x * 256 + threadIdx.x;
     const int e = id / 21, d = id - e * 21;
-    if (e >= a.big_n[im]) return;
-    const int win_size = a.big_par[im * a.cap + e].y;
+    const BigList bl = big_list(a.big_n, im);
+    if (e >= bl.total) return;
+    const int win_size = a.big_par[big_slot(bl, im, a.cap, e)].y;
     const double scale = 1. / ((double)21 / win_size);
     tabs[((size_t)im * a.cap + e) * 21 + d] = area_tab(d, win_size, scale);
 }
@@ -781,44 +854,58 @@ __device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__built
 // One task per WAVE (no workgroup barriers: four independent waves per workgroup, 8192 tasks in flight on the chip).
 __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int h, uint8_t* __restrict__ patch, const AreaTab* __restrict__ tabs)
 {
-    const int im = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nb = a.big_n[im];
+    const int im = blockIdx.y, lane = threadIdx.x & 63, wv = sgpr_i(threadIdx.x >> 6);
+    const BigList bl = big_list(a.big_n, im);
     __shared__ float s_bufrow[4][740];
     float* bufrow = s_bufrow[wv];
     const uint8_t* __restrict__ img = a.img[im];
-    const int t_first = blockIdx.x * 4 + wv, t_stride = gridDim.x * 4;
+    // Tasks t = 21*e + dx run down the cost-sorted list and are dealt to the waves in rounds of alternating direction
+    // (round r hands task r*NW + p to wave p, or to wave NW-1-p when r is odd): costs span 1..9 units, and this keeps the
+    // per-wave totals within about one task of each other, where a plain stride left the waves that drew the giants
+    // running long after the rest.  (A shared atomic cursor does not work here: ~55k device-scope increments of one
+    // address from 8 XCDs serialise at ~7 ns each.)
+    const int ntask = bl.total * 21, NW = gridDim.x * 4, wid = blockIdx.x * 4 + wv;
+    auto task_of = [&](int r) { return r * NW + ((r & 1) ? NW - 1 - wid : wid); };
     int4 par_next = make_int4(0, 0, 0, 0);
-    if (t_first < nb * 21) par_next = a.big_par[im * a.cap + t_first / 21];
-    for (int t = t_first; t < nb * 21; t += t_stride) {
-        const int e = t / 21, dx = t - e * 21;
+    if (task_of(0) < ntask) par_next = a.big_par[big_slot(bl, im, a.cap, task_of(0) / 21)];
+    for (int r = 0; r * NW < ntask; r++) {
+        const int t = task_of(r);
         const int4 par = par_next;                            // (sorted index, win_size, start_x, start_y) from k_rank_scatter
-        if (t + t_stride < nb * 21) par_next = a.big_par[im * a.cap + (t + t_stride) / 21];      // next task's, in flight meanwhile
-        const int win_size = par.y, start_x = par.z, start_y = par.w;
+        if (task_of(r + 1) < ntask) par_next = a.big_par[big_slot(bl, im, a.cap, task_of(r + 1) / 21)];      // next task's, in flight meanwhile
+        if (t >= ntask) continue;
+        const int e = t / 21, dx = t - e * 21;
+        // the task is the same for every lane: scalar registers, so that row clamps, row addresses and tap weights are SALU work
+        const int win_size = sgpr_i(par.y), start_x = sgpr_i(par.z), start_y = sgpr_i(par.w);
         const double inv_scale = (double)21 / win_size;
         const double scale = 1. / inv_scale;
         const int iscale = cv_round_d(scale);
         const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
         uint8_t* out = patch + ((size_t)im * a.cap + e) * kPatchStride;
         int* colsum = reinterpret_cast<int*>(bufrow);
-        // window inside the image and rows 4-byte aligned: aligned 32-bit loads cover four columns at a time
-        const bool vec_ok = (w & 3) == 0 && start_x >= 0 && start_x + win_size <= w;
-        const int xa = start_x & ~3;
+        // rows 4-byte aligned: aligned 32-bit loads cover four columns at a time over the window's in-image columns
+        // [xlo, xhi); window columns left or right of the image replicate the border column (WIN clamps x), so their
+        // sums are copies of the first / last in-image column's
+        const int xlo = start_x > 0 ? start_x : 0, xhi = start_x + win_size < w ? start_x + win_size : w;
+        const bool vec_ok = (w & 3) == 0 && xlo < xhi;
+        const int xa = xlo & ~3, ilo = xlo - start_x, ihi = xhi - start_x;
         if (area_fast) {
             // resizeAreaFast_: integer block sums (any order); column c = dy*iscale + sy of the window
             if (vec_ok) {
-                for (int x4 = xa + 4 * lane; x4 < start_x + win_size; x4 += 256) {
+                for (int x4 = xa + 4 * lane; x4 < xhi; x4 += 256) {
                     int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
                     for (int sx = 0; sx < iscale; sx++) {
                         int y = start_y - (dx * iscale + sx); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
-                        const unsigned v = *reinterpret_cast<const unsigned*>(img + (size_t)y * w + x4);
+                        const unsigned v = *reinterpret_cast<const unsigned*>(img + ((unsigned)(y * w) + (unsigned)x4));
                         s0 += v & 255u; s1 += (v >> 8) & 255u; s2 += (v >> 16) & 255u; s3 += v >> 24;
                     }
                     const int c = x4 - start_x;
-                    if (c >= 0) colsum[c] = s0;
-                    if (c + 1 >= 0 && c + 1 < win_size) colsum[c + 1] = s1;
-                    if (c + 2 >= 0 && c + 2 < win_size) colsum[c + 2] = s2;
-                    if (c + 3 >= 0 && c + 3 < win_size) colsum[c + 3] = s3;
+                    if (c >= ilo) colsum[c] = s0;
+                    if (c + 1 >= ilo && c + 1 < ihi) colsum[c + 1] = s1;
+                    if (c + 2 >= ilo && c + 2 < ihi) colsum[c + 2] = s2;
+                    if (c + 3 >= ilo && c + 3 < ihi) colsum[c + 3] = s3;
                 }
+                if (ilo > 0) { const int v = colsum[ilo]; for (int c = lane; c < ilo; c += 64) colsum[c] = v; }
+                if (ihi < win_size) { const int v = colsum[ihi - 1]; for (int c = ihi + lane; c < win_size; c += 64) colsum[c] = v; }
             } else
             for (int c = lane; c < win_size; c += 64) {
                 int x = start_x + c; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
@@ -848,14 +935,14 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
             const int c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
             if (vec_ok) {
                 // four adjacent window rows (image columns) per lane from one aligned 32-bit load per tap
-                for (int x4 = xa + 4 * lane; x4 < start_x + win_size; x4 += 256) {
+                for (int x4 = xa + 4 * lane; x4 < xhi; x4 += 256) {
                     float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
                     for (int c0 = c_begin; c0 < c_end; c0 += 16) {         // sixteen taps in flight, accumulated in order
                         unsigned v[16];
 #pragma unroll
                         for (int q = 0; q < 16; q++) {
                             int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
-                            v[q] = *reinterpret_cast<const unsigned*>(img + (size_t)y * w + x4);
+                            v[q] = *reinterpret_cast<const unsigned*>(img + ((unsigned)(y * w) + (unsigned)x4));       // scalar row offset + vector column: one 32-bit add
                         }
 #pragma unroll
                         for (int q = 0; q < 16; q++) {
@@ -868,11 +955,13 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
                         }
                     }
                     const int i = x4 - start_x;
-                    if (i >= 0) bufrow[i] = b0;
-                    if (i + 1 >= 0 && i + 1 < win_size) bufrow[i + 1] = b1;
-                    if (i + 2 >= 0 && i + 2 < win_size) bufrow[i + 2] = b2;
-                    if (i + 3 >= 0 && i + 3 < win_size) bufrow[i + 3] = b3;
+                    if (i >= ilo) bufrow[i] = b0;
+                    if (i + 1 >= ilo && i + 1 < ihi) bufrow[i + 1] = b1;
+                    if (i + 2 >= ilo && i + 2 < ihi) bufrow[i + 2] = b2;
+                    if (i + 3 >= ilo && i + 3 < ihi) bufrow[i + 3] = b3;
                 }
+                if (ilo > 0) { const float v = bufrow[ilo]; for (int i = lane; i < ilo; i += 64) bufrow[i] = v; }
+                if (ihi < win_size) { const float v = bufrow[ihi - 1]; for (int i = ihi + lane; i < win_size; i += 64) bufrow[i] = v; }
             } else
             for (int i = lane; i < win_size; i += 64) {
                 int x = start_x + i; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
@@ -913,13 +1002,14 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
 __global__ __launch_bounds__(256) void k_descriptor64_big_finish(DescArgs a, const uint8_t* __restrict__ patch)
 {
     const int im = blockIdx.y, tid = threadIdx.x;
-    const int nb = a.big_n[im];
+    const BigList bl = big_list(a.big_n, im);
+    const int nb = bl.total;
     __shared__ int PATCH[21][21];
     for (int e = blockIdx.x; e < nb; e += gridDim.x) {
         const uint8_t* src = patch + ((size_t)im * a.cap + e) * kPatchStride;
         for (int o = tid; o < 441; o += 256) PATCH[o / 21][o % 21] = src[o];
         __syncthreads();
-        describe_tail(a, im, a.big_par[im * a.cap + e].x, PATCH);
+        describe_tail(a, im, a.big_par[big_slot(bl, im, a.cap, e)].x, PATCH);
         __syncthreads();
     }
 }
@@ -1007,8 +1097,21 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             OctavePat op;
             make_octave(o, c->p.SURF_OCTAVES_LAYERS, w, h, &op);
             hipError_t e;
-            if (o == 0)      e = launch_hessian_c<0, 64, 32, 512>(c, nimg, op, thr);
-            else if (o == 1) e = launch_hessian_c<1, 32, 16, 512>(c, nimg, op, thr);
+            static const int v0 = getenv("UVO_O0V") ? atoi(getenv("UVO_O0V")) : 0, v1 = getenv("UVO_O1V") ? atoi(getenv("UVO_O1V")) : 0;
+            if (o == 0) {
+                if (v0 == 0)      e = launch_hessian_c<0, 64, 32, 512>(c, nimg, op, thr);
+                else if (v0 == 1) e = launch_hessian_c<0, 64, 32, 1024>(c, nimg, op, thr);
+                else if (v0 == 2) e = launch_hessian_c<0, 64, 16, 512>(c, nimg, op, thr);
+                else if (v0 == 3) e = launch_hessian_c<0, 64, 16, 256>(c, nimg, op, thr);
+                else              e = launch_hessian_c<0, 128, 16, 512>(c, nimg, op, thr);
+            }
+            else if (o == 1) {
+                if (v1 == 0)      e = launch_hessian_c<1, 32, 16, 512>(c, nimg, op, thr);
+                else if (v1 == 1) e = launch_hessian_c<1, 32, 32, 1024>(c, nimg, op, thr);
+                else if (v1 == 2) e = launch_hessian_c<1, 64, 16, 1024>(c, nimg, op, thr);
+                else if (v1 == 3) e = launch_hessian_c<1, 32, 32, 512>(c, nimg, op, thr);
+                else              e = launch_hessian_c<1, 64, 16, 512>(c, nimg, op, thr);
+            }
             else if (o == 2) e = launch_hessian_p<2, 32, 16, 512>(c, nimg, op, thr);
             else             e = launch_hessian_p<3, 16, 16, 256>(c, nimg, op, thr);
             UVO_HIP_TRY(c, e);
@@ -1028,7 +1131,7 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
         StageTimer t(c, ST_DESCRIPTOR);
         DescArgs da = { { c->d_img[0], c->d_img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
                         { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par, c->d_big_n, c->cap };
-        const size_t lds_small = sizeof(float) * 21 * 128;
+        const size_t lds_small = sizeof(float) * 21 * (kSmallWin | 1);
         hipLaunchKernelGGL(k_descriptor64_big_tabs, dim3((c->cap * 21 + 255) / 256, nimg), dim3(256), 0, c->stream, da, c->d_big_tabs);
         hipLaunchKernelGGL(k_descriptor64_big, dim3(1024, nimg), dim3(256), 0, c->stream, da, w, h, c->d_big_patch, c->d_big_tabs);
         hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(256, nimg), dim3(256), 0, c->stream, da, c->d_big_patch);

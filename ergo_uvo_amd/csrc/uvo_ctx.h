@@ -34,7 +34,7 @@ static const char* const kStageNames[ST_COUNT] = {
 
 // fixed slots of Ctx::d_counts / h_counts
 enum { CN_T = 0, CN_G = 1, CN_NINL = 2, CN_NQA = 3, CN_NQB = 4, CN_MEFF = 5, CN_NL = 6, CN_NR = 7,
-       CN_CAND0 = 8, CN_CAND1 = 9, CN_M = 10, CN_TRAW = 11, CN_AS0 = 12, CN_AS1 = 13, CN_BIG0 = 14, CN_BIG1 = 15, CN_TOTAL = 16 };
+       CN_CAND0 = 8, CN_CAND1 = 9, CN_M = 10, CN_TRAW = 11, CN_AS0 = 12, CN_AS1 = 13, CN_BIG0 = 14, CN_TOTAL = 22 };   // CN_BIG0 + 4*image + class: large-window keypoints per cost class (surf.hip big_class)
 // The gate ladder of the stereo loop, evaluated on the device by the last thread of the kernel that produces the count it
 // tests (no launches of their own): mode 1 = VO:567 after the stereo matcher's compaction, mode 2 = VO:626 after the
 // triangular matcher's.
@@ -65,7 +65,7 @@ struct Ctx {
     int plane_pw = 0, plane_stride = 0;
     uvo_keypoint* d_cand[2] = {nullptr, nullptr};// unsorted candidates
     int* d_cand_n = nullptr;                     // [2] raw atomic counters
-    int4* d_big_par = nullptr; int* d_big_n = nullptr;   // [2][cap] (sorted index, win, start_x, start_y) of large-window keypoints, [2] counts
+    int4* d_big_par = nullptr; int* d_big_n = nullptr;   // [2][4][cap] (sorted index, win, start_x, start_y) of large-window keypoints by cost class, [2][4] counts
     struct AreaTab* d_big_tabs = nullptr;        // [2][cap][21] resize tables of the large-window keypoints
     uint8_t* d_big_patch = nullptr;              // [2][cap][448] 21x21 patches of the large-window keypoints
     int* d_rank = nullptr;                       // [2][cap] sort ranks (zero between frames)
