@@ -616,14 +616,12 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
 
 // Stage B of one lane's pair (VO:634-648), on the lane's worker thread: wait for stage A, then solvePnPRansac.
 namespace uvo { extern bool g_bdbg; extern std::atomic<double> g_bstat[8]; double now_us(); void operator+=(std::atomic<double>& a, double v); }
-static void run_stage_b(uvo_ctx* L)
+static void run_stage_b(uvo_ctx* L, bool stage_a_ok)
 {
     Ctx::BJob& j = L->job;
     const Ctx* m = L->master ? L->master : L;
     j.st = UVO_OK; j.err.clear(); j.ran = j.ninl = j.ok = j.wrote = 0;
-    const double t0 = g_bdbg ? now_us() : 0;
-    if (hipEventSynchronize(L->evA[0]) != hipSuccess) { j.st = UVO_HIP_ERROR; j.err = "stage A of the pair failed"; return; }
-    if (g_bdbg) g_bstat[0] += now_us() - t0;
+    if (!stage_a_ok) { j.st = UVO_HIP_ERROR; j.err = "stage A of the pair failed"; return; }
     const int* hc = L->h_countsA[0];
     const int cap = L->cap;
     if (hc[CN_CAND0] > cap || hc[CN_CAND1] > cap || hc[CN_M] > cap || hc[CN_TRAW] > cap) return;    // reported by collect
@@ -647,7 +645,11 @@ static void lane_worker(uvo_ctx* L)
         L->cv.wait(lk, [&] { return L->quit || L->job.state == 1; });
         if (L->quit) return;
         lk.unlock();
-        {   // at most max_b PnP stages at a time over all lanes (the device runs only ~3 kernels concurrently: leave room for stage A)
+        // stage A's end is awaited before a PnP slot is taken, so a slot is never held idle
+        const double t0 = g_bdbg ? now_us() : 0;
+        const bool stage_a_ok = hipEventSynchronize(L->evA[0]) == hipSuccess;
+        if (g_bdbg) g_bstat[0] += now_us() - t0;
+        {   // at most max_b PnP stages at a time over all lanes: their thin, latency-bound kernels slow down and are slowed by stage A's
             Ctx* m = L->master ? L->master : L;
             std::unique_lock<std::mutex> g(m->b_mu);
             const double tw = g_bdbg ? now_us() : 0;
@@ -655,7 +657,7 @@ static void lane_worker(uvo_ctx* L)
             if (g_bdbg) g_bstat[5] += now_us() - tw;
             m->b_running++;
             g.unlock();
-            run_stage_b(L);
+            run_stage_b(L, stage_a_ok);
             g.lock();
             m->b_running--;
             m->b_cv.notify_one();

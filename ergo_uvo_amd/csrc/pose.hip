@@ -196,6 +196,7 @@ static const int kMaxPnpBatch = 8;
 struct PnpJob {
     const float* opts; const uvo_point2f* ipts; const int* subsets; double* models; int* hcount;
     int* inliers; double* ws; int* countsB; double* pose;
+    int* ninl_host;                          // pinned host mirrors (hcount, pose and ninl_host are written straight into host memory: no copies to queue)
     int G, nhyp, best;
 };
 struct PnpBatch { int n, cap; double fx, fy, cx, cy; float thr2; PnpJob job[kMaxPnpBatch]; };
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256) void k_pnp_refit(PnpBatch b)
     e.pcs = P::Arr{ws + 9 * (size_t)cap}; e.tmp = P::Arr{ws + 18 * (size_t)cap};
     double rvec[3], tvec[3];
     e.compute_pose(rvec, tvec);
-    if (threadIdx.x == 0) { pose[0] = rvec[0]; pose[1] = rvec[1]; pose[2] = rvec[2]; pose[3] = tvec[0]; pose[4] = tvec[1]; pose[5] = tvec[2]; }
+    if (threadIdx.x == 0) { pose[0] = rvec[0]; pose[1] = rvec[1]; pose[2] = rvec[2]; pose[3] = tvec[0]; pose[4] = tvec[1]; pose[5] = tvec[2]; jb.ninl_host[0] = n; }
 }
 
 // single 5-point solve when npoints == model_points (solvePnPRansac short-cut): reuse k_pnp_hyp with
@@ -406,8 +407,15 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
     b.cap = m->cap; b.fx = K[0]; b.fy = K[4]; b.cx = K[2]; b.cy = K[5];
     const double threshold = reprojectionError;
     b.thr2 = (float)(threshold * threshold);
-    int idx[kMaxPnpBatch];                    // batch slot -> job
-    int nb = 0, max_hyp = 0;
+    // Hypotheses are evaluated in rounds: the first kFirstHyp, then -- only if RANSAC's adaptive iteration count still
+    // reaches past them after the replayed scan -- all the rest.  The scan visits the same counts in the same order either
+    // way, so the chosen model is the one a single launch of all ITERATIONS_COUNT hypotheses would give; with the
+    // inlier ratios of a working odometry the count drops to a handful after the first good hypothesis and one round of
+    // 8 workgroups replaces 63 (whose 54 KB of LDS each would otherwise sit beside other pairs' stage-A kernels).
+    struct Scan { int job, G, niters, maxGood, best, last, iter, computed; uint64_t rng; bool active; };
+    Scan sc[kMaxPnpBatch];
+    PnpJob base[kMaxPnpBatch];                // full-range pointers of each active job
+    int ns = 0;
     for (int i = 0; i < n; i++) {
         PnpResult& r = res[i];
         r.st = UVO_OK; r.wrote = r.ok = r.ninl = 0;
@@ -415,64 +423,95 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
         if (G[i] < 4) { c->err = "solvePnPRansac needs at least 4 points (OpenCV asserts)"; r.st = UVO_TOO_FEW_POINTS; continue; }
         if (G[i] == 4) { c->err = "solvePnPRansac with exactly 4 points takes OpenCV's P3P path, which the reference never reaches; not implemented"; r.st = UVO_TOO_FEW_POINTS; continue; }
         if (niters0 > kMaxHyp) { c->err = "iterations_count exceeds the compiled hypothesis capacity (2048)"; r.st = UVO_CAPACITY; continue; }
-        int nhyp;
-        if (G[i] == modelPoints) {
-            for (int k = 0; k < 5; k++) c->h_subsets[k] = k;
-            nhyp = 1;
-        } else {
-            // getSubset (ptsetreg.cpp): cv::RNG((uint64)-1), uniform(0, count), redraw while duplicate
-            uint64_t state = (uint64_t)-1;
-            for (int it = 0; it < niters0; it++) {
-                int* sub = c->h_subsets + it * 5;
-                for (int k = 0; k < modelPoints; k++) {
-                    int idx_k;
-                    for (;;) {
-                        idx_k = (int)(rng_next(state) % (uint32_t)G[i]);
-                        bool dup = false;
-                        for (int q = 0; q < k; q++) dup = dup || sub[q] == idx_k;
-                        if (!dup) break;
+        // subsets are read from, and the per-hypothesis counts, the pose and the inlier count written to, pinned host memory
+        // by the kernels themselves: the queue holds launches only (each small copy costs ~10 us of stage-B latency)
+        PnpJob& j = base[ns];
+        j.opts = c->d_opts[0]; j.ipts = c->d_ipts[0]; j.subsets = c->h_subsets; j.models = c->d_models; j.hcount = c->h_hcount;
+        j.inliers = c->d_inliers; j.ws = c->d_refit; j.countsB = c->d_countsB; j.pose = c->h_pose; j.ninl_host = c->h_countsB;
+        j.G = G[i]; j.nhyp = 0; j.best = 0;
+        Scan& q = sc[ns++];
+        q.job = i; q.G = G[i]; q.niters = G[i] == modelPoints ? 1 : niters0; q.maxGood = 0; q.best = -1; q.last = 0; q.iter = 0; q.computed = 0;
+        q.rng = (uint64_t)-1;                 // getSubset (ptsetreg.cpp): cv::RNG((uint64)-1)
+        q.active = true;
+    }
+    if (ns == 0) return UVO_OK;
+    const int kFirstHyp = 64;
+    for (int round = 0; ; round++) {
+        int slot_of[kMaxPnpBatch], nb = 0, max_hyp = 0;
+        for (int k = 0; k < ns; k++) {
+            Scan& q = sc[k];
+            if (!q.active) continue;
+            Ctx* c = lanes[q.job];
+            const int count = round == 0 ? (q.niters < kFirstHyp ? q.niters : kFirstHyp) : q.niters - q.computed;
+            if (q.G == modelPoints) { for (int t = 0; t < 5; t++) c->h_subsets[t] = t; }
+            else {
+                // getSubset: uniform(0, count), redraw while duplicate; the generator runs on from round to round
+                for (int it = q.computed; it < q.computed + count; it++) {
+                    int* sub = c->h_subsets + it * 5;
+                    for (int t = 0; t < modelPoints; t++) {
+                        int idx_k;
+                        for (;;) {
+                            idx_k = (int)(rng_next(q.rng) % (uint32_t)q.G);
+                            bool dup = false;
+                            for (int u = 0; u < t; u++) dup = dup || sub[u] == idx_k;
+                            if (!dup) break;
+                        }
+                        sub[t] = idx_k;
                     }
-                    sub[k] = idx_k;
                 }
             }
-            nhyp = niters0;
+            PnpJob& j = b.job[nb];
+            j = base[k];
+            j.subsets = base[k].subsets + (size_t)q.computed * 5; j.models = base[k].models + (size_t)q.computed * 6; j.hcount = base[k].hcount + q.computed;
+            j.nhyp = count;
+            if (count > max_hyp) max_hyp = count;
+            slot_of[nb++] = k;
         }
-        UVO_HIP_TRY(m, hipMemcpyAsync(c->d_subsets, c->h_subsets, sizeof(int) * 5 * nhyp, hipMemcpyHostToDevice, st));
-        PnpJob& j = b.job[nb];
-        j.opts = c->d_opts[0]; j.ipts = c->d_ipts[0]; j.subsets = c->d_subsets; j.models = c->d_models; j.hcount = c->d_hcount;
-        j.inliers = c->d_inliers; j.ws = c->d_refit; j.countsB = c->d_countsB; j.pose = c->d_pose;
-        j.G = G[i]; j.nhyp = nhyp; j.best = 0;
-        if (nhyp > max_hyp) max_hyp = nhyp;
-        idx[nb++] = i;
+        if (nb == 0) break;
+        b.n = nb;
+        {
+            StageTimer t(m, ST_PNP_HYP, st);
+            hipLaunchKernelGGL(k_pnp_hyp, dim3((max_hyp + kHypGroups - 1) / kHypGroups, nb), dim3(64), hyp_lds, st, b);
+            UVO_HIP_TRY(m, hipGetLastError());
+        }
+        bool any_scored = false;
+        for (int s_ = 0; s_ < nb; s_++) any_scored = any_scored || sc[slot_of[s_]].G != modelPoints;
+        if (any_scored) {
+            StageTimer t(m, ST_PNP_SCORE, st);
+            hipLaunchKernelGGL(k_pnp_score, dim3(max_hyp, nb), dim3(256), 0, st, b);
+            UVO_HIP_TRY(m, hipGetLastError());
+        }
+        for (int s_ = 0; s_ < nb; s_++) {
+            Ctx* c = lanes[sc[slot_of[s_]].job];
+            if (sc[slot_of[s_]].G == modelPoints) UVO_HIP_TRY(m, hipMemcpyAsync(c->h_pose, c->d_models, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
+        }
+        UVO_HIP_TRY(m, hipStreamSynchronize(st));
+        // replay of RANSACPointSetRegistrator::run's sequential scan over the counts that exist so far, per job
+        for (int s_ = 0; s_ < nb; s_++) {
+            Scan& q = sc[slot_of[s_]];
+            Ctx* c = lanes[q.job];
+            q.computed += b.job[s_].nhyp;
+            if (q.G == modelPoints) { q.active = false; continue; }
+            for (; q.iter < q.niters && q.iter < q.computed; q.iter++) {
+                q.last = q.iter;
+                const int goodCount = c->h_hcount[q.iter];
+                if (goodCount > (q.maxGood > modelPoints - 1 ? q.maxGood : modelPoints - 1)) {
+                    q.best = q.iter; q.maxGood = goodCount;
+                    q.niters = ransac_update_num_iters(confidence, (double)(q.G - goodCount) / q.G, modelPoints, q.niters);
+                }
+            }
+            if (q.iter >= q.niters) q.active = false;       // the scan is over; otherwise it needs hypotheses past `computed`
+        }
     }
-    if (nb == 0) return UVO_OK;
-    b.n = nb;
-    {
-        StageTimer t(m, ST_PNP_HYP, st);
-        hipLaunchKernelGGL(k_pnp_hyp, dim3((max_hyp + kHypGroups - 1) / kHypGroups, nb), dim3(64), hyp_lds, st, b);
-        UVO_HIP_TRY(m, hipGetLastError());
-    }
-    {
-        StageTimer t(m, ST_PNP_SCORE, st);
-        hipLaunchKernelGGL(k_pnp_score, dim3(max_hyp, nb), dim3(256), 0, st, b);
-        UVO_HIP_TRY(m, hipGetLastError());
-    }
-    for (int s = 0; s < nb; s++) {
-        Ctx* c = lanes[idx[s]];
-        if (b.job[s].G == modelPoints) UVO_HIP_TRY(m, hipMemcpyAsync(c->h_pose, c->d_models, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
-        else UVO_HIP_TRY(m, hipMemcpyAsync(c->h_hcount, c->d_hcount, sizeof(int) * b.job[s].nhyp, hipMemcpyDeviceToHost, st));
-    }
-    UVO_HIP_TRY(m, hipStreamSynchronize(st));
     if (g_bdbg) { g_bstat[1] += now_us() - t_b0; t_b0 = now_us(); }
-    // replay of RANSACPointSetRegistrator::run's sequential scan, per job
     PnpBatch b2 = b;
     int idx2[kMaxPnpBatch], nb2 = 0;
     bool need_sync = false;
-    for (int s = 0; s < nb; s++) {
-        Ctx* c = lanes[idx[s]];
-        PnpResult& r = res[idx[s]];
-        const int Gs = b.job[s].G;
-        if (Gs == modelPoints) {              // npoints == model_points: the single model, all five points inliers
+    for (int k = 0; k < ns; k++) {
+        const Scan& q = sc[k];
+        Ctx* c = lanes[q.job];
+        PnpResult& r = res[q.job];
+        if (q.G == modelPoints) {              // npoints == model_points: the single model, all five points inliers
             memcpy(r.rvec, c->h_pose, sizeof(double) * 3); memcpy(r.tvec, c->h_pose + 3, sizeof(double) * 3);
             int ids[5] = {0, 1, 2, 3, 4};
             UVO_HIP_TRY(m, hipMemcpyAsync(c->d_inliers, ids, sizeof(ids), hipMemcpyHostToDevice, st));
@@ -480,24 +519,15 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
             r.wrote = 1; r.ok = 1; r.ninl = 5;
             continue;
         }
-        int niters = niters0, maxGoodCount = 0, best = -1, last = 0;
-        for (int iter = 0; iter < niters; iter++) {
-            last = iter;
-            int goodCount = c->h_hcount[iter];
-            if (goodCount > (maxGoodCount > modelPoints - 1 ? maxGoodCount : modelPoints - 1)) {
-                best = iter; maxGoodCount = goodCount;
-                niters = ransac_update_num_iters(confidence, (double)(Gs - goodCount) / Gs, modelPoints, niters);
-            }
-        }
-        if (best < 0) {
+        if (q.best < 0) {
             // RANSAC failed: OpenCV hands back the last hypothesis' rvec/tvec and no inliers
-            UVO_HIP_TRY(m, hipMemcpyAsync(c->h_pose, c->d_models + (size_t)last * 6, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
+            UVO_HIP_TRY(m, hipMemcpyAsync(c->h_pose, c->d_models + (size_t)q.last * 6, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
             need_sync = true;
             r.wrote = 2;                      // pose arrives with the final sync
             continue;
         }
-        b2.job[nb2] = b.job[s]; b2.job[nb2].best = best;
-        idx2[nb2++] = idx[s];
+        b2.job[nb2] = base[k]; b2.job[nb2].best = q.best;
+        idx2[nb2++] = q.job;
     }
     if (nb2 > 0) {
         b2.n = nb2;
@@ -509,12 +539,7 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
         hipLaunchKernelGGL(k_pnp_refit, dim3(nb2), dim3(256), refit_lds, st, b2);
         UVO_HIP_TRY(m, hipGetLastError());
     }
-    for (int s = 0; s < nb2; s++) {
-        Ctx* c = lanes[idx2[s]];
-        UVO_HIP_TRY(m, hipMemcpyAsync(c->h_pose, c->d_pose, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
-        UVO_HIP_TRY(m, hipMemcpyAsync(c->h_countsB, c->d_countsB, sizeof(int), hipMemcpyDeviceToHost, st));
-        need_sync = true;
-    }
+    if (nb2 > 0) need_sync = true;
     if (g_bdbg) { g_bstat[2] += now_us() - t_b0; t_b0 = now_us(); }
     if (need_sync) UVO_HIP_TRY(m, hipStreamSynchronize(st));
     if (g_bdbg) { g_bstat[3] += now_us() - t_b0; g_bstat[4] += 1; }
@@ -532,7 +557,7 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
     if (getenv("UVO_DBG_PHASE")) {
         long long k[16];
         UVO_HIP_TRY(m, hipMemcpyFromSymbol(k, HIP_SYMBOL(g_hyp_clk), sizeof(k)));
-        fprintf(stderr, "[uvo] pnp batch %d; hyp phases (us): ctrl %.1f bary %.1f mtm %.1f svd12 %.1f betas %.1f pcs %.1f sums %.1f svd3 %.1f reproj %.1f\n", nb,
+        fprintf(stderr, "[uvo] pnp batch %d; hyp phases (us): ctrl %.1f bary %.1f mtm %.1f svd12 %.1f betas %.1f pcs %.1f sums %.1f svd3 %.1f reproj %.1f\n", ns,
                 (k[1]-k[0])*0.01, (k[2]-k[1])*0.01, (k[3]-k[2])*0.01, (k[4]-k[3])*0.01, (k[5]-k[4])*0.01, (k[6]-k[5])*0.01,
                 (k[7]-k[6])*0.01, (k[8]-k[7])*0.01, (k[9]-k[8])*0.01);
         fprintf(stderr, "[uvo]   hyp betas split (us): L %.1f  find_betas %.1f  gauss_newton %.1f  ccs %.1f\n", (k[10]-k[4])*0.01, (k[11]-k[10])*0.01,

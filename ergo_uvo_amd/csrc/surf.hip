@@ -1097,21 +1097,10 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             OctavePat op;
             make_octave(o, c->p.SURF_OCTAVES_LAYERS, w, h, &op);
             hipError_t e;
-            static const int v0 = getenv("UVO_O0V") ? atoi(getenv("UVO_O0V")) : 0, v1 = getenv("UVO_O1V") ? atoi(getenv("UVO_O1V")) : 0;
-            if (o == 0) {
-                if (v0 == 0)      e = launch_hessian_c<0, 64, 32, 512>(c, nimg, op, thr);
-                else if (v0 == 1) e = launch_hessian_c<0, 64, 32, 1024>(c, nimg, op, thr);
-                else if (v0 == 2) e = launch_hessian_c<0, 64, 16, 512>(c, nimg, op, thr);
-                else if (v0 == 3) e = launch_hessian_c<0, 64, 16, 256>(c, nimg, op, thr);
-                else              e = launch_hessian_c<0, 128, 16, 512>(c, nimg, op, thr);
-            }
-            else if (o == 1) {
-                if (v1 == 0)      e = launch_hessian_c<1, 32, 16, 512>(c, nimg, op, thr);
-                else if (v1 == 1) e = launch_hessian_c<1, 32, 32, 1024>(c, nimg, op, thr);
-                else if (v1 == 2) e = launch_hessian_c<1, 64, 16, 1024>(c, nimg, op, thr);
-                else if (v1 == 3) e = launch_hessian_c<1, 32, 32, 512>(c, nimg, op, thr);
-                else              e = launch_hessian_c<1, 64, 16, 512>(c, nimg, op, thr);
-            }
+            // octave 0: 64 x 16 samples per workgroup = 40 KB of LDS (20 KB det planes + 20 KB integral tile): four per CU, and
+            // two still fit beside a 54 KB k_pnp_hyp workgroup of another pair; 64 x 32 (66 KB) was slower in the pipeline
+            if (o == 0)      e = launch_hessian_c<0, 64, 16, 512>(c, nimg, op, thr);
+            else if (o == 1) e = launch_hessian_c<1, 32, 16, 512>(c, nimg, op, thr);
             else if (o == 2) e = launch_hessian_p<2, 32, 16, 512>(c, nimg, op, thr);
             else             e = launch_hessian_p<3, 16, 16, 256>(c, nimg, op, thr);
             UVO_HIP_TRY(c, e);

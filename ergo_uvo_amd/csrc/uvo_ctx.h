@@ -143,7 +143,7 @@ struct Ctx {
         int ran = 0, ninl = 0, ok = 0, wrote = 0; double rvec[3], tvec[3];
     } job;
     std::thread worker; std::mutex mu; std::condition_variable cv; bool quit = false;
-    std::mutex b_mu; std::condition_variable b_cv; int b_running = 0, max_b = 2;   // master: PnP stages running / allowed at once
+    std::mutex b_mu; std::condition_variable b_cv; int b_running = 0, max_b = 3;   // master: PnP stages running / allowed at once
 
     // last-step bookkeeping for uvo_stereo_get
     int last_nL = 0, last_nR = 0, last_M = 0, last_T = 0, last_G = 0, last_ninl = 0;
