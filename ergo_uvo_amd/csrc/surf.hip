@@ -13,6 +13,8 @@
 // All float arithmetic keeps OpenCV's operation order (int box sum * float weight accumulated in
 // double; no FMA contraction) so results are bit-identical to the CPU restatement.
 #include "uvo_ctx.h"
+#include <type_traits>
+#include <string.h>
 #include "uvo_math.h"
 
 namespace uvo {
@@ -23,7 +25,7 @@ namespace uvo {
 // planes[im]: the integral image de-interleaved by (row & 3, column & 3): 16 planes of ph x pw, plane (ry, rx) holds
 // S[4i + ry][4j + rx] at [i][j].  The step-4 / step-8 sample walks of octaves 2 and 3 become unit / two-element
 // strides in them (coalesced), where the row-major image gives one useful word per 16 or 32 bytes.
-struct ImgPair { const uint8_t* img[2]; int32_t* sum[2]; int32_t* planes[2]; int pw, pstride; int* cand_n; int* big_n; };
+struct ImgPair { const uint8_t* img[2]; int32_t* sum[2]; int32_t* planes[2]; int pw, pstride; int* cand_n; int* big_n; int* surv_n; };
 static const int kSegRows = 32;
 
 __global__ __launch_bounds__(256) void k_integral_rows(ImgPair ip, int w, int h)
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256) void k_integral_rows(ImgPair ip, int w, int h)
     for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) { run += src[x]; dst[x + 1] = run; } }
     if (tid == 0) dst[0] = 0;
     if (y == 0) { int32_t* r0 = ip.sum[im]; for (int x = tid; x < sw; x += 256) r0[x] = 0; }
-    if (y == 0 && tid < 4) { if (tid == 0) ip.cand_n[im] = 0; ip.big_n[im * 4 + tid] = 0; }       // the frame's candidate / large-window counters start at zero
+    if (y == 0 && tid < 4) { if (tid == 0) { ip.cand_n[im] = 0; if (im == 0) *ip.surv_n = 0; } ip.big_n[im * 4 + tid] = 0; }       // the frame's candidate / large-window counters start at zero
 }
 
 __global__ __launch_bounds__(256) void k_integral_colsum(ImgPair ip, int w, int h, int32_t* part, int nseg)
@@ -149,6 +151,7 @@ __device__ __forceinline__ void haar_response(const LayerPat& lp, SumAt S, float
         d += (float)v * lp.w[k];
     }
     *pdy = (float)d;
+    if (!pdxy) return;                     // the Laplacian sign needs dx + dy only
     d = 0;
 #pragma unroll
     for (int k = 6; k < 10; k++) {
@@ -179,11 +182,11 @@ __device__ __forceinline__ void solve3f(const float a[3][3], const float b[3], f
 
 struct CandOut { uvo_keypoint* cand[2]; int* count; int cap; };
 
-// findMaximaInLayer's tail for one 3x3x3 maximum: centre, interpolateKeypoint, SURFInvoker's size check,
-// append.  `trace` is dx + dy of the centre sample.
+// findMaximaInLayer's tail for one 3x3x3 maximum: centre, interpolateKeypoint, SURFInvoker's size check
+// (the caller appends).  `trace` is dx + dy of the centre sample.
 template <int STEP>
-__device__ __forceinline__ void emit_keypoint(float N9[3][9], float val0, float trace, int i, int j, int size, int ds, int octave,
-                                              int w, int h, int im, const CandOut& out)
+__device__ __forceinline__ bool make_keypoint(float N9[3][9], float val0, float trace, int i, int j, int size, int ds, int octave,
+                                              int w, int h, uvo_keypoint* pkp)
 {
     int sum_i = STEP * (i - (size / 2) / STEP);
     int sum_j = STEP * (j - (size / 2) / STEP);
@@ -198,7 +201,7 @@ __device__ __forceinline__ void emit_keypoint(float N9[3][9], float val0, float 
     solve3f(A, bb, x);
     bool ok = (x[0] != 0 || x[1] != 0 || x[2] != 0) &&
               fabsf(x[0]) <= 1 && fabsf(x[1]) <= 1 && fabsf(x[2]) <= 1;
-    if (!ok) return;
+    if (!ok) return false;
     uvo_keypoint kp;
     kp.x = center_j + x[0] * STEP;
     kp.y = center_i + x[1] * STEP;
@@ -210,9 +213,9 @@ __device__ __forceinline__ void emit_keypoint(float N9[3][9], float val0, float 
     // SURFInvoker: keypoints whose gradient wavelet exceeds the integral image are dropped
     float s = kp.size * 1.2f / 9.0f;
     int grad_wav_size = 2 * cv_round_f(2 * s);
-    if (h + 1 < grad_wav_size || w + 1 < grad_wav_size) return;
-    int slot = atomicAdd(&out.count[im], 1);
-    if (slot < out.cap) out.cand[im][slot] = kp;
+    if (h + 1 < grad_wav_size || w + 1 < grad_wav_size) return false;
+    *pkp = kp;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -298,6 +301,14 @@ struct __attribute__((packed, aligned(4))) SumQuad { int32_t a, b, c, d; };     
     constexpr float wd0 = LC::wt(1, 1, 1, 4, 4), wd1 = LC::wt(-1, 5, 1, 8, 4), wd2 = LC::wt(-1, 1, 5, 4, 8), wd3 = LC::wt(1, 5, 5, 8, 8); \
     (void)c0; (void)c9
 
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+
+// det plane of layer L (1..3) of a workgroup's TW x TH samples from the integral tile in LDS; 0 where the template does not fit
 template <int O, int L, int TW, int TH, int NT>
 __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, float* __restrict__ sdet, const OctavePat& op,
                                             int px0, int py0)
@@ -322,7 +333,7 @@ __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, f
             const int32_t* base = stile + ry * (STEP * STEP * PW) + rx;
             UVO_HESSIAN_DET(SV, det)
         }
-        sdet[(L * TH + ry) * TW + rx] = det;
+        sdet[((L - 1) * TH + ry) * TW + rx] = det;
     }
 #undef SV
 }
@@ -350,13 +361,167 @@ __device__ __forceinline__ void det_layer_p(const int32_t* __restrict__ planes, 
             const int32_t* base = planes + (size_t)(oi * Q) * pw + oj * Q;
             UVO_HESSIAN_DET(SVP, det)
         }
-        sdet[(L * TH + ry) * TW + rx] = det;
+        sdet[((L - 1) * TH + ry) * TW + rx] = det;
     }
 #undef SVP
 }
 
+// ------------------------------------------------------------------------------------------
+// Non-maximum suppression with lazy outer layers, in two kernels.  findMaximaInLayer needs, for each middle layer
+// L = 1..3, the 3 x 3 x 3 neighbourhood in layers L-1, L, L+1.  Layers 1..3 are centres and are computed for every
+// sample (`sdet`, three planes); layers 0 and 4 only ever appear as neighbours, so they are evaluated just around the
+// samples that already beat their threshold, their eight in-layer neighbours and the adjacent layers held in sdet:
+// a few thousand per frame instead of 2/5 of all determinants.  The detection kernels append those survivors, with the
+// neighbourhood values they have, to a global list; k_hessian_finish (every octave in one launch) evaluates the missing
+// nine determinants, makes the last comparison and emits the keypoint.  Keeping the interpolation / Laplacian-sign code
+// out of the detection kernels also keeps them at ~60 VGPRs.  The comparisons made are the same ones, so the keypoints
+// are the same.
+// ------------------------------------------------------------------------------------------
+struct SurvOut { Survivor* list; int* count; int cap; };
+
+// LDS of nms_survivors: the workgroup's survivor list, its length and its base in the global list.  Survivors are strict 3 x 3
+// maxima of their own layer, so no two are adjacent: at most ceil((TW-2)/2) x ceil((TH-2)/2) per layer, in three layers.
+template <int TW, int TH>
+struct NmsLds { static constexpr int kList = 3 * ((TW - 1) / 2) * ((TH - 1) / 2), kWords = kList + 2; };
+
+template <int TW, int TH, int NT>
+__device__ __forceinline__ void nms_survivors(const float* __restrict__ sdet, unsigned* __restrict__ s_list, const OctavePat& op, float thr,
+                                              int px0, int py0, int im, const SurvOut& sv)
+{
+    const int tid = threadIdx.x;
+    int* s_n = reinterpret_cast<int*>(s_list + NmsLds<TW, TH>::kList);       // [0] count, [1] base
+    if (tid == 0) s_n[0] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int L = 1; L <= 3; L++) {
+        const LayerPat& lp = op.L[L];
+        if (lp.samples_i == 0 || op.L[L + 1].samples_i == 0) continue;
+        const int m = op.nms_margin[L - 1];
+        for (int idx = tid; idx < (TW - 2) * (TH - 2); idx += NT) {
+            const int ry = idx / (TW - 2) + 1, rx = idx - (ry - 1) * (TW - 2) + 1;
+            const int i = py0 + ry, j = px0 + rx;
+            if (i < m || i >= op.rows - m || j < m || j >= op.cols - m) continue;
+            const float* d2 = sdet + ((L - 1) * TH + ry) * TW + rx;
+            const float val0 = d2[0];
+            if (!(val0 > thr)) continue;
+            bool is_max = val0 > d2[-TW-1] && val0 > d2[-TW] && val0 > d2[-TW+1] && val0 > d2[-1] && val0 > d2[1] &&
+                          val0 > d2[TW-1] && val0 > d2[TW] && val0 > d2[TW+1];
+            const float* d1 = d2 - TH * TW;
+            const float* d3 = d2 + TH * TW;
+            if (is_max && L <= 2)
+                is_max = val0 > d3[-TW-1] && val0 > d3[-TW] && val0 > d3[-TW+1] && val0 > d3[-1] && val0 > d3[0] && val0 > d3[1] &&
+                         val0 > d3[TW-1] && val0 > d3[TW] && val0 > d3[TW+1];
+            if (is_max && L >= 2)
+                is_max = val0 > d1[-TW-1] && val0 > d1[-TW] && val0 > d1[-TW+1] && val0 > d1[-1] && val0 > d1[0] && val0 > d1[1] &&
+                         val0 > d1[TW-1] && val0 > d1[TW] && val0 > d1[TW+1];
+            if (is_max) s_list[atomicAdd(&s_n[0], 1)] = (unsigned)L | ((unsigned)ry << 8) | ((unsigned)rx << 16);
+        }
+    }
+    __syncthreads();
+    // one global atomic per workgroup (a device-scope increment of one address costs ~7 ns chip-wide, and its wave a round trip)
+    const int nloc = s_n[0];
+    if (nloc == 0) return;
+    if (tid == 0) s_n[1] = atomicAdd(sv.count, nloc);
+    __syncthreads();
+    const int base = s_n[1];
+    for (int t = tid; t < nloc; t += NT) {
+        if (base + t >= sv.cap) continue;             // k_hessian_finish turns the overflow into the capacity error
+        const unsigned e = s_list[t];
+        const int L = e & 255u, ry = (e >> 8) & 255u, rx = e >> 16;
+        const float* d2 = sdet + ((L - 1) * TH + ry) * TW + rx;
+        const float* d1 = d2 - TH * TW;
+        const float* d3 = d2 + TH * TW;
+        Survivor* r = sv.list + base + t;
+        r->im = im; r->octave = op.octave; r->L = L; r->i = py0 + ry; r->j = px0 + rx;
+        const int nb[9] = { -TW-1, -TW, -TW+1, -1, 0, 1, TW-1, TW, TW+1 };
+#pragma unroll
+        for (int b = 0; b < 9; b++) {
+            r->n9[b] = L >= 2 ? d1[nb[b]] : 0.f;
+            r->n9[9 + b] = d2[nb[b]];
+            r->n9[18 + b] = L <= 2 ? d3[nb[b]] : 0.f;
+        }
+    }
+}
+
+// Sixteen lanes per survivor, 64 survivors per workgroup: lanes 0..8 evaluate the nine determinants of the outer layer (0
+// below layer 1, 4 above layer 3) from the integral image with the run-time box patterns (calcLayerDetAndTrace's
+// arithmetic, as k_hessian_layer_debug); lane 0 makes the comparison against them and runs findMaximaInLayer's tail.  The
+// workgroup's keypoints are collected in LDS and appended with one atomic per image.
+static const int kFinishPerWg = 32;
+__global__ __launch_bounds__(256) void k_hessian_finish(SurvOut sv, const OctavePat* __restrict__ ops, ImgPair ip, int w, int h, CandOut out)
+{
+    __shared__ uvo_keypoint s_kp[2][kFinishPerWg];
+    __shared__ int s_cnt[2], s_base[2];
+    const int grp = threadIdx.x >> 4, k = threadIdx.x & 15;
+    const int n = min(*sv.count, sv.cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && *sv.count > sv.cap) atomicAdd(&out.count[0], out.cap + 1);     // more survivors than the list holds: reported as the keypoint capacity error
+    if (blockIdx.x * kFinishPerWg >= n) return;
+    if (threadIdx.x < 2) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int sw = w + 1;
+#pragma unroll 1
+    for (int rd = 0; rd < kFinishPerWg / 16; rd++) {
+        const int t = blockIdx.x * kFinishPerWg + rd * 16 + grp;
+        if (t >= n) continue;                            // whole groups skip together
+        const Survivor* r = sv.list + t;
+        const int im = r->im, L = r->L, i = r->i, j = r->j;
+        const OctavePat& op = ops[r->octave];
+        const int step = op.step;
+        const int32_t* __restrict__ gsum = ip.sum[im];
+        float det = 0.f;
+        if (L != 2 && k < 9) {
+            const LayerPat& lo = op.L[L == 1 ? 0 : 4];
+            const int oi = i + k / 3 - 1 - lo.margin, oj = j + k % 3 - 1 - lo.margin;
+            if (oi >= 0 && oi < lo.samples_i && oj >= 0 && oj < lo.samples_j) {
+                const int32_t* o = gsum + (size_t)(oi * step) * sw + oj * step;
+                float dx, dy, dxy;
+                haar_response(lo, [&](int yy, int xx) { return o[(size_t)yy * sw + xx]; }, &dx, &dy, &dxy);
+                det = dx * dy - 0.81f * dxy * dxy;
+            }
+        }
+        float o9[9];
+        const int g0 = (threadIdx.x & 63) & ~15;          // first lane of this group within the wave
+#pragma unroll
+        for (int b = 0; b < 9; b++) o9[b] = __shfl(det, g0 + b);
+        if (k != 0) continue;
+        float N9[3][9];
+#pragma unroll
+        for (int b = 0; b < 9; b++) { N9[0][b] = r->n9[b]; N9[1][b] = r->n9[9 + b]; N9[2][b] = r->n9[18 + b]; }
+        const float val0 = N9[1][4];
+        if (L != 2) {
+            bool is_max = true;
+#pragma unroll
+            for (int b = 0; b < 9; b++) { is_max = is_max && (val0 > o9[b]); if (L == 1) N9[0][b] = o9[b]; else N9[2][b] = o9[b]; }
+            if (!is_max) continue;
+        }
+        const LayerPat& lp = op.L[L];
+        float dx, dy;
+        {
+            const int32_t* o = gsum + (size_t)((i - lp.margin) * step) * sw + (j - lp.margin) * step;
+            haar_response(lp, [&](int yy, int xx) { return o[(size_t)yy * sw + xx]; }, &dx, &dy, nullptr);
+        }
+        const int ds = lp.size - op.L[L - 1].size;
+        uvo_keypoint kp;
+        bool ok;
+        switch (step) {
+        case 1:  ok = make_keypoint<1>(N9, val0, dx + dy, i, j, lp.size, ds, op.octave, w, h, &kp); break;
+        case 2:  ok = make_keypoint<2>(N9, val0, dx + dy, i, j, lp.size, ds, op.octave, w, h, &kp); break;
+        case 4:  ok = make_keypoint<4>(N9, val0, dx + dy, i, j, lp.size, ds, op.octave, w, h, &kp); break;
+        default: ok = make_keypoint<8>(N9, val0, dx + dy, i, j, lp.size, ds, op.octave, w, h, &kp); break;
+        }
+        if (ok) s_kp[im][atomicAdd(&s_cnt[im], 1)] = kp;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_cnt[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&out.count[threadIdx.x], s_cnt[threadIdx.x]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * kFinishPerWg; e += 256) {
+        const int im = e / kFinishPerWg, q = e - im * kFinishPerWg;
+        if (q < s_cnt[im] && s_base[im] + q < out.cap) out.cand[im][s_base[im] + q] = s_kp[im][q];
+    }
+}
+
 template <int O, int TW, int TH, int NT>
-__global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, OctavePat op, float thr, CandOut out)
+__global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, OctavePat op, float thr, SurvOut sv)
 {
     using OC = OctC<O>;
     constexpr int STEP = OC::STEP;
@@ -367,8 +532,8 @@ __global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, 
     const int tid = threadIdx.x, im = blockIdx.z;
     const int sw = w + 1;
     const int32_t* __restrict__ gsum = ip.sum[im];
-    float* sdet = reinterpret_cast<float*>(smem);                    // [5][TH][TW]
-    int32_t* stile = reinterpret_cast<int32_t*>(smem + sizeof(float) * 5 * TH * TW);   // [THs][STEP][PW]
+    float* sdet = reinterpret_cast<float*>(smem);                    // [3][TH][TW]: layers 1..3
+    int32_t* stile = reinterpret_cast<int32_t*>(smem + sizeof(float) * 3 * TH * TW);   // [THs][STEP][PW]
 
     const int px0 = blockIdx.x * (TW - 2) - 1, py0 = blockIdx.y * (TH - 2) - 1;
     const int sx0 = px0 * STEP + OC::LO, sy0 = py0 * STEP + OC::LO;
@@ -406,99 +571,26 @@ __global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, 
         }
     }
     __syncthreads();
-    det_layer_c<O, 0, TW, TH, NT>(stile, sdet, op, px0, py0);
     det_layer_c<O, 1, TW, TH, NT>(stile, sdet, op, px0, py0);
     det_layer_c<O, 2, TW, TH, NT>(stile, sdet, op, px0, py0);
     det_layer_c<O, 3, TW, TH, NT>(stile, sdet, op, px0, py0);
-    det_layer_c<O, 4, TW, TH, NT>(stile, sdet, op, px0, py0);
     __syncthreads();
-
-#pragma unroll 1
-    for (int L = 1; L <= 3; L++) {
-        const LayerPat& lp = op.L[L];
-        if (lp.samples_i == 0 || op.L[L + 1].samples_i == 0) continue;
-        const int m = op.nms_margin[L - 1];
-        for (int idx = tid; idx < (TW - 2) * (TH - 2); idx += NT) {
-            int ry = idx / (TW - 2) + 1, rx = idx - (ry - 1) * (TW - 2) + 1;
-            int i = py0 + ry, j = px0 + rx;
-            if (i < m || i >= op.rows - m || j < m || j >= op.cols - m) continue;
-            const float* d2 = sdet + (L * TH + ry) * TW + rx;
-            float val0 = d2[0];
-            if (!(val0 > thr)) continue;
-            const float* d1 = d2 - TH * TW;
-            const float* d3 = d2 + TH * TW;
-            float N9[3][9] = {
-                { d1[-TW-1], d1[-TW], d1[-TW+1], d1[-1], d1[0], d1[1], d1[TW-1], d1[TW], d1[TW+1] },
-                { d2[-TW-1], d2[-TW], d2[-TW+1], d2[-1], d2[0], d2[1], d2[TW-1], d2[TW], d2[TW+1] },
-                { d3[-TW-1], d3[-TW], d3[-TW+1], d3[-1], d3[0], d3[1], d3[TW-1], d3[TW], d3[TW+1] } };
-            bool is_max = true;
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int b = 0; b < 9; b++)
-                    if (!(a == 1 && b == 4)) is_max = is_max && (val0 > N9[a][b]);
-            if (!is_max) continue;
-            float dx, dy, dxy;
-            {
-                const int ty0 = (i - lp.margin) * STEP - sy0, tx0 = (j - lp.margin) * STEP - sx0;
-                haar_response(lp, [&](int yy, int xx) { int ty = ty0 + yy, tx = tx0 + xx; return stile[(ty * STEP + tx % STEP) * PW + tx / STEP]; },
-                              &dx, &dy, &dxy);
-            }
-            emit_keypoint<STEP>(N9, val0, dx + dy, i, j, lp.size, lp.size - op.L[L - 1].size, op.octave, w, h, im, out);
-        }
-    }
+    nms_survivors<TW, TH, NT>(sdet, reinterpret_cast<unsigned*>(stile + THs * STEP * PW), op, thr, px0, py0, im, sv);
 }
 
-// Octaves 2 and 3: det layers from the de-interleaved planes, det planes in LDS, NMS as above.
+// Octaves 2 and 3: det layers from the de-interleaved planes, det planes in LDS, survivors as above.
 template <int O, int TW, int TH, int NT>
-__global__ __launch_bounds__(NT) void k_hessian_nms_p(ImgPair ip, int w, int h, OctavePat op, float thr, CandOut out)
+__global__ __launch_bounds__(NT) void k_hessian_nms_p(ImgPair ip, int w, int h, OctavePat op, float thr, SurvOut sv)
 {
-    using OC = OctC<O>;
-    constexpr int STEP = OC::STEP;
-    __shared__ float sdet[5 * TH * TW];
-    const int tid = threadIdx.x, im = blockIdx.z;
-    const int sw = w + 1;
-    const int32_t* __restrict__ gsum = ip.sum[im];
+    __shared__ float sdet[3 * TH * TW];
+    __shared__ unsigned s_list[NmsLds<TW, TH>::kWords];
+    const int im = blockIdx.z;
     const int px0 = blockIdx.x * (TW - 2) - 1, py0 = blockIdx.y * (TH - 2) - 1;
-    det_layer_p<O, 0, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
     det_layer_p<O, 1, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
     det_layer_p<O, 2, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
     det_layer_p<O, 3, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
-    det_layer_p<O, 4, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
     __syncthreads();
-#pragma unroll 1
-    for (int L = 1; L <= 3; L++) {
-        const LayerPat& lp = op.L[L];
-        if (lp.samples_i == 0 || op.L[L + 1].samples_i == 0) continue;
-        const int m = op.nms_margin[L - 1];
-        for (int idx = tid; idx < (TW - 2) * (TH - 2); idx += NT) {
-            int ry = idx / (TW - 2) + 1, rx = idx - (ry - 1) * (TW - 2) + 1;
-            int i = py0 + ry, j = px0 + rx;
-            if (i < m || i >= op.rows - m || j < m || j >= op.cols - m) continue;
-            const float* d2 = sdet + (L * TH + ry) * TW + rx;
-            float val0 = d2[0];
-            if (!(val0 > thr)) continue;
-            const float* d1 = d2 - TH * TW;
-            const float* d3 = d2 + TH * TW;
-            float N9[3][9] = {
-                { d1[-TW-1], d1[-TW], d1[-TW+1], d1[-1], d1[0], d1[1], d1[TW-1], d1[TW], d1[TW+1] },
-                { d2[-TW-1], d2[-TW], d2[-TW+1], d2[-1], d2[0], d2[1], d2[TW-1], d2[TW], d2[TW+1] },
-                { d3[-TW-1], d3[-TW], d3[-TW+1], d3[-1], d3[0], d3[1], d3[TW-1], d3[TW], d3[TW+1] } };
-            bool is_max = true;
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int b = 0; b < 9; b++)
-                    if (!(a == 1 && b == 4)) is_max = is_max && (val0 > N9[a][b]);
-            if (!is_max) continue;
-            float dx, dy, dxy;
-            {
-                const int32_t* o = gsum + (size_t)((i - lp.margin) * STEP) * sw + (j - lp.margin) * STEP;
-                haar_response(lp, [&](int yy, int xx) { return o[(size_t)yy * sw + xx]; }, &dx, &dy, &dxy);
-            }
-            emit_keypoint<STEP>(N9, val0, dx + dy, i, j, lp.size, lp.size - op.L[L - 1].size, op.octave, w, h, im, out);
-        }
-    }
+    nms_survivors<TW, TH, NT>(sdet, s_list, op, thr, px0, py0, im, sv);
 }
 
 // debug / parity hook: one det+trace layer written to global planes (rows x cols)
@@ -1033,7 +1125,7 @@ uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int 
 uvo_status surf_integral(Ctx* c, int nimg)
 {
     const int w = c->img_w, h = c->img_h, sw = w + 1;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n };
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
     int nseg = (h + kSegRows - 1) / kSegRows;
     StageTimer t(c, ST_INTEGRAL);
     hipLaunchKernelGGL(k_integral_rows, dim3(h, 1, nimg), dim3(256), 0, c->stream, ip, w, h);
@@ -1048,10 +1140,10 @@ template <int O, int TW, int TH, int NT>
 static hipError_t launch_hessian_p(Ctx* c, int nimg, const OctavePat& op, float thr)
 {
     const int w = c->img_w, h = c->img_h;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n };
-    CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
+    SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
     dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
-    hipLaunchKernelGGL((k_hessian_nms_p<O, TW, TH, NT>), grid, dim3(NT), 0, c->stream, ip, w, h, op, thr, out);
+    hipLaunchKernelGGL((k_hessian_nms_p<O, TW, TH, NT>), grid, dim3(NT), 0, c->stream, ip, w, h, op, thr, sv);
     return hipGetLastError();
 }
 
@@ -1063,9 +1155,9 @@ static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float 
     constexpr int THs = (TH - 1) * STEP + (OC::HI - OC::LO) + 1;
     constexpr int PW = OctTile<O, TW>::PW;
     const int w = c->img_w, h = c->img_h;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n };
-    CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
-    const size_t lds = sizeof(float) * 5 * TW * TH + sizeof(int32_t) * (size_t)THs * STEP * PW;
+    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
+    SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
+    const size_t lds = sizeof(float) * 3 * TW * TH + sizeof(int32_t) * (size_t)THs * STEP * PW + sizeof(unsigned) * NmsLds<TW, TH>::kWords;
     dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
     auto kern = k_hessian_nms_c<O, TW, TH, NT>;
     static bool attr_set = false;
@@ -1074,7 +1166,7 @@ static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, c->stream, ip, w, h, op, thr, out);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, c->stream, ip, w, h, op, thr, sv);
     return hipGetLastError();
 }
 
@@ -1092,10 +1184,19 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
     UVO_TRY(surf_integral(c, nimg));
     const float thr = (float)c->p.SURF_MIN_HESSIAN;
     {
+        OctavePat ops[4];
+        memset(ops, 0, sizeof(ops));
+        for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER; o++) make_octave(o, c->p.SURF_OCTAVES_LAYERS, w, h, &ops[o]);
+        if (!c->d_octpat) UVO_HIP_TRY(c, hipMalloc(&c->d_octpat, sizeof(ops)));
+        if (c->h_octpat.size() != sizeof(ops) || memcmp(c->h_octpat.data(), ops, sizeof(ops)) != 0) {      // new image size or octave count
+            UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));          // nothing may still read the old table or the staging copy
+            c->h_octpat.assign(reinterpret_cast<const unsigned char*>(ops), reinterpret_cast<const unsigned char*>(ops) + sizeof(ops));
+            UVO_HIP_TRY(c, hipMemcpyAsync(c->d_octpat, c->h_octpat.data(), sizeof(ops), hipMemcpyHostToDevice, c->stream));
+            UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
         for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER; o++) {
             StageTimer t(c, ST_HESSIAN_O0 + o);
-            OctavePat op;
-            make_octave(o, c->p.SURF_OCTAVES_LAYERS, w, h, &op);
+            const OctavePat& op = ops[o];
             hipError_t e;
             // octave 0: 64 x 16 samples per workgroup = 40 KB of LDS (20 KB det planes + 20 KB integral tile): four per CU, and
             // two still fit beside a 54 KB k_pnp_hyp workgroup of another pair; 64 x 32 (66 KB) was slower in the pipeline
@@ -1104,6 +1205,14 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             else if (o == 2) e = launch_hessian_p<2, 32, 16, 512>(c, nimg, op, thr);
             else             e = launch_hessian_p<3, 16, 16, 256>(c, nimg, op, thr);
             UVO_HIP_TRY(c, e);
+        }
+        {   // the survivors of every octave: outer-layer determinants, last comparison, keypoints
+            StageTimer t(c, ST_HESSIAN_O0 + c->p.SURF_OCTAVES_NUMBER - 1);
+            ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
+            SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
+            CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
+            hipLaunchKernelGGL(k_hessian_finish, dim3((c->surv_cap + kFinishPerWg - 1) / kFinishPerWg), dim3(256), 0, c->stream, sv, static_cast<const OctavePat*>(c->d_octpat), ip, w, h, out);
+            UVO_HIP_TRY(c, hipGetLastError());
         }
     }
     {
