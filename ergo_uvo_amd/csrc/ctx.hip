@@ -87,7 +87,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     }
     c->surv_cap = 4 * (int)cap; A(dalloc(&c->d_surv, (size_t)c->surv_cap));
     A(dalloc(&c->d_colpart, (size_t)2 * nseg * (max_w + 1)));
-    A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_par, cap * 8)); A(dalloc(&c->d_big_patch, cap * 2 * 448)); A(hipMalloc(reinterpret_cast<void**>(&c->d_big_tabs), cap * 2 * 21 * 32));
+    A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_par, cap * 4)); A(dalloc(&c->d_big_patch, cap * 2 * 448)); A(hipMalloc(reinterpret_cast<void**>(&c->d_big_tabs), cap * 2 * 21 * 32));
     A(dalloc(&c->d_mpart, nchunks * cap)); A(dalloc(&c->d_mscratch, nchunks + 4)); A(dalloc(&c->d_knn_idx, cap * 2)); A(dalloc(&c->d_knn_dist, cap * 2));
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
     A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_tmp_idx, cap));

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_integral_rows(ImgPair ip, int w, int h)
     for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) { run += src[x]; dst[x + 1] = run; } }
     if (tid == 0) dst[0] = 0;
     if (y == 0) { int32_t* r0 = ip.sum[im]; for (int x = tid; x < sw; x += 256) r0[x] = 0; }
-    if (y == 0 && tid < 4) { if (tid == 0) { ip.cand_n[im] = 0; if (im == 0) *ip.surv_n = 0; } ip.big_n[im * 4 + tid] = 0; }       // the frame's candidate / large-window counters start at zero
+    if (y == 0 && tid == 0) { ip.cand_n[im] = 0; ip.big_n[im] = 0; if (im == 0) *ip.surv_n = 0; }       // the frame's candidate / large-window counters start at zero
 }
 
 __global__ __launch_bounds__(256) void k_integral_colsum(ImgPair ip, int w, int h, int32_t* part, int nseg)
@@ -633,22 +633,35 @@ __device__ __forceinline__ SortKey make_sort_key(const uvo_keypoint& kp)
 struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* out[2]; int* out_n[2]; int* rank; int cap;
                   int4* big_par; int* big_n; int* gate_nqa; int gate_min_features; };
 static const int kSmallWin = 128;       // descriptor windows up to this size use the small-LDS kernel
-// Large windows are listed by cost class (a (keypoint, column) task of k_descriptor64_big costs about
-// ceil(win/256) lane passes x ceil((win/21 + 2)/16) tap batches): 0: > 512, 1: 295..512, 2: 257..294, 3: 129..256.
-// Walking the classes in this order gives a list sorted by descending cost, which the task dealing relies on.
-__device__ __forceinline__ int big_class(int win_size) { return win_size > 512 ? 0 : win_size > 294 ? 1 : win_size > 256 ? 2 : 3; }
-struct BigList { int p1, p2, p3, total; };                 // prefix counts of the four class lists
-__device__ __forceinline__ BigList big_list(const int* big_n, int im)
+// Large windows are listed in append order by k_rank_scatter and then sorted by descending window size (a (keypoint,
+// column) task of k_descriptor64_big costs about ceil(win/256) lane passes x ceil((win/21 + 2)/16) tap batches, 1..9 units),
+// which the task dealing of that kernel relies on.  Counting sort, one workgroup per image.
+static const int kBigBins = 1024;
+__global__ __launch_bounds__(1024) void k_big_sort(const int4* __restrict__ in, int4* __restrict__ out, const int* __restrict__ big_n, int cap)
 {
-    const int n0 = big_n[im * 4], n1 = big_n[im * 4 + 1], n2 = big_n[im * 4 + 2], n3 = big_n[im * 4 + 3];
-    return BigList{ n0, n0 + n1, n0 + n1 + n2, n0 + n1 + n2 + n3 };
-}
-// entry e of the concatenated class lists -> index into big_par
-__device__ __forceinline__ int big_slot(const BigList& b, int im, int cap, int e)
-{
-    const int c = (e >= b.p1) + (e >= b.p2) + (e >= b.p3);
-    const int base = e >= b.p3 ? b.p3 : e >= b.p2 ? b.p2 : e >= b.p1 ? b.p1 : 0;
-    return (im * 4 + c) * cap + (e - base);
+    const int im = blockIdx.x, tid = threadIdx.x;
+    const int n = min(big_n[im], cap);
+    __shared__ int hist[kBigBins], scan[kBigBins];
+    hist[tid] = 0;
+    __syncthreads();
+    for (int e = tid; e < n; e += 1024) atomicAdd(&hist[min(kBigBins - 1, max(0, kBigBins - 1 - in[im * cap + e].y))], 1);
+    __syncthreads();
+    // exclusive scan of the 1024 bins (Hillis-Steele on the inclusive sums)
+    int v = hist[tid];
+    scan[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < kBigBins; off <<= 1) {
+        const int add = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
+    }
+    hist[tid] = scan[tid] - v;                     // first output position of the bin
+    __syncthreads();
+    for (int e = tid; e < n; e += 1024) {
+        const int4 par = in[im * cap + e];
+        out[im * cap + atomicAdd(&hist[min(kBigBins - 1, max(0, kBigBins - 1 - par.y))], 1)] = par;
+    }
 }
 static const int kSortChunk = 128;     // compared-against keypoints per workgroup: small, so that ~600 workgroups share the work
 
@@ -682,7 +695,7 @@ __global__ __launch_bounds__(256) void k_rank_scatter(SortArgs a)
     const int im = blockIdx.y;
     const int n = min(a.cand_n[im], a.cap);
     const int me = blockIdx.x * 256 + threadIdx.x;
-    int cls = -1;
+    bool big = false;
     int4 par = make_int4(0, 0, 0, 0);
     if (me < n) {
         int r = a.rank[im * a.cap + me];
@@ -695,19 +708,20 @@ __global__ __launch_bounds__(256) void k_rank_scatter(SortArgs a)
         const int win_size = (int)((20 + 1) * sc);
         if (win_size > kSmallWin) {
             const float win_offset = -(float)(win_size - 1) / 2;
-            cls = big_class(win_size);
+            big = true;
             par = make_int4(r, win_size, cv_round_f(kp.x + win_offset), cv_round_f(kp.y - win_offset));
         }
     }
-    // one atomic per wave and class (per-lane addresses would defeat the compiler's wave aggregation)
-    const int lane = threadIdx.x & 63;
-    for (int c = 0; c < 4; c++) {
-        const unsigned long long m = __ballot(cls == c);
-        if (m == 0) continue;
-        int base = 0;
-        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&a.big_n[im * 4 + c], __popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1);
-        if (cls == c) a.big_par[(im * 4 + c) * a.cap + base + __popcll(m & ((1ull << lane) - 1))] = par;
+    {   // one atomic per wave
+        const int lane = threadIdx.x & 63;
+        const unsigned long long m = __ballot(big);
+        if (m != 0) {
+            int base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(&a.big_n[im], __popcll(m));
+            base = __shfl(base, leader);
+            if (big) a.big_par[im * a.cap + base + __popcll(m & ((1ull << lane) - 1))] = par;
+        }
     }
     if (me == 0) *a.out_n[im] = n;
     if (me == 0 && im == 0 && a.gate_nqa) {          // VO:556: both images need >= MIN_NUM_FEATURES keypoints, else no stereo matching
@@ -934,9 +948,8 @@ __global__ __launch_bounds__(256) void k_descriptor64_big_tabs(DescArgs a, AreaT
     const int im = blockIdx.y;
     const int id = blockIdx.x * 256 + threadIdx.x;
     const int e = id / 21, d = id - e * 21;
-    const BigList bl = big_list(a.big_n, im);
-    if (e >= bl.total) return;
-    const int win_size = a.big_par[big_slot(bl, im, a.cap, e)].y;
+    if (e >= a.big_n[im]) return;
+    const int win_size = a.big_par[im * a.cap + e].y;
     const double scale = 1. / ((double)21 / win_size);
     tabs[((size_t)im * a.cap + e) * 21 + d] = area_tab(d, win_size, scale);
 }
@@ -947,7 +960,7 @@ __device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__built
 __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int h, uint8_t* __restrict__ patch, const AreaTab* __restrict__ tabs)
 {
     const int im = blockIdx.y, lane = threadIdx.x & 63, wv = sgpr_i(threadIdx.x >> 6);
-    const BigList bl = big_list(a.big_n, im);
+    const int nb = a.big_n[im];
     __shared__ float s_bufrow[4][740];
     float* bufrow = s_bufrow[wv];
     const uint8_t* __restrict__ img = a.img[im];
@@ -956,14 +969,14 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
     // per-wave totals within about one task of each other, where a plain stride left the waves that drew the giants
     // running long after the rest.  (A shared atomic cursor does not work here: ~55k device-scope increments of one
     // address from 8 XCDs serialise at ~7 ns each.)
-    const int ntask = bl.total * 21, NW = gridDim.x * 4, wid = blockIdx.x * 4 + wv;
+    const int ntask = nb * 21, NW = gridDim.x * 4, wid = blockIdx.x * 4 + wv;
     auto task_of = [&](int r) { return r * NW + ((r & 1) ? NW - 1 - wid : wid); };
     int4 par_next = make_int4(0, 0, 0, 0);
-    if (task_of(0) < ntask) par_next = a.big_par[big_slot(bl, im, a.cap, task_of(0) / 21)];
+    if (task_of(0) < ntask) par_next = a.big_par[im * a.cap + task_of(0) / 21];
     for (int r = 0; r * NW < ntask; r++) {
         const int t = task_of(r);
         const int4 par = par_next;                            // (sorted index, win_size, start_x, start_y) from k_rank_scatter
-        if (task_of(r + 1) < ntask) par_next = a.big_par[big_slot(bl, im, a.cap, task_of(r + 1) / 21)];      // next task's, in flight meanwhile
+        if (task_of(r + 1) < ntask) par_next = a.big_par[im * a.cap + task_of(r + 1) / 21];      // next task's, in flight meanwhile
         if (t >= ntask) continue;
         const int e = t / 21, dx = t - e * 21;
         // the task is the same for every lane: scalar registers, so that row clamps, row addresses and tap weights are SALU work
@@ -1094,14 +1107,13 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
 __global__ __launch_bounds__(256) void k_descriptor64_big_finish(DescArgs a, const uint8_t* __restrict__ patch)
 {
     const int im = blockIdx.y, tid = threadIdx.x;
-    const BigList bl = big_list(a.big_n, im);
-    const int nb = bl.total;
+    const int nb = a.big_n[im];
     __shared__ int PATCH[21][21];
     for (int e = blockIdx.x; e < nb; e += gridDim.x) {
         const uint8_t* src = patch + ((size_t)im * a.cap + e) * kPatchStride;
         for (int o = tid; o < 441; o += 256) PATCH[o / 21][o % 21] = src[o];
         __syncthreads();
-        describe_tail(a, im, a.big_par[big_slot(bl, im, a.cap, e)].x, PATCH);
+        describe_tail(a, im, a.big_par[im * a.cap + e].x, PATCH);
         __syncthreads();
     }
 }
@@ -1198,10 +1210,10 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             StageTimer t(c, ST_HESSIAN_O0 + o);
             const OctavePat& op = ops[o];
             hipError_t e;
-            // octave 0: 64 x 16 samples per workgroup = 40 KB of LDS (20 KB det planes + 20 KB integral tile): four per CU, and
-            // two still fit beside a 54 KB k_pnp_hyp workgroup of another pair; 64 x 32 (66 KB) was slower in the pipeline
-            if (o == 0)      e = launch_hessian_c<0, 64, 16, 512>(c, nimg, op, thr);
-            else if (o == 1) e = launch_hessian_c<1, 32, 16, 512>(c, nimg, op, thr);
+            // tile shapes chosen by pipelined throughput (tools/probe/ab.sh): octave 0 64 x 24 samples = 47 KB of LDS (18 KB det planes,
+            // 28 KB integral tile), octave 1 32 x 24 = 76 KB (9 KB + 66 KB: the 66-pixel templates make the halo most of the tile)
+            if (o == 0)      e = launch_hessian_c<0, 64, 24, 512>(c, nimg, op, thr);
+            else if (o == 1) e = launch_hessian_c<1, 32, 24, 512>(c, nimg, op, thr);
             else if (o == 2) e = launch_hessian_p<2, 32, 16, 512>(c, nimg, op, thr);
             else             e = launch_hessian_p<3, 16, 16, 256>(c, nimg, op, thr);
             UVO_HIP_TRY(c, e);
@@ -1228,11 +1240,12 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
     {
         StageTimer t(c, ST_DESCRIPTOR);
         DescArgs da = { { c->d_img[0], c->d_img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
-                        { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par, c->d_big_n, c->cap };
+                        { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->cap };      // the sorted list
         const size_t lds_small = sizeof(float) * 21 * (kSmallWin | 1);
+        hipLaunchKernelGGL(k_big_sort, dim3(nimg), dim3(1024), 0, c->stream, c->d_big_par, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->cap);
         hipLaunchKernelGGL(k_descriptor64_big_tabs, dim3((c->cap * 21 + 255) / 256, nimg), dim3(256), 0, c->stream, da, c->d_big_tabs);
         hipLaunchKernelGGL(k_descriptor64_big, dim3(1024, nimg), dim3(256), 0, c->stream, da, w, h, c->d_big_patch, c->d_big_tabs);
-        hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(256, nimg), dim3(256), 0, c->stream, da, c->d_big_patch);
+        hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(1024, nimg), dim3(256), 0, c->stream, da, c->d_big_patch);
         hipLaunchKernelGGL(k_descriptor64_small, dim3(c->cap, nimg), dim3(256), lds_small, c->stream, da, w, h);
         UVO_HIP_TRY(c, hipGetLastError());
     }

@@ -28,7 +28,7 @@ def counter_avg(dirname, counter):
 def main(tag):
     fetch, nf = counter_avg("pmc_fetch", "FETCH_SIZE")
     write, nw = counter_avg("pmc_write", "WRITE_SIZE")
-    res = {"kernel": "uvo::k_hessian_nms_c<0, 64, 16, 512> (octave 0, both images of a pair per launch)",
+    res = {"kernel": "uvo::k_hessian_nms_c<0, 64, 24, 512> (octave 0, both images of a pair per launch)",
            "launches_sampled": [nf, nw], "FETCH_SIZE_KiB_avg": fetch, "WRITE_SIZE_KiB_avg": write}
     if fetch is not None and write is not None:
         res["hbm_bytes_per_launch_raw"] = int((fetch + write) * 1024)
