@@ -65,6 +65,33 @@ def test_surf_detect_describe_bit_exact(ctx, oracle, shape, thr):
     assert np.array_equal(desc.view(np.uint32), odesc.view(np.uint32))
 
 
+@pytest.mark.parametrize("shape,thr", [((200, 262), 1), ((96, 350), 20)])
+def test_surf_dense_maxima_bit_exact(ctx, oracle, shape, thr):
+    """White noise and an almost-zero threshold: every local maximum of every layer is a candidate, so the list of samples
+    whose outer-layer determinants are evaluated lazily (k_hessian_finish) is as long as it gets; odd widths take the
+    descriptor kernels' scalar paths."""
+    import ergo_uvo_amd as uvo
+    img = np.random.default_rng(11).integers(0, 256, shape).astype(np.uint8)
+    ctx.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=thr))
+    kps, desc = ctx.detect_features(img)
+    okps, odesc = oracle.surf(img, thr)
+    assert len(okps) > 200
+    _assert_kps_equal(kps, okps)
+    assert np.array_equal(desc.view(np.uint32), odesc.view(np.uint32))
+
+
+def test_surf_capacity_overflow_is_an_error():
+    """More candidates than max_kpts (and more NMS survivors than the 4 x max_kpts list) must fail loudly, never truncate."""
+    import ergo_uvo_amd as uvo
+    c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=1), 0, 640, 360, 64)
+    try:
+        with pytest.raises(uvo.UvoError) as ei:
+            c.detect_features(_rand_img(3, 360, 640))
+        assert ei.value.status == 3          # UVO_CAPACITY
+    finally:
+        c.close()
+
+
 def test_surf_empty_and_tiny(ctx, oracle):
     import ergo_uvo_amd as uvo
     ctx.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=100))
