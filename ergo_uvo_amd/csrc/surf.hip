@@ -219,8 +219,9 @@ __device__ __forceinline__ bool make_keypoint(float N9[3][9], float val0, float 
 }
 
 // ------------------------------------------------------------------------------------------
-// Octaves 0 and 1: one workgroup computes TW x TH plane samples (1-sample halo, (TW-2) x (TH-2) NMS outputs) of all five
-// layers from an integral tile in LDS, with the box patterns, weights and every LDS offset
+// Octaves 0 and 1: one workgroup computes TW x TH plane samples (1-sample halo, (TW-2) x (TH-2) NMS outputs) of the three
+// middle layers from an integral tile in LDS (the outer layers 0 and 4 are evaluated lazily, see nms_survivors /
+// k_hessian_finish below), with the box patterns, weights and every LDS offset
 // resolved at compile time (sizes (9+6l)<<O are fixed by the octave), so one box corner is one
 // ds_read_b32 with an immediate offset and corners shared between the boxes of a filter are read
 // once (32 reads per sample instead of 40, no address arithmetic).  For STEP > 1 the integral tile
