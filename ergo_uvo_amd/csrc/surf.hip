@@ -36,8 +36,17 @@ __global__ __launch_bounds__(256) void k_integral_rows(ImgPair ip, int w, int h)
     int32_t* dst = ip.sum[im] + (size_t)(y + 1) * sw;
     const int chunk = (w + 255) / 256;
     const int x0 = tid * chunk;
+    // eight pixels per thread from one aligned 64-bit load when the row geometry allows (1920: chunk 8, rows 8-byte aligned)
+    const bool vec8 = chunk == 8 && (w & 7) == 0;
+    unsigned char px[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (vec8 && x0 < w) {
+        const uint2 v = *reinterpret_cast<const uint2*>(src + x0);
+        px[0] = v.x & 255u; px[1] = (v.x >> 8) & 255u; px[2] = (v.x >> 16) & 255u; px[3] = v.x >> 24;
+        px[4] = v.y & 255u; px[5] = (v.y >> 8) & 255u; px[6] = (v.y >> 16) & 255u; px[7] = v.y >> 24;
+    }
     int local = 0;
-    for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) local += src[x]; }
+    if (vec8) { for (int k = 0; k < 8; k++) local += px[k]; }
+    else for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) local += src[x]; }
     // block exclusive scan of `local`
     __shared__ int wsum[4];
     int lane = tid & 63, wv = tid >> 6;
@@ -48,7 +57,8 @@ __global__ __launch_bounds__(256) void k_integral_rows(ImgPair ip, int w, int h)
     int base = 0;
     for (int k = 0; k < wv; k++) base += wsum[k];
     int run = base + inc - local;
-    for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) { run += src[x]; dst[x + 1] = run; } }
+    if (vec8) { if (x0 < w) for (int k = 0; k < 8; k++) { run += px[k]; dst[x0 + k + 1] = run; } }
+    else for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) { run += src[x]; dst[x + 1] = run; } }
     if (tid == 0) dst[0] = 0;
     if (y == 0) { int32_t* r0 = ip.sum[im]; for (int x = tid; x < sw; x += 256) r0[x] = 0; }
     if (y == 0 && tid == 0) { ip.cand_n[im] = 0; ip.big_n[im] = 0; if (im == 0) *ip.surv_n = 0; }       // the frame's candidate / large-window counters start at zero
@@ -660,8 +670,14 @@ __global__ __launch_bounds__(1024) void k_big_sort(const int4* __restrict__ in, 
     hist[tid] = scan[tid] - v;                     // first output position of the bin
     __syncthreads();
     for (int e = tid; e < n; e += 1024) {
-        const int4 par = in[im * cap + e];
-        out[im * cap + atomicAdd(&hist[min(kBigBins - 1, max(0, kBigBins - 1 - par.y))], 1)] = par;
+        int4 par = in[im * cap + e];
+        const int pos = atomicAdd(&hist[min(kBigBins - 1, max(0, kBigBins - 1 - par.y))], 1);
+        // resizeAreaFast_ applies when the scale is an integer to within DBL_EPSILON: decided once per keypoint here (two
+        // fp64 divisions) instead of once per task; .y = win_size | (iscale << 16), iscale = 0 for the general path
+        const double scale = 1. / ((double)21 / par.y);
+        const int iscale = cv_round_d(scale);
+        if (fabs(scale - iscale) < DBL_EPSILON) par.y |= iscale << 16;
+        out[im * cap + pos] = par;
     }
 }
 static const int kSortChunk = 128;     // compared-against keypoints per workgroup: small, so that ~600 workgroups share the work
@@ -915,14 +931,11 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
         for (int o = tid; o < 441; o += 256) {
             int dy = o / 21, dx = o - dy * 21;
             const AreaTab ty = tab[dy];
-            const int r_begin = ty.has_first ? ty.sx1 - 1 : ty.sx1;
-            const int r_end = ty.has_last ? ty.sx2 + 1 : ty.sx2;
             const float* col = buf + dx * bp;
             float sum = 0.f;
-            for (int r = r_begin; r < r_end; r++) {
-                float beta = r < ty.sx1 ? ty.a_first : (r < ty.sx2 ? ty.a_mid : ty.a_last);
-                sum += beta * col[r];
-            }
+            if (ty.has_first) sum += ty.a_first * col[ty.sx1 - 1];                    // the loop of resizeArea_'s table, split by weight
+            for (int r = ty.sx1; r < ty.sx2; r++) sum += ty.a_mid * col[r];
+            if (ty.has_last) sum += ty.a_last * col[ty.sx2];
             PATCH[dy][dx] = sat_u8(sum);
         }
     }
@@ -950,44 +963,44 @@ __global__ __launch_bounds__(256) void k_descriptor64_big_tabs(DescArgs a, AreaT
     const int id = blockIdx.x * 256 + threadIdx.x;
     const int e = id / 21, d = id - e * 21;
     if (e >= a.big_n[im]) return;
-    const int win_size = a.big_par[im * a.cap + e].y;
+    const int win_size = a.big_par[im * a.cap + e].y & 0xFFFF;
     const double scale = 1. / ((double)21 / win_size);
     tabs[((size_t)im * a.cap + e) * 21 + d] = area_tab(d, win_size, scale);
 }
 __device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
-// One task per WAVE (no workgroup barriers: four independent waves per workgroup, 8192 tasks in flight on the chip).
+static const int kBigCols = 1, kBigTriples = 21 / kBigCols;   // destination columns per task, tasks per keypoint (3 x 7 was slower: 36 KB of row buffers per workgroup halve the resident waves)
+// One task per WAVE (no workgroup barriers: four independent waves per workgroup, 8192 waves resident).  A task is kBigCols
+// adjacent destination columns of one keypoint: their horizontal passes run one after the other into kBigCols row
+// buffers, then one vertical pass finishes the 21 * kBigCols outputs, a lane each.
 __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int h, uint8_t* __restrict__ patch, const AreaTab* __restrict__ tabs)
 {
     const int im = blockIdx.y, lane = threadIdx.x & 63, wv = sgpr_i(threadIdx.x >> 6);
     const int nb = a.big_n[im];
-    __shared__ float s_bufrow[4][740];
-    float* bufrow = s_bufrow[wv];
+    __shared__ float s_bufrow[4][kBigCols][740];
+    float* bufrow0 = s_bufrow[wv][0];
     const uint8_t* __restrict__ img = a.img[im];
-    // Tasks t = 21*e + dx run down the cost-sorted list and are dealt to the waves in rounds of alternating direction
+    // Tasks t = kBigTriples*e + dx/kBigCols run down the cost-sorted list and are dealt to the waves in rounds of alternating direction
     // (round r hands task r*NW + p to wave p, or to wave NW-1-p when r is odd): costs span 1..9 units, and this keeps the
     // per-wave totals within about one task of each other, where a plain stride left the waves that drew the giants
     // running long after the rest.  (A shared atomic cursor does not work here: ~55k device-scope increments of one
     // address from 8 XCDs serialise at ~7 ns each.)
-    const int ntask = nb * 21, NW = gridDim.x * 4, wid = blockIdx.x * 4 + wv;
+    const int ntask = nb * kBigTriples, NW = gridDim.x * 4, wid = blockIdx.x * 4 + wv;
     auto task_of = [&](int r) { return r * NW + ((r & 1) ? NW - 1 - wid : wid); };
     int4 par_next = make_int4(0, 0, 0, 0);
-    if (task_of(0) < ntask) par_next = a.big_par[im * a.cap + task_of(0) / 21];
+    if (task_of(0) < ntask) par_next = a.big_par[im * a.cap + task_of(0) / kBigTriples];
     for (int r = 0; r * NW < ntask; r++) {
         const int t = task_of(r);
         const int4 par = par_next;                            // (sorted index, win_size, start_x, start_y) from k_rank_scatter
-        if (task_of(r + 1) < ntask) par_next = a.big_par[im * a.cap + task_of(r + 1) / 21];      // next task's, in flight meanwhile
+        if (task_of(r + 1) < ntask) par_next = a.big_par[im * a.cap + task_of(r + 1) / kBigTriples];      // next task's, in flight meanwhile
         if (t >= ntask) continue;
-        const int e = t / 21, dx = t - e * 21;
+        const int e = t / kBigTriples, dx0 = (t - e * kBigTriples) * kBigCols;
         // the task is the same for every lane: scalar registers, so that row clamps, row addresses and tap weights are SALU work
-        const int win_size = sgpr_i(par.y), start_x = sgpr_i(par.z), start_y = sgpr_i(par.w);
-        const double inv_scale = (double)21 / win_size;
-        const double scale = 1. / inv_scale;
-        const int iscale = cv_round_d(scale);
-        const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
+        const int win_size = sgpr_i(par.y) & 0xFFFF, start_x = sgpr_i(par.z), start_y = sgpr_i(par.w);
+        const int iscale = sgpr_i(par.y) >> 16;               // non-zero: resizeAreaFast_ with this integer scale (k_big_sort)
+        const bool area_fast = iscale != 0;
         uint8_t* out = patch + ((size_t)im * a.cap + e) * kPatchStride;
-        int* colsum = reinterpret_cast<int*>(bufrow);
         // rows 4-byte aligned: aligned 32-bit loads cover four columns at a time over the window's in-image columns
         // [xlo, xhi); window columns left or right of the image replicate the border column (WIN clamps x), so their
         // sums are copies of the first / last in-image column's
@@ -996,110 +1009,121 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
         const int xa = xlo & ~3, ilo = xlo - start_x, ihi = xhi - start_x;
         if (area_fast) {
             // resizeAreaFast_: integer block sums (any order); column c = dy*iscale + sy of the window
-            if (vec_ok) {
-                for (int x4 = xa + 4 * lane; x4 < xhi; x4 += 256) {
-                    int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            for (int d = 0; d < kBigCols; d++) {
+                const int dx = dx0 + d;
+                int* colsum = reinterpret_cast<int*>(bufrow0 + d * 740);
+                if (vec_ok) {
+                    for (int x4 = xa + 4 * lane; x4 < xhi; x4 += 256) {
+                        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                        for (int sx = 0; sx < iscale; sx++) {
+                            int y = start_y - (dx * iscale + sx); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                            const unsigned v = *reinterpret_cast<const unsigned*>(img + ((unsigned)(y * w) + (unsigned)x4));
+                            s0 += v & 255u; s1 += (v >> 8) & 255u; s2 += (v >> 16) & 255u; s3 += v >> 24;
+                        }
+                        const int c = x4 - start_x;
+                        if (c >= ilo) colsum[c] = s0;
+                        if (c + 1 >= ilo && c + 1 < ihi) colsum[c + 1] = s1;
+                        if (c + 2 >= ilo && c + 2 < ihi) colsum[c + 2] = s2;
+                        if (c + 3 >= ilo && c + 3 < ihi) colsum[c + 3] = s3;
+                    }
+                    if (ilo > 0) { const int v = colsum[ilo]; for (int c = lane; c < ilo; c += 64) colsum[c] = v; }
+                    if (ihi < win_size) { const int v = colsum[ihi - 1]; for (int c = ihi + lane; c < win_size; c += 64) colsum[c] = v; }
+                } else
+                for (int c = lane; c < win_size; c += 64) {
+                    int x = start_x + c; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
+                    int sum = 0;
                     for (int sx = 0; sx < iscale; sx++) {
                         int y = start_y - (dx * iscale + sx); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
-                        const unsigned v = *reinterpret_cast<const unsigned*>(img + ((unsigned)(y * w) + (unsigned)x4));
-                        s0 += v & 255u; s1 += (v >> 8) & 255u; s2 += (v >> 16) & 255u; s3 += v >> 24;
+                        sum += img[(size_t)y * w + x];
                     }
-                    const int c = x4 - start_x;
-                    if (c >= ilo) colsum[c] = s0;
-                    if (c + 1 >= ilo && c + 1 < ihi) colsum[c + 1] = s1;
-                    if (c + 2 >= ilo && c + 2 < ihi) colsum[c + 2] = s2;
-                    if (c + 3 >= ilo && c + 3 < ihi) colsum[c + 3] = s3;
+                    colsum[c] = sum;
                 }
-                if (ilo > 0) { const int v = colsum[ilo]; for (int c = lane; c < ilo; c += 64) colsum[c] = v; }
-                if (ihi < win_size) { const int v = colsum[ihi - 1]; for (int c = ihi + lane; c < win_size; c += 64) colsum[c] = v; }
-            } else
-            for (int c = lane; c < win_size; c += 64) {
-                int x = start_x + c; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
-                int sum = 0;
-                for (int sx = 0; sx < iscale; sx++) {
-                    int y = start_y - (dx * iscale + sx); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
-                    sum += img[(size_t)y * w + x];
-                }
-                colsum[c] = sum;
             }
             __builtin_amdgcn_wave_barrier();
-            if (lane < 21) {
+            if (lane < 21 * kBigCols) {
+                const int d = lane / 21, dy = lane - d * 21;
+                const int* colsum = reinterpret_cast<const int*>(bufrow0 + d * 740);
                 int sum = 0;
-                for (int sy = 0; sy < iscale; sy++) sum += colsum[lane * iscale + sy];
+                for (int sy = 0; sy < iscale; sy++) sum += colsum[dy * iscale + sy];
                 int result;
                 if (iscale == 2) result = (sum + 2) >> 2;
                 else { float sc = 1.f / (iscale * iscale); result = sat_u8(sum * sc); }
-                out[lane * 21 + dx] = (uint8_t)result;
+                out[dy * 21 + dx0 + d] = (uint8_t)result;
             }
         } else {
             const AreaTab* tab = tabs + ((size_t)im * a.cap + e) * 21;
-            AreaTab tx = tab[dx];                           // the same for every lane: keep it in scalar registers
-            tx.sx1 = sgpr_i(tx.sx1); tx.sx2 = sgpr_i(tx.sx2);
-            tx.a_first = sgpr_f(tx.a_first); tx.a_mid = sgpr_f(tx.a_mid); tx.a_last = sgpr_f(tx.a_last);
-            tx.has_first = sgpr_i(tx.has_first) != 0; tx.has_last = sgpr_i(tx.has_last) != 0;
-            const int c_begin = tx.has_first ? tx.sx1 - 1 : tx.sx1;
-            const int c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
-            if (vec_ok) {
-                // four adjacent window rows (image columns) per lane from one aligned 32-bit load per tap
-                for (int x4 = xa + 4 * lane; x4 < xhi; x4 += 256) {
-                    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-                    for (int c0 = c_begin; c0 < c_end; c0 += 16) {         // sixteen taps in flight, accumulated in order
-                        unsigned v[16];
+            for (int d = 0; d < kBigCols; d++) {
+                const int dx = dx0 + d;
+                float* bufrow = bufrow0 + d * 740;
+                AreaTab tx = tab[dx];                          // the same for every lane: keep it in scalar registers
+                tx.sx1 = sgpr_i(tx.sx1); tx.sx2 = sgpr_i(tx.sx2);
+                tx.a_first = sgpr_f(tx.a_first); tx.a_mid = sgpr_f(tx.a_mid); tx.a_last = sgpr_f(tx.a_last);
+                tx.has_first = sgpr_i(tx.has_first) != 0; tx.has_last = sgpr_i(tx.has_last) != 0;
+                const int c_begin = tx.has_first ? tx.sx1 - 1 : tx.sx1;
+                const int c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
+                if (vec_ok) {
+                    // four adjacent window rows (image columns) per lane from one aligned 32-bit load per tap
+                    for (int x4 = xa + 4 * lane; x4 < xhi; x4 += 256) {
+                        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+                        for (int c0 = c_begin; c0 < c_end; c0 += 16) {         // sixteen taps in flight, accumulated in order
+                            unsigned v[16];
 #pragma unroll
-                        for (int q = 0; q < 16; q++) {
-                            int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
-                            v[q] = *reinterpret_cast<const unsigned*>(img + ((unsigned)(y * w) + (unsigned)x4));       // scalar row offset + vector column: one 32-bit add
-                        }
+                            for (int q = 0; q < 16; q++) {
+                                int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                                v[q] = *reinterpret_cast<const unsigned*>(img + ((unsigned)(y * w) + (unsigned)x4));       // scalar row offset + vector column: one 32-bit add
+                            }
 #pragma unroll
-                        for (int q = 0; q < 16; q++) {
-                            int cc = c0 + q;
-                            float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
-                            if (cc < c_end) {
-                                b0 += (int)(v[q] & 255u) * alpha; b1 += (int)((v[q] >> 8) & 255u) * alpha;
-                                b2 += (int)((v[q] >> 16) & 255u) * alpha; b3 += (int)(v[q] >> 24) * alpha;
+                            for (int q = 0; q < 16; q++) {
+                                int cc = c0 + q;
+                                float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
+                                if (cc < c_end) {
+                                    b0 += (int)(v[q] & 255u) * alpha; b1 += (int)((v[q] >> 8) & 255u) * alpha;
+                                    b2 += (int)((v[q] >> 16) & 255u) * alpha; b3 += (int)(v[q] >> 24) * alpha;
+                                }
                             }
                         }
+                        const int i = x4 - start_x;
+                        if (i >= ilo) bufrow[i] = b0;
+                        if (i + 1 >= ilo && i + 1 < ihi) bufrow[i + 1] = b1;
+                        if (i + 2 >= ilo && i + 2 < ihi) bufrow[i + 2] = b2;
+                        if (i + 3 >= ilo && i + 3 < ihi) bufrow[i + 3] = b3;
                     }
-                    const int i = x4 - start_x;
-                    if (i >= ilo) bufrow[i] = b0;
-                    if (i + 1 >= ilo && i + 1 < ihi) bufrow[i + 1] = b1;
-                    if (i + 2 >= ilo && i + 2 < ihi) bufrow[i + 2] = b2;
-                    if (i + 3 >= ilo && i + 3 < ihi) bufrow[i + 3] = b3;
-                }
-                if (ilo > 0) { const float v = bufrow[ilo]; for (int i = lane; i < ilo; i += 64) bufrow[i] = v; }
-                if (ihi < win_size) { const float v = bufrow[ihi - 1]; for (int i = ihi + lane; i < win_size; i += 64) bufrow[i] = v; }
-            } else
-            for (int i = lane; i < win_size; i += 64) {
-                int x = start_x + i; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
-                float b = 0.f;
-                // taps fetched eight at a time (independent loads in flight), accumulated in order
-                for (int c0 = c_begin; c0 < c_end; c0 += 8) {
-                    int v[8];
+                    if (ilo > 0) { const float v = bufrow[ilo]; for (int i = lane; i < ilo; i += 64) bufrow[i] = v; }
+                    if (ihi < win_size) { const float v = bufrow[ihi - 1]; for (int i = ihi + lane; i < win_size; i += 64) bufrow[i] = v; }
+                } else
+                for (int i = lane; i < win_size; i += 64) {
+                    int x = start_x + i; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
+                    float b = 0.f;
+                    // taps fetched eight at a time (independent loads in flight), accumulated in order
+                    for (int c0 = c_begin; c0 < c_end; c0 += 8) {
+                        int v[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
-                        v[q] = img[(size_t)y * w + x];
-                    }
+                        for (int q = 0; q < 8; q++) {
+                            int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
+                            v[q] = img[(size_t)y * w + x];
+                        }
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        int cc = c0 + q;
-                        float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
-                        if (cc < c_end) b += v[q] * alpha;
+                        for (int q = 0; q < 8; q++) {
+                            int cc = c0 + q;
+                            float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
+                            if (cc < c_end) b += v[q] * alpha;
+                        }
                     }
+                    bufrow[i] = b;
                 }
-                bufrow[i] = b;
             }
             __builtin_amdgcn_wave_barrier();
-            if (lane < 21) {                                // vertical pass of this column
-                const AreaTab ty = tab[lane];
+            if (lane < 21 * kBigCols) {                     // vertical passes of the three columns, 21 lanes each
+                const int d = lane / 21, dy = lane - d * 21;
+                const float* bufrow = bufrow0 + d * 740;
+                const AreaTab ty = tab[dy];
                 const int r_begin = ty.has_first ? ty.sx1 - 1 : ty.sx1;
                 const int r_end = ty.has_last ? ty.sx2 + 1 : ty.sx2;
                 float sum = 0.f;
-                for (int r = r_begin; r < r_end; r++) {
-                    float beta = r < ty.sx1 ? ty.a_first : (r < ty.sx2 ? ty.a_mid : ty.a_last);
-                    sum += beta * bufrow[r];
-                }
-                out[lane * 21 + dx] = sat_u8(sum);
+                if (ty.has_first) sum += ty.a_first * bufrow[ty.sx1 - 1];            // the loop of resizeArea_'s table, split by weight
+                for (int r = ty.sx1; r < ty.sx2; r++) sum += ty.a_mid * bufrow[r];
+                if (ty.has_last) sum += ty.a_last * bufrow[ty.sx2];
+                out[dy * 21 + dx0 + d] = sat_u8(sum);
             }
         }
         __builtin_amdgcn_wave_barrier();
