@@ -101,12 +101,16 @@ __global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ dq
 {
     const int nq = nq_p ? *nq_p : nq_imm, nt = nt_p ? *nt_p : nt_imm;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int q0 = blockIdx.x * 128 + wave * 32, t0 = blockIdx.y * kMfmaChunk;
-    if (blockIdx.x * 128 >= nq || t0 >= nt) return;
     __shared__ __align__(16) float s_tn[4][32];
     __shared__ __align__(16) float s_rows[kMfmaChunk * kRowStride];      // the chunk's train rows, shared by the four waves
     float* tn_lds = s_tn[wave];
     const int n = lane & 31, h = lane >> 5;
+    // the counts live on the device, so the grid is a fixed number of workgroups that walk the (query tile, train chunk)
+    // pairs: a cap x cap grid would be 4096 workgroups of which ~530 find work
+    const int nqt = (nq + 127) / 128, ntiles = nqt * ((nt + kMfmaChunk - 1) / kMfmaChunk);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tile_q = tile % nqt, tile_c = tile / nqt;
+    const int q0 = tile_q * 128 + wave * 32, t0 = tile_c * kMfmaChunk;
     // B operand: this lane's query, k = 32h .. 32h+31 (MFMA step i consumes k = 32h + i from both operands)
     const int q = q0 + n;
     float breg[32];
@@ -134,10 +138,12 @@ __global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ dq
         float o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32), o3 = __shfl_xor(k3, 32);
         top4_keys(o0, k0, k1, k2, k3); top4_keys(o1, k0, k1, k2, k3); top4_keys(o2, k0, k1, k2, k3); top4_keys(o3, k0, k1, k2, k3);
     }
-    if (h == 0 && q < nq) part[(size_t)blockIdx.y * cap + q] = make_float4(k0, k1, k2, k3);
-    if (blockIdx.x == 0 && wave == 0) {                     // one wave per chunk reports the largest |t|^2
+    if (h == 0 && q < nq) part[(size_t)tile_c * cap + q] = make_float4(k0, k1, k2, k3);
+    if (tile_q == 0 && wave == 0) {                         // one wave per chunk reports the largest |t|^2
         for (int o = 16; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-        if (lane == 0) chunk_tnmax[blockIdx.y] = wmax;
+        if (lane == 0) chunk_tnmax[tile_c] = wmax;
+    }
+    __syncthreads();                                        // s_rows is restaged by the next tile
     }
 }
 
@@ -296,7 +302,8 @@ uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, con
     float* tnmax = c->d_mscratch;                    // [chunk] max |t|^2
     {
         StageTimer t(c, ST_MATCH);
-        dim3 grid((nq_max + 127) / 128, (nt_max + kMfmaChunk - 1) / kMfmaChunk);
+        const int tiles_max = ((nq_max + 127) / 128) * ((nt_max + kMfmaChunk - 1) / kMfmaChunk);
+        dim3 grid(tiles_max < 768 ? tiles_max : 768);          // three workgroups per CU; larger problems loop
         hipLaunchKernelGGL(k_match_mfma, grid, dim3(256), 0, c->stream, d_q, d_nq, nq_max, d_t, d_nt, nt_max, c->cap, c->d_mpart, tnmax);
         UVO_HIP_TRY(c, hipGetLastError());
     }

@@ -684,27 +684,33 @@ static const int kSortChunk = 128;     // compared-against keypoints per workgro
 
 __global__ __launch_bounds__(256) void k_rank_partial(SortArgs a)
 {
-    const int im = blockIdx.z, tid = threadIdx.x;
+    const int im = blockIdx.y, tid = threadIdx.x;
     const int n = min(a.cand_n[im], a.cap);
-    const int i0 = blockIdx.x * 256, j0 = blockIdx.y * kSortChunk;
-    if (i0 >= n || j0 >= n) return;
     __shared__ SortKey tile[kSortChunk];
-    const int cnt = min(kSortChunk, n - j0);
-    for (int t = tid; t < cnt; t += 256) tile[t] = make_sort_key(a.cand[im][j0 + t]);
-    __syncthreads();
-    const int me = i0 + tid;
-    if (me >= n) return;
-    const SortKey mine = make_sort_key(a.cand[im][me]);
-    int rank = 0;
+    // the count lives on the device: a fixed grid walks the (256 keypoints) x (kSortChunk compared-against) tiles that exist
+    // (a cap x cap grid is 4096 workgroups of which ~550 find work, and dispatching the empty ones costs more than the work)
+    const int nib = (n + 255) / 256, ntiles = nib * ((n + kSortChunk - 1) / kSortChunk);
+    for (int t_ = blockIdx.x; t_ < ntiles; t_ += gridDim.x) {
+        const int i0 = (t_ % nib) * 256, j0 = (t_ / nib) * kSortChunk;
+        const int cnt = min(kSortChunk, n - j0);
+        for (int t = tid; t < cnt; t += 256) tile[t] = make_sort_key(a.cand[im][j0 + t]);
+        __syncthreads();
+        const int me = i0 + tid;
+        if (me < n) {
+            const SortKey mine = make_sort_key(a.cand[im][me]);
+            int rank = 0;
 #pragma unroll 8
-    for (int k = 0; k < cnt; k++) {
-        const SortKey o = tile[k];
-        bool before = o.k1 > mine.k1 ||
-                      (o.k1 == mine.k1 && (o.k2 > mine.k2 ||
-                                           (o.k2 == mine.k2 && (o.k3 > mine.k3 || (o.k3 == mine.k3 && j0 + k < me)))));
-        rank += before ? 1 : 0;
+            for (int k = 0; k < cnt; k++) {
+                const SortKey o = tile[k];
+                bool before = o.k1 > mine.k1 ||
+                              (o.k1 == mine.k1 && (o.k2 > mine.k2 ||
+                                                   (o.k2 == mine.k2 && (o.k3 > mine.k3 || (o.k3 == mine.k3 && j0 + k < me)))));
+                rank += before ? 1 : 0;
+            }
+            atomicAdd(&a.rank[im * a.cap + me], rank);
+        }
+        __syncthreads();
     }
-    atomicAdd(&a.rank[im * a.cap + me], rank);
 }
 
 __global__ __launch_bounds__(256) void k_rank_scatter(SortArgs a)
@@ -946,9 +952,14 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
 // small windows: one workgroup per keypoint
 __global__ __launch_bounds__(256) void k_descriptor64_small(DescArgs a, int w, int h)
 {
-    const int k = blockIdx.x, im = blockIdx.y;
-    if (k >= *a.n[im]) return;
-    describe_keypoint(a, w, h, k, im);
+    const int im = blockIdx.y;
+    const int n = *a.n[im];
+    // one workgroup per keypoint when the grid has max_kpts of them (measured faster than a smaller grid walking the list:
+    // the hardware hands the next keypoint to whichever CU frees up); the loop covers smaller grids
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        describe_keypoint(a, w, h, k, im);
+        __syncthreads();                     // the LDS buffers are reused by the next keypoint
+    }
 }
 // Large windows (up to 739 samples: the keypoints of octaves 2 and 3).  One keypoint is 21 independent tasks, one per
 // destination column dx of the area resize: a task needs only the ~win/21 image rows of that column's taps, computes
@@ -1257,8 +1268,8 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
         SortArgs sa = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, { c->det[0].kps, c->det[1].kps },
                         { c->det[0].n, c->det[1].n }, c->d_rank, c->cap, c->d_big_par, c->d_big_n,
                         gate_min_features >= 0 && nimg == 2 ? c->d_counts + CN_NQA : nullptr, gate_min_features };
-        dim3 g((c->cap + 255) / 256, (c->cap + kSortChunk - 1) / kSortChunk, nimg);
-        hipLaunchKernelGGL(k_rank_partial, g, dim3(256), 0, c->stream, sa);
+        const int tiles_max = ((c->cap + 255) / 256) * ((c->cap + kSortChunk - 1) / kSortChunk);
+        hipLaunchKernelGGL(k_rank_partial, dim3(tiles_max < 512 ? tiles_max : 512, nimg), dim3(256), 0, c->stream, sa);
         hipLaunchKernelGGL(k_rank_scatter, dim3((c->cap + 255) / 256, nimg), dim3(256), 0, c->stream, sa);
         UVO_HIP_TRY(c, hipGetLastError());
     }
