@@ -162,11 +162,10 @@ __device__ __forceinline__ void top2_lex(float d, int t, float& d0, int& i0, flo
     else if (d < d1 || (d == d1 && t < i1)) { d1 = d; i1 = t; }
 }
 // normL2Sqr_ + sqrt with the 16 accumulators on the 16 lanes of a group: lane l holds q[4l..4l+3]; returns on every lane
-__device__ __forceinline__ float group_distance(const float4 qv, const float* __restrict__ trow, int sub)
+__device__ __forceinline__ float group_distance_tv(const float4 qv, const float4 tv, int sub)
 {
     // accumulator a (= j mod 16) sums elements a, a+16, a+32, a+48 in that order; element e lives in lane e/4, slot e%4
     // lane `sub` computes accumulator a = sub: it needs q/t elements sub + 16k, i.e. slot sub%4 of lane sub/4 + 4k
-    const float4 tv = reinterpret_cast<const float4*>(trow)[sub];
     const float dx = qv.x - tv.x, dy = qv.y - tv.y, dz = qv.z - tv.z, dw = qv.w - tv.w;
     const float px = dx * dx, py = dy * dy, pz = dz * dz, pw = dw * dw;       // squared differences of elements 4sub..4sub+3
     const int base = (threadIdx.x & 63 & ~15);
@@ -185,6 +184,10 @@ __device__ __forceinline__ float group_distance(const float4 qv, const float* __
     const float v = ((a0 + a1) + a2) + a3;                  // lanes with the same l hold the same v
     const float v0 = __shfl(v, base + 0), v1 = __shfl(v, base + 1), v2 = __shfl(v, base + 2), v3 = __shfl(v, base + 3);
     return sqrtf((v0 + v2) + (v1 + v3));
+}
+__device__ __forceinline__ float group_distance(const float4 qv, const float* __restrict__ trow, int sub)
+{
+    return group_distance_tv(qv, reinterpret_cast<const float4*>(trow)[sub], sub);
 }
 
 __global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__ dq, const int* nq_p, int nq_imm,
@@ -224,18 +227,38 @@ __global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__
             if (p.y <= lim) b = c * kMfmaChunk + (int)(__float_as_uint(p.y) & 127u);
             if (p.z <= lim) e3 = c * kMfmaChunk + (int)(__float_as_uint(p.z) & 127u);
         }
-        for (int l = 0; l < 16; l++) {                     // the lanes' findings, one lane at a time, all 16 lanes working
-            const int base = threadIdx.x & 63 & ~15;
-            const bool sc = __shfl((int)scan, base + l) != 0;
-            if (sc) {
-                const int cc = cb + l, te = min((cc + 1) * kMfmaChunk, nt);
-                for (int t = cc * kMfmaChunk; t < te; t++) top2_lex(group_distance(qv, dt + (size_t)t * 64, sub), t, d0, i0, d1, i1);
-            } else {
-                const int ta = __shfl(a, base + l), tb2 = __shfl(b, base + l), tc = __shfl(e3, base + l);
-                if (ta >= 0) top2_lex(group_distance(qv, dt + (size_t)ta * 64, sub), ta, d0, i0, d1, i1);
-                if (tb2 >= 0) top2_lex(group_distance(qv, dt + (size_t)tb2 * 64, sub), tb2, d0, i0, d1, i1);
-                if (tc >= 0) top2_lex(group_distance(qv, dt + (size_t)tc * 64, sub), tc, d0, i0, d1, i1);
+        const int base = threadIdx.x & 63 & ~15;
+        const int gshift = threadIdx.x & 48;                // this group's 16 bits of a wave ballot
+        // chunks whose shortlist may be incomplete are scanned row by row (rare: near-duplicate descriptors)
+        unsigned gm_scan = (unsigned)(__ballot(scan) >> gshift) & 0xFFFFu;
+        while (gm_scan) {
+            const int l = __ffs(gm_scan) - 1;
+            gm_scan &= gm_scan - 1;
+            const int cc = cb + l, te = min((cc + 1) * kMfmaChunk, nt);
+            for (int t = cc * kMfmaChunk; t < te; t++) top2_lex(group_distance(qv, dt + (size_t)t * 64, sub), t, d0, i0, d1, i1);
+        }
+        if (scan) { a = -1; b = -1; e3 = -1; }             // covered by the scan
+        // the other chunks' candidates: slot s = 16*which + lane; four train rows are fetched at a time (one memory round trip
+        // per four candidates instead of one each) and evaluated by the whole group, in any order (top2_lex is symmetric)
+        unsigned long long m = ((unsigned long long)((unsigned)(__ballot(a >= 0) >> gshift) & 0xFFFFu)) |
+                               ((unsigned long long)((unsigned)(__ballot(b >= 0) >> gshift) & 0xFFFFu) << 16) |
+                               ((unsigned long long)((unsigned)(__ballot(e3 >= 0) >> gshift) & 0xFFFFu) << 32);
+        while (m) {
+            int cnd[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int sl = m ? __ffsll((long long)m) - 1 : -1;
+                if (m) m &= m - 1;
+                const int ln = base + (sl & 15);
+                const int va = __shfl(a, ln), vb = __shfl(b, ln), vc = __shfl(e3, ln);
+                cnd[k] = sl < 0 ? -1 : (sl < 16 ? va : (sl < 32 ? vb : vc));
             }
+            float4 tv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) tv[k] = reinterpret_cast<const float4*>(dt + (size_t)max(cnd[k], 0) * 64)[sub];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (cnd[k] >= 0) top2_lex(group_distance_tv(qv, tv[k], sub), cnd[k], d0, i0, d1, i1);
         }
     }
     if (live && sub == 0) {
