@@ -648,7 +648,8 @@ static const int kSmallWin = 128;       // descriptor windows up to this size us
 // column) task of k_descriptor64_big costs about ceil(win/256) lane passes x ceil((win/21 + 2)/16) tap batches, 1..9 units),
 // which the task dealing of that kernel relies on.  Counting sort, one workgroup per image.
 static const int kBigBins = 1024;
-__global__ __launch_bounds__(1024) void k_big_sort(const int4* __restrict__ in, int4* __restrict__ out, const int* __restrict__ big_n, int cap)
+static const int kTripleWin = 246;     // windows up to this size: three destination columns per task (3 x 246 floats share the 740-float row buffer)
+__global__ __launch_bounds__(1024) void k_big_sort(const int4* __restrict__ in, int4* __restrict__ out, const int* __restrict__ big_n, int* __restrict__ big_large, int cap)
 {
     const int im = blockIdx.x, tid = threadIdx.x;
     const int n = min(big_n[im], cap);
@@ -668,6 +669,7 @@ __global__ __launch_bounds__(1024) void k_big_sort(const int4* __restrict__ in, 
         __syncthreads();
     }
     hist[tid] = scan[tid] - v;                     // first output position of the bin
+    if (tid == kBigBins - 1 - kTripleWin) big_large[im] = scan[tid] - v;     // entries before this bin are wider than kTripleWin
     __syncthreads();
     for (int e = tid; e < n; e += 1024) {
         int4 par = in[im * cap + e];
@@ -781,7 +783,7 @@ __device__ __forceinline__ AreaTab area_tab(int dx, int ssize, double scale)
 __device__ __forceinline__ uint8_t sat_u8(float v) { int iv = cv_round_f(v); return (uint8_t)(iv < 0 ? 0 : iv > 255 ? 255 : iv); }
 
 struct DescArgs { const uint8_t* img[2]; uvo_keypoint* kps[2]; float* desc[2]; const int* n[2]; const float* DW;
-                  const int4* big_par; const int* big_n; int cap; };
+                  const int4* big_par; const int* big_n; const int* big_large; int cap; };
 
 // PATCH (21 x 21, shared) -> gradients, 4x4x4 sums, normalisation -> a.desc[im][k]; 256 threads, PATCH already synchronised
 __device__ __forceinline__ void describe_tail(const DescArgs& a, int im, int k, const int (*PATCH)[21])
@@ -981,32 +983,36 @@ __global__ __launch_bounds__(256) void k_descriptor64_big_tabs(DescArgs a, AreaT
 __device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
-static const int kBigCols = 1, kBigTriples = 21 / kBigCols;   // destination columns per task, tasks per keypoint (3 x 7 was slower: 36 KB of row buffers per workgroup halve the resident waves)
-// One task per WAVE (no workgroup barriers: four independent waves per workgroup, 8192 waves resident).  A task is kBigCols
-// adjacent destination columns of one keypoint: their horizontal passes run one after the other into kBigCols row
-// buffers, then one vertical pass finishes the 21 * kBigCols outputs, a lane each.
+// One task per WAVE (no workgroup barriers: four independent waves per workgroup, 8192 waves resident).  A task is one
+// destination column of a keypoint whose window is wider than kTripleWin, or three adjacent columns of a narrower one (their
+// horizontal passes run one after the other into three thirds of the row buffer, then one vertical pass finishes the 63
+// outputs, a lane each): the per-task work that does not depend on the window -- parameters, tables, the vertical pass,
+// its 21-of-64 lanes -- is shared by three columns where the LDS allows it.
 __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int h, uint8_t* __restrict__ patch, const AreaTab* __restrict__ tabs)
 {
     const int im = blockIdx.y, lane = threadIdx.x & 63, wv = sgpr_i(threadIdx.x >> 6);
-    const int nb = a.big_n[im];
-    __shared__ float s_bufrow[4][kBigCols][740];
-    float* bufrow0 = s_bufrow[wv][0];
+    const int nb = a.big_n[im], nl = min(a.big_large[im], nb);        // the sorted list: nl wide windows first
+    __shared__ float s_bufrow[4][740];
+    float* bufrow0 = s_bufrow[wv];
     const uint8_t* __restrict__ img = a.img[im];
-    // Tasks t = kBigTriples*e + dx/kBigCols run down the cost-sorted list and are dealt to the waves in rounds of alternating direction
-    // (round r hands task r*NW + p to wave p, or to wave NW-1-p when r is odd): costs span 1..9 units, and this keeps the
-    // per-wave totals within about one task of each other, where a plain stride left the waves that drew the giants
-    // running long after the rest.  (A shared atomic cursor does not work here: ~55k device-scope increments of one
-    // address from 8 XCDs serialise at ~7 ns each.)
-    const int ntask = nb * kBigTriples, NW = gridDim.x * 4, wid = blockIdx.x * 4 + wv;
+    // Tasks run down the size-sorted list (21 per wide keypoint, then 7 per narrower one) and are dealt to the waves in
+    // rounds of alternating direction (round r hands task r*NW + p to wave p, or to wave NW-1-p when r is odd): costs span
+    // 1..9 units, and this keeps the per-wave totals within about one task of each other, where a plain stride left the
+    // waves that drew the giants running long after the rest.  (A shared atomic cursor does not work here: ~55k
+    // device-scope increments of one address from 8 XCDs serialise at ~7 ns each.)
+    const int nt1 = nl * 21, ntask = nt1 + (nb - nl) * 7, NW = gridDim.x * 4, wid = blockIdx.x * 4 + wv;
     auto task_of = [&](int r) { return r * NW + ((r & 1) ? NW - 1 - wid : wid); };
+    auto entry_of = [&](int t) { return t < nt1 ? t / 21 : nl + (t - nt1) / 7; };
     int4 par_next = make_int4(0, 0, 0, 0);
-    if (task_of(0) < ntask) par_next = a.big_par[im * a.cap + task_of(0) / kBigTriples];
+    if (task_of(0) < ntask) par_next = a.big_par[im * a.cap + entry_of(task_of(0))];
     for (int r = 0; r * NW < ntask; r++) {
         const int t = task_of(r);
         const int4 par = par_next;                            // (sorted index, win_size, start_x, start_y) from k_rank_scatter
-        if (task_of(r + 1) < ntask) par_next = a.big_par[im * a.cap + task_of(r + 1) / kBigTriples];      // next task's, in flight meanwhile
+        if (task_of(r + 1) < ntask) par_next = a.big_par[im * a.cap + entry_of(task_of(r + 1))];      // next task's, in flight meanwhile
         if (t >= ntask) continue;
-        const int e = t / kBigTriples, dx0 = (t - e * kBigTriples) * kBigCols;
+        const int e = entry_of(t);
+        const int ncols = t < nt1 ? 1 : 3, dx0 = t < nt1 ? t - e * 21 : 3 * ((t - nt1) - (e - nl) * 7);
+        const int bstride = kTripleWin;                       // floats between the column buffers of a three-column task
         // the task is the same for every lane: scalar registers, so that row clamps, row addresses and tap weights are SALU work
         const int win_size = sgpr_i(par.y) & 0xFFFF, start_x = sgpr_i(par.z), start_y = sgpr_i(par.w);
         const int iscale = sgpr_i(par.y) >> 16;               // non-zero: resizeAreaFast_ with this integer scale (k_big_sort)
@@ -1020,9 +1026,9 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
         const int xa = xlo & ~3, ilo = xlo - start_x, ihi = xhi - start_x;
         if (area_fast) {
             // resizeAreaFast_: integer block sums (any order); column c = dy*iscale + sy of the window
-            for (int d = 0; d < kBigCols; d++) {
+            for (int d = 0; d < ncols; d++) {
                 const int dx = dx0 + d;
-                int* colsum = reinterpret_cast<int*>(bufrow0 + d * 740);
+                int* colsum = reinterpret_cast<int*>(bufrow0 + d * bstride);
                 if (vec_ok) {
                     for (int x4 = xa + 4 * lane; x4 < xhi; x4 += 256) {
                         int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
@@ -1051,9 +1057,9 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (lane < 21 * kBigCols) {
+            if (lane < 21 * ncols) {
                 const int d = lane / 21, dy = lane - d * 21;
-                const int* colsum = reinterpret_cast<const int*>(bufrow0 + d * 740);
+                const int* colsum = reinterpret_cast<const int*>(bufrow0 + d * bstride);
                 int sum = 0;
                 for (int sy = 0; sy < iscale; sy++) sum += colsum[dy * iscale + sy];
                 int result;
@@ -1063,9 +1069,9 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
             }
         } else {
             const AreaTab* tab = tabs + ((size_t)im * a.cap + e) * 21;
-            for (int d = 0; d < kBigCols; d++) {
+            for (int d = 0; d < ncols; d++) {
                 const int dx = dx0 + d;
-                float* bufrow = bufrow0 + d * 740;
+                float* bufrow = bufrow0 + d * bstride;
                 AreaTab tx = tab[dx];                          // the same for every lane: keep it in scalar registers
                 tx.sx1 = sgpr_i(tx.sx1); tx.sx2 = sgpr_i(tx.sx2);
                 tx.a_first = sgpr_f(tx.a_first); tx.a_mid = sgpr_f(tx.a_mid); tx.a_last = sgpr_f(tx.a_last);
@@ -1124,9 +1130,9 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (lane < 21 * kBigCols) {                     // vertical passes of the three columns, 21 lanes each
+            if (lane < 21 * ncols) {                        // vertical passes of the task's columns, 21 lanes each
                 const int d = lane / 21, dy = lane - d * 21;
-                const float* bufrow = bufrow0 + d * 740;
+                const float* bufrow = bufrow0 + d * bstride;
                 const AreaTab ty = tab[dy];
                 const int r_begin = ty.has_first ? ty.sx1 - 1 : ty.sx1;
                 const int r_end = ty.has_last ? ty.sx2 + 1 : ty.sx2;
@@ -1276,9 +1282,9 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
     {
         StageTimer t(c, ST_DESCRIPTOR);
         DescArgs da = { { c->d_img[0], c->d_img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
-                        { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->cap };      // the sorted list
+                        { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap };      // the sorted list
         const size_t lds_small = sizeof(float) * 21 * (kSmallWin | 1);
-        hipLaunchKernelGGL(k_big_sort, dim3(nimg), dim3(1024), 0, c->stream, c->d_big_par, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->cap);
+        hipLaunchKernelGGL(k_big_sort, dim3(nimg), dim3(1024), 0, c->stream, c->d_big_par, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap);
         hipLaunchKernelGGL(k_descriptor64_big_tabs, dim3((c->cap * 21 + 255) / 256, nimg), dim3(256), 0, c->stream, da, c->d_big_tabs);
         hipLaunchKernelGGL(k_descriptor64_big, dim3(1024, nimg), dim3(256), 0, c->stream, da, w, h, c->d_big_patch, c->d_big_tabs);
         hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(1024, nimg), dim3(256), 0, c->stream, da, c->d_big_patch);
