@@ -106,7 +106,7 @@ def main():
     ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
 
     order = ping_pong(args.frames)
-    records = torch.zeros((max(args.steps, 1), multirank.RECORD_WIDTH), dtype=torch.float64)
+    records = np.zeros((max(args.steps, 1), multirank.RECORD_WIDTH), dtype=np.float64)
 
     def step():
         k = next(order)
@@ -140,8 +140,8 @@ def main():
         r = ctx.stereo_collect(0.05)
         n_valid += r.valid
         kp_sum += r.n_left
-        records[i] = multirank.make_record(rank, i, r)
-    allrec = multirank.gather_records(records, dev)  # pose records of all streams: one RCCL all-gather (N > 1)
+        multirank.fill_record(records, i, rank, i, r)
+    allrec = multirank.gather_records(torch.from_numpy(records), dev)  # pose records of all streams: one RCCL all-gather (N > 1)
     fence()
     dt = multirank.max_over_ranks(time.perf_counter() - t0, dev)
     assert [int(v) for v in allrec[:, 0, 0].tolist()] == list(range(world))
