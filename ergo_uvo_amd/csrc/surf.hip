@@ -258,8 +258,10 @@ struct OctC {
     static constexpr int STEP = 1 << O;
     static constexpr int size(int l) { return (9 + 6 * l) << O; }
     static constexpr int margin(int l) { return (size(l) / 2) / STEP; }
-    static constexpr int LO = -margin(4) * STEP;                  // the largest layer reaches furthest left/up ...
-    static constexpr int HI = -margin(4) * STEP + size(4);        // ... and furthest right/down
+    // extent of the integral tile around a sample: the largest layer a detection workgroup evaluates is layer 3 (the outer
+    // layers 0 and 4 are evaluated by k_hessian_finish from the global integral), and it reaches furthest both ways
+    static constexpr int LO = -margin(3) * STEP;
+    static constexpr int HI = -margin(3) * STEP + size(3);
 };
 
 // Integral tile of a TW-sample-wide workgroup: TWs columns, padded to whole quads (TWq), PW words per column-residue plane.
@@ -1252,8 +1254,9 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             StageTimer t(c, ST_HESSIAN_O0 + o);
             const OctavePat& op = ops[o];
             hipError_t e;
-            // tile shapes chosen by pipelined throughput (tools/probe/ab.sh): octave 0 64 x 24 samples = 47 KB of LDS (18 KB det planes,
-            // 28 KB integral tile), octave 1 32 x 24 = 76 KB (9 KB + 66 KB: the 66-pixel templates make the halo most of the tile)
+            // tile shapes chosen by pipelined throughput (tools/probe/ab.sh): octave 0 64 x 24 samples = 40 KB of LDS (18 KB det planes,
+            // 19 KB integral tile, 3 KB survivor list), octave 1 32 x 24 = 59 KB (9 KB + 48 KB: the 54-pixel templates make the halo
+            // most of the tile)
             if (o == 0)      e = launch_hessian_c<0, 64, 24, 512>(c, nimg, op, thr);
             else if (o == 1) e = launch_hessian_c<1, 32, 24, 512>(c, nimg, op, thr);
             else if (o == 2) e = launch_hessian_p<2, 32, 16, 512>(c, nimg, op, thr);
