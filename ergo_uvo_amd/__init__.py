@@ -400,3 +400,16 @@ class Context:
             self._lib.uvo_timing_get(self._h, i, C.byref(ms), C.byref(n))
             out[self._lib.uvo_timing_name(self._h, i).decode()] = (ms.value, n.value)
         return out
+
+
+def resize_camera_matrix(original_width: int, original_height: int, desired_width: int, K, dist4):
+    """resize_camera_matrix (VO_utility.cpp:658-675): -> (K scaled by the width ratio, newK = getOptimalNewCameraMatrix(alpha=0),
+    desired_height).  Host arithmetic, once per run; no context needed."""
+    Ks = np.array(K, np.float64).reshape(3, 3).copy()
+    newK = np.zeros((3, 3), np.float64)
+    d4 = _np(dist4, np.float64)
+    dh = C.c_int(0)
+    st = _lib.lib().uvo_resize_camera_matrix(int(original_width), int(original_height), int(desired_width), _p(Ks), _p(d4), _p(newK), C.byref(dh))
+    if st != 0:
+        raise UvoError(st, "uvo_resize_camera_matrix")
+    return Ks, newK, dh.value

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <atomic>
 #include <math.h>
+#include <float.h>
 #include <new>
 #include <algorithm>
 #include <atomic>
@@ -761,6 +762,65 @@ extern "C" int uvo_stereo_get(uvo_ctx* m, const char* what, void* out, int cap_b
 
 
 // ------------------------------------------------------------------------------------------ get_image
+// cvUndistortPointsInternal for one point, no R, no P (normalised output): five fixed-point iterations of the inverse of the
+// (k1, k2, p1, p2) model
+static void undistort_point_normalised(double u, double v, const double* K, const double* d4, double* xo, double* yo)
+{
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5], ifx = 1. / fx, ify = 1. / fy;
+    const double k1 = d4[0], k2 = d4[1], p1 = d4[2], p2 = d4[3];
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((0 * r2 + k2) * r2 + k1) * r2);
+        if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+        const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x) + 0 * r2 + 0 * r2 * r2;
+        const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y + 0 * r2 + 0 * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    *xo = x; *yo = y;
+}
+
+// VO_utility.cpp:658-675.  getOptimalNewCameraMatrix(alpha = 0, no validPixROI, centerPrincipalPoint = false): a 9 x 9 grid of
+// image points is undistorted to normalised coordinates, the rectangle inscribed in the grid's border is mapped onto the
+// viewport (calibration.cpp cvGetOptimalNewCameraMatrix / icvGetRectangles).  Host arithmetic, once per run.
+extern "C" uvo_status uvo_resize_camera_matrix(int original_width, int original_height, int desired_width, double* K, const double* dist4,
+                                               double* newK, int* desired_height_out)
+{
+    if (!K || !dist4 || !newK || desired_width <= 0 || original_width <= 0 || original_height <= 0) return UVO_INVALID_ARG;
+    const double ratio = (double)original_width / (double)desired_width;
+    const int desired_height = (int)(original_height / ratio);
+    if (desired_height_out) *desired_height_out = desired_height;
+    const double skew = K[1];
+    for (int i = 0; i < 9; i++) K[i] = K[i] / ratio;
+    K[1] = skew; K[8] = 1;
+    const int N = 9;
+    double iX0 = -DBL_MAX, iX1 = DBL_MAX, iY0 = -DBL_MAX, iY1 = DBL_MAX;
+    double oX0 = DBL_MAX, oX1 = -DBL_MAX, oY0 = DBL_MAX, oY1 = -DBL_MAX;
+    for (int y = 0; y < N; y++)
+        for (int x = 0; x < N; x++) {
+            double px, py;
+            undistort_point_normalised((double)x * (desired_width - 1) / (N - 1), (double)y * (desired_height - 1) / (N - 1), K, dist4, &px, &py);
+            oX0 = std::min(oX0, px); oX1 = std::max(oX1, px); oY0 = std::min(oY0, py); oY1 = std::max(oY1, py);
+            if (x == 0) iX0 = std::max(iX0, px);
+            if (x == N - 1) iX1 = std::min(iX1, px);
+            if (y == 0) iY0 = std::max(iY0, py);
+            if (y == N - 1) iY1 = std::min(iY1, py);
+        }
+    const double alpha = 0;
+    const double fx0 = (desired_width - 1) / (iX1 - iX0), fy0 = (desired_height - 1) / (iY1 - iY0);
+    const double cx0 = -fx0 * iX0, cy0 = -fy0 * iY0;
+    const double fx1 = (desired_width - 1) / (oX1 - oX0), fy1 = (desired_height - 1) / (oY1 - oY0);
+    const double cx1 = -fx1 * oX0, cy1 = -fy1 * oY0;
+    for (int i = 0; i < 9; i++) newK[i] = K[i];
+    newK[0] = fx0 * (1 - alpha) + fx1 * alpha;
+    newK[4] = fy0 * (1 - alpha) + fy1 * alpha;
+    newK[2] = cx0 * (1 - alpha) + cx1 * alpha;
+    newK[5] = cy0 * (1 - alpha) + cy1 * alpha;
+    return UVO_OK;
+}
+
 extern "C" uvo_status uvo_get_image(uvo_ctx* c, const uint8_t* rgb, int w, int h, int stride, int mem, const double* K, const double* dist4,
                                     const double* newK, int desired_width, int clahe, int clip_limit, uint8_t* out, int out_mem,
                                     int* out_w, int* out_h)

@@ -256,6 +256,22 @@ Mat convert_from_homogeneous_coords(const Mat& points4d)
     return out;
 }
 
+// VOU:658-675: cameraMatrix /= ratio (skew kept, K[2][2] = 1); newCamMatrix = getOptimalNewCameraMatrix(K, dist, size, 0, size, 0)
+void resize_camera_matrix(Mat original_image, Mat& cameraMatrix, Mat distortionCoeff, Mat& newCamMatrix)
+{
+    require(!original_image.empty(), "resize_camera_matrix: empty image");
+    double K[9], newK[9], d4[4] = {0, 0, 0, 0};
+    doubles_of(cameraMatrix, 3, 3, K, "resize_camera_matrix: cameraMatrix must be 3x3 CV_64F");
+    require(!distortionCoeff.empty() && distortionCoeff.type() == CV_64FC1 && distortionCoeff.rows * distortionCoeff.cols == 4,
+            "resize_camera_matrix: distortion must be (k1, k2, p1, p2) CV_64F");
+    for (int i = 0, k = 0; i < distortionCoeff.rows; i++) for (int j = 0; j < distortionCoeff.cols; j++) d4[k++] = distortionCoeff.at<double>(i, j);
+    int dh = 0;
+    SHIM_TRY(uvo_resize_camera_matrix(original_image.cols, original_image.rows, DESIRED_WIDTH, K, d4, newK, &dh), "uvo_resize_camera_matrix");
+    if (cameraMatrix.empty() || cameraMatrix.type() != CV_64FC1) cameraMatrix = Mat(3, 3, CV_64FC1);
+    newCamMatrix = Mat(3, 3, CV_64FC1);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { cameraMatrix.at<double>(i, j) = K[3*i + j]; newCamMatrix.at<double>(i, j) = newK[3*i + j]; }
+}
+
 // VOU:337-379: resize INTER_AREA to DESIRED_WIDTH -> RGB2GRAY -> undistort -> CLAHE(CLIP_LIMIT) when CLAHE_CORRECTION
 Mat get_image(const Mat& current_img, const Mat& cameraMatrix, const Mat& distortionCoeff, const Mat& newCamMatrix)
 {

@@ -199,6 +199,13 @@ uvo_status uvo_get_image(uvo_ctx* c, const uint8_t* rgb, int w, int h, int strid
                          const double* newK, int desired_width, int clahe, int clip_limit, uint8_t* out, int out_mem,
                          int* out_w, int* out_h);
 
+/* ---- resize_camera_matrix (VO_utility.h:112 -> VO_utility.cpp:658-675), once per run, host arithmetic only (no context):
+ * K (3x3 row-major, in/out) is divided by ratio = original_width / desired_width with the skew K[0][1] kept and K[2][2] = 1;
+ * newK (3x3 out) = cv::getOptimalNewCameraMatrix(K, dist4, Size(desired_width, desired_height), alpha = 0, same size), where
+ * desired_height = (int)(original_height / ratio) is also returned.  dist4 = (k1, k2, p1, p2). */
+uvo_status uvo_resize_camera_matrix(int original_width, int original_height, int desired_width, double* K, const double* dist4,
+                                    double* newK, int* desired_height);
+
 /* ---- per-stage device timing (HIP events on the context's stream) for bench.py ---- */
 uvo_status uvo_timing_enable(uvo_ctx* c, int on);
 int        uvo_timing_count(uvo_ctx* c);

@@ -38,6 +38,8 @@ uvocv::Mat compute_projection_matrix(const uvocv::Mat& R, const uvocv::Mat& t, c
 double     compute_scale_factor(float distance, const uvocv::Mat& world_points);                                        // VOU:23-38
 uvocv::Mat convert_3Dpoints_camera(const uvocv::Mat& points_to_convert, const uvocv::Mat& R_to_from, const uvocv::Mat& t_to_from); // VOU:46-63
 uvocv::Mat convert_from_homogeneous_coords(const uvocv::Mat& points4d);                                                 // VOU:71-83
+// VO_utility.h:112: scales cameraMatrix in place by original width / DESIRED_WIDTH, newCamMatrix = getOptimalNewCameraMatrix(alpha = 0)
+void resize_camera_matrix(uvocv::Mat original_image, uvocv::Mat& cameraMatrix, uvocv::Mat distortionCoeff, uvocv::Mat& newCamMatrix);
 uvocv::Mat get_image(const uvocv::Mat& current_img, const uvocv::Mat& cameraMatrix, const uvocv::Mat& distortionCoeff,
                      const uvocv::Mat& newCamMatrix);                                                                  // VOU:337-379
 void detect_features(uvocv::Mat img, std::vector<uvocv::KeyPoint>& keypoints, uvocv::Mat& descriptors);                 // VOU:91-126

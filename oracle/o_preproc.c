@@ -225,3 +225,69 @@ int orc_get_image(const uint8_t* rgb, int w, int h, int stride, int desired_widt
     free(gray);
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * resize_camera_matrix (reference uvo_libraries/src/VO_utility.cpp:658-675): K scaled in place by the width ratio (skew and
+ * K[2][2] restored), then cv::getOptimalNewCameraMatrix(K, dist, Size(dw, dh), alpha = 0, Size(dw, dh), validPixROI = 0,
+ * centerPrincipalPoint = false).  OpenCV 4.5 calib3d (calibration.cpp cvGetOptimalNewCameraMatrix / icvGetRectangles,
+ * undistort.dispatch.cpp cvUndistortPointsInternal), restated from the published algorithm -- PARITY UNPINNED, like the
+ * rest of this file: a 9 x 9 grid of image points (x*(w-1)/8, y*(h-1)/8) is undistorted to normalised coordinates (five
+ * fixed-point iterations, no R, no P), the inscribed rectangle of the grid's border is mapped onto the viewport.
+ * ------------------------------------------------------------------------------------------- */
+static void undistort_point_normalised(double u, double v, const double* K, const double* d4, double* xo, double* yo)
+{
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5], ifx = 1. / fx, ify = 1. / fy;
+    const double k1 = d4[0], k2 = d4[1], p1 = d4[2], p2 = d4[3];
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        /* k3..k6 = 0: icdist = (1 + ((k[7]*r2 + k[6])*r2 + k[5])*r2) / (1 + ((k[4]*r2 + k[1])*r2 + k[0])*r2) */
+        double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((0 * r2 + k2) * r2 + k1) * r2);
+        if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }        /* "test: undistortPoints.regression_14583" */
+        const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x) + 0 * r2 + 0 * r2 * r2;
+        const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y + 0 * r2 + 0 * r2 * r2;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    *xo = x; *yo = y;
+}
+
+int orc_resize_camera_matrix(int original_width, int original_height, int desired_width, double* K, const double* dist4, double* newK,
+                             int* desired_height_out)
+{
+    if (desired_width <= 0 || original_width <= 0 || original_height <= 0) return -1;
+    const double ratio = (double)original_width / (double)desired_width;
+    const int desired_height = (int)(original_height / ratio);
+    if (desired_height_out) *desired_height_out = desired_height;
+    const double skew = K[1];
+    for (int i = 0; i < 9; i++) K[i] = K[i] / ratio;
+    K[1] = skew; K[8] = 1;
+    /* icvGetRectangles */
+    const int N = 9;
+    double iX0 = -DBL_MAX, iX1 = DBL_MAX, iY0 = -DBL_MAX, iY1 = DBL_MAX;
+    double oX0 = DBL_MAX, oX1 = -DBL_MAX, oY0 = DBL_MAX, oY1 = -DBL_MAX;
+    for (int y = 0; y < N; y++)
+        for (int x = 0; x < N; x++) {
+            double px, py;
+            undistort_point_normalised((double)x * (desired_width - 1) / (N - 1), (double)y * (desired_height - 1) / (N - 1), K, dist4, &px, &py);
+            oX0 = oX0 < px ? oX0 : px; oX1 = oX1 > px ? oX1 : px; oY0 = oY0 < py ? oY0 : py; oY1 = oY1 > py ? oY1 : py;
+            if (x == 0) iX0 = iX0 > px ? iX0 : px;
+            if (x == N - 1) iX1 = iX1 < px ? iX1 : px;
+            if (y == 0) iY0 = iY0 > py ? iY0 : py;
+            if (y == N - 1) iY1 = iY1 < py ? iY1 : py;
+        }
+    const double inner_x = iX0, inner_y = iY0, inner_w = iX1 - iX0, inner_h = iY1 - iY0;
+    const double outer_x = oX0, outer_y = oY0, outer_w = oX1 - oX0, outer_h = oY1 - oY0;
+    const double alpha = 0;
+    const double fx0 = (desired_width - 1) / inner_w, fy0 = (desired_height - 1) / inner_h;
+    const double cx0 = -fx0 * inner_x, cy0 = -fy0 * inner_y;
+    const double fx1 = (desired_width - 1) / outer_w, fy1 = (desired_height - 1) / outer_h;
+    const double cx1 = -fx1 * outer_x, cy1 = -fy1 * outer_y;
+    for (int i = 0; i < 9; i++) newK[i] = K[i];                      /* cvConvert(cameraMatrix, &matM): the other entries are K's */
+    newK[0] = fx0 * (1 - alpha) + fx1 * alpha;
+    newK[4] = fy0 * (1 - alpha) + fy1 * alpha;
+    newK[2] = cx0 * (1 - alpha) + cx1 * alpha;
+    newK[5] = cy0 * (1 - alpha) + cy1 * alpha;
+    return 0;
+}

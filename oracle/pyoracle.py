@@ -446,3 +446,15 @@ def get_image(rgb, desired_width, K, dist4, newK, clahe_on=True, clip_limit=3):
         raise ValueError("get_image: enlarging is outside the restatement")
     assert (ow.value, oh.value) == (desired_width, dh)
     return out
+
+
+def resize_camera_matrix(original_width, original_height, desired_width, K, dist4):
+    """-> (K scaled, newK, desired_height): reference VO_utility.cpp:658-675."""
+    Ks = np.array(K, np.float64).reshape(3, 3).copy()
+    newK = np.zeros((3, 3), np.float64)
+    dh = C.c_int(0)
+    rc = lib().orc_resize_camera_matrix(int(original_width), int(original_height), int(desired_width), _p(Ks), _p(_c(dist4, np.float64)),
+                                        _p(newK), C.byref(dh))
+    if rc != 0:
+        raise ValueError("resize_camera_matrix: bad sizes")
+    return Ks, newK, dh.value

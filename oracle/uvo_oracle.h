@@ -204,5 +204,8 @@ void orc_undistort_u8(const uint8_t* src, int w, int h, const double* K, const d
 void orc_clahe_u8(const uint8_t* src, int w, int h, double clip_limit, uint8_t* dst);
 int  orc_get_image(const uint8_t* rgb, int w, int h, int stride, int desired_width, const double* K, const double* dist4,
                    const double* newK, int clahe_on, int clip_limit, uint8_t* out, int* out_w, int* out_h);
+/* reference VO_utility.cpp:658-675 (resize_camera_matrix): K scaled in place, newK = getOptimalNewCameraMatrix(alpha = 0) */
+int  orc_resize_camera_matrix(int original_width, int original_height, int desired_width, double* K, const double* dist4, double* newK,
+                              int* desired_height_out);
 
 #endif

@@ -140,3 +140,40 @@ def test_get_image_device_in_out_feeds_the_detector(ctx, oracle):
     assert np.array_equal(desc.view(np.uint32), odesc.view(np.uint32))
     with pytest.raises(uvo.UvoError):
         ctx.get_image(img, 1280, K, d, newK)                                           # enlarging is not provided
+
+
+# ---- resize_camera_matrix (VO_utility.cpp:658-675): host arithmetic, no GPU needed ----
+def test_resize_camera_matrix_zero_distortion_is_the_scaled_matrix():
+    from oracle import pyoracle as po
+    K = np.array([[1400.0, 0.7, 955.0], [0, 1395.0, 542.0], [0, 0, 1]])
+    Ks, newK, dh = po.resize_camera_matrix(1920, 1080, 960, K, [0, 0, 0, 0])
+    assert dh == 540
+    expect = K / 2.0
+    expect[0, 1] = 0.7; expect[2, 2] = 1.0                       # skew kept, K[2][2] restored
+    assert np.array_equal(Ks, expect)
+    # without distortion the undistorted 9 x 9 grid is the pixel grid: the inscribed rectangle is the whole image and the
+    # optimal matrix reproduces fx, fy, cx, cy (the skew is not part of the undistortion model, so cx is only as exact as it)
+    K0 = K.copy(); K0[0, 1] = 0
+    Ks0, newK0, _ = po.resize_camera_matrix(1920, 1080, 960, K0, [0, 0, 0, 0])
+    assert np.allclose(newK0, Ks0, rtol=0, atol=1e-9)
+
+
+def test_resize_camera_matrix_centred_radial_distortion_stays_centred():
+    from oracle import pyoracle as po
+    W, H, DW = 1280, 720, 640
+    K = np.array([[800.0, 0, (W - 1) / 2.0], [0, 800.0, (H - 1) / 2.0], [0, 0, 1]])
+    for k1 in (-0.25, 0.12):
+        Ks, newK, dh = po.resize_camera_matrix(W, H, DW, K, [k1, 0.03, 0, 0])
+        assert dh == 360
+        assert np.isfinite(newK).all() and newK[0, 0] > 0 and newK[1, 1] > 0
+        # distortion symmetric about the principal point: the inscribed rectangle stays centred on it
+        assert abs(newK[0, 2] - Ks[0, 2]) < 0.5 and abs(newK[1, 2] - Ks[1, 2]) < 0.5
+        # barrel (k1 < 0): undistorting stretches the border outwards, so the rectangle inscribed in it is larger in
+        # normalised units and alpha = 0 gives a shorter focal length; pincushion the other way round
+        assert (newK[0, 0] < Ks[0, 0]) == (k1 < 0) and (newK[1, 1] < Ks[1, 1]) == (k1 < 0)
+    # the library's host implementation is the same arithmetic (loads without a GPU: no device call is made)
+    import ergo_uvo_amd as uvo
+    for d in ([-0.25, 0.03, 1e-3, -2e-3], [0.12, -0.01, 0, 0], [0, 0, 0, 0]):
+        a = po.resize_camera_matrix(W, H, DW, K, d)
+        b = uvo.resize_camera_matrix(W, H, DW, K, d)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]

@@ -137,8 +137,13 @@ def test_get_image_through_the_shim_matches_oracle(oracle, tmp_path):
     raw = open(outp, "rb").read()
     ow, oh = struct.unpack("<2i", raw[:8])
     assert (ow, oh) == (DW, dh)
-    got = np.frombuffer(raw[8:], np.uint8).reshape(oh, ow)
+    got = np.frombuffer(raw[8:8 + ow * oh], np.uint8).reshape(oh, ow)
     assert np.array_equal(got, oracle.get_image(img, DW, K, dist, newK, True, 8))
+    # resize_camera_matrix through the same function surface: K scaled in place, newK = getOptimalNewCameraMatrix(alpha = 0)
+    both = np.frombuffer(raw[8 + ow * oh:], np.float64)
+    oK, oN, odh = oracle.resize_camera_matrix(img.shape[1], img.shape[0], DW, K, dist)
+    assert odh == dh
+    assert np.array_equal(both[:9].reshape(3, 3), oK) and np.array_equal(both[9:].reshape(3, 3), oN)
 
 
 @pytest.mark.gpu
