@@ -35,6 +35,7 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT = 1920, 1080
 MIN_HESSIAN_C3 = 6387            # frozen: frame 0 of seed 20250906 gives 3001 / 3008 keypoints
 MFMA_F32_PEAK_TFLOPS = 157.3    # dense f32-input MFMA, MI355X_MICROARCH.md
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -223,9 +224,13 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5)},
-            "roofline_match": {"bound": "mfma", "kernel": "k_match_mfma (v_mfma_f32_32x32x2_f32), two calls per pair",
+            # the f32 contraction (F = 2 Nq Nt 64) is priced against the f32 MFMA peak; it is executed on the bf16 pipe
+            # as three bf16 products per f32 product (hi.hi + hi.lo + lo.hi), so the executed rate is 3x, against the bf16 peak
+            "roofline_match": {"bound": "mfma", "kernel": "k_match_mfma (v_mfma_f32_32x32x16_bf16 on bf16 hi/lo splits), two calls per pair",
                                "achieved": round(mm_tflops, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": round(mm_tflops / MFMA_F32_PEAK_TFLOPS, 5), "flops_per_pair": f_pair},
+                               "frac": round(mm_tflops / MFMA_F32_PEAK_TFLOPS, 5), "flops_per_pair": f_pair,
+                               "executed": {"achieved": round(3 * mm_tflops, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s (bf16)",
+                                            "frac": round(3 * mm_tflops / MFMA_BF16_PEAK_TFLOPS, 5)}},
             "step_latency_ms": latency,
             "pair_hbm_frac": round(algorithmic_bytes_pair(WIDTH, HEIGHT, 3000) * value / world / 1e9 / HBM_PEAK_GBS, 5),
             "stage_ms": stage_ms, "stage_launches_per_step": stage_calls,

@@ -7,8 +7,8 @@
 // that order is ~190 VALU operations per pair.  So the all-pairs work is done on the matrix cores instead, as a
 // SHORTLIST, and the exact order is spent only on the survivors:
 //
-// k_match_mfma    : S' = |t|^2 - 2 t.q for every (train, query) pair with v_mfma_f32_32x32x2_f32 (exact f32
-//                   products, 64 k-steps), grid (query tiles of 128, train chunks of 128).  Each lane owns one query
+// k_match_mfma    : S' = |t|^2 - 2 t.q for every (train, query) pair with v_mfma_f32_32x32x16_bf16 on bf16 hi/lo splits of the
+//                   floats (three MFMAs per 16 k), tiles of (128 queries, 128 train rows).  Each lane owns one query
 //                   column and keeps the four smallest S' of its rows (the row index rides in the low mantissa
 //                   bits); per (query, chunk) it emits those four.
 // k_match_resolve : 16 lanes per query.  lim = (second-smallest S' over all candidates) + margin.  Every train row that can
@@ -19,17 +19,16 @@
 //                   train index) are kept -- exactly what BFMatcher's insertion rule leaves after the full scan.
 // k_match_compact : ratio test + ordered stream compaction of the surviving matches (single workgroup scan).
 //
-// Margin: the MFMA value and OpenCV's float sum both differ from the real squared distance by at most
-// ~64 ulp of (|q|^2 + |t|^2), and the index bits cost 2^-16 of |S'|; kMarginRel = 6e-5 of that scale covers all three
-// several times over.
+// Margin: the split-bf16 contraction differs from the real t.q by less than (2^-15 + 2^-16) sum|t_k q_k| <= 2.3e-5 (|q|^2 + |t|^2),
+// so S' by twice that; OpenCV's float sum is within ~64 ulp of the real squared distance and the index bits cost 2^-16 of
+// |S'|: together below 6.5e-5 (|q|^2 + |t|^2) per value.  lim allows 2 * kMarginRel = 3e-4 of that scale.
 #include "uvo_ctx.h"
 #include "uvo_math.h"
 
 namespace uvo {
 
 static const int kMfmaChunk = 128;             // train rows per workgroup of k_match_mfma (7 index bits, see shortlist_key)
-static const int kRowStride = 68;              // floats per staged row: 64 + 4 so that the lanes' b128 reads spread over the LDS banks
-static const float kMarginRel = 6e-5f;
+static const float kMarginRel = 1.5e-4f;
 static const float kBig = 3.0e38f;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -49,50 +48,36 @@ __device__ __forceinline__ void top4_keys(float v, float& k0, float& k1, float& 
     k0 = fminf(k0, v);
 }
 
-// rows past the end are clamped to the last row (an unconditional load keeps the code free of branches); the caller
-// masks them through |t|^2 = kBig / q < nq
-__device__ __forceinline__ void load_half_row(const float* base, int row, int nrows, int h, float* reg)
+// ------------------------------------------------------------------------------------------
+// The contraction runs on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16: 16 k per instruction, 32 cycles) with every
+// float split in two bf16 terms, x = hi + lo (+ residual below 2^-16 |x|, round-to-nearest both times), and
+// t.q ~ hi.hi + hi.lo + lo.hi accumulated in f32: three MFMAs per 16 k instead of eight f32 ones (32x32x2, 64 cycles each),
+// 5.3x less matrix time for a product error below 2^-15 + 2^-16 of |t_k q_k| -- inside the margin the exact
+// re-evaluation of the shortlist already allows for (kMarginRel).  The chunk's train rows are split once, while they are
+// staged in LDS, and |t|^2 is taken from the f32 values there.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)       // bits 15:0 = bf16(a), 31:16 = bf16(b), round to nearest even
 {
-    const float4* src = reinterpret_cast<const float4*>(base + (size_t)min(row, nrows - 1) * 64 + 32 * h);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        float4 v = src[i];
-        reg[4*i] = v.x; reg[4*i+1] = v.y; reg[4*i+2] = v.z; reg[4*i+3] = v.w;
-    }
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void split_bf16(float x0, float x1, unsigned& hi, unsigned& lo)
+{
+    hi = cvt_pk_bf16(x0, x1);
+    const float h0 = __uint_as_float(hi << 16), h1 = __uint_as_float(hi & 0xFFFF0000u);
+    lo = cvt_pk_bf16(x0 - h0, x1 - h1);                                   // the differences are exact in f32
+}
+__device__ __forceinline__ void split_bf16x8(const float4 v0, const float4 v1, uint4& hi, uint4& lo)
+{
+    split_bf16(v0.x, v0.y, hi.x, lo.x); split_bf16(v0.z, v0.w, hi.y, lo.y);
+    split_bf16(v1.x, v1.y, hi.z, lo.z); split_bf16(v1.z, v1.w, hi.w, lo.w);
 }
 
-// one 32-row step: dots of the 32 train rows in `areg` with this lane's query, then the three smallest keys
-__device__ __forceinline__ void mfma_step(const float* areg, const float* breg, int tb, int t0, int nt, int n, int h, float* tn_lds,
-                                          float& wmax, float& k0, float& k1, float& k2, float& k3)
-{
-    f32x16 acc;
-#pragma unroll
-    for (int j = 0; j < 16; j++) acc[j] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; i++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[i], breg[i], acc, 0, 0, 0);
-    // |t|^2 of train row tb + n (any summation order will do: the margin absorbs it), handed to the lanes that hold
-    // that row's dots through the wave's LDS line
-    float tnr = 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; i++) tnr = __builtin_fmaf(areg[i], areg[i], tnr);
-    tnr += __shfl_xor(tnr, 32);
-    const bool valid = tb + n < nt;
-    wmax = fmaxf(wmax, valid ? tnr : 0.f);
-    if (h == 0) tn_lds[n] = valid ? tnr : kBig;             // rows past the end never win
-    __builtin_amdgcn_wave_barrier();
-    // acc[j] = t.q for train row tb + (j&3) + 8(j>>2) + 4h and this lane's query
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const int rl = 8*g + 4*h;
-        const float4 nn = *reinterpret_cast<const float4*>(tn_lds + rl);
-        const int rc = tb - t0 + rl;
-        top4_keys(shortlist_key(__builtin_fmaf(-2.f, acc[4*g + 0], nn.x), rc),     k0, k1, k2, k3);
-        top4_keys(shortlist_key(__builtin_fmaf(-2.f, acc[4*g + 1], nn.y), rc + 1), k0, k1, k2, k3);
-        top4_keys(shortlist_key(__builtin_fmaf(-2.f, acc[4*g + 2], nn.z), rc + 2), k0, k1, k2, k3);
-        top4_keys(shortlist_key(__builtin_fmaf(-2.f, acc[4*g + 3], nn.w), rc + 3), k0, k1, k2, k3);
-    }
-    __builtin_amdgcn_wave_barrier();
-}
+static const int kRowQuads = 17;               // uint4 per staged row: 8 of hi (64 bf16), 8 of lo, 1 of padding (68 words: the lanes'
+                                               // b128 reads spread over the LDS banks)
 
 // part: [chunk][cap] (k0, k1, k2, k3): the four smallest shortlist keys; chunk_tnmax[chunk]: max |t|^2 of the chunk's rows
 __global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ dq, const int* nq_p, int nq_imm,
@@ -101,49 +86,82 @@ __global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ dq
 {
     const int nq = nq_p ? *nq_p : nq_imm, nt = nt_p ? *nt_p : nt_imm;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    __shared__ __align__(16) float s_tn[4][32];
-    __shared__ __align__(16) float s_rows[kMfmaChunk * kRowStride];      // the chunk's train rows, shared by the four waves
-    float* tn_lds = s_tn[wave];
+    __shared__ __align__(16) float s_tn[kMfmaChunk];                     // |t|^2 of the staged rows (kBig past the end: never wins)
+    __shared__ uint4 s_rows[kMfmaChunk * kRowQuads];                     // the chunk's train rows as bf16 hi | lo, shared by the four waves
+    __shared__ int s_wmax;
     const int n = lane & 31, h = lane >> 5;
     // the counts live on the device, so the grid is a fixed number of workgroups that walk the (query tile, train chunk)
     // pairs: a cap x cap grid would be 4096 workgroups of which ~530 find work
     const int nqt = (nq + 127) / 128, ntiles = nqt * ((nt + kMfmaChunk - 1) / kMfmaChunk);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int tile_q = tile % nqt, tile_c = tile / nqt;
-    const int q0 = tile_q * 128 + wave * 32, t0 = tile_c * kMfmaChunk;
-    // B operand: this lane's query, k = 32h .. 32h+31 (MFMA step i consumes k = 32h + i from both operands)
-    const int q = q0 + n;
-    float breg[32];
-    load_half_row(dq, q, nq, h, breg);
-    {   // stage the chunk once: 128 rows x 16 float4, coalesced; rows past the end repeat the last one (masked below)
-        const float4* src = reinterpret_cast<const float4*>(dt);
-        for (int e = threadIdx.x; e < kMfmaChunk * 16; e += 256) {
-            const int r = e >> 4, c4 = e & 15;
-            *reinterpret_cast<float4*>(s_rows + r * kRowStride + 4 * c4) = src[(size_t)min(t0 + r, nt - 1) * 16 + c4];
-        }
-    }
-    __syncthreads();
-    float k0 = kBig, k1 = kBig, k2 = kBig, k3 = kBig;
-    const int tend = min(t0 + kMfmaChunk, nt);
-    float wmax = 0.f;
-    for (int tb = t0; tb < tend; tb += 32) {
-        float areg[32];                                    // A operand: train row tb + n, same k range
-        const float4* src = reinterpret_cast<const float4*>(s_rows + (tb - t0 + n) * kRowStride + 32 * h);
+        const int tile_q = tile % nqt, tile_c = tile / nqt;
+        const int q0 = tile_q * 128 + wave * 32, t0 = tile_c * kMfmaChunk;
+        // B operand: this lane's query; MFMA m of a step consumes k = 16m + 8h + j (j = 0..7) from both operands
+        const int q = q0 + n;
+        uint4 bhi[4], blo[4];
+        {
+            const float4* src = reinterpret_cast<const float4*>(dq + (size_t)min(q, nq - 1) * 64);
 #pragma unroll
-        for (int i = 0; i < 8; i++) { float4 v = src[i]; areg[4*i] = v.x; areg[4*i+1] = v.y; areg[4*i+2] = v.z; areg[4*i+3] = v.w; }
-        mfma_step(areg, breg, tb, t0, nt, n, h, tn_lds, wmax, k0, k1, k2, k3);
-    }
-    // the other half-wave saw the other rows of the same query: merge its four
-    {
-        float o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32), o3 = __shfl_xor(k3, 32);
-        top4_keys(o0, k0, k1, k2, k3); top4_keys(o1, k0, k1, k2, k3); top4_keys(o2, k0, k1, k2, k3); top4_keys(o3, k0, k1, k2, k3);
-    }
-    if (h == 0 && q < nq) part[(size_t)tile_c * cap + q] = make_float4(k0, k1, k2, k3);
-    if (tile_q == 0 && wave == 0) {                         // one wave per chunk reports the largest |t|^2
-        for (int o = 16; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
-        if (lane == 0) chunk_tnmax[tile_c] = wmax;
-    }
-    __syncthreads();                                        // s_rows is restaged by the next tile
+            for (int m = 0; m < 4; m++) split_bf16x8(src[4 * m + 2 * h], src[4 * m + 2 * h + 1], bhi[m], blo[m]);
+        }
+        if (threadIdx.x == 0) s_wmax = 0;
+        __syncthreads();
+        {   // stage the chunk once: 128 rows x 16 float4, coalesced, split into bf16 hi / lo; rows past the end repeat the last one
+            const float4* src = reinterpret_cast<const float4*>(dt);
+            for (int e = threadIdx.x; e < kMfmaChunk * 16; e += 256) {
+                const int r = e >> 4, c4 = e & 15;
+                const float4 v = src[(size_t)min(t0 + r, nt - 1) * 16 + c4];
+                uint2 hi, lo;
+                split_bf16(v.x, v.y, hi.x, lo.x); split_bf16(v.z, v.w, hi.y, lo.y);
+                uint2* row = reinterpret_cast<uint2*>(s_rows + r * kRowQuads);
+                row[c4] = hi; row[16 + c4] = lo;
+                // |t|^2 of the row (any summation order will do: the margin absorbs it): its 16 quarter-rows sit on 16 adjacent lanes
+                float tn = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, __builtin_fmaf(v.z, v.z, v.w * v.w)));
+                tn += __shfl_xor(tn, 8); tn += __shfl_xor(tn, 4); tn += __shfl_xor(tn, 2); tn += __shfl_xor(tn, 1);
+                if (c4 == 0) {
+                    const bool valid = t0 + r < nt;
+                    s_tn[r] = valid ? tn : kBig;
+                    if (valid) atomicMax(&s_wmax, __float_as_int(tn));     // non-negative floats order as their bit patterns
+                }
+            }
+        }
+        __syncthreads();
+        float k0 = kBig, k1 = kBig, k2 = kBig, k3 = kBig;
+        const int tend = min(t0 + kMfmaChunk, nt);
+        for (int tb = t0; tb < tend; tb += 32) {
+            // A operand: train row tb + n, the same k ranges
+            const uint4* rowp = s_rows + (tb - t0 + n) * kRowQuads;
+            f32x16 acc;
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc[j] = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const bf16x8 ahi = __builtin_bit_cast(bf16x8, rowp[2 * m + h]), alo = __builtin_bit_cast(bf16x8, rowp[8 + 2 * m + h]);
+                const bf16x8 qhi = __builtin_bit_cast(bf16x8, bhi[m]), qlo = __builtin_bit_cast(bf16x8, blo[m]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, qhi, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, qlo, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, qhi, acc, 0, 0, 0);
+            }
+            // acc[j] = t.q for train row tb + (j&3) + 8(j>>2) + 4h and this lane's query
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int rl = 8*g + 4*h;
+                const float4 nn = *reinterpret_cast<const float4*>(s_tn + (tb - t0) + rl);
+                const int rc = tb - t0 + rl;
+                top4_keys(shortlist_key(__builtin_fmaf(-2.f, acc[4*g + 0], nn.x), rc),     k0, k1, k2, k3);
+                top4_keys(shortlist_key(__builtin_fmaf(-2.f, acc[4*g + 1], nn.y), rc + 1), k0, k1, k2, k3);
+                top4_keys(shortlist_key(__builtin_fmaf(-2.f, acc[4*g + 2], nn.z), rc + 2), k0, k1, k2, k3);
+                top4_keys(shortlist_key(__builtin_fmaf(-2.f, acc[4*g + 3], nn.w), rc + 3), k0, k1, k2, k3);
+            }
+        }
+        // the other half-wave saw the other rows of the same query: merge its four
+        {
+            float o0 = __shfl_xor(k0, 32), o1 = __shfl_xor(k1, 32), o2 = __shfl_xor(k2, 32), o3 = __shfl_xor(k3, 32);
+            top4_keys(o0, k0, k1, k2, k3); top4_keys(o1, k0, k1, k2, k3); top4_keys(o2, k0, k1, k2, k3); top4_keys(o3, k0, k1, k2, k3);
+        }
+        if (h == 0 && q < nq) part[(size_t)tile_c * cap + q] = make_float4(k0, k1, k2, k3);
+        if (tile_q == 0 && threadIdx.x == 0) chunk_tnmax[tile_c] = __int_as_float(s_wmax);      // the largest |t|^2 of the chunk
+        __syncthreads();                                        // s_rows is restaged by the next tile
     }
 }
 

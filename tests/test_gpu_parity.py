@@ -121,6 +121,29 @@ def test_match_knn_and_ratio_bit_exact(ctx, oracle, scene_small):
         assert np.array_equal(m["distance"].view(np.uint32), om["distance"].view(np.uint32))
 
 
+@pytest.mark.parametrize("seed,kind", [(0, "unit"), (1, "unit"), (2, "clustered"), (3, "scaled"), (4, "tiny")])
+def test_match_shortlist_margin_holds(ctx, oracle, seed, kind):
+    """The matrix-core shortlist works on bf16 hi/lo splits of the descriptors; whatever it lets through is re-evaluated in
+    OpenCV's order, so the result must equal the brute force exactly as long as the margin covers the split's error.
+    Random unit vectors put almost every row at the same distance (a dense band around the second-nearest), `clustered` adds
+    near-duplicates 1e-4 apart, `scaled` / `tiny` move the magnitudes away from SURF's unit norm."""
+    rng = np.random.default_rng(100 + seed)
+    nq, nt = 700, 900
+    if kind == "clustered":
+        base = np.abs(rng.normal(size=(60, 64)))
+        dt = base[rng.integers(0, 60, nt)] + rng.normal(scale=1e-4, size=(nt, 64))
+        dq = base[rng.integers(0, 60, nq)] + rng.normal(scale=1e-4, size=(nq, 64))
+    else:
+        dt = rng.normal(size=(nt, 64)); dq = rng.normal(size=(nq, 64))
+    dt /= np.linalg.norm(dt, axis=1, keepdims=True); dq /= np.linalg.norm(dq, axis=1, keepdims=True)
+    scale = {"scaled": 37.5, "tiny": 3e-3}.get(kind, 1.0)
+    dt = (dt * scale).astype(np.float32); dq = (dq * scale).astype(np.float32)
+    idx, dist = ctx.knn_match(dq, dt)
+    oidx, odist = oracle.knn2(dq, dt)
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32))
+
+
 def test_match_ties_and_edges(ctx, oracle):
     rng = np.random.default_rng(7)
     d2 = rng.normal(size=(300, 64)).astype(np.float32)
