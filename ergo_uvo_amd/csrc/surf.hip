@@ -691,25 +691,29 @@ __global__ __launch_bounds__(256) void k_rank_partial(SortArgs a)
     const int im = blockIdx.y, tid = threadIdx.x;
     const int n = min(a.cand_n[im], a.cap);
     __shared__ SortKey tile[kSortChunk];
+    __shared__ unsigned long long tile_k1[kSortChunk];
     // the count lives on the device: a fixed grid walks the (256 keypoints) x (kSortChunk compared-against) tiles that exist
     // (a cap x cap grid is 4096 workgroups of which ~550 find work, and dispatching the empty ones costs more than the work)
     const int nib = (n + 255) / 256, ntiles = nib * ((n + kSortChunk - 1) / kSortChunk);
     for (int t_ = blockIdx.x; t_ < ntiles; t_ += gridDim.x) {
         const int i0 = (t_ % nib) * 256, j0 = (t_ / nib) * kSortChunk;
         const int cnt = min(kSortChunk, n - j0);
-        for (int t = tid; t < cnt; t += 256) tile[t] = make_sort_key(a.cand[im][j0 + t]);
+        for (int t = tid; t < cnt; t += 256) { tile[t] = make_sort_key(a.cand[im][j0 + t]); tile_k1[t] = tile[t].k1; }
         __syncthreads();
         const int me = i0 + tid;
         if (me < n) {
             const SortKey mine = make_sort_key(a.cand[im][me]);
             int rank = 0;
-#pragma unroll 8
+            // the first key (response, size) decides almost every comparison: one 64-bit compare per pair on a dense array of
+            // first keys, the full lexicographic comparison only on the rare equal ones
+#pragma unroll 16
             for (int k = 0; k < cnt; k++) {
-                const SortKey o = tile[k];
-                bool before = o.k1 > mine.k1 ||
-                              (o.k1 == mine.k1 && (o.k2 > mine.k2 ||
-                                                   (o.k2 == mine.k2 && (o.k3 > mine.k3 || (o.k3 == mine.k3 && j0 + k < me)))));
-                rank += before ? 1 : 0;
+                const unsigned long long o1 = tile_k1[k];
+                rank += o1 > mine.k1 ? 1 : 0;
+                if (o1 == mine.k1) {
+                    const SortKey o = tile[k];
+                    rank += (o.k2 > mine.k2 || (o.k2 == mine.k2 && (o.k3 > mine.k3 || (o.k3 == mine.k3 && j0 + k < me)))) ? 1 : 0;
+                }
             }
             atomicAdd(&a.rank[im * a.cap + me], rank);
         }
