@@ -10,3 +10,4 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 tools/prof_stereo.py 6 > gpurun_out/pmc_write.log 2>&1
 python tools/bench_configs.py > gpurun_out/bench_configs.json 2> gpurun_out/bench_configs.err
 tail -c 900 gpurun_out/bench_configs.json
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_MFMA --output-format csv -d gpurun_out/pmc_mfma -- python3 tools/prof_stereo.py 6 > gpurun_out/pmc_mfma.log 2>&1
