@@ -380,6 +380,20 @@ class Context:
         self._check(self._lib.uvo_mono_step(self._h, p, w, h, w, mem, C.c_double(range_), C.c_double(dt), C.byref(r)))
         return r
 
+    def mono_submit(self, img, range_=1.0):
+        """Pipelined mono frame (uvo_mono_submit): at most `stereo_set_depth` frames in flight, collect in order."""
+        h, w = img.shape[-2], img.shape[-1]
+        p, mem, keep = _ptr_mem(img, np.uint8)
+        self._check(self._lib.uvo_mono_submit(self._h, p, w, h, w, mem, C.c_double(range_)))
+
+    def mono_collect(self, dt: float = 0.05) -> MonoResult:
+        r = MonoResult()
+        self._check(self._lib.uvo_mono_collect(self._h, C.c_double(dt), C.byref(r)))
+        return r
+
+    def mono_reset(self):
+        self._check(self._lib.uvo_mono_reset(self._h))
+
     def mono_get(self, what: str):
         spec = {"kps": KP_DTYPE, "matches": DM_DTYPE, "mask": np.dtype("u1"), "good_pts": np.dtype(("f8", 3))}[what]
         buf = np.zeros(self.max_kpts, spec)

@@ -53,6 +53,7 @@ static void make_desc_weights(float* DW)
 }
 
 static void lane_worker(uvo_ctx* L);
+static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok);
 static void destroy_one(uvo_ctx* c);
 
 // one set of buffers, streams and a stage-B worker thread: the caller's context, or a further pipeline lane of it
@@ -99,6 +100,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
         A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsA[i]), sizeof(int) * CN_TOTAL));
     }
     A(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
+    A(hipEventCreateWithFlags(&c->evDet, hipEventDisableTiming)); A(hipEventCreateWithFlags(&c->evPrevRead, hipEventDisableTiming));
     A(hipStreamCreateWithFlags(&c->pnp_stream, hipStreamNonBlocking));
     A(dalloc(&c->d_countsB, (size_t)4)); A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsB), sizeof(int) * 4));
     A(dalloc(&c->d_counts, (size_t)CN_TOTAL));
@@ -201,6 +203,8 @@ static void destroy_one(uvo_ctx* c)
     for (int i = 0; i < 2; i++) { (void)hipHostFree(c->h_countsA[i]); if (c->evA[i]) (void)hipEventDestroy(c->evA[i]); }
     if (c->pnp_stream) (void)hipStreamDestroy(c->pnp_stream);
     if (c->evAS) (void)hipEventDestroy(c->evAS);
+    if (c->evDet) (void)hipEventDestroy(c->evDet);
+    if (c->evPrevRead) (void)hipEventDestroy(c->evPrevRead);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -659,7 +663,8 @@ static void lane_worker(uvo_ctx* L)
             if (g_bdbg) g_bstat[5] += now_us() - tw;
             m->b_running++;
             g.unlock();
-            run_stage_b(L, stage_a_ok);
+            if (L->job.kind == 1) { const double tb = g_bdbg ? now_us() : 0; run_mono_stage_b(L, stage_a_ok); if (g_bdbg) { g_bstat[1] += now_us() - tb; g_bstat[4] += 1; } }
+            else run_stage_b(L, stage_a_ok);
             g.lock();
             m->b_running--;
             m->b_cv.notify_one();
@@ -947,6 +952,11 @@ extern "C" uvo_status uvo_mono_set_camera(uvo_ctx* c, const double* K)
 extern "C" uvo_status uvo_mono_reset(uvo_ctx* c)
 {
     if (!c) return UVO_INVALID_ARG;
+    while (c->n_pending > 0 && (c->inflight[0] < 0 || c->lanes[c->inflight[0]]->job.kind == 1)) { uvo_mono_result r; (void)uvo_mono_collect(c, 1.0, &r); }       // mono frames still in flight are dropped
+    c->mono_init_results.clear();
+    for (Ctx* l : c->lanes) { if (l->stream) (void)hipStreamSynchronize(l->stream); l->prev_read_pending = false; l->pending = Ctx::Pending(); }
+    if (c->n_pending == 0) { c->prev_lane = 0; c->next_lane = 0; }
+    c->mono_pipelined = false;
     c->mono_initialized = false; c->mono_use_essential = 1; c->mono_SF = 1.0; c->mono_n_prev = 0;
     const double I[9] = {1,0,0,0,1,0,0,0,1};
     memcpy(c->mono_R, I, sizeof(I)); c->mono_t[0] = c->mono_t[1] = c->mono_t[2] = 0;
@@ -960,6 +970,7 @@ extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h
 {
     if (!c || !img || !out) return UVO_INVALID_ARG;
     if (!c->mono_cam_set) return fail(c, UVO_INVALID_ARG, "uvo_mono_set_camera has not been called");
+    if (c->mono_pipelined) return fail(c, UVO_INVALID_ARG, "uvo_mono_step after uvo_mono_submit: call uvo_mono_reset first (the previous frame is held by the pipeline)");
     (void)hipSetDevice(c->device);
     const uvo_params& p = c->p;
     memset(out, 0, sizeof(*out));
@@ -1058,15 +1069,214 @@ extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h
     return roll_state();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// mono pipeline (uvo_mono_submit / uvo_mono_collect): the loop body of uvo_mono_step split at the point where the host
+// takes over.  Stage A (this thread, the lane's stream, no host sync): upload, detect, match the previous frame's
+// descriptors -- read straight from the previous lane's buffers behind its evDet -- against this frame's, ratio test,
+// gather the matched point pairs.  Stage B (the lane's worker): the gates on the counts, method selection, the
+// host-orchestrated estimators, triangulation and scale.  Every exit of the reference's loop body rolls the state, so the
+// previous frame is always the frame before; what is sequential is R, t (kept when no estimator wrote them) and the
+// scale factor: uvo_mono_collect applies them in order.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gather_mono_pairs(const uvo_dmatch* __restrict__ m, const int* __restrict__ count, int cap,
+                                                           const uvo_keypoint* __restrict__ prev_kps, const uvo_keypoint* __restrict__ kps,
+                                                           uvo_point2f* __restrict__ x1, uvo_point2f* __restrict__ x2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= min(*count, cap)) return;
+    const uvo_keypoint a = prev_kps[m[i].queryIdx], b = kps[m[i].trainIdx];              // VOU:567-568
+    x1[i] = uvo_point2f{a.x, a.y}; x2[i] = uvo_point2f{b.x, b.y};
+}
+
+extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int h, int stride, int mem, double range)
+{
+    if (!c || !img) return UVO_INVALID_ARG;
+    if (!c->mono_cam_set) return fail(c, UVO_INVALID_ARG, "uvo_mono_set_camera has not been called");
+    const int depth = (int)c->lanes.size();
+    if (depth < 2) return fail(c, UVO_INVALID_ARG, "uvo_mono_submit needs at least two lanes (uvo_stereo_set_depth): a frame is matched against the previous lane's buffers");
+    if (c->n_pending >= depth) return fail(c, UVO_INVALID_ARG, "uvo_mono_submit: the pipeline is full; collect a frame first (uvo_stereo_set_depth)");
+    (void)hipSetDevice(c->device);
+    const uvo_params& p = c->p;
+    if (!c->mono_initialized) {                                                            // VO:227-245 on lane 0, synchronous
+        // (earlier init frames may still await their collect: they are complete, only their result is queued)
+        uvo_mono_result r;
+        memset(&r, 0, sizeof(r));
+        UVO_TRY(uvo_mono_step(c, img, w, h, stride, mem, range, 1.0, &r));                 // nothing is published before initialisation
+        c->mono_init_results.push_back(r);
+        c->inflight[c->n_pending++] = -1; c->n_submitted++;                               // -1: a synchronous init frame
+        c->prev_lane = 0; c->next_lane = 1 % depth;
+        UVO_HIP_TRY(c, hipEventRecord(c->evDet, c->stream));                               // lane 0 holds the frame the next one matches against
+        return UVO_OK;
+    }
+    const int li = c->next_lane;
+    uvo_ctx* L = static_cast<uvo_ctx*>(c->lanes[li]);
+    Ctx* P = c->lanes[c->prev_lane];
+    c->mono_pipelined = true;                  // the previous frame now lives in a lane's buffers, not in uvo_mono_step's rolled state
+#define LANE_TRY(expr) do { uvo_status st_ = (expr); if (st_ != UVO_OK) { if (L != c) c->err = L->err; return st_; } } while (0)
+    hipStream_t st = L->stream;
+    L->pending = Ctx::Pending(); L->pending.used = true;
+    if (L->prev_read_pending) { UVO_HIP_TRY(c, hipStreamWaitEvent(st, L->evPrevRead, 0)); L->prev_read_pending = false; }   // the frame after this lane's last one has read its buffers
+    LANE_TRY(surf_upload(L, 0, img, w, h, stride, mem));
+    LANE_TRY(surf_detect(L, 1));                                                           // VO:274
+    UVO_HIP_TRY(c, hipEventRecord(L->evDet, st));
+    int* cn = L->d_counts;
+    const int cap = c->cap;
+    if (P != L) UVO_HIP_TRY(c, hipStreamWaitEvent(st, P->evDet, 0));
+    // match_features 7-arg (VO:287 -> VOU:551-573): query = previous frame, train = this frame; the counts stay on the device
+    LANE_TRY(match_knn2(L, P->det[0].desc, P->det[0].n, cap, L->det[0].desc, L->det[0].n, cap));
+    LANE_TRY(match_ratio_compact(L, P->det[0].n, cap, (float)p.LOWE_RATIO_THRESHOLD, L->d_matches[0], cn + CN_M, cap));
+    hipLaunchKernelGGL(k_gather_mono_pairs, dim3((cap + 255) / 256), dim3(256), 0, st, L->d_matches[0], cn + CN_M, cap,
+                       P->det[0].kps, L->det[0].kps, L->d_x1, L->d_x2);
+    UVO_HIP_TRY(c, hipGetLastError());
+    if (P != L) { UVO_HIP_TRY(c, hipEventRecord(P->evPrevRead, st)); P->prev_read_pending = true; }
+    UVO_HIP_TRY(c, hipMemcpyAsync(L->h_countsA[0], L->d_counts, sizeof(int) * CN_TOTAL, hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipEventRecord(L->evA[0], st));
+    c->prev_lane = li; c->next_lane = (li + 1) % depth;
+    c->inflight[c->n_pending++] = li; c->n_submitted++;
+    {
+        std::lock_guard<std::mutex> lk(L->mu);
+        L->job.kind = 1; L->job.range = range; L->job.state = 1;
+    }
+    L->cv.notify_all();
+    return UVO_OK;
+#undef LANE_TRY
+}
+
+// Stage B of one mono frame on the lane's worker (VO:276-376 after the matching): fills job.mres / pose_written / sf_written
+static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok)
+{
+    Ctx::BJob& j = L->job;
+    const Ctx* m = L->master ? L->master : L;
+    const uvo_params& p = L->p;
+    j.st = UVO_OK; j.err.clear(); j.pose_written = j.sf_written = false;
+    memset(&j.mres, 0, sizeof(j.mres));
+    L->mono_matches.clear(); L->mono_mask.clear(); L->mono_good_pts.clear(); L->mono_kps.clear();
+    if (!stage_a_ok) { j.st = UVO_HIP_ERROR; j.err = "stage A of the frame failed"; return; }
+    auto hip_ok = [&](hipError_t e) { if (e != hipSuccess && j.st == UVO_OK) { j.st = UVO_HIP_ERROR; j.err = hipGetErrorString(e); } return e == hipSuccess; };
+    const int* hc = L->h_countsA[0];
+    const int cap = L->cap;
+    if (hc[CN_CAND0] > cap) { j.st = UVO_CAPACITY; j.err = "SURF found more keypoints than the context's max_kpts; results would be order-dependent"; return; }
+    const int n = hc[CN_NL], M = hc[CN_M];
+    j.mres.initialized = 1; j.mres.n_kps = n;
+    hipStream_t st = L->stream;
+    L->mono_kps.resize(n);
+    if (n && !hip_ok(hipMemcpyAsync(L->mono_kps.data(), L->det[0].kps, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, st))) return;
+    if (n < p.MIN_NUM_FEATURES) { (void)hip_ok(hipStreamSynchronize(st)); return; }       // VO:276-284
+    if (M > cap) { j.st = UVO_CAPACITY; j.err = "match count exceeds max_kpts"; return; }
+    j.mres.n_matches = M;
+    L->mono_matches.resize(M);
+    std::vector<uvo_point2f> k1(M), k2(M), in1(M), in2(M);
+    if (M) {
+        if (!hip_ok(hipMemcpyAsync(L->mono_matches.data(), L->d_matches[0], sizeof(uvo_dmatch) * M, hipMemcpyDeviceToHost, st))) return;
+        if (!hip_ok(hipMemcpyAsync(k1.data(), L->d_x1, sizeof(uvo_point2f) * M, hipMemcpyDeviceToHost, st))) return;
+        if (!hip_ok(hipMemcpyAsync(k2.data(), L->d_x2, sizeof(uvo_point2f) * M, hipMemcpyDeviceToHost, st))) return;
+    }
+    if (!hip_ok(hipStreamSynchronize(st))) return;
+    if (M < p.MIN_NUM_FEATURES) return;                                                    // VO:299-307
+    int use_essential = uvo_select_estimation_method(k1.data(), k2.data(), M, p.DISTANCE);   // VO:310-317
+    int n_in = 0, success = 0;
+    L->mono_mask.assign(M, 0);
+    // R, t are in/out in the reference (kept when no estimator writes them): run on a sentinel and report whether they were written
+    double R[9], t[3];
+    const double kSentinel = -7.0e300;
+    for (int i = 0; i < 9; i++) R[i] = kSentinel;
+    for (int i = 0; i < 3; i++) t[i] = kSentinel;
+    j.st = uvo_estimate_relative_pose(L, k1.data(), k2.data(), M, m->mono_K, &use_essential, R, t, in1.data(), in2.data(), &n_in,
+                                      L->mono_mask.data(), &success);                      // VO:323
+    if (j.st != UVO_OK) { j.err = L->err; return; }
+    j.pose_written = R[0] != kSentinel;
+    if (j.pose_written) { memcpy(j.R, R, sizeof(R)); memcpy(j.t, t, sizeof(t)); }
+    j.mres.success = success; j.mres.used_essential = use_essential; j.mres.n_inliers = n_in;
+    j.mres.published = 1;
+    int valid = success ? 1 : 0;                                                           // VO:335-344
+    if (success) {                                                                         // VO:351-376 (success implies the pose was written)
+        const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
+        double P_prev[12], P_curr[12];
+        projection_matrix(I, z, m->mono_K, P_prev);
+        projection_matrix(R, t, m->mono_K, P_curr);
+        int G = 0;
+        if (n_in > 0) {
+            if (!hip_ok(hipMemcpyAsync(L->d_x1, in1.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, st))) return;
+            if (!hip_ok(hipMemcpyAsync(L->d_x2, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, st))) return;
+            if (!hip_ok(hipMemcpyAsync(L->d_xc, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, st))) return;
+            if ((j.st = pose_triangulate(L, P_prev, P_curr, nullptr, n_in)) != UVO_OK) { j.err = L->err; return; }          // VO:355
+            if ((j.st = pose_extract3d(L, 0, I, z, R, t, m->mono_K, m->mono_K, nullptr, n_in)) != UVO_OK) { j.err = L->err; return; }   // VO:356
+            if ((j.st = read_counts(L)) != UVO_OK) { j.err = L->err; return; }
+            G = L->h_counts[CN_G];
+            L->mono_good_pts.resize((size_t)3 * G);
+            if (G && !hip_ok(hipMemcpyAsync(L->mono_good_pts.data(), L->d_good_pts[0], sizeof(double) * 3 * G, hipMemcpyDeviceToHost, st))) return;
+            if (!hip_ok(hipStreamSynchronize(st))) return;
+        }
+        j.mres.n_good3d = G;
+        if (G < p.MIN_NUM_3DPOINTS) valid = 0;                                             // VO:358
+        else {
+            std::vector<double> zs;                                                        // convert_3Dpoints_camera (VOU:46-63)
+            for (int i = 0; i < G; i++) {
+                const double* q = &L->mono_good_pts[3 * (size_t)i];
+                double zt = (R[6]*q[0] + R[7]*q[1] + R[8]*q[2]) * 1.0 + t[2] * 1.0;
+                if (zt > 0) zs.push_back(q[2]);
+            }
+            j.mres.n_front = (int)zs.size();
+            if (!zs.empty()) { j.SF = (float)j.range / compute_median(zs); j.sf_written = true; }   // compute_scale_factor (VOU:23-38)
+            else valid = 0;
+        }
+    }
+    j.mres.valid = valid;
+}
+
+extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* out)
+{
+    if (!c || !out) return UVO_INVALID_ARG;
+    if (c->n_pending <= 0) return fail(c, UVO_INVALID_ARG, "uvo_mono_collect: nothing submitted");
+    (void)hipSetDevice(c->device);
+    const int li = c->inflight[0];
+    for (int i = 1; i < c->n_pending; i++) c->inflight[i - 1] = c->inflight[i];
+    c->n_pending--; c->n_collected++;
+    if (li < 0) {                                          // a synchronous init frame (its state is already applied)
+        *out = c->mono_init_results.front();
+        c->mono_init_results.pop_front();
+        c->last_lane = 0;
+        return UVO_OK;
+    }
+    uvo_ctx* L = static_cast<uvo_ctx*>(c->lanes[li]);
+    c->last_lane = li;
+    L->pending.used = false;
+    {
+        std::unique_lock<std::mutex> lk(L->mu);
+        L->cv.wait(lk, [&] { return L->job.state == 2; });
+        L->job.state = 0;
+    }
+    const Ctx::BJob& j = L->job;
+    if (j.st != UVO_OK) return fail(c, j.st, j.err.c_str());
+    *out = j.mres;
+    // (uvo_mono_get reads the frame's intermediates from this lane, c->last_lane, until the lane is submitted to again)
+    if (j.pose_written) { memcpy(c->mono_R, j.R, sizeof(c->mono_R)); memcpy(c->mono_t, j.t, sizeof(c->mono_t)); }
+    if (j.sf_written) c->mono_SF = j.SF;
+    c->mono_use_essential = j.mres.published ? j.mres.used_essential : c->mono_use_essential;
+    if (j.mres.published) {
+        // mono_output_computation (VO:126-140): -SF * R^T * t / dt as one gemm with alpha = (-SF) * (1/dt)
+        double alpha = (-c->mono_SF) * (1.0 / dt);
+        for (int i = 0; i < 3; i++) {
+            double acc = 0;
+            for (int k = 0; k < 3; k++) acc += c->mono_R[k*3 + i] * c->mono_t[k];
+            out->velocity[i] = acc * alpha;
+        }
+        out->SF = c->mono_SF;
+        memcpy(out->R, c->mono_R, sizeof(out->R)); memcpy(out->t, c->mono_t, sizeof(out->t));
+    }
+    return UVO_OK;
+}
+
 extern "C" int uvo_mono_get(uvo_ctx* c, const char* what, void* out, int cap_bytes)
 {
     if (!c || !what || !out) return 0;
     const void* src = nullptr; size_t nb = 0; int count = 0;
     std::string w(what);
-    if (w == "kps") { src = c->mono_kps.data(); count = (int)c->mono_kps.size(); nb = (size_t)count * sizeof(uvo_keypoint); }
-    else if (w == "matches") { src = c->mono_matches.data(); count = (int)c->mono_matches.size(); nb = (size_t)count * sizeof(uvo_dmatch); }
-    else if (w == "mask") { src = c->mono_mask.data(); count = (int)c->mono_mask.size(); nb = (size_t)count; }
-    else if (w == "good_pts") { src = c->mono_good_pts.data(); count = (int)c->mono_good_pts.size() / 3; nb = (size_t)count * 3 * sizeof(double); }
+    const Ctx* f = c->mono_pipelined ? c->lanes[c->last_lane] : c;       // the lane of the last collected frame
+    if (w == "kps") { src = f->mono_kps.data(); count = (int)f->mono_kps.size(); nb = (size_t)count * sizeof(uvo_keypoint); }
+    else if (w == "matches") { src = f->mono_matches.data(); count = (int)f->mono_matches.size(); nb = (size_t)count * sizeof(uvo_dmatch); }
+    else if (w == "mask") { src = f->mono_mask.data(); count = (int)f->mono_mask.size(); nb = (size_t)count; }
+    else if (w == "good_pts") { src = f->mono_good_pts.data(); count = (int)f->mono_good_pts.size() / 3; nb = (size_t)count * 3 * sizeof(double); }
     else return 0;
     if (nb > (size_t)cap_bytes) return -count;
     if (nb) memcpy(out, src, nb);

@@ -656,7 +656,8 @@ static int make_subsets(int* out, int niters, int model_points, int count, int m
 
 // sequential replays over the device scores
 struct Winner { int hyp = -1, model = 0; double min_median = DBL_MAX; int max_good = 0; };
-static Winner replay_ransac(const int* nmodels, const int* counts, int stride, int nsub, int niters0, int count, int modelPoints, double confidence)
+static Winner replay_ransac(const int* nmodels, const int* counts, int stride, int nsub, int niters0, int count, int modelPoints, double confidence,
+                            int* niters_out = nullptr)
 {
     Winner w; int niters = niters0;
     for (int iter = 0; iter < niters && iter < nsub; iter++) {
@@ -668,6 +669,7 @@ static Winner replay_ransac(const int* nmodels, const int* counts, int stride, i
             }
         }
     }
+    if (niters_out) *niters_out = niters;          // the iteration count the adaptive rule has settled on so far
     return w;
 }
 static Winner replay_lmeds(const int* nmodels, const double* medians, int stride, int nsub)
@@ -714,7 +716,13 @@ uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f*
     if (n == modelPoints) { for (int i = 0; i < 5; i++) w->h_subsets[i] = i; nsub = 1; }
     else nsub = make_subsets(w->h_subsets.data(), niters, modelPoints, n, lmeds ? 1000 : 10000, nullptr, nullptr, &failed_first);
     UVO_HIP_TRY(c, hipMemcpyAsync(w->subsets, w->h_subsets.data(), sizeof(int) * 5 * nsub, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_fivepoint_hyp, dim3((nsub + kFpPerWg - 1) / kFpPerWg), dim3(64), 0, st, w->q1, w->q2, w->subsets, nsub, w->models, w->nmodels);
+    // RANSAC hypotheses are solved and scored in rounds: the first kFirstRound subsets, then -- only if the adaptive iteration count
+    // still reaches past them after the replayed scan -- the rest.  The scan visits the same counts in the same order either
+    // way.  (A five-point solve keeps a SIMD busy for 0.85 ms whether 32 or 500 waves run, so the first round's latency is the
+    // same, but it leaves the chip to the other frames of a pipeline and scores 16x fewer models.)  LMedS needs all of them.
+    const int kFirstRound = 128;
+    const int first = (!lmeds && n != modelPoints && nsub > kFirstRound) ? kFirstRound : nsub;
+    hipLaunchKernelGGL(k_fivepoint_hyp, dim3((first + kFpPerWg - 1) / kFpPerWg), dim3(64), 0, st, w->q1, w->q2, w->subsets, first, w->models, w->nmodels);
     UVO_HIP_TRY(c, hipGetLastError());
     if (getenv("UVO_DBG_PHASE")) {
         long long clk[8];
@@ -734,15 +742,31 @@ uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f*
     }
     const int npow2 = next_pow2(n);
     const float thr2 = (float)(threshold * threshold);
-    hipLaunchKernelGGL(k_e_score, dim3(10, nsub), dim3(256), lmeds ? sizeof(float) * npow2 : 0, st, w->q1, w->q2, n, w->models, w->nmodels,
+    hipLaunchKernelGGL(k_e_score, dim3(10, first), dim3(256), lmeds ? sizeof(float) * npow2 : 0, st, w->q1, w->q2, n, w->models, w->nmodels,
                        lmeds ? 1 : 0, thr2, npow2, w->counts, w->medians);
     UVO_HIP_TRY(c, hipGetLastError());
-    UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data(), w->nmodels, sizeof(int) * nsub, hipMemcpyDeviceToHost, st));
-    if (lmeds) UVO_HIP_TRY(c, hipMemcpyAsync(w->h_medians.data(), w->medians, sizeof(double) * 10 * nsub, hipMemcpyDeviceToHost, st));
-    else UVO_HIP_TRY(c, hipMemcpyAsync(w->h_counts.data(), w->counts, sizeof(int) * 10 * nsub, hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data(), w->nmodels, sizeof(int) * first, hipMemcpyDeviceToHost, st));
+    if (lmeds) UVO_HIP_TRY(c, hipMemcpyAsync(w->h_medians.data(), w->medians, sizeof(double) * 10 * first, hipMemcpyDeviceToHost, st));
+    else UVO_HIP_TRY(c, hipMemcpyAsync(w->h_counts.data(), w->counts, sizeof(int) * 10 * first, hipMemcpyDeviceToHost, st));
     UVO_HIP_TRY(c, hipStreamSynchronize(st));
-    Winner win = lmeds ? replay_lmeds(w->h_nmodels.data(), w->h_medians.data(), 10, nsub)
-                       : replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 10, nsub, niters, n, modelPoints, prob);
+    Winner win;
+    if (lmeds) win = replay_lmeds(w->h_nmodels.data(), w->h_medians.data(), 10, nsub);
+    else {
+        int settled = niters;
+        win = replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 10, first, niters, n, modelPoints, prob, &settled);
+        if (first < nsub && settled > first) {                 // the scan goes on past the first round: solve and score the rest, rescan
+            const int rest = nsub - first;
+            hipLaunchKernelGGL(k_fivepoint_hyp, dim3((rest + kFpPerWg - 1) / kFpPerWg), dim3(64), 0, st, w->q1, w->q2, w->subsets + (size_t)5 * first, rest,
+                               w->models + (size_t)90 * first, w->nmodels + first);
+            hipLaunchKernelGGL(k_e_score, dim3(10, rest), dim3(256), 0, st, w->q1, w->q2, n, w->models + (size_t)90 * first, w->nmodels + first,
+                               0, thr2, npow2, w->counts + (size_t)10 * first, w->medians + (size_t)10 * first);
+            UVO_HIP_TRY(c, hipGetLastError());
+            UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data() + first, w->nmodels + first, sizeof(int) * rest, hipMemcpyDeviceToHost, st));
+            UVO_HIP_TRY(c, hipMemcpyAsync(w->h_counts.data() + (size_t)10 * first, w->counts + (size_t)10 * first, sizeof(int) * 10 * rest, hipMemcpyDeviceToHost, st));
+            UVO_HIP_TRY(c, hipStreamSynchronize(st));
+            win = replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 10, nsub, niters, n, modelPoints, prob);
+        }
+    }
     if (win.hyp < 0) return UVO_OK;
     double final_thr = threshold;
     if (lmeds) {
@@ -820,7 +844,8 @@ uvo_status mono_recover_pose(Ctx* c, const double* E, const uvo_point2f* p1, con
     memcpy(R, Rc[best], sizeof(double) * 9);
     for (int i = 0; i < 3; i++) t[i] = sg[best] * tt[i];
     if (n > 0) {
-        UVO_HIP_TRY(c, hipMemcpy(mask, w->masks + (size_t)best * n, n, hipMemcpyDeviceToHost));
+        UVO_HIP_TRY(c, hipMemcpyAsync(mask, w->masks + (size_t)best * n, n, hipMemcpyDeviceToHost, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     *good_out = good[best];
     return UVO_OK;

@@ -6,6 +6,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <vector>
+#include <deque>
 #include <stdint.h>
 #include "../../include/uvo_hip.h"
 
@@ -147,9 +148,17 @@ struct Ctx {
     // stage-B worker of this lane
     struct BJob {
         int state = 0;                           // 0 idle, 1 queued, 2 done
+        int kind = 0;                            // 0: stereo PnP stage, 1: mono pose stage
         uvo_status st = UVO_OK; std::string err;
         int ran = 0, ninl = 0, ok = 0, wrote = 0; double rvec[3], tvec[3];
+        // mono (uvo_mono_submit): inputs and what uvo_mono_collect applies in order
+        double range = 0;
+        uvo_mono_result mres;                    // counters and flags of the frame (pose, SF, velocity are filled by collect)
+        bool pose_written = false; double R[9], t[3];      // estimate_relative_pose wrote R, t (kept from the previous frame otherwise)
+        bool sf_written = false; double SF = 0;
     } job;
+    // mono pipeline: this lane's keypoints/descriptors are ready (evDet); the following frame has finished reading them (evPrevRead)
+    hipEvent_t evDet = nullptr, evPrevRead = nullptr; bool prev_read_pending = false;
     std::thread worker; std::mutex mu; std::condition_variable cv; bool quit = false;
     std::mutex b_mu; std::condition_variable b_cv; int b_running = 0, max_b = 3;   // master: PnP stages running / allowed at once
 
@@ -159,11 +168,12 @@ struct Ctx {
     // ---- mono stage (mono.hip) ----
     void* mono_ws = nullptr;                     // MonoWs*, allocated on first use
     void* pre_ws = nullptr;                      // PreWs* (get_image), allocated on first use
-    double mono_K[9]; bool mono_cam_set = false, mono_initialized = false;
+    double mono_K[9]; bool mono_cam_set = false, mono_initialized = false, mono_pipelined = false;
     int mono_use_essential = 1;                  // the reference's global `use_essential` (VOH:89)
     double mono_R[9] = {1,0,0,0,1,0,0,0,1}, mono_t[3] = {0,0,0}, mono_SF = 1.0;
     std::vector<uvo_keypoint> mono_prev_kps, mono_kps;   // host copies (prev frame / last frame)
     int mono_n_prev = 0;                         // rows of the prev descriptors kept in d_as_descL[0]
+    std::deque<uvo_mono_result> mono_init_results;   // uvo_mono_submit: results of the synchronous init frames awaiting their collect
     std::vector<uvo_dmatch> mono_matches; std::vector<uint8_t> mono_mask; std::vector<double> mono_good_pts;
 
     // ---- timing ----

@@ -185,6 +185,14 @@ uvo_status uvo_mono_set_camera(uvo_ctx* c, const double* K);     /* new_camera_m
 uvo_status uvo_mono_reset(uvo_ctx* c);
 uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h, int stride, int mem, double range, double dt,
                          uvo_mono_result* out);
+/* The same loop body, pipelined like uvo_stereo_submit / uvo_stereo_collect (uvo_stereo_set_depth sets the number of lanes):
+ * submit enqueues detection and the matching against the previous frame on a lane and returns; the lane's worker runs the
+ * host-orchestrated pose stage (method selection, RANSAC / LMedS, recoverPose, triangulation, scale) beside the next frames'
+ * detection; collect returns the oldest frame's result and applies the sequential state (R, t kept when no estimate wrote
+ * them; the scale factor) in order.  Results equal uvo_mono_step's.  The first frames (until one has MIN_NUM_FEATURES
+ * keypoints) are processed synchronously inside submit. */
+uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int h, int stride, int mem, double range);
+uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* out);
 /* last step's intermediates: "kps", "matches", "mask", "good_pts" */
 int        uvo_mono_get(uvo_ctx* c, const char* what, void* out, int cap_bytes);
 

@@ -450,3 +450,52 @@ def test_mono_sequence_parity(ctx, oracle, mono_small):
                 assert np.array_equal(m["queryIdx"], om["queryIdx"]) and np.array_equal(m["trainIdx"], om["trainIdx"])
                 assert _beq(ctx.mono_get("good_pts"), ovo.get("good_pts"))
         assert n_pub >= 3
+
+
+@pytest.mark.parametrize("depth", [2, 3])
+def test_mono_pipelined_submit_collect_equals_step(mono_small, depth):
+    """uvo_mono_submit / uvo_mono_collect with `depth` frames in flight give uvo_mono_step's results bit for bit, including the
+    frames that fail a gate (blank images) and the state they leave behind (R, t, SF kept)."""
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    blank = np.full((360, 640), 90, np.uint8)
+    seq = [blank, mono_small[0], mono_small[1], mono_small[2], blank, mono_small[1], mono_small[0], mono_small[2], mono_small[1], blank,
+           mono_small[0], mono_small[1]]
+    fields = ("published", "valid", "initialized", "used_essential", "success", "n_kps", "n_matches", "n_inliers", "n_good3d", "n_front")
+    for method in (8, 4):
+        kw = dict(SURF_MIN_HESSIAN=400, ESSENTIAL_OUTLIER_METHOD=method, HOMOGRAPHY_OUTLIER_METHOD=method, REPROJECTION_TOLERANCE=3.0)
+        if method == 8:
+            kw.update(ESSENTIAL_THRESHOLD=1.0, HOMOGRAPHY_THRESHOLD=1.0)
+        a = uvo.Context(uvo.Params.mono(**kw), 0, 640, 360, 8192)
+        b = uvo.Context(uvo.Params.mono(**kw), 0, 640, 360, 8192)
+        try:
+            a.mono_set_camera(rig.K_left); b.mono_set_camera(rig.K_left)
+            b.stereo_set_depth(depth)
+            want = []
+            for img in seq:
+                r = a.mono_step(img, 4.0, 0.2)
+                want.append((r, a.mono_get("mask").copy(), a.mono_get("matches").copy(), a.mono_get("good_pts").copy()))
+            got = []
+            sub = 0
+            for i in range(len(seq)):
+                while sub < len(seq) and sub - i < depth:
+                    b.mono_submit(seq[sub], 4.0); sub += 1
+                r = b.mono_collect(0.2)
+                got.append((r, b.mono_get("mask").copy(), b.mono_get("matches").copy(), b.mono_get("good_pts").copy()))
+            n_pub = 0
+            for k, ((rw, mw, tw, gw), (rg, mg, tg, gg)) in enumerate(zip(want, got)):
+                for f in fields:
+                    assert getattr(rg, f) == getattr(rw, f), (method, depth, k, f)
+                n_pub += rw.published
+                if rw.published:
+                    for x, y in ((rg.R, rw.R), (rg.t, rw.t), (rg.velocity, rw.velocity), ([rg.SF], [rw.SF])):
+                        assert _beq(np.array(list(x)), np.array(list(y))), (method, depth, k)
+                    assert np.array_equal(mg, mw) and np.array_equal(tg, tw) and _beq(gg, gw)
+            assert n_pub >= 5
+            with pytest.raises(uvo.UvoError):
+                b.mono_step(seq[1], 4.0, 0.2)                 # mixing needs a reset
+            b.mono_reset()
+            assert b.mono_step(seq[1], 4.0, 0.2).initialized == 0
+        finally:
+            a.close(); b.close()

@@ -95,6 +95,25 @@ def main():
         nv += r.valid; ne += r.used_essential
     out["C4_mono_1920x1080_ransac"] = {"kpts": r.n_kps, "matches": r.n_matches, "valid": nv, "essential_used": ne,
                                        "frames_per_s": round(steps / (time.perf_counter() - t0), 1)}
+    # the same frames through uvo_mono_submit / uvo_mono_collect, six in flight
+    ctx.mono_reset()
+    depth = 6
+    ctx.stereo_set_depth(depth)
+    steps = 600
+    sub = 0
+    for i in range(24):
+        while sub < 24 and sub - i < depth:
+            ctx.mono_submit(dmono[order[sub % 6]], rng); sub += 1
+        r = ctx.mono_collect(0.2)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    nv = 0
+    sub = 0
+    for i in range(steps):
+        while sub < steps and sub - i < depth:
+            ctx.mono_submit(dmono[order[sub % 6]], rng); sub += 1
+        nv += ctx.mono_collect(0.2).valid
+    out["C4_mono_1920x1080_ransac"].update({"frames_per_s_pipelined": round(steps / (time.perf_counter() - t0), 1), "valid_pipelined": nv,
+                                            "pipelined_steps": steps})
     ctx.close()
     print(json.dumps(out))
 
