@@ -72,7 +72,7 @@ def ping_pong(n_frames: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic stereo pairs (ping-pong order)")
     ap.add_argument("--depth", type=int, default=int(os.environ.get("UVO_PIPELINE_DEPTH", "6")),

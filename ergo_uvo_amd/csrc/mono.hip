@@ -1020,19 +1020,38 @@ uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f
             UVO_HIP_TRY(c, hipMemcpyAsync(w->src, src.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
             UVO_HIP_TRY(c, hipMemcpyAsync(w->dst, dst.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
             UVO_HIP_TRY(c, hipMemcpyAsync(w->subsets, w->h_subsets.data(), sizeof(int) * 4 * nsub, hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_h_hyp, dim3((nsub + kHHypThreads - 1) / kHHypThreads), dim3(kHHypThreads), 0, st, w->src, w->dst, w->subsets, nsub,
+            // RANSAC in rounds, as mono_find_essential: the first kFirstRound subsets, the rest only if the adaptive count reaches past them
+            const int kFirstRound = 128;
+            const int first = (!lmeds && nsub > kFirstRound) ? kFirstRound : nsub;
+            hipLaunchKernelGGL(k_h_hyp, dim3((first + kHHypThreads - 1) / kHHypThreads), dim3(kHHypThreads), 0, st, w->src, w->dst, w->subsets, first,
                                w->models, w->nmodels);
             const int npow2 = next_pow2(n);
             const float thr2 = (float)(thr * thr);
-            hipLaunchKernelGGL(k_h_score, dim3(nsub), dim3(256), lmeds ? sizeof(float) * npow2 : 0, st, w->src, w->dst, n, w->models, w->nmodels,
+            hipLaunchKernelGGL(k_h_score, dim3(first), dim3(256), lmeds ? sizeof(float) * npow2 : 0, st, w->src, w->dst, n, w->models, w->nmodels,
                                lmeds ? 1 : 0, thr2, npow2, w->counts, w->medians);
             UVO_HIP_TRY(c, hipGetLastError());
-            UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data(), w->nmodels, sizeof(int) * nsub, hipMemcpyDeviceToHost, st));
-            if (lmeds) UVO_HIP_TRY(c, hipMemcpyAsync(w->h_medians.data(), w->medians, sizeof(double) * nsub, hipMemcpyDeviceToHost, st));
-            else UVO_HIP_TRY(c, hipMemcpyAsync(w->h_counts.data(), w->counts, sizeof(int) * nsub, hipMemcpyDeviceToHost, st));
+            UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data(), w->nmodels, sizeof(int) * first, hipMemcpyDeviceToHost, st));
+            if (lmeds) UVO_HIP_TRY(c, hipMemcpyAsync(w->h_medians.data(), w->medians, sizeof(double) * first, hipMemcpyDeviceToHost, st));
+            else UVO_HIP_TRY(c, hipMemcpyAsync(w->h_counts.data(), w->counts, sizeof(int) * first, hipMemcpyDeviceToHost, st));
             UVO_HIP_TRY(c, hipStreamSynchronize(st));
-            Winner win = lmeds ? replay_lmeds(w->h_nmodels.data(), w->h_medians.data(), 1, nsub)
-                               : replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 1, nsub, niters, n, modelPoints, confidence);
+            Winner win;
+            if (lmeds) win = replay_lmeds(w->h_nmodels.data(), w->h_medians.data(), 1, nsub);
+            else {
+                int settled = niters;
+                win = replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 1, first, niters, n, modelPoints, confidence, &settled);
+                if (first < nsub && settled > first) {
+                    const int rest = nsub - first;
+                    hipLaunchKernelGGL(k_h_hyp, dim3((rest + kHHypThreads - 1) / kHHypThreads), dim3(kHHypThreads), 0, st, w->src, w->dst,
+                                       w->subsets + (size_t)4 * first, rest, w->models + (size_t)9 * first, w->nmodels + first);
+                    hipLaunchKernelGGL(k_h_score, dim3(rest), dim3(256), 0, st, w->src, w->dst, n, w->models + (size_t)9 * first, w->nmodels + first,
+                                       0, thr2, npow2, w->counts + first, w->medians + first);
+                    UVO_HIP_TRY(c, hipGetLastError());
+                    UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data() + first, w->nmodels + first, sizeof(int) * rest, hipMemcpyDeviceToHost, st));
+                    UVO_HIP_TRY(c, hipMemcpyAsync(w->h_counts.data() + first, w->counts + first, sizeof(int) * rest, hipMemcpyDeviceToHost, st));
+                    UVO_HIP_TRY(c, hipStreamSynchronize(st));
+                    win = replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 1, nsub, niters, n, modelPoints, confidence);
+                }
+            }
             if (win.hyp >= 0) {
                 double final_thr = thr;
                 if (lmeds) {

@@ -377,7 +377,7 @@ def test_find_essential_and_recover_pose_parity(ctx, oracle, n, method, thr, out
 
 
 @pytest.mark.parametrize("n,method,thr,outl", [(4, 8, 1.0, 0.0), (5, 8, 1.0, 0.0), (250, 8, 1.0, 0.2), (250, 4, 0.1, 0.2),
-                                               (1500, 8, 0.5, 0.5), (1500, 4, 0.1, 0.4)])
+                                               (1500, 8, 0.5, 0.5), (1500, 4, 0.1, 0.4), (600, 8, 0.5, 0.7)])
 def test_find_homography_parity(ctx, oracle, n, method, thr, outl):
     import ergo_uvo_amd as uvo
     ctx.set_params(uvo.Params.mono())                       # HOMOGRAPHY_DISTANCE = 50 (mono_VO_parameters.yaml:28)
