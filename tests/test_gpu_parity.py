@@ -53,7 +53,8 @@ def _assert_kps_equal(a, b):
             assert np.array_equal(av, bv), f
 
 
-@pytest.mark.parametrize("shape,thr", [((120, 160), 50), ((360, 640), 400), ((240, 320), 1500), ((720, 1280), 1500)])
+@pytest.mark.parametrize("shape,thr", [((120, 160), 50), ((360, 640), 400), ((240, 320), 1500), ((720, 1280), 1500),
+                                       ((100, 1920), 300), ((1080, 96), 300), ((67, 125), 30), ((187, 249), 100)])
 def test_surf_detect_describe_bit_exact(ctx, oracle, shape, thr):
     import ergo_uvo_amd as uvo
     img = _rand_img(3, *shape)
