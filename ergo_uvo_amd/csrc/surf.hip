@@ -238,6 +238,7 @@ __device__ __forceinline__ bool make_keypoint(float N9[3][9], float val0, float 
 // is stored de-interleaved by column residue, which turns the stride-STEP sample walk into
 // unit-stride (conflict-free) LDS reads.
 // ------------------------------------------------------------------------------------------
+static const float kDetBelow = -3.0e38f;      // sdet marker: determinant not evaluated, known to be <= the threshold
 constexpr int cround_pos(float v)      // cvRound for v >= 0 (round half to even), usable in constant expressions
 {
     int i = (int)v;
@@ -275,6 +276,9 @@ struct __attribute__((packed, aligned(4))) SumQuad { int32_t a, b, c, d; };     
 
 // dx, dy, dxy -> det of one sample; SV(dy, dx) fetches the integral value at compile-time offset (dy, dx) from the
 // template's top-left corner.  Corners shared between the boxes of a filter are read once (32 reads per sample).
+// `skip_thr` (in scope at the expansion): when dx*dy <= skip_thr the determinant cannot exceed the threshold either
+// (det = fl(dx*dy - fl(0.81f*dxy*dxy)) <= dx*dy), so Dxy's 16 corners are not read and the sample gets kDetBelow: it can
+// neither be a maximum nor beat one, and k_hessian_finish evaluates it exactly if it ends up in a keypoint's neighbourhood.
 #define UVO_HESSIAN_DET(SV, det)                                                                          \
     {                                                                                                     \
         /* Dx: boxes (0,2,3,7,+1) (3,2,6,7,-2) (6,2,9,7,+1) */                                            \
@@ -293,6 +297,8 @@ struct __attribute__((packed, aligned(4))) SumQuad { int32_t a, b, c, d; };     
         d += (float)(e3 + f6 - e6 - f3) * wy1;                                                            \
         d += (float)(e6 + f9 - e9 - f6) * wy2;                                                            \
         const float dy = (float)d;                                                                        \
+        const float pp_ = dx * dy;                                                                        \
+        if (!(pp_ > skip_thr)) det = kDetBelow; else {                                                 \
         /* Dxy: boxes (1,1,4,4,+1) (5,1,8,4,-1) (1,5,4,8,-1) (5,5,8,8,+1) */                              \
         int g11 = SV(c1, c1), g14 = SV(c1, c4), g15 = SV(c1, c5), g18 = SV(c1, c8);                       \
         int g41 = SV(c4, c1), g44 = SV(c4, c4), g45 = SV(c4, c5), g48 = SV(c4, c8);                       \
@@ -304,7 +310,7 @@ struct __attribute__((packed, aligned(4))) SumQuad { int32_t a, b, c, d; };     
         d += (float)(g51 + g84 - g81 - g54) * wd2;                                                        \
         d += (float)(g55 + g88 - g85 - g58) * wd3;                                                        \
         const float dxy = (float)d;                                                                       \
-        det = dx * dy - 0.81f * dxy * dxy;                                                                \
+        det = pp_ - 0.81f * dxy * dxy; }                                                                  \
     }
 #define UVO_HESSIAN_CONSTS(LC)                                                                            \
     constexpr int c0 = LC::r(0), c1 = LC::r(1), c2 = LC::r(2), c3 = LC::r(3), c4 = LC::r(4), c5 = LC::r(5), \
@@ -324,7 +330,7 @@ __device__ __forceinline__ void static_for(F&& f)
 // det plane of layer L (1..3) of a workgroup's TW x TH samples from the integral tile in LDS; 0 where the template does not fit
 template <int O, int L, int TW, int TH, int NT>
 __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, float* __restrict__ sdet, const OctavePat& op,
-                                            int px0, int py0)
+                                            int px0, int py0, float skip_thr)
 {
     using OC = OctC<O>;
     constexpr int STEP = OC::STEP, SIZE = OC::size(L);
@@ -356,7 +362,7 @@ __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, f
 // plane (dy & 3, dx & 3) at [STEP/4*oi + dy/4][STEP/4*oj + dx/4]: plane and offsets are compile-time, lanes along oj.
 template <int O, int L, int TW, int TH, int NT>
 __device__ __forceinline__ void det_layer_p(const int32_t* __restrict__ planes, int pw, int pstride, float* __restrict__ sdet,
-                                            const OctavePat& op, int px0, int py0)
+                                            const OctavePat& op, int px0, int py0, float skip_thr)
 {
     using OC = OctC<O>;
     constexpr int STEP = OC::STEP, SIZE = OC::size(L), Q = STEP / 4;
@@ -481,30 +487,38 @@ __global__ __launch_bounds__(256) void k_hessian_finish(SurvOut sv, const Octave
         const OctavePat& op = ops[r->octave];
         const int step = op.step;
         const int32_t* __restrict__ gsum = ip.sum[im];
-        float det = 0.f;
-        if (L != 2 && k < 9) {
-            const LayerPat& lo = op.L[L == 1 ? 0 : 4];
-            const int oi = i + k / 3 - 1 - lo.margin, oj = j + k % 3 - 1 - lo.margin;
+        // Row r of the neighbourhood is layer L-1+r.  The outer row (layer 0 below L = 1, layer 4 above L = 3) was never evaluated;
+        // the other rows come from the detection kernel and may hold kDetBelow where dx*dy <= threshold made the determinant
+        // irrelevant to the comparisons -- its exact value still enters the interpolation, so those are evaluated here too.
+        auto exact_det = [&](const LayerPat& lo, int ii, int jj) {
+            const int oi = ii - lo.margin, oj = jj - lo.margin;
+            float d = 0.f;
             if (oi >= 0 && oi < lo.samples_i && oj >= 0 && oj < lo.samples_j) {
                 const int32_t* o = gsum + (size_t)(oi * step) * sw + oj * step;
                 float dx, dy, dxy;
                 haar_response(lo, [&](int yy, int xx) { return o[(size_t)yy * sw + xx]; }, &dx, &dy, &dxy);
-                det = dx * dy - 0.81f * dxy * dxy;
+                d = dx * dy - 0.81f * dxy * dxy;
             }
+            return d;
+        };
+        float v3[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int row = 0; row < 3; row++) {
+            const bool outer = (L == 1 && row == 0) || (L == 3 && row == 2);
+            float v = (k < 9 && !outer) ? r->n9[row * 9 + k] : 0.f;
+            if (k < 9 && (outer || v == kDetBelow)) v = exact_det(op.L[L - 1 + row], i + k / 3 - 1, j + k % 3 - 1);
+            v3[row] = v;
         }
-        float o9[9];
         const int g0 = (threadIdx.x & 63) & ~15;          // first lane of this group within the wave
-#pragma unroll
-        for (int b = 0; b < 9; b++) o9[b] = __shfl(det, g0 + b);
-        if (k != 0) continue;
         float N9[3][9];
 #pragma unroll
-        for (int b = 0; b < 9; b++) { N9[0][b] = r->n9[b]; N9[1][b] = r->n9[9 + b]; N9[2][b] = r->n9[18 + b]; }
+        for (int b = 0; b < 9; b++) { N9[0][b] = __shfl(v3[0], g0 + b); N9[1][b] = __shfl(v3[1], g0 + b); N9[2][b] = __shfl(v3[2], g0 + b); }
+        if (k != 0) continue;
         const float val0 = N9[1][4];
         if (L != 2) {
             bool is_max = true;
 #pragma unroll
-            for (int b = 0; b < 9; b++) { is_max = is_max && (val0 > o9[b]); if (L == 1) N9[0][b] = o9[b]; else N9[2][b] = o9[b]; }
+            for (int b = 0; b < 9; b++) is_max = is_max && (val0 > (L == 1 ? N9[0][b] : N9[2][b]));
             if (!is_max) continue;
         }
         const LayerPat& lp = op.L[L];
@@ -584,9 +598,9 @@ __global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, 
         }
     }
     __syncthreads();
-    det_layer_c<O, 1, TW, TH, NT>(stile, sdet, op, px0, py0);
-    det_layer_c<O, 2, TW, TH, NT>(stile, sdet, op, px0, py0);
-    det_layer_c<O, 3, TW, TH, NT>(stile, sdet, op, px0, py0);
+    det_layer_c<O, 1, TW, TH, NT>(stile, sdet, op, px0, py0, thr);
+    det_layer_c<O, 2, TW, TH, NT>(stile, sdet, op, px0, py0, thr);
+    det_layer_c<O, 3, TW, TH, NT>(stile, sdet, op, px0, py0, thr);
     __syncthreads();
     nms_survivors<TW, TH, NT>(sdet, reinterpret_cast<unsigned*>(stile + THs * STEP * PW), op, thr, px0, py0, im, sv);
 }
@@ -599,9 +613,9 @@ __global__ __launch_bounds__(NT) void k_hessian_nms_p(ImgPair ip, int w, int h, 
     __shared__ unsigned s_list[NmsLds<TW, TH>::kWords];
     const int im = blockIdx.z;
     const int px0 = blockIdx.x * (TW - 2) - 1, py0 = blockIdx.y * (TH - 2) - 1;
-    det_layer_p<O, 1, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
-    det_layer_p<O, 2, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
-    det_layer_p<O, 3, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0);
+    det_layer_p<O, 1, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0, thr);
+    det_layer_p<O, 2, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0, thr);
+    det_layer_p<O, 3, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0, thr);
     __syncthreads();
     nms_survivors<TW, TH, NT>(sdet, s_list, op, thr, px0, py0, im, sv);
 }
