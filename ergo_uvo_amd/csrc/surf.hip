@@ -466,7 +466,7 @@ __device__ __forceinline__ void nms_survivors(const float* __restrict__ sdet, un
 // below layer 1, 4 above layer 3) from the integral image with the run-time box patterns (calcLayerDetAndTrace's
 // arithmetic, as k_hessian_layer_debug); lane 0 makes the comparison against them and runs findMaximaInLayer's tail.  The
 // workgroup's keypoints are collected in LDS and appended with one atomic per image.
-static const int kFinishPerWg = 32;
+static const int kFinishPerWg = 16;
 __global__ __launch_bounds__(256) void k_hessian_finish(SurvOut sv, const OctavePat* __restrict__ ops, ImgPair ip, int w, int h, CandOut out)
 {
     __shared__ uvo_keypoint s_kp[2][kFinishPerWg];
@@ -501,18 +501,25 @@ __global__ __launch_bounds__(256) void k_hessian_finish(SurvOut sv, const Octave
             }
             return d;
         };
-        float v3[3] = {0.f, 0.f, 0.f};
+        // the 27 entries are spread over the group's 16 lanes: lane k takes entries k and k + 16 (entry e = 9 * row + neighbour)
+        float v2[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int e = k + 16 * q;
+            v2[q] = r->n9[e < 27 ? e : 0];
+        }
 #pragma unroll 1
-        for (int row = 0; row < 3; row++) {
+        for (int q = 0; q < 2; q++) {
+            const int e = k + 16 * q;
+            if (e >= 27) continue;
+            const int row = e / 9, nb = e - row * 9;
             const bool outer = (L == 1 && row == 0) || (L == 3 && row == 2);
-            float v = (k < 9 && !outer) ? r->n9[row * 9 + k] : 0.f;
-            if (k < 9 && (outer || v == kDetBelow)) v = exact_det(op.L[L - 1 + row], i + k / 3 - 1, j + k % 3 - 1);
-            v3[row] = v;
+            if (outer || v2[q] == kDetBelow) v2[q] = exact_det(op.L[L - 1 + row], i + nb / 3 - 1, j + nb % 3 - 1);
         }
         const int g0 = (threadIdx.x & 63) & ~15;          // first lane of this group within the wave
         float N9[3][9];
 #pragma unroll
-        for (int b = 0; b < 9; b++) { N9[0][b] = __shfl(v3[0], g0 + b); N9[1][b] = __shfl(v3[1], g0 + b); N9[2][b] = __shfl(v3[2], g0 + b); }
+        for (int e = 0; e < 27; e++) N9[e / 9][e % 9] = __shfl(v2[e / 16], g0 + (e & 15));
         if (k != 0) continue;
         const float val0 = N9[1][4];
         if (L != 2) {
