@@ -161,7 +161,7 @@ def main():
     if rank == 0:
         # ---- latency leg: synchronous uvo_stereo_step, one pair in flight, wall clock per call ----
         lat = []
-        for _ in range(60):
+        for _ in range(200):
             a = time.perf_counter()
             rl = step()
             lat.append((time.perf_counter() - a) * 1e3)
