@@ -138,27 +138,33 @@ __global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const 
         if (tid == 0) counts[1] = 0;
         return;
     }
-    {   // MU:35-56: sum and sum of squares in index order; z values are staged through LDS in chunks
-        __shared__ double zbuf[2048];
-        double sum = 0.0, sumsq = 0.0;
+    {   // MU:35-56: sum and sum of squares in index order.  z and z*z are staged through LDS in chunks; the two sequential chains run
+        // on two different waves (one lane each), so each issues one fp64 add per element instead of sharing a SIMD's issue slots
+        __shared__ double zbuf[2048], zsq[2048];
+        __shared__ double s_sumsq;
+        double acc = 0.0;                                   // lane 0: the sum; lane 64: the sum of squares
         for (int base = 0; base < ngood; base += 2048) {
             const int cnt = min(2048, ngood - base);
-            for (int i = tid; i < cnt; i += 1024) zbuf[i] = cam1[3 * tmp_idx[base + i] + 2];
+            for (int i = tid; i < cnt; i += 1024) { const double z = cam1[3 * tmp_idx[base + i] + 2]; zbuf[i] = z; zsq[i] = z * z; }
             __syncthreads();
-            if (tid == 0) {
+            if (tid == 0 || tid == 64) {
+                const double* src = tid == 0 ? zbuf : zsq;
                 int i = 0;
                 for (; i + 8 <= cnt; i += 8) {
                     double z[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) z[q] = zbuf[i + q];
+                    for (int q = 0; q < 8; q++) z[q] = src[i + q];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) { sum += z[q]; sumsq += z[q] * z[q]; }
+                    for (int q = 0; q < 8; q++) acc += z[q];
                 }
-                for (; i < cnt; i++) { double z = zbuf[i]; sum += z; sumsq += z * z; }
+                for (; i < cnt; i++) acc += src[i];
             }
             __syncthreads();
         }
+        if (tid == 64) s_sumsq = acc;
+        __syncthreads();
         if (tid == 0) {
+            const double sum = acc, sumsq = s_sumsq;
             double mean = sum / ngood;
             double variance = (sumsq / ngood) - (mean * mean);
             s_mean = mean; s_sd3 = 3.0 * sqrt(variance);
