@@ -244,6 +244,11 @@ __global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__
             if (p.x <= lim) a = c * kMfmaChunk + (int)(__float_as_uint(p.x) & 127u);
             if (p.y <= lim) b = c * kMfmaChunk + (int)(__float_as_uint(p.y) & 127u);
             if (p.z <= lim) e3 = c * kMfmaChunk + (int)(__float_as_uint(p.z) & 127u);
+            // keys of the padding rows of the last 32-row block (|t|^2 = kBig) only get under lim when the train set has a
+            // single row (lim is then a padding key itself): they are not rows
+            if (a >= nt) a = -1;
+            if (b >= nt) b = -1;
+            if (e3 >= nt) e3 = -1;
         }
         const int base = threadIdx.x & 63 & ~15;
         const int gshift = threadIdx.x & 48;                // this group's 16 bits of a wave ballot

@@ -22,7 +22,7 @@ _FX_R, _FY_R, _CX_R, _CY_R = 1.330461901943011e+03, 1.328225165048530e+03, 0.684
 _T_RIGHT = np.array([-0.33, 0.0, 0.0])
 _CAL_WIDTH = 1280.0
 
-SEEDS = {"C2": 20250905, "C3": 20250906, "C4": 20250907, "C5": 20250910}
+SEEDS = {"C1": 20250904, "C2": 20250905, "C3": 20250906, "C4": 20250907, "C5": 20250910}
 
 
 @dataclass
@@ -120,15 +120,40 @@ class Scene:
         return float(t)
 
 
-def camera_pose(k: int):
-    """World->camera rotation and camera centre of the left camera at frame k (world = frame 0)."""
+def _frac_step(f: float):
+    """A fraction f of the per-frame step: rotation about STEP_R's axis by f times its angle, translation f * STEP_T."""
+    from scipy.spatial.transform import Rotation
+    rv = Rotation.from_matrix(STEP_R).as_rotvec()
+    return Rotation.from_rotvec(f * rv).as_matrix(), f * STEP_T
+
+
+def camera_pose(k):
+    """World->camera rotation and camera centre of the left camera at frame k (world = frame 0).  k may be negative
+    (the motion run backwards) or fractional (whole steps, then a fraction of one step: low-parallax frames)."""
     R = np.eye(3)
     C = np.zeros(3)
-    for _ in range(k):
+    whole = int(np.floor(k)) if k >= 0 else -int(np.floor(-k))
+    for _ in range(max(whole, 0)):
         # X_new = STEP_R (X_old - STEP_T)
         C = C + R.T @ STEP_T
         R = STEP_R @ R
+    for _ in range(max(-whole, 0)):
+        # the inverse step: X_old = STEP_R^T X_new + STEP_T
+        R = STEP_R.T @ R
+        C = C - R.T @ STEP_T
+    f = float(k) - whole
+    if f != 0.0:
+        Rf, Tf = _frac_step(f)
+        C = C + R.T @ Tf
+        R = Rf @ R
     return R, C
+
+
+def mono_frame(scene: Scene, k, width: int, height: int):
+    """Left view at (possibly negative or fractional) frame k; the noise key is derived from k so frames differ."""
+    rig = stereo_rig(width)
+    R, C = camera_pose(k)
+    return scene.render(rig.K_left, R, C, width, height, int(round(k * 64)) * 2 + (1 << 20))
 
 
 def stereo_pair(scene: Scene, k: int, width: int, height: int):
