@@ -15,6 +15,7 @@
 #include <atomic>
 #include <chrono>
 #include "uvo_epnp.h"
+#include "uvo_epnp_fast.h"
 #include <string.h>
 #include <stdlib.h>
 #include <mutex>
@@ -205,7 +206,7 @@ struct PnpJob {
     int* ninl_host;                          // pinned host mirrors (hcount, pose and ninl_host are written straight into host memory: no copies to queue)
     int G, nhyp, best;
 };
-struct PnpBatch { int n, cap; double fx, fy, cx, cy; float thr2; PnpJob job[kMaxPnpBatch]; };
+struct PnpBatch { int n, cap; double fx, fy, cx, cy; float thr2; int dbg; PnpJob job[kMaxPnpBatch]; };
 
 __global__ __launch_bounds__(64) void k_pnp_hyp(PnpBatch b)
 {
@@ -316,7 +317,8 @@ __global__ __launch_bounds__(1024) void k_pnp_mask(PnpBatch b)
     if (tid == 0) counts[0] = s_base;
 }
 
-__device__ long long g_refit_clk[16];       // diagnostic: phase stamps of the last refit (printed when UVO_DBG_PHASE is set)
+__device__ long long g_refit_clk[16];
+__device__ double g_dbg_small[2][EPNP_SMALL];   // UVO_DBG_REFIT: the fixed-size state of the sequential [0] and the parallel [1] refit of the same inliers       // diagnostic: phase stamps of the last refit (printed when UVO_DBG_PHASE is set)
 // inlier refit: one workgroup, block-cooperative EPnP.  ws: pws 3c | us 2c | alphas 4c | pcs 9c | tmp 3c (c = cap)
 __global__ __launch_bounds__(256) void k_pnp_refit(PnpBatch b)
 {
@@ -327,6 +329,7 @@ __global__ __launch_bounds__(256) void k_pnp_refit(PnpBatch b)
     extern __shared__ __align__(16) unsigned char refit_smem[];
     double* stage_buf = reinterpret_cast<double*>(refit_smem);       // Epnp<BlockPolicy>::kStageDoubles doubles (dynamic: > 64 KB)
     const int n = jb.countsB[0];
+    if (n >= kFastRefitMin && !b.dbg) return;                        // k_pnp_refit_fast's case
     using P = BlockPolicy;
     Epnp<P> e;
     e.uc = cx; e.vc = cy; e.fu = fx; e.fv = fy; e.n = n;
@@ -335,6 +338,26 @@ __global__ __launch_bounds__(256) void k_pnp_refit(PnpBatch b)
     e.pcs = P::Arr{ws + 9 * (size_t)cap}; e.tmp = P::Arr{ws + 18 * (size_t)cap};
     double rvec[3], tvec[3];
     e.compute_pose(rvec, tvec);
+    if (b.dbg) { __syncthreads(); for (int i = threadIdx.x; i < EPNP_SMALL; i += blockDim.x) g_dbg_small[0][i] = small[i]; if (n >= kFastRefitMin) return; }
+    if (threadIdx.x == 0) { pose[0] = rvec[0]; pose[1] = rvec[1]; pose[2] = rvec[2]; pose[3] = tvec[0]; pose[4] = tvec[1]; pose[5] = tvec[2]; jb.ninl_host[0] = n; }
+}
+
+// inlier refit, the usual case (>= kFastRefitMin inliers): the workgroup-parallel solver of uvo_epnp_fast.h.  The pose is the
+// refit's only output and its contract is 1e-4 relative, so the long sums are tree reductions, M^T M runs on the fp64
+// matrix pipe and the small decompositions use fast rotations; with fewer inliers it leaves the job to k_pnp_refit.
+__global__ __launch_bounds__(kFastThreads) void k_pnp_refit_fast(PnpBatch b)
+{
+    const PnpJob& jb = b.job[blockIdx.x];
+    __shared__ double lds[kFastLdsDoubles];
+    const int n = jb.countsB[0];
+    if (n < kFastRefitMin) return;
+    EpnpFast e;
+    e.uc = b.cx; e.vc = b.cy; e.fu = b.fx; e.fv = b.fy; e.n = n; e.cap = b.cap; e.ws = jb.ws; e.lds = lds;
+    e.clk = blockIdx.x == 0 ? g_refit_clk : nullptr;
+    double rvec[3], tvec[3];
+    e.compute_pose(rvec, tvec);
+    if (b.dbg) { __syncthreads(); for (int i = threadIdx.x; i < EPNP_SMALL; i += blockDim.x) g_dbg_small[1][i] = lds[i]; }
+    double* pose = jb.pose;
     if (threadIdx.x == 0) { pose[0] = rvec[0]; pose[1] = rvec[1]; pose[2] = rvec[2]; pose[3] = tvec[0]; pose[4] = tvec[1]; pose[5] = tvec[2]; jb.ninl_host[0] = n; }
 }
 
@@ -511,6 +534,7 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
     }
     if (g_bdbg) { g_bstat[1] += now_us() - t_b0; t_b0 = now_us(); }
     PnpBatch b2 = b;
+    b2.dbg = getenv("UVO_DBG_REFIT") != nullptr;
     int idx2[kMaxPnpBatch], nb2 = 0;
     bool need_sync = false;
     for (int k = 0; k < ns; k++) {
@@ -542,7 +566,8 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
         const size_t refit_lds = sizeof(double) * Epnp<BlockPolicy>::kStageDoubles;
         static std::once_flag refit_once;
         std::call_once(refit_once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_refit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)refit_lds); });
-        hipLaunchKernelGGL(k_pnp_refit, dim3(nb2), dim3(256), refit_lds, st, b2);
+        hipLaunchKernelGGL(k_pnp_refit_fast, dim3(nb2), dim3(kFastThreads), 0, st, b2);
+        hipLaunchKernelGGL(k_pnp_refit, dim3(nb2), dim3(256), refit_lds, st, b2);       // returns at once unless a job has < kFastRefitMin inliers
         UVO_HIP_TRY(m, hipGetLastError());
     }
     if (nb2 > 0) need_sync = true;
@@ -559,6 +584,18 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
         Ctx* c = lanes[i];
         memcpy(res[i].rvec, c->h_pose, sizeof(double) * 3); memcpy(res[i].tvec, c->h_pose + 3, sizeof(double) * 3);
         res[i].wrote = 1;
+    }
+    if (b2.dbg && nb2 > 0) {
+        static double h[2][EPNP_SMALL];
+        UVO_HIP_TRY(m, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dbg_small), sizeof(h)));
+        auto show = [&](const char* name, int off, int cnt) {
+            fprintf(stderr, "[refit dbg] %-8s", name);
+            for (int i = 0; i < cnt; i++) fprintf(stderr, " %.6e|%.6e", h[0][off + i], h[1][off + i]);
+            fprintf(stderr, "\n");
+        };
+        show("cws", EP_CWS, 12); show("D", EP_D, 12); show("ut11", EP_MTM + 132, 12); show("ut10", EP_MTM + 120, 12); show("rho", EP_RHO, 6);
+        show("L row0", EP_L, 10);
+        for (int br = 0; br < 3; br++) { show("betas", EP_BR + br * EPB_SIZE + EPB_BETAS, 4); show("ccs", EP_BR + br * EPB_SIZE + EPB_CCS, 12); show("R", EP_BR + br * EPB_SIZE + EPB_RS, 9); show("t", EP_BR + br * EPB_SIZE + EPB_TS, 3); show("rep", EP_BR + br * EPB_SIZE + EPB_REP, 1); }
     }
     if (getenv("UVO_DBG_PHASE")) {
         long long k[16];

@@ -156,6 +156,13 @@ def test_match_ties_and_edges(ctx, oracle):
     assert list(idx[0]) == [5, 17]                               # ties keep the lower train index first
     # train set with a single row: no second neighbour -> no matches (reference would index out of bounds)
     assert len(ctx.match_features(d1, d2[:1], 0.8)) == 0
+    # ... whatever an earlier call left in the staging buffer right behind that row: near (d2[1] == the queries' own rows) or far
+    for filler in (np.concatenate([d1[:1], d1[:64]]), np.concatenate([d1[:1], 1e3 * d1[:64]])):
+        ctx.knn_match(d1, filler)                                # stages `filler` where d2[:1] goes next
+        idx1, dist1 = ctx.knn_match(d1, d2[:1])
+        assert np.all(idx1[:, 0] == 0) and np.all(idx1[:, 1] == -1)
+        assert np.array_equal(dist1[:, 0].view(np.uint32), oracle.knn2(d1, d2[:1])[1][:, 0].view(np.uint32))
+        assert len(ctx.match_features(d1, d2[:1], 0.99)) == 0
     assert len(ctx.match_features(d1[:0], d2, 0.8)) == 0
     # append semantics (VOU:538)
     first = ctx.match_features(d1, d2, 0.9)
@@ -227,9 +234,15 @@ def test_pnp_ransac_parity(ctx, oracle, n, outliers, noise):
     assert np.array_equal(inl, oinl)                    # bit-exact inlier set
     def rel(a, b):
         return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
+    # the pose comes from the refit on the (bit-exact) inlier set.  With fewer than 24 inliers the refit is the sequential,
+    # OpenCV-ordered one (bitwise equal to the oracle); otherwise the workgroup-parallel one of uvo_epnp_fast.h, held to the
+    # north_star tolerance of 1e-4 relative (observed: ~1e-11)
     assert rel(rvec, orvec) < 1e-4 and rel(tvec, otvec) < 1e-4
-    assert np.array_equal(rvec.view(np.uint64), orvec.view(np.uint64)), (rvec, orvec)
-    assert np.array_equal(tvec.view(np.uint64), otvec.view(np.uint64))
+    if len(oinl) < 24:
+        assert np.array_equal(rvec.view(np.uint64), orvec.view(np.uint64)), (rvec, orvec)
+        assert np.array_equal(tvec.view(np.uint64), otvec.view(np.uint64))
+    elif ok:
+        assert rel(rvec, orvec) < 1e-8 and rel(tvec, otvec) < 1e-8, (rel(rvec, orvec), rel(tvec, otvec))
     if outliers <= 0.5 and n > 5:
         assert ok and rel(tvec, tt) < 0.05
 
@@ -260,8 +273,7 @@ def test_stereo_sequence_parity(ctx, oracle, scene_small):
             assert r.valid == 1
             for a, b in ((r.rvec, o.rvec), (r.tvec, o.tvec), (r.t_prev_curr, o.t_prev_curr), (r.velocity, o.velocity)):
                 a, b = np.array(list(a)), np.array(list(b))
-                assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)
-                assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+                assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)          # north_star tolerance (refit: uvo_epnp_fast.h)
     Rt, tt = synth.true_relative_motion()
     assert np.linalg.norm(np.array(list(r.tvec)) - tt) < 0.01
 
@@ -320,10 +332,20 @@ def test_failure_paths_through_the_pipeline(ctx, oracle, scene_small):
     ovo = oracle.StereoVO(oracle.stereo_params(1500), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
     want = [fields(ovo.step(L, R, 0.05)) for L, R in seq]
     assert [w[0] for w in want] == [0, 1, 0, 0, 1, 0, 0, 1, 1]       # init, ok, blank, no prev set, ok, half-blank, no prev set, ok, ok
+    def same(got, exp):
+        """gate results and counts exactly; poses to the north_star tolerance (the refit is not bitwise: uvo_epnp_fast.h)"""
+        assert len(got) == len(exp)
+        for g, e in zip(got, exp):
+            assert g[:8] == e[:8], (g[:8], e[:8])
+            for a, b in zip(g[8:], e[8:]):
+                a, b = np.array(a), np.array(b)
+                assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b), (a, b)
+        return True
+
     ctx.stereo_set_depth(1)
     ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
     sync = [fields(ctx.stereo_step(L, R, 0.05)) for L, R in seq]
-    assert sync == want
+    assert same(sync, want)
     for depth in (2, 4):
         ctx.stereo_set_depth(depth)
         ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
@@ -334,7 +356,7 @@ def test_failure_paths_through_the_pipeline(ctx, oracle, scene_small):
             while sub < len(seq) and sub - len(piped) < depth:
                 ctx.stereo_submit(*seq[sub]); sub += 1
             piped.append(fields(ctx.stereo_collect(0.05)))
-        assert piped == want, depth
+        assert piped == sync, depth                 # the pipelined path is the synchronous one, bit for bit
     ctx.stereo_set_depth(2)
 
 

@@ -110,7 +110,8 @@ def test_stereo_node_loop_through_the_shim_matches_oracle(oracle, scene_small, t
         want = [o.valid, o.initialized, o.n_left, o.n_right, o.n_stereo_matches, o.n_tri_matches, o.n_good3d, o.n_inliers]
         assert list(rec["i"][k]) == want, (k, list(rec["i"][k]), want)
         d = np.array(list(o.rvec) + list(o.tvec) + list(o.t_prev_curr))
-        assert np.array_equal(rec["d"][k].view(np.uint64), d.view(np.uint64)), (k, rec["d"][k], d)
+        for a, b in zip(rec["d"][k].reshape(3, 3), d.reshape(3, 3)):          # pose: north_star tolerance (parallel refit, uvo_epnp_fast.h)
+            assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b), (k, rec["d"][k], d)
         nvalid += o.valid
     assert nvalid == len(seq) - 1
 
