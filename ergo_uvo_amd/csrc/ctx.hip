@@ -121,9 +121,39 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     if (hipMemcpy(c->d_DW, c->h_DW, sizeof(float) * 400, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->d_rank, 0, sizeof(int) * cap * 2) != hipSuccess ||
         hipMemset(c->d_counts, 0, sizeof(int) * CN_TOTAL) != hipSuccess) { destroy_one(c); return UVO_HIP_ERROR; }
+    if (getenv("UVO_TRACE")) {
+        c->trace.resize(Ctx::kTraceRing);
+        for (auto& r : c->trace) for (int k = 0; k < 6; k++) if (hipEventCreate(&r.ev[k]) != hipSuccess) { destroy_one(c); return UVO_HIP_ERROR; }
+        c->trace_on = true;
+    }
     c->worker = std::thread(lane_worker, c);
     *out = c;
     return UVO_OK;
+}
+
+// UVO_TRACE: one CSV row per traced pair, times in ms relative to the earliest "A begin"
+static void write_trace(uvo_ctx* c)
+{
+    const char* path = getenv("UVO_TRACE");
+    if (!path || !c->trace_on) return;
+    (void)hipDeviceSynchronize();
+    struct Row { long long pair; int lane; float t[6]; };
+    std::vector<Row> rows;
+    hipEvent_t ref = nullptr; long long ref_pair = -1;
+    for (Ctx* l : c->lanes) for (auto& r : l->trace) if (r.pair >= 0 && (ref_pair < 0 || r.pair < ref_pair)) { ref = r.ev[0]; ref_pair = r.pair; }
+    if (!ref) return;
+    for (Ctx* l : c->lanes) for (auto& r : l->trace) {
+        if (r.pair < 0) continue;
+        Row w; w.pair = r.pair; w.lane = l->lane_id;
+        for (int k = 0; k < 6; k++) { w.t[k] = -1.f; if (k < 3 || r.b_used) (void)hipEventElapsedTime(&w.t[k], ref, r.ev[k]); }
+        rows.push_back(w);
+    }
+    std::sort(rows.begin(), rows.end(), [](const Row& a, const Row& b) { return a.pair < b.pair; });
+    FILE* f = fopen(path, "w");
+    if (!f) return;
+    fprintf(f, "pair,lane,a_begin_ms,detect_end_ms,a_end_ms,b_begin_ms,b_scored_ms,b_end_ms\n");
+    for (const Row& w : rows) fprintf(f, "%lld,%d,%.4f,%.4f,%.4f,%.4f,%.4f,%.4f\n", w.pair, w.lane, w.t[0], w.t[1], w.t[2], w.t[3], w.t[4], w.t[5]);
+    fclose(f);
 }
 
 static uvo_status set_depth(uvo_ctx* c, int depth)
@@ -148,7 +178,8 @@ extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w,
     uvo_status st = create_one(p, device, max_w, max_h, max_kpts, out);
     if (st != UVO_OK) return st;
     (*out)->lanes.push_back(*out);
-    if (getenv("UVO_MAX_B")) (*out)->max_b = atoi(getenv("UVO_MAX_B"));
+    if (getenv("UVO_MAX_B")) (*out)->max_b = std::min(8, std::max(1, atoi(getenv("UVO_MAX_B"))));
+    if (getenv("UVO_A_OVERLAP")) (*out)->a_overlap = std::min(8, std::max(0, atoi(getenv("UVO_A_OVERLAP"))));
     st = set_depth(*out, 2);                      // two pairs in flight by default (uvo_stereo_set_depth changes it)
     if (st != UVO_OK) { uvo_ctx_destroy(*out); *out = nullptr; }
     return st;
@@ -170,6 +201,7 @@ extern "C" void uvo_ctx_destroy(uvo_ctx* c)
                 n, uvo::g_bstat[0].load() / n, uvo::g_bstat[1].load() / n, uvo::g_bstat[2].load() / n, uvo::g_bstat[3].load() / n, uvo::g_bstat[5].load() / n);
         fprintf(stderr, "[uvo] uvo_stereo_submit host wall: %.1f us per pair over %.0f pairs\n", uvo::g_bstat[6].load() / std::max(1.0, uvo::g_bstat[7].load()), uvo::g_bstat[7].load());
     }
+    write_trace(c);
     for (size_t i = c->lanes.size(); i > 1; i--) destroy_one(static_cast<uvo_ctx*>(c->lanes[i - 1]));
     c->lanes.clear();
     destroy_one(c);
@@ -203,6 +235,7 @@ static void destroy_one(uvo_ctx* c)
     for (int i = 0; i < 2; i++) { (void)hipHostFree(c->h_countsA[i]); if (c->evA[i]) (void)hipEventDestroy(c->evA[i]); }
     if (c->pnp_stream) (void)hipStreamDestroy(c->pnp_stream);
     if (c->evAS) (void)hipEventDestroy(c->evAS);
+    for (auto& r : c->trace) for (int k = 0; k < 6; k++) if (r.ev[k]) (void)hipEventDestroy(r.ev[k]);
     if (c->evDet) (void)hipEventDestroy(c->evDet);
     if (c->evPrevRead) (void)hipEventDestroy(c->evPrevRead);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -570,9 +603,25 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     L->pending.used = true;
     memset(&L->pending.res, 0, sizeof(L->pending.res));
 #define LANE_TRY(expr) do { uvo_status st_ = (expr); if (st_ != UVO_OK) { if (L != c) c->err = L->err; return st_; } } while (0)
+    Ctx::TraceRec* tr = nullptr;
+    if (L->trace_on) {
+        L->trace_cur = (int)(L->trace_count++ % Ctx::kTraceRing);
+        tr = &L->trace[L->trace_cur]; tr->pair = c->n_submitted; tr->b_used = false;
+        UVO_HIP_TRY(c, hipEventRecord(tr->ev[0], L->stream));
+    }
     LANE_TRY(surf_upload(L, 0, left, w, h, stride, mem));
     LANE_TRY(surf_upload(L, 1, right, w, h, stride, mem));
+    // Stage A is a run of chip-filling detection kernels followed by thin ones.  Two stage As side by side fill each other's
+    // gaps; three or more interleave at kernel granularity, evict each other's LDS-sized workgroups and every one of them
+    // slows down (measured with UVO_TRACE: detection 390 us with two, 1050 us with five lanes in stage A).
+    // So this pair's kernels wait for the end of the stage A submitted a_overlap pairs ago; the lanes beyond that hold pairs
+    // in their PnP stage.
+    if (c->a_overlap > 0 && depth > c->a_overlap) {
+        Ctx* H = c->lanes[(li + depth - c->a_overlap) % depth];
+        UVO_HIP_TRY(c, hipStreamWaitEvent(L->stream, H->evA[0], 0));
+    }
     LANE_TRY(surf_detect(L, 2, p.MIN_NUM_FEATURES));                                       // VO:548-549, and the VO:556 gate
+    if (tr) UVO_HIP_TRY(c, hipEventRecord(tr->ev[1], L->stream));
     const int cap = c->cap, curr = L->as_w, prev = c->prev_buf;
     int* cn = L->d_counts;
     const float ratio = (float)p.LOWE_RATIO_THRESHOLD;
@@ -605,6 +654,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     LANE_TRY(pose_extract3d(L, 0, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap));
     UVO_HIP_TRY(c, hipMemcpyAsync(L->h_countsA[0], L->d_counts, sizeof(int) * CN_TOTAL, hipMemcpyDeviceToHost, st));
     UVO_HIP_TRY(c, hipEventRecord(L->evA[0], st));
+    if (tr) UVO_HIP_TRY(c, hipEventRecord(tr->ev[2], st));
     // state carry VO:727-733: this pair's set is the next pair's "prev"
     L->as_w = curr ^ 1;
     c->prev_lane = li; c->prev_buf = curr; c->prev_sync = false;
@@ -1117,6 +1167,10 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
     L->pending = Ctx::Pending(); L->pending.used = true;
     if (L->prev_read_pending) { UVO_HIP_TRY(c, hipStreamWaitEvent(st, L->evPrevRead, 0)); L->prev_read_pending = false; }   // the frame after this lane's last one has read its buffers
     LANE_TRY(surf_upload(L, 0, img, w, h, stride, mem));
+    if (c->a_overlap > 0 && depth > c->a_overlap) {                                        // as uvo_stereo_submit: at most a_overlap stage As side by side
+        Ctx* H = c->lanes[(li + depth - c->a_overlap) % depth];
+        UVO_HIP_TRY(c, hipStreamWaitEvent(st, H->evA[0], 0));
+    }
     LANE_TRY(surf_detect(L, 1));                                                           // VO:274
     UVO_HIP_TRY(c, hipEventRecord(L->evDet, st));
     int* cn = L->d_counts;

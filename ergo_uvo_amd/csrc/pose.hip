@@ -205,6 +205,7 @@ struct PnpJob {
     int* inliers; double* ws; int* countsB; double* pose;
     int* ninl_host;                          // pinned host mirrors (hcount, pose and ninl_host are written straight into host memory: no copies to queue)
     int G, nhyp, best;
+    int n_best, seq;                         // inliers of the winning hypothesis; refit by the sequential (OpenCV-ordered) kernel
 };
 struct PnpBatch { int n, cap; double fx, fy, cx, cy; float thr2; int dbg; PnpJob job[kMaxPnpBatch]; };
 
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void k_pnp_refit(PnpBatch b)
     extern __shared__ __align__(16) unsigned char refit_smem[];
     double* stage_buf = reinterpret_cast<double*>(refit_smem);       // Epnp<BlockPolicy>::kStageDoubles doubles (dynamic: > 64 KB)
     const int n = jb.countsB[0];
-    if (n >= kFastRefitMin && !b.dbg) return;                        // k_pnp_refit_fast's case
+    if (!jb.seq && !b.dbg) return;                                   // k_pnp_refit_fast's job
     using P = BlockPolicy;
     Epnp<P> e;
     e.uc = cx; e.vc = cy; e.fu = fx; e.fv = fy; e.n = n;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256) void k_pnp_refit(PnpBatch b)
     e.pcs = P::Arr{ws + 9 * (size_t)cap}; e.tmp = P::Arr{ws + 18 * (size_t)cap};
     double rvec[3], tvec[3];
     e.compute_pose(rvec, tvec);
-    if (b.dbg) { __syncthreads(); for (int i = threadIdx.x; i < EPNP_SMALL; i += blockDim.x) g_dbg_small[0][i] = small[i]; if (n >= kFastRefitMin) return; }
+    if (b.dbg) { __syncthreads(); for (int i = threadIdx.x; i < EPNP_SMALL; i += blockDim.x) g_dbg_small[0][i] = small[i]; if (!jb.seq) return; }
     if (threadIdx.x == 0) { pose[0] = rvec[0]; pose[1] = rvec[1]; pose[2] = rvec[2]; pose[3] = tvec[0]; pose[4] = tvec[1]; pose[5] = tvec[2]; jb.ninl_host[0] = n; }
 }
 
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(kFastThreads) void k_pnp_refit_fast(PnpBatch b)
     const PnpJob& jb = b.job[blockIdx.x];
     __shared__ double lds[kFastLdsDoubles];
     const int n = jb.countsB[0];
-    if (n < kFastRefitMin) return;
+    if (jb.seq) return;
     EpnpFast e;
     e.uc = b.cx; e.vc = b.cy; e.fu = b.fx; e.fv = b.fy; e.n = n; e.cap = b.cap; e.ws = jb.ws; e.lds = lds;
     e.clk = blockIdx.x == 0 ? g_refit_clk : nullptr;
@@ -457,13 +458,15 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
         PnpJob& j = base[ns];
         j.opts = c->d_opts[0]; j.ipts = c->d_ipts[0]; j.subsets = c->h_subsets; j.models = c->d_models; j.hcount = c->h_hcount;
         j.inliers = c->d_inliers; j.ws = c->d_refit; j.countsB = c->d_countsB; j.pose = c->h_pose; j.ninl_host = c->h_countsB;
-        j.G = G[i]; j.nhyp = 0; j.best = 0;
+        j.G = G[i]; j.nhyp = 0; j.best = 0; j.n_best = 0; j.seq = 0;
         Scan& q = sc[ns++];
         q.job = i; q.G = G[i]; q.niters = G[i] == modelPoints ? 1 : niters0; q.maxGood = 0; q.best = -1; q.last = 0; q.iter = 0; q.computed = 0;
         q.rng = (uint64_t)-1;                 // getSubset (ptsetreg.cpp): cv::RNG((uint64)-1)
         q.active = true;
     }
     if (ns == 0) return UVO_OK;
+    Ctx::TraceRec* tr = (n == 1 && lanes[0]->trace_on && lanes[0]->trace_cur >= 0) ? &lanes[0]->trace[lanes[0]->trace_cur] : nullptr;   // UVO_TRACE
+    if (tr) { tr->b_used = true; (void)hipEventRecord(tr->ev[3], st); (void)hipEventRecord(tr->ev[4], st); (void)hipEventRecord(tr->ev[5], st); }
     const int kFirstHyp = 64;
     for (int round = 0; ; round++) {
         int slot_of[kMaxPnpBatch], nb = 0, max_hyp = 0;
@@ -514,6 +517,7 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
             Ctx* c = lanes[sc[slot_of[s_]].job];
             if (sc[slot_of[s_]].G == modelPoints) UVO_HIP_TRY(m, hipMemcpyAsync(c->h_pose, c->d_models, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
         }
+        if (tr) (void)hipEventRecord(tr->ev[4], st);
         UVO_HIP_TRY(m, hipStreamSynchronize(st));
         // replay of RANSACPointSetRegistrator::run's sequential scan over the counts that exist so far, per job
         for (int s_ = 0; s_ < nb; s_++) {
@@ -556,7 +560,7 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
             r.wrote = 2;                      // pose arrives with the final sync
             continue;
         }
-        b2.job[nb2] = base[k]; b2.job[nb2].best = q.best;
+        b2.job[nb2] = base[k]; b2.job[nb2].best = q.best; b2.job[nb2].n_best = q.maxGood;
         idx2[nb2++] = q.job;
     }
     if (nb2 > 0) {
@@ -566,11 +570,19 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
         const size_t refit_lds = sizeof(double) * Epnp<BlockPolicy>::kStageDoubles;
         static std::once_flag refit_once;
         std::call_once(refit_once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_refit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)refit_lds); });
-        hipLaunchKernelGGL(k_pnp_refit_fast, dim3(nb2), dim3(kFastThreads), 0, st, b2);
-        hipLaunchKernelGGL(k_pnp_refit, dim3(nb2), dim3(256), refit_lds, st, b2);       // returns at once unless a job has < kFastRefitMin inliers
+        // the inlier count is known here: it is the winning hypothesis' count (k_pnp_mask repeats the same test)
+        static const bool force_seq = getenv("UVO_REFIT_SEQUENTIAL") != nullptr;       // diagnostics: the OpenCV-ordered refit for every job
+        bool any_fast = false, any_seq = b2.dbg != 0;
+        for (int s = 0; s < nb2; s++) {
+            b2.job[s].seq = force_seq || b2.job[s].n_best < kFastRefitMin;
+            any_fast = any_fast || !b2.job[s].seq; any_seq = any_seq || b2.job[s].seq;
+        }
+        if (any_fast) hipLaunchKernelGGL(k_pnp_refit_fast, dim3(nb2), dim3(kFastThreads), 0, st, b2);
+        if (any_seq) hipLaunchKernelGGL(k_pnp_refit, dim3(nb2), dim3(256), refit_lds, st, b2);
         UVO_HIP_TRY(m, hipGetLastError());
     }
     if (nb2 > 0) need_sync = true;
+    if (tr) (void)hipEventRecord(tr->ev[5], st);
     if (g_bdbg) { g_bstat[2] += now_us() - t_b0; t_b0 = now_us(); }
     if (need_sync) UVO_HIP_TRY(m, hipStreamSynchronize(st));
     if (g_bdbg) { g_bstat[3] += now_us() - t_b0; g_bstat[4] += 1; }

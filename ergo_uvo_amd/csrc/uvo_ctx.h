@@ -133,6 +133,7 @@ struct Ctx {
     hipEvent_t evA[2] = {nullptr, nullptr};      // [0]: stage A of this lane's pair finished (counts in h_countsA[0])
     int* h_countsA[2] = {nullptr, nullptr};      // pinned copy of d_counts
     hipEvent_t evAS = nullptr;                   // this lane's "after stereo match" set is written
+    int a_overlap = 2;                           // master: stage As (detect .. extract_3Dpoints) allowed side by side (env UVO_A_OVERLAP, 0 = no limit)
     std::vector<Ctx*> lanes;                     // master only: lanes[0] == this
     Ctx* master = nullptr;                       // children only
     int lane_id = 0;
@@ -175,6 +176,13 @@ struct Ctx {
     int mono_n_prev = 0;                         // rows of the prev descriptors kept in d_as_descL[0]
     std::deque<uvo_mono_result> mono_init_results;   // uvo_mono_submit: results of the synchronous init frames awaiting their collect
     std::vector<uvo_dmatch> mono_matches; std::vector<uint8_t> mono_mask; std::vector<double> mono_good_pts;
+
+    // ---- UVO_TRACE=<file>: device timestamps of every pipelined pair's phases (hipEvents with timing), written as CSV by
+    // uvo_ctx_destroy: pair, lane, A begin, detection end, A end, B begin, B hypotheses scored, B end (ms since the first) ----
+    static const int kTraceRing = 256;
+    struct TraceRec { long long pair = -1; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool b_used = false; };
+    std::vector<TraceRec> trace; int trace_cur = -1; long long trace_count = 0;
+    bool trace_on = false;
 
     // ---- timing ----
     bool timing = false;

@@ -295,7 +295,7 @@ __device__ inline void rodrigues_mat2vec_orthonormal(const double* R, double* rv
 
 // The refit.  One workgroup of kFastThreads threads; lds = kFastLdsDoubles doubles of LDS.
 // ws (global): pws 3c | us 2c | alphas 4c | pcs 9c (c = cap), as the sequential refit.
-static const int kFastThreads = 512, kFastWaves = kFastThreads / 64;       // 8 waves: 256 registers per lane for the register-resident solvers
+static const int kFastThreads = 256, kFastWaves = kFastThreads / 64;       // 4 waves, one per SIMD: a workgroup that fits beside the detection kernels
 static const int kFastTile = 64 * 6;                                       // per-wave tile: 64 points x (a0..a3, uc - u, vc - v)
 static const int kFastUnion = kFastWaves * kFastTile > kFastWaves * 256 ? kFastWaves * kFastTile : kFastWaves * 256;
 static const int kFastLdsDoubles = EPNP_SMALL + 160 + kFastWaves * 40 + 40 + kFastUnion;
