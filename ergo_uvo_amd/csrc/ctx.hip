@@ -89,7 +89,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     }
     c->surv_cap = 4 * (int)cap; A(dalloc(&c->d_surv, (size_t)c->surv_cap));
     A(dalloc(&c->d_colpart, (size_t)2 * nseg * (max_w + 1)));
-    A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_par, cap * 4)); A(dalloc(&c->d_big_patch, cap * 2 * 448)); A(hipMalloc(reinterpret_cast<void**>(&c->d_big_tabs), cap * 2 * 21 * 32));
+    A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_par, cap * 4)); A(dalloc(&c->d_big_patch, cap * 2 * 448));
     A(dalloc(&c->d_mpart, nchunks * cap)); A(dalloc(&c->d_mscratch, nchunks + 4)); A(dalloc(&c->d_knn_idx, cap * 2)); A(dalloc(&c->d_knn_dist, cap * 2));
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
     A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_tmp_idx, cap));
@@ -117,6 +117,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     c->d_nmatch = c->d_counts + CN_M;
     c->d_as_n = c->d_counts + CN_AS0;
     c->d_big_n = c->d_counts + CN_BIG0;
+    if (surf_build_area_tables(c) != UVO_OK) { destroy_one(c); return UVO_HIP_ERROR; }
     make_desc_weights(c->h_DW);
     if (hipMemcpy(c->d_DW, c->h_DW, sizeof(float) * 400, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->d_rank, 0, sizeof(int) * cap * 2) != hipSuccess ||
@@ -225,7 +226,7 @@ static void destroy_one(uvo_ctx* c)
     if (c->pnp_stream) (void)hipStreamSynchronize(c->pnp_stream);
     mono_ws_free(c);
     pre_ws_free(c);
-    void* ptrs[] = { c->d_surv, c->d_octpat, c->d_colpart, c->d_DW, c->d_rank, c->d_big_par, c->d_big_patch, c->d_big_tabs, c->d_mpart, c->d_mscratch, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
+    void* ptrs[] = { c->d_surv, c->d_octpat, c->d_colpart, c->d_DW, c->d_rank, c->d_big_par, c->d_big_patch, c->d_area_tabs, c->d_area_iscale, c->d_mpart, c->d_mscratch, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
                      c->d_flag, c->d_tmp_idx, c->d_good_pts[0], c->d_good_pts[1], c->d_good_idx[0], c->d_good_idx[1], c->d_opts[0], c->d_opts[1],
                      c->d_ipts[0], c->d_ipts[1], c->d_counts, c->d_countsB, c->d_subsets, c->d_models,
                      c->d_hcount, c->d_inliers, c->d_refit, c->d_pose };

@@ -667,12 +667,14 @@ __device__ __forceinline__ SortKey make_sort_key(const uvo_keypoint& kp)
 struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* out[2]; int* out_n[2]; int* rank; int cap;
                   int4* big_par; int* big_n; int* gate_nqa; int gate_min_features; };
 static const int kSmallWin = 128;       // descriptor windows up to this size use the small-LDS kernel
+static const int kMaxWin = 740;         // (int)(21 * 264 * 1.2f / 9) = 739: the window of the largest octave-3 keypoint
 // Large windows are listed in append order by k_rank_scatter and then sorted by descending window size (a (keypoint,
 // column) task of k_descriptor64_big costs about ceil(win/256) lane passes x ceil((win/21 + 2)/16) tap batches, 1..9 units),
 // which the task dealing of that kernel relies on.  Counting sort, one workgroup per image.
 static const int kBigBins = 1024;
 static const int kTripleWin = 246;     // windows up to this size: three destination columns per task (3 x 246 floats share the 740-float row buffer)
-__global__ __launch_bounds__(1024) void k_big_sort(const int4* __restrict__ in, int4* __restrict__ out, const int* __restrict__ big_n, int* __restrict__ big_large, int cap)
+__global__ __launch_bounds__(1024) void k_big_sort(const int4* __restrict__ in, int4* __restrict__ out, const int* __restrict__ big_n, int* __restrict__ big_large, int cap,
+                                                   const int* __restrict__ iscale_tab)
 {
     const int im = blockIdx.x, tid = threadIdx.x;
     const int n = min(big_n[im], cap);
@@ -697,11 +699,9 @@ __global__ __launch_bounds__(1024) void k_big_sort(const int4* __restrict__ in, 
     for (int e = tid; e < n; e += 1024) {
         int4 par = in[im * cap + e];
         const int pos = atomicAdd(&hist[min(kBigBins - 1, max(0, kBigBins - 1 - par.y))], 1);
-        // resizeAreaFast_ applies when the scale is an integer to within DBL_EPSILON: decided once per keypoint here (two
-        // fp64 divisions) instead of once per task; .y = win_size | (iscale << 16), iscale = 0 for the general path
-        const double scale = 1. / ((double)21 / par.y);
-        const int iscale = cv_round_d(scale);
-        if (fabs(scale - iscale) < DBL_EPSILON) par.y |= iscale << 16;
+        // resizeAreaFast_ applies when the scale is an integer to within DBL_EPSILON (tabulated per window size):
+        // .y = win_size | (iscale << 16), iscale = 0 for the general path
+        par.y |= iscale_tab[min(par.y, kMaxWin)] << 16;
         out[im * cap + pos] = par;
     }
 }
@@ -787,8 +787,10 @@ __global__ __launch_bounds__(256) void k_rank_scatter(SortArgs a)
 // ------------------------------------------------------------------------------------------
 struct AreaTab { int sx1, sx2; float a_first, a_mid, a_last; bool has_first, has_last; };
 
-// computeResizeAreaTab (resize.cpp) for one destination index
-__device__ __forceinline__ AreaTab area_tab(int dx, int ssize, double scale)
+// computeResizeAreaTab (resize.cpp) for one destination index.  The tables depend on the window size only, so they are built
+// once per context on the host for every possible size (surf_build_area_tables; plain IEEE double arithmetic, the same
+// values a device evaluation gives) and the kernels look them up.
+__host__ __device__ __forceinline__ AreaTab area_tab(int dx, int ssize, double scale)
 {
     AreaTab t;
     double fsx1 = dx * scale;
@@ -810,7 +812,8 @@ __device__ __forceinline__ AreaTab area_tab(int dx, int ssize, double scale)
 __device__ __forceinline__ uint8_t sat_u8(float v) { int iv = cv_round_f(v); return (uint8_t)(iv < 0 ? 0 : iv > 255 ? 255 : iv); }
 
 struct DescArgs { const uint8_t* img[2]; uvo_keypoint* kps[2]; float* desc[2]; const int* n[2]; const float* DW;
-                  const int4* big_par; const int* big_n; const int* big_large; int cap; };
+                  const int4* big_par; const int* big_n; const int* big_large; int cap;
+                  const AreaTab* tabs; const int* iscale; };     // [kMaxWin + 1][21] resize tables, [kMaxWin + 1] integer scale (0: general path)
 
 // PATCH (21 x 21, shared) -> gradients, 4x4x4 sums, normalisation -> a.desc[im][k]; 256 threads, PATCH already synchronised
 __device__ __forceinline__ void describe_tail(const DescArgs& a, int im, int k, const int (*PATCH)[21])
@@ -869,6 +872,7 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
     const float win_offset = -(float)(win_size - 1) / 2;
     const int start_x = cv_round_f(kp.x + win_offset);
     const int start_y = cv_round_f(kp.y - win_offset);
+    // (computed here rather than looked up in a.tabs / a.iscale: a second dependent fetch costs this latency-bound kernel more)
     const double inv_scale = (double)21 / win_size;
     const double scale = 1. / inv_scale;
     const int iscale = cv_round_d(scale);
@@ -995,19 +999,16 @@ __global__ __launch_bounds__(256) void k_descriptor64_small(DescArgs a, int w, i
 // buf[i][dx] for every window row i exactly as above, and finishes the 21 outputs PATCH[dy][dx] of its column.  A
 // fixed grid walks the (keypoint, dx) tasks of the list built by k_rank_scatter, so the largest window is spread over
 // 21 workgroups instead of serialising one; k_descriptor64_big_finish turns the patches into descriptors.
+static const int kTapBatch = 16;           // image rows a lane of k_descriptor64_big has in flight
 static const int kPatchStride = 448;       // bytes of patch scratch per keypoint (441 used)
-// the 21 resize tables of every large-window keypoint (they depend on win_size only), once instead of once per task
-__global__ __launch_bounds__(256) void k_descriptor64_big_tabs(DescArgs a, AreaTab* __restrict__ tabs)
-{
-    const int im = blockIdx.y;
-    const int id = blockIdx.x * 256 + threadIdx.x;
-    const int e = id / 21, d = id - e * 21;
-    if (e >= a.big_n[im]) return;
-    const int win_size = a.big_par[im * a.cap + e].y & 0xFFFF;
-    const double scale = 1. / ((double)21 / win_size);
-    tabs[((size_t)im * a.cap + e) * 21 + d] = area_tab(d, win_size, scale);
-}
 __device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a < b ? x : y on scalar registers (the compiler turns the C expression into VALU selects on copies of the operands)
+__device__ __forceinline__ int ssel_lt(int a, int b, int x, int y)
+{
+    int r;
+    asm volatile("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(r) : "s"(a), "s"(b), "s"(x), "s"(y) : "scc");
+    return r;
+}
 __device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
 // One task per WAVE (no workgroup barriers: four independent waves per workgroup, 8192 waves resident).  A task is one
@@ -1015,7 +1016,7 @@ __device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__built
 // horizontal passes run one after the other into three thirds of the row buffer, then one vertical pass finishes the 63
 // outputs, a lane each): the per-task work that does not depend on the window -- parameters, tables, the vertical pass,
 // its 21-of-64 lanes -- is shared by three columns where the LDS allows it.
-__global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int h, uint8_t* __restrict__ patch, const AreaTab* __restrict__ tabs)
+__global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int h, uint8_t* __restrict__ patch)
 {
     const int im = blockIdx.y, lane = threadIdx.x & 63, wv = sgpr_i(threadIdx.x >> 6);
     const int nb = a.big_n[im], nl = min(a.big_large[im], nb);        // the sorted list: nl wide windows first
@@ -1030,12 +1031,21 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
     const int nt1 = nl * 21, ntask = nt1 + (nb - nl) * 7, NW = gridDim.x * 4, wid = blockIdx.x * 4 + wv;
     auto task_of = [&](int r) { return r * NW + ((r & 1) ? NW - 1 - wid : wid); };
     auto entry_of = [&](int t) { return t < nt1 ? t / 21 : nl + (t - nt1) / 7; };
+    // A task starts with two dependent fetches -- its keypoint's parameters, then that window size's resize table -- and a wave
+    // runs only a few tasks, one after the other: both are fetched one task ahead (lane l keeps entry l % 21 of the table; the
+    // column's entry is read out of lane dx with v_readlane), so a task begins with everything in registers.
+    const int tl = lane % 21;
     int4 par_next = make_int4(0, 0, 0, 0);
-    if (task_of(0) < ntask) par_next = a.big_par[im * a.cap + entry_of(task_of(0))];
+    AreaTab tab_next = a.tabs[tl];
+    if (task_of(0) < ntask) { par_next = a.big_par[im * a.cap + entry_of(task_of(0))]; tab_next = a.tabs[min(par_next.y & 0xFFFF, kMaxWin) * 21 + tl]; }
     for (int r = 0; r * NW < ntask; r++) {
         const int t = task_of(r);
         const int4 par = par_next;                            // (sorted index, win_size, start_x, start_y) from k_rank_scatter
-        if (task_of(r + 1) < ntask) par_next = a.big_par[im * a.cap + entry_of(task_of(r + 1))];      // next task's, in flight meanwhile
+        const AreaTab ty = tab_next;                          // entry lane % 21 of this task's resize table
+        if (task_of(r + 1) < ntask) {                         // the next task's, in flight meanwhile
+            par_next = a.big_par[im * a.cap + entry_of(task_of(r + 1))];
+            tab_next = a.tabs[min(par_next.y & 0xFFFF, kMaxWin) * 21 + tl];
+        }
         if (t >= ntask) continue;
         const int e = entry_of(t);
         const int ncols = t < nt1 ? 1 : 3, dx0 = t < nt1 ? t - e * 21 : 3 * ((t - nt1) - (e - nl) * 7);
@@ -1095,31 +1105,34 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
                 out[dy * 21 + dx0 + d] = (uint8_t)result;
             }
         } else {
-            const AreaTab* tab = tabs + ((size_t)im * a.cap + e) * 21;
             for (int d = 0; d < ncols; d++) {
                 const int dx = dx0 + d;
                 float* bufrow = bufrow0 + d * bstride;
-                AreaTab tx = tab[dx];                          // the same for every lane: keep it in scalar registers
-                tx.sx1 = sgpr_i(tx.sx1); tx.sx2 = sgpr_i(tx.sx2);
-                tx.a_first = sgpr_f(tx.a_first); tx.a_mid = sgpr_f(tx.a_mid); tx.a_last = sgpr_f(tx.a_last);
-                tx.has_first = sgpr_i(tx.has_first) != 0; tx.has_last = sgpr_i(tx.has_last) != 0;
+                AreaTab tx;                                    // the column's entry, the same for every lane: scalar registers
+                tx.sx1 = __builtin_amdgcn_readlane(ty.sx1, dx); tx.sx2 = __builtin_amdgcn_readlane(ty.sx2, dx);
+                tx.a_first = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_first), dx));
+                tx.a_mid = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_mid), dx));
+                tx.a_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_last), dx));
+                tx.has_first = __builtin_amdgcn_readlane((int)ty.has_first, dx) != 0; tx.has_last = __builtin_amdgcn_readlane((int)ty.has_last, dx) != 0;
                 const int c_begin = tx.has_first ? tx.sx1 - 1 : tx.sx1;
                 const int c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
+                const int ai_first = sgpr_i(__float_as_int(tx.a_first)), ai_mid = sgpr_i(__float_as_int(tx.a_mid)), ai_last = sgpr_i(__float_as_int(tx.a_last));
                 if (vec_ok) {
                     // four adjacent window rows (image columns) per lane from one aligned 32-bit load per tap
                     for (int x4 = xa + 4 * lane; x4 < xhi; x4 += 256) {
                         float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-                        for (int c0 = c_begin; c0 < c_end; c0 += 16) {         // sixteen taps in flight, accumulated in order
-                            unsigned v[16];
+                        for (int c0 = c_begin; c0 < c_end; c0 += kTapBatch) {  // kTapBatch taps in flight, accumulated in order
+                            unsigned v[kTapBatch];
 #pragma unroll
-                            for (int q = 0; q < 16; q++) {
+                            for (int q = 0; q < kTapBatch; q++) {
                                 int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
                                 v[q] = *reinterpret_cast<const unsigned*>(img + ((unsigned)(y * w) + (unsigned)x4));       // scalar row offset + vector column: one 32-bit add
                             }
 #pragma unroll
-                            for (int q = 0; q < 16; q++) {
+                            for (int q = 0; q < kTapBatch; q++) {
                                 int cc = c0 + q;
-                                float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
+                                // the tap's weight is the same for every lane: chosen with scalar selects on the bit patterns
+                                const float alpha = __int_as_float(ssel_lt(cc, tx.sx1, ai_first, ssel_lt(cc, tx.sx2, ai_mid, ai_last)));
                                 if (cc < c_end) {
                                     b0 += (int)(v[q] & 255u) * alpha; b1 += (int)((v[q] >> 8) & 255u) * alpha;
                                     b2 += (int)((v[q] >> 16) & 255u) * alpha; b3 += (int)(v[q] >> 24) * alpha;
@@ -1160,7 +1173,6 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
             if (lane < 21 * ncols) {                        // vertical passes of the task's columns, 21 lanes each
                 const int d = lane / 21, dy = lane - d * 21;
                 const float* bufrow = bufrow0 + d * bstride;
-                const AreaTab ty = tab[dy];
                 const int r_begin = ty.has_first ? ty.sx1 - 1 : ty.sx1;
                 const int r_end = ty.has_last ? ty.sx2 + 1 : ty.sx2;
                 float sum = 0.f;
@@ -1190,6 +1202,25 @@ __global__ __launch_bounds__(256) void k_descriptor64_big_finish(DescArgs a, con
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// resize tables and integer-scale flags of every window size, once per context
+uvo_status surf_build_area_tables(Ctx* c)
+{
+    std::vector<AreaTab> tabs((size_t)(kMaxWin + 1) * 21);
+    std::vector<int> isc(kMaxWin + 1, 0);
+    memset(tabs.data(), 0, tabs.size() * sizeof(AreaTab));
+    for (int win = 1; win <= kMaxWin; win++) {
+        const double scale = 1. / ((double)21 / win);              // cv::resize: inv_scale_x = dsize.width / ssize.width, scale_x = 1. / inv_scale_x
+        for (int d = 0; d < 21; d++) tabs[(size_t)win * 21 + d] = area_tab(d, win, scale);
+        const int iscale = cv_round_d(scale);
+        if (fabs(scale - iscale) < DBL_EPSILON) isc[win] = iscale;
+    }
+    UVO_HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_area_tabs), tabs.size() * sizeof(AreaTab)));
+    UVO_HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_area_iscale), isc.size() * sizeof(int)));
+    UVO_HIP_TRY(c, hipMemcpy(c->d_area_tabs, tabs.data(), tabs.size() * sizeof(AreaTab), hipMemcpyHostToDevice));
+    UVO_HIP_TRY(c, hipMemcpy(c->d_area_iscale, isc.data(), isc.size() * sizeof(int), hipMemcpyHostToDevice));
+    return UVO_OK;
+}
+
 uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int stride, int mem)
 {
     if (!gray || w <= 0 || h <= 0 || w > c->max_w || h > c->max_h || stride < w || slot < 0 || slot > 1) {
@@ -1310,11 +1341,11 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
     {
         StageTimer t(c, ST_DESCRIPTOR);
         DescArgs da = { { c->d_img[0], c->d_img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
-                        { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap };      // the sorted list
+                        { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap,      // the sorted list
+                        c->d_area_tabs, c->d_area_iscale };
         const size_t lds_small = sizeof(float) * 21 * (kSmallWin | 1);
-        hipLaunchKernelGGL(k_big_sort, dim3(nimg), dim3(1024), 0, c->stream, c->d_big_par, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap);
-        hipLaunchKernelGGL(k_descriptor64_big_tabs, dim3((c->cap * 21 + 255) / 256, nimg), dim3(256), 0, c->stream, da, c->d_big_tabs);
-        hipLaunchKernelGGL(k_descriptor64_big, dim3(1024, nimg), dim3(256), 0, c->stream, da, w, h, c->d_big_patch, c->d_big_tabs);
+        hipLaunchKernelGGL(k_big_sort, dim3(nimg), dim3(1024), 0, c->stream, c->d_big_par, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap, c->d_area_iscale);
+        hipLaunchKernelGGL(k_descriptor64_big, dim3(1024, nimg), dim3(256), 0, c->stream, da, w, h, c->d_big_patch);
         hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(1024, nimg), dim3(256), 0, c->stream, da, c->d_big_patch);
         hipLaunchKernelGGL(k_descriptor64_small, dim3(c->cap, nimg), dim3(256), lds_small, c->stream, da, w, h);
         UVO_HIP_TRY(c, hipGetLastError());

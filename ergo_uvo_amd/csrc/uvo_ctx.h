@@ -75,7 +75,8 @@ struct Ctx {
     void* d_octpat = nullptr;                    // the four OctavePat of the current image size, for k_hessian_finish
     std::vector<unsigned char> h_octpat;         // what d_octpat holds
     int4* d_big_par = nullptr; int* d_big_n = nullptr;   // [2][cap] (sorted index, win, start_x, start_y) of large-window keypoints in append order, then [2][cap] by descending win; [2] counts
-    struct AreaTab* d_big_tabs = nullptr;        // [2][cap][21] resize tables of the large-window keypoints
+    struct AreaTab* d_area_tabs = nullptr;       // [kMaxWin + 1][21] INTER_AREA resize tables of every descriptor window size (surf_build_area_tables)
+    int* d_area_iscale = nullptr;                // [kMaxWin + 1] integer scale of the sizes resizeAreaFast_ handles, else 0
     uint8_t* d_big_patch = nullptr;              // [2][cap][448] 21x21 patches of the large-window keypoints
     int* d_rank = nullptr;                       // [2][cap] sort ranks (zero between frames)
     DetectSet det[2];                            // current left/right
@@ -209,6 +210,7 @@ struct StageTimer {
 // surf.hip
 uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int stride, int mem);
 uvo_status surf_integral(Ctx* c, int nimg);
+uvo_status surf_build_area_tables(Ctx* c);
 uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features = -1);   // integral -> ... -> sorted kps + descriptors in c->det[];
                                                                         // gate_min_features >= 0: also evaluate VO:556 into d_counts[CN_NQA]
 uvo_status surf_hessian_layer_debug(Ctx* c, int octave, int layer, float* det, float* trace);
