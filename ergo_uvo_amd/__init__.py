@@ -9,6 +9,7 @@ may also be torch CUDA(ROCm) tensors, in which case they are used in place (no h
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 
 import numpy as np
@@ -113,6 +114,9 @@ class Context:
         if st != 0:
             raise UvoError(st, "uvo_ctx_create failed (no usable HIP device?)" if st == 5 else "uvo_ctx_create failed")
         self._h = h
+        self._inflight = collections.deque()       # tensors handed to submit: kept alive until the matching collect
+        self._producer = None
+        self.set_producer_stream("torch")           # device tensors are ordered after the torch stream that is current at each call
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, st):
@@ -134,6 +138,26 @@ class Context:
     def stream(self) -> int:
         return self._lib.uvo_ctx_stream(self._h)
 
+    @property
+    def warning(self) -> str:
+        """Advice about the process environment noticed by the library (e.g. GPU_MAX_HW_QUEUES too small for the pipeline depth)."""
+        return (self._lib.uvo_ctx_warning(self._h) or b"").decode()
+
+    def set_producer_stream(self, stream):
+        """Declare the stream that produces device inputs: a raw hipStream_t (int, 0 = the default stream), a torch.cuda.Stream,
+        "torch" for torch's current stream at each call, or None to switch the ordering off (inputs must then be complete
+        before each call).  Tensors handed to stereo_submit / mono_submit are kept alive until the matching collect."""
+        self._producer = stream
+        if stream is None:
+            self._check(self._lib.uvo_ctx_set_producer_stream(self._h, None, 0))
+        elif stream != "torch":
+            self._check(self._lib.uvo_ctx_set_producer_stream(self._h, C.c_void_p(int(getattr(stream, "cuda_stream", stream)) or None), 1))
+
+    def _order_after_producer(self, *arrays):
+        if self._producer == "torch" and any(_is_device(a) for a in arrays):
+            import torch
+            self._check(self._lib.uvo_ctx_set_producer_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream or None), 1))
+
     def set_params(self, params: Params):
         self.params = params
         self._check(self._lib.uvo_ctx_set_params(self._h, C.byref(params)))
@@ -146,6 +170,7 @@ class Context:
         n = C.c_int(0)
         kps = np.zeros(self.max_kpts, KP_DTYPE)
         desc = np.zeros((self.max_kpts, 64), np.float32)
+        self._order_after_producer(img)
         self._check(self._lib.uvo_surf_detect(self._h, p, w, h, w, mem, _p(kps), _p(desc), self.max_kpts, C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
@@ -253,6 +278,7 @@ class Context:
         if ml != mr:
             raise ValueError("left and right must live in the same memory space")
         r = StereoResult()
+        self._order_after_producer(left, right)
         self._check(self._lib.uvo_stereo_step(self._h, pl, pr, w, h, w, ml, C.c_double(dt), C.byref(r)))
         return r
 
@@ -292,12 +318,18 @@ class Context:
         pr, mr, kr = _ptr_mem(right, np.uint8)
         if ml != mr:
             raise ValueError("left and right must live in the same memory space")
+        self._order_after_producer(left, right)
         self._check(self._lib.uvo_stereo_submit(self._h, pl, pr, w, h, w, ml))
+        self._inflight.append((kl, kr))             # read asynchronously: alive until the pair is collected
 
     def stereo_collect(self, dt: float = 0.05) -> StereoResult:
         """Finish the oldest submitted pair (PnP-RANSAC + pose); same result as stereo_step."""
         r = StereoResult()
-        self._check(self._lib.uvo_stereo_collect(self._h, C.c_double(dt), C.byref(r)))
+        try:
+            self._check(self._lib.uvo_stereo_collect(self._h, C.c_double(dt), C.byref(r)))
+        finally:
+            if self._inflight:
+                self._inflight.popleft()
         return r
 
     def stereo_get(self, what: str):
@@ -377,6 +409,7 @@ class Context:
         h, w = img.shape[-2], img.shape[-1]
         p, mem, keep = _ptr_mem(img, np.uint8)
         r = MonoResult()
+        self._order_after_producer(img)
         self._check(self._lib.uvo_mono_step(self._h, p, w, h, w, mem, C.c_double(range_), C.c_double(dt), C.byref(r)))
         return r
 
@@ -384,11 +417,17 @@ class Context:
         """Pipelined mono frame (uvo_mono_submit): at most `stereo_set_depth` frames in flight, collect in order."""
         h, w = img.shape[-2], img.shape[-1]
         p, mem, keep = _ptr_mem(img, np.uint8)
+        self._order_after_producer(img)
         self._check(self._lib.uvo_mono_submit(self._h, p, w, h, w, mem, C.c_double(range_)))
+        self._inflight.append((keep,))
 
     def mono_collect(self, dt: float = 0.05) -> MonoResult:
         r = MonoResult()
-        self._check(self._lib.uvo_mono_collect(self._h, C.c_double(dt), C.byref(r)))
+        try:
+            self._check(self._lib.uvo_mono_collect(self._h, C.c_double(dt), C.byref(r)))
+        finally:
+            if self._inflight:
+                self._inflight.popleft()
         return r
 
     def mono_reset(self):

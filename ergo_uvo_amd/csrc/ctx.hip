@@ -16,6 +16,12 @@ using namespace uvo;
 
 struct uvo_ctx : public uvo::Ctx {};
 
+// Every pipeline lane owns two HIP streams; with ROCm's default of four hardware queues the lanes share queues and one lane's
+// detection waits behind another lane's PnP kernels (2010 pairs/s instead of 2830 at depth 6).  The
+// variable is read when the HIP runtime initialises, so it is set when this library is loaded -- before main() when the node
+// links it -- unless the process already chose a value.
+__attribute__((constructor)) static void uvo_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 
 extern "C" void uvo_params_default_stereo(uvo_params* p)
 {   // uvo/config/stereo_VO_parameters.yaml:20-47 (keys absent from that file stay zero, as the globals do)
@@ -57,11 +63,20 @@ static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok);
 static void destroy_one(uvo_ctx* c);
 
 // one set of buffers, streams and a stage-B worker thread: the caller's context, or a further pipeline lane of it
+// parameters the implementation cannot honour are refused, never silently replaced (the reference passes them to OpenCV)
+static const char* unsupported_params(const uvo_params* p)
+{
+    if (p->ITERATIONS_COUNT > 0 && p->PNP_METHOD_FLAG != 1)
+        return "PNP_METHOD_FLAG: only 1 (cv::SOLVEPNP_EPNP, the value shipped in stereo_VO_parameters.yaml) is implemented";
+    if (p->USE_EXTRINSIC_GUESS != 0) return "USE_EXTRINSIC_GUESS: only false is implemented (EPnP ignores the guess)";
+    return nullptr;
+}
+
 static uvo_status create_one(const uvo_params* p, int device, int max_w, int max_h, int max_kpts, uvo_ctx** out)
 {
     if (!out) return UVO_INVALID_ARG;
     *out = nullptr;
-    if (!p || max_w < 16 || max_h < 16 || max_kpts < 16) return UVO_INVALID_ARG;
+    if (!p || max_w < 16 || max_h < 16 || max_kpts < 16 || unsupported_params(p)) return UVO_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return UVO_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return UVO_HIP_ERROR;
@@ -100,6 +115,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
         A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsA[i]), sizeof(int) * CN_TOTAL));
     }
     A(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
+    A(hipEventCreateWithFlags(&c->evProducer, hipEventDisableTiming));
     A(hipEventCreateWithFlags(&c->evDet, hipEventDisableTiming)); A(hipEventCreateWithFlags(&c->evPrevRead, hipEventDisableTiming));
     A(hipStreamCreateWithFlags(&c->pnp_stream, hipStreamNonBlocking));
     A(dalloc(&c->d_countsB, (size_t)4)); A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsB), sizeof(int) * 4));
@@ -170,6 +186,14 @@ static uvo_status set_depth(uvo_ctx* c, int depth)
         c->lanes.push_back(l);
     }
     // the previous pair's "after stereo match" set may live in a lane that no longer exists: restart the sequence
+    c->warning.clear();
+    {
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        const int nq = q ? atoi(q) : 4;
+        if (depth > 2 && nq < 2 * depth)
+            c->warning = "GPU_MAX_HW_QUEUES = " + std::to_string(nq) + " with " + std::to_string(depth) + " pipeline lanes (two HIP streams each): lanes share "
+                         "hardware queues and the pipeline runs well below its rate; set GPU_MAX_HW_QUEUES >= " + std::to_string(2 * depth) + " before the HIP runtime starts";
+    }
     if (c->prev_lane >= depth || c->next_lane >= depth) { c->vo_initialized = false; c->init_matches.clear(); c->prev_lane = 0; c->next_lane = 0; c->prev_sync = true; }
     return UVO_OK;
 }
@@ -236,6 +260,7 @@ static void destroy_one(uvo_ctx* c)
     for (int i = 0; i < 2; i++) { (void)hipHostFree(c->h_countsA[i]); if (c->evA[i]) (void)hipEventDestroy(c->evA[i]); }
     if (c->pnp_stream) (void)hipStreamDestroy(c->pnp_stream);
     if (c->evAS) (void)hipEventDestroy(c->evAS);
+    if (c->evProducer) (void)hipEventDestroy(c->evProducer);
     for (auto& r : c->trace) for (int k = 0; k < 6; k++) if (r.ev[k]) (void)hipEventDestroy(r.ev[k]);
     if (c->evDet) (void)hipEventDestroy(c->evDet);
     if (c->evPrevRead) (void)hipEventDestroy(c->evPrevRead);
@@ -251,8 +276,32 @@ extern "C" uvo_status uvo_ctx_set_params(uvo_ctx* c, const uvo_params* p)
 {
     if (!c || !p) return UVO_INVALID_ARG;
     if (c->n_pending != 0) { c->err = "parameters cannot change while pairs are in flight"; return UVO_INVALID_ARG; }
+    if (const char* why = unsupported_params(p)) { c->err = why; return UVO_INVALID_ARG; }
     for (Ctx* l : c->lanes) l->p = *p;
     return UVO_OK;
+}
+extern "C" uvo_status uvo_ctx_set_producer_stream(uvo_ctx* c, void* hip_stream, int enabled)
+{
+    if (!c) return UVO_INVALID_ARG;
+    c->producer_stream = static_cast<hipStream_t>(hip_stream); c->has_producer = enabled != 0;
+    return UVO_OK;
+}
+extern "C" const char* uvo_ctx_warning(const uvo_ctx* c) { return c ? c->warning.c_str() : ""; }
+
+// UVO_MEM_DEVICE inputs: order lane L's next reads after the work queued so far on the declared producer stream
+static uvo_status wait_for_producer(uvo_ctx* m, Ctx* L, int mem)
+{
+    if (mem != UVO_MEM_DEVICE || !m->has_producer) return UVO_OK;
+    UVO_HIP_TRY(m, hipEventRecord(L->evProducer, m->producer_stream));
+    UVO_HIP_TRY(m, hipStreamWaitEvent(L->stream, L->evProducer, 0));
+    return UVO_OK;
+}
+// the standalone operators work on lane 0's buffers and stream: not while pipelined pairs or frames are in flight
+static uvo_status need_idle(uvo_ctx* c, const char* who)
+{
+    if (c->n_pending == 0) return UVO_OK;
+    c->err = std::string(who) + ": collect the pairs / frames in flight first (the operator uses lane 0's buffers)";
+    return UVO_INVALID_ARG;
 }
 
 static uvo_status fail(uvo_ctx* c, uvo_status s, const char* msg) { c->err = msg; return s; }
@@ -278,6 +327,8 @@ extern "C" uvo_status uvo_surf_detect(uvo_ctx* c, const uint8_t* gray, int w, in
 {
     if (!c || !n) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_surf_detect"));
+    UVO_TRY(wait_for_producer(c, c, mem));
     UVO_TRY(surf_upload(c, 0, gray, w, h, stride, mem));
     UVO_TRY(surf_detect(c, 1));
     UVO_TRY(read_counts(c));
@@ -295,6 +346,8 @@ extern "C" uvo_status uvo_integral(uvo_ctx* c, const uint8_t* gray, int w, int h
 {
     if (!c || !sum) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_integral"));
+    UVO_TRY(wait_for_producer(c, c, mem));
     UVO_TRY(surf_upload(c, 0, gray, w, h, stride, mem));
     UVO_TRY(surf_integral(c, 1));
     UVO_HIP_TRY(c, hipMemcpyAsync(sum, c->d_sum[0], sizeof(int32_t) * (size_t)(w + 1) * (h + 1), hipMemcpyDeviceToHost, c->stream));
@@ -323,8 +376,10 @@ extern "C" uvo_status uvo_match_knn2(uvo_ctx* c, const float* d1, int n1, const 
 {
     if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !idx || !dist) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_match_knn2"));
     if (n1 == 0) return UVO_OK;
     if (n2 == 0) { for (int i = 0; i < 2 * n1; i++) { idx[i] = -1; dist[i] = FLT_MAX; } return UVO_OK; }
+    UVO_TRY(wait_for_producer(c, c, mem));
     const float *q, *t;
     UVO_TRY(stage_desc(c, 0, d1, n1, mem, &q));
     UVO_TRY(stage_desc(c, 1, d2, n2, mem, &t));
@@ -340,7 +395,9 @@ extern "C" uvo_status uvo_match_knn2_ratio(uvo_ctx* c, const float* d1, int n1, 
 {
     if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !out || !m || *m < 0) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_match_knn2_ratio"));
     if (n1 == 0 || n2 == 0) return UVO_OK;          // knnMatch on an empty query/train set yields no matches
+    UVO_TRY(wait_for_producer(c, c, mem));
     const float *q, *t;
     UVO_TRY(stage_desc(c, 0, d1, n1, mem, &q));
     UVO_TRY(stage_desc(c, 1, d2, n2, mem, &t));
@@ -361,6 +418,7 @@ extern "C" uvo_status uvo_triangulate_points(uvo_ctx* c, const double* P1, const
 {
     if (!c || !P1 || !P2 || n < 0 || (n && (!x1 || !x2 || !out4xn))) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_triangulate_points"));
     if (n == 0) return UVO_OK;
     if (n > c->cap) return fail(c, UVO_CAPACITY, "point count exceeds the context's max_kpts");
     UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x1, x1, sizeof(uvo_point2f) * n, hipMemcpyHostToDevice, c->stream));
@@ -381,6 +439,7 @@ extern "C" uvo_status uvo_extract_3d_points(uvo_ctx* c, const uvo_point2f* k1, c
     if (!c || n < 0 || !g || !R1 || !t1 || !R2 || !t2 || !K1 || !K2 || (n && (!k1 || !k2 || !points4d || !pts || !idx))) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     *g = 0;
+    UVO_TRY(need_idle(c, "uvo_extract_3d_points"));
     if (n == 0) return UVO_OK;
     if (n > c->cap) return fail(c, UVO_CAPACITY, "point count exceeds the context's max_kpts");
     std::vector<float4> tmp(n);
@@ -406,6 +465,7 @@ extern "C" uvo_status uvo_reproject_errors(uvo_ctx* c, const double* world, int 
 {
     if (!c || n < 0 || !R || !t || !K || (n && (!world || !img || !err))) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_reproject_errors"));
     if (n == 0) return UVO_OK;
     if (n > c->cap) return fail(c, UVO_CAPACITY, "point count exceeds the context's max_kpts");
     return pose_reproject_errors(c, world, n, R, t, K, img, err);
@@ -417,7 +477,7 @@ extern "C" uvo_status uvo_solve_pnp_ransac(uvo_ctx* c, const double* obj, const 
 {
     if (!c || !obj || !img || !K || !rvec || !tvec || !n_inliers || !ok || n < 0) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
-    if (c->n_pending != 0) return fail(c, UVO_INVALID_ARG, "uvo_solve_pnp_ransac: collect the pairs in flight first (the PnP buffers are in use)");
+    UVO_TRY(need_idle(c, "uvo_solve_pnp_ransac"));
     if (n > c->cap) return fail(c, UVO_CAPACITY, "point count exceeds the context's max_kpts");
     std::vector<float> of((size_t)3 * n);
     for (int i = 0; i < 3 * n; i++) of[i] = (float)obj[i];                     // opoints0.convertTo(opoints, CV_32F)
@@ -587,6 +647,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
         c->pending = Ctx::Pending();
         c->pending.used = true;
         memset(&c->pending.res, 0, sizeof(c->pending.res));
+        UVO_TRY(wait_for_producer(c, c, mem));
         UVO_TRY(surf_upload(c, 0, left, w, h, stride, mem));
         UVO_TRY(surf_upload(c, 1, right, w, h, stride, mem));
         UVO_TRY(surf_detect(c, 2));
@@ -610,6 +671,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
         tr = &L->trace[L->trace_cur]; tr->pair = c->n_submitted; tr->b_used = false;
         UVO_HIP_TRY(c, hipEventRecord(tr->ev[0], L->stream));
     }
+    UVO_TRY(wait_for_producer(c, L, mem));
     LANE_TRY(surf_upload(L, 0, left, w, h, stride, mem));
     LANE_TRY(surf_upload(L, 1, right, w, h, stride, mem));
     // Stage A is a run of chip-filling detection kernels followed by thin ones.  Two stage As side by side fill each other's
@@ -663,7 +725,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     c->inflight[c->n_pending++] = li; c->n_submitted++;
     {   // hand stage B to the lane's worker
         std::lock_guard<std::mutex> lk(L->mu);
-        L->job.state = 1;
+        L->job.kind = 0; L->job.state = 1;
     }
     L->cv.notify_all();
     if (uvo::g_bdbg) { uvo::g_bstat[6] += uvo::now_us() - t_sub; uvo::g_bstat[7] += 1; }
@@ -731,6 +793,8 @@ extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_resul
 {
     if (!c || !out) return UVO_INVALID_ARG;
     if (c->n_pending <= 0) return fail(c, UVO_INVALID_ARG, "uvo_stereo_collect: nothing submitted");
+    if (c->inflight[0] < 0 || (!c->lanes[c->inflight[0]]->pending.init_done && c->lanes[c->inflight[0]]->job.kind != 0))
+        return fail(c, UVO_INVALID_ARG, "uvo_stereo_collect: the oldest entry in flight is a mono frame (uvo_mono_collect)");
     (void)hipSetDevice(c->device);
     const uvo_params& p = c->p;
     const int li = c->inflight[0];
@@ -1026,6 +1090,7 @@ extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h
     const uvo_params& p = c->p;
     memset(out, 0, sizeof(*out));
     c->mono_matches.clear(); c->mono_mask.clear(); c->mono_good_pts.clear();
+    UVO_TRY(wait_for_producer(c, c, mem));
     UVO_TRY(surf_upload(c, 0, img, w, h, stride, mem));
     UVO_TRY(surf_detect(c, 1));                                                            // VO:238 / VO:274
     UVO_TRY(read_counts(c));
@@ -1167,6 +1232,7 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
     hipStream_t st = L->stream;
     L->pending = Ctx::Pending(); L->pending.used = true;
     if (L->prev_read_pending) { UVO_HIP_TRY(c, hipStreamWaitEvent(st, L->evPrevRead, 0)); L->prev_read_pending = false; }   // the frame after this lane's last one has read its buffers
+    UVO_TRY(wait_for_producer(c, L, mem));
     LANE_TRY(surf_upload(L, 0, img, w, h, stride, mem));
     if (c->a_overlap > 0 && depth > c->a_overlap) {                                        // as uvo_stereo_submit: at most a_overlap stage As side by side
         Ctx* H = c->lanes[(li + depth - c->a_overlap) % depth];
@@ -1283,6 +1349,8 @@ extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* o
 {
     if (!c || !out) return UVO_INVALID_ARG;
     if (c->n_pending <= 0) return fail(c, UVO_INVALID_ARG, "uvo_mono_collect: nothing submitted");
+    if (c->inflight[0] >= 0 && (c->lanes[c->inflight[0]]->pending.init_done || c->lanes[c->inflight[0]]->job.kind != 1))
+        return fail(c, UVO_INVALID_ARG, "uvo_mono_collect: the oldest entry in flight is a stereo pair (uvo_stereo_collect)");
     (void)hipSetDevice(c->device);
     const int li = c->inflight[0];
     for (int i = 1; i < c->n_pending; i++) c->inflight[i - 1] = c->inflight[i];

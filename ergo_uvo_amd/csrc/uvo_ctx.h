@@ -59,7 +59,9 @@ struct Ctx {
     uvo_params p;
     int device = 0, max_w = 0, max_h = 0, cap = 0;
     hipStream_t stream = nullptr;
-    std::string err;
+    std::string err, warning;
+    hipStream_t producer_stream = nullptr; bool has_producer = false;   // master: uvo_ctx_set_producer_stream
+    hipEvent_t evProducer = nullptr;             // this lane's marker on the producer stream
 
     // ---- SURF ----
     uint8_t* d_img[2] = {nullptr, nullptr};

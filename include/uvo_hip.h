@@ -35,8 +35,11 @@ typedef enum {
     UVO_NO_DEVICE = 5
 } uvo_status;
 
-/* UVO_MEM_DEVICE buffers are read/written on the context's own (non-blocking) streams: the caller makes sure the
- * data is complete before the call (e.g. synchronises the stream that produced it). */
+/* UVO_MEM_DEVICE buffers are read/written on the context's own (non-blocking) streams.  Ordering: either the data is
+ * complete before the call (the caller synchronised the stream that produced it), or the producing stream is declared with
+ * uvo_ctx_set_producer_stream and the context orders its reads after the work queued on that stream at call time.
+ * Lifetime: a buffer given to a synchronous call may be reused when the call returns; a buffer given to uvo_stereo_submit /
+ * uvo_mono_submit is read asynchronously and must stay valid and unmodified until the matching collect returns. */
 enum { UVO_MEM_HOST = 0, UVO_MEM_DEVICE = 1 };
 
 /* cv::KeyPoint (28 B), cv::DMatch (16 B), cv::Point2f -- same field order and size */
@@ -71,6 +74,12 @@ void        uvo_ctx_destroy(uvo_ctx* c);
 const char* uvo_last_error(const uvo_ctx* c);           /* message of the last non-OK status */
 void*       uvo_ctx_stream(uvo_ctx* c);                 /* the context's hipStream_t */
 uvo_status  uvo_ctx_set_params(uvo_ctx* c, const uvo_params* p);
+/* The hipStream_t on which the caller produces its UVO_MEM_DEVICE inputs (NULL = the default stream): while `enabled`,
+ * every image upload first waits for the work queued on that stream so far.  May be changed between any two calls. */
+uvo_status  uvo_ctx_set_producer_stream(uvo_ctx* c, void* hip_stream, int enabled);
+/* Non-fatal advice about the process environment noticed at context creation ("" when there is none), e.g. a pipeline
+ * deeper than two lanes with GPU_MAX_HW_QUEUES left at the ROCm default of 4 (lanes then share hardware queues). */
+const char* uvo_ctx_warning(const uvo_ctx* c);
 
 /* ---- detect_features, SURF branch (VO_utility.h:100 -> VO_utility.cpp:114-119) ----
  * gray: 8-bit single channel, `stride` bytes per row.  kps/desc (n x 64 f32) are host buffers of
@@ -145,7 +154,8 @@ uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uint8_t* right
 uvo_status uvo_stereo_set_depth(uvo_ctx* c, int depth);
 uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, int mem);
 uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_result* out);
-/* last step's intermediates for parity tests (only meaningful after a non-pipelined uvo_stereo_step): "kps_left", "kps_right", "desc_left", "desc_right",
+/* intermediates of the pair returned by the last uvo_stereo_step / uvo_stereo_collect, read from its lane (valid until the
+ * next uvo_stereo_submit reuses that lane, i.e. call it right after the collect): "kps_left", "kps_right", "desc_left", "desc_right",
  * "matches_stereo", "matches_tri", "points4d", "good_pts", "good_idx", "inliers".
  * Returns the element count, or -(count) if cap_bytes is too small. */
 int        uvo_stereo_get(uvo_ctx* c, const char* what, void* out, int cap_bytes);

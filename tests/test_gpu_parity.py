@@ -522,3 +522,71 @@ def test_mono_pipelined_submit_collect_equals_step(mono_small, depth):
             assert b.mono_step(seq[1], 4.0, 0.2).initialized == 0
         finally:
             a.close(); b.close()
+
+
+def test_device_inputs_are_ordered_after_the_producing_torch_stream(scene_small):
+    """A frame still being written on a torch stream when it is handed over: the uploads wait for that stream (uvo_ctx_set_producer_stream),
+    so the result is the one of the finished frame; submitted tensors stay alive until the collect even when the caller drops them."""
+    import torch
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=1500), 0, 640, 360, 8192)
+    try:
+        L, R = scene_small[0]
+        want_k, want_d = c.detect_features(L)
+        side = torch.cuda.Stream()
+        src = torch.from_numpy(L).cuda()
+        big = torch.randn(4096, 4096, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                big = big @ big * 1e-4                     # keeps the stream busy for a while
+            frame = torch.zeros_like(src)
+            frame.copy_(src)                               # the frame appears only after the matmuls
+            got_k, got_d = c.detect_features(frame)         # "torch" mode: ordered after `side`, the current stream here
+        assert np.array_equal(got_k, want_k) and np.array_equal(got_d.view(np.uint32), want_d.view(np.uint32))
+        # lifetime: the tensors of a submitted pair are dropped by the caller before the pair is collected
+        c.stereo_set_depth(3)
+        c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        want = [c.stereo_step(*p, 0.05) for p in scene_small]
+        c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        c.stereo_step(*scene_small[0], 0.05)
+        for k in (1, 2):
+            a, b = torch.from_numpy(scene_small[k][0]).cuda(), torch.from_numpy(scene_small[k][1]).cuda()
+            c.stereo_submit(a, b)
+            del a, b
+            torch.cuda.empty_cache()
+        for k in (1, 2):
+            r = c.stereo_collect(0.05)
+            assert (r.valid, r.n_left, r.n_inliers, tuple(r.tvec)) == (want[k].valid, want[k].n_left, want[k].n_inliers, tuple(want[k].tvec))
+    finally:
+        c.close()
+
+
+def test_misuse_is_refused_loudly(scene_small):
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    with pytest.raises(uvo.UvoError):                        # solvePnPRansac flags other than EPNP are not silently replaced
+        uvo.Context(uvo.Params.stereo(PNP_METHOD_FLAG=2), 0, 640, 360, 1024)
+    with pytest.raises(uvo.UvoError):
+        uvo.Context(uvo.Params.stereo(USE_EXTRINSIC_GUESS=1), 0, 640, 360, 1024)
+    c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=1500), 0, 640, 360, 8192)
+    try:
+        assert c.warning == ""                               # two lanes by default: the default hardware queues are enough
+        with pytest.raises(uvo.UvoError):
+            c.set_params(uvo.Params.stereo(PNP_METHOD_FLAG=0))
+        c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        c.stereo_step(*scene_small[0], 0.05)
+        c.stereo_submit(*scene_small[1])
+        d = np.zeros((8, 64), np.float32)
+        for call in (lambda: c.detect_features(scene_small[0][0]), lambda: c.knn_match(d, d), lambda: c.integral(scene_small[0][0]),
+                     lambda: c.triangulatePoints(np.eye(3, 4), np.eye(3, 4), np.zeros((2, 2)), np.zeros((2, 2))),
+                     lambda: c.mono_collect(0.05)):
+            with pytest.raises(uvo.UvoError):
+                call()                                       # lane 0's buffers belong to the pair in flight; a stereo pair is not a mono frame
+        assert c.stereo_collect(0.05).valid == 1
+        c.detect_features(scene_small[0][0])
+    finally:
+        c.close()
