@@ -307,6 +307,30 @@ class Context:
         assert (ow.value, oh.value) == (desired_width, dh)
         return out
 
+    def decode_image(self, data: bytes, fmt: str = "bgr8; jpeg compressed bgr8", device_out=False):
+        """from_ros_to_cv_image (math_utility.cpp:154-173): the payload of a sensor_msgs/CompressedImage -> H x W x 3 BGR (or H x W grey);
+        a format containing "bayer" is demosaiced with COLOR_BayerBGGR2BGR.  Returns a numpy array, or a CUDA tensor when device_out."""
+        buf = np.frombuffer(data, np.uint8)
+        w, h, ch = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self._lib.uvo_decode_image(self._h, _p(buf), len(buf), fmt.encode(), None, 0, 0, C.byref(w), C.byref(h), C.byref(ch)))
+        shape = (h.value, w.value, ch.value) if ch.value > 1 else (h.value, w.value)
+        if device_out:
+            import torch
+            out = torch.empty(shape, dtype=torch.uint8, device="cuda")
+            dst, omem, nb = C.c_void_p(out.data_ptr()), 1, out.numel()
+        else:
+            out = np.empty(shape, np.uint8)
+            dst, omem, nb = _p(out), 0, out.nbytes
+        self._check(self._lib.uvo_decode_image(self._h, _p(buf), len(buf), fmt.encode(), dst, nb, omem, C.byref(w), C.byref(h), C.byref(ch)))
+        return out
+
+    def bayer_bggr2bgr(self, bayer):
+        h, w = bayer.shape
+        p, mem, keep = _ptr_mem(bayer, np.uint8)
+        out = np.empty((h, w, 3), np.uint8)
+        self._check(self._lib.uvo_bayer_bggr2bgr(self._h, p, w, h, w, mem, _p(out), 0))
+        return out
+
     def stereo_set_depth(self, depth):
         """Number of consecutive pairs that may be in flight between stereo_submit and stereo_collect (default 2)."""
         self._check(self._lib.uvo_stereo_set_depth(self._h, int(depth)))

@@ -21,7 +21,7 @@ EXPORTS = [
     "uvo_stereo_set_depth", "uvo_stereo_submit", "uvo_stereo_collect",
     "uvo_stereo_get", "uvo_find_essential_mat", "uvo_recover_pose", "uvo_find_homography", "uvo_decompose_homography_mat",
     "uvo_recover_pose_homography", "uvo_select_estimation_method", "uvo_estimate_relative_pose", "uvo_mono_set_camera",
-    "uvo_mono_reset", "uvo_mono_step", "uvo_mono_submit", "uvo_mono_collect", "uvo_mono_get", "uvo_get_image", "uvo_resize_camera_matrix", "uvo_timing_enable", "uvo_timing_count", "uvo_timing_name", "uvo_timing_get", "uvo_timing_reset",
+    "uvo_mono_reset", "uvo_mono_step", "uvo_mono_submit", "uvo_mono_collect", "uvo_mono_get", "uvo_get_image", "uvo_decode_image", "uvo_bayer_bggr2bgr", "uvo_resize_camera_matrix", "uvo_timing_enable", "uvo_timing_count", "uvo_timing_name", "uvo_timing_get", "uvo_timing_reset",
 ]
 
 
@@ -43,6 +43,12 @@ def lib() -> C.CDLL:
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             build()
+        # PyTorch-ROCm bundles its own HIP runtime; if /opt/rocm's is initialised first (by this library), torch later reports
+        # "No HIP GPUs are available".  Loading torch first makes both use the same runtime, in either order of use.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.uvo_last_error.restype = C.c_char_p
         _lib.uvo_last_error.argtypes = [C.c_void_p]
@@ -51,6 +57,7 @@ def lib() -> C.CDLL:
         _lib.uvo_ctx_warning.restype = C.c_char_p
         _lib.uvo_ctx_warning.argtypes = [C.c_void_p]
         _lib.uvo_ctx_set_producer_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _lib.uvo_decode_image.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.uvo_ctx_destroy.argtypes = [C.c_void_p]
         _lib.uvo_ctx_destroy.restype = None
         _lib.uvo_timing_name.restype = C.c_char_p

@@ -250,6 +250,7 @@ static void destroy_one(uvo_ctx* c)
     if (c->pnp_stream) (void)hipStreamSynchronize(c->pnp_stream);
     mono_ws_free(c);
     pre_ws_free(c);
+    codec_ws_free(c);
     void* ptrs[] = { c->d_surv, c->d_octpat, c->d_colpart, c->d_DW, c->d_rank, c->d_big_par, c->d_big_patch, c->d_area_tabs, c->d_area_iscale, c->d_mpart, c->d_mscratch, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
                      c->d_flag, c->d_tmp_idx, c->d_good_pts[0], c->d_good_pts[1], c->d_good_idx[0], c->d_good_idx[1], c->d_opts[0], c->d_opts[1],
                      c->d_ipts[0], c->d_ipts[1], c->d_counts, c->d_countsB, c->d_subsets, c->d_models,
@@ -951,6 +952,37 @@ extern "C" uvo_status uvo_get_image(uvo_ctx* c, const uint8_t* rgb, int w, int h
     UVO_TRY(pre_get_image(c, rgb, w, h, stride, mem, K, dist4, newK, desired_width, clahe, clip_limit, &d_res, out_w, out_h));
     const size_t n = (size_t)*out_w * *out_h;
     UVO_HIP_TRY(c, hipMemcpyAsync(out, d_res, n, out_mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return UVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------ compressed-image ingest
+extern "C" uvo_status uvo_decode_image(uvo_ctx* c, const uint8_t* data, size_t n, const char* format, uint8_t* out, size_t cap_bytes, int out_mem,
+                                       int* w, int* h, int* channels)
+{
+    if (!c || !data || !w || !h || !channels) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_decode_image"));
+    const std::string fmt = format ? format : "";
+    if (fmt.find("png") != std::string::npos) return fail(c, UVO_INVALID_ARG, "uvo_decode_image: PNG payloads are not supported (JPEG only)");
+    const uint8_t* d_res = nullptr;
+    UVO_TRY(codec_decode(c, data, n, fmt.find("bayer") != std::string::npos ? 1 : 0, &d_res, w, h, channels));
+    const size_t bytes = (size_t)*w * *h * *channels;
+    if (!out) return UVO_OK;                                  // size query
+    if (bytes > cap_bytes) return fail(c, UVO_CAPACITY, "uvo_decode_image: output capacity too small");
+    UVO_HIP_TRY(c, hipMemcpyAsync(out, d_res, bytes, out_mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return UVO_OK;
+}
+extern "C" uvo_status uvo_bayer_bggr2bgr(uvo_ctx* c, const uint8_t* bayer, int w, int h, int stride, int mem, uint8_t* out_bgr, int out_mem)
+{
+    if (!c || !bayer || !out_bgr || w <= 0 || h <= 0 || stride < w) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_bayer_bggr2bgr"));
+    UVO_TRY(wait_for_producer(c, c, mem));
+    const uint8_t* d_res = nullptr;
+    UVO_TRY(codec_bayer(c, bayer, w, h, stride, mem, &d_res));
+    UVO_HIP_TRY(c, hipMemcpyAsync(out_bgr, d_res, (size_t)w * h * 3, out_mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return UVO_OK;
 }

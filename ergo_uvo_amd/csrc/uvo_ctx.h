@@ -172,6 +172,7 @@ struct Ctx {
     // ---- mono stage (mono.hip) ----
     void* mono_ws = nullptr;                     // MonoWs*, allocated on first use
     void* pre_ws = nullptr;                      // PreWs* (get_image), allocated on first use
+    void* codec_ws = nullptr;                    // CodecWs* (uvo_decode_image), allocated on first use
     double mono_K[9]; bool mono_cam_set = false, mono_initialized = false, mono_pipelined = false;
     int mono_use_essential = 1;                  // the reference's global `use_essential` (VOH:89)
     double mono_R[9] = {1,0,0,0,1,0,0,0,1}, mono_t[3] = {0,0,0}, mono_SF = 1.0;
@@ -236,6 +237,10 @@ int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters);
 void pre_ws_free(Ctx* c);
 uvo_status pre_get_image(Ctx* c, const uint8_t* rgb, int w, int h, int stride, int mem, const double* K, const double* dist4, const double* newK,
                          int desired_width, int clahe_on, int clip_limit, const uint8_t** d_out, int* out_w, int* out_h);
+// codec.hip
+void codec_ws_free(Ctx* c);
+uvo_status codec_decode(Ctx* c, const uint8_t* data, size_t n, int bayer, const uint8_t** d_out, int* w, int* h, int* channels);
+uvo_status codec_bayer(Ctx* c, const uint8_t* bayer, int w, int h, int stride, int mem, const uint8_t** d_out);
 // mono.hip
 void mono_ws_free(Ctx* c);
 uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K, int method,

@@ -19,6 +19,7 @@
 #define UVO_HIP_H
 
 #include <stdint.h>
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -216,6 +217,18 @@ int        uvo_mono_get(uvo_ctx* c, const char* what, void* out, int cap_bytes);
 uvo_status uvo_get_image(uvo_ctx* c, const uint8_t* rgb, int w, int h, int stride, int mem, const double* K, const double* dist4,
                          const double* newK, int desired_width, int clahe, int clip_limit, uint8_t* out, int out_mem,
                          int* out_w, int* out_h);
+
+/* ---- compressed-image ingest: from_ros_to_cv_image (math_utility.h -> uvo_libraries/src/math_utility.cpp:154-173) =
+ * cv_bridge::toCvCopy(sensor_msgs/CompressedImage) -> cv::imdecode, then cv::cvtColor(COLOR_BayerBGGR2BGR) when the message's
+ * `format` contains "bayer".  data: the message payload (a baseline / sequential Huffman JPEG, 8 bit, 1 or 3 components,
+ * sampling factors <= 2; progressive, arithmetic-coded and PNG payloads are refused with UVO_INVALID_ARG).  The entropy
+ * decoding runs on the host, dequantisation + IDCT + chroma upsampling + colour conversion (+ demosaicing) on the device,
+ * byte-identical to libjpeg's defaults (JDCT_ISLOW, fancy upsampling).  out: h x w x channels u8 (BGR order for 3 channels) in host
+ * or device memory per out_mem; out = NULL only reports the size.  Feed the result to uvo_get_image. */
+uvo_status uvo_decode_image(uvo_ctx* c, const uint8_t* data, size_t n, const char* format, uint8_t* out, size_t cap_bytes, int out_mem,
+                            int* w, int* h, int* channels);
+/* cv::cvtColor(src, dst, COLOR_BayerBGGR2BGR) of an 8-bit mosaic (bilinear; borders copy their neighbour) */
+uvo_status uvo_bayer_bggr2bgr(uvo_ctx* c, const uint8_t* bayer, int w, int h, int stride, int mem, uint8_t* out_bgr, int out_mem);
 
 /* ---- resize_camera_matrix (VO_utility.h:112 -> VO_utility.cpp:658-675), once per run, host arithmetic only (no context):
  * K (3x3 row-major, in/out) is divided by ratio = original_width / desired_width with the skew K[0][1] kept and K[2][2] = 1;

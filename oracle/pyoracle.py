@@ -458,3 +458,26 @@ def resize_camera_matrix(original_width, original_height, desired_width, K, dist
     if rc != 0:
         raise ValueError("resize_camera_matrix: bad sizes")
     return Ks, newK, dh.value
+
+
+# ---------------------------------------------------------------- compressed-image ingest
+def jpeg_decode(data: bytes) -> np.ndarray:
+    """cv::imdecode(IMREAD_UNCHANGED) of a baseline JPEG: H x W x 3 BGR, or H x W grey."""
+    buf = np.frombuffer(data, np.uint8)
+    w, h, ch = C.c_int(0), C.c_int(0), C.c_int(0)
+    lib().orc_jpeg_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = lib().orc_jpeg_decode(_p(buf), len(buf), None, 0, C.byref(w), C.byref(h), C.byref(ch))
+    if rc != 0:
+        raise ValueError(f"jpeg_decode: error {rc}")
+    out = np.empty((h.value, w.value, ch.value), np.uint8)
+    rc = lib().orc_jpeg_decode(_p(buf), len(buf), _p(out), out.nbytes, C.byref(w), C.byref(h), C.byref(ch))
+    if rc != 0:
+        raise ValueError(f"jpeg_decode: error {rc}")
+    return out[..., 0] if ch.value == 1 else out
+
+
+def bayer_bggr2bgr(bayer: np.ndarray) -> np.ndarray:
+    bayer = _c(bayer, np.uint8); h, w = bayer.shape
+    out = np.empty((h, w, 3), np.uint8)
+    lib().orc_bayer_bggr2bgr(_p(bayer), w, h, w, _p(out))
+    return out

@@ -1,0 +1,312 @@
+"""The reference's parameter surface and node class without ROS.
+
+CPU: the YAML loader (include/uvo_libraries_hip/uvo_config.h) reads the keys get_VO_parameters / get_*_camera_parameters read
+(VO_utility.cpp:387-507) into the reference's globals, with roscpp's conversions.  The parameter VALUES below are the ones
+shipped in uvo/config/*.yaml, re-typed here as data -- the reference's files are not copied.
+GPU: the ROS-free visual_odometry_core runs the mono and stereo node loops (get_image -> detect -> match -> pose -> output)
+through the uvo_libraries surface; every published sample is compared with the CPU oracle's state machines."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM_DIR = os.path.join(ROOT, "ergo_uvo_amd", "shim")
+DRIVER = os.path.join(ROOT, "tests", "cpp", "build", "shim_vo_node")
+
+MONO_PARAMS = """
+node_freq: 20
+preprocessing:
+  desired_width: 640      # width of the resized images
+  clahe: true
+  clip_limit: 3
+vo_params:
+  distance: 10.0                   # an int global fed with a double
+  feature_detector: 'SURF'
+  lowe_ratio_test: 0.7
+  essential_outlier_method: 4      # LMEDS
+  essential_max_iters: 2000        # a double global fed with an int
+  essential_confidence: 0.99
+  essential_threshold: 0.1
+  homography_outlier_method: 4
+  homography_max_iters: 2000
+  homography_confidence: 0.99
+  homography_threshold: 0.1
+  homography_distance: 50.0
+  valid_point_fraction: 0.4
+  reprojection_threshold: 0.1
+  min_num_features: 20.0
+  min_num_inliers: 10.0
+  min_num_3Dpoints: 5.0
+visualization:
+  fps: 100
+  show_match: false
+surf_params:
+  min_hessian: 50
+  n_octaves: 4
+  n_octave_layers: 3
+  extended: false
+  upright: true
+"""
+
+STEREO_PARAMS = """
+node_freq: 20
+preprocessing:
+  desired_width: 640
+  clahe: true
+  clip_limit: 8
+vo_params:
+  feature_detector: 'SURF'
+  min_num_features: 5.0
+  min_num_3Dpoints: 5.0
+  min_num_inliers: 5.0
+  reprojection_threshold: 3.0
+  lowe_ratio_test: 0.8
+  iterations_count: 1000
+  reprojection_error: 1.0
+  confidence: 0.99
+  use_extrinsic_guess: false
+  pnp_method_flag: 1          # SOLVEPNP_EPNP
+visualization:
+  fps: 100
+  show_match: false
+surf_params:
+  min_hessian: 1500
+  n_octaves: 4
+  n_octave_layers: 3
+  extended: false
+  upright: true
+"""
+
+MONO_INTRINSICS = """
+downward_camera:
+  camera_intrinsic:
+    fx: 2305.660253962050
+    fy: 2303.950911497790
+    ccx: 1281.944364189583
+    ccy: 1028.352241411627
+  distortion_coefficient:
+    radial:
+      k1: 0.08
+      k2: 0.45
+    tangential:
+      p1: 0.0
+      p2: 0.0
+frontal_camera:
+  camera_intrinsic:
+    fx: 1.335036735254999e+03
+    fy: 1.332419247540885e+03
+    ccx: 0.644564474737301e+03
+    ccy: 0.357685235527149e+03
+  distortion_coefficient:
+    radial:
+      k1: 0.475667186716851
+      k2: 0.126480045385593
+    tangential:
+      p1: 0.0
+      p2: 0.0
+"""
+
+STEREO_INTRINSICS = """
+frontal_camera:
+  camera_intrinsic_left:
+    fx: 1.335036735254999e+03
+    fy: 1.332419247540885e+03
+    ccx: 0.644564474737301e+03
+    ccy: 0.357685235527149e+03
+  camera_intrinsic_right:
+    fx: 1.330461901943011e+03
+    fy: 1.328225165048530e+03
+    ccx: 0.684598875987595e+03
+    ccy: 0.382841174819059e+03
+  distortion_coefficient_left:
+    radial:
+      k1: 0.475667186716851
+      k2: 0.126480045385593
+    tangential:
+      p1: 0.0
+      p2: 0.0
+  distortion_coefficient_right:
+    radial:
+      k1: 0.493006394402676
+      k2: 0.037112494470407
+    tangential:
+      p1: 0.0
+      p2: 0.0
+  left_camera_rotation_matrix:
+    rows: 3
+    cols: 3
+    data: [1, 0, 0, 0, 1, 0, 0, 0, 1]
+  left_camera_translation_vector:
+    rows: 3
+    cols: 1
+    data: [0, 0, 0]
+  right_camera_rotation_matrix:
+    rows: 3
+    cols: 3
+    data: [1, 0, 0, 0, 1, 0, 0, 0, 1]
+  right_camera_translation_vector:
+    rows: 3
+    cols: 1
+    data: [-0.33, 0.0, 0.0]
+"""
+
+
+def _build():
+    from ergo_uvo_amd import _lib
+    _lib.build()
+    subprocess.check_call(["make", "-C", SHIM_DIR, "-s"])
+
+
+def _config(tmp_path, mode, cam, *texts):
+    _build()
+    files = []
+    for i, t in enumerate(texts):
+        p = tmp_path / f"cfg{i}.yaml"; p.write_text(t); files.append(str(p))
+    res = subprocess.run([DRIVER, "--config-only", mode, cam] + files, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    out = {}
+    for line in res.stdout.splitlines():
+        k, *v = line.split()
+        out[k] = v
+    return out
+
+
+def test_yaml_loader_reads_the_shipped_mono_values(tmp_path):
+    g = _config(tmp_path, "mono", "downward_camera", MONO_PARAMS, MONO_INTRINSICS)
+    want_i = dict(NODE_FREQ=20, DESIRED_WIDTH=640, CLAHE_CORRECTION=1, CLIP_LIMIT=3, DISTANCE=10, ESSENTIAL_OUTLIER_METHOD=4, HOMOGRAPHY_OUTLIER_METHOD=4,
+                  MIN_NUM_FEATURES=20, MIN_NUM_INLIERS=10, MIN_NUM_3DPOINTS=5, FPS=100, SHOW_MATCHES=0, SURF_MIN_HESSIAN=50, SURF_OCTAVES_NUMBER=4,
+                  SURF_OCTAVES_LAYERS=3, SURF_EXTENDED=0, SURF_UPRIGHT=1)
+    want_d = dict(LOWE_RATIO_THRESHOLD=0.7, ESSENTIAL_MAX_ITERS=2000.0, ESSENTIAL_CONFIDENCE=0.99, ESSENTIAL_THRESHOLD=0.1, HOMOGRAPHY_MAX_ITERS=2000.0,
+                  HOMOGRAPHY_CONFIDENCE=0.99, HOMOGRAPHY_THRESHOLD=0.1, HOMOGRAPHY_DISTANCE=50.0, VPF_THRESHOLD=0.4, REPROJECTION_TOLERANCE=0.1,
+                  fx=2305.660253962050, fy=2303.950911497790, ccx=1281.944364189583, ccy=1028.352241411627, k1=0.08, k2=0.45, p1=0.0, p2=0.0)
+    for k, v in want_i.items():
+        assert int(g[k][0]) == v, k
+    for k, v in want_d.items():
+        assert float(g[k][0]) == v, k
+    assert g["FEATURE_DETECTOR"] == ["SURF"]
+    # the library's built-in mono defaults are these same values
+    from ergo_uvo_amd import Params
+    p = Params.mono()
+    for k in ("DISTANCE", "ESSENTIAL_OUTLIER_METHOD", "HOMOGRAPHY_OUTLIER_METHOD", "MIN_NUM_FEATURES", "MIN_NUM_INLIERS", "MIN_NUM_3DPOINTS", "SURF_MIN_HESSIAN"):
+        assert getattr(p, k) == want_i[k], k
+    for k in ("LOWE_RATIO_THRESHOLD", "ESSENTIAL_THRESHOLD", "HOMOGRAPHY_DISTANCE", "VPF_THRESHOLD", "REPROJECTION_TOLERANCE"):
+        assert getattr(p, k) == want_d[k], k
+    g2 = _config(tmp_path, "mono", "frontal_camera", MONO_PARAMS, MONO_INTRINSICS)       # /camera_name selects the block
+    assert float(g2["fx"][0]) == 1.335036735254999e+03 and float(g2["k1"][0]) == 0.475667186716851
+
+
+def test_yaml_loader_reads_the_shipped_stereo_values(tmp_path):
+    g = _config(tmp_path, "stereo", "frontal_camera", STEREO_PARAMS, STEREO_INTRINSICS)
+    want_i = dict(CLIP_LIMIT=8, MIN_NUM_FEATURES=5, MIN_NUM_3DPOINTS=5, MIN_NUM_INLIERS=5, ITERATIONS_COUNT=1000, USE_EXTRINSIC_GUESS=0, PNP_METHOD_FLAG=1,
+                  SURF_MIN_HESSIAN=1500, SURF_UPRIGHT=1, SURF_EXTENDED=0)
+    want_d = dict(LOWE_RATIO_THRESHOLD=0.8, REPROJECTION_TOLERANCE=3.0, REPROJECTION_ERROR_THRESHOLD=1.0, CONFIDENCE=0.99,
+                  fx_left=1.335036735254999e+03, ccy_right=0.382841174819059e+03, k1_left=0.475667186716851, k2_right=0.037112494470407, p2_right=0.0)
+    for k, v in want_i.items():
+        assert int(g[k][0]) == v, k
+    for k, v in want_d.items():
+        assert float(g[k][0]) == v, k
+    assert [float(x) for x in g["R_right"]] == [1, 0, 0, 0, 1, 0, 0, 0, 1] and [float(x) for x in g["t_right"]] == [-0.33, 0.0, 0.0]
+    assert g["R_left_rows"] == ["3", "t_left_rows", "3"]
+    from ergo_uvo_amd import Params
+    p = Params.stereo()
+    assert (p.ITERATIONS_COUNT, p.PNP_METHOD_FLAG, p.SURF_MIN_HESSIAN, p.MIN_NUM_FEATURES) == (1000, 1, 1500, 5) and p.LOWE_RATIO_THRESHOLD == 0.8
+
+
+def test_getparam_conversions_follow_roscpp(tmp_path):
+    g = _config(tmp_path, "mono", "cam", "vo_params:\n  distance: 9.5\n  min_num_features: 20.49\n  lowe_ratio_test: 1\n  feature_detector: ORB\n"
+                                           "preprocessing:\n  clahe: 1      # an int is not a bool: the global keeps its value\n  clip_limit: 'x'\n")
+    assert int(g["DISTANCE"][0]) == 10 and int(g["MIN_NUM_FEATURES"][0]) == 20          # double -> int: rounded, .5 up
+    assert float(g["LOWE_RATIO_THRESHOLD"][0]) == 1.0 and g["FEATURE_DETECTOR"] == ["ORB"]
+    assert int(g["CLAHE_CORRECTION"][0]) == 1 and int(g["CLIP_LIMIT"][0]) == 8          # untouched defaults (type mismatch)
+
+
+# ------------------------------------------------------------------ the node loops on the GPU
+def _rgb(gray):
+    return np.repeat(gray[..., None], 3, axis=2)
+
+
+def _run_node(tmp_path, mode, cam, frames, params, intr):
+    _build()
+    inp, outp, pf, cf = tmp_path / "frames.bin", tmp_path / "out.bin", tmp_path / "params.yaml", tmp_path / "intr.yaml"
+    pf.write_text(params); cf.write_text(intr)
+    H, W = frames[0][2].shape[:2]
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<3i", W, H, len(frames)))
+        for stamp, rng, *imgs in frames:
+            f.write(struct.pack("<2d", stamp, rng))
+            for im in imgs:
+                f.write(np.ascontiguousarray(im).tobytes())
+    res = subprocess.run([DRIVER, mode, cam, str(inp), str(outp), str(pf), str(cf)], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    return np.fromfile(outp, np.dtype([("i", "<i4", 6), ("d", "<f8", 4)]))
+
+
+def _intr_yaml(K, cam="frontal_camera", stereo=None):
+    def block(name, K):
+        return f"  {name}:\n    fx: {float(K[0, 0])!r}\n    fy: {float(K[1, 1])!r}\n    ccx: {float(K[0, 2])!r}\n    ccy: {float(K[1, 2])!r}\n"
+    zero = "    radial:\n      k1: 0.0\n      k2: 0.0\n    tangential:\n      p1: 0.0\n      p2: 0.0\n"
+    if stereo is None:
+        return f"{cam}:\n" + block("camera_intrinsic", K) + "  distortion_coefficient:\n" + zero
+    KR, R, t = stereo
+    mat = lambda name, m, r, c: f"  {name}:\n    rows: {r}\n    cols: {c}\n    data: [{', '.join(repr(float(x)) for x in np.asarray(m).ravel())}]\n"
+    return (f"{cam}:\n" + block("camera_intrinsic_left", K) + block("camera_intrinsic_right", KR) + "  distortion_coefficient_left:\n" + zero +
+            "  distortion_coefficient_right:\n" + zero + mat("left_camera_rotation_matrix", np.eye(3), 3, 3) + mat("left_camera_translation_vector", np.zeros(3), 3, 1) +
+            mat("right_camera_rotation_matrix", R, 3, 3) + mat("right_camera_translation_vector", t, 3, 1))
+
+
+@pytest.mark.gpu
+def test_mono_node_loop_matches_oracle(oracle, tmp_path):
+    """C1 substitute through the node class: 640x480 colour frames, the shipped mono parameters (LMedS), get_image included."""
+    from ergo_uvo_amd import synth
+    W, H = 640, 480
+    scene = synth.Scene(synth.SEEDS["C1"], W)
+    rig = synth.stereo_rig(W)
+    ks = [0, 2, 4, 4.25, 4.5, 6, 4]
+    grays = [synth.mono_frame(scene, k, W, H) for k in ks]
+    R0, C0 = synth.camera_pose(0)
+    rng = scene.depth_at_center(C0, R0)
+    frames = [(1.0 + 0.2 * i, rng, _rgb(g)) for i, g in enumerate(grays)]
+    rec = _run_node(tmp_path, "mono", "frontal_camera", frames, MONO_PARAMS, _intr_yaml(rig.K_left))
+    # the oracle's side of the same node: resize_camera_matrix, get_image, then the mono state machine
+    Ks, newK, _ = oracle.resize_camera_matrix(W, H, 640, rig.K_left, np.zeros(4))
+    ovo = oracle.MonoVO(oracle.mono_params(), newK)
+    n_pub = 0
+    for i, g in enumerate(grays):
+        pre = oracle.get_image(_rgb(g), 640, Ks, np.zeros(4), newK, True, 3)
+        o = ovo.step(pre, rng, 0.2)
+        r = rec[i]
+        assert (r["i"][0], r["i"][2]) == (o.published, o.n_kps), (i, list(r["i"]))
+        if o.published:
+            n_pub += 1
+            assert (r["i"][1], r["i"][3], r["i"][4], r["i"][5]) == (o.valid, o.n_matches, o.n_inliers, o.n_good3d), (i, list(r["i"]))
+            v, ov = r["d"][:3], np.array(list(o.velocity))
+            assert np.linalg.norm(v - ov) <= 1e-4 * np.linalg.norm(ov), (i, v, ov)
+    assert n_pub == len(ks) - 1
+
+
+@pytest.mark.gpu
+def test_stereo_node_loop_matches_oracle(oracle, scene_small, tmp_path):
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    seq = [scene_small[k] for k in (0, 1, 2, 1, 0)]
+    frames = [(2.0 + 0.05 * i, 0.0, _rgb(L), _rgb(R)) for i, (L, R) in enumerate(seq)]
+    rec = _run_node(tmp_path, "stereo", "frontal_camera", frames, STEREO_PARAMS, _intr_yaml(rig.K_left, stereo=(rig.K_right, rig.R_right, rig.t_right)))
+    KsL, newKL, _ = oracle.resize_camera_matrix(640, 360, 640, rig.K_left, np.zeros(4))
+    KsR, newKR, _ = oracle.resize_camera_matrix(640, 360, 640, rig.K_right, np.zeros(4))
+    ovo = oracle.StereoVO(oracle.stereo_params(1500), newKL, newKR, rig.R_right, rig.t_right)
+    n_valid = 0
+    for i, (L, R) in enumerate(seq):
+        pl = oracle.get_image(_rgb(L), 640, KsL, np.zeros(4), newKL, True, 8)
+        pr = oracle.get_image(_rgb(R), 640, KsR, np.zeros(4), newKR, True, 8)
+        o = ovo.step(pl, pr, 0.05)
+        r = rec[i]
+        assert r["i"][0] == o.initialized and r["i"][2] == o.n_left, (i, list(r["i"]))
+        if o.initialized:
+            assert (r["i"][1], r["i"][3], r["i"][4], r["i"][5]) == (o.valid, o.n_tri_matches, o.n_inliers, o.n_good3d), (i, list(r["i"]))
+            v, ov = r["d"][:3], np.array(list(o.velocity))
+            assert np.linalg.norm(v - ov) <= 1e-4 * max(np.linalg.norm(ov), 1e-300), (i, v, ov)
+            n_valid += o.valid
+    assert n_valid == len(seq) - 1
