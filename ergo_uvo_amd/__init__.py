@@ -169,7 +169,7 @@ class Context:
         p, mem, keep = _ptr_mem(img, np.uint8)
         n = C.c_int(0)
         kps = np.zeros(self.max_kpts, KP_DTYPE)
-        desc = np.zeros((self.max_kpts, 64), np.float32)
+        desc = np.zeros((self.max_kpts, 128 if self.params.SURF_EXTENDED else 64), np.float32)
         self._order_after_producer(img)
         self._check(self._lib.uvo_surf_detect(self._h, p, w, h, w, mem, _p(kps), _p(desc), self.max_kpts, C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()

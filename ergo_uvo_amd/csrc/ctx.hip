@@ -98,7 +98,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
         if (e == hipSuccess) e = hipMemset(c->d_planes[i], 0, sizeof(int32_t) * 16 * c->plane_stride);       // row 0 / padding stay zero
         A(dalloc(&c->d_img[i], npx)); A(dalloc(&c->d_sum_base[i], nsum + 2 * kSumPad));
         if (e == hipSuccess) { e = hipMemset(c->d_sum_base[i], 0, sizeof(int32_t) * (nsum + 2 * kSumPad)); c->d_sum[i] = c->d_sum_base[i] + kSumPad; }
-        A(dalloc(&c->d_cand[i], cap)); A(dalloc(&c->det[i].kps, cap)); A(dalloc(&c->det[i].desc, cap * 64));
+        A(dalloc(&c->d_cand[i], cap)); A(dalloc(&c->det[i].kps, cap)); A(dalloc(&c->det[i].desc, cap * 128));      // 128: SURF_EXTENDED rows
         A(dalloc(&c->d_tmp_desc[i], cap * 64)); A(dalloc(&c->d_matches[i], cap));
         A(dalloc(&c->d_as_kpsL[i], cap)); A(dalloc(&c->d_as_kpsR[i], cap)); A(dalloc(&c->d_as_descL[i], cap * 64));
     }
@@ -251,7 +251,7 @@ static void destroy_one(uvo_ctx* c)
     mono_ws_free(c);
     pre_ws_free(c);
     codec_ws_free(c);
-    void* ptrs[] = { c->d_surv, c->d_octpat, c->d_colpart, c->d_DW, c->d_rank, c->d_big_par, c->d_big_patch, c->d_area_tabs, c->d_area_iscale, c->d_mpart, c->d_mscratch, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
+    void* ptrs[] = { c->d_surv, c->d_octpat, c->d_colpart, c->d_DW, c->d_rank, c->d_big_par, c->d_big_patch, c->d_area_tabs, c->d_area_iscale, c->d_ori_w, c->d_mpart, c->d_mscratch, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
                      c->d_flag, c->d_tmp_idx, c->d_good_pts[0], c->d_good_pts[1], c->d_good_idx[0], c->d_good_idx[1], c->d_opts[0], c->d_opts[1],
                      c->d_ipts[0], c->d_ipts[1], c->d_counts, c->d_countsB, c->d_subsets, c->d_models,
                      c->d_hcount, c->d_inliers, c->d_refit, c->d_pose };
@@ -317,6 +317,8 @@ static uvo_status read_counts(uvo_ctx* c)
 
 static uvo_status check_cand_overflow(uvo_ctx* c, int nimg)
 {
+    if (c->h_counts[CN_ORI_DROP] != 0)
+        return fail(c, UVO_INVALID_ARG, "SURF orientation: a keypoint had no gradient sample inside the image; OpenCV drops such keypoints, which this build does not do");
     for (int i = 0; i < nimg; i++)
         if (c->h_counts[CN_CAND0 + i] > c->cap)
             return fail(c, UVO_CAPACITY, "SURF found more keypoints than the context's max_kpts; results would be order-dependent");
@@ -338,7 +340,8 @@ extern "C" uvo_status uvo_surf_detect(uvo_ctx* c, const uint8_t* gray, int w, in
     *n = cnt;
     if ((kps || desc) && cnt > cap) return fail(c, UVO_CAPACITY, "uvo_surf_detect: output capacity too small");
     if (kps && cnt) UVO_HIP_TRY(c, hipMemcpyAsync(kps, c->det[0].kps, sizeof(uvo_keypoint) * cnt, hipMemcpyDeviceToHost, c->stream));
-    if (desc && cnt) UVO_HIP_TRY(c, hipMemcpyAsync(desc, c->det[0].desc, sizeof(float) * 64 * cnt, hipMemcpyDeviceToHost, c->stream));
+    const int dsize = c->p.SURF_EXTENDED ? 128 : 64;
+    if (desc && cnt) UVO_HIP_TRY(c, hipMemcpyAsync(desc, c->det[0].desc, sizeof(float) * dsize * cnt, hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return UVO_OK;
 }
@@ -638,6 +641,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
 {
     if (!c || !left || !right) return UVO_INVALID_ARG;
     if (!c->rig_set) return fail(c, UVO_INVALID_ARG, "uvo_stereo_set_rig has not been called");
+    if (c->p.SURF_EXTENDED) return fail(c, UVO_INVALID_ARG, "SURF_EXTENDED: 128-element descriptors come out of uvo_surf_detect; the matcher and the VO loops work on 64-element rows");
     const int depth = (int)c->lanes.size();
     if (c->n_pending >= depth) return fail(c, UVO_INVALID_ARG, "uvo_stereo_submit: the pipeline is full; collect a pair first (uvo_stereo_set_depth)");
     if (c->timing && c->n_pending > 0) return fail(c, UVO_INVALID_ARG, "timing mode measures one pair at a time: collect before submitting");
@@ -1118,6 +1122,7 @@ extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h
     if (!c || !img || !out) return UVO_INVALID_ARG;
     if (!c->mono_cam_set) return fail(c, UVO_INVALID_ARG, "uvo_mono_set_camera has not been called");
     if (c->mono_pipelined) return fail(c, UVO_INVALID_ARG, "uvo_mono_step after uvo_mono_submit: call uvo_mono_reset first (the previous frame is held by the pipeline)");
+    if (c->p.SURF_EXTENDED) return fail(c, UVO_INVALID_ARG, "SURF_EXTENDED: 128-element descriptors come out of uvo_surf_detect; the matcher and the VO loops work on 64-element rows");
     (void)hipSetDevice(c->device);
     const uvo_params& p = c->p;
     memset(out, 0, sizeof(*out));
@@ -1241,6 +1246,7 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
     if (!c || !img) return UVO_INVALID_ARG;
     if (!c->mono_cam_set) return fail(c, UVO_INVALID_ARG, "uvo_mono_set_camera has not been called");
     const int depth = (int)c->lanes.size();
+    if (c->p.SURF_EXTENDED) return fail(c, UVO_INVALID_ARG, "SURF_EXTENDED: 128-element descriptors come out of uvo_surf_detect; the matcher and the VO loops work on 64-element rows");
     if (depth < 2) return fail(c, UVO_INVALID_ARG, "uvo_mono_submit needs at least two lanes (uvo_stereo_set_depth): a frame is matched against the previous lane's buffers");
     if (c->n_pending >= depth) return fail(c, UVO_INVALID_ARG, "uvo_mono_submit: the pipeline is full; collect a frame first (uvo_stereo_set_depth)");
     (void)hipSetDevice(c->device);

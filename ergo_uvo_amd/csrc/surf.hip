@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void k_integral_rows(ImgPair ip, int w, int h)
     else for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) { run += src[x]; dst[x + 1] = run; } }
     if (tid == 0) dst[0] = 0;
     if (y == 0) { int32_t* r0 = ip.sum[im]; for (int x = tid; x < sw; x += 256) r0[x] = 0; }
-    if (y == 0 && tid == 0) { ip.cand_n[im] = 0; ip.big_n[im] = 0; if (im == 0) *ip.surv_n = 0; }       // the frame's candidate / large-window counters start at zero
+    if (y == 0 && tid == 0) { ip.cand_n[im] = 0; ip.big_n[im] = 0; if (im == 0) { *ip.surv_n = 0; ip.surv_n[CN_ORI_DROP - CN_SURV] = 0; } }       // the frame's candidate / large-window / survivor counters start at zero
 }
 
 __global__ __launch_bounds__(256) void k_integral_colsum(ImgPair ip, int w, int h, int32_t* part, int nseg)
@@ -813,15 +813,19 @@ __device__ __forceinline__ uint8_t sat_u8(float v) { int iv = cv_round_f(v); ret
 
 struct DescArgs { const uint8_t* img[2]; uvo_keypoint* kps[2]; float* desc[2]; const int* n[2]; const float* DW;
                   const int4* big_par; const int* big_n; const int* big_large; int cap;
-                  const AreaTab* tabs; const int* iscale; };     // [kMaxWin + 1][21] resize tables, [kMaxWin + 1] integer scale (0: general path)
+                  const AreaTab* tabs; const int* iscale;        // [kMaxWin + 1][21] resize tables, [kMaxWin + 1] integer scale (0: general path)
+                  int extended;                                  // SURF_EXTENDED: 128 elements per descriptor row (8 sums per cell)
+                  const int32_t* sum[2]; const float* ori_w; int* ori_drop; };   // orientation assignment (SURF_UPRIGHT = false): integral images, sample weights
 
-// PATCH (21 x 21, shared) -> gradients, 4x4x4 sums, normalisation -> a.desc[im][k]; 256 threads, PATCH already synchronised
+// PATCH (21 x 21, shared) -> gradients, 4x4 cells of 4 (extended: 8) sums, normalisation -> row k of a.desc[im]; 256 threads,
+// PATCH already synchronised
 __device__ __forceinline__ void describe_tail(const DescArgs& a, int im, int k, const int (*PATCH)[21])
 {
     const int tid = threadIdx.x;
     __shared__ float DX[20][20], DY[20][20];
-    __shared__ float vec[64];
+    __shared__ float vec[128];
     __shared__ float s_scale;
+    const int dsize = a.extended ? 128 : 64;
     for (int o = tid; o < 400; o += 256) {
         int i = o / 20, j = o - i * 20;
         float dw = a.DW[o];
@@ -830,24 +834,36 @@ __device__ __forceinline__ void describe_tail(const DescArgs& a, int im, int k, 
         DX[i][j] = vx; DY[i][j] = vy;
     }
     __syncthreads();
-    if (tid < 64) {
-        int cell = tid >> 2, comp = tid & 3, ci = cell >> 2, cj = cell & 3;
+    if (tid < dsize) {
         float acc = 0.f;
-        for (int y = ci * 5; y < ci * 5 + 5; y++)
-            for (int x = cj * 5; x < cj * 5 + 5; x++) {
-                float t = (comp & 1) ? DY[y][x] : DX[y][x];
-                acc += (comp & 2) ? (float)fabs(t) : t;
-            }
+        if (!a.extended) {
+            int cell = tid >> 2, comp = tid & 3, ci = cell >> 2, cj = cell & 3;
+            for (int y = ci * 5; y < ci * 5 + 5; y++)
+                for (int x = cj * 5; x < cj * 5 + 5; x++) {
+                    float t = (comp & 1) ? DY[y][x] : DX[y][x];
+                    acc += (comp & 2) ? (float)fabs(t) : t;
+                }
+        } else {
+            // surf.cpp, extended: (sum tx, sum |tx|) over ty >= 0 and over ty < 0, then (sum ty, sum |ty|) over tx >= 0 and over tx < 0
+            int cell = tid >> 3, comp = tid & 7, ci = cell >> 2, cj = cell & 3;
+            for (int y = ci * 5; y < ci * 5 + 5; y++)
+                for (int x = cj * 5; x < cj * 5 + 5; x++) {
+                    const float tx = DX[y][x], ty = DY[y][x];
+                    const float val = comp < 4 ? tx : ty, sel = comp < 4 ? ty : tx;
+                    const bool take = (comp & 2) ? sel < 0 : sel >= 0;
+                    if (take) acc += (comp & 1) ? (float)fabs(val) : val;
+                }
+        }
         vec[tid] = acc;
     }
     __syncthreads();
     if (tid == 0) {
         double square_mag = 0;
-        for (int kk = 0; kk < 64; kk++) square_mag += vec[kk] * vec[kk];
+        for (int kk = 0; kk < dsize; kk++) square_mag += vec[kk] * vec[kk];
         s_scale = (float)(1. / (sqrt(square_mag) + FLT_EPSILON));
     }
     __syncthreads();
-    if (tid < 64) a.desc[im][(size_t)k * 64 + tid] = vec[tid] * s_scale;
+    if (tid < dsize) a.desc[im][(size_t)k * dsize + tid] = vec[tid] * s_scale;
 }
 
 // One workgroup per keypoint.  PATCH = cv::resize(WIN, 21x21, INTER_AREA) with
@@ -980,6 +996,213 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
     }
     __syncthreads();
     describe_tail(a, im, k, PATCH);
+}
+
+// ------------------------------------------------------------------------------------------
+// SURF_UPRIGHT = false (the shipped configurations are upright): orientation assignment and the rotated
+// sampling window of SURFInvoker, surf.cpp.
+// ------------------------------------------------------------------------------------------
+static const int kOriRadius = 6, kOriWin = 60, kOriInc = 5, kOriSamples = 113;       // points (i, j), |i|, |j| <= 6, i*i + j*j <= 36
+// cv::fastAtan2 (degrees), which is also what cv::phase(X, Y, angle, true) evaluates per element
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float sc = (float)(180 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * sc, p3 = -0.3258083974640975f * sc, p5 = 0.1555786518463281f * sc, p7 = -0.04432655554792128f * sc;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) { c = ay / (ax + (float)DBL_EPSILON); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + (float)DBL_EPSILON); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+// resizeHaarPattern + calcHaarPattern for the two 2-box gradient wavelets (dx_s = {0,0,2,4,-1},{2,0,4,4,1}; dy_s = {0,0,4,2,1},{0,2,4,4,-1})
+// of size `gws` at integral position p (row pitch sw): int box sum * float weight accumulated in double, as the detector does
+__device__ __forceinline__ void ori_gradients(const int32_t* __restrict__ p, int sw, int gws, float* vx, float* vy)
+{
+    const float ratio = (float)gws / 4;
+    const int c0 = cv_round_f(ratio * 0), c2 = cv_round_f(ratio * 2), c4 = cv_round_f(ratio * 4);
+    auto box = [&](int x1, int y1, int x2, int y2) { return p[y1 * sw + x1] + p[y2 * sw + x2] - p[y2 * sw + x1] - p[y1 * sw + x2]; };
+    {
+        const float w0 = -1 / ((float)(c2 - c0) * (c4 - c0)), w1 = 1 / ((float)(c4 - c2) * (c4 - c0));
+        double d = 0;
+        d += box(c0, c0, c2, c4) * w0; d += box(c2, c0, c4, c4) * w1;
+        *vx = (float)d;
+    }
+    {
+        const float w0 = 1 / ((float)(c4 - c0) * (c2 - c0)), w1 = -1 / ((float)(c4 - c0) * (c4 - c2));
+        double d = 0;
+        d += box(c0, c0, c4, c2) * w0; d += box(c0, c2, c4, c4) * w1;
+        *vy = (float)d;
+    }
+}
+
+// One wave per keypoint: the 113 gradient samples (two per lane), then the 72 sliding windows -- lane d sums the samples of
+// window 5d (and 5(d + 64)) in sample order, as the sequential loop does -- and the first largest window gives the direction.
+__global__ __launch_bounds__(256) void k_surf_orientation(DescArgs a, int w, int h)
+{
+    const int im = blockIdx.y, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = *a.n[im];
+    const int k = blockIdx.x * 4 + wv;
+    __shared__ float sX[4][128], sY[4][128]; __shared__ int sA[4][128];        // the valid samples, compacted in sample order
+    if (k >= n) return;
+    uvo_keypoint kp = a.kps[im][k];
+    const float s = kp.size * 1.2f / 9.0f;
+    const int gws = 2 * cv_round_f(2 * s);
+    const int sum_rows = h + 1, sw = w + 1;
+    const int32_t* __restrict__ sum = a.sum[im];
+    // sample kk is the kk-th (i, j) of the raster walk over [-6, 6]^2 with i*i + j*j <= 36: the 169 cells in three lane passes,
+    // the valid ones compacted in that order with ballots
+    int cnt_before = 0;
+    for (int pass = 0; pass < 3; pass++) {
+        const int cell = pass * 64 + lane;
+        bool inside = false, valid = false; float vx = 0, vy = 0;
+        if (cell < 169) {
+            const int i = cell / 13 - kOriRadius, j = cell % 13 - kOriRadius;
+            inside = i * i + j * j <= kOriRadius * kOriRadius;
+            if (inside) {
+                const int x = cv_round_f(kp.x + i * s - (float)(gws - 1) / 2), y = cv_round_f(kp.y + j * s - (float)(gws - 1) / 2);
+                if (!(y < 0 || y >= sum_rows - gws || x < 0 || x >= sw - gws)) {
+                    valid = true;
+                    ori_gradients(sum + (size_t)y * sw + x, sw, gws, &vx, &vy);
+                    const float wgt = a.ori_w[(i + kOriRadius) * 13 + (j + kOriRadius)];
+                    vx *= wgt; vy *= wgt;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(valid);
+        if (valid) {
+            const int pos = cnt_before + __popcll(m & ((1ull << lane) - 1ull));
+            sX[wv][pos] = vx; sY[wv][pos] = vy; sA[wv][pos] = cv_round_f(fast_atan2_deg(vy, vx));
+        }
+        cnt_before += __popcll(m);
+    }
+    const int nangle = cnt_before;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (nangle == 0) { if (lane == 0) atomicAdd(a.ori_drop, 1); return; }      // OpenCV drops the keypoint: reported, never silently kept
+    float best_mod = 0.f, bx = 0.f, by = 0.f; int best_i = 1 << 30;
+    for (int d = lane; d < 360 / kOriInc; d += 64) {
+        const int i = d * kOriInc;
+        float sumx = 0.f, sumy = 0.f;
+        for (int j = 0; j < nangle; j++) {
+            const int dd = abs(sA[wv][j] - i);
+            if (dd < kOriWin / 2 || dd > 360 - kOriWin / 2) { sumx += sX[wv][j]; sumy += sY[wv][j]; }
+        }
+        const float mod = sumx * sumx + sumy * sumy;
+        if (mod > best_mod) { best_mod = mod; bx = sumx; by = sumy; best_i = i; }      // per lane: its windows in increasing order, strict >
+    }
+    // the sequential scan keeps the FIRST window with the largest modulus (strict >; a zero modulus never wins)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(best_mod, o), ox = __shfl_xor(bx, o), oy = __shfl_xor(by, o); const int oi = __shfl_xor(best_i, o);
+        if (om > best_mod || (om == best_mod && oi < best_i)) { best_mod = om; bx = ox; by = oy; best_i = oi; }
+    }
+    if (lane == 0) a.kps[im][k].angle = fast_atan2_deg(-by, bx);
+}
+
+// The descriptor of one keypoint with a rotated sampling window, one workgroup per keypoint.  WIN[i][j] is the bilinear sample
+// at start + i (sin, cos) + j (cos, -sin) with OpenCV's running sums (a float accumulated per row i, a double per column j), so
+// thread i walks its row j = 0 .. win-1 and feeds cv::resize(INTER_AREA)'s horizontal pass on the fly; the vertical pass and the
+// tail are the upright kernels'.  LDS: 21 x (win | 1) floats (dynamic) + the per-row start positions.
+__global__ __launch_bounds__(256) void k_descriptor_rot(DescArgs a, int w, int h)
+{
+    const int im = blockIdx.y, tid = threadIdx.x;
+    const int n = *a.n[im];
+    extern __shared__ __align__(16) unsigned char smem_rot[];
+    float* buf = reinterpret_cast<float*>(smem_rot);                    // [21][bp]
+    __shared__ float s_sx[kMaxWin + 1], s_sy[kMaxWin + 1];
+    __shared__ AreaTab tab[21];
+    __shared__ int PATCH[21][21];
+    const uint8_t* __restrict__ img = a.img[im];
+    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+        const uvo_keypoint kp = a.kps[im][k];
+        const float s = kp.size * 1.2f / 9.0f;
+        const int win_size = (int)((20 + 1) * s);
+        const int bp = win_size | 1;
+        const int iscale = a.iscale[min(win_size, kMaxWin)];
+        if (tid < 21) tab[tid] = a.tabs[min(win_size, kMaxWin) * 21 + tid];
+        float descriptor_dir = kp.angle;
+        descriptor_dir *= (float)(3.14159265358979323846 / 180);
+        double sd, cd;
+        det_sincos((double)descriptor_dir, &sd, &cd);                   // OpenCV: std::sin / std::cos of a float; here the double series rounded to float (glibc sinf/cosf round the same way but for rare ties)
+        const float sin_dir = -(float)sd, cos_dir = (float)cd;
+        if (tid == 0) {                                                 // start_x += sin_dir; start_y += cos_dir, row after row (float)
+            const float win_offset = -(float)(win_size - 1) / 2;
+            float start_x = kp.x + win_offset * cos_dir + win_offset * sin_dir;
+            float start_y = kp.y - win_offset * sin_dir + win_offset * cos_dir;
+            for (int i = 0; i < win_size; i++, start_x += sin_dir, start_y += cos_dir) { s_sx[i] = start_x; s_sy[i] = start_y; }
+        }
+        __syncthreads();
+        const int ncols1 = w - 1, nrows1 = h - 1;
+        for (int i = tid; i < win_size; i += 256) {
+            double pixel_x = s_sx[i], pixel_y = s_sy[i];
+            int dx = 0;
+            float b = 0.f;                                              // running sum of destination column dx
+            int isum = 0;
+            AreaTab tx = tab[0];
+            for (int j = 0; j < win_size; j++, pixel_x += cos_dir, pixel_y -= sin_dir) {
+                const int ix = cv_floor_d(pixel_x), iy = cv_floor_d(pixel_y);
+                int v;
+                if ((unsigned)ix < (unsigned)ncols1 && (unsigned)iy < (unsigned)nrows1) {
+                    const float fa = (float)(pixel_x - ix), fb = (float)(pixel_y - iy);
+                    const uint8_t* ip = img + (size_t)iy * w + ix;
+                    v = cv_round_f(ip[0] * (1.f - fa) * (1.f - fb) + ip[1] * fa * (1.f - fb) + ip[w] * (1.f - fa) * fb + ip[w + 1] * fa * fb) & 255;
+                } else {
+                    int x = cv_round_d(pixel_x), y = cv_round_d(pixel_y);
+                    x = x > 0 ? x : 0; x = x < ncols1 ? x : ncols1; y = y > 0 ? y : 0; y = y < nrows1 ? y : nrows1;
+                    v = img[(size_t)y * w + x];
+                }
+                if (iscale) {                                           // resizeAreaFast_: integer block sums along j
+                    isum += v;
+                    if ((j + 1) % iscale == 0) { if (dx < 21) reinterpret_cast<int*>(buf)[dx * bp + i] = isum; isum = 0; dx++; }
+                } else {
+                    // source column j belongs to destination column dx as its (partial) first tap, a middle tap, or its (partial)
+                    // last tap -- and then also to column dx + 1 as that one's first tap
+                    while (dx < 21) {
+                        const int c_begin = tx.has_first ? tx.sx1 - 1 : tx.sx1, c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
+                        if (j < c_begin) break;
+                        if (j < c_end) {
+                            const float alpha = j < tx.sx1 ? tx.a_first : (j < tx.sx2 ? tx.a_mid : tx.a_last);
+                            b += v * alpha;
+                        }
+                        if (j + 1 >= c_end) {                           // column dx is complete after this source column
+                            buf[dx * bp + i] = b; b = 0.f; dx++;
+                            if (dx < 21) tx = tab[dx];
+                            continue;                                   // the same source column may open the next destination column
+                        }
+                        break;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (iscale) {
+            for (int o = tid; o < 441; o += 256) {
+                const int dy = o / 21, dx = o - dy * 21;
+                int sum = 0;
+                for (int sy = 0; sy < iscale; sy++) sum += reinterpret_cast<const int*>(buf)[dx * bp + dy * iscale + sy];
+                int result;
+                if (iscale == 2) result = (sum + 2) >> 2;
+                else { float sc = 1.f / (iscale * iscale); result = sat_u8(sum * sc); }
+                PATCH[dy][dx] = result;
+            }
+        } else {
+            for (int o = tid; o < 441; o += 256) {
+                const int dy = o / 21, dx = o - dy * 21;
+                const AreaTab ty = tab[dy];
+                const float* col = buf + dx * bp;
+                float sum = 0.f;
+                if (ty.has_first) sum += ty.a_first * col[ty.sx1 - 1];
+                for (int r = ty.sx1; r < ty.sx2; r++) sum += ty.a_mid * col[r];
+                if (ty.has_last) sum += ty.a_last * col[ty.sx2];
+                PATCH[dy][dx] = sat_u8(sum);
+            }
+        }
+        __syncthreads();
+        describe_tail(a, im, k, PATCH);
+        __syncthreads();
+    }
 }
 
 // small windows: one workgroup per keypoint
@@ -1218,6 +1441,18 @@ uvo_status surf_build_area_tables(Ctx* c)
     UVO_HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_area_iscale), isc.size() * sizeof(int)));
     UVO_HIP_TRY(c, hipMemcpy(c->d_area_tabs, tabs.data(), tabs.size() * sizeof(AreaTab), hipMemcpyHostToDevice));
     UVO_HIP_TRY(c, hipMemcpy(c->d_area_iscale, isc.data(), isc.size() * sizeof(int), hipMemcpyHostToDevice));
+    // SURFInvoker ctor: getGaussianKernel(2 * ORI_RADIUS + 1, SURF_ORI_SIGMA = 2.5, CV_32F), weights G[i] * G[j] of the orientation samples
+    {
+        const int N = 2 * kOriRadius + 1;
+        double t[N], sum = 0; float G[N], W[N * N];
+        const double sigma = 2.5f, scale2X = -0.5 / (sigma * sigma);
+        for (int i = 0; i < N; i++) { const double x = i - (N - 1) * 0.5; t[i] = exp(scale2X * x * x); sum += t[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < N; i++) G[i] = (float)(t[i] * sum);
+        for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) W[i * N + j] = G[i] * G[j];
+        UVO_HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_ori_w), sizeof(W)));
+        UVO_HIP_TRY(c, hipMemcpy(c->d_ori_w, W, sizeof(W), hipMemcpyHostToDevice));
+    }
     return UVO_OK;
 }
 
@@ -1285,10 +1520,6 @@ static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float 
 uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
 {
     const int w = c->img_w, h = c->img_h;
-    if (c->p.SURF_EXTENDED || !c->p.SURF_UPRIGHT) {
-        c->err = "only the reference's configured SURF branch (extended=false, upright=true) is implemented";
-        return UVO_INVALID_ARG;
-    }
     if (c->p.SURF_OCTAVES_NUMBER < 1 || c->p.SURF_OCTAVES_NUMBER > 4 || c->p.SURF_OCTAVES_LAYERS != 3) {
         c->err = "SURF: supported nOctaves 1..4, nOctaveLayers 3";
         return UVO_INVALID_ARG;
@@ -1342,12 +1573,21 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
         StageTimer t(c, ST_DESCRIPTOR);
         DescArgs da = { { c->d_img[0], c->d_img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
                         { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap,      // the sorted list
-                        c->d_area_tabs, c->d_area_iscale };
+                        c->d_area_tabs, c->d_area_iscale, c->p.SURF_EXTENDED ? 1 : 0, { c->d_sum[0], c->d_sum[1] }, c->d_ori_w, c->d_counts + CN_ORI_DROP };
         const size_t lds_small = sizeof(float) * 21 * (kSmallWin | 1);
         hipLaunchKernelGGL(k_big_sort, dim3(nimg), dim3(1024), 0, c->stream, c->d_big_par, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap, c->d_area_iscale);
-        hipLaunchKernelGGL(k_descriptor64_big, dim3(1024, nimg), dim3(256), 0, c->stream, da, w, h, c->d_big_patch);
-        hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(1024, nimg), dim3(256), 0, c->stream, da, c->d_big_patch);
-        hipLaunchKernelGGL(k_descriptor64_small, dim3(c->cap, nimg), dim3(256), lds_small, c->stream, da, w, h);
+        if (c->p.SURF_UPRIGHT) hipLaunchKernelGGL(k_descriptor64_big, dim3(1024, nimg), dim3(256), 0, c->stream, da, w, h, c->d_big_patch);
+        if (c->p.SURF_UPRIGHT) {
+            hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(1024, nimg), dim3(256), 0, c->stream, da, c->d_big_patch);
+            hipLaunchKernelGGL(k_descriptor64_small, dim3(c->cap, nimg), dim3(256), lds_small, c->stream, da, w, h);
+        } else {
+            // orientation assignment, then every descriptor from its rotated window (not the shipped configuration)
+            const size_t lds_rot = sizeof(float) * 21 * (kMaxWin + 1);
+            static bool rot_attr = false;
+            if (!rot_attr) { UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_descriptor_rot), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rot)); rot_attr = true; }
+            hipLaunchKernelGGL(k_surf_orientation, dim3((c->cap + 3) / 4, nimg), dim3(256), 0, c->stream, da, w, h);
+            hipLaunchKernelGGL(k_descriptor_rot, dim3(2048, nimg), dim3(256), lds_rot, c->stream, da, w, h);
+        }
         UVO_HIP_TRY(c, hipGetLastError());
     }
     return UVO_OK;

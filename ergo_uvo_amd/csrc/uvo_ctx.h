@@ -35,7 +35,7 @@ static const char* const kStageNames[ST_COUNT] = {
 
 // fixed slots of Ctx::d_counts / h_counts
 enum { CN_T = 0, CN_G = 1, CN_NINL = 2, CN_NQA = 3, CN_NQB = 4, CN_MEFF = 5, CN_NL = 6, CN_NR = 7,
-       CN_CAND0 = 8, CN_CAND1 = 9, CN_M = 10, CN_TRAW = 11, CN_AS0 = 12, CN_AS1 = 13, CN_BIG0 = 14, CN_BIG1 = 15, CN_SURV = 16, CN_BIGL0 = 17, CN_BIGL1 = 18, CN_TOTAL = 19 };   // CN_BIG*: large-window keypoints per image, CN_BIGL*: those too wide for three-column tasks; CN_SURV: NMS survivors
+       CN_CAND0 = 8, CN_CAND1 = 9, CN_M = 10, CN_TRAW = 11, CN_AS0 = 12, CN_AS1 = 13, CN_BIG0 = 14, CN_BIG1 = 15, CN_SURV = 16, CN_BIGL0 = 17, CN_BIGL1 = 18, CN_ORI_DROP = 19, CN_TOTAL = 20 };   // CN_BIG*: large-window keypoints per image, CN_BIGL*: those too wide for three-column tasks; CN_SURV: NMS survivors
 // The gate ladder of the stereo loop, evaluated on the device by the last thread of the kernel that produces the count it
 // tests (no launches of their own): mode 1 = VO:567 after the stereo matcher's compaction, mode 2 = VO:626 after the
 // triangular matcher's.
@@ -78,6 +78,7 @@ struct Ctx {
     std::vector<unsigned char> h_octpat;         // what d_octpat holds
     int4* d_big_par = nullptr; int* d_big_n = nullptr;   // [2][cap] (sorted index, win, start_x, start_y) of large-window keypoints in append order, then [2][cap] by descending win; [2] counts
     struct AreaTab* d_area_tabs = nullptr;       // [kMaxWin + 1][21] INTER_AREA resize tables of every descriptor window size (surf_build_area_tables)
+    float* d_ori_w = nullptr;                    // 13 x 13 Gaussian weights of the orientation samples (SURF_UPRIGHT = false)
     int* d_area_iscale = nullptr;                // [kMaxWin + 1] integer scale of the sizes resizeAreaFast_ handles, else 0
     uint8_t* d_big_patch = nullptr;              // [2][cap][448] 21x21 patches of the large-window keypoints
     int* d_rank = nullptr;                       // [2][cap] sort ranks (zero between frames)

@@ -303,7 +303,8 @@ void detect_features(Mat img, vector<KeyPoint>& keypoints, Mat& descriptors)
     uvo_ctx* c = ctx_now();
     const int cap = g.max_kpts;
     vector<uvo_keypoint> kps((size_t)cap);
-    vector<float> desc((size_t)cap * 64);
+    const int dsize = SURF_EXTENDED ? 128 : 64;      // SURF::descriptorSize()
+    vector<float> desc((size_t)cap * dsize);
     int n = 0;
     // rows may be padded in a real cv::Mat: pass the row pitch
     const int stride = img.rows > 1 ? (int)(img.ptr<uint8_t>(1) - img.ptr<uint8_t>(0)) : img.cols;
@@ -311,8 +312,8 @@ void detect_features(Mat img, vector<KeyPoint>& keypoints, Mat& descriptors)
              "uvo_surf_detect");
     keypoints.resize((size_t)n);
     if (n) memcpy(static_cast<void*>(keypoints.data()), kps.data(), sizeof(uvo_keypoint) * n);
-    descriptors.create(n, 64, CV_32FC1);
-    for (int i = 0; i < n; i++) memcpy(descriptors.ptr<float>(i), desc.data() + (size_t)i * 64, sizeof(float) * 64);
+    descriptors.create(n, dsize, CV_32FC1);
+    for (int i = 0; i < n; i++) memcpy(descriptors.ptr<float>(i), desc.data() + (size_t)i * dsize, sizeof(float) * dsize);
 }
 
 namespace {

@@ -83,8 +83,10 @@ uvo_status  uvo_ctx_set_producer_stream(uvo_ctx* c, void* hip_stream, int enable
 const char* uvo_ctx_warning(const uvo_ctx* c);
 
 /* ---- detect_features, SURF branch (VO_utility.h:100 -> VO_utility.cpp:114-119) ----
- * gray: 8-bit single channel, `stride` bytes per row.  kps/desc (n x 64 f32) are host buffers of
- * capacity `cap`, either may be NULL.  Overwrites outputs (as detectAndCompute does). */
+ * gray: 8-bit single channel, `stride` bytes per row.  kps/desc are host buffers of capacity `cap`, either may be NULL;
+ * desc is n x 64 f32, or n x 128 when the context's SURF_EXTENDED is set.  SURF_UPRIGHT = 0 runs the orientation assignment
+ * and samples the descriptor window rotated (keypoint.angle = the orientation, 270 when upright).  Overwrites outputs (as
+ * detectAndCompute does).  The matcher and the stereo / mono steps work on 64-element rows: they refuse SURF_EXTENDED. */
 uvo_status uvo_surf_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem,
                            uvo_keypoint* kps, float* desc, int cap, int* n);
 /* test hooks into the detector's first stages (host outputs): integral image (h+1)x(w+1) s32 of the

@@ -6,7 +6,10 @@
  * resizeHaarPattern, calcHaarPattern, findMaximaInLayer, interpolateKeypoint,
  * KeypointGreater, SURFInvoker), imgproc integral (CV_32S) and resize INTER_AREA (u8).
  * SURVEY.md App. A.1.  PARITY UNPINNED vs OpenCV (see uvo_oracle.h).
- * Only the branch the reference configures is restated: extended=false, upright=true.
+ * The branch the reference configures is extended=false, upright=true; the other values of the two flags
+ * (orientation assignment with the rotated sampling window, the 128-element descriptor: SURVEY.md 8(f) N4) are
+ * restated as well, from the same SURFInvoker.  sin / cos of the orientation are orc_sincos (shared with the HIP
+ * path operation for operation) narrowed to float, where OpenCV calls std::sin / std::cos on a float.
  */
 #include "uvo_oracle.h"
 #include <math.h>
@@ -257,30 +260,124 @@ void orc_resize_area_u8(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw
     free(buf); free(xtab);
 }
 
-/* [UPSTREAM] surf.cpp SURFInvoker::operator(), upright + 64-D branch.  Returns 0 if the keypoint is
- * marked for deletion (size = -1). */
-static int surf_describe(const uint8_t* img, int w, int h, int stride, const float* DW,
+#define ORI_RADIUS          6
+#define ORI_WIN             60
+#define SURF_ORI_SEARCH_INC 5
+#define SURF_ORI_SIGMA      2.5f
+#define ORI_MAX_SAMPLES     ((2 * ORI_RADIUS + 1) * (2 * ORI_RADIUS + 1))
+
+/* [UPSTREAM] core mathfuncs_core: cv::fastAtan2 (degrees), also what cv::phase(.., angleInDegrees = true) evaluates per element */
+float orc_fast_atan2(float y, float x)
+{
+    const float s = (float)(180 / 3.14159265358979323846);
+    const float p1 = 0.9997878412794807f * s, p3 = -0.3258083974640975f * s, p5 = 0.1555786518463281f * s, p7 = -0.04432655554792128f * s;
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) { c = ay / (ax + (float)DBL_EPSILON); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + (float)DBL_EPSILON); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+typedef struct { int n; int x[ORI_MAX_SAMPLES], y[ORI_MAX_SAMPLES]; float w[ORI_MAX_SAMPLES]; } OriTab;
+
+/* SURFInvoker ctor: the sampling pattern of the orientation assignment (points of the 13 x 13 grid inside radius 6, Gaussian weights) */
+static void make_ori_tab(OriTab* t)
+{
+    float G[2 * ORI_RADIUS + 1];
+    orc_gaussian_kernel_f32(2 * ORI_RADIUS + 1, SURF_ORI_SIGMA, G);
+    t->n = 0;
+    for (int i = -ORI_RADIUS; i <= ORI_RADIUS; i++)
+        for (int j = -ORI_RADIUS; j <= ORI_RADIUS; j++)
+            if (i * i + j * j <= ORI_RADIUS * ORI_RADIUS) { t->x[t->n] = i; t->y[t->n] = j; t->w[t->n] = G[i + ORI_RADIUS] * G[j + ORI_RADIUS]; t->n++; }
+}
+
+/* [UPSTREAM] surf.cpp SURFInvoker::operator() for one keypoint: orientation (unless upright), sampling window, INTER_AREA
+ * resize to 21 x 21, Haar responses, 4 x 4 cells of 4 (or, extended, 8) sums, normalisation.  `sum` is the integral image.
+ * Returns 0 if the keypoint is marked for deletion (size = -1). */
+static int surf_describe(const uint8_t* img, const int32_t* sum, int w, int h, int stride, const float* DW, const OriTab* ot, int upright, int extended,
                          orc_keypoint* kp, float* vec, uint8_t* winbuf)
 {
+    static const int dx_s[2][5] = { {0, 0, 2, 4, -1}, {2, 0, 4, 4, 1} };
+    static const int dy_s[2][5] = { {0, 0, 4, 2, 1}, {0, 2, 4, 4, -1} };
     uint8_t PATCH[PATCH_SZ + 1][PATCH_SZ + 1];
     float DX[PATCH_SZ][PATCH_SZ], DY[PATCH_SZ][PATCH_SZ];
+    const int dsize = extended ? 128 : 64;
     float size = kp->size;
     float s = size * 1.2f / 9.0f;
     int grad_wav_size = 2 * orc_cvRoundf(2 * s);
-    if (h + 1 < grad_wav_size || w + 1 < grad_wav_size) { kp->size = -1; return 0; }
-    kp->angle = 360.f - 90.f;
+    const int sum_rows = h + 1, sum_cols = w + 1;
+    if (sum_rows < grad_wav_size || sum_cols < grad_wav_size) { kp->size = -1; return 0; }
+    float descriptor_dir = 360.f - 90.f;
+    if (!upright) {
+        SurfHF dx_t[2], dy_t[2];
+        float X[ORI_MAX_SAMPLES], Y[ORI_MAX_SAMPLES], angle[ORI_MAX_SAMPLES];
+        resize_haar_pattern(dx_s, dx_t, 2, 4, grad_wav_size, sum_cols);
+        resize_haar_pattern(dy_s, dy_t, 2, 4, grad_wav_size, sum_cols);
+        int nangle = 0;
+        for (int kk = 0; kk < ot->n; kk++) {
+            int x = orc_cvRoundf(kp->x + ot->x[kk] * s - (float)(grad_wav_size - 1) / 2);
+            int y = orc_cvRoundf(kp->y + ot->y[kk] * s - (float)(grad_wav_size - 1) / 2);
+            if (y < 0 || y >= sum_rows - grad_wav_size || x < 0 || x >= sum_cols - grad_wav_size) continue;
+            const int32_t* ptr = sum + (size_t)y * sum_cols + x;
+            float vx = calc_haar_pattern(ptr, dx_t, 2), vy = calc_haar_pattern(ptr, dy_t, 2);
+            X[nangle] = vx * ot->w[kk]; Y[nangle] = vy * ot->w[kk];
+            nangle++;
+        }
+        if (nangle == 0) { kp->size = -1; return 0; }        /* no gradient could be sampled: the keypoint is dropped */
+        for (int k = 0; k < nangle; k++) angle[k] = orc_fast_atan2(Y[k], X[k]);      /* cv::phase(X, Y, angle, true) */
+        float bestx = 0, besty = 0, descriptor_mod = 0;
+        for (int i = 0; i < 360; i += SURF_ORI_SEARCH_INC) {
+            float sumx = 0, sumy = 0, temp_mod;
+            for (int j = 0; j < nangle; j++) {
+                int d = abs(orc_cvRoundf(angle[j]) - i);
+                if (d < ORI_WIN / 2 || d > 360 - ORI_WIN / 2) { sumx += X[j]; sumy += Y[j]; }
+            }
+            temp_mod = sumx * sumx + sumy * sumy;
+            if (temp_mod > descriptor_mod) { descriptor_mod = temp_mod; bestx = sumx; besty = sumy; }
+        }
+        descriptor_dir = orc_fast_atan2(-besty, bestx);
+    }
+    kp->angle = descriptor_dir;
     int win_size = (int)((PATCH_SZ + 1) * s);
-    float win_offset = -(float)(win_size - 1) / 2;
-    int start_x = orc_cvRoundf(kp->x + win_offset);
-    int start_y = orc_cvRoundf(kp->y - win_offset);
-    for (int i = 0; i < win_size; i++, start_x++) {
-        int pixel_x = start_x, pixel_y = start_y;
-        for (int j = 0; j < win_size; j++, pixel_y--) {
-            int x = pixel_x > 0 ? pixel_x : 0;
-            int y = pixel_y > 0 ? pixel_y : 0;
-            x = x < w - 1 ? x : w - 1;
-            y = y < h - 1 ? y : h - 1;
-            winbuf[i * win_size + j] = img[(size_t)y * stride + x];
+    if (!upright) {
+        descriptor_dir *= (float)(3.14159265358979323846 / 180);
+        double sd, cd;
+        orc_sincos((double)descriptor_dir, &sd, &cd);
+        float sin_dir = -(float)sd, cos_dir = (float)cd;
+        float win_offset = -(float)(win_size - 1) / 2;
+        float start_x = kp->x + win_offset * cos_dir + win_offset * sin_dir;
+        float start_y = kp->y - win_offset * sin_dir + win_offset * cos_dir;
+        const int ncols1 = w - 1, nrows1 = h - 1;
+        for (int i = 0; i < win_size; i++, start_x += sin_dir, start_y += cos_dir) {
+            double pixel_x = start_x, pixel_y = start_y;
+            for (int j = 0; j < win_size; j++, pixel_x += cos_dir, pixel_y -= sin_dir) {
+                int ix = orc_cvFloor(pixel_x), iy = orc_cvFloor(pixel_y);
+                if ((unsigned)ix < (unsigned)ncols1 && (unsigned)iy < (unsigned)nrows1) {
+                    float a = (float)(pixel_x - ix), b = (float)(pixel_y - iy);
+                    const uint8_t* ip = img + (size_t)iy * stride + ix;
+                    winbuf[i * win_size + j] = (uint8_t)orc_cvRoundf(ip[0] * (1.f - a) * (1.f - b) + ip[1] * a * (1.f - b) + ip[stride] * (1.f - a) * b + ip[stride + 1] * a * b);
+                } else {
+                    int x = orc_cvRound(pixel_x), y = orc_cvRound(pixel_y);
+                    x = x > 0 ? x : 0; x = x < ncols1 ? x : ncols1;
+                    y = y > 0 ? y : 0; y = y < nrows1 ? y : nrows1;
+                    winbuf[i * win_size + j] = img[(size_t)y * stride + x];
+                }
+            }
+        }
+    } else {
+        float win_offset = -(float)(win_size - 1) / 2;
+        int start_x = orc_cvRoundf(kp->x + win_offset);
+        int start_y = orc_cvRoundf(kp->y - win_offset);
+        for (int i = 0; i < win_size; i++, start_x++) {
+            int pixel_x = start_x, pixel_y = start_y;
+            for (int j = 0; j < win_size; j++, pixel_y--) {
+                int x = pixel_x > 0 ? pixel_x : 0;
+                int y = pixel_y > 0 ? pixel_y : 0;
+                x = x < w - 1 ? x : w - 1;
+                y = y < h - 1 ? y : h - 1;
+                winbuf[i * win_size + j] = img[(size_t)y * stride + x];
+            }
         }
     }
     orc_resize_area_u8(winbuf, win_size, win_size, &PATCH[0][0], PATCH_SZ + 1, PATCH_SZ + 1);
@@ -291,7 +388,7 @@ static int surf_describe(const uint8_t* img, int w, int h, int stride, const flo
             float vy = (PATCH[i+1][j] - PATCH[i][j] + PATCH[i+1][j+1] - PATCH[i][j+1]) * dw;
             DX[i][j] = vx; DY[i][j] = vy;
         }
-    for (int kk = 0; kk < 64; kk++) vec[kk] = 0;
+    for (int kk = 0; kk < dsize; kk++) vec[kk] = 0;
     double square_mag = 0;
     float* v = vec;
     for (int i = 0; i < 4; i++)
@@ -299,14 +396,20 @@ static int surf_describe(const uint8_t* img, int w, int h, int stride, const flo
             for (int y = i*5; y < i*5+5; y++)
                 for (int x = j*5; x < j*5+5; x++) {
                     float tx = DX[y][x], ty = DY[y][x];
-                    v[0] += tx; v[1] += ty;
-                    v[2] += (float)fabs(tx); v[3] += (float)fabs(ty);
+                    if (!extended) {
+                        v[0] += tx; v[1] += ty;
+                        v[2] += (float)fabs(tx); v[3] += (float)fabs(ty);
+                    } else {
+                        if (ty >= 0) { v[0] += tx; v[1] += (float)fabs(tx); } else { v[2] += tx; v[3] += (float)fabs(tx); }
+                        if (tx >= 0) { v[4] += ty; v[5] += (float)fabs(ty); } else { v[6] += ty; v[7] += (float)fabs(ty); }
+                    }
                 }
-            for (int kk = 0; kk < 4; kk++) square_mag += v[kk] * v[kk];
-            v += 4;
+            const int per = extended ? 8 : 4;
+            for (int kk = 0; kk < per; kk++) square_mag += v[kk] * v[kk];
+            v += per;
         }
     float scale = (float)(1. / (sqrt(square_mag) + FLT_EPSILON));
-    for (int kk = 0; kk < 64; kk++) vec[kk] *= scale;
+    for (int kk = 0; kk < dsize; kk++) vec[kk] *= scale;
     return 1;
 }
 
@@ -400,14 +503,20 @@ int orc_surf_detect_and_compute(const uint8_t* img, int w, int h, int stride, co
     int imaxSize = orc_cvCeil((PATCH_SZ + 1) * maxSize * 1.2f / 9.0f); if (imaxSize < 1) imaxSize = 1;
     uint8_t* winbuf = (uint8_t*)malloc((size_t)imaxSize * imaxSize);
     int j = 0, overflow = 0;
-    float vec[64];
+    float vec[128];
+    const int dsize = p->extended ? 128 : 64;
+    OriTab ot;
+    make_ori_tab(&ot);
+    int32_t* isum = NULL;
+    if (!p->upright) { isum = (int32_t*)malloc(sizeof(int32_t) * (size_t)(w + 1) * (h + 1)); orc_integral_u8(img, w, h, stride, isum); }
     for (int k = 0; k < nk; k++) {
-        if (surf_describe(img, w, h, stride, DW, &kps[k], vec, winbuf)) {
-            if (j < cap) { kps_out[j] = kps[k]; if (desc_out) memcpy(desc_out + (size_t)j * 64, vec, sizeof(vec)); }
+        if (surf_describe(img, isum, w, h, stride, DW, &ot, p->upright, p->extended, &kps[k], vec, winbuf)) {
+            if (j < cap) { kps_out[j] = kps[k]; if (desc_out) memcpy(desc_out + (size_t)j * dsize, vec, sizeof(float) * dsize); }
             else overflow = 1;
             j++;
         }
     }
+    free(isum);
     free(winbuf); free(kps);
     return overflow ? -j : j;
 }

@@ -136,12 +136,12 @@ def surf_layer(sum_: np.ndarray, size: int, step: int):
     return det, tr
 
 
-def surf(img: np.ndarray, hessian=1500.0, n_octaves=4, n_layers=3, cap=20000):
+def surf(img: np.ndarray, hessian=1500.0, n_octaves=4, n_layers=3, cap=20000, extended=False, upright=True):
     img = _c(img, np.uint8)
     h, w = img.shape
-    sp = SurfParams(float(hessian), n_octaves, n_layers, 0, 1)
+    sp = SurfParams(float(hessian), n_octaves, n_layers, int(bool(extended)), int(bool(upright)))
     kps = np.zeros(cap, KP_DTYPE)
-    desc = np.zeros((cap, 64), np.float32)
+    desc = np.zeros((cap, 128 if extended else 64), np.float32)
     n = lib().orc_surf_detect_and_compute(_p(img), w, h, w, C.byref(sp), _p(kps), _p(desc), cap)
     if n < 0:
         raise RuntimeError(f"oracle SURF: capacity {cap} too small ({-n} keypoints)")

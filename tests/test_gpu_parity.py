@@ -81,6 +81,30 @@ def test_surf_dense_maxima_bit_exact(ctx, oracle, shape, thr):
     assert np.array_equal(desc.view(np.uint32), odesc.view(np.uint32))
 
 
+@pytest.mark.parametrize("shape,thr,upright,extended", [((240, 320), 300, False, False), ((360, 640), 800, True, True), ((360, 640), 800, False, True),
+                                                      ((187, 249), 100, False, False), ((1080, 1920), 9000, False, False)])
+def test_surf_orientation_and_extended_bit_exact(ctx, oracle, shape, thr, upright, extended):
+    """orientation assignment + rotated sampling window (SURF_UPRIGHT = false) and the 128-element descriptor
+    (SURF_EXTENDED = true) of detect_features (VO_utility.cpp:114-119 passes both flags to SURF::create)."""
+    import ergo_uvo_amd as uvo
+    if shape[0] >= 1080:
+        from ergo_uvo_amd import synth
+        img = synth.mono_frame(synth.Scene(9, 1920), 0, 1920, 1080)              # blobs of every scale: windows up to ~700 px
+    else:
+        img = _rand_img(3, *shape)
+    ctx.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=thr, SURF_UPRIGHT=int(upright), SURF_EXTENDED=int(extended)))
+    try:
+        kps, desc = ctx.detect_features(img)
+        okps, odesc = oracle.surf(img, thr, upright=upright, extended=extended)
+        assert len(okps) > 20 and desc.shape[1] == (128 if extended else 64)
+        _assert_kps_equal(kps, okps)
+        assert np.array_equal(desc.view(np.uint32), odesc.view(np.uint32))
+        if not upright:
+            assert len(np.unique(kps["angle"])) > 10
+    finally:
+        ctx.set_params(uvo.Params.stereo())
+
+
 def test_surf_capacity_overflow_is_an_error():
     """More candidates than max_kpts (and more NMS survivors than the 4 x max_kpts list) must fail loudly, never truncate."""
     import ergo_uvo_amd as uvo
@@ -588,5 +612,9 @@ def test_misuse_is_refused_loudly(scene_small):
                 call()                                       # lane 0's buffers belong to the pair in flight; a stereo pair is not a mono frame
         assert c.stereo_collect(0.05).valid == 1
         c.detect_features(scene_small[0][0])
+        c.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=1500, SURF_EXTENDED=1))       # 128-element rows: detect_features only
+        assert c.detect_features(scene_small[0][0])[1].shape[1] == 128
+        with pytest.raises(uvo.UvoError):
+            c.stereo_step(*scene_small[0], 0.05)
     finally:
         c.close()

@@ -318,3 +318,50 @@ def test_stereo_sequence_tracks_motion_and_gates(oracle, scene_small):
     assert r.valid == 0 and r.n_tri_matches == 0 and r.n_stereo_matches > 100
     r = vo.step(*scene_small[1], 0.05)
     assert r.valid == 1
+
+
+# ---------------------------------------------------------------- SURF orientation / extended
+def test_surf_extended_folds_to_the_64_element_descriptor(oracle):
+    from ergo_uvo_amd import synth
+    img = synth.mono_frame(synth.Scene(5, 640), 0, 640, 360)
+    k0, d0 = oracle.surf(img, 800)
+    k2, d2 = oracle.surf(img, 800, extended=True)
+    assert d2.shape == (len(k0), 128) and np.array_equal(k0["x"], k2["x"])
+    # (sum tx | ty >= 0) + (sum tx | ty < 0) = sum tx, ...: the 128-element row folds to the 64-element one before normalisation
+    fold = np.stack([d2[:, 0::8] + d2[:, 2::8], d2[:, 4::8] + d2[:, 6::8], d2[:, 1::8] + d2[:, 3::8], d2[:, 5::8] + d2[:, 7::8]], -1).reshape(len(d2), 64)
+    fold /= np.linalg.norm(fold, axis=1, keepdims=True)
+    assert np.abs(fold - d0).max() < 1e-6
+    assert np.allclose(np.linalg.norm(d2, axis=1), 1.0, atol=1e-6)
+
+
+def test_surf_orientation_is_rotation_covariant(oracle):
+    """rot90 of the image: the same keypoints, orientations turned by a quarter turn, rotated-window descriptors unchanged --
+    while the upright descriptors of the same keypoints change."""
+    from ergo_uvo_amd import synth
+    img = synth.mono_frame(synth.Scene(5, 640), 0, 640, 360)
+    W = img.shape[1]
+    rot = np.ascontiguousarray(np.rot90(img))
+    k1, d1 = oracle.surf(img, 800, upright=False)
+    kr, dr = oracle.surf(rot, 800, upright=False)
+    k0, d0 = oracle.surf(img, 800)
+    ku, du = oracle.surf(rot, 800)
+    assert np.all(k0["angle"] == 270.0) and len(np.unique(np.round(k1["angle"]))) > 50
+    pos = {(round(float(a), 2), round(float(b), 2)): i for i, (a, b) in enumerate(zip(kr["x"], kr["y"]))}
+    dist, shift, dist_up = [], [], []
+    for i, (x, y) in enumerate(zip(k1["x"], k1["y"])):
+        j = pos.get((round(float(y), 2), round(float(W - 1 - x), 2)))
+        if j is not None:
+            dist.append(np.linalg.norm(d1[i] - dr[j])); shift.append((kr["angle"][j] - k1["angle"][i]) % 360); dist_up.append(np.linalg.norm(d0[i] - du[j]))
+    assert len(dist) > 0.95 * len(k1)
+    assert np.median(dist) < 0.02 and abs(np.median(shift) - 270.0) < 1.0 and np.median(dist_up) > 0.5
+
+
+def test_fast_atan2_matches_atan2_to_its_stated_accuracy(oracle):
+    import ctypes as C
+    oracle.lib().orc_fast_atan2.restype = C.c_float
+    oracle.lib().orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+    rng = np.random.default_rng(1)
+    for y, x in rng.normal(size=(500, 2)):
+        a = oracle.lib().orc_fast_atan2(float(y), float(x))
+        assert abs(((a - np.degrees(np.arctan2(y, x))) + 180) % 360 - 180) < 0.3          # cv::fastAtan2: accuracy ~0.3 degrees
+    assert oracle.lib().orc_fast_atan2(0.0, 0.0) == 0.0 and oracle.lib().orc_fast_atan2(1.0, 0.0) == 90.0
