@@ -664,6 +664,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     }
     const int li = c->next_lane;
     const double t_sub = uvo::g_bdbg ? uvo::now_us() : 0;
+    Range r_submit("uvo:stereo_submit");
     uvo_ctx* L = static_cast<uvo_ctx*>(c->lanes[li]);
     Ctx* P = c->lanes[c->prev_lane];
     L->pending = Ctx::Pending();
@@ -688,13 +689,14 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
         Ctx* H = c->lanes[(li + depth - c->a_overlap) % depth];
         UVO_HIP_TRY(c, hipStreamWaitEvent(L->stream, H->evA[0], 0));
     }
-    LANE_TRY(surf_detect(L, 2, p.MIN_NUM_FEATURES));                                       // VO:548-549, and the VO:556 gate
+    { Range r("uvo:detect_features x2"); LANE_TRY(surf_detect(L, 2, p.MIN_NUM_FEATURES)); }        // VO:548-549, and the VO:556 gate
     if (tr) UVO_HIP_TRY(c, hipEventRecord(tr->ev[1], L->stream));
     const int cap = c->cap, curr = L->as_w, prev = c->prev_buf;
     int* cn = L->d_counts;
     const float ratio = (float)p.LOWE_RATIO_THRESHOLD;
     hipStream_t st = L->stream;
     // stereo matching L -> R (VO:558), gated on device by VO:556
+    { Range r_ms("uvo:match_features stereo + select");
     LANE_TRY(match_knn2(L, L->det[0].desc, cn + CN_NQA, cap, L->det[1].desc, cn + CN_NR, cap));
     // from here on the previous pair's "after stereo match" set (another lane's buffers) is needed
     if (!c->prev_sync && P != L) UVO_HIP_TRY(c, hipStreamWaitEvent(st, P->evAS, 0));
@@ -706,7 +708,9 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
                            L->det[0].kps, L->det[1].kps, L->det[0].desc, L->d_as_kpsL[curr], L->d_as_kpsR[curr], L->d_as_descL[curr]);
     }
     UVO_HIP_TRY(c, hipEventRecord(L->evAS, st));
+    }
     // triangular matching prev-left-after-stereo -> curr-left (VO:592)
+    { Range r_mt("uvo:match_features triangular + select");
     LANE_TRY(match_knn2(L, P->d_as_descL[prev], cn + CN_NQB, cap, L->det[0].desc, cn + CN_NL, cap));
     const GateArgs gate_c = { 2, cn, p.MIN_NUM_FEATURES, cap, nullptr, nullptr };                           // VO:626
     LANE_TRY(match_ratio_compact(L, cn + CN_NQB, cap, ratio, L->d_matches[1], cn + CN_TRAW, cap, &gate_c));
@@ -716,7 +720,9 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
                            P->d_as_kpsL[prev], P->d_as_kpsR[prev], L->det[0].kps, L->d_x1, L->d_x2, L->d_xc);
     }
     UVO_HIP_TRY(c, hipGetLastError());
+    }
     // triangulation + extract_3Dpoints (VO:631-632)
+    Range r_tri("uvo:triangulatePoints + extract_3Dpoints");
     LANE_TRY(pose_triangulate(L, c->P_eye_left, c->P_right, cn + CN_T, cap));
     const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
     LANE_TRY(pose_extract3d(L, 0, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap));
@@ -753,6 +759,7 @@ static void run_stage_b(uvo_ctx* L, bool stage_a_ok)
     const uvo_params& p = L->p;
     if (G > p.MIN_NUM_3DPOINTS) {                                                          // VO:634
         j.ran = 1;
+        Range rg("uvo:solvePnPRansac");
         PnpResult r;
         Ctx* one[1] = { L };
         j.st = pose_pnp_ransac_batch(L, 1, one, &G, m->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE, &r);   // VO:647-648
@@ -801,6 +808,7 @@ extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_resul
     if (c->inflight[0] < 0 || (!c->lanes[c->inflight[0]]->pending.init_done && c->lanes[c->inflight[0]]->job.kind != 0))
         return fail(c, UVO_INVALID_ARG, "uvo_stereo_collect: the oldest entry in flight is a mono frame (uvo_mono_collect)");
     (void)hipSetDevice(c->device);
+    Range r_collect("uvo:stereo_collect");
     const uvo_params& p = c->p;
     const int li = c->inflight[0];
     for (int i = 1; i < c->n_pending; i++) c->inflight[i - 1] = c->inflight[i];
@@ -1057,6 +1065,7 @@ extern "C" uvo_status uvo_estimate_relative_pose(uvo_ctx* c, const uvo_point2f* 
 {
     if (!c || !k1 || !k2 || !K || !use_essential || !R || !t || !in1 || !in2 || !n_in || !mask || !success || n <= 0) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
+    Range r_erp("uvo:estimate_relative_pose");
     const uvo_params& p = c->p;
     if ((p.ESSENTIAL_OUTLIER_METHOD != 4 && p.ESSENTIAL_OUTLIER_METHOD != 8) || (p.HOMOGRAPHY_OUTLIER_METHOD != 4 && p.HOMOGRAPHY_OUTLIER_METHOD != 8))
         return fail(c, UVO_INVALID_ARG, "outlier methods must be 4 (LMEDS) or 8 (RANSAC)");
@@ -1125,6 +1134,7 @@ extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h
     if (c->p.SURF_EXTENDED) return fail(c, UVO_INVALID_ARG, "SURF_EXTENDED: 128-element descriptors come out of uvo_surf_detect; the matcher and the VO loops work on 64-element rows");
     (void)hipSetDevice(c->device);
     const uvo_params& p = c->p;
+    Range r_step("uvo:mono_step");
     memset(out, 0, sizeof(*out));
     c->mono_matches.clear(); c->mono_mask.clear(); c->mono_good_pts.clear();
     UVO_TRY(wait_for_producer(c, c, mem));
@@ -1250,6 +1260,7 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
     if (depth < 2) return fail(c, UVO_INVALID_ARG, "uvo_mono_submit needs at least two lanes (uvo_stereo_set_depth): a frame is matched against the previous lane's buffers");
     if (c->n_pending >= depth) return fail(c, UVO_INVALID_ARG, "uvo_mono_submit: the pipeline is full; collect a frame first (uvo_stereo_set_depth)");
     (void)hipSetDevice(c->device);
+    Range r_submit("uvo:mono_submit");
     const uvo_params& p = c->p;
     if (!c->mono_initialized) {                                                            // VO:227-245 on lane 0, synchronous
         // (earlier init frames may still await their collect: they are complete, only their result is queued)
@@ -1311,6 +1322,7 @@ static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok)
     memset(&j.mres, 0, sizeof(j.mres));
     L->mono_matches.clear(); L->mono_mask.clear(); L->mono_good_pts.clear(); L->mono_kps.clear();
     if (!stage_a_ok) { j.st = UVO_HIP_ERROR; j.err = "stage A of the frame failed"; return; }
+    Range r_b("uvo:mono estimate_relative_pose + triangulation + scale");
     auto hip_ok = [&](hipError_t e) { if (e != hipSuccess && j.st == UVO_OK) { j.st = UVO_HIP_ERROR; j.err = hipGetErrorString(e); } return e == hipSuccess; };
     const int* hc = L->h_countsA[0];
     const int cap = L->cap;

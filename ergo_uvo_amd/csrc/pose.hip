@@ -11,6 +11,7 @@
 //     sequential "better than best => shrink niters" scan over the counts to pick the identical
 //     winner; the winner's mask is recomputed and the inlier refit runs block-cooperatively with
 //     each floating-point sum kept in its sequential order.
+#include <dlfcn.h>
 #include "uvo_ctx.h"
 #include <atomic>
 #include <chrono>
@@ -416,6 +417,25 @@ uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const doubl
 // UVO_DBG_BSTAGE=1: host wall time of the PnP stage's segments, summed over calls (printed by uvo_ctx_destroy)
 bool g_bdbg = getenv("UVO_DBG_BSTAGE") != nullptr;
 std::atomic<double> g_bstat[8];
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char* e = getenv("UVO_ROCTX");
+        if (!e || !*e || *e == '0') return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { fprintf(stderr, "uvo: UVO_ROCTX is set but no roctx library could be loaded\n"); return; }
+        push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const Roctx& roctx() { static Roctx r; return r; }
+}
+void range_push(const char* name) { const Roctx& r = roctx(); if (r.push) r.push(name); }
+void range_pop() { const Roctx& r = roctx(); if (r.pop) r.pop(); }
 double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 void operator+=(std::atomic<double>& a, double v) { double o = a.load(); while (!a.compare_exchange_weak(o, o + v)) {} }
 

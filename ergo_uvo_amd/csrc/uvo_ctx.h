@@ -211,6 +211,12 @@ struct StageTimer {
     }
 };
 
+// UVO_ROCTX=1: named ranges around the phases of a step (rocprofv3 --marker-trace shows them beside the kernels).  The marker
+// library is looked up at run time (librocprofiler-sdk-roctx.so, then libroctx64.so); without the variable a range costs one load.
+void range_push(const char* name);
+void range_pop();
+struct Range { explicit Range(const char* name) { range_push(name); } ~Range() { range_pop(); } Range(const Range&) = delete; Range& operator=(const Range&) = delete; };
+
 // surf.hip
 uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int stride, int mem);
 uvo_status surf_integral(Ctx* c, int nimg);

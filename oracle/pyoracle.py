@@ -71,7 +71,8 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        _lib = C.CDLL(_LIB_PATH)
+        # UVO_ORACLE_LIB: another build of the same sources (the sanitizer build of `make -C oracle asan`, tests/test_oracle_sanitizers.py)
+        _lib = C.CDLL(os.environ.get("UVO_ORACLE_LIB") or _LIB_PATH)
         _lib.orc_l2_distance_f32.restype = C.c_float
         _lib.orc_hypot.restype = C.c_double
         _lib.orc_hypot.argtypes = [C.c_double, C.c_double]
