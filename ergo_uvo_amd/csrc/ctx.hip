@@ -85,13 +85,14 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     c->p = *p; c->device = device; c->max_w = max_w; c->max_h = max_h; c->cap = max_kpts;
     const size_t cap = (size_t)max_kpts;
     const size_t npx = (size_t)max_w * max_h, nsum = (size_t)(max_w + 1) * (max_h + 1);
-    const int nseg = (max_h + 31) / 32;
+    const int nstrip = (max_h + 7) / 8;                          // integral image: strips of 8 rows (surf.hip)
+    c->colpart_stride = ((max_w + 1 + 2047) / 2048) * 2048;
     const size_t nchunks = (cap + 127) / 128;                   // matcher shortlist: (cap/128) x cap float4 (match.hip)
     hipError_t e = hipSuccess;
 #define A(expr) do { if (e == hipSuccess) e = (expr); } while (0)
     A(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     A(hipEventCreate(&c->ev0)); A(hipEventCreate(&c->ev1));
-    c->plane_pw = (max_w + 1 + 3) / 4 + 1;
+    c->plane_pw = ((max_w + 1 + 3) / 4 + 1 + 1) & ~1;            // even: the integral kernel stores pairs of plane entries
     c->plane_stride = c->plane_pw * ((max_h + 1 + 3) / 4 + 1);
     for (int i = 0; i < 2; i++) {
         A(dalloc(&c->d_planes[i], (size_t)16 * c->plane_stride));
@@ -103,7 +104,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
         A(dalloc(&c->d_as_kpsL[i], cap)); A(dalloc(&c->d_as_kpsR[i], cap)); A(dalloc(&c->d_as_descL[i], cap * 64));
     }
     c->surv_cap = 4 * (int)cap; A(dalloc(&c->d_surv, (size_t)c->surv_cap));
-    A(dalloc(&c->d_colpart, (size_t)2 * nseg * (max_w + 1)));
+    A(dalloc(&c->d_colpart, (size_t)2 * nstrip * c->colpart_stride));
     A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_par, cap * 4)); A(dalloc(&c->d_big_patch, cap * 2 * 448));
     A(dalloc(&c->d_mpart, nchunks * cap)); A(dalloc(&c->d_mscratch, nchunks + 4)); A(dalloc(&c->d_knn_idx, cap * 2)); A(dalloc(&c->d_knn_dist, cap * 2));
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));

@@ -26,68 +26,165 @@ namespace uvo {
 // S[4i + ry][4j + rx] at [i][j].  The step-4 / step-8 sample walks of octaves 2 and 3 become unit / two-element
 // strides in them (coalesced), where the row-major image gives one useful word per 16 or 32 bytes.
 struct ImgPair { const uint8_t* img[2]; int32_t* sum[2]; int32_t* planes[2]; int pw, pstride; int* cand_n; int* big_n; int* surv_n; };
-static const int kSegRows = 32;
+// The integral image in three launches that move 4 + 4 + 33 MB for a 1080p pair (image twice, result once):
+//   k_integral_strip_sums   a workgroup per strip of 8 image rows: row prefixes in registers, their column sums over the strip
+//   k_integral_strip_scan   exclusive scan of those sums over the strips (a 135 x 1921 matrix at 1080p)
+//   k_integral_strip_final  the row prefixes again, running column sums from the scanned offsets, results to the row-major
+//                           image (through LDS, so that rows are written as consecutive words) and to the 16 planes
+// Integer arithmetic: any order of additions gives cv::integral's CV_32S values.
+static const int kStripRows = 8;
+static const int kStripCols = 2048;           // columns of the sum image per pass of a workgroup: 8 per thread
 
-__global__ __launch_bounds__(256) void k_integral_rows(ImgPair ip, int w, int h)
+// Row prefixes of the strip's rows at this thread's eight columns c0 .. c0 + 7 of the sum image: E[r] = sum of the pixels of row
+// y0 + r left of column c0 (pixel x contributes to sum columns > x); lo/hi = the eight pixels c0 .. c0 + 7 of that row, packed.
+// carry[r] (uniform) = the row's total over the previous passes, updated for the next one.
+__device__ __forceinline__ void strip_row_prefix(const uint8_t* img, int w, int h, int y0, int c0, int (*wt)[4], int (&carry)[kStripRows],
+                                                 unsigned (&lo)[kStripRows], unsigned (&hi)[kStripRows], int (&E)[kStripRows])
 {
-    const int y = blockIdx.x, im = blockIdx.z, tid = threadIdx.x;
-    const int sw = w + 1;
-    const uint8_t* src = ip.img[im] + (size_t)y * w;
-    int32_t* dst = ip.sum[im] + (size_t)(y + 1) * sw;
-    const int chunk = (w + 255) / 256;
-    const int x0 = tid * chunk;
-    // eight pixels per thread from one aligned 64-bit load when the row geometry allows (1920: chunk 8, rows 8-byte aligned)
-    const bool vec8 = chunk == 8 && (w & 7) == 0;
-    unsigned char px[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (vec8 && x0 < w) {
-        const uint2 v = *reinterpret_cast<const uint2*>(src + x0);
-        px[0] = v.x & 255u; px[1] = (v.x >> 8) & 255u; px[2] = (v.x >> 16) & 255u; px[3] = v.x >> 24;
-        px[4] = v.y & 255u; px[5] = (v.y >> 8) & 255u; px[6] = (v.y >> 16) & 255u; px[7] = v.y >> 24;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool vec8 = (w & 7) == 0;
+#pragma unroll
+    for (int r = 0; r < kStripRows; r++) {
+        const int y = y0 + r;
+        lo[r] = hi[r] = 0;
+        if (y < h && c0 < w) {
+            const uint8_t* src = img + (size_t)y * w + c0;
+            if (vec8) { const uint2 v = *reinterpret_cast<const uint2*>(src); lo[r] = v.x; hi[r] = v.y; }     // w % 8 == 0: rows and c0 are 8-byte aligned
+            else {
+                for (int k = 0; k < 8; k++) if (c0 + k < w) { if (k < 4) lo[r] |= (unsigned)src[k] << (8 * k); else hi[r] |= (unsigned)src[k] << (8 * (k - 4)); }
+            }
+        }
     }
-    int local = 0;
-    if (vec8) { for (int k = 0; k < 8; k++) local += px[k]; }
-    else for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) local += src[x]; }
-    // block exclusive scan of `local`
-    __shared__ int wsum[4];
-    int lane = tid & 63, wv = tid >> 6;
-    int inc = local;
-    for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
-    if (lane == 63) wsum[wv] = inc;
+    int local[kStripRows], inc[kStripRows];
+#pragma unroll
+    for (int r = 0; r < kStripRows; r++) inc[r] = local[r] = (int)__builtin_amdgcn_sad_u8(lo[r], 0u, __builtin_amdgcn_sad_u8(hi[r], 0u, 0u));
+    // inclusive scan over the wave in six DPP steps: within the rows of 16 lanes, then the rows' totals carried across
+#pragma unroll
+    for (int r = 0; r < kStripRows; r++) {
+        int v = inc[r];
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+        v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+        v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+        inc[r] = v;
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int r = 0; r < kStripRows; r++) wt[r][wv] = inc[r];
+    }
     __syncthreads();
-    int base = 0;
-    for (int k = 0; k < wv; k++) base += wsum[k];
-    int run = base + inc - local;
-    if (vec8) { if (x0 < w) for (int k = 0; k < 8; k++) { run += px[k]; dst[x0 + k + 1] = run; } }
-    else for (int k = 0; k < chunk; k++) { int x = x0 + k; if (x < w) { run += src[x]; dst[x + 1] = run; } }
-    if (tid == 0) dst[0] = 0;
-    if (y == 0) { int32_t* r0 = ip.sum[im]; for (int x = tid; x < sw; x += 256) r0[x] = 0; }
-    if (y == 0 && tid == 0) { ip.cand_n[im] = 0; ip.big_n[im] = 0; if (im == 0) { *ip.surv_n = 0; ip.surv_n[CN_ORI_DROP - CN_SURV] = 0; } }       // the frame's candidate / large-window / survivor counters start at zero
-}
-
-__global__ __launch_bounds__(256) void k_integral_colsum(ImgPair ip, int w, int h, int32_t* part, int nseg)
-{
-    const int sw = w + 1, x = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y, im = blockIdx.z;
-    if (x >= sw) return;
-    const int32_t* s = ip.sum[im];
-    int y0 = 1 + seg * kSegRows, y1 = min(h + 1, y0 + kSegRows);
-    int acc = 0;
-    for (int y = y0; y < y1; y++) acc += s[(size_t)y * sw + x];
-    part[((size_t)im * nseg + seg) * sw + x] = acc;
-}
-
-__global__ __launch_bounds__(256) void k_integral_colfinal(ImgPair ip, int w, int h, const int32_t* part, int nseg)
-{
-    const int sw = w + 1, x = blockIdx.x * 256 + threadIdx.x, seg = blockIdx.y, im = blockIdx.z;
-    if (x >= sw) return;
-    int32_t* s = ip.sum[im];
-    int acc = 0;
-    for (int k = 0; k < seg; k++) acc += part[((size_t)im * nseg + k) * sw + x];
-    int y0 = 1 + seg * kSegRows, y1 = min(h + 1, y0 + kSegRows);
-    int32_t* pl = ip.planes[im] + (size_t)(x & 3) * ip.pstride + (x >> 2);
-    for (int y = y0; y < y1; y++) {
-        acc += s[(size_t)y * sw + x]; s[(size_t)y * sw + x] = acc;
-        pl[(size_t)((y & 3) * 4) * ip.pstride + (size_t)(y >> 2) * ip.pw] = acc;       // (row 0 is zero from allocation)
+#pragma unroll
+    for (int r = 0; r < kStripRows; r++) {
+        const int t0 = wt[r][0], t1 = wt[r][1], t2 = wt[r][2], t3 = wt[r][3];
+        const int base = carry[r] + (wv > 0 ? t0 : 0) + (wv > 1 ? t1 : 0) + (wv > 2 ? t2 : 0);
+        E[r] = base + inc[r] - local[r];
+        carry[r] += t0 + t1 + t2 + t3;
     }
+}
+__device__ __forceinline__ int packed_px(unsigned lo, unsigned hi, int k) { return (int)(((k < 4 ? lo : hi) >> (8 * (k & 3))) & 255u); }
+
+__global__ __launch_bounds__(256) void k_integral_strip_sums(ImgPair ip, int w, int h, int32_t* part, int cstride, int nstrip)
+{
+    const int strip = blockIdx.x, im = blockIdx.y, tid = threadIdx.x;
+    __shared__ int wt[kStripRows][4];
+    int carry[kStripRows];
+#pragma unroll
+    for (int r = 0; r < kStripRows; r++) carry[r] = 0;
+    int32_t* dst = part + ((size_t)im * nstrip + strip) * cstride;
+    for (int cb = 0; cb <= w; cb += kStripCols) {
+        unsigned lo[kStripRows], hi[kStripRows]; int E[kStripRows];
+        strip_row_prefix(ip.img[im], w, h, strip * kStripRows, cb + 8 * tid, wt, carry, lo, hi, E);
+        int cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < kStripRows; r++) {
+            int run = E[r];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { cs[k] += run; run += packed_px(lo[r], hi[r], k); }
+        }
+        int4* d4 = reinterpret_cast<int4*>(dst + cb + 8 * tid);                      // cstride is a multiple of kStripCols: aligned
+        d4[0] = make_int4(cs[0], cs[1], cs[2], cs[3]); d4[1] = make_int4(cs[4], cs[5], cs[6], cs[7]);
+        __syncthreads();                                                                // wt is rewritten by the next pass
+    }
+    if (strip == 0 && tid == 0) { ip.cand_n[im] = 0; ip.big_n[im] = 0; if (im == 0) { *ip.surv_n = 0; ip.surv_n[CN_ORI_DROP - CN_SURV] = 0; } }   // the frame's candidate / large-window / survivor counters start at zero
+}
+
+// part[im][s][x] <- sum of part[im][0 .. s-1][x]: 32 columns x 8 groups of strips per workgroup
+__global__ __launch_bounds__(256) void k_integral_strip_scan(int32_t* part, int cstride, int nstrip, int w)
+{
+    const int tid = threadIdx.x, xl = tid & 31, g = tid >> 5, x = blockIdx.x * 32 + xl, im = blockIdx.y;
+    __shared__ int gsum[8][32];
+    const int per = (nstrip + 7) / 8, s0 = g * per, s1 = min(nstrip, s0 + per);
+    int32_t* p = part + (size_t)im * nstrip * cstride + x;
+    const bool live = x <= w;
+    int tot = 0;
+#pragma unroll 8
+    for (int sI = s0; sI < s1; sI++) tot += live ? p[(size_t)sI * cstride] : 0;
+    gsum[g][xl] = tot;
+    __syncthreads();
+    int acc = 0;
+    for (int k = 0; k < g; k++) acc += gsum[k][xl];
+    if (!live) return;
+#pragma unroll 8
+    for (int sI = s0; sI < s1; sI++) { const int v = p[(size_t)sI * cstride]; p[(size_t)sI * cstride] = acc; acc += v; }
+}
+
+__global__ __launch_bounds__(256) void k_integral_strip_final(ImgPair ip, int w, int h, const int32_t* part, int cstride, int nstrip)
+{
+    const int strip = blockIdx.x, im = blockIdx.y, tid = threadIdx.x;
+    const int sw = w + 1, y0 = strip * kStripRows;
+    __shared__ int wt[kStripRows][4];
+    __shared__ __align__(16) int rowbuf[kStripRows / 2][kStripCols];
+    int carry[kStripRows];
+#pragma unroll
+    for (int r = 0; r < kStripRows; r++) carry[r] = 0;
+    const int32_t* src = part + ((size_t)im * nstrip + strip) * cstride;
+    int32_t* sum = ip.sum[im];
+    int32_t* planes = ip.planes[im];
+    for (int cb = 0; cb <= w; cb += kStripCols) {
+        const int c0 = cb + 8 * tid;
+        const int4* s4 = reinterpret_cast<const int4*>(src + c0);
+        const int4 a0 = s4[0], a1 = s4[1];                                               // S[y0][c0 .. c0 + 7]
+        unsigned lo[kStripRows], hi[kStripRows]; int E[kStripRows];
+        strip_row_prefix(ip.img[im], w, h, y0, c0, wt, carry, lo, hi, E);
+        int acc[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+            for (int rr = 0; rr < kStripRows / 2; rr++) {
+                const int r = half * (kStripRows / 2) + rr, ys = y0 + r + 1;               // row of the sum image
+                int run = E[r];
+#pragma unroll
+                for (int k = 0; k < 8; k++) { acc[k] += run; run += packed_px(lo[r], hi[r], k); }
+                int4* rb = reinterpret_cast<int4*>(&rowbuf[rr][8 * tid]);
+                rb[0] = make_int4(acc[0], acc[1], acc[2], acc[3]); rb[1] = make_int4(acc[4], acc[5], acc[6], acc[7]);
+                if (ys <= h && c0 <= w) {
+                    // planes: sum column x -> plane (ys & 3, x & 3) at [ys >> 2][x >> 2]; this thread's columns give two adjacent entries per plane
+                    int32_t* pl = planes + (size_t)((ys & 3) * 4) * ip.pstride + (size_t)(ys >> 2) * ip.pw + (c0 >> 2);
+                    if (c0 + 7 <= w) {
+#pragma unroll
+                        for (int rx = 0; rx < 4; rx++) *reinterpret_cast<int2*>(pl + (size_t)rx * ip.pstride) = make_int2(acc[rx], acc[rx + 4]);   // pw, pstride even: 8-byte aligned
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; k++) if (c0 + k <= w) pl[(size_t)(k & 3) * ip.pstride + (k >> 2)] = acc[k];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < kStripRows / 2; rr++) {
+                const int ys = y0 + half * (kStripRows / 2) + rr + 1;
+                if (ys <= h) {
+                    int32_t* drow = sum + (size_t)ys * sw + cb;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { const int xs = tid + 256 * j; if (cb + xs <= w) drow[xs] = rowbuf[rr][xs]; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (strip == 0) for (int x = tid; x < sw; x += 256) sum[x] = 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1473,12 +1570,11 @@ uvo_status surf_integral(Ctx* c, int nimg)
 {
     const int w = c->img_w, h = c->img_h, sw = w + 1;
     ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
-    int nseg = (h + kSegRows - 1) / kSegRows;
+    const int nstrip = (h + kStripRows - 1) / kStripRows, cstride = c->colpart_stride;
     StageTimer t(c, ST_INTEGRAL);
-    hipLaunchKernelGGL(k_integral_rows, dim3(h, 1, nimg), dim3(256), 0, c->stream, ip, w, h);
-    dim3 g((sw + 255) / 256, nseg, nimg);
-    hipLaunchKernelGGL(k_integral_colsum, g, dim3(256), 0, c->stream, ip, w, h, c->d_colpart, nseg);
-    hipLaunchKernelGGL(k_integral_colfinal, g, dim3(256), 0, c->stream, ip, w, h, c->d_colpart, nseg);
+    hipLaunchKernelGGL(k_integral_strip_sums, dim3(nstrip, nimg), dim3(256), 0, c->stream, ip, w, h, c->d_colpart, cstride, nstrip);
+    hipLaunchKernelGGL(k_integral_strip_scan, dim3((sw + 31) / 32, nimg), dim3(256), 0, c->stream, c->d_colpart, cstride, nstrip, w);
+    hipLaunchKernelGGL(k_integral_strip_final, dim3(nstrip, nimg), dim3(256), 0, c->stream, ip, w, h, c->d_colpart, cstride, nstrip);
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }

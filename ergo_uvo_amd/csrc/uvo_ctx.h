@@ -68,7 +68,8 @@ struct Ctx {
     int32_t* d_sum[2] = {nullptr, nullptr};      // (max_h+1) x (max_w+1); = d_sum_base + kSumPad
     int32_t* d_sum_base[2] = {nullptr, nullptr}; // allocation: kSumPad ints of slack on both sides, so the Hessian tile fill can
                                                  // read whole quads of a clamped row without per-element bounds checks
-    int32_t* d_colpart = nullptr;                // [2][nseg][max_w+1]
+    int32_t* d_colpart = nullptr;                // [2][strips of 8 rows][colpart_stride]: column sums of the strips, then their scan
+    int colpart_stride = 0;
     int32_t* d_planes[2] = {nullptr, nullptr};   // integral de-interleaved by (row & 3, col & 3): 16 planes of plane_ph x plane_pw
     int plane_pw = 0, plane_stride = 0;
     uvo_keypoint* d_cand[2] = {nullptr, nullptr};// unsorted candidates

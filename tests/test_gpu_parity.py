@@ -32,6 +32,19 @@ def test_integral_exact(ctx, oracle, shape):
     assert got[-1, -1] == int(img.astype(np.int64).sum())
 
 
+def test_integral_wider_than_one_pass_and_ragged(oracle):
+    """More than 2048 sum columns (two column passes of a strip's workgroup), heights that are not multiples of the strip's 8 rows,
+    widths that are / are not multiples of 8 (vector / byte pixel loads)."""
+    import ergo_uvo_amd as uvo
+    c = uvo.Context(uvo.Params.stereo(), 0, 2600, 70, 256)
+    try:
+        for shape in ((37, 2500), (64, 2048), (9, 2047), (1, 1), (8, 8), (70, 2600), (17, 2056)):
+            img = np.random.default_rng(shape[0] * 7 + shape[1]).integers(0, 256, shape).astype(np.uint8)
+            assert np.array_equal(c.integral(img), oracle.integral(img)), shape
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("octave,layer", [(0, 0), (0, 4), (1, 2), (2, 1), (3, 0), (3, 4)])
 def test_hessian_layer_bit_exact(ctx, oracle, octave, layer):
     img = _rand_img(2, 360, 640)
