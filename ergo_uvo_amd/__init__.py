@@ -192,6 +192,7 @@ class Context:
     def match_features(self, descriptors1, descriptors2, ratio=None, matches=None):
         """match_features (VO_utility.cpp:515-543); appends to `matches` like the reference."""
         ratio = float(self.params.LOWE_RATIO_THRESHOLD if ratio is None else ratio)
+        self._check_desc_width(descriptors1, descriptors2)
         n1, n2 = int(descriptors1.shape[0]), int(descriptors2.shape[0])
         p1, m1, k1 = _ptr_mem(descriptors1, np.float32)
         p2, m2, k2 = _ptr_mem(descriptors2, np.float32)
@@ -205,7 +206,14 @@ class Context:
         self._check(self._lib.uvo_match_knn2_ratio(self._h, p1, n1, p2, n2, m1, C.c_float(ratio), _p(out), len(out), C.byref(m)))
         return out[:m.value].copy()
 
+    def _check_desc_width(self, *descs):
+        dim = 128 if self.params.SURF_EXTENDED else 64
+        for d in descs:
+            if d.ndim != 2 or int(d.shape[1]) != dim:
+                raise ValueError("descriptor rows must have %d elements (SURF_EXTENDED = %d in this context's parameters)" % (dim, int(self.params.SURF_EXTENDED)))
+
     def knn_match(self, descriptors1, descriptors2):
+        self._check_desc_width(descriptors1, descriptors2)
         n1, n2 = int(descriptors1.shape[0]), int(descriptors2.shape[0])
         p1, m1, k1 = _ptr_mem(descriptors1, np.float32)
         p2, m2, k2 = _ptr_mem(descriptors2, np.float32)
@@ -357,8 +365,8 @@ class Context:
         return r
 
     def stereo_get(self, what: str):
-        spec = {"kps_left": KP_DTYPE, "kps_right": KP_DTYPE, "desc_left": np.dtype(("f4", 64)),
-                "desc_right": np.dtype(("f4", 64)), "matches_stereo": DM_DTYPE, "matches_tri": DM_DTYPE,
+        spec = {"kps_left": KP_DTYPE, "kps_right": KP_DTYPE, "desc_left": np.dtype(("f4", 128 if self.params.SURF_EXTENDED else 64)),
+                "desc_right": np.dtype(("f4", 128 if self.params.SURF_EXTENDED else 64)), "matches_stereo": DM_DTYPE, "matches_tri": DM_DTYPE,
                 "points4d": np.dtype(("f4", 4)), "good_pts": np.dtype(("f8", 3)), "good_idx": np.dtype("i4"),
                 "inliers": np.dtype("i4")}[what]
         buf = np.zeros(self.max_kpts, spec)

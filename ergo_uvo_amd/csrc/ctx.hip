@@ -59,6 +59,7 @@ static void make_desc_weights(float* DW)
 }
 
 static void lane_worker(uvo_ctx* L);
+extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* out);
 static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok);
 static void destroy_one(uvo_ctx* c);
 
@@ -100,8 +101,8 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
         A(dalloc(&c->d_img[i], npx)); A(dalloc(&c->d_sum_base[i], nsum + 2 * kSumPad));
         if (e == hipSuccess) { e = hipMemset(c->d_sum_base[i], 0, sizeof(int32_t) * (nsum + 2 * kSumPad)); c->d_sum[i] = c->d_sum_base[i] + kSumPad; }
         A(dalloc(&c->d_cand[i], cap)); A(dalloc(&c->det[i].kps, cap)); A(dalloc(&c->det[i].desc, cap * 128));      // 128: SURF_EXTENDED rows
-        A(dalloc(&c->d_tmp_desc[i], cap * 64)); A(dalloc(&c->d_matches[i], cap));
-        A(dalloc(&c->d_as_kpsL[i], cap)); A(dalloc(&c->d_as_kpsR[i], cap)); A(dalloc(&c->d_as_descL[i], cap * 64));
+        A(dalloc(&c->d_tmp_desc[i], cap * 128)); A(dalloc(&c->d_matches[i], cap));
+        A(dalloc(&c->d_as_kpsL[i], cap)); A(dalloc(&c->d_as_kpsR[i], cap)); A(dalloc(&c->d_as_descL[i], cap * 128));
     }
     c->surv_cap = 4 * (int)cap; A(dalloc(&c->d_surv, (size_t)c->surv_cap));
     A(dalloc(&c->d_colpart, (size_t)2 * nstrip * c->colpart_stride));
@@ -279,6 +280,10 @@ extern "C" uvo_status uvo_ctx_set_params(uvo_ctx* c, const uvo_params* p)
     if (!c || !p) return UVO_INVALID_ARG;
     if (c->n_pending != 0) { c->err = "parameters cannot change while pairs are in flight"; return UVO_INVALID_ARG; }
     if (const char* why = unsupported_params(p)) { c->err = why; return UVO_INVALID_ARG; }
+    if ((p->SURF_EXTENDED != 0) != (c->p.SURF_EXTENDED != 0) && (c->vo_initialized || c->mono_initialized)) {
+        c->err = "SURF_EXTENDED changes the descriptor width: the previous frame's descriptors held by the running VO loop would not match (uvo_stereo_reset / uvo_mono_reset first)";
+        return UVO_INVALID_ARG;
+    }
     for (Ctx* l : c->lanes) l->p = *p;
     return UVO_OK;
 }
@@ -372,7 +377,7 @@ static uvo_status stage_desc(uvo_ctx* c, int slot, const float* d, int n, int me
 {
     if (n > c->cap) return fail(c, UVO_CAPACITY, "descriptor count exceeds the context's max_kpts");
     if (mem == UVO_MEM_DEVICE) { *out = d; return UVO_OK; }
-    if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->d_tmp_desc[slot], d, sizeof(float) * 64 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->d_tmp_desc[slot], d, sizeof(float) * c->desc_dim() * (size_t)n, hipMemcpyHostToDevice, c->stream));
     *out = c->d_tmp_desc[slot];
     return UVO_OK;
 }
@@ -518,13 +523,13 @@ extern "C" uvo_status uvo_rodrigues(const double* in, int n_in, double* out)
 // ------------------------------------------------------------------------------------------ stereo step
 // VO:569-579: curr_{left,right}_{descr,keypoints}_after_stereo_match by the stereo matches' indices
 __global__ __launch_bounds__(256) void k_gather_after_stereo(const uvo_dmatch* m, const int* cn, const uvo_keypoint* kL, const uvo_keypoint* kR,
-                                                             const float* dL, uvo_keypoint* okL, uvo_keypoint* okR, float* odL)
+                                                             const float* dL, uvo_keypoint* okL, uvo_keypoint* okR, float* odL, int dim)
 {
     const int meff = cn[CN_MEFF];
     const int row = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (row >= meff) return;
     const int q = m[row].queryIdx, t = m[row].trainIdx;
-    reinterpret_cast<float4*>(odL + (size_t)row * 64)[sub] = reinterpret_cast<const float4*>(dL + (size_t)q * 64)[sub];
+    for (int v = sub; v < dim / 4; v += 16) reinterpret_cast<float4*>(odL + (size_t)row * dim)[v] = reinterpret_cast<const float4*>(dL + (size_t)q * dim)[v];
     if (sub == 0) { okL[row] = kL[q]; okR[row] = kR[t]; }
 }
 // VO:601-617, 637-640: points of the triangular matches (prev left / prev right by queryIdx, curr left by trainIdx)
@@ -544,14 +549,16 @@ __global__ void k_gather_kps_idx(const uvo_keypoint* src, const int* idx, int n,
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
 }
-__global__ void k_gather_desc_idx(const float* src, int nsrc, const int* idx, int n, float* dst)
+__global__ void k_gather_desc_idx(const float* src, int nsrc, const int* idx, int n, float* dst, int dim)
 {
     int row = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (row >= n) return;
     int q = idx[row];
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // the reference leaves an out-of-range row uninitialised (VOU:690)
-    if (q >= 0 && q < nsrc) v = reinterpret_cast<const float4*>(src + (size_t)q * 64)[sub];
-    reinterpret_cast<float4*>(dst + (size_t)row * 64)[sub] = v;
+    for (int e = sub; e < dim / 4; e += 16) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);      // the reference leaves an out-of-range row uninitialised (VOU:690)
+        if (q >= 0 && q < nsrc) v = reinterpret_cast<const float4*>(src + (size_t)q * dim)[e];
+        reinterpret_cast<float4*>(dst + (size_t)row * dim)[e] = v;
+    }
 }
 
 extern "C" uvo_status uvo_stereo_set_rig(uvo_ctx* c, const double* K_left, const double* K_right, const double* R_right, const double* t_right)
@@ -566,19 +573,31 @@ extern "C" uvo_status uvo_stereo_set_rig(uvo_ctx* c, const double* K_left, const
     return uvo_stereo_reset(c);
 }
 
+// collect and drop every entry in flight, stereo pairs and mono frames alike (each collect dequeues its entry even when the pair failed)
+static void drain_in_flight(uvo_ctx* c)
+{
+    while (c->n_pending > 0) {
+        const int e = c->inflight[0];
+        const bool mono = e == Ctx::kInflightMonoInit || (e >= 0 && c->lanes[e]->job.kind == 1);
+        const int before = c->n_pending;
+        if (mono) { uvo_mono_result r; (void)uvo_mono_collect(c, 1.0, &r); }
+        else { uvo_stereo_result r; (void)uvo_stereo_collect(c, 1.0, &r); }
+        if (c->n_pending == before) break;                 // cannot happen; never spin
+    }
+}
+
 extern "C" uvo_status uvo_stereo_reset(uvo_ctx* c)
 {
     if (!c) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
-    // drain whatever is still in flight (results are dropped)
-    while (c->n_pending > 0) { uvo_stereo_result r; (void)uvo_stereo_collect(c, 1.0, &r); }
+    drain_in_flight(c);                                    // results of whatever is still in flight are dropped
     for (Ctx* l : c->lanes) {
         if (l->pnp_stream) (void)hipStreamSynchronize(l->pnp_stream);
         UVO_HIP_TRY(c, hipMemsetAsync(l->d_counts, 0, sizeof(int) * CN_TOTAL, l->stream));
         UVO_HIP_TRY(c, hipStreamSynchronize(l->stream));
         l->as_w = 0; l->pending = Ctx::Pending();
     }
-    c->vo_initialized = false; c->init_matches.clear();
+    c->vo_initialized = false; c->init_matches.clear(); c->stereo_init_results.clear();
     c->prev_lane = 0; c->prev_buf = 0; c->prev_sync = true; c->next_lane = 0;
     c->n_pending = 0; c->n_submitted = c->n_collected = 0;
     for (int i = 0; i < 3; i++) c->t_prev_curr[i] = c->rvec[i] = c->tvec[i] = 0;
@@ -621,7 +640,7 @@ static uvo_status stereo_init_step(uvo_ctx* c, uvo_stereo_result* out)
         c->as_w ^= 1; c->prev_lane = 0; c->prev_buf = b; c->prev_sync = true;
         int* d_idx = c->d_tmp_idx;     // scratch
         UVO_HIP_TRY(c, hipMemcpyAsync(d_idx, iL.data(), sizeof(int) * total, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_gather_desc_idx, dim3((total + 15) / 16), dim3(256), 0, c->stream, c->det[0].desc, nL, d_idx, total, c->d_as_descL[b]);
+        hipLaunchKernelGGL(k_gather_desc_idx, dim3((total + 15) / 16), dim3(256), 0, c->stream, c->det[0].desc, nL, d_idx, total, c->d_as_descL[b], c->desc_dim());
         hipLaunchKernelGGL(k_gather_kps_idx, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->det[0].kps, d_idx, total, c->d_as_kpsL[b]);
         UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
         UVO_HIP_TRY(c, hipMemcpyAsync(d_idx, iR.data(), sizeof(int) * total, hipMemcpyHostToDevice, c->stream));
@@ -642,24 +661,22 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
 {
     if (!c || !left || !right) return UVO_INVALID_ARG;
     if (!c->rig_set) return fail(c, UVO_INVALID_ARG, "uvo_stereo_set_rig has not been called");
-    if (c->p.SURF_EXTENDED) return fail(c, UVO_INVALID_ARG, "SURF_EXTENDED: 128-element descriptors come out of uvo_surf_detect; the matcher and the VO loops work on 64-element rows");
     const int depth = (int)c->lanes.size();
     if (c->n_pending >= depth) return fail(c, UVO_INVALID_ARG, "uvo_stereo_submit: the pipeline is full; collect a pair first (uvo_stereo_set_depth)");
     if (c->timing && c->n_pending > 0) return fail(c, UVO_INVALID_ARG, "timing mode measures one pair at a time: collect before submitting");
     (void)hipSetDevice(c->device);
     const uvo_params& p = c->p;
     if (!c->vo_initialized) {                                                               // VO:474-520, on lane 0, synchronous
-        if (c->n_pending != 0) return fail(c, UVO_INVALID_ARG, "uvo_stereo_submit: the init phase cannot be pipelined");
-        c->pending = Ctx::Pending();
-        c->pending.used = true;
-        memset(&c->pending.res, 0, sizeof(c->pending.res));
+        // (earlier init pairs may still await their collect: they are complete, only their results are queued)
+        uvo_stereo_result res;
+        memset(&res, 0, sizeof(res));
         UVO_TRY(wait_for_producer(c, c, mem));
         UVO_TRY(surf_upload(c, 0, left, w, h, stride, mem));
         UVO_TRY(surf_upload(c, 1, right, w, h, stride, mem));
         UVO_TRY(surf_detect(c, 2));
-        UVO_TRY(stereo_init_step(c, &c->pending.res));
-        c->pending.init_done = true;
-        c->inflight[c->n_pending++] = 0; c->n_submitted++;
+        UVO_TRY(stereo_init_step(c, &res));
+        c->stereo_init_results.push_back(res);
+        c->inflight[c->n_pending++] = Ctx::kInflightStereoInit; c->n_submitted++;
         c->next_lane = 0;
         return UVO_OK;
     }
@@ -670,7 +687,6 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     Ctx* P = c->lanes[c->prev_lane];
     L->pending = Ctx::Pending();
     L->pending.used = true;
-    memset(&L->pending.res, 0, sizeof(L->pending.res));
 #define LANE_TRY(expr) do { uvo_status st_ = (expr); if (st_ != UVO_OK) { if (L != c) c->err = L->err; return st_; } } while (0)
     Ctx::TraceRec* tr = nullptr;
     if (L->trace_on) {
@@ -706,7 +722,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     {
         StageTimer t(L, ST_GATHER);
         hipLaunchKernelGGL(k_gather_after_stereo, dim3((cap + 15) / 16), dim3(256), 0, st, L->d_matches[0], cn,
-                           L->det[0].kps, L->det[1].kps, L->det[0].desc, L->d_as_kpsL[curr], L->d_as_kpsR[curr], L->d_as_descL[curr]);
+                           L->det[0].kps, L->det[1].kps, L->det[0].desc, L->d_as_kpsL[curr], L->d_as_kpsR[curr], L->d_as_descL[curr], L->desc_dim());
     }
     UVO_HIP_TRY(c, hipEventRecord(L->evAS, st));
     }
@@ -806,7 +822,7 @@ extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_resul
 {
     if (!c || !out) return UVO_INVALID_ARG;
     if (c->n_pending <= 0) return fail(c, UVO_INVALID_ARG, "uvo_stereo_collect: nothing submitted");
-    if (c->inflight[0] < 0 || (!c->lanes[c->inflight[0]]->pending.init_done && c->lanes[c->inflight[0]]->job.kind != 0))
+    if (c->inflight[0] == Ctx::kInflightMonoInit || (c->inflight[0] >= 0 && c->lanes[c->inflight[0]]->job.kind != 0))
         return fail(c, UVO_INVALID_ARG, "uvo_stereo_collect: the oldest entry in flight is a mono frame (uvo_mono_collect)");
     (void)hipSetDevice(c->device);
     Range r_collect("uvo:stereo_collect");
@@ -814,11 +830,15 @@ extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_resul
     const int li = c->inflight[0];
     for (int i = 1; i < c->n_pending; i++) c->inflight[i - 1] = c->inflight[i];
     c->n_pending--; c->n_collected++;
+    if (li == Ctx::kInflightStereoInit) {                       // a synchronous init pair (its state is already applied)
+        *out = c->stereo_init_results.front();
+        c->stereo_init_results.pop_front();
+        c->last_lane = 0;
+        return UVO_OK;
+    }
     uvo_ctx* L = static_cast<uvo_ctx*>(c->lanes[li]);
     c->last_lane = li;
-    Ctx::Pending& pd = L->pending;
-    pd.used = false;
-    if (pd.init_done) { *out = pd.res; return UVO_OK; }
+    L->pending.used = false;
     {
         std::unique_lock<std::mutex> lk(L->mu);
         L->cv.wait(lk, [&] { return L->job.state == 2; });
@@ -878,8 +898,8 @@ extern "C" int uvo_stereo_get(uvo_ctx* m, const char* what, void* out, int cap_b
     std::string w(what);
     if (w == "kps_left") { src = c->det[0].kps; count = c->last_nL; esz = sizeof(uvo_keypoint); }
     else if (w == "kps_right") { src = c->det[1].kps; count = c->last_nR; esz = sizeof(uvo_keypoint); }
-    else if (w == "desc_left") { src = c->det[0].desc; count = c->last_nL; esz = 64 * sizeof(float); }
-    else if (w == "desc_right") { src = c->det[1].desc; count = c->last_nR; esz = 64 * sizeof(float); }
+    else if (w == "desc_left") { src = c->det[0].desc; count = c->last_nL; esz = c->desc_dim() * sizeof(float); }
+    else if (w == "desc_right") { src = c->det[1].desc; count = c->last_nR; esz = c->desc_dim() * sizeof(float); }
     else if (w == "matches_stereo") { src = c->d_matches[0]; count = c->last_M; esz = sizeof(uvo_dmatch); }
     else if (w == "matches_tri") { src = c->d_matches[1]; count = c->h_counts[CN_TRAW]; esz = sizeof(uvo_dmatch); }
     else if (w == "points4d") { src = c->d_pts4; count = c->last_T; esz = sizeof(float4); }
@@ -1113,7 +1133,7 @@ extern "C" uvo_status uvo_mono_set_camera(uvo_ctx* c, const double* K)
 extern "C" uvo_status uvo_mono_reset(uvo_ctx* c)
 {
     if (!c) return UVO_INVALID_ARG;
-    while (c->n_pending > 0 && (c->inflight[0] < 0 || c->lanes[c->inflight[0]]->job.kind == 1)) { uvo_mono_result r; (void)uvo_mono_collect(c, 1.0, &r); }       // mono frames still in flight are dropped
+    drain_in_flight(c);                                    // results of whatever is still in flight are dropped
     c->mono_init_results.clear();
     for (Ctx* l : c->lanes) { if (l->stream) (void)hipStreamSynchronize(l->stream); l->prev_read_pending = false; l->pending = Ctx::Pending(); }
     if (c->n_pending == 0) { c->prev_lane = 0; c->next_lane = 0; }
@@ -1132,7 +1152,6 @@ extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h
     if (!c || !img || !out) return UVO_INVALID_ARG;
     if (!c->mono_cam_set) return fail(c, UVO_INVALID_ARG, "uvo_mono_set_camera has not been called");
     if (c->mono_pipelined) return fail(c, UVO_INVALID_ARG, "uvo_mono_step after uvo_mono_submit: call uvo_mono_reset first (the previous frame is held by the pipeline)");
-    if (c->p.SURF_EXTENDED) return fail(c, UVO_INVALID_ARG, "SURF_EXTENDED: 128-element descriptors come out of uvo_surf_detect; the matcher and the VO loops work on 64-element rows");
     (void)hipSetDevice(c->device);
     const uvo_params& p = c->p;
     Range r_step("uvo:mono_step");
@@ -1149,7 +1168,7 @@ extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h
     if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->mono_kps.data(), c->det[0].kps, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     auto roll_state = [&]() -> uvo_status {                                                // VO:279-282 / VO:392-395
-        if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->d_as_descL[0], c->det[0].desc, sizeof(float) * 64 * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+        if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->d_as_descL[0], c->det[0].desc, sizeof(float) * c->desc_dim() * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
         UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->mono_prev_kps = c->mono_kps; c->mono_n_prev = n;
         return UVO_OK;
@@ -1257,7 +1276,6 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
     if (!c || !img) return UVO_INVALID_ARG;
     if (!c->mono_cam_set) return fail(c, UVO_INVALID_ARG, "uvo_mono_set_camera has not been called");
     const int depth = (int)c->lanes.size();
-    if (c->p.SURF_EXTENDED) return fail(c, UVO_INVALID_ARG, "SURF_EXTENDED: 128-element descriptors come out of uvo_surf_detect; the matcher and the VO loops work on 64-element rows");
     if (depth < 2) return fail(c, UVO_INVALID_ARG, "uvo_mono_submit needs at least two lanes (uvo_stereo_set_depth): a frame is matched against the previous lane's buffers");
     if (c->n_pending >= depth) return fail(c, UVO_INVALID_ARG, "uvo_mono_submit: the pipeline is full; collect a frame first (uvo_stereo_set_depth)");
     (void)hipSetDevice(c->device);
@@ -1269,7 +1287,7 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
         memset(&r, 0, sizeof(r));
         UVO_TRY(uvo_mono_step(c, img, w, h, stride, mem, range, 1.0, &r));                 // nothing is published before initialisation
         c->mono_init_results.push_back(r);
-        c->inflight[c->n_pending++] = -1; c->n_submitted++;                               // -1: a synchronous init frame
+        c->inflight[c->n_pending++] = Ctx::kInflightMonoInit; c->n_submitted++;                // a synchronous init frame
         c->prev_lane = 0; c->next_lane = 1 % depth;
         UVO_HIP_TRY(c, hipEventRecord(c->evDet, c->stream));                               // lane 0 holds the frame the next one matches against
         return UVO_OK;
@@ -1400,7 +1418,7 @@ extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* o
 {
     if (!c || !out) return UVO_INVALID_ARG;
     if (c->n_pending <= 0) return fail(c, UVO_INVALID_ARG, "uvo_mono_collect: nothing submitted");
-    if (c->inflight[0] >= 0 && (c->lanes[c->inflight[0]]->pending.init_done || c->lanes[c->inflight[0]]->job.kind != 1))
+    if (c->inflight[0] == Ctx::kInflightStereoInit || (c->inflight[0] >= 0 && c->lanes[c->inflight[0]]->job.kind != 1))
         return fail(c, UVO_INVALID_ARG, "uvo_mono_collect: the oldest entry in flight is a stereo pair (uvo_stereo_collect)");
     (void)hipSetDevice(c->device);
     const int li = c->inflight[0];

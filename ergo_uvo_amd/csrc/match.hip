@@ -76,10 +76,13 @@ __device__ __forceinline__ void split_bf16x8(const float4 v0, const float4 v1, u
     split_bf16(v1.x, v1.y, hi.z, lo.z); split_bf16(v1.z, v1.w, hi.w, lo.w);
 }
 
-static const int kRowQuads = 17;               // uint4 per staged row: 8 of hi (64 bf16), 8 of lo, 1 of padding (68 words: the lanes'
-                                               // b128 reads spread over the LDS banks)
+// D = 64 (SURF) or 128 (SURF_EXTENDED) elements per descriptor.  uint4 per staged row: D/8 of hi (bf16), D/8 of lo, 1 of padding
+// (68 or 132 words: the lanes' b128 reads spread over the LDS banks)
+template <int D> struct RowQuads { static constexpr int value = D / 4 + 1; };
+template <int D> static constexpr size_t match_rows_lds() { return sizeof(uint4) * kMfmaChunk * RowQuads<D>::value; }
 
 // part: [chunk][cap] (k0, k1, k2, k3): the four smallest shortlist keys; chunk_tnmax[chunk]: max |t|^2 of the chunk's rows
+template <int D>
 __global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ dq, const int* nq_p, int nq_imm,
                                                     const float* __restrict__ dt, const int* nt_p, int nt_imm,
                                                     int cap, float4* part, float* chunk_tnmax)
@@ -87,7 +90,8 @@ __global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ dq
     const int nq = nq_p ? *nq_p : nq_imm, nt = nt_p ? *nt_p : nt_imm;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __shared__ __align__(16) float s_tn[kMfmaChunk];                     // |t|^2 of the staged rows (kBig past the end: never wins)
-    __shared__ uint4 s_rows[kMfmaChunk * kRowQuads];                     // the chunk's train rows as bf16 hi | lo, shared by the four waves
+    extern __shared__ uint4 s_rows[];                                    // [kMfmaChunk][kRowQuads]: the chunk's train rows as bf16 hi | lo, shared by the four waves
+    constexpr int kRowQuads = RowQuads<D>::value, M = D / 16, QW = D / 4;
     __shared__ int s_wmax;
     const int n = lane & 31, h = lane >> 5;
     // the counts live on the device, so the grid is a fixed number of workgroups that walk the (query tile, train chunk)
@@ -98,25 +102,26 @@ __global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ dq
         const int q0 = tile_q * 128 + wave * 32, t0 = tile_c * kMfmaChunk;
         // B operand: this lane's query; MFMA m of a step consumes k = 16m + 8h + j (j = 0..7) from both operands
         const int q = q0 + n;
-        uint4 bhi[4], blo[4];
+        uint4 bhi[M], blo[M];
         {
-            const float4* src = reinterpret_cast<const float4*>(dq + (size_t)min(q, nq - 1) * 64);
+            const float4* src = reinterpret_cast<const float4*>(dq + (size_t)min(q, nq - 1) * D);
 #pragma unroll
-            for (int m = 0; m < 4; m++) split_bf16x8(src[4 * m + 2 * h], src[4 * m + 2 * h + 1], bhi[m], blo[m]);
+            for (int m = 0; m < M; m++) split_bf16x8(src[4 * m + 2 * h], src[4 * m + 2 * h + 1], bhi[m], blo[m]);
         }
         if (threadIdx.x == 0) s_wmax = 0;
         __syncthreads();
-        {   // stage the chunk once: 128 rows x 16 float4, coalesced, split into bf16 hi / lo; rows past the end repeat the last one
+        {   // stage the chunk once: 128 rows x D/4 float4, coalesced, split into bf16 hi / lo; rows past the end repeat the last one
             const float4* src = reinterpret_cast<const float4*>(dt);
-            for (int e = threadIdx.x; e < kMfmaChunk * 16; e += 256) {
-                const int r = e >> 4, c4 = e & 15;
-                const float4 v = src[(size_t)min(t0 + r, nt - 1) * 16 + c4];
+            for (int e = threadIdx.x; e < kMfmaChunk * QW; e += 256) {
+                const int r = e / QW, c4 = e % QW;
+                const float4 v = src[(size_t)min(t0 + r, nt - 1) * QW + c4];
                 uint2 hi, lo;
                 split_bf16(v.x, v.y, hi.x, lo.x); split_bf16(v.z, v.w, hi.y, lo.y);
                 uint2* row = reinterpret_cast<uint2*>(s_rows + r * kRowQuads);
-                row[c4] = hi; row[16 + c4] = lo;
-                // |t|^2 of the row (any summation order will do: the margin absorbs it): its 16 quarter-rows sit on 16 adjacent lanes
+                row[c4] = hi; row[QW + c4] = lo;
+                // |t|^2 of the row (any summation order will do: the margin absorbs it): its D/4 pieces sit on D/4 adjacent lanes
                 float tn = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, __builtin_fmaf(v.z, v.z, v.w * v.w)));
+                if (QW == 32) tn += __shfl_xor(tn, 16);
                 tn += __shfl_xor(tn, 8); tn += __shfl_xor(tn, 4); tn += __shfl_xor(tn, 2); tn += __shfl_xor(tn, 1);
                 if (c4 == 0) {
                     const bool valid = t0 + r < nt;
@@ -135,8 +140,8 @@ __global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ dq
 #pragma unroll
             for (int j = 0; j < 16; j++) acc[j] = 0.f;
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                const bf16x8 ahi = __builtin_bit_cast(bf16x8, rowp[2 * m + h]), alo = __builtin_bit_cast(bf16x8, rowp[8 + 2 * m + h]);
+            for (int m = 0; m < M; m++) {
+                const bf16x8 ahi = __builtin_bit_cast(bf16x8, rowp[2 * m + h]), alo = __builtin_bit_cast(bf16x8, rowp[D / 8 + 2 * m + h]);
                 const bf16x8 qhi = __builtin_bit_cast(bf16x8, bhi[m]), qlo = __builtin_bit_cast(bf16x8, blo[m]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, qhi, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, qlo, acc, 0, 0, 0);
@@ -179,22 +184,27 @@ __device__ __forceinline__ void top2_lex(float d, int t, float& d0, int& i0, flo
     if (d < d0 || (d == d0 && t < i0)) { d1 = d0; i1 = i0; d0 = d; i0 = t; }
     else if (d < d1 || (d == d1 && t < i1)) { d1 = d; i1 = t; }
 }
-// normL2Sqr_ + sqrt with the 16 accumulators on the 16 lanes of a group: lane l holds q[4l..4l+3]; returns on every lane
-__device__ __forceinline__ float group_distance_tv(const float4 qv, const float4 tv, int sub)
+// normL2Sqr_ + sqrt with the 16 accumulators on the 16 lanes of a group: lane l holds elements 64v + 4l .. 64v + 4l + 3 of the row
+// in its v-th float4 (v < D/64); returns on every lane
+template <int NV>
+__device__ __forceinline__ float group_distance_tv(const float4 (&qv)[NV], const float4 (&tv)[NV], int sub)
 {
-    // accumulator a (= j mod 16) sums elements a, a+16, a+32, a+48 in that order; element e lives in lane e/4, slot e%4
-    // lane `sub` computes accumulator a = sub: it needs q/t elements sub + 16k, i.e. slot sub%4 of lane sub/4 + 4k
-    const float dx = qv.x - tv.x, dy = qv.y - tv.y, dz = qv.z - tv.z, dw = qv.w - tv.w;
-    const float px = dx * dx, py = dy * dy, pz = dz * dz, pw = dw * dw;       // squared differences of elements 4sub..4sub+3
+    // accumulator a (= j mod 16) sums elements a, a+16, a+32, ... in that order; element e lives in float4 e/64 of lane (e%64)/4, slot e%4:
+    // lane `sub` computes accumulator a = sub from slot sub%4 of lanes sub/4 + 4k (k = 0..3), first float4 first
     const int base = (threadIdx.x & 63 & ~15);
+    const int slot = sub & 3;
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int src = base + (sub >> 2) + 4 * k;           // lane holding element sub + 16k
-        const float vx = __shfl(px, src), vy = __shfl(py, src), vz = __shfl(pz, src), vw = __shfl(pw, src);
-        const int slot = sub & 3;
-        const float term = slot == 0 ? vx : (slot == 1 ? vy : (slot == 2 ? vz : vw));
-        acc = term + acc;
+    for (int v = 0; v < NV; v++) {
+        const float dx = qv[v].x - tv[v].x, dy = qv[v].y - tv[v].y, dz = qv[v].z - tv[v].z, dw = qv[v].w - tv[v].w;
+        const float px = dx * dx, py = dy * dy, pz = dz * dz, pw = dw * dw;       // squared differences of this lane's four elements
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int src = base + (sub >> 2) + 4 * k;           // lane holding element 64v + sub + 16k
+            const float vx = __shfl(px, src), vy = __shfl(py, src), vz = __shfl(pz, src), vw = __shfl(pw, src);
+            const float term = slot == 0 ? vx : (slot == 1 ? vy : (slot == 2 ? vz : vw));
+            acc = term + acc;
+        }
     }
     // v[l] = ((acc[l] + acc[4+l]) + acc[8+l]) + acc[12+l], d = (v0 + v2) + (v1 + v3)
     const int l = sub & 3;
@@ -203,11 +213,21 @@ __device__ __forceinline__ float group_distance_tv(const float4 qv, const float4
     const float v0 = __shfl(v, base + 0), v1 = __shfl(v, base + 1), v2 = __shfl(v, base + 2), v3 = __shfl(v, base + 3);
     return sqrtf((v0 + v2) + (v1 + v3));
 }
-__device__ __forceinline__ float group_distance(const float4 qv, const float* __restrict__ trow, int sub)
+template <int NV>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, int sub, float4 (&out)[NV])
 {
-    return group_distance_tv(qv, reinterpret_cast<const float4*>(trow)[sub], sub);
+#pragma unroll
+    for (int v = 0; v < NV; v++) out[v] = reinterpret_cast<const float4*>(row)[16 * v + sub];
+}
+template <int NV>
+__device__ __forceinline__ float group_distance(const float4 (&qv)[NV], const float* __restrict__ trow, int sub)
+{
+    float4 tv[NV];
+    load_row<NV>(trow, sub, tv);
+    return group_distance_tv<NV>(qv, tv, sub);
 }
 
+template <int D>
 __global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__ dq, const int* nq_p, int nq_imm,
                                                       const float* __restrict__ dt, const int* nt_p, int nt_imm,
                                                       int cap, const float4* part, const float* chunk_tnmax,
@@ -219,8 +239,12 @@ __global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__
     if (blockIdx.x * 16 >= nq) return;
     const bool live = q < nq;                              // whole groups are live or not
     const int qq = live ? q : nq - 1;
-    const float4 qv = reinterpret_cast<const float4*>(dq + (size_t)qq * 64)[sub];
-    float qn = qv.x*qv.x + qv.y*qv.y + qv.z*qv.z + qv.w*qv.w;
+    constexpr int NV = D / 64;
+    float4 qv[NV];
+    load_row<NV>(dq + (size_t)qq * D, sub, qv);
+    float qn = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; v++) qn += qv[v].x*qv[v].x + qv[v].y*qv[v].y + qv[v].z*qv[v].z + qv[v].w*qv[v].w;
     qn += __shfl_xor(qn, 8); qn += __shfl_xor(qn, 4); qn += __shfl_xor(qn, 2); qn += __shfl_xor(qn, 1);
     const int nchunks = (nt + kMfmaChunk - 1) / kMfmaChunk;
     // pass 1: two smallest S' over all candidates of this query (lanes stride the chunks)
@@ -258,7 +282,7 @@ __global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__
             const int l = __ffs(gm_scan) - 1;
             gm_scan &= gm_scan - 1;
             const int cc = cb + l, te = min((cc + 1) * kMfmaChunk, nt);
-            for (int t = cc * kMfmaChunk; t < te; t++) top2_lex(group_distance(qv, dt + (size_t)t * 64, sub), t, d0, i0, d1, i1);
+            for (int t = cc * kMfmaChunk; t < te; t++) top2_lex(group_distance<NV>(qv, dt + (size_t)t * D, sub), t, d0, i0, d1, i1);
         }
         if (scan) { a = -1; b = -1; e3 = -1; }             // covered by the scan
         // the other chunks' candidates: slot s = 16*which + lane; four train rows are fetched at a time (one memory round trip
@@ -276,12 +300,12 @@ __global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__
                 const int va = __shfl(a, ln), vb = __shfl(b, ln), vc = __shfl(e3, ln);
                 cnd[k] = sl < 0 ? -1 : (sl < 16 ? va : (sl < 32 ? vb : vc));
             }
-            float4 tv[4];
+            float4 tv[4][NV];
 #pragma unroll
-            for (int k = 0; k < 4; k++) tv[k] = reinterpret_cast<const float4*>(dt + (size_t)max(cnd[k], 0) * 64)[sub];
+            for (int k = 0; k < 4; k++) load_row<NV>(dt + (size_t)max(cnd[k], 0) * D, sub, tv[k]);
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (cnd[k] >= 0) top2_lex(group_distance_tv(qv, tv[k], sub), cnd[k], d0, i0, d1, i1);
+                if (cnd[k] >= 0) top2_lex(group_distance_tv<NV>(qv, tv[k], sub), cnd[k], d0, i0, d1, i1);
         }
     }
     if (live && sub == 0) {
@@ -341,25 +365,38 @@ __global__ __launch_bounds__(1024) void k_match_compact(const int* knn_idx, cons
     }
 }
 
-uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, const float* d_t, const int* d_nt, int nt_max)
+template <int D>
+static uvo_status match_knn2_d(Ctx* c, const float* d_q, const int* d_nq, int nq_max, const float* d_t, const int* d_nt, int nt_max)
 {
-    if (nq_max <= 0 || nt_max <= 0) return UVO_OK;
-    if (nq_max > c->cap || nt_max > c->cap) { c->err = "match: descriptor count exceeds the context's max_kpts"; return UVO_CAPACITY; }
     float* tnmax = c->d_mscratch;                    // [chunk] max |t|^2
     {
         StageTimer t(c, ST_MATCH);
         const int tiles_max = ((nq_max + 127) / 128) * ((nt_max + kMfmaChunk - 1) / kMfmaChunk);
         dim3 grid(tiles_max < 768 ? tiles_max : 768);          // three workgroups per CU; larger problems loop
-        hipLaunchKernelGGL(k_match_mfma, grid, dim3(256), 0, c->stream, d_q, d_nq, nq_max, d_t, d_nt, nt_max, c->cap, c->d_mpart, tnmax);
+        static bool attr_set = false;                          // more than 64 KB of LDS (D = 128) has to be asked for, once per process
+        if (!attr_set && match_rows_lds<D>() > 48 * 1024) {
+            UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_mfma<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)match_rows_lds<D>()));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_match_mfma<D>, grid, dim3(256), match_rows_lds<D>(), c->stream, d_q, d_nq, nq_max, d_t, d_nt, nt_max, c->cap, c->d_mpart, tnmax);
         UVO_HIP_TRY(c, hipGetLastError());
     }
     {
         StageTimer t(c, ST_MATCH_MERGE);
-        hipLaunchKernelGGL(k_match_resolve, dim3((nq_max + 15) / 16), dim3(256), 0, c->stream, d_q, d_nq, nq_max, d_t, d_nt, nt_max,
+        hipLaunchKernelGGL(k_match_resolve<D>, dim3((nq_max + 15) / 16), dim3(256), 0, c->stream, d_q, d_nq, nq_max, d_t, d_nt, nt_max,
                            c->cap, c->d_mpart, tnmax, c->d_knn_idx, c->d_knn_dist);
         UVO_HIP_TRY(c, hipGetLastError());
     }
     return UVO_OK;
+}
+
+// rows of c->desc_dim() floats: SURF::descriptorSize(), 64 or 128 (SURF_EXTENDED)
+uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, const float* d_t, const int* d_nt, int nt_max)
+{
+    if (nq_max <= 0 || nt_max <= 0) return UVO_OK;
+    if (nq_max > c->cap || nt_max > c->cap) { c->err = "match: descriptor count exceeds the context's max_kpts"; return UVO_CAPACITY; }
+    return c->desc_dim() == 128 ? match_knn2_d<128>(c, d_q, d_nq, nq_max, d_t, d_nt, nt_max)
+                                : match_knn2_d<64>(c, d_q, d_nq, nq_max, d_t, d_nt, nt_max);
 }
 
 uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio, uvo_dmatch* d_out, int* d_nout, int out_cap,

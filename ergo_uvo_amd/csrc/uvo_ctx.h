@@ -146,7 +146,8 @@ struct Ctx {
     int prev_lane = 0, prev_buf = 0;             // master: where the previous pair's as-set lives
     bool prev_sync = true;                       // master: that set was written synchronously (init step), no event to wait for
     int next_lane = 0;                           // master: lane of the next submitted pair
-    struct Pending { bool used = false; bool init_done = false; uvo_stereo_result res; };
+    struct Pending { bool used = false; };
+    static const int kInflightMonoInit = -1, kInflightStereoInit = -2;      // inflight[] entries of the synchronous init frames / pairs (else: the lane)
     Pending pending;                             // this lane's pair
     int inflight[8]; int n_pending = 0;          // master: lanes of the submitted, not yet collected pairs (FIFO)
     long long n_submitted = 0, n_collected = 0;
@@ -181,6 +182,7 @@ struct Ctx {
     std::vector<uvo_keypoint> mono_prev_kps, mono_kps;   // host copies (prev frame / last frame)
     int mono_n_prev = 0;                         // rows of the prev descriptors kept in d_as_descL[0]
     std::deque<uvo_mono_result> mono_init_results;   // uvo_mono_submit: results of the synchronous init frames awaiting their collect
+    std::deque<uvo_stereo_result> stereo_init_results;   // uvo_stereo_submit: the same for the stereo init pairs (VO:474-520)
     std::vector<uvo_dmatch> mono_matches; std::vector<uint8_t> mono_mask; std::vector<double> mono_good_pts;
 
     // ---- UVO_TRACE=<file>: device timestamps of every pipelined pair's phases (hipEvents with timing), written as CSV by
@@ -189,6 +191,8 @@ struct Ctx {
     struct TraceRec { long long pair = -1; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool b_used = false; };
     std::vector<TraceRec> trace; int trace_cur = -1; long long trace_count = 0;
     bool trace_on = false;
+
+    int desc_dim() const { return p.SURF_EXTENDED ? 128 : 64; }      // SURF::descriptorSize(): floats per descriptor row
 
     // ---- timing ----
     bool timing = false;

@@ -319,16 +319,17 @@ void detect_features(Mat img, vector<KeyPoint>& keypoints, Mat& descriptors)
 namespace {
 vector<float> tight_descriptors(const Mat& d, const char* what)
 {
-    require(d.empty() || (d.type() == CV_32FC1 && d.cols == 64), what);
-    vector<float> v((size_t)d.rows * 64);
-    for (int i = 0; i < d.rows; i++) memcpy(v.data() + (size_t)i * 64, d.ptr<float>(i), sizeof(float) * 64);
+    const int dsize = SURF_EXTENDED ? 128 : 64;      // the rows detect_features produced under the same parameters
+    require(d.empty() || (d.type() == CV_32FC1 && d.cols == dsize), what);
+    vector<float> v((size_t)d.rows * dsize);
+    for (int i = 0; i < d.rows; i++) memcpy(v.data() + (size_t)i * dsize, d.ptr<float>(i), sizeof(float) * dsize);
     return v;
 }
 // BFMatcher(NORM_L2).knnMatch(k = 2) + Lowe ratio; results are APPENDED to `matches` as the reference's push_back does
 void match_impl(const Mat& d1, const Mat& d2, vector<DMatch>& matches)
 {
-    vector<float> a = tight_descriptors(d1, "match_features: descriptors1 must be N x 64 CV_32F");
-    vector<float> b = tight_descriptors(d2, "match_features: descriptors2 must be N x 64 CV_32F");
+    vector<float> a = tight_descriptors(d1, "match_features: descriptors1 must be CV_32F with SURF's descriptor size (64, or 128 with SURF_EXTENDED) columns");
+    vector<float> b = tight_descriptors(d2, "match_features: descriptors2 must be CV_32F with SURF's descriptor size (64, or 128 with SURF_EXTENDED) columns");
     const int n1 = d1.rows, n2 = d2.rows;
     if (n1 == 0) return;
     vector<uvo_dmatch> out((size_t)n1);

@@ -173,8 +173,8 @@ orc_mono* orc_mono_create(const orc_vo_params* p, const double* K, int max_kpts)
     s->p = *p; memcpy(s->K, K, sizeof(s->K)); s->cap = max_kpts; s->use_essential = 1; s->SF = 1.0;
     s->R[0] = s->R[4] = s->R[8] = 1.0;
     size_t c = (size_t)max_kpts;
-    s->prev_kps = (orc_keypoint*)malloc(sizeof(orc_keypoint)*c); s->prev_desc = (float*)malloc(sizeof(float)*64*c);
-    s->kps = (orc_keypoint*)malloc(sizeof(orc_keypoint)*c); s->desc = (float*)malloc(sizeof(float)*64*c);
+    s->prev_kps = (orc_keypoint*)malloc(sizeof(orc_keypoint)*c); s->prev_desc = (float*)malloc(sizeof(float)*128*c);
+    s->kps = (orc_keypoint*)malloc(sizeof(orc_keypoint)*c); s->desc = (float*)malloc(sizeof(float)*128*c);
     s->matches = (orc_dmatch*)malloc(sizeof(orc_dmatch)*c); s->mask = (uint8_t*)malloc(c);
     s->good_pts = (double*)malloc(sizeof(double)*3*c);
     return s;
@@ -195,14 +195,14 @@ int orc_mono_step(orc_mono* s, const uint8_t* img, int w, int h, int stride, dou
     if (n < 0) n = s->cap;
     s->n_kps = n; out->n_kps = n;
     if (!s->vo_initialized) {                                            /* VO:227-245 */
-        memcpy(s->prev_kps, s->kps, sizeof(orc_keypoint)*(size_t)n); memcpy(s->prev_desc, s->desc, sizeof(float)*64*(size_t)n); s->n_prev = n;
+        memcpy(s->prev_kps, s->kps, sizeof(orc_keypoint)*(size_t)n); memcpy(s->prev_desc, s->desc, sizeof(float)*(p->SURF_EXTENDED ? 128 : 64)*(size_t)n); s->n_prev = n;
         if (n >= p->MIN_NUM_FEATURES) s->vo_initialized = 1;
         return 0;
     }
     out->initialized = 1;
-#define ROLL_STATE() do { memcpy(s->prev_kps, s->kps, sizeof(orc_keypoint)*(size_t)n); memcpy(s->prev_desc, s->desc, sizeof(float)*64*(size_t)n); s->n_prev = n; } while (0)
+#define ROLL_STATE() do { memcpy(s->prev_kps, s->kps, sizeof(orc_keypoint)*(size_t)n); memcpy(s->prev_desc, s->desc, sizeof(float)*(p->SURF_EXTENDED ? 128 : 64)*(size_t)n); s->n_prev = n; } while (0)
     if (n < p->MIN_NUM_FEATURES) { ROLL_STATE(); return 0; }             /* VO:276-284 */
-    orc_match_knn2_ratio(s->prev_desc, s->n_prev, s->desc, n, 64, (float)p->LOWE_RATIO_THRESHOLD, s->matches, s->cap, &s->n_matches);   /* VO:287 */
+    orc_match_knn2_ratio(s->prev_desc, s->n_prev, s->desc, n, p->SURF_EXTENDED ? 128 : 64, (float)p->LOWE_RATIO_THRESHOLD, s->matches, s->cap, &s->n_matches);   /* VO:287 */
     int M = s->n_matches;
     out->n_matches = M;
     if (M < p->MIN_NUM_FEATURES) { ROLL_STATE(); return 0; }             /* VO:299-307 */

@@ -54,9 +54,9 @@ orc_stereo* orc_stereo_create(const orc_vo_params* p, const double* K_left, cons
     s->results_match_prev = (orc_dmatch*)malloc(sizeof(orc_dmatch) * c * 4);
     s->prevL_kps_as = (orc_keypoint*)malloc(sizeof(orc_keypoint) * c * 4);
     s->prevR_kps_as = (orc_keypoint*)malloc(sizeof(orc_keypoint) * c * 4);
-    s->prevL_desc_as = (float*)malloc(sizeof(float) * 64 * c * 4);
+    s->prevL_desc_as = (float*)malloc(sizeof(float) * 128 * c * 4);
     s->kpsL = (orc_keypoint*)malloc(sizeof(orc_keypoint) * c); s->kpsR = (orc_keypoint*)malloc(sizeof(orc_keypoint) * c);
-    s->descL = (float*)malloc(sizeof(float) * 64 * c); s->descR = (float*)malloc(sizeof(float) * 64 * c);
+    s->descL = (float*)malloc(sizeof(float) * 128 * c); s->descR = (float*)malloc(sizeof(float) * 128 * c);
     s->m_curr = (orc_dmatch*)malloc(sizeof(orc_dmatch) * c); s->m_pc = (orc_dmatch*)malloc(sizeof(orc_dmatch) * c * 4);
     s->points4D = (float*)malloc(sizeof(float) * 4 * c * 4);
     s->good_pts = (double*)malloc(sizeof(double) * 3 * c * 4); s->good_idx = (int*)malloc(sizeof(int) * c * 4);
@@ -87,13 +87,15 @@ static int gather_keypoints(const orc_keypoint* src, int nsrc, const int* idx, i
     for (int i = 0; i < nidx; i++) if (idx[i] >= 0 && idx[i] < nsrc) dst[k++] = src[idx[i]];
     return k;
 }
-static void gather_descriptors(const float* src, int nsrc, const int* idx, int nidx, float* dst)
+static void gather_descriptors(const float* src, int nsrc, const int* idx, int nidx, float* dst, int dim)
 {
     for (int i = 0; i < nidx; i++) {
-        if (idx[i] >= 0 && idx[i] < nsrc) memcpy(dst + (size_t)i*64, src + (size_t)idx[i]*64, sizeof(float)*64);
-        else memset(dst + (size_t)i*64, 0, sizeof(float)*64);   /* reference leaves the row uninitialised */
+        if (idx[i] >= 0 && idx[i] < nsrc) memcpy(dst + (size_t)i*dim, src + (size_t)idx[i]*dim, sizeof(float)*dim);
+        else memset(dst + (size_t)i*dim, 0, sizeof(float)*dim);   /* reference leaves the row uninitialised */
     }
 }
+/* SURF::descriptorSize(): 64, or 128 with `extended` */
+static int desc_dim(const orc_stereo* s) { return s->p.SURF_EXTENDED ? 128 : 64; }
 
 int orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
                     double dt, orc_stereo_result* out)
@@ -110,14 +112,14 @@ int orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* right, in
     if (!s->vo_initialized) {
         /* ---- VO:474-520 ---- */
         if (s->nL >= p->MIN_NUM_FEATURES && s->nR >= p->MIN_NUM_FEATURES) {
-            orc_match_knn2_ratio(s->descL, s->nL, s->descR, s->nR, 64, (float)p->LOWE_RATIO_THRESHOLD,
+            orc_match_knn2_ratio(s->descL, s->nL, s->descR, s->nR, desc_dim(s), (float)p->LOWE_RATIO_THRESHOLD,
                                  s->results_match_prev, s->cap * 4, &s->n_match_prev);
             if (s->n_match_prev > p->MIN_NUM_FEATURES) s->vo_initialized = 1;
         }
         out->n_stereo_matches = s->n_match_prev;
         if (s->vo_initialized) {
             for (int i = 0; i < s->n_match_prev; i++) { ia[i] = s->results_match_prev[i].queryIdx; ib[i] = s->results_match_prev[i].trainIdx; }
-            gather_descriptors(s->descL, s->nL, ia, s->n_match_prev, s->prevL_desc_as); s->n_prevL_desc_as = s->n_match_prev;
+            gather_descriptors(s->descL, s->nL, ia, s->n_match_prev, s->prevL_desc_as, desc_dim(s)); s->n_prevL_desc_as = s->n_match_prev;
             s->n_prevL_as = gather_keypoints(s->kpsL, s->nL, ia, s->n_match_prev, s->prevL_kps_as);
             s->n_prevR_as = gather_keypoints(s->kpsR, s->nR, ib, s->n_match_prev, s->prevR_kps_as);
             memcpy(s->m_curr, s->results_match_prev, sizeof(orc_dmatch) * (size_t)(s->n_match_prev < s->cap ? s->n_match_prev : s->cap));
@@ -133,20 +135,21 @@ int orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* right, in
     int valid = 0;
     orc_keypoint* currL_kps_as = (orc_keypoint*)malloc(sizeof(orc_keypoint) * (size_t)s->cap);
     orc_keypoint* currR_kps_as = (orc_keypoint*)malloc(sizeof(orc_keypoint) * (size_t)s->cap);
-    float* currL_desc_as = (float*)malloc(sizeof(float) * 64 * (size_t)s->cap);
+    float* currL_desc_as = (float*)malloc(sizeof(float) * 128 * (size_t)s->cap);
+    const int dim = desc_dim(s);
     int n_currL_as = 0, n_currR_as = 0, n_currL_desc_as = 0;
 
     if (s->nL >= p->MIN_NUM_FEATURES && s->nR >= p->MIN_NUM_FEATURES) {                     /* VO:556 */
-        orc_match_knn2_ratio(s->descL, s->nL, s->descR, s->nR, 64, (float)p->LOWE_RATIO_THRESHOLD,
+        orc_match_knn2_ratio(s->descL, s->nL, s->descR, s->nR, desc_dim(s), (float)p->LOWE_RATIO_THRESHOLD,
                              s->m_curr, s->cap, &s->n_m_curr);                              /* VO:558 */
         if (s->n_m_curr > p->MIN_NUM_FEATURES) {                                             /* VO:567 */
             for (int i = 0; i < s->n_m_curr; i++) { ia[i] = s->m_curr[i].queryIdx; ib[i] = s->m_curr[i].trainIdx; }
-            gather_descriptors(s->descL, s->nL, ia, s->n_m_curr, currL_desc_as); n_currL_desc_as = s->n_m_curr;   /* VO:576 */
+            gather_descriptors(s->descL, s->nL, ia, s->n_m_curr, currL_desc_as, dim); n_currL_desc_as = s->n_m_curr;   /* VO:576 */
             n_currL_as = gather_keypoints(s->kpsL, s->nL, ia, s->n_m_curr, currL_kps_as);                         /* VO:578 */
             n_currR_as = gather_keypoints(s->kpsR, s->nR, ib, s->n_m_curr, currR_kps_as);                         /* VO:579 */
 
             /* triangular matching VO:592 */
-            orc_match_knn2_ratio(s->prevL_desc_as, s->n_prevL_desc_as, s->descL, s->nL, 64, (float)p->LOWE_RATIO_THRESHOLD,
+            orc_match_knn2_ratio(s->prevL_desc_as, s->n_prevL_desc_as, s->descL, s->nL, desc_dim(s), (float)p->LOWE_RATIO_THRESHOLD,
                                  s->m_pc, s->cap * 4, &s->n_m_pc);
             int T = s->n_m_pc;
             for (int i = 0; i < T; i++) { ia[i] = s->m_pc[i].queryIdx; ib[i] = s->m_pc[i].trainIdx; }
@@ -198,7 +201,7 @@ int orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* right, in
     /* state carry VO:727-733 (happens on failure too, with possibly empty sets) */
     memcpy(s->prevL_kps_as, currL_kps_as, sizeof(orc_keypoint) * (size_t)n_currL_as); s->n_prevL_as = n_currL_as;
     memcpy(s->prevR_kps_as, currR_kps_as, sizeof(orc_keypoint) * (size_t)n_currR_as); s->n_prevR_as = n_currR_as;
-    memcpy(s->prevL_desc_as, currL_desc_as, sizeof(float) * 64 * (size_t)n_currL_desc_as); s->n_prevL_desc_as = n_currL_desc_as;
+    memcpy(s->prevL_desc_as, currL_desc_as, sizeof(float) * dim * (size_t)n_currL_desc_as); s->n_prevL_desc_as = n_currL_desc_as;
     free(currL_kps_as); free(currR_kps_as); free(currL_desc_as); free(ia); free(ib);
     return 0;
 }
@@ -209,8 +212,8 @@ int orc_stereo_get(orc_stereo* s, const char* what, void* out, int cap_bytes)
 #define CASE(name, ptr, cnt, esz) if (!strcmp(what, name)) { src = (ptr); count = (cnt); nb = (size_t)(cnt) * (esz); }
     CASE("kps_left", s->kpsL, s->nL, sizeof(orc_keypoint))
     CASE("kps_right", s->kpsR, s->nR, sizeof(orc_keypoint))
-    CASE("desc_left", s->descL, s->nL, 64*sizeof(float))
-    CASE("desc_right", s->descR, s->nR, 64*sizeof(float))
+    CASE("desc_left", s->descL, s->nL, desc_dim(s)*sizeof(float))
+    CASE("desc_right", s->descR, s->nR, desc_dim(s)*sizeof(float))
     CASE("matches_stereo", s->m_curr, s->n_m_curr, sizeof(orc_dmatch))
     CASE("matches_tri", s->m_pc, s->n_m_pc, sizeof(orc_dmatch))
     CASE("points4d", s->points4D, s->nT, 4*sizeof(float))

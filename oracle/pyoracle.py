@@ -171,7 +171,7 @@ def match(d1: np.ndarray, d2: np.ndarray, ratio: float) -> np.ndarray:
     d2 = _c(d2, np.float32)
     out = np.zeros(max(len(d1), 1), DM_DTYPE)
     m = C.c_int(0)
-    lib().orc_match_knn2_ratio(_p(d1), len(d1), _p(d2), len(d2), 64, C.c_float(ratio), _p(out), len(out), C.byref(m))
+    lib().orc_match_knn2_ratio(_p(d1), len(d1), _p(d2), len(d2), d1.shape[1] if d1.ndim == 2 else 64, C.c_float(ratio), _p(out), len(out), C.byref(m))
     return out[:m.value].copy()
 
 
@@ -244,6 +244,7 @@ class StereoVO:
     def __init__(self, params: VoParams, K_left, K_right, R_right, t_right, max_kpts=20000):
         self._keep = [_c(x, np.float64) for x in (K_left, K_right, R_right, t_right)]
         self.cap = max_kpts
+        self.dim = 128 if params.SURF_EXTENDED else 64
         self.h = lib().orc_stereo_create(C.byref(params), *[_p(x) for x in self._keep], max_kpts)
 
     def step(self, left, right, dt=0.05) -> StereoResult:
@@ -254,8 +255,8 @@ class StereoVO:
         return r
 
     def get(self, what: str):
-        spec = {"kps_left": KP_DTYPE, "kps_right": KP_DTYPE, "desc_left": np.dtype(("f4", 64)),
-                "desc_right": np.dtype(("f4", 64)), "matches_stereo": DM_DTYPE, "matches_tri": DM_DTYPE,
+        spec = {"kps_left": KP_DTYPE, "kps_right": KP_DTYPE, "desc_left": np.dtype(("f4", self.dim)),
+                "desc_right": np.dtype(("f4", self.dim)), "matches_stereo": DM_DTYPE, "matches_tri": DM_DTYPE,
                 "points4d": np.dtype(("f4", 4)), "good_pts": np.dtype(("f8", 3)), "good_idx": np.dtype("i4"),
                 "inliers": np.dtype("i4")}[what]
         buf = np.zeros(self.cap * 4, spec)

@@ -625,9 +625,119 @@ def test_misuse_is_refused_loudly(scene_small):
                 call()                                       # lane 0's buffers belong to the pair in flight; a stereo pair is not a mono frame
         assert c.stereo_collect(0.05).valid == 1
         c.detect_features(scene_small[0][0])
-        c.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=1500, SURF_EXTENDED=1))       # 128-element rows: detect_features only
-        assert c.detect_features(scene_small[0][0])[1].shape[1] == 128
         with pytest.raises(uvo.UvoError):
-            c.stereo_step(*scene_small[0], 0.05)
+            c.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=1500, SURF_EXTENDED=1))   # the running loop holds 64-element rows of the previous pair
+        c.stereo_reset()
+        c.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=1500, SURF_EXTENDED=1))
+        assert c.detect_features(scene_small[0][0])[1].shape[1] == 128
+        with pytest.raises(ValueError):
+            c.knn_match(d, d)                                # 64-element rows into a 128-element context
+    finally:
+        c.close()
+
+
+# ---------------------------------------------------------------- SURF_EXTENDED / SURF_UPRIGHT = 0 through the matcher and the loops
+@pytest.mark.parametrize("seed,kind", [(0, "unit"), (2, "clustered"), (4, "tiny")])
+def test_match_128_element_rows_bit_exact(oracle, seed, kind):
+    """BFMatcher(NORM_L2).knnMatch(k = 2) + ratio on 128-element rows (SURF extended): indices and distances bitwise, on random rows
+    with near-duplicates (the row-by-row scan path) and on real extended descriptors."""
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rng = np.random.default_rng(seed)
+    c = uvo.Context(uvo.Params.stereo(SURF_EXTENDED=1), 0, 640, 480, 4096)
+    try:
+        for n1, n2 in ((700, 900), (1, 1), (130, 1), (257, 129), (3000, 3000) if kind == "unit" else (300, 260)):
+            a = rng.standard_normal((n1, 128)).astype(np.float32)
+            b = rng.standard_normal((n2, 128)).astype(np.float32)
+            if kind == "clustered" and n2 > 8:
+                b[n2 // 2:] = b[: n2 - n2 // 2] + rng.standard_normal((n2 - n2 // 2, 128)).astype(np.float32) * 1e-4
+                a[: min(n1, n2) // 3] = b[: min(n1, n2) // 3]
+            if kind == "tiny":
+                a *= 1e-3; b *= 1e-3
+            a /= np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-12) if kind != "tiny" else 1.0
+            idx, dist = c.knn_match(a, b)
+            oidx, odist = oracle.knn2(a, b)
+            assert np.array_equal(idx, oidx), (kind, n1, n2)
+            assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32)), (kind, n1, n2)
+            m, om = c.match_features(a, b, 0.8), oracle.match(a, b, 0.8)
+            assert np.array_equal(m["queryIdx"], om["queryIdx"]) and np.array_equal(m["trainIdx"], om["trainIdx"])
+        scene = synth.Scene(11, 640)
+        L, R = synth.stereo_pair(scene, 0, 640, 480)
+        _, dL = oracle.surf(L, 500, extended=True)
+        _, dR = oracle.surf(R, 500, extended=True)
+        m, om = c.match_features(dL, dR, 0.7), oracle.match(dL, dR, 0.7)
+        assert len(om) > 50 and np.array_equal(m["queryIdx"], om["queryIdx"]) and np.array_equal(m["trainIdx"], om["trainIdx"])
+        assert np.array_equal(m["distance"].view(np.uint32), om["distance"].view(np.uint32))
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("extended,upright", [(1, 1), (0, 0), (1, 0)])
+def test_stereo_and_mono_loops_with_extended_and_oriented_surf(oracle, scene_small, mono_small, extended, upright):
+    """The whole stereo and mono steps with every SURF switch of the parameter files (surf_extended, surf_upright): counts, both match
+    lists, inlier sets bitwise, pose to 1e-4, synchronous and with three pairs in flight."""
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=1500, SURF_EXTENDED=extended, SURF_UPRIGHT=upright), 0, 640, 360, 8192)
+    try:
+        c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        op = oracle.stereo_params(1500); op.SURF_EXTENDED = extended; op.SURF_UPRIGHT = upright
+        ovo = oracle.StereoVO(op, rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        seq = [scene_small[k] for k in (0, 1, 2, 1, 0)]
+        ref = []
+        for k, (L, R) in enumerate(seq):
+            r, o = c.stereo_step(L, R, 0.05), ovo.step(L, R, 0.05)
+            for f in ("valid", "initialized", "n_left", "n_right", "n_stereo_matches", "n_tri_matches", "n_good3d", "n_inliers"):
+                assert getattr(r, f) == getattr(o, f), (k, f, getattr(r, f), getattr(o, f))
+            assert np.array_equal(c.stereo_get("desc_left").view(np.uint32), ovo.get("desc_left").view(np.uint32))
+            assert c.stereo_get("desc_left").shape[1] == (128 if extended else 64)
+            ms, oms = c.stereo_get("matches_stereo"), ovo.get("matches_stereo")
+            assert np.array_equal(ms["queryIdx"], oms["queryIdx"]) and np.array_equal(ms["trainIdx"], oms["trainIdx"])
+            if k > 0:
+                mt, omt = c.stereo_get("matches_tri"), ovo.get("matches_tri")
+                assert np.array_equal(mt["queryIdx"], omt["queryIdx"]) and np.array_equal(mt["trainIdx"], omt["trainIdx"])
+                assert np.array_equal(c.stereo_get("inliers"), ovo.get("inliers"))
+                assert r.valid == 1
+                for a, b in ((r.rvec, o.rvec), (r.tvec, o.tvec), (r.t_prev_curr, o.t_prev_curr)):
+                    a, b = np.array(list(a)), np.array(list(b))
+                    assert np.linalg.norm(a - b) <= 1e-4 * np.linalg.norm(b)
+            ref.append((r.valid, r.n_left, r.n_stereo_matches, r.n_tri_matches, r.n_good3d, r.n_inliers, tuple(r.tvec)))
+        # the same sequence with three pairs in flight
+        c.stereo_reset(); c.stereo_set_depth(3)
+        got, pending = [], 0
+        for L, R in seq:
+            if pending == 3:
+                got.append(c.stereo_collect(0.05)); pending -= 1
+            c.stereo_submit(L, R); pending += 1
+        while pending:
+            got.append(c.stereo_collect(0.05)); pending -= 1
+        for r, e in zip(got, ref):
+            assert (r.valid, r.n_left, r.n_stereo_matches, r.n_tri_matches, r.n_good3d, r.n_inliers) == e[:6]
+            assert np.linalg.norm(np.array(list(r.tvec)) - np.array(e[6])) <= 1e-4 * max(np.linalg.norm(np.array(e[6])), 1e-12)
+    finally:
+        c.close()
+    kw = dict(SURF_MIN_HESSIAN=400, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8, REPROJECTION_TOLERANCE=3.0, ESSENTIAL_THRESHOLD=1.0,
+              HOMOGRAPHY_THRESHOLD=1.0, SURF_EXTENDED=extended, SURF_UPRIGHT=upright)
+    op = oracle.mono_params(400, method=8); op.REPROJECTION_TOLERANCE = 3.0; op.ESSENTIAL_THRESHOLD = 1.0; op.HOMOGRAPHY_THRESHOLD = 1.0
+    op.SURF_EXTENDED = extended; op.SURF_UPRIGHT = upright
+    c = uvo.Context(uvo.Params.mono(**kw), 0, 640, 360, 8192)
+    try:
+        c.mono_set_camera(rig.K_left)
+        ovo = oracle.MonoVO(op, rig.K_left)
+        n_pub = 0
+        for k, img in enumerate([mono_small[0], mono_small[1], mono_small[2], mono_small[1]]):
+            r, o = c.mono_step(img, 4.0, 0.2), ovo.step(img, 4.0, 0.2)
+            for f in ("published", "valid", "initialized", "used_essential", "success", "n_kps", "n_matches", "n_inliers", "n_good3d", "n_front"):
+                assert getattr(r, f) == getattr(o, f), (k, f, getattr(r, f), getattr(o, f))
+            n_pub += r.published
+            if r.published:
+                assert np.array_equal(c.mono_get("mask"), ovo.get("mask"))
+                m, om = c.mono_get("matches"), ovo.get("matches")
+                assert np.array_equal(m["queryIdx"], om["queryIdx"]) and np.array_equal(m["trainIdx"], om["trainIdx"])
+                for a, b in ((r.R, o.R), (r.t, o.t)):
+                    a, b = np.array(list(a)), np.array(list(b))
+                    assert np.linalg.norm(a - b) <= 1e-4 * max(np.linalg.norm(b), 1e-12)
+        assert n_pub >= 2
     finally:
         c.close()
