@@ -51,13 +51,13 @@ def algorithmic_bytes_hessian_o0(w: int, h: int, nimg: int) -> int:
     return nimg * (4 * (w + 1) * (h + 1) + 3 * s0)
 
 
-def algorithmic_bytes_pair(w: int, h: int, n_kp: int) -> float:
-    """SURVEY.md 8(d) B_pair = 2*B_det + 2*B_desc + 2*B_match (descriptor term at its ~7.5 MB midpoint)."""
+def algorithmic_bytes_pair(w: int, h: int, n_kp: int, b_desc_pair=None) -> float:
+    """SURVEY.md 8(d) B_pair = 2*B_det + 2*B_desc + 2*B_match.  b_desc_pair: the descriptor term of both images from the run's
+    actual windows (the synthetic scene's windows are large: ~185 MB per pair); without it SURVEY's ~7.5 MB per image midpoint."""
     s = sum(5 * 4 * (h >> o) * (w >> o) for o in range(4))
     b_det = w * h + 4 * (w + 1) * (h + 1) + 4 * 4 * (w + 1) * (h + 1) + 3 * s
-    b_desc = 7.5e6
     b_match = (n_kp + n_kp) * 256 + n_kp * 16
-    return 2 * b_det + 2 * b_desc + 2 * b_match
+    return 2 * b_det + (2 * 7.5e6 if b_desc_pair is None else b_desc_pair) + 2 * b_match
 
 
 def ping_pong(n_frames: int):
@@ -317,7 +317,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5)},
-            "roofline_desc": {"bound": "hbm", "kernel": "descriptor stage of a pair (k_desc_tabs, k_big_sort, k_descriptor64_small/_big, finish)",
+            "roofline_desc": {"bound": "hbm", "kernel": "descriptor stage of a pair (k_big_sort, k_descriptor64_small, k_descriptor64_big, k_descriptor64_big_finish)",
                               "achieved": round(desc_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(desc_gbs / HBM_PEAK_GBS, 6),
                               "algorithmic_bytes_per_pair": b_desc, "stage_ms_per_pair": round(d_ms, 5)},
             # the f32 contraction (F = 2 Nq Nt 64) is priced against the f32 MFMA peak; it is executed on the bf16 pipe
@@ -328,7 +328,8 @@ def main():
                                "executed": {"achieved": round(3 * mm_tflops, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s (bf16)",
                                             "frac": round(3 * mm_tflops / MFMA_BF16_PEAK_TFLOPS, 5)}},
             "step_latency_ms": latency,
-            "pair_hbm_frac": round(algorithmic_bytes_pair(WIDTH, HEIGHT, 3000) * value / world / 1e9 / HBM_PEAK_GBS, 5),
+            "pair_hbm_frac": round(algorithmic_bytes_pair(WIDTH, HEIGHT, 3000, b_desc) * value / world / 1e9 / HBM_PEAK_GBS, 5),
+            "algorithmic_bytes_per_pair": int(algorithmic_bytes_pair(WIDTH, HEIGHT, 3000, b_desc)),
             "stage_ms": stage_ms, "stage_launches_per_step": stage_calls,
             "cpu_baseline": cpu,
         }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Secondary measurements for the other BASELINE.json configs (the headline C3 line comes from bench.py):
   C2  stereo 1280x720, ~1500 kpts (min_hessian 5685), pipelined submit/collect and synchronous step
-  C4  mono 1920x1080 + range, ~3000 kpts, RANSAC for both E and H (frames 0,4,8,.. so depth/baseline < 50)
+  C4  mono 1920x1080 + range, ~3000 kpts, min_hessian 6456 (3000 kpts), RANSAC for both E and H: frames two steps apart (essential) and a quarter step apart (homography)
 Prints one JSON object; run on the GPU box:  python tools/bench_configs.py"""
 import json
 import os
@@ -76,22 +76,26 @@ def main():
     ctx.close()
     # ---------------- C4 ----------------
     scene = synth.Scene(synth.SEEDS["C4"], W)
-    ks = [0, 4, 8, 12]
-    mono = [synth.stereo_pair(scene, k, W, H)[0] for k in ks]
-    dmono = [torch.from_numpy(m).cuda() for m in mono]
+    # frames two steps apart (parallax: the essential branch) and a quarter step apart (select_estimation_method picks the
+    # homography): both RANSACs are scored, as tests/test_gpu_configs.py checks against the oracle on the same frames
+    ks = [0, 2, 4, 2, 0, 0.25, 0.5, 0.25]
+    frames = {k: synth.mono_frame(scene, k, W, H) for k in sorted(set(ks))}
+    dev = {k: torch.from_numpy(m).cuda() for k, m in frames.items()}
+    dmono = [dev[k] for k in ks]
+    order = list(range(len(ks)))
     R0, C0 = synth.camera_pose(0)
     rng = scene.depth_at_center(C0, R0)
-    p = uvo.Params.mono(SURF_MIN_HESSIAN=6387, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8,
+    p = uvo.Params.mono(SURF_MIN_HESSIAN=6456, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8,
                         ESSENTIAL_THRESHOLD=1.0, HOMOGRAPHY_THRESHOLD=1.0, REPROJECTION_TOLERANCE=3.0)
     ctx = uvo.Context(p, 0, W, H, 8192)
     ctx.mono_set_camera(rig.K_left)
     for i in range(8):
-        r = ctx.mono_step(dmono[order[i % 6]], rng, 0.2)
-    steps = 100
+        r = ctx.mono_step(dmono[order[i % len(order)]], rng, 0.2)
+    steps = 96
     torch.cuda.synchronize(); t0 = time.perf_counter()
     nv = ne = 0
     for i in range(steps):
-        r = ctx.mono_step(dmono[order[i % 6]], rng, 0.2)
+        r = ctx.mono_step(dmono[order[i % len(order)]], rng, 0.2)
         nv += r.valid; ne += r.used_essential
     out["C4_mono_1920x1080_ransac"] = {"kpts": r.n_kps, "matches": r.n_matches, "valid": nv, "essential_used": ne,
                                        "frames_per_s": round(steps / (time.perf_counter() - t0), 1)}
@@ -103,14 +107,14 @@ def main():
     sub = 0
     for i in range(24):
         while sub < 24 and sub - i < depth:
-            ctx.mono_submit(dmono[order[sub % 6]], rng); sub += 1
+            ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
         r = ctx.mono_collect(0.2)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     nv = 0
     sub = 0
     for i in range(steps):
         while sub < steps and sub - i < depth:
-            ctx.mono_submit(dmono[order[sub % 6]], rng); sub += 1
+            ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
         nv += ctx.mono_collect(0.2).valid
     out["C4_mono_1920x1080_ransac"].update({"frames_per_s_pipelined": round(steps / (time.perf_counter() - t0), 1), "valid_pipelined": nv,
                                             "pipelined_steps": steps})
