@@ -46,7 +46,10 @@ def test_integral_wider_than_one_pass_and_ragged(oracle):
 
 
 @pytest.mark.parametrize("octave,layer", [(0, 0), (0, 4), (1, 2), (2, 1), (3, 0), (3, 4)])
-def test_hessian_layer_bit_exact(ctx, oracle, octave, layer):
+def test_hessian_layer_debug_hook_bit_exact(ctx, oracle, octave, layer):
+    """uvo_hessian_layer is the parity hook (k_hessian_layer_debug: calcLayerDetAndTrace from the run-time box patterns, the
+    arithmetic k_hessian_finish uses); the fused detection kernels k_hessian_nms_c / _p are covered by the keypoint equality of
+    the SURF tests below, which any wrong determinant near a maximum breaks."""
     img = _rand_img(2, 360, 640)
     s = ctx.integral(img)
     det, tr = ctx.hessian_layer(img.shape, octave, layer)
@@ -741,3 +744,29 @@ def test_stereo_and_mono_loops_with_extended_and_oriented_surf(oracle, scene_sma
         assert n_pub >= 2
     finally:
         c.close()
+
+
+def test_contexts_come_and_go_without_leaking_device_memory(scene_small):
+    """Twelve contexts with six lanes each, used and destroyed: the device's free memory returns to where it was."""
+    import torch
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    torch.cuda.synchronize()
+    free0 = None
+    for it in range(12):
+        c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=1500), 0, 1920, 1080, 8192)
+        c.stereo_set_depth(6)
+        c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        for L, R in scene_small:
+            c.stereo_submit(L, R)
+        for _ in scene_small:
+            c.stereo_collect(0.05)
+        c.stereo_submit(*scene_small[0])                # destroyed with a pair still in flight
+        c.close()
+        torch.cuda.synchronize()
+        free = torch.cuda.mem_get_info()[0]
+        if it == 1:
+            free0 = free                                # after the first rounds: allocator pools and code objects are in place
+        if it > 1:
+            assert free0 - free < 64 << 20, (it, free0, free)
