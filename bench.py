@@ -85,9 +85,21 @@ def self_launch(n: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # a rank that dies before the rendezvous would leave the others waiting for it: when one fails, the rest are ended (by PID)
+    import time as _time
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(code))
+            if code != 0:
+                for q in live:
+                    q.terminate()
+        _time.sleep(0.05)
     return rc
 
 
