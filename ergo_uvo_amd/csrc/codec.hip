@@ -31,11 +31,14 @@ struct Huff {
     int mincode[18], maxcode[18], valptr[18];
     uint16_t fast[512];                                       // (length << 8) | symbol, 0 = longer than 9 bits
     bool present = false;
-    void build()
+    // false: the code lengths do not form a prefix code (more codes of a length than remain): jdhuff.c's JERR_BAD_HUFF_TABLE
+    bool build()
     {
         int code = 0, k = 0;
         memset(fast, 0, sizeof(fast));
+        present = false;
         for (int l = 1; l <= 16; l++) {
+            if (code + bits[l] > (1 << l)) return false;
             valptr[l] = k; mincode[l] = code;
             for (int i = 0; i < bits[l]; i++, k++, code++)
                 if (l <= 9) { const int lo = code << (9 - l); for (int f = 0; f < (1 << (9 - l)); f++) fast[lo + f] = (uint16_t)((l << 8) | vals[k]); }
@@ -43,7 +46,9 @@ struct Huff {
             code <<= 1;
         }
         present = true;
+        return true;
     }
+    bool dc_symbols_ok() const { int cnt = 0; for (int l = 1; l <= 16; l++) cnt += bits[l]; for (int i = 0; i < cnt; i++) if (vals[i] > 15) return false; return true; }
 };
 
 struct BitReader {
@@ -160,13 +165,15 @@ static uvo_status jpeg_entropy_decode(Ctx* c, CodecWs* ws, const uint8_t* data, 
                 o += 16;
                 if (cnt > 256 || o + cnt > sl) return bad("bad Huffman table");
                 memcpy(h.vals, s + o, (size_t)cnt); o += cnt;
-                h.build();
+                if (!h.build()) return bad("bad Huffman table (not a prefix code)");
             }
             break;
         case 0xC0: case 0xC1: {
+            if (have_sof) return bad("second frame header");
             if (sl < 6 || s[0] != 8) return bad("only 8-bit samples are supported");
             j->h = be16(s + 1); j->w = be16(s + 3); j->ncomp = s[5];
             if (j->w <= 0 || j->h <= 0) return bad("empty image");
+            if ((long long)j->w * j->h > (1LL << 26)) return bad("images above 64 Mpixel are refused (a damaged header must not ask for gigabytes)");
             if (j->ncomp != 1 && j->ncomp != 3) return bad("only 1 or 3 components are supported");
             if (sl < 6 + 3 * j->ncomp) return bad("truncated frame header");
             j->hmax = j->vmax = 1;
@@ -190,14 +197,16 @@ static uvo_status jpeg_entropy_decode(Ctx* c, CodecWs* ws, const uint8_t* data, 
             have_sof = true;
             break;
         }
-        case 0xDD: j->restart = be16(s); break;
+        case 0xDD: if (sl < 2) return bad("truncated restart interval"); j->restart = be16(s); break;
         case 0xDA: {
             if (!have_sof) return bad("scan before frame header");
-            if (s[0] != j->ncomp) return bad("non-interleaved scans are not supported");
+            if (sl < 1 || s[0] != j->ncomp) return bad("non-interleaved scans are not supported");
+            if (sl < 1 + 2 * j->ncomp + 3) return bad("truncated scan header");
             for (int i = 0; i < s[0]; i++)
                 for (int k = 0; k < j->ncomp; k++)
                     if (j->comp[k].id == s[1 + 2 * i]) { j->comp[k].td = s[2 + 2 * i] >> 4; j->comp[k].ta = s[2 + 2 * i] & 15; }
             for (int k = 0; k < j->ncomp; k++) if (j->comp[k].td > 3 || j->comp[k].ta > 3 || !j->dc[j->comp[k].td].present || !j->ac[j->comp[k].ta].present) return bad("scan refers to a missing Huffman table");
+            for (int k = 0; k < j->ncomp; k++) if (!j->dc[j->comp[k].td].dc_symbols_ok()) return bad("bad DC Huffman table (category above 15)");
             BitReader b; b.p = data + pos + len; b.end = data + n;
             int left = j->restart;
             for (int my = 0; my < j->mcuy; my++)
@@ -216,7 +225,7 @@ static uvo_status jpeg_entropy_decode(Ctx* c, CodecWs* ws, const uint8_t* data, 
                             for (int bx = 0; bx < q.h; bx++) {
                                 int16_t* blk = ws->h_coef + (q.coef_off + (size_t)(my * q.v + by) * q.bw + (mx * q.h + bx)) * 64;
                                 const int t = b.decode(hd);
-                                q.dc_pred += t ? extend(b.get(t), t) : 0;
+                                q.dc_pred = (int)((unsigned)q.dc_pred + (unsigned)(t ? extend(b.get(t), t) : 0));   // (wraps on damaged streams)
                                 blk[0] = (int16_t)q.dc_pred;
                                 for (int kk = 1; kk < 64;) {
                                     const int rs = b.decode(ha), r = rs >> 4, sz = rs & 15;
@@ -246,29 +255,33 @@ static uvo_status jpeg_entropy_decode(Ctx* c, CodecWs* ws, const uint8_t* data, 
 struct IdctComp { size_t coef_off; int bw, bh, tq; size_t plane_off; };
 struct IdctArgs { IdctComp comp[3]; int ncomp; size_t total_blocks; };
 
-#define UVO_DESCALE(x, n) (((x) + (1 << ((n) - 1))) >> (n))
+#define UVO_DESCALE(x, n) ((int)((unsigned)(x) + (1u << ((n) - 1))) >> (n))
 __device__ __forceinline__ uint8_t jpeg_range_limit(int x)
 {
     x = (x + 128) & 1023;                                     // libjpeg's range_limit table: clamp(x + 128), wrapping beyond +-512
     return (uint8_t)(x < 256 ? x : (x < 512 ? 255 : 0));
 }
 // jidctint.c's butterfly on eight values (in place); both passes use it with different descaling
-__device__ __forceinline__ void islow_1d(const int (&in)[8], int (&o)[8])
+// (every add / multiply modulo 2^32: a damaged stream with out-of-range coefficients gives some picture, never undefined behaviour)
+__device__ __forceinline__ void islow_1d(const int (&in_s)[8], int (&o)[8])
 {
-    int z2 = in[2], z3 = in[6];
-    int z1 = (z2 + z3) * 4433;
-    int tmp2 = z1 + z3 * (-15137), tmp3 = z1 + z2 * 6270;
-    int tmp0 = (in[0] + in[4]) * 8192, tmp1 = (in[0] - in[4]) * 8192;
-    const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    unsigned in[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) in[k] = (unsigned)in_s[k];
+    unsigned z2 = in[2], z3 = in[6];
+    unsigned z1 = (z2 + z3) * 4433u;
+    unsigned tmp2 = z1 + z3 * (unsigned)(-15137), tmp3 = z1 + z2 * 6270u;
+    unsigned tmp0 = (in[0] + in[4]) * 8192u, tmp1 = (in[0] - in[4]) * 8192u;
+    const unsigned tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
     tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
-    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; int z4 = tmp1 + tmp3;
-    const int z5 = (z3 + z4) * 9633;
-    tmp0 *= 2446; tmp1 *= 16819; tmp2 *= 25172; tmp3 *= 12299;
-    z1 *= -7373; z2 *= -20995; z3 *= -16069; z4 *= -3196;
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; unsigned z4 = tmp1 + tmp3;
+    const unsigned z5 = (z3 + z4) * 9633u;
+    tmp0 *= 2446u; tmp1 *= 16819u; tmp2 *= 25172u; tmp3 *= 12299u;
+    z1 *= (unsigned)(-7373); z2 *= (unsigned)(-20995); z3 *= (unsigned)(-16069); z4 *= (unsigned)(-3196);
     z3 += z5; z4 += z5;
     tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-    o[0] = tmp10 + tmp3; o[7] = tmp10 - tmp3; o[1] = tmp11 + tmp2; o[6] = tmp11 - tmp2;
-    o[2] = tmp12 + tmp1; o[5] = tmp12 - tmp1; o[3] = tmp13 + tmp0; o[4] = tmp13 - tmp0;
+    o[0] = (int)(tmp10 + tmp3); o[7] = (int)(tmp10 - tmp3); o[1] = (int)(tmp11 + tmp2); o[6] = (int)(tmp11 - tmp2);
+    o[2] = (int)(tmp12 + tmp1); o[5] = (int)(tmp12 - tmp1); o[3] = (int)(tmp13 + tmp0); o[4] = (int)(tmp13 - tmp0);
 }
 
 // Eight threads per block, one column then one row each; the block's workspace lives in LDS ([block in workgroup][8][9] ints)

@@ -89,7 +89,10 @@ static const uint8_t kZigzag[64] = { 0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 1
 #define FIX_3_072711026 25172
 #define CONST_BITS 13
 #define PASS1_BITS 2
-#define DESCALE(x, n) (((x) + ((int32_t)1 << ((n) - 1))) >> (n))
+/* libjpeg computes in JLONG; valid streams stay far inside 32 bits, corrupt ones may not: every add / multiply here is done modulo
+ * 2^32 (unsigned), so a damaged stream gives some picture instead of undefined behaviour -- as the SIMD IDCTs of libjpeg-turbo do */
+typedef uint32_t wi;
+#define DESCALE(x, n) ((wi)((int32_t)((x) + ((wi)1 << ((n) - 1))) >> (n)))
 
 static uint8_t range_limit(int32_t x)
 {
@@ -103,22 +106,22 @@ static uint8_t range_limit(int32_t x)
 
 void orc_jpeg_idct_islow(const int16_t* coef /* natural order */, const uint16_t* quant /* natural order */, uint8_t* out, int stride)
 {
-    int32_t ws[64];
+    wi ws[64];
     for (int c = 0; c < 8; c++) {
-        int32_t in[8];
-        for (int r = 0; r < 8; r++) in[r] = (int32_t)coef[r * 8 + c] * quant[r * 8 + c];
-        int32_t z2 = in[2], z3 = in[6];
-        int32_t z1 = (z2 + z3) * FIX_0_541196100;
-        int32_t tmp2 = z1 + z3 * (-FIX_1_847759065);
-        int32_t tmp3 = z1 + z2 * FIX_0_765366865;
+        wi in[8];
+        for (int r = 0; r < 8; r++) in[r] = (wi)((int32_t)coef[r * 8 + c] * (int32_t)quant[r * 8 + c]);
+        wi z2 = in[2], z3 = in[6];
+        wi z1 = (z2 + z3) * FIX_0_541196100;
+        wi tmp2 = z1 + z3 * (wi)(-FIX_1_847759065);
+        wi tmp3 = z1 + z2 * FIX_0_765366865;
         z2 = in[0]; z3 = in[4];
-        int32_t tmp0 = (z2 + z3) * (1 << CONST_BITS), tmp1 = (z2 - z3) * (1 << CONST_BITS);
-        int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        wi tmp0 = (z2 + z3) * (1 << CONST_BITS), tmp1 = (z2 - z3) * (1 << CONST_BITS);
+        wi tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
-        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; int32_t z4 = tmp1 + tmp3;
-        int32_t z5 = (z3 + z4) * FIX_1_175875602;
+        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; wi z4 = tmp1 + tmp3;
+        wi z5 = (z3 + z4) * FIX_1_175875602;
         tmp0 *= FIX_0_298631336; tmp1 *= FIX_2_053119869; tmp2 *= FIX_3_072711026; tmp3 *= FIX_1_501321110;
-        z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
+        z1 *= (wi)(-FIX_0_899976223); z2 *= (wi)(-FIX_2_562915447); z3 *= (wi)(-FIX_1_961570560); z4 *= (wi)(-FIX_0_390180644);
         z3 += z5; z4 += z5;
         tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
         ws[0 * 8 + c] = DESCALE(tmp10 + tmp3, CONST_BITS - PASS1_BITS); ws[7 * 8 + c] = DESCALE(tmp10 - tmp3, CONST_BITS - PASS1_BITS);
@@ -127,26 +130,26 @@ void orc_jpeg_idct_islow(const int16_t* coef /* natural order */, const uint16_t
         ws[3 * 8 + c] = DESCALE(tmp13 + tmp0, CONST_BITS - PASS1_BITS); ws[4 * 8 + c] = DESCALE(tmp13 - tmp0, CONST_BITS - PASS1_BITS);
     }
     for (int r = 0; r < 8; r++) {
-        const int32_t* w = ws + r * 8;
-        int32_t z2 = w[2], z3 = w[6];
-        int32_t z1 = (z2 + z3) * FIX_0_541196100;
-        int32_t tmp2 = z1 + z3 * (-FIX_1_847759065);
-        int32_t tmp3 = z1 + z2 * FIX_0_765366865;
-        int32_t tmp0 = (w[0] + w[4]) * (1 << CONST_BITS), tmp1 = (w[0] - w[4]) * (1 << CONST_BITS);
-        int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        const wi* w = ws + r * 8;
+        wi z2 = w[2], z3 = w[6];
+        wi z1 = (z2 + z3) * FIX_0_541196100;
+        wi tmp2 = z1 + z3 * (wi)(-FIX_1_847759065);
+        wi tmp3 = z1 + z2 * FIX_0_765366865;
+        wi tmp0 = (w[0] + w[4]) * (1 << CONST_BITS), tmp1 = (w[0] - w[4]) * (1 << CONST_BITS);
+        wi tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
-        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; int32_t z4 = tmp1 + tmp3;
-        int32_t z5 = (z3 + z4) * FIX_1_175875602;
+        z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2; wi z4 = tmp1 + tmp3;
+        wi z5 = (z3 + z4) * FIX_1_175875602;
         tmp0 *= FIX_0_298631336; tmp1 *= FIX_2_053119869; tmp2 *= FIX_3_072711026; tmp3 *= FIX_1_501321110;
-        z1 *= -FIX_0_899976223; z2 *= -FIX_2_562915447; z3 *= -FIX_1_961570560; z4 *= -FIX_0_390180644;
+        z1 *= (wi)(-FIX_0_899976223); z2 *= (wi)(-FIX_2_562915447); z3 *= (wi)(-FIX_1_961570560); z4 *= (wi)(-FIX_0_390180644);
         z3 += z5; z4 += z5;
         tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
         uint8_t* o = out + (size_t)r * stride;
         const int S = CONST_BITS + PASS1_BITS + 3;
-        o[0] = range_limit(DESCALE(tmp10 + tmp3, S)); o[7] = range_limit(DESCALE(tmp10 - tmp3, S));
-        o[1] = range_limit(DESCALE(tmp11 + tmp2, S)); o[6] = range_limit(DESCALE(tmp11 - tmp2, S));
-        o[2] = range_limit(DESCALE(tmp12 + tmp1, S)); o[5] = range_limit(DESCALE(tmp12 - tmp1, S));
-        o[3] = range_limit(DESCALE(tmp13 + tmp0, S)); o[4] = range_limit(DESCALE(tmp13 - tmp0, S));
+        o[0] = range_limit((int32_t)DESCALE(tmp10 + tmp3, S)); o[7] = range_limit((int32_t)DESCALE(tmp10 - tmp3, S));
+        o[1] = range_limit((int32_t)DESCALE(tmp11 + tmp2, S)); o[6] = range_limit((int32_t)DESCALE(tmp11 - tmp2, S));
+        o[2] = range_limit((int32_t)DESCALE(tmp12 + tmp1, S)); o[5] = range_limit((int32_t)DESCALE(tmp12 - tmp1, S));
+        o[3] = range_limit((int32_t)DESCALE(tmp13 + tmp0, S)); o[4] = range_limit((int32_t)DESCALE(tmp13 - tmp0, S));
     }
 }
 
@@ -184,7 +187,7 @@ static int jpeg_read(const uint8_t* data, size_t n, jdec* d)
             int o = 0;
             while (o < sl) {
                 const int pq = s[o] >> 4, tq = s[o] & 15; o++;
-                if (tq > 3) return -1;
+                if (tq > 3 || pq > 1 || o + (pq ? 128 : 64) > sl) return -1;
                 for (int k = 0; k < 64; k++) { d->quant[tq][kZigzag[k]] = (uint16_t)(pq ? rd16(s + o + 2 * k) : s[o + k]); }
                 o += pq ? 128 : 64;
             }
@@ -203,10 +206,13 @@ static int jpeg_read(const uint8_t* data, size_t n, jdec* d)
                 huff_build(h); h->present = 1;
             }
         } else if (m == 0xC0 || m == 0xC1) {                 /* SOF0 / SOF1 */
+            if (have_sof || sl < 6) return -1;               /* (a second frame header would also leak the first one's planes) */
             if (s[0] != 8) return -2;
             d->h = rd16(s + 1); d->w = rd16(s + 3); d->ncomp = s[5];
             if (d->w <= 0 || d->h <= 0) return -1;
+            if ((long long)d->w * d->h > (1LL << 26)) return -2;                                  /* 64 Mpixel cap: a damaged header must not ask for gigabytes */
             if (d->ncomp != 1 && d->ncomp != 3) return -2;
+            if (sl < 6 + 3 * d->ncomp) return -1;
             for (int c = 0; c < d->ncomp; c++) {
                 jcomp* k = &d->comp[c];
                 k->id = s[6 + 3 * c]; k->h = s[7 + 3 * c] >> 4; k->v = s[7 + 3 * c] & 15; k->tq = s[8 + 3 * c];
@@ -226,14 +232,24 @@ static int jpeg_read(const uint8_t* data, size_t n, jdec* d)
         } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
             return -2;                                       /* progressive, lossless, arithmetic ... */
         } else if (m == 0xDD) {
+            if (sl < 2) return -1;
             d->restart_interval = rd16(s);
         } else if (m == 0xDA) {                              /* SOS: one interleaved scan with every component (baseline encoders) */
-            if (!have_sof) return -1;
+            if (!have_sof || sl < 1) return -1;
             const int ns = s[0];
             if (ns != d->ncomp) return -2;
+            if (sl < 1 + 2 * ns + 3) return -1;
             for (int i = 0; i < ns; i++) {
                 const int cid = s[1 + 2 * i];
                 for (int c = 0; c < d->ncomp; c++) if (d->comp[c].id == cid) { d->comp[c].td = s[2 + 2 * i] >> 4; d->comp[c].ta = s[2 + 2 * i] & 15; }
+            }
+            for (int c = 0; c < d->ncomp; c++) {             /* jdhuff.c start_pass: the tables a scan names must exist; DC categories are 0..15 */
+                const jcomp* k = &d->comp[c];
+                if (k->td > 3 || k->ta > 3 || !d->dc[k->td].present || !d->ac[k->ta].present) return -1;
+                const hufftab* h = &d->dc[k->td];
+                int cnt = 0;
+                for (int l = 1; l <= 16; l++) cnt += h->bits[l];
+                for (int i = 0; i < cnt; i++) if (h->vals[i] > 15) return -1;
             }
             bitreader b = { data + pos + len, data + n, 0, 0, 0 };
             int restarts_left = d->restart_interval;
@@ -255,7 +271,7 @@ static int jpeg_read(const uint8_t* data, size_t n, jdec* d)
                                 int16_t* blk = k->coef + ((size_t)(my * k->v + by) * k->bw + (mx * k->h + bx)) * 64;
                                 int s_ = huff_decode(&b, &d->dc[k->td]);
                                 int diff = s_ ? extend(br_get(&b, s_), s_) : 0;
-                                k->dc_pred += diff;
+                                k->dc_pred = (int)((unsigned)k->dc_pred + (unsigned)diff);   /* (wraps on damaged streams) */
                                 blk[0] = (int16_t)k->dc_pred;
                                 for (int kk = 1; kk < 64;) {
                                     const int rs = huff_decode(&b, &d->ac[k->ta]);

@@ -140,3 +140,39 @@ def test_hip_bayer_jpeg_message(ctx, oracle):
     mosaic = oracle.jpeg_decode(b.getvalue())
     got = ctx.decode_image(b.getvalue(), "bayer_bggr8; jpeg compressed bayer_bggr8")
     assert got.shape == (120, 160, 3) and np.array_equal(got, oracle.bayer_bggr2bgr(mosaic))
+
+
+@pytest.mark.gpu
+def test_damaged_streams_are_refused_or_decoded_never_fatal(cases):
+    """A camera topic can carry anything: 60 mutations per fixture (byte flips, truncations, injected markers, inserted bytes) go
+    through uvo_decode_image; each returns an image or UvoError, and the context still decodes a good stream afterwards.  (The
+    same mutations run through the oracle's decoder under ASan + UBSan in tests/test_oracle_sanitizers.py.)"""
+    import ergo_uvo_amd as uvo
+    c = uvo.Context(uvo.Params.stereo(), 0, 640, 480, 256)
+    frng = np.random.default_rng(99)
+    n_ok = n_bad = 0
+    try:
+        for name in cases["names"]:
+            base = bytearray(bytes(cases[f"{name}_jpeg"]))
+            for trial in range(60):
+                d = bytearray(base)
+                kind = trial % 4
+                if kind == 0:
+                    for _ in range(1 + trial // 8):
+                        d[int(frng.integers(2, len(d)))] = int(frng.integers(0, 256))
+                elif kind == 1:
+                    d = d[: int(frng.integers(2, len(d)))]
+                elif kind == 2:
+                    pos = int(frng.integers(2, len(d) - 4)); d[pos:pos + 2] = bytes([0xFF, int(frng.integers(0xC0, 0xFF))])
+                else:
+                    pos = int(frng.integers(2, len(d))); d[pos:pos] = bytes(frng.integers(0, 256, int(frng.integers(1, 40)), dtype=np.uint8))
+                try:
+                    img = c.decode_image(bytes(d), "jpeg"); n_ok += 1
+                    assert img.size <= (1 << 26) * 3
+                except uvo.UvoError:
+                    n_bad += 1
+            good = c.decode_image(bytes(base), "jpeg")
+            assert np.array_equal(good, _bgr(cases[f"{name}_rgb"])), name
+        assert n_bad > 50 and n_ok + n_bad == 60 * len(cases["names"])
+    finally:
+        c.close()

@@ -59,6 +59,30 @@ CHILD = textwrap.dedent(r"""
         orc.jpeg_decode(buf.getvalue())
     except ImportError:
         pass
+    # malformed streams must be refused or decoded, never read or write out of bounds: mutations of the committed fixtures
+    cases = np.load(%(root)r + "/tests/golden/jpeg_cases.npz")
+    frng = np.random.default_rng(99)
+    n_ok = n_bad = 0
+    for name in cases["names"]:
+        base = bytearray(bytes(cases[str(name) + "_jpeg"]))
+        for trial in range(60):
+            d = bytearray(base)
+            kind = trial %% 4
+            if kind == 0:
+                for _ in range(1 + trial // 8):
+                    d[int(frng.integers(2, len(d)))] = int(frng.integers(0, 256))
+            elif kind == 1:
+                d = d[: int(frng.integers(2, len(d)))]
+            elif kind == 2:
+                pos = int(frng.integers(2, len(d) - 4)); d[pos:pos + 2] = bytes([0xFF, int(frng.integers(0xC0, 0xFF))])
+            else:
+                pos = int(frng.integers(2, len(d))); d[pos:pos] = bytes(frng.integers(0, 256, int(frng.integers(1, 40)), dtype=np.uint8))
+            try:
+                img = orc.jpeg_decode(bytes(d)); n_ok += 1
+                assert img.size <= 4096 * 4096 * 3
+            except ValueError:
+                n_bad += 1
+    assert n_ok + n_bad == 60 * len(cases["names"]) and n_bad > 50
     print("SANITIZED-OK")
 """)
 
