@@ -310,3 +310,54 @@ def test_stereo_node_loop_matches_oracle(oracle, scene_small, tmp_path):
             assert np.linalg.norm(v - ov) <= 1e-4 * max(np.linalg.norm(ov), 1e-300), (i, v, ov)
             n_valid += o.valid
     assert n_valid == len(seq) - 1
+
+
+def test_parameter_tree_survives_damaged_yaml_under_sanitizers(tmp_path):
+    """ParamTree + the three loaders on ~800 mutated copies of the parameter texts (byte flips, cut lines, broken brackets and quotes,
+    changed indentation, duplicated keys), built with -fsanitize=address,undefined: a parameter file edited by hand may be refused
+    or half-read, it may not crash the node."""
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not (os.path.isabs(asan) and os.path.exists(asan)):
+        pytest.skip("no libasan for g++ here")
+    _build()
+    exe = tmp_path / "fuzz_param_tree"
+    inc, lib = os.path.join(ROOT, "include"), os.path.join(ROOT, "ergo_uvo_amd", "lib")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-DUVO_NO_OPENCV", "-I", inc,
+                           os.path.join(ROOT, "tests", "cpp", "fuzz_param_tree.cpp"), os.path.join(SHIM_DIR, "uvo_config.cpp"),
+                           os.path.join(SHIM_DIR, "VO_utility_hip.cpp"), "-L", lib, "-luvo_hip", "-Wl,-rpath," + lib,
+                           "-Wl,--allow-shlib-undefined", "-o", str(exe)])
+    rng = np.random.default_rng(5)
+    K = np.array([[400.0, 0, 320], [0, 400.0, 240], [0, 0, 1]])
+    seeds = [MONO_PARAMS, STEREO_PARAMS, _intr_yaml(K, "cam"), _intr_yaml(K, "cam", stereo=(K, np.eye(3), np.array([-0.3, 0, 0]))),
+             MONO_PARAMS + _intr_yaml(K, "cam")]
+    cases = list(seeds)
+    for base in seeds:
+        for trial in range(160):
+            t = bytearray(base.encode())
+            kind = trial % 8
+            if kind == 0:
+                for _ in range(1 + trial // 16):
+                    t[int(rng.integers(0, len(t)))] = int(rng.integers(1, 256))
+            elif kind == 1:
+                t = t[: int(rng.integers(0, len(t)))]
+            elif kind == 2:
+                t = bytearray(bytes(t).replace(b"]", b"", 1)) if trial % 16 < 8 else bytearray(bytes(t).replace(b"[", b"[[", 2))
+            elif kind == 3:
+                t = bytearray(bytes(t).replace(b"'", b"", 1).replace(b": ", b":", int(rng.integers(1, 5))))
+            elif kind == 4:
+                lines = bytes(t).split(b"\n"); i = int(rng.integers(0, len(lines))); lines[i] = b" " * int(rng.integers(0, 9)) + lines[i].lstrip()
+                t = bytearray(b"\n".join(lines))
+            elif kind == 5:
+                lines = bytes(t).split(b"\n"); i = int(rng.integers(0, len(lines))); lines.insert(i, lines[int(rng.integers(0, len(lines)))])
+                t = bytearray(b"\n".join(lines))
+            elif kind == 6:
+                t = bytearray(bytes(t).replace(b"\n", b"\r\n").replace(b"  ", b"\t", int(rng.integers(1, 6))))
+            else:
+                pos = int(rng.integers(0, len(t))); t[pos:pos] = bytes(rng.integers(1, 256, int(rng.integers(1, 30)), dtype=np.uint8))
+            cases.append(bytes(t).decode("latin-1"))
+    blob = tmp_path / "cases.txt"
+    blob.write_bytes("===CASE===\n".join(c if c.endswith("\n") else c + "\n" for c in cases).encode("latin-1"))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:exitcode=66", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1:exitcode=67")
+    r = subprocess.run([str(exe), str(blob)], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "FUZZ-OK" in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-4000:])
+    assert "runtime error" not in r.stderr, r.stderr[-4000:]
