@@ -1,10 +1,10 @@
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 torch.cuda.init()
 import ergo_uvo_amd as uvo
 from oracle import pyoracle as po
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 from test_preproc import _rgb, _cam
 ctx = uvo.Context(uvo.Params.stereo(), 0, 1920, 1080, 8192)
 img = _rgb(360, 640, 21)

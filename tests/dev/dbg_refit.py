@@ -1,7 +1,7 @@
 """Refit diagnostics on the GPU box: HIP solvePnPRansac vs the oracle for growing inlier counts (relative pose differences),
-then a C3 run with UVO_DBG_PHASE for the refit's phase times.  python tools/dbg_refit.py"""
+then a C3 run with UVO_DBG_PHASE for the refit's phase times.  python tests/dev/dbg_refit.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import ergo_uvo_amd as uvo
 from ergo_uvo_amd import synth
