@@ -740,9 +740,8 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     }
     // triangulation + extract_3Dpoints (VO:631-632)
     Range r_tri("uvo:triangulatePoints + extract_3Dpoints");
-    LANE_TRY(pose_triangulate(L, c->P_eye_left, c->P_right, cn + CN_T, cap));
     const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
-    LANE_TRY(pose_extract3d(L, 0, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap));
+    LANE_TRY(pose_triangulate_extract3d(L, 0, c->P_eye_left, c->P_right, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap));
     UVO_HIP_TRY(c, hipMemcpyAsync(L->h_countsA[0], L->d_counts, sizeof(int) * CN_TOTAL, hipMemcpyDeviceToHost, st));
     UVO_HIP_TRY(c, hipEventRecord(L->evA[0], st));
     if (tr) UVO_HIP_TRY(c, hipEventRecord(tr->ev[2], st));
@@ -1216,8 +1215,7 @@ extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h
             UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x1, in1.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, c->stream));
             UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x2, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, c->stream));
             UVO_HIP_TRY(c, hipMemcpyAsync(c->d_xc, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, c->stream));
-            UVO_TRY(pose_triangulate(c, P_prev, P_curr, nullptr, n_in));                   // VO:355
-            UVO_TRY(pose_extract3d(c, 0, I, z, c->mono_R, c->mono_t, c->mono_K, c->mono_K, nullptr, n_in));   // VO:356
+            UVO_TRY(pose_triangulate_extract3d(c, 0, P_prev, P_curr, I, z, c->mono_R, c->mono_t, c->mono_K, c->mono_K, nullptr, n_in));   // VO:355-356
             UVO_TRY(read_counts(c));
             G = c->h_counts[CN_G];
             c->mono_good_pts.resize((size_t)3 * G);
@@ -1389,8 +1387,7 @@ static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok)
             if (!hip_ok(hipMemcpyAsync(L->d_x1, in1.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, st))) return;
             if (!hip_ok(hipMemcpyAsync(L->d_x2, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, st))) return;
             if (!hip_ok(hipMemcpyAsync(L->d_xc, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, st))) return;
-            if ((j.st = pose_triangulate(L, P_prev, P_curr, nullptr, n_in)) != UVO_OK) { j.err = L->err; return; }          // VO:355
-            if ((j.st = pose_extract3d(L, 0, I, z, R, t, m->mono_K, m->mono_K, nullptr, n_in)) != UVO_OK) { j.err = L->err; return; }   // VO:356
+            if ((j.st = pose_triangulate_extract3d(L, 0, P_prev, P_curr, I, z, R, t, m->mono_K, m->mono_K, nullptr, n_in)) != UVO_OK) { j.err = L->err; return; }   // VO:355-356
             if ((j.st = read_counts(L)) != UVO_OK) { j.err = L->err; return; }
             G = L->h_counts[CN_G];
             L->mono_good_pts.resize((size_t)3 * G);

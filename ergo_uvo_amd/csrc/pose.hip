@@ -41,8 +41,29 @@ struct Cam { double R[9], t[3], fx, fy, cx, cy; };
 
 // ---------------------------------------------------------------- triangulatePoints
 static const int kTriThreads = 64;
+// extract_3Dpoints, per point (VOU:188-221): convertPointsFromHomogeneous (float) + mean reprojection error in both views + z > 0
+__device__ __forceinline__ void extract3d_point(const float4 p, const uvo_point2f k1, const uvo_point2f k2, const Cam& c1, const Cam& c2, double tol,
+                                                double* cam1, int* flag, int i)
+{
+    float scale = p.w != 0.f ? 1.f / p.w : 1.f;
+    double X = (double)(p.x * scale), Y = (double)(p.y * scale), Z = (double)(p.z * scale);
+    cam1[3*i] = X; cam1[3*i + 1] = Y; cam1[3*i + 2] = Z;
+    double u, v;
+    project_point(X, Y, Z, c1.R, c1.t, c1.fx, c1.fy, c1.cx, c1.cy, &u, &v);
+    double dx = k1.x - u, dy = k1.y - v;
+    double e1 = sqrt(dx * dx + dy * dy);
+    project_point(X, Y, Z, c2.R, c2.t, c2.fx, c2.fy, c2.cx, c2.cy, &u, &v);
+    dx = k2.x - u; dy = k2.y - v;
+    double e2 = sqrt(dx * dx + dy * dy);
+    double mean = (e1 + e2) / 2.0;
+    flag[i] = ((mean < tol) && (Z > 0)) ? 1 : 0;
+}
+
+// FILTER: the loops call triangulatePoints and extract_3Dpoints back to back on the same point pairs (VO:631-632, VO:355-356);
+// the per-point part of the latter then runs on the point just triangulated instead of in a launch of its own
+template <bool FILTER>
 __global__ __launch_bounds__(kTriThreads) void k_triangulate(Mat34 P1, Mat34 P2, const uvo_point2f* x1, const uvo_point2f* x2,
-                                                             const int* n_p, int n_imm, float4* out)
+                                                             const int* n_p, int n_imm, float4* out, Cam c1, Cam c2, double tol, double* cam1, int* flag)
 {
     const int n = n_p ? *n_p : n_imm;
     const int i = blockIdx.x * kTriThreads + threadIdx.x;
@@ -58,11 +79,13 @@ __global__ __launch_bounds__(kTriThreads) void k_triangulate(Mat34 P1, Mat34 P2,
         Am[3*4 + k] = yb * P2.v[2*4 + k] - P2.v[1*4 + k];
     }
     svd_square<4>(Am, At, W, Vt, Wt);
-    out[i] = make_float4((float)Vt[12], (float)Vt[13], (float)Vt[14], (float)Vt[15]);
+    const float4 X = make_float4((float)Vt[12], (float)Vt[13], (float)Vt[14], (float)Vt[15]);
+    out[i] = X;
+    if (FILTER) extract3d_point(X, x1[i], x2[i], c1, c2, tol, cam1, flag, i);
 }
 
 // ---------------------------------------------------------------- extract_3Dpoints
-// stage A: convertPointsFromHomogeneous (float) + mean reprojection error in both views + z > 0
+// stage A on caller-provided homogeneous points (uvo_extract_3d_points)
 __global__ __launch_bounds__(256) void k_extract3d_a(const float4* pts4, const uvo_point2f* k1, const uvo_point2f* k2,
                                                      Cam c1, Cam c2, double tol, const int* n_p, int n_imm,
                                                      double* cam1, int* flag)
@@ -70,19 +93,7 @@ __global__ __launch_bounds__(256) void k_extract3d_a(const float4* pts4, const u
     const int n = n_p ? *n_p : n_imm;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float4 p = pts4[i];
-    float scale = p.w != 0.f ? 1.f / p.w : 1.f;
-    double X = (double)(p.x * scale), Y = (double)(p.y * scale), Z = (double)(p.z * scale);
-    cam1[3*i] = X; cam1[3*i + 1] = Y; cam1[3*i + 2] = Z;
-    double u, v;
-    project_point(X, Y, Z, c1.R, c1.t, c1.fx, c1.fy, c1.cx, c1.cy, &u, &v);
-    double dx = k1[i].x - u, dy = k1[i].y - v;
-    double e1 = sqrt(dx * dx + dy * dy);
-    project_point(X, Y, Z, c2.R, c2.t, c2.fx, c2.fy, c2.cx, c2.cy, &u, &v);
-    dx = k2[i].x - u; dy = k2[i].y - v;
-    double e2 = sqrt(dx * dx + dy * dy);
-    double mean = (e1 + e2) / 2.0;
-    flag[i] = ((mean < tol) && (Z > 0)) ? 1 : 0;
+    extract3d_point(pts4[i], k1[i], k2[i], c1, c2, tol, cam1, flag, i);
 }
 
 // reproject_errors (VOU:632-651) on caller-provided points
@@ -367,13 +378,32 @@ __global__ __launch_bounds__(kFastThreads) void k_pnp_refit_fast(PnpBatch b)
 // the identity subset.
 
 // ---------------------------------------------------------------- host orchestration
+static Cam make_cam(const double* R, const double* t, const double* K);
 uvo_status pose_triangulate(Ctx* c, const double* P1, const double* P2, const int* d_n, int n_max)
 {
     if (n_max <= 0) return UVO_OK;
     Mat34 a, b; memcpy(a.v, P1, sizeof(a.v)); memcpy(b.v, P2, sizeof(b.v));
     StageTimer t(c, ST_TRIANGULATE);
-    hipLaunchKernelGGL(k_triangulate, dim3((n_max + kTriThreads - 1) / kTriThreads), dim3(kTriThreads), 0, c->stream,
-                       a, b, c->d_x1, c->d_x2, d_n, n_max, c->d_pts4);
+    hipLaunchKernelGGL(k_triangulate<false>, dim3((n_max + kTriThreads - 1) / kTriThreads), dim3(kTriThreads), 0, c->stream,
+                       a, b, c->d_x1, c->d_x2, d_n, n_max, c->d_pts4, Cam(), Cam(), 0.0, nullptr, nullptr);
+    UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+// triangulatePoints + extract_3Dpoints on the same point pairs (d_x1, d_x2), as both loops call them: two launches instead of three
+uvo_status pose_triangulate_extract3d(Ctx* c, int slot, const double* P1, const double* P2, const double* R1, const double* t1,
+                                      const double* R2, const double* t2, const double* K1, const double* K2, const int* d_n, int n_max)
+{
+    if (n_max > 0) {
+        Mat34 a, b; memcpy(a.v, P1, sizeof(a.v)); memcpy(b.v, P2, sizeof(b.v));
+        StageTimer t(c, ST_TRIANGULATE);
+        hipLaunchKernelGGL(k_triangulate<true>, dim3((n_max + kTriThreads - 1) / kTriThreads), dim3(kTriThreads), 0, c->stream,
+                           a, b, c->d_x1, c->d_x2, d_n, n_max, c->d_pts4, make_cam(R1, t1, K1), make_cam(R2, t2, K2),
+                           c->p.REPROJECTION_TOLERANCE, c->d_cam1, c->d_flag);
+    }
+    StageTimer t(c, ST_EXTRACT3D);
+    hipLaunchKernelGGL(k_extract3d_b, dim3(1), dim3(1024), 0, c->stream, c->d_cam1, c->d_flag, c->d_xc, d_n, n_max,
+                       c->p.MIN_NUM_3DPOINTS, c->d_tmp_idx, c->d_good_pts[slot], c->d_good_idx[slot], c->d_opts[slot], c->d_ipts[slot],
+                       c->d_counts);
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }

@@ -1561,15 +1561,20 @@ uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int 
     }
     if (slot == 1 && (w != c->img_w || h != c->img_h)) { c->err = "left/right image sizes differ"; return UVO_INVALID_ARG; }
     c->img_w = w; c->img_h = h;
+    // A tight, 16-byte aligned image that is already in device memory is read in place: the caller keeps it valid and unmodified
+    // until the pair is collected (include/uvo_hip.h, "memory"), which is what the copy needed too -- it is queued, not done, when
+    // submit returns.  Saves two 2 MB device-to-device copies and two launches per pair.
+    if (mem == UVO_MEM_DEVICE && stride == w && (reinterpret_cast<uintptr_t>(gray) & 15u) == 0) { c->img[slot] = gray; return UVO_OK; }
     UVO_HIP_TRY(c, hipMemcpy2DAsync(c->d_img[slot], w, gray, stride, w, h,
                                     mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    c->img[slot] = c->d_img[slot];
     return UVO_OK;
 }
 
 uvo_status surf_integral(Ctx* c, int nimg)
 {
     const int w = c->img_w, h = c->img_h, sw = w + 1;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
+    ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
     const int nstrip = (h + kStripRows - 1) / kStripRows, cstride = c->colpart_stride;
     StageTimer t(c, ST_INTEGRAL);
     hipLaunchKernelGGL(k_integral_strip_sums, dim3(nstrip, nimg), dim3(256), 0, c->stream, ip, w, h, c->d_colpart, cstride, nstrip);
@@ -1583,7 +1588,7 @@ template <int O, int TW, int TH, int NT>
 static hipError_t launch_hessian_p(Ctx* c, int nimg, const OctavePat& op, float thr)
 {
     const int w = c->img_w, h = c->img_h;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
+    ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
     SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
     dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
     hipLaunchKernelGGL((k_hessian_nms_p<O, TW, TH, NT>), grid, dim3(NT), 0, c->stream, ip, w, h, op, thr, sv);
@@ -1598,7 +1603,7 @@ static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float 
     constexpr int THs = (TH - 1) * STEP + (OC::HI - OC::LO) + 1;
     constexpr int PW = OctTile<O, TW>::PW;
     const int w = c->img_w, h = c->img_h;
-    ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
+    ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
     SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
     const size_t lds = sizeof(float) * 3 * TW * TH + sizeof(int32_t) * (size_t)THs * STEP * PW + sizeof(unsigned) * NmsLds<TW, TH>::kWords;
     dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
@@ -1648,7 +1653,7 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
         }
         {   // the survivors of every octave: outer-layer determinants, last comparison, keypoints
             StageTimer t(c, ST_HESSIAN_O0 + c->p.SURF_OCTAVES_NUMBER - 1);
-            ImgPair ip = { { c->d_img[0], c->d_img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
+            ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
             SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
             CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
             hipLaunchKernelGGL(k_hessian_finish, dim3((c->surv_cap + kFinishPerWg - 1) / kFinishPerWg), dim3(256), 0, c->stream, sv, static_cast<const OctavePat*>(c->d_octpat), ip, w, h, out);
@@ -1667,7 +1672,7 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
     }
     {
         StageTimer t(c, ST_DESCRIPTOR);
-        DescArgs da = { { c->d_img[0], c->d_img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
+        DescArgs da = { { c->img[0], c->img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
                         { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap,      // the sorted list
                         c->d_area_tabs, c->d_area_iscale, c->p.SURF_EXTENDED ? 1 : 0, { c->d_sum[0], c->d_sum[1] }, c->d_ori_w, c->d_counts + CN_ORI_DROP };
         const size_t lds_small = sizeof(float) * 21 * (kSmallWin | 1);

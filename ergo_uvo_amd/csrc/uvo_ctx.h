@@ -65,6 +65,7 @@ struct Ctx {
 
     // ---- SURF ----
     uint8_t* d_img[2] = {nullptr, nullptr};
+    const uint8_t* img[2] = {nullptr, nullptr};   // what the kernels read: d_img[i], or the caller's device image when it can be read in place
     int32_t* d_sum[2] = {nullptr, nullptr};      // (max_h+1) x (max_w+1); = d_sum_base + kSumPad
     int32_t* d_sum_base[2] = {nullptr, nullptr}; // allocation: kSumPad ints of slack on both sides, so the Hessian tile fill can
                                                  // read whole quads of a clamped row without per-element bounds checks
@@ -235,6 +236,8 @@ uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio,
                                const GateArgs* gate = nullptr);
 // pose.hip
 uvo_status pose_triangulate(Ctx* c, const double* P1, const double* P2, const int* d_n, int n_max);
+uvo_status pose_triangulate_extract3d(Ctx* c, int slot, const double* P1, const double* P2, const double* R1, const double* t1,
+                                      const double* R2, const double* t2, const double* K1, const double* K2, const int* d_n, int n_max);
 uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, const double* R2, const double* t2,
                           const double* K1, const double* K2, const int* d_n, int n_max);
 uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const double* R, const double* t, const double* K,

@@ -40,7 +40,8 @@ typedef enum {
  * complete before the call (the caller synchronised the stream that produced it), or the producing stream is declared with
  * uvo_ctx_set_producer_stream and the context orders its reads after the work queued on that stream at call time.
  * Lifetime: a buffer given to a synchronous call may be reused when the call returns; a buffer given to uvo_stereo_submit /
- * uvo_mono_submit is read asynchronously and must stay valid and unmodified until the matching collect returns. */
+ * uvo_mono_submit is read asynchronously and must stay valid and unmodified until the matching collect returns (a device image with
+ * tight pitch and a 16-byte aligned base is not even copied: the detector reads it in place). */
 enum { UVO_MEM_HOST = 0, UVO_MEM_DEVICE = 1 };
 
 /* cv::KeyPoint (28 B), cv::DMatch (16 B), cv::Point2f -- same field order and size */
