@@ -741,8 +741,8 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     // triangulation + extract_3Dpoints (VO:631-632)
     Range r_tri("uvo:triangulatePoints + extract_3Dpoints");
     const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
-    LANE_TRY(pose_triangulate_extract3d(L, 0, c->P_eye_left, c->P_right, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap));
-    UVO_HIP_TRY(c, hipMemcpyAsync(L->h_countsA[0], L->d_counts, sizeof(int) * CN_TOTAL, hipMemcpyDeviceToHost, st));
+    LANE_TRY(pose_triangulate_extract3d(L, 0, c->P_eye_left, c->P_right, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap,
+                                        L->h_countsA[0]));                                  // the counters land in pinned memory, no copy queued
     UVO_HIP_TRY(c, hipEventRecord(L->evA[0], st));
     if (tr) UVO_HIP_TRY(c, hipEventRecord(tr->ev[2], st));
     // state carry VO:727-733: this pair's set is the next pair's "prev"

@@ -129,10 +129,13 @@ __device__ __forceinline__ int block_compact_pos(bool keep, int* wtot, int* s_ba
 __global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const int* flag, const uvo_point2f* xc,
                                                       const int* n_p, int n_imm, int min_pts,
                                                       int* tmp_idx, double* good_pts, int* good_idx, float* opts, uvo_point2f* ipts,
-                                                      int* counts /* [1] = G */)
+                                                      int* counts /* [1] = G */, int* counts_host /* pinned mirror of all the step's counters, or null */)
 {
     const int n = n_p ? *n_p : n_imm;
     const int tid = threadIdx.x;
+    // the last kernel of the loops' device stage: it leaves the counters where the host reads them (no copy to queue behind it)
+    // (every thread calls it with the same G: one wave-wide store, i.e. one burst over PCIe instead of twenty single writes)
+    auto publish = [&](int G) { if (tid == 0) counts[1] = G; if (counts_host && tid < CN_TOTAL) counts_host[tid] = tid == 1 ? G : counts[tid]; };
     __shared__ int wtot[16];
     __shared__ int s_base;
     __shared__ double s_mean, s_sd3;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const 
     __syncthreads();
     const int ngood = s_base;
     if (ngood < min_pts || ngood == 0) {                    // VOU:222
-        if (tid == 0) counts[1] = 0;
+        publish(0);
         return;
     }
     {   // MU:35-56: sum and sum of squares in index order.  z and z*z are staged through LDS in chunks; the two sequential chains run
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const 
         }
     }
     __syncthreads();
-    if (tid == 0) counts[1] = s_base;
+    publish(s_base);
 }
 
 // ---------------------------------------------------------------- PnP RANSAC
@@ -391,7 +394,8 @@ uvo_status pose_triangulate(Ctx* c, const double* P1, const double* P2, const in
 }
 // triangulatePoints + extract_3Dpoints on the same point pairs (d_x1, d_x2), as both loops call them: two launches instead of three
 uvo_status pose_triangulate_extract3d(Ctx* c, int slot, const double* P1, const double* P2, const double* R1, const double* t1,
-                                      const double* R2, const double* t2, const double* K1, const double* K2, const int* d_n, int n_max)
+                                      const double* R2, const double* t2, const double* K1, const double* K2, const int* d_n, int n_max,
+                                      int* counts_host)
 {
     if (n_max > 0) {
         Mat34 a, b; memcpy(a.v, P1, sizeof(a.v)); memcpy(b.v, P2, sizeof(b.v));
@@ -403,7 +407,7 @@ uvo_status pose_triangulate_extract3d(Ctx* c, int slot, const double* P1, const 
     StageTimer t(c, ST_EXTRACT3D);
     hipLaunchKernelGGL(k_extract3d_b, dim3(1), dim3(1024), 0, c->stream, c->d_cam1, c->d_flag, c->d_xc, d_n, n_max,
                        c->p.MIN_NUM_3DPOINTS, c->d_tmp_idx, c->d_good_pts[slot], c->d_good_idx[slot], c->d_opts[slot], c->d_ipts[slot],
-                       c->d_counts);
+                       c->d_counts, counts_host);
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }
@@ -418,6 +422,7 @@ static Cam make_cam(const double* R, const double* t, const double* K)
 uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, const double* R2, const double* t2,
                           const double* K1, const double* K2, const int* d_n, int n_max)
 {
+    int* counts_host = nullptr;
     StageTimer t(c, ST_EXTRACT3D);
     if (n_max > 0) {
         hipLaunchKernelGGL(k_extract3d_a, dim3((n_max + 255) / 256), dim3(256), 0, c->stream, c->d_pts4, c->d_x1, c->d_x2,
@@ -425,7 +430,7 @@ uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, 
     }
     hipLaunchKernelGGL(k_extract3d_b, dim3(1), dim3(1024), 0, c->stream, c->d_cam1, c->d_flag, c->d_xc, d_n, n_max,
                        c->p.MIN_NUM_3DPOINTS, c->d_tmp_idx, c->d_good_pts[slot], c->d_good_idx[slot], c->d_opts[slot], c->d_ipts[slot],
-                       c->d_counts);
+                       c->d_counts, counts_host);
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }

@@ -237,7 +237,8 @@ uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio,
 // pose.hip
 uvo_status pose_triangulate(Ctx* c, const double* P1, const double* P2, const int* d_n, int n_max);
 uvo_status pose_triangulate_extract3d(Ctx* c, int slot, const double* P1, const double* P2, const double* R1, const double* t1,
-                                      const double* R2, const double* t2, const double* K1, const double* K2, const int* d_n, int n_max);
+                                      const double* R2, const double* t2, const double* K1, const double* K2, const int* d_n, int n_max,
+                                      int* counts_host = nullptr);     // counts_host: pinned mirror of d_counts written by the last kernel
 uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, const double* R2, const double* t2,
                           const double* K1, const double* K2, const int* d_n, int n_max);
 uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const double* R, const double* t, const double* K,
