@@ -242,13 +242,16 @@ def main():
         avg_ms = ms / max(n, 1)
         alg_bytes = algorithmic_bytes_hessian_o0(WIDTH, HEIGHT, 2)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed counter passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/probe/
+        # final_profiles_r02.sh, FETCH_SIZE doubled per MI355X_MICROARCH.md): the newest summary that has the kernel
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_hessian_o0.json")
-        if os.path.exists(pmc_path):
+        for name, pick in (("r02_pmc_stage_kernels.json", lambda d: d["kernels"]["hessian_o0"]["hbm_bytes_fetch_x2"]),
+                           ("pmc_hessian_o0.json", lambda d: d["hbm_bytes_per_launch"])):
             try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                traffic = int(pick(json.load(open(os.path.join(ROOT, "profiles", name)))))
+                break
             except Exception:
-                traffic = None
+                continue
         # the all-pairs contraction of the matcher against the f32 MFMA peak (F = 2 Nq Nt 64 per call)
         mm_ms, mm_n = tm["match_top2"]
         f_pair = 2.0 * 64 * (rl.n_left * rl.n_right + rl.n_stereo_matches * rl.n_left)
