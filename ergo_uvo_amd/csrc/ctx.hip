@@ -10,7 +10,7 @@
 #include <new>
 #include <algorithm>
 #include <atomic>
-namespace uvo { extern bool g_bdbg; extern std::atomic<double> g_bstat[8]; double now_us(); void operator+=(std::atomic<double>& a, double v); }
+namespace uvo { extern bool g_bdbg; extern std::atomic<double> g_bstat[16]; double now_us(); void operator+=(std::atomic<double>& a, double v); }
 
 using namespace uvo;
 
@@ -227,6 +227,9 @@ extern "C" void uvo_ctx_destroy(uvo_ctx* c)
         fprintf(stderr, "[uvo] stage B over %.0f calls, host wall us per call: wait-for-A %.1f | hyp+score to sync %.1f | host scan + refit launch %.1f | refit to sync %.1f | semaphore wait %.1f\n",
                 n, uvo::g_bstat[0].load() / n, uvo::g_bstat[1].load() / n, uvo::g_bstat[2].load() / n, uvo::g_bstat[3].load() / n, uvo::g_bstat[5].load() / n);
         fprintf(stderr, "[uvo] uvo_stereo_submit host wall: %.1f us per pair over %.0f pairs\n", uvo::g_bstat[6].load() / std::max(1.0, uvo::g_bstat[7].load()), uvo::g_bstat[7].load());
+        const double np = std::max(1.0, uvo::g_bstat[7].load());
+        fprintf(stderr, "[uvo]   of which: upload %.1f | a_overlap wait %.1f | detector launches %.1f | matcher .. extract_3Dpoints launches %.1f\n",
+                uvo::g_bstat[8].load() / np, uvo::g_bstat[9].load() / np, uvo::g_bstat[10].load() / np, uvo::g_bstat[11].load() / np);
     }
     write_trace(c);
     for (size_t i = c->lanes.size(); i > 1; i--) destroy_one(static_cast<uvo_ctx*>(c->lanes[i - 1]));
@@ -702,11 +705,22 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     // slows down (measured with UVO_TRACE: detection 390 us with two, 1050 us with five lanes in stage A).
     // So this pair's kernels wait for the end of the stage A submitted a_overlap pairs ago; the lanes beyond that hold pairs
     // in their PnP stage.
+    double t_seg = uvo::g_bdbg ? uvo::now_us() : 0;
+    auto seg = [&](int slot) { if (uvo::g_bdbg) { const double t = uvo::now_us(); uvo::g_bstat[slot] += t - t_seg; t_seg = t; } };
+    seg(8);                                                                                // upload (+ producer wait)
+    // Pacing.  At most a_overlap stage As run side by side, and it is the submitting thread that waits (hipEventSynchronize spins) for
+    // the stage A submitted a_overlap pairs ago before it queues this pair's kernels.  A device-side wait instead (hipStreamWaitEvent on
+    // an event that is still pending, so that the kernels sit behind a barrier packet in their hardware queue) was measured at 1200-2200
+    // pairs/s against 3800: a queue parked on a barrier slows the other queues down.  evA[1] is the twin of the event the lane's worker
+    // blocks on -- the runtime holds an event's lock while a thread waits on it.
+    // (Queueing the light integral kernels ahead of the wait was tried: no gain.)
     if (c->a_overlap > 0 && depth > c->a_overlap) {
         Ctx* H = c->lanes[(li + depth - c->a_overlap) % depth];
-        UVO_HIP_TRY(c, hipStreamWaitEvent(L->stream, H->evA[0], 0));
+        if (c->n_pending >= c->a_overlap) (void)hipEventSynchronize(H->evA[1]);
     }
+    seg(9);                                                                                // the a_overlap wait
     { Range r("uvo:detect_features x2"); LANE_TRY(surf_detect(L, 2, p.MIN_NUM_FEATURES)); }        // VO:548-549, and the VO:556 gate
+    seg(10);                                                                               // detector launches
     if (tr) UVO_HIP_TRY(c, hipEventRecord(tr->ev[1], L->stream));
     const int cap = c->cap, curr = L->as_w, prev = c->prev_buf;
     int* cn = L->d_counts;
@@ -744,6 +758,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     LANE_TRY(pose_triangulate_extract3d(L, 0, c->P_eye_left, c->P_right, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap,
                                         L->h_countsA[0]));                                  // the counters land in pinned memory, no copy queued
     UVO_HIP_TRY(c, hipEventRecord(L->evA[0], st));
+    UVO_HIP_TRY(c, hipEventRecord(L->evA[1], st));                                          // the same point for other streams (see uvo_ctx.h)
     if (tr) UVO_HIP_TRY(c, hipEventRecord(tr->ev[2], st));
     // state carry VO:727-733: this pair's set is the next pair's "prev"
     L->as_w = curr ^ 1;
@@ -755,13 +770,14 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
         L->job.kind = 0; L->job.state = 1;
     }
     L->cv.notify_all();
+    seg(11);                                                                               // matcher .. extract_3Dpoints launches, hand-over
     if (uvo::g_bdbg) { uvo::g_bstat[6] += uvo::now_us() - t_sub; uvo::g_bstat[7] += 1; }
     return UVO_OK;
 #undef LANE_TRY
 }
 
 // Stage B of one lane's pair (VO:634-648), on the lane's worker thread: wait for stage A, then solvePnPRansac.
-namespace uvo { extern bool g_bdbg; extern std::atomic<double> g_bstat[8]; double now_us(); void operator+=(std::atomic<double>& a, double v); }
+namespace uvo { extern bool g_bdbg; extern std::atomic<double> g_bstat[16]; double now_us(); void operator+=(std::atomic<double>& a, double v); }
 static void run_stage_b(uvo_ctx* L, bool stage_a_ok)
 {
     Ctx::BJob& j = L->job;
@@ -1300,9 +1316,9 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
     if (L->prev_read_pending) { UVO_HIP_TRY(c, hipStreamWaitEvent(st, L->evPrevRead, 0)); L->prev_read_pending = false; }   // the frame after this lane's last one has read its buffers
     UVO_TRY(wait_for_producer(c, L, mem));
     LANE_TRY(surf_upload(L, 0, img, w, h, stride, mem));
-    if (c->a_overlap > 0 && depth > c->a_overlap) {                                        // as uvo_stereo_submit: at most a_overlap stage As side by side
+    if (c->a_overlap > 0 && depth > c->a_overlap) {                                        // as uvo_stereo_submit: at most a_overlap stage As side by side, paced by this thread
         Ctx* H = c->lanes[(li + depth - c->a_overlap) % depth];
-        UVO_HIP_TRY(c, hipStreamWaitEvent(st, H->evA[0], 0));
+        if (c->n_pending >= c->a_overlap) (void)hipEventSynchronize(H->evA[1]);
     }
     LANE_TRY(surf_detect(L, 1));                                                           // VO:274
     UVO_HIP_TRY(c, hipEventRecord(L->evDet, st));
@@ -1318,6 +1334,7 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
     if (P != L) { UVO_HIP_TRY(c, hipEventRecord(P->evPrevRead, st)); P->prev_read_pending = true; }
     UVO_HIP_TRY(c, hipMemcpyAsync(L->h_countsA[0], L->d_counts, sizeof(int) * CN_TOTAL, hipMemcpyDeviceToHost, st));
     UVO_HIP_TRY(c, hipEventRecord(L->evA[0], st));
+    UVO_HIP_TRY(c, hipEventRecord(L->evA[1], st));                                          // the same point for other streams (see uvo_ctx.h)
     c->prev_lane = li; c->next_lane = (li + 1) % depth;
     c->inflight[c->n_pending++] = li; c->n_submitted++;
     {

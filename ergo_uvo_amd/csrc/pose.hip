@@ -451,7 +451,7 @@ uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const doubl
 
 // UVO_DBG_BSTAGE=1: host wall time of the PnP stage's segments, summed over calls (printed by uvo_ctx_destroy)
 bool g_bdbg = getenv("UVO_DBG_BSTAGE") != nullptr;
-std::atomic<double> g_bstat[8];
+std::atomic<double> g_bstat[16];
 namespace {
 struct Roctx {
     int (*push)(const char*) = nullptr; int (*pop)() = nullptr;

@@ -136,7 +136,10 @@ struct Ctx {
     // "after stereo match" set, read from the previous lane's buffers behind an event.
     hipStream_t pnp_stream = nullptr;
     int* d_countsB = nullptr;  int* h_countsB = nullptr;             // [0] = n_inliers
-    hipEvent_t evA[2] = {nullptr, nullptr};      // [0]: stage A of this lane's pair finished (counts in h_countsA[0])
+    hipEvent_t evA[2] = {nullptr, nullptr};      // stage A of this lane's pair finished (counts in h_countsA[0]): [0] is the one the lane's worker
+                                                 // blocks on (hipEventSynchronize), [1] its twin for other lanes' hipStreamWaitEvent -- the runtime holds
+                                                 // an event's lock while a host thread waits on it, so a stream wait on the SAME event blocked the
+                                                 // submitting thread until the event completed (133 us per pair at C3)
     int* h_countsA[2] = {nullptr, nullptr};      // pinned copy of d_counts
     hipEvent_t evAS = nullptr;                   // this lane's "after stereo match" set is written
     int a_overlap = 2;                           // master: stage As (detect .. extract_3Dpoints) allowed side by side (env UVO_A_OVERLAP, 0 = no limit)

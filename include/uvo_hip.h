@@ -152,7 +152,8 @@ uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uint8_t* right
  * extract_3Dpoints on its pipeline lane and returns at once; the lane's worker thread runs PnP-RANSAC as soon as
  * that work finishes; uvo_stereo_collect returns the result of the OLDEST submitted pair.  Up to `depth` pairs may
  * be in flight (uvo_stereo_set_depth), so the detector of pairs k+1.. overlaps the pose solve of pair k; results
- * are identical to uvo_stereo_step's.  The pairs consumed by the init loop (VO:474-520) run synchronously inside
+ * are identical to uvo_stereo_step's.  Submit paces the pipeline: it may block until the detector stage of the pair submitted two
+ * pairs earlier has drained (at most two detector stages run side by side).  The pairs consumed by the init loop (VO:474-520) run synchronously inside
  * uvo_stereo_submit; their results queue like any other, so a caller need not know when the loop initialises.
  * Pipeline depth: 1..8, default 2.  Each unit of depth is one more set of device buffers, two more HIP streams and
  * one more host worker thread; changing it restarts nothing unless the lane holding the previous pair is removed. */
