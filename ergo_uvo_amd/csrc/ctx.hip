@@ -107,7 +107,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     c->surv_cap = 4 * (int)cap; A(dalloc(&c->d_surv, (size_t)c->surv_cap));
     A(dalloc(&c->d_colpart, (size_t)2 * nstrip * c->colpart_stride));
     A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_par, cap * 4)); A(dalloc(&c->d_big_patch, cap * 2 * 448));
-    A(dalloc(&c->d_mpart, nchunks * cap)); A(dalloc(&c->d_mscratch, nchunks + 4)); A(dalloc(&c->d_knn_idx, cap * 2)); A(dalloc(&c->d_knn_dist, cap * 2));
+    A(dalloc(&c->d_mpart, 2 * nchunks * cap)); A(dalloc(&c->d_mscratch, 2 * (nchunks + 4))); A(dalloc(&c->d_knn_idx, 2 * cap * 2)); A(dalloc(&c->d_knn_dist, 2 * cap * 2));
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
     A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_tmp_idx, cap));
     for (int i = 0; i < 2; i++) {
@@ -726,25 +726,24 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     int* cn = L->d_counts;
     const float ratio = (float)p.LOWE_RATIO_THRESHOLD;
     hipStream_t st = L->stream;
-    // stereo matching L -> R (VO:558), gated on device by VO:556
-    { Range r_ms("uvo:match_features stereo + select");
-    LANE_TRY(match_knn2(L, L->det[0].desc, cn + CN_NQA, cap, L->det[1].desc, cn + CN_NR, cap));
-    // from here on the previous pair's "after stereo match" set (another lane's buffers) is needed
+    // Stereo matching L -> R (VO:558, gated on the device by VO:556) and triangular matching prev-left-after-stereo -> curr-left
+    // (VO:592) share their launches: both only need this pair's descriptors and the previous pair's "after stereo match" set
+    // (another lane's buffers, behind its event).  The triangular match is computed for every row of that set; whether it is used
+    // is VO:567's decision, taken by the first compaction's gate and read by the second's (cn[CN_NQB]).
+    { Range r_ms("uvo:match_features stereo + triangular, select");
     if (!c->prev_sync && P != L) UVO_HIP_TRY(c, hipStreamWaitEvent(st, P->evAS, 0));
+    LANE_TRY(match_knn2_two(L, L->det[0].desc, cn + CN_NQA, L->det[1].desc, cn + CN_NR,
+                            P->d_as_descL[prev], P->d_as_n + prev, L->det[0].desc, cn + CN_NL, cap));
     const GateArgs gate_b = { 1, cn, p.MIN_NUM_FEATURES, cap, L->d_as_n + curr, P->d_as_n + prev };       // VO:567
-    LANE_TRY(match_ratio_compact(L, cn + CN_NQA, cap, ratio, L->d_matches[0], cn + CN_M, cap, &gate_b));
+    const GateArgs gate_c = { 2, cn, p.MIN_NUM_FEATURES, cap, nullptr, nullptr };                           // VO:626
+    LANE_TRY(match_ratio_compact2(L, ratio, cn + CN_NQA, L->d_matches[0], cn + CN_M, gate_b,
+                                  cn + CN_NQB, L->d_matches[1], cn + CN_TRAW, gate_c, cap, cap));
     {
         StageTimer t(L, ST_GATHER);
         hipLaunchKernelGGL(k_gather_after_stereo, dim3((cap + 15) / 16), dim3(256), 0, st, L->d_matches[0], cn,
                            L->det[0].kps, L->det[1].kps, L->det[0].desc, L->d_as_kpsL[curr], L->d_as_kpsR[curr], L->d_as_descL[curr], L->desc_dim());
     }
     UVO_HIP_TRY(c, hipEventRecord(L->evAS, st));
-    }
-    // triangular matching prev-left-after-stereo -> curr-left (VO:592)
-    { Range r_mt("uvo:match_features triangular + select");
-    LANE_TRY(match_knn2(L, P->d_as_descL[prev], cn + CN_NQB, cap, L->det[0].desc, cn + CN_NL, cap));
-    const GateArgs gate_c = { 2, cn, p.MIN_NUM_FEATURES, cap, nullptr, nullptr };                           // VO:626
-    LANE_TRY(match_ratio_compact(L, cn + CN_NQB, cap, ratio, L->d_matches[1], cn + CN_TRAW, cap, &gate_c));
     {
         StageTimer t(L, ST_GATHER);
         hipLaunchKernelGGL(k_gather_triangular, dim3((cap + 255) / 256), dim3(256), 0, st, L->d_matches[1], cn,

@@ -81,13 +81,20 @@ __device__ __forceinline__ void split_bf16x8(const float4 v0, const float4 v1, u
 template <int D> struct RowQuads { static constexpr int value = D / 4 + 1; };
 template <int D> static constexpr size_t match_rows_lds() { return sizeof(uint4) * kMfmaChunk * RowQuads<D>::value; }
 
-// part: [chunk][cap] (k0, k1, k2, k3): the four smallest shortlist keys; chunk_tnmax[chunk]: max |t|^2 of the chunk's rows
+// One or two independent matching problems per launch (blockIdx.y): the stereo loop's L -> R and prev -> curr matches are both
+// ready to run once the detector has finished, and one launch of ~1060 tiles fills the chip where two of ~530 each did not.
+// part: [chunk][cap] (k0, k1, k2, k3): the four smallest shortlist keys; tnmax[chunk]: max |t|^2 of the chunk's rows
+struct MatchProb { const float* dq; const int* nq_p; int nq_imm; const float* dt; const int* nt_p; int nt_imm;
+                   float4* part; float* tnmax; int* knn_idx; float* knn_dist; };
+struct MatchBatch { MatchProb p[2]; int cap; };
+
 template <int D>
-__global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ dq, const int* nq_p, int nq_imm,
-                                                    const float* __restrict__ dt, const int* nt_p, int nt_imm,
-                                                    int cap, float4* part, float* chunk_tnmax)
+__global__ __launch_bounds__(256) void k_match_mfma(MatchBatch mb)
 {
-    const int nq = nq_p ? *nq_p : nq_imm, nt = nt_p ? *nt_p : nt_imm;
+    const MatchProb& P = mb.p[blockIdx.y];
+    const float* __restrict__ dq = P.dq; const float* __restrict__ dt = P.dt;
+    float4* part = P.part; float* chunk_tnmax = P.tnmax; const int cap = mb.cap;
+    const int nq = P.nq_p ? *P.nq_p : P.nq_imm, nt = P.nt_p ? *P.nt_p : P.nt_imm;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     __shared__ __align__(16) float s_tn[kMfmaChunk];                     // |t|^2 of the staged rows (kBig past the end: never wins)
     extern __shared__ uint4 s_rows[];                                    // [kMfmaChunk][kRowQuads]: the chunk's train rows as bf16 hi | lo, shared by the four waves
@@ -228,12 +235,13 @@ __device__ __forceinline__ float group_distance(const float4 (&qv)[NV], const fl
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__ dq, const int* nq_p, int nq_imm,
-                                                      const float* __restrict__ dt, const int* nt_p, int nt_imm,
-                                                      int cap, const float4* part, const float* chunk_tnmax,
-                                                      int* knn_idx, float* knn_dist)
+__global__ __launch_bounds__(256) void k_match_resolve(MatchBatch mb)
 {
-    const int nq = nq_p ? *nq_p : nq_imm, nt = nt_p ? *nt_p : nt_imm;
+    const MatchProb& P = mb.p[blockIdx.y];
+    const float* __restrict__ dq = P.dq; const float* __restrict__ dt = P.dt;
+    const float4* part = P.part; const float* chunk_tnmax = P.tnmax; const int cap = mb.cap;
+    int* knn_idx = P.knn_idx; float* knn_dist = P.knn_dist;
+    const int nq = P.nq_p ? *P.nq_p : P.nq_imm, nt = P.nt_p ? *P.nt_p : P.nt_imm;
     const int sub = threadIdx.x & 15;
     const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
     if (blockIdx.x * 16 >= nq) return;
@@ -314,77 +322,96 @@ __global__ __launch_bounds__(256) void k_match_resolve(const float* __restrict__
     }
 }
 
-// ratio test + ordered compaction, one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void k_match_compact(const int* knn_idx, const float* knn_dist, const int* nq_p, int nq_imm,
-                                                        float ratio, uvo_dmatch* out, int* nout, int out_cap, GateArgs g)
+// ratio test + ordered compaction, one workgroup of 1024 threads; with two problems they are compacted one after the other (the
+// second's query count is the one the first's gate has just written: VO:567 decides whether the triangular matches are used)
+struct CompactProb { const int* knn_idx; const float* knn_dist; const int* nq_p; int nq_imm; uvo_dmatch* out; int* nout; int out_cap; GateArgs g; };
+struct CompactBatch { CompactProb p[2]; int np; float ratio; };
+__global__ __launch_bounds__(1024) void k_match_compact(CompactBatch cb)
 {
-    const int nq = nq_p ? *nq_p : nq_imm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     __shared__ int wtot[16];
     __shared__ int s_base;
-    if (tid == 0) s_base = 0;
-    __syncthreads();
-    for (int base = 0; base < nq; base += 1024) {
-        int q = base + tid;
-        bool keep = false; int i0 = -1; float d0 = 0.f;
-        if (q < nq) {
-            i0 = knn_idx[2*q]; int i1 = knn_idx[2*q + 1];
-            d0 = knn_dist[2*q]; float d1 = knn_dist[2*q + 1];
-            keep = i0 >= 0 && i1 >= 0 && d0 < ratio * d1;
-        }
-        unsigned long long bal = __ballot(keep);
-        int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wtot[wv] = __popcll(bal);
+    for (int pi = 0; pi < cb.np; pi++) {
+        const CompactProb& P = cb.p[pi];
+        const int* knn_idx = P.knn_idx; const float* knn_dist = P.knn_dist;
+        uvo_dmatch* out = P.out; const int out_cap = P.out_cap; const GateArgs g = P.g; const float ratio = cb.ratio;
+        if (tid == 0) s_base = 0;
         __syncthreads();
-        int off = s_base;
-        for (int k = 0; k < wv; k++) off += wtot[k];
-        if (keep) {
-            int pos = off + before;
-            if (pos < out_cap) { uvo_dmatch m; m.queryIdx = q; m.trainIdx = i0; m.imgIdx = 0; m.distance = d0; out[pos] = m; }
+        const int nq = P.nq_p ? *P.nq_p : P.nq_imm;
+        for (int base = 0; base < nq; base += 1024) {
+            int q = base + tid;
+            bool keep = false; int i0 = -1; float d0 = 0.f;
+            if (q < nq) {
+                i0 = knn_idx[2*q]; int i1 = knn_idx[2*q + 1];
+                d0 = knn_dist[2*q]; float d1 = knn_dist[2*q + 1];
+                keep = i0 >= 0 && i1 >= 0 && d0 < ratio * d1;
+            }
+            unsigned long long bal = __ballot(keep);
+            int before = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) wtot[wv] = __popcll(bal);
+            __syncthreads();
+            int off = s_base;
+            for (int k = 0; k < wv; k++) off += wtot[k];
+            if (keep) {
+                int pos = off + before;
+                if (pos < out_cap) { uvo_dmatch m; m.queryIdx = q; m.trainIdx = i0; m.imgIdx = 0; m.distance = d0; out[pos] = m; }
+            }
+            __syncthreads();
+            if (tid == 0) { int t = 0; for (int k = 0; k < 16; k++) t += wtot[k]; s_base += t; }
+            __syncthreads();
         }
-        __syncthreads();
-        if (tid == 0) { int t = 0; for (int k = 0; k < 16; k++) t += wtot[k]; s_base += t; }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        *nout = s_base;                // may exceed out_cap: the host reports UVO_CAPACITY
-        int* cn = g.cn;
-        if (g.mode == 1) {             // VO:567: results_match_curr.size() > MIN_NUM_FEATURES, else the "after stereo match" sets stay empty
-            int M = cn[CN_NQA] > 0 ? cn[CN_M] : 0;
-            if (cn[CN_NQA] == 0) cn[CN_M] = 0;
-            int meff = (M > g.min_features) ? min(M, g.cap) : 0;
-            cn[CN_MEFF] = meff;
-            *g.as_curr_n = meff;
-            cn[CN_NQB] = meff > 0 ? *g.as_prev_n : 0;      // triangular matching only runs inside that branch
-        } else if (g.mode == 2) {      // VO:626: results_match_prev_curr.size() > MIN_NUM_FEATURES
-            int T = cn[CN_NQB] > 0 ? cn[CN_TRAW] : 0;
-            if (cn[CN_NQB] == 0) cn[CN_TRAW] = 0;
-            cn[CN_T] = (T > g.min_features) ? min(T, g.cap) : 0;
-            cn[CN_G] = 0;
+        if (tid == 0) {
+            *P.nout = s_base;                // may exceed out_cap: the host reports UVO_CAPACITY
+            int* cn = g.cn;
+            if (g.mode == 1) {             // VO:567: results_match_curr.size() > MIN_NUM_FEATURES, else the "after stereo match" sets stay empty
+                int M = cn[CN_NQA] > 0 ? cn[CN_M] : 0;
+                if (cn[CN_NQA] == 0) cn[CN_M] = 0;
+                int meff = (M > g.min_features) ? min(M, g.cap) : 0;
+                cn[CN_MEFF] = meff;
+                *g.as_curr_n = meff;
+                cn[CN_NQB] = meff > 0 ? *g.as_prev_n : 0;      // triangular matching only runs inside that branch
+            } else if (g.mode == 2) {      // VO:626: results_match_prev_curr.size() > MIN_NUM_FEATURES
+                int T = cn[CN_NQB] > 0 ? cn[CN_TRAW] : 0;
+                if (cn[CN_NQB] == 0) cn[CN_TRAW] = 0;
+                cn[CN_T] = (T > g.min_features) ? min(T, g.cap) : 0;
+                cn[CN_G] = 0;
+            }
         }
+        __threadfence_block();
+        __syncthreads();                    // the next problem reads the counters written above
     }
 }
 
-template <int D>
-static uvo_status match_knn2_d(Ctx* c, const float* d_q, const int* d_nq, int nq_max, const float* d_t, const int* d_nt, int nt_max)
+static size_t mpart_elems(const Ctx* c) { return (size_t)((c->cap + kMfmaChunk - 1) / kMfmaChunk) * c->cap; }     // float4 per problem
+static MatchProb make_prob(Ctx* c, int slot, const float* d_q, const int* d_nq, int nq_max, const float* d_t, const int* d_nt, int nt_max)
 {
-    float* tnmax = c->d_mscratch;                    // [chunk] max |t|^2
+    MatchProb p;
+    p.dq = d_q; p.nq_p = d_nq; p.nq_imm = nq_max; p.dt = d_t; p.nt_p = d_nt; p.nt_imm = nt_max;
+    p.part = c->d_mpart + (size_t)slot * mpart_elems(c);
+    p.tnmax = c->d_mscratch + (size_t)slot * ((c->cap + kMfmaChunk - 1) / kMfmaChunk + 4);
+    p.knn_idx = c->d_knn_idx + (size_t)slot * 2 * c->cap; p.knn_dist = c->d_knn_dist + (size_t)slot * 2 * c->cap;
+    return p;
+}
+
+template <int D>
+static uvo_status match_launch(Ctx* c, const MatchBatch& mb, int np, int nq_max, int nt_max)
+{
     {
         StageTimer t(c, ST_MATCH);
         const int tiles_max = ((nq_max + 127) / 128) * ((nt_max + kMfmaChunk - 1) / kMfmaChunk);
-        dim3 grid(tiles_max < 768 ? tiles_max : 768);          // three workgroups per CU; larger problems loop
+        const int gmax = 768 / np;                              // three workgroups per CU over the whole launch; larger problems loop
+        dim3 grid(tiles_max < gmax ? tiles_max : gmax, np);
         static bool attr_set = false;                          // more than 64 KB of LDS (D = 128) has to be asked for, once per process
         if (!attr_set && match_rows_lds<D>() > 48 * 1024) {
             UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_mfma<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)match_rows_lds<D>()));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_match_mfma<D>, grid, dim3(256), match_rows_lds<D>(), c->stream, d_q, d_nq, nq_max, d_t, d_nt, nt_max, c->cap, c->d_mpart, tnmax);
+        hipLaunchKernelGGL(k_match_mfma<D>, grid, dim3(256), match_rows_lds<D>(), c->stream, mb);
         UVO_HIP_TRY(c, hipGetLastError());
     }
     {
         StageTimer t(c, ST_MATCH_MERGE);
-        hipLaunchKernelGGL(k_match_resolve<D>, dim3((nq_max + 15) / 16), dim3(256), 0, c->stream, d_q, d_nq, nq_max, d_t, d_nt, nt_max,
-                           c->cap, c->d_mpart, tnmax, c->d_knn_idx, c->d_knn_dist);
+        hipLaunchKernelGGL(k_match_resolve<D>, dim3((nq_max + 15) / 16, np), dim3(256), 0, c->stream, mb);
         UVO_HIP_TRY(c, hipGetLastError());
     }
     return UVO_OK;
@@ -395,18 +422,49 @@ uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, con
 {
     if (nq_max <= 0 || nt_max <= 0) return UVO_OK;
     if (nq_max > c->cap || nt_max > c->cap) { c->err = "match: descriptor count exceeds the context's max_kpts"; return UVO_CAPACITY; }
-    return c->desc_dim() == 128 ? match_knn2_d<128>(c, d_q, d_nq, nq_max, d_t, d_nt, nt_max)
-                                : match_knn2_d<64>(c, d_q, d_nq, nq_max, d_t, d_nt, nt_max);
+    MatchBatch mb;
+    mb.p[0] = mb.p[1] = make_prob(c, 0, d_q, d_nq, nq_max, d_t, d_nt, nt_max); mb.cap = c->cap;
+    return c->desc_dim() == 128 ? match_launch<128>(c, mb, 1, nq_max, nt_max) : match_launch<64>(c, mb, 1, nq_max, nt_max);
+}
+
+// Two independent problems in one launch each of the shortlist and the resolve kernels: results of problem s in slot s of the
+// shortlist / kNN buffers (match_ratio_compact2 reads them from there).
+uvo_status match_knn2_two(Ctx* c, const float* d_q0, const int* d_nq0, const float* d_t0, const int* d_nt0,
+                          const float* d_q1, const int* d_nq1, const float* d_t1, const int* d_nt1, int n_max)
+{
+    if (n_max <= 0) return UVO_OK;
+    if (n_max > c->cap) { c->err = "match: descriptor count exceeds the context's max_kpts"; return UVO_CAPACITY; }
+    MatchBatch mb;
+    mb.p[0] = make_prob(c, 0, d_q0, d_nq0, n_max, d_t0, d_nt0, n_max);
+    mb.p[1] = make_prob(c, 1, d_q1, d_nq1, n_max, d_t1, d_nt1, n_max);
+    mb.cap = c->cap;
+    return c->desc_dim() == 128 ? match_launch<128>(c, mb, 2, n_max, n_max) : match_launch<64>(c, mb, 2, n_max, n_max);
 }
 
 uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio, uvo_dmatch* d_out, int* d_nout, int out_cap,
                                const GateArgs* gate)
 {
     StageTimer t(c, ST_MATCH_MERGE);
+    CompactBatch cb;
     GateArgs g = { 0, nullptr, 0, 0, nullptr, nullptr };
     if (gate) g = *gate;
-    hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(1024), 0, c->stream, c->d_knn_idx, c->d_knn_dist, d_nq, nq_max, ratio,
-                       d_out, d_nout, out_cap, g);
+    cb.p[0] = CompactProb{ c->d_knn_idx, c->d_knn_dist, d_nq, nq_max, d_out, d_nout, out_cap, g };
+    cb.p[1] = cb.p[0]; cb.np = 1; cb.ratio = ratio;
+    hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(1024), 0, c->stream, cb);
+    UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+
+// the ratio tests + compactions of match_knn2_two's problems, with their gates, in order, in one launch
+uvo_status match_ratio_compact2(Ctx* c, float ratio, const int* d_nq0, uvo_dmatch* d_out0, int* d_nout0, const GateArgs& g0,
+                                const int* d_nq1, uvo_dmatch* d_out1, int* d_nout1, const GateArgs& g1, int n_max, int out_cap)
+{
+    StageTimer t(c, ST_MATCH_MERGE);
+    CompactBatch cb;
+    cb.p[0] = CompactProb{ c->d_knn_idx, c->d_knn_dist, d_nq0, n_max, d_out0, d_nout0, out_cap, g0 };
+    cb.p[1] = CompactProb{ c->d_knn_idx + (size_t)2 * c->cap, c->d_knn_dist + (size_t)2 * c->cap, d_nq1, n_max, d_out1, d_nout1, out_cap, g1 };
+    cb.np = 2; cb.ratio = ratio;
+    hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(1024), 0, c->stream, cb);
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }

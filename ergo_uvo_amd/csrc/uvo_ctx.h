@@ -90,9 +90,10 @@ struct Ctx {
     float* d_DW = nullptr;
 
     // ---- matcher ----
-    float4* d_mpart = nullptr;                   // shortlist per (train chunk, query): (s0, i0, s1, i1)
-    float* d_mscratch = nullptr;                 // [train chunk] max |t|^2 of the chunk
-    int* d_knn_idx = nullptr;  float* d_knn_dist = nullptr;   // [cap][2]
+    // two slots each (the stereo loop's two matches share their launches, match_knn2_two)
+    float4* d_mpart = nullptr;                   // [2] shortlist per (train chunk, query): the four smallest keys
+    float* d_mscratch = nullptr;                 // [2][train chunk] max |t|^2 of the chunk
+    int* d_knn_idx = nullptr;  float* d_knn_dist = nullptr;   // [2][cap][2]
     float* d_tmp_desc[2] = {nullptr, nullptr};   // staging for the standalone match API
     uvo_dmatch* d_matches[2] = {nullptr, nullptr};            // [0] stereo (L-R), [1] triangular (prev-curr)
     int* d_nmatch = nullptr;                     // [2]
@@ -235,6 +236,10 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features = -1);   // integ
 uvo_status surf_hessian_layer_debug(Ctx* c, int octave, int layer, float* det, float* trace);
 // match.hip
 uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, const float* d_t, const int* d_nt, int nt_max);
+uvo_status match_knn2_two(Ctx* c, const float* d_q0, const int* d_nq0, const float* d_t0, const int* d_nt0,
+                          const float* d_q1, const int* d_nq1, const float* d_t1, const int* d_nt1, int n_max);
+uvo_status match_ratio_compact2(Ctx* c, float ratio, const int* d_nq0, uvo_dmatch* d_out0, int* d_nout0, const GateArgs& g0,
+                                const int* d_nq1, uvo_dmatch* d_out1, int* d_nout1, const GateArgs& g1, int n_max, int out_cap);
 uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio, uvo_dmatch* d_out, int* d_nout, int out_cap,
                                const GateArgs* gate = nullptr);
 // pose.hip
