@@ -724,6 +724,36 @@ __global__ __launch_bounds__(NT) void k_hessian_nms_p(ImgPair ip, int w, int h, 
     nms_survivors<TW, TH, NT>(sdet, s_list, op, thr, px0, py0, im, sv);
 }
 
+// Octaves 2 and 3 in one launch (blockIdx.x walks octave 2's tiles, then octave 3's): both are latency-bound on plane reads and
+// neither fills the chip (5120 and 2560 waves); side by side they take about what octave 2 took alone.
+static const int kP23Threads = 512;
+__global__ __launch_bounds__(kP23Threads) void k_hessian_nms_p23(ImgPair ip, int w, int h, OctavePat op2, OctavePat op3, float thr, SurvOut sv,
+                                                                 int nbx2, int nb2, int nbx3)
+{
+    constexpr int TW2 = 32, TH2 = 16, TW3 = 16, TH3 = 16;
+    __shared__ float sdet[3 * TH2 * TW2];
+    __shared__ unsigned s_list[NmsLds<TW2, TH2>::kWords];
+    static_assert(TW3 * TH3 <= TW2 * TH2 && NmsLds<TW3, TH3>::kWords <= NmsLds<TW2, TH2>::kWords, "octave 3 reuses octave 2's LDS");
+    const int im = blockIdx.y;
+    int b = blockIdx.x;
+    if (b < nb2) {
+        const int px0 = (b % nbx2) * (TW2 - 2) - 1, py0 = (b / nbx2) * (TH2 - 2) - 1;
+        det_layer_p<2, 1, TW2, TH2, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op2, px0, py0, thr);
+        det_layer_p<2, 2, TW2, TH2, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op2, px0, py0, thr);
+        det_layer_p<2, 3, TW2, TH2, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op2, px0, py0, thr);
+        __syncthreads();
+        nms_survivors<TW2, TH2, kP23Threads>(sdet, s_list, op2, thr, px0, py0, im, sv);
+    } else {
+        b -= nb2;
+        const int px0 = (b % nbx3) * (TW3 - 2) - 1, py0 = (b / nbx3) * (TH3 - 2) - 1;
+        det_layer_p<3, 1, TW3, TH3, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op3, px0, py0, thr);
+        det_layer_p<3, 2, TW3, TH3, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op3, px0, py0, thr);
+        det_layer_p<3, 3, TW3, TH3, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op3, px0, py0, thr);
+        __syncthreads();
+        nms_survivors<TW3, TH3, kP23Threads>(sdet, s_list, op3, thr, px0, py0, im, sv);
+    }
+}
+
 // debug / parity hook: one det+trace layer written to global planes (rows x cols)
 __global__ void k_hessian_layer_debug(const int32_t* gsum, int w, int h, LayerPat lp, int step, int rows, int cols,
                                       float* det, float* trace)
@@ -1638,10 +1668,22 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             UVO_HIP_TRY(c, hipMemcpyAsync(c->d_octpat, c->h_octpat.data(), sizeof(ops), hipMemcpyHostToDevice, c->stream));
             UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
+        const bool merge23 = c->p.SURF_OCTAVES_NUMBER == 4;
         for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER; o++) {
             StageTimer t(c, ST_HESSIAN_O0 + o);
             const OctavePat& op = ops[o];
             hipError_t e;
+            if (merge23 && o == 3) break;                      // octave 3 ran inside octave 2's launch
+            if (merge23 && o == 2) {
+                ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
+                SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
+                const int nbx2 = (ops[2].cols + 32 - 3) / (32 - 2), nby2 = (ops[2].rows + 16 - 3) / (16 - 2);
+                const int nbx3 = (ops[3].cols + 16 - 3) / (16 - 2), nby3 = (ops[3].rows + 16 - 3) / (16 - 2);
+                hipLaunchKernelGGL(k_hessian_nms_p23, dim3(nbx2 * nby2 + nbx3 * nby3, nimg), dim3(kP23Threads), 0, c->stream, ip, w, h, ops[2], ops[3], thr, sv,
+                                   nbx2, nbx2 * nby2, nbx3);
+                UVO_HIP_TRY(c, hipGetLastError());
+                continue;
+            }
             // tile shapes chosen by pipelined throughput (tools/probe/ab.sh): octave 0 64 x 24 samples = 40 KB of LDS (18 KB det planes,
             // 19 KB integral tile, 3 KB survivor list), octave 1 32 x 24 = 59 KB (9 KB + 48 KB: the 54-pixel templates make the halo
             // most of the tile)
