@@ -332,7 +332,7 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5)},
-            "roofline_desc": {"bound": "hbm", "kernel": "descriptor stage of a pair (k_big_sort, k_descriptor64_small, k_descriptor64_big, k_descriptor64_big_finish)",
+            "roofline_desc": {"bound": "hbm", "kernel": "descriptor stage of a pair (k_big_sort, k_descriptor64: small- and large-window blocks in one launch, k_descriptor64_big_finish)",
                               "achieved": round(desc_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(desc_gbs / HBM_PEAK_GBS, 6),
                               "algorithmic_bytes_per_pair": b_desc, "stage_ms_per_pair": round(d_ms, 5)},
             # the f32 contraction (F = 2 Nq Nt 64) is priced against the f32 MFMA peak; it is executed on the bf16 pipe

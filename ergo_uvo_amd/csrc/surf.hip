@@ -796,7 +796,7 @@ struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* 
 static const int kSmallWin = 128;       // descriptor windows up to this size use the small-LDS kernel
 static const int kMaxWin = 740;         // (int)(21 * 264 * 1.2f / 9) = 739: the window of the largest octave-3 keypoint
 // Large windows are listed in append order by k_rank_scatter and then sorted by descending window size (a (keypoint,
-// column) task of k_descriptor64_big costs about ceil(win/256) lane passes x ceil((win/21 + 2)/16) tap batches, 1..9 units),
+// column) task of descriptor64_big costs about ceil(win/256) lane passes x ceil((win/21 + 2)/16) tap batches, 1..9 units),
 // which the task dealing of that kernel relies on.  Counting sort, one workgroup per image.
 static const int kBigBins = 1024;
 static const int kTripleWin = 246;     // windows up to this size: three destination columns per task (3 x 246 floats share the 740-float row buffer)
@@ -997,7 +997,7 @@ __device__ __forceinline__ void describe_tail(const DescArgs& a, int im, int k, 
 // WIN[i][j] = img(clamp(start_y - j), clamp(start_x + i)) is evaluated separably, exactly as
 // resizeArea_ does: buf[i][dx] = sum_j WIN[i][j]*alpha_j (lanes run along i = image x, coalesced),
 // then PATCH[dy][dx] = sum_i beta_i*buf[i][dx].  Windows up to kSmallWin = 128 samples (10.5 KB of LDS); larger
-// ones are skipped here and handled by k_descriptor64_big.
+// ones are skipped here and handled by descriptor64_big.
 __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int h, int k, int im)
 {
     const int tid = threadIdx.x;
@@ -1005,7 +1005,7 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
     const float size = kp.size;
     const float s = size * 1.2f / 9.0f;
     const int win_size = (int)((20 + 1) * s);
-    if (win_size > kSmallWin) return;                  // large windows: k_descriptor64_big
+    if (win_size > kSmallWin) return;                  // large windows: descriptor64_big
     extern __shared__ __align__(16) unsigned char smem_desc[];
     float* buf = reinterpret_cast<float*>(smem_desc);                 // [21][bp]
     const int bp = win_size | 1;                                      // odd pitch: the vertical pass walks 21 columns bank-conflict-free
@@ -1332,14 +1332,14 @@ __global__ __launch_bounds__(256) void k_descriptor_rot(DescArgs a, int w, int h
     }
 }
 
-// small windows: one workgroup per keypoint
-__global__ __launch_bounds__(256) void k_descriptor64_small(DescArgs a, int w, int h)
+// small windows: one workgroup per keypoint (block bx of nbx of the launch's small-window part)
+__device__ __forceinline__ void descriptor64_small(const DescArgs& a, int w, int h, int bx, int nbx)
 {
     const int im = blockIdx.y;
     const int n = *a.n[im];
     // one workgroup per keypoint when the grid has max_kpts of them (measured faster than a smaller grid walking the list:
     // the hardware hands the next keypoint to whichever CU frees up); the loop covers smaller grids
-    for (int k = blockIdx.x; k < n; k += gridDim.x) {
+    for (int k = bx; k < n; k += nbx) {
         describe_keypoint(a, w, h, k, im);
         __syncthreads();                     // the LDS buffers are reused by the next keypoint
     }
@@ -1349,7 +1349,7 @@ __global__ __launch_bounds__(256) void k_descriptor64_small(DescArgs a, int w, i
 // buf[i][dx] for every window row i exactly as above, and finishes the 21 outputs PATCH[dy][dx] of its column.  A
 // fixed grid walks the (keypoint, dx) tasks of the list built by k_rank_scatter, so the largest window is spread over
 // 21 workgroups instead of serialising one; k_descriptor64_big_finish turns the patches into descriptors.
-static const int kTapBatch = 16;           // image rows a lane of k_descriptor64_big has in flight
+static const int kTapBatch = 16;           // image rows a lane of descriptor64_big has in flight
 static const int kPatchStride = 448;       // bytes of patch scratch per keypoint (441 used)
 __device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // a < b ? x : y on scalar registers (the compiler turns the C expression into VALU selects on copies of the operands)
@@ -1366,19 +1366,20 @@ __device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__built
 // horizontal passes run one after the other into three thirds of the row buffer, then one vertical pass finishes the 63
 // outputs, a lane each): the per-task work that does not depend on the window -- parameters, tables, the vertical pass,
 // its 21-of-64 lanes -- is shared by three columns where the LDS allows it.
-__global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int h, uint8_t* __restrict__ patch)
+static const int kBigRow = 740;            // floats of row buffer per wave of the large-window part
+__device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h, uint8_t* __restrict__ patch, int bx, int nbx)
 {
     const int im = blockIdx.y, lane = threadIdx.x & 63, wv = sgpr_i(threadIdx.x >> 6);
     const int nb = a.big_n[im], nl = min(a.big_large[im], nb);        // the sorted list: nl wide windows first
-    __shared__ float s_bufrow[4][740];
-    float* bufrow0 = s_bufrow[wv];
+    extern __shared__ __align__(16) unsigned char smem_desc[];        // shared with the small-window part: 4 x kBigRow floats here
+    float* bufrow0 = reinterpret_cast<float*>(smem_desc) + wv * kBigRow;
     const uint8_t* __restrict__ img = a.img[im];
     // Tasks run down the size-sorted list (21 per wide keypoint, then 7 per narrower one) and are dealt to the waves in
     // rounds of alternating direction (round r hands task r*NW + p to wave p, or to wave NW-1-p when r is odd): costs span
     // 1..9 units, and this keeps the per-wave totals within about one task of each other, where a plain stride left the
     // waves that drew the giants running long after the rest.  (A shared atomic cursor does not work here: ~55k
     // device-scope increments of one address from 8 XCDs serialise at ~7 ns each.)
-    const int nt1 = nl * 21, ntask = nt1 + (nb - nl) * 7, NW = gridDim.x * 4, wid = blockIdx.x * 4 + wv;
+    const int nt1 = nl * 21, ntask = nt1 + (nb - nl) * 7, NW = nbx * 4, wid = bx * 4 + wv;
     auto task_of = [&](int r) { return r * NW + ((r & 1) ? NW - 1 - wid : wid); };
     auto entry_of = [&](int t) { return t < nt1 ? t / 21 : nl + (t - nt1) / 7; };
     // A task starts with two dependent fetches -- its keypoint's parameters, then that window size's resize table -- and a wave
@@ -1534,6 +1535,15 @@ __global__ __launch_bounds__(256) void k_descriptor64_big(DescArgs a, int w, int
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+// Both window classes in one launch: blocks [0, nbig) are the persistent waves of the large-window tasks, the rest take one
+// small-window keypoint each.  The large-window part stalls on its per-tap dependency chains, the small-window part on its
+// barriers; resident together they keep the VALU busier than one after the other (and a launch is saved).
+__global__ __launch_bounds__(256) void k_descriptor64(DescArgs a, int w, int h, uint8_t* __restrict__ patch, int nbig)
+{
+    // (large-window blocks first: small-window blocks first measured 78 us, alternating blocks 97 us, against 66-68 us)
+    if ((int)blockIdx.x < nbig) descriptor64_big(a, w, h, patch, blockIdx.x, nbig);
+    else descriptor64_small(a, w, h, blockIdx.x - nbig, gridDim.x - nbig);
 }
 __global__ __launch_bounds__(256) void k_descriptor64_big_finish(DescArgs a, const uint8_t* __restrict__ patch)
 {
@@ -1717,12 +1727,12 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
         DescArgs da = { { c->img[0], c->img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
                         { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap,      // the sorted list
                         c->d_area_tabs, c->d_area_iscale, c->p.SURF_EXTENDED ? 1 : 0, { c->d_sum[0], c->d_sum[1] }, c->d_ori_w, c->d_counts + CN_ORI_DROP };
-        const size_t lds_small = sizeof(float) * 21 * (kSmallWin | 1);
+        const size_t lds_small = sizeof(float) * 21 * (kSmallWin | 1), lds_big = sizeof(float) * 4 * kBigRow;
         hipLaunchKernelGGL(k_big_sort, dim3(nimg), dim3(1024), 0, c->stream, c->d_big_par, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap, c->d_area_iscale);
-        if (c->p.SURF_UPRIGHT) hipLaunchKernelGGL(k_descriptor64_big, dim3(1024, nimg), dim3(256), 0, c->stream, da, w, h, c->d_big_patch);
         if (c->p.SURF_UPRIGHT) {
+            const int nbig = 1024;                             // 8192 persistent waves for the large-window tasks (512: 80 us, 768..2048: 66-69 us)
+            hipLaunchKernelGGL(k_descriptor64, dim3(nbig + c->cap, nimg), dim3(256), lds_small > lds_big ? lds_small : lds_big, c->stream, da, w, h, c->d_big_patch, nbig);
             hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(1024, nimg), dim3(256), 0, c->stream, da, c->d_big_patch);
-            hipLaunchKernelGGL(k_descriptor64_small, dim3(c->cap, nimg), dim3(256), lds_small, c->stream, da, w, h);
         } else {
             // orientation assignment, then every descriptor from its rotated window (not the shipped configuration)
             const size_t lds_rot = sizeof(float) * 21 * (kMaxWin + 1);

@@ -17,11 +17,9 @@ T = sys.argv[1] if len(sys.argv) > 1 else "r02"
 KERNELS = {
     "hessian_o0": "k_hessian_nms_c<0",
     "hessian_o1": "k_hessian_nms_c<1",
-    "hessian_o2": "k_hessian_nms_p<2",
-    "hessian_o3": "k_hessian_nms_p<3",
     "hessian_finish": "k_hessian_finish",
-    "descriptor_big": "k_descriptor64_big(",
-    "descriptor_small": "k_descriptor64_small",
+    "descriptor64": "k_descriptor64(",
+    "hessian_o2_o3": "k_hessian_nms_p23",
     "integral_strip_final": "k_integral_strip_final",
     "rank_partial": "k_rank_partial",
     "match_mfma": "k_match_mfma",

@@ -11,7 +11,7 @@ g = np.diff(hs); i0 = int(np.argmax(np.convolve((g < 600_000).astype(int), np.on
 t0 = hs[i0] + int(t_start * 1e6) * 0 + int(t_start * 1e6) - int(30e6) + 0 if False else hs[i0] + int(t_start * 1e6)
 t1 = t0 + int(t_len * 1e6)
 code = {"k_integral": "i", "k_hessian_nms_c<0": "0", "k_hessian_nms_c<1": "1", "k_hessian_nms_p<2": "2", "k_hessian_nms_p<3": "3", "k_hessian_finish": "f", "k_rank": "r",
-        "k_big_sort": "s", "k_descriptor64_big_tabs": "t", "k_descriptor64_big_finish": "e", "k_descriptor64_big": "D", "k_descriptor64_small": "d", "k_match_mfma": "M",
+        "k_big_sort": "s", "k_descriptor64_big_tabs": "t", "k_descriptor64_big_finish": "e", "k_descriptor64(": "D", "k_match_mfma": "M",
         "k_match_resolve": "m", "k_match_compact": "c", "k_gather": "g", "k_triangulate": "T", "k_extract3d": "x", "k_pnp_hyp": "H", "k_pnp_score": "S", "k_pnp_mask": "k",
         "k_pnp_refit": "R", "__amd": "u"}
 W = 200
