@@ -651,22 +651,23 @@ __global__ __launch_bounds__(256) void k_hessian_finish(SurvOut sv, const Octave
     }
 }
 
+// One tile of octave 0 or 1 (tile bx, by of image im): the body of k_hessian_nms_c and of the octave-0 blocks of k_hessian_nms_c0_p23
 template <int O, int TW, int TH, int NT>
-__global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, OctavePat op, float thr, SurvOut sv)
+__device__ __forceinline__ void hessian_nms_c_tile(const ImgPair& ip, int w, int h, const OctavePat& op, float thr, const SurvOut& sv,
+                                                   int bx, int by, int im, unsigned char* smem)
 {
     using OC = OctC<O>;
     constexpr int STEP = OC::STEP;
     constexpr int TWs = OctTile<O, TW>::TWs;
     constexpr int THs = (TH - 1) * STEP + (OC::HI - OC::LO) + 1;
     constexpr int PW = OctTile<O, TW>::PW;
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int tid = threadIdx.x, im = blockIdx.z;
+    const int tid = threadIdx.x;
     const int sw = w + 1;
     const int32_t* __restrict__ gsum = ip.sum[im];
     float* sdet = reinterpret_cast<float*>(smem);                    // [3][TH][TW]: layers 1..3
     int32_t* stile = reinterpret_cast<int32_t*>(smem + sizeof(float) * 3 * TH * TW);   // [THs][STEP][PW]
 
-    const int px0 = blockIdx.x * (TW - 2) - 1, py0 = blockIdx.y * (TH - 2) - 1;
+    const int px0 = bx * (TW - 2) - 1, py0 = by * (TH - 2) - 1;
     const int sx0 = px0 * STEP + OC::LO, sy0 = py0 * STEP + OC::LO;
     // Tile fill: whole quads (global_load_dwordx4 at 4-byte alignment, ds_write_b128 / 2 x ds_write_b64), kFill of them in
     // flight per thread before the first LDS store.  Rows are clamped to the image; columns are not: every corner a valid
@@ -708,6 +709,12 @@ __global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, 
     __syncthreads();
     nms_survivors<TW, TH, NT>(sdet, reinterpret_cast<unsigned*>(stile + THs * STEP * PW), op, thr, px0, py0, im, sv);
 }
+template <int O, int TW, int TH, int NT>
+__global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, OctavePat op, float thr, SurvOut sv)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    hessian_nms_c_tile<O, TW, TH, NT>(ip, w, h, op, thr, sv, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+}
 
 // Octaves 2 and 3: det layers from the de-interleaved planes, det planes in LDS, survivors as above.
 template <int O, int TW, int TH, int NT>
@@ -724,33 +731,53 @@ __global__ __launch_bounds__(NT) void k_hessian_nms_p(ImgPair ip, int w, int h, 
     nms_survivors<TW, TH, NT>(sdet, s_list, op, thr, px0, py0, im, sv);
 }
 
-// Octaves 2 and 3 in one launch (blockIdx.x walks octave 2's tiles, then octave 3's): both are latency-bound on plane reads and
+// Octaves 2 and 3 in one launch (block b walks octave 2's tiles, then octave 3's): both are latency-bound on plane reads and
 // neither fills the chip (5120 and 2560 waves); side by side they take about what octave 2 took alone.
 static const int kP23Threads = 512;
-__global__ __launch_bounds__(kP23Threads) void k_hessian_nms_p23(ImgPair ip, int w, int h, OctavePat op2, OctavePat op3, float thr, SurvOut sv,
-                                                                 int nbx2, int nb2, int nbx3)
+struct P23Grid { int nbx2, nb2, nbx3, nb3; };
+__device__ __forceinline__ void hessian_nms_p23_tile(const ImgPair& ip, const OctavePat& op2, const OctavePat& op3, float thr, const SurvOut& sv,
+                                                     const P23Grid& g, int b, int im, float* sdet, unsigned* s_list)
 {
     constexpr int TW2 = 32, TH2 = 16, TW3 = 16, TH3 = 16;
-    __shared__ float sdet[3 * TH2 * TW2];
-    __shared__ unsigned s_list[NmsLds<TW2, TH2>::kWords];
     static_assert(TW3 * TH3 <= TW2 * TH2 && NmsLds<TW3, TH3>::kWords <= NmsLds<TW2, TH2>::kWords, "octave 3 reuses octave 2's LDS");
-    const int im = blockIdx.y;
-    int b = blockIdx.x;
-    if (b < nb2) {
-        const int px0 = (b % nbx2) * (TW2 - 2) - 1, py0 = (b / nbx2) * (TH2 - 2) - 1;
+    if (b < g.nb2) {
+        const int px0 = (b % g.nbx2) * (TW2 - 2) - 1, py0 = (b / g.nbx2) * (TH2 - 2) - 1;
         det_layer_p<2, 1, TW2, TH2, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op2, px0, py0, thr);
         det_layer_p<2, 2, TW2, TH2, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op2, px0, py0, thr);
         det_layer_p<2, 3, TW2, TH2, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op2, px0, py0, thr);
         __syncthreads();
         nms_survivors<TW2, TH2, kP23Threads>(sdet, s_list, op2, thr, px0, py0, im, sv);
     } else {
-        b -= nb2;
-        const int px0 = (b % nbx3) * (TW3 - 2) - 1, py0 = (b / nbx3) * (TH3 - 2) - 1;
+        b -= g.nb2;
+        const int px0 = (b % g.nbx3) * (TW3 - 2) - 1, py0 = (b / g.nbx3) * (TH3 - 2) - 1;
         det_layer_p<3, 1, TW3, TH3, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op3, px0, py0, thr);
         det_layer_p<3, 2, TW3, TH3, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op3, px0, py0, thr);
         det_layer_p<3, 3, TW3, TH3, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op3, px0, py0, thr);
         __syncthreads();
         nms_survivors<TW3, TH3, kP23Threads>(sdet, s_list, op3, thr, px0, py0, im, sv);
+    }
+}
+static const int kP23SdetFloats = 3 * 16 * 32;
+// Octave 0 (VALU-bound: 79 % busy) and octaves 2 + 3 (latency-bound plane reads) in ONE launch: the plane tiles are spread among
+// the octave-0 tiles (`every`: one plane tile after that many octave-0 tiles, the rest of octave 0 at the end), so that every CU
+// holds both kinds and the plane reads wait while the box sums issue.  Every block reserves octave 0's LDS (40 KB: four blocks per
+// CU either way, the limit is the 32 waves).  The patterns come from the device copy of the table (three of them exceed the 4 KB
+// of kernel arguments).
+template <int TW, int TH>
+__global__ __launch_bounds__(kP23Threads) void k_hessian_nms_c0_p23(ImgPair ip, int w, int h, const OctavePat* __restrict__ ops, float thr, SurvOut sv,
+                                                                    int nbx0, int nb0, P23Grid g, int every)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int im = blockIdx.y, b = blockIdx.x, nb23 = g.nb2 + g.nb3;
+    const int mixed = nb23 * (every + 1);                      // blocks [0, mixed): groups of `every` octave-0 tiles and one plane tile
+    int b0 = -1, b23 = -1;
+    if (b < mixed) { const int grp = b / (every + 1), r = b - grp * (every + 1); if (r < every) b0 = grp * every + r; else b23 = grp; }
+    else b0 = b - nb23;
+    if (b23 >= 0) {
+        float* sdet = reinterpret_cast<float*>(smem);
+        hessian_nms_p23_tile(ip, ops[2], ops[3], thr, sv, g, b23, im, sdet, reinterpret_cast<unsigned*>(sdet + kP23SdetFloats));
+    } else if (b0 < nb0) {
+        hessian_nms_c_tile<0, TW, TH, kP23Threads>(ip, w, h, ops[0], thr, sv, b0 % nbx0, b0 / nbx0, im, smem);
     }
 }
 
@@ -1678,22 +1705,37 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             UVO_HIP_TRY(c, hipMemcpyAsync(c->d_octpat, c->h_octpat.data(), sizeof(ops), hipMemcpyHostToDevice, c->stream));
             UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
-        const bool merge23 = c->p.SURF_OCTAVES_NUMBER == 4;
-        for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER; o++) {
+        // four octaves (the shipped configuration): octave 0 and octaves 2 + 3 share a launch, octave 1 has its own
+        const bool merged = c->p.SURF_OCTAVES_NUMBER == 4;
+        if (merged) {
+            ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
+            SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
+            constexpr int TW0 = 64, TH0 = 24;
+            using OC = OctC<0>;
+            constexpr int THs = (TH0 - 1) * OC::STEP + (OC::HI - OC::LO) + 1;
+            const size_t lds = sizeof(float) * 3 * TW0 * TH0 + sizeof(int32_t) * (size_t)THs * OC::STEP * OctTile<0, TW0>::PW + sizeof(unsigned) * NmsLds<TW0, TH0>::kWords;
+            const int nbx0 = (ops[0].cols + TW0 - 3) / (TW0 - 2), nb0 = nbx0 * ((ops[0].rows + TH0 - 3) / (TH0 - 2));
+            P23Grid g;
+            g.nbx2 = (ops[2].cols + 32 - 3) / (32 - 2); g.nb2 = g.nbx2 * ((ops[2].rows + 16 - 3) / (16 - 2));
+            g.nbx3 = (ops[3].cols + 16 - 3) / (16 - 2); g.nb3 = g.nbx3 * ((ops[3].rows + 16 - 3) / (16 - 2));
+            static const int every_env = getenv("UVO_HESSIAN_MIX") ? atoi(getenv("UVO_HESSIAN_MIX")) : -1;
+            int every = every_env >= 0 ? every_env : nb0 / (g.nb2 + g.nb3);
+            if (every * (g.nb2 + g.nb3) > nb0) every = nb0 / (g.nb2 + g.nb3);
+            auto kern = k_hessian_nms_c0_p23<TW0, TH0>;
+            static bool attr_set = false;
+            if (!attr_set) { UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
+            {
+                StageTimer t(c, ST_HESSIAN_O0);
+                hipLaunchKernelGGL(kern, dim3(nb0 + g.nb2 + g.nb3, nimg), dim3(kP23Threads), lds, c->stream, ip, w, h, static_cast<const OctavePat*>(c->d_octpat), thr, sv, nbx0, nb0, g, every);
+                UVO_HIP_TRY(c, hipGetLastError());
+            }
+            StageTimer t(c, ST_HESSIAN_O1);
+            UVO_HIP_TRY(c, (launch_hessian_c<1, 32, 24, 512>(c, nimg, ops[1], thr)));
+        }
+        for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER && !merged; o++) {
             StageTimer t(c, ST_HESSIAN_O0 + o);
             const OctavePat& op = ops[o];
             hipError_t e;
-            if (merge23 && o == 3) break;                      // octave 3 ran inside octave 2's launch
-            if (merge23 && o == 2) {
-                ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
-                SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
-                const int nbx2 = (ops[2].cols + 32 - 3) / (32 - 2), nby2 = (ops[2].rows + 16 - 3) / (16 - 2);
-                const int nbx3 = (ops[3].cols + 16 - 3) / (16 - 2), nby3 = (ops[3].rows + 16 - 3) / (16 - 2);
-                hipLaunchKernelGGL(k_hessian_nms_p23, dim3(nbx2 * nby2 + nbx3 * nby3, nimg), dim3(kP23Threads), 0, c->stream, ip, w, h, ops[2], ops[3], thr, sv,
-                                   nbx2, nbx2 * nby2, nbx3);
-                UVO_HIP_TRY(c, hipGetLastError());
-                continue;
-            }
             // tile shapes chosen by pipelined throughput (tools/probe/ab.sh): octave 0 64 x 24 samples = 40 KB of LDS (18 KB det planes,
             // 19 KB integral tile, 3 KB survivor list), octave 1 32 x 24 = 59 KB (9 KB + 48 KB: the 54-pixel templates make the halo
             // most of the tile)
