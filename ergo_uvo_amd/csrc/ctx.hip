@@ -525,27 +525,37 @@ extern "C" uvo_status uvo_rodrigues(const double* in, int n_in, double* out)
 
 // ------------------------------------------------------------------------------------------ stereo step
 // VO:569-579: curr_{left,right}_{descr,keypoints}_after_stereo_match by the stereo matches' indices
-__global__ __launch_bounds__(256) void k_gather_after_stereo(const uvo_dmatch* m, const int* cn, const uvo_keypoint* kL, const uvo_keypoint* kR,
-                                                             const float* dL, uvo_keypoint* okL, uvo_keypoint* okR, float* odL, int dim)
+__device__ __forceinline__ void gather_after_stereo(int bx, const uvo_dmatch* m, const int* cn, const uvo_keypoint* kL, const uvo_keypoint* kR,
+                                                    const float* dL, uvo_keypoint* okL, uvo_keypoint* okR, float* odL, int dim)
 {
     const int meff = cn[CN_MEFF];
-    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int row = bx * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
     if (row >= meff) return;
     const int q = m[row].queryIdx, t = m[row].trainIdx;
     for (int v = sub; v < dim / 4; v += 16) reinterpret_cast<float4*>(odL + (size_t)row * dim)[v] = reinterpret_cast<const float4*>(dL + (size_t)q * dim)[v];
     if (sub == 0) { okL[row] = kL[q]; okR[row] = kR[t]; }
 }
 // VO:601-617, 637-640: points of the triangular matches (prev left / prev right by queryIdx, curr left by trainIdx)
-__global__ __launch_bounds__(256) void k_gather_triangular(const uvo_dmatch* m, const int* cn, const uvo_keypoint* pL, const uvo_keypoint* pR,
-                                                           const uvo_keypoint* cL, uvo_point2f* x1, uvo_point2f* x2, uvo_point2f* xc)
+__device__ __forceinline__ void gather_triangular(int bx, const uvo_dmatch* m, const int* cn, const uvo_keypoint* pL, const uvo_keypoint* pR,
+                                                  const uvo_keypoint* cL, uvo_point2f* x1, uvo_point2f* x2, uvo_point2f* xc)
 {
     const int T = cn[CN_T];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = bx * 256 + threadIdx.x;
     if (i >= T) return;
     const int q = m[i].queryIdx, t = m[i].trainIdx;
     x1[i] = uvo_point2f{pL[q].x, pL[q].y};
     x2[i] = uvo_point2f{pR[q].x, pR[q].y};
     xc[i] = uvo_point2f{cL[t].x, cL[t].y};
+}
+// both gathers of a stereo step in one launch: blocks [0, n_as) build this pair's "after stereo match" set, the rest the point
+// pairs of the triangular matches
+struct GatherArgs { const uvo_dmatch* m_s; const uvo_dmatch* m_t; const int* cn; const uvo_keypoint* kL; const uvo_keypoint* kR; const float* dL;
+                    uvo_keypoint* okL; uvo_keypoint* okR; float* odL; int dim; const uvo_keypoint* pL; const uvo_keypoint* pR;
+                    uvo_point2f* x1; uvo_point2f* x2; uvo_point2f* xc; int n_as; };
+__global__ __launch_bounds__(256) void k_gather_stereo_step(GatherArgs a)
+{
+    if ((int)blockIdx.x < a.n_as) gather_after_stereo(blockIdx.x, a.m_s, a.cn, a.kL, a.kR, a.dL, a.okL, a.okR, a.odL, a.dim);
+    else gather_triangular(blockIdx.x - a.n_as, a.m_t, a.cn, a.pL, a.pR, a.kL, a.x1, a.x2, a.xc);
 }
 __global__ void k_gather_kps_idx(const uvo_keypoint* src, const int* idx, int n, uvo_keypoint* dst)
 {
@@ -740,15 +750,12 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
                                   cn + CN_NQB, L->d_matches[1], cn + CN_TRAW, gate_c, cap, cap));
     {
         StageTimer t(L, ST_GATHER);
-        hipLaunchKernelGGL(k_gather_after_stereo, dim3((cap + 15) / 16), dim3(256), 0, st, L->d_matches[0], cn,
-                           L->det[0].kps, L->det[1].kps, L->det[0].desc, L->d_as_kpsL[curr], L->d_as_kpsR[curr], L->d_as_descL[curr], L->desc_dim());
+        GatherArgs ga = { L->d_matches[0], L->d_matches[1], cn, L->det[0].kps, L->det[1].kps, L->det[0].desc,
+                          L->d_as_kpsL[curr], L->d_as_kpsR[curr], L->d_as_descL[curr], L->desc_dim(), P->d_as_kpsL[prev], P->d_as_kpsR[prev],
+                          L->d_x1, L->d_x2, L->d_xc, (cap + 15) / 16 };
+        hipLaunchKernelGGL(k_gather_stereo_step, dim3((cap + 15) / 16 + (cap + 255) / 256), dim3(256), 0, st, ga);
     }
     UVO_HIP_TRY(c, hipEventRecord(L->evAS, st));
-    {
-        StageTimer t(L, ST_GATHER);
-        hipLaunchKernelGGL(k_gather_triangular, dim3((cap + 255) / 256), dim3(256), 0, st, L->d_matches[1], cn,
-                           P->d_as_kpsL[prev], P->d_as_kpsR[prev], L->det[0].kps, L->d_x1, L->d_x2, L->d_xc);
-    }
     UVO_HIP_TRY(c, hipGetLastError());
     }
     // triangulation + extract_3Dpoints (VO:631-632)
