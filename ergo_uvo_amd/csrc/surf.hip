@@ -1718,15 +1718,14 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             P23Grid g;
             g.nbx2 = (ops[2].cols + 32 - 3) / (32 - 2); g.nb2 = g.nbx2 * ((ops[2].rows + 16 - 3) / (16 - 2));
             g.nbx3 = (ops[3].cols + 16 - 3) / (16 - 2); g.nb3 = g.nbx3 * ((ops[3].rows + 16 - 3) / (16 - 2));
-            static const int every_env = getenv("UVO_HESSIAN_MIX") ? atoi(getenv("UVO_HESSIAN_MIX")) : -1;
-            int every = every_env >= 0 ? every_env : nb0 / (g.nb2 + g.nb3);
-            if (every * (g.nb2 + g.nb3) > nb0) every = nb0 / (g.nb2 + g.nb3);
+            const int nb23 = g.nb2 + g.nb3;
+            const int every = nb23 > 0 ? nb0 / nb23 : 0;       // one plane tile after every `every` octave-0 tiles (1 .. 3 measured alike)
             auto kern = k_hessian_nms_c0_p23<TW0, TH0>;
             static bool attr_set = false;
             if (!attr_set) { UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
             {
                 StageTimer t(c, ST_HESSIAN_O0);
-                hipLaunchKernelGGL(kern, dim3(nb0 + g.nb2 + g.nb3, nimg), dim3(kP23Threads), lds, c->stream, ip, w, h, static_cast<const OctavePat*>(c->d_octpat), thr, sv, nbx0, nb0, g, every);
+                hipLaunchKernelGGL(kern, dim3(nb0 + nb23, nimg), dim3(kP23Threads), lds, c->stream, ip, w, h, static_cast<const OctavePat*>(c->d_octpat), thr, sv, nbx0, nb0, g, every);
                 UVO_HIP_TRY(c, hipGetLastError());
             }
             StageTimer t(c, ST_HESSIAN_O1);

@@ -82,6 +82,25 @@ def test_surf_detect_describe_bit_exact(ctx, oracle, shape, thr):
     assert np.array_equal(desc.view(np.uint32), odesc.view(np.uint32))
 
 
+@pytest.mark.parametrize("n_octaves", [1, 2, 3, 4])
+@pytest.mark.parametrize("shape", [(48, 48), (36, 300), (240, 320)])
+def test_surf_octave_counts_and_tiny_images_bit_exact(ctx, oracle, shape, n_octaves):
+    """nOctaves 1..4 (four takes the launch that carries octaves 0, 2 and 3 together, fewer the per-octave kernels) on images so
+    small that the upper octaves have few or no samples: same keypoints and descriptors as the oracle, or none on both sides."""
+    import ergo_uvo_amd as uvo
+    img = _rand_img(5, *shape)
+    ctx.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=20, SURF_OCTAVES_NUMBER=n_octaves))
+    try:
+        kps, desc = ctx.detect_features(img)
+        okps, odesc = oracle.surf(img, 20, n_octaves=n_octaves)
+        _assert_kps_equal(kps, okps)
+        assert np.array_equal(desc.view(np.uint32), odesc.view(np.uint32))
+        if shape == (240, 320):
+            assert len(okps) > 100 and (n_octaves < 3 or int(okps["octave"].max()) >= 2)
+    finally:
+        ctx.set_params(uvo.Params.stereo())
+
+
 @pytest.mark.parametrize("shape,thr", [((200, 262), 1), ((96, 350), 20)])
 def test_surf_dense_maxima_bit_exact(ctx, oracle, shape, thr):
     """White noise and an almost-zero threshold: every local maximum of every layer is a candidate, so the list of samples
