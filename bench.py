@@ -41,9 +41,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def algorithmic_bytes_hessian_launch(w: int, h: int, nimg: int, octaves=(0, 2, 3)) -> int:
+def algorithmic_bytes_hessian_launch(w: int, h: int, nimg: int, octaves=(0, 1, 2, 3)) -> int:
     """SURVEY.md 8(d) B_det restricted to what the dominant detection launch produces.  Since round 2 that launch
-    (k_hessian_nms_c0_p23) evaluates octaves 0, 2 and 3; per octave o of an image the model charges one read of the integral
+    (k_hessian_nms_all) evaluates all four octaves; per octave o of an image the model charges one read of the integral
     image (4(W+1)(H+1): "read once per octave") + det and trace written (2*S_o) + det read by the NMS (S_o), with
     S_o = 3 layers * 4 B * (H >> o)(W >> o) -- the launch evaluates the three middle layers of an octave for every sample; the
     two outer layers are only evaluated around the few thousand NMS survivors by k_hessian_finish, so their 2/5 of the
@@ -246,7 +246,7 @@ def main():
         # HBM bytes per launch from the committed counter passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/probe/
         # final_profiles_r02.sh, FETCH_SIZE doubled per MI355X_MICROARCH.md): the newest summary that has the kernel
         traffic = None
-        for name, pick in (("r02_pmc_stage_kernels.json", lambda d: d["kernels"]["hessian_o0_o2_o3"]["hbm_bytes_fetch_x2"]),):
+        for name, pick in (("r02_pmc_stage_kernels.json", lambda d: d["kernels"]["hessian_all_octaves"]["hbm_bytes_fetch_x2"]),):
             try:
                 traffic = int(pick(json.load(open(os.path.join(ROOT, "profiles", name)))))
                 break
@@ -328,7 +328,7 @@ def main():
                        "valid_steps": n_valid, "frames": args.frames, "parallelism": f"streams{world}", "pipeline": f"submit/collect, {args.depth} pairs in flight per image stream"},
             "value_device_resident": round(value, 3),
             "value_h2d_inclusive": None if h2d_value is None else round(h2d_value, 3),
-            "roofline": {"bound": "hbm", "kernel": "k_hessian_nms_c0_p23 (octaves 0, 2 and 3: 3 middle layers each, 2 images per launch)",
+            "roofline": {"bound": "hbm", "kernel": "k_hessian_nms_all (the four octaves, 3 middle layers each, 2 images per launch)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5)},

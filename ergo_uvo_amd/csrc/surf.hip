@@ -16,6 +16,9 @@
 #include <type_traits>
 #include <string.h>
 #include "uvo_math.h"
+#include <algorithm>
+#include <utility>
+#include <vector>
 
 namespace uvo {
 
@@ -758,26 +761,26 @@ __device__ __forceinline__ void hessian_nms_p23_tile(const ImgPair& ip, const Oc
     }
 }
 static const int kP23SdetFloats = 3 * 16 * 32;
-// Octave 0 (VALU-bound: 79 % busy) and octaves 2 + 3 (latency-bound plane reads) in ONE launch: the plane tiles are spread among
-// the octave-0 tiles (`every`: one plane tile after that many octave-0 tiles, the rest of octave 0 at the end), so that every CU
-// holds both kinds and the plane reads wait while the box sums issue.  Every block reserves octave 0's LDS (40 KB: four blocks per
-// CU either way, the limit is the 32 waves).  The patterns come from the device copy of the table (three of them exceed the 4 KB
-// of kernel arguments).
+// All four octaves in ONE launch.  Octave 0 is VALU-bound (79 % busy on its own), octave 1 waits on its L2 -> LDS tile fill
+// (VALU 46 %), octaves 2 + 3 on plane reads (7-21 %): their tiles are dealt out evenly over the launch (`order[b]`: kind and tile
+// index of block b, built on the host so that every kind is spread uniformly), so that every CU holds all kinds and the memory waits
+// of one hide behind the box sums of another.  Every block reserves the largest tile's LDS (octave 1 with 20 sample rows: 52.6 KB,
+// three blocks per CU -- the octave-0 / plane mix runs as fast with three as with four, 63 us, but not with two, 81 us).  The
+// patterns come from the device copy of the table (four of them exceed the 4 KB of kernel arguments).
+static const int kO1TileRows = 18;             // sample rows of an octave-1 tile in the merged launch
 template <int TW, int TH>
-__global__ __launch_bounds__(kP23Threads) void k_hessian_nms_c0_p23(ImgPair ip, int w, int h, const OctavePat* __restrict__ ops, float thr, SurvOut sv,
-                                                                    int nbx0, int nb0, P23Grid g, int every)
+__global__ __launch_bounds__(kP23Threads) void k_hessian_nms_all(ImgPair ip, int w, int h, const OctavePat* __restrict__ ops, float thr, SurvOut sv,
+                                                                 const uint16_t* __restrict__ order, int nbx0, int nbx1, P23Grid g)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int im = blockIdx.y, b = blockIdx.x, nb23 = g.nb2 + g.nb3;
-    const int mixed = nb23 * (every + 1);                      // blocks [0, mixed): groups of `every` octave-0 tiles and one plane tile
-    int b0 = -1, b23 = -1;
-    if (b < mixed) { const int grp = b / (every + 1), r = b - grp * (every + 1); if (r < every) b0 = grp * every + r; else b23 = grp; }
-    else b0 = b - nb23;
-    if (b23 >= 0) {
+    const int im = blockIdx.y;
+    const unsigned e = order[blockIdx.x];
+    const int kind = e >> 14, idx = e & 0x3FFF;
+    if (kind == 0) hessian_nms_c_tile<0, TW, TH, kP23Threads>(ip, w, h, ops[0], thr, sv, idx % nbx0, idx / nbx0, im, smem);
+    else if (kind == 1) hessian_nms_c_tile<1, 32, kO1TileRows, kP23Threads>(ip, w, h, ops[1], thr, sv, idx % nbx1, idx / nbx1, im, smem);
+    else {
         float* sdet = reinterpret_cast<float*>(smem);
-        hessian_nms_p23_tile(ip, ops[2], ops[3], thr, sv, g, b23, im, sdet, reinterpret_cast<unsigned*>(sdet + kP23SdetFloats));
-    } else if (b0 < nb0) {
-        hessian_nms_c_tile<0, TW, TH, kP23Threads>(ip, w, h, ops[0], thr, sv, b0 % nbx0, b0 / nbx0, im, smem);
+        hessian_nms_p23_tile(ip, ops[2], ops[3], thr, sv, g, idx, im, sdet, reinterpret_cast<unsigned*>(sdet + kP23SdetFloats));
     }
 }
 
@@ -1705,31 +1708,51 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             UVO_HIP_TRY(c, hipMemcpyAsync(c->d_octpat, c->h_octpat.data(), sizeof(ops), hipMemcpyHostToDevice, c->stream));
             UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
-        // four octaves (the shipped configuration): octave 0 and octaves 2 + 3 share a launch, octave 1 has its own
+        // four octaves (the shipped configuration): one launch for all of them
         const bool merged = c->p.SURF_OCTAVES_NUMBER == 4;
         if (merged) {
             ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
             SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
-            constexpr int TW0 = 64, TH0 = 24;
-            using OC = OctC<0>;
-            constexpr int THs = (TH0 - 1) * OC::STEP + (OC::HI - OC::LO) + 1;
-            const size_t lds = sizeof(float) * 3 * TW0 * TH0 + sizeof(int32_t) * (size_t)THs * OC::STEP * OctTile<0, TW0>::PW + sizeof(unsigned) * NmsLds<TW0, TH0>::kWords;
+            constexpr int TW0 = 64, TH0 = 32, TW1 = 32, TH1 = kO1TileRows;
+            constexpr int THs0 = (TH0 - 1) * OctC<0>::STEP + (OctC<0>::HI - OctC<0>::LO) + 1, THs1 = (TH1 - 1) * OctC<1>::STEP + (OctC<1>::HI - OctC<1>::LO) + 1;
+            constexpr size_t lds0 = sizeof(float) * 3 * TW0 * TH0 + sizeof(int32_t) * (size_t)THs0 * OctC<0>::STEP * OctTile<0, TW0>::PW + sizeof(unsigned) * NmsLds<TW0, TH0>::kWords;
+            constexpr size_t lds1 = sizeof(float) * 3 * TW1 * TH1 + sizeof(int32_t) * (size_t)THs1 * OctC<1>::STEP * OctTile<1, TW1>::PW + sizeof(unsigned) * NmsLds<TW1, TH1>::kWords;
+            constexpr size_t lds = lds0 > lds1 ? lds0 : lds1;
+            static_assert(lds <= 54600, "three blocks of the merged detection launch must fit a CU's 160 KB of LDS");
             const int nbx0 = (ops[0].cols + TW0 - 3) / (TW0 - 2), nb0 = nbx0 * ((ops[0].rows + TH0 - 3) / (TH0 - 2));
+            const int nbx1 = (ops[1].cols + TW1 - 3) / (TW1 - 2), nb1 = nbx1 * ((ops[1].rows + TH1 - 3) / (TH1 - 2));
             P23Grid g;
             g.nbx2 = (ops[2].cols + 32 - 3) / (32 - 2); g.nb2 = g.nbx2 * ((ops[2].rows + 16 - 3) / (16 - 2));
             g.nbx3 = (ops[3].cols + 16 - 3) / (16 - 2); g.nb3 = g.nbx3 * ((ops[3].rows + 16 - 3) / (16 - 2));
-            const int nb23 = g.nb2 + g.nb3;
-            const int every = nb23 > 0 ? nb0 / nb23 : 0;       // one plane tile after every `every` octave-0 tiles (1 .. 3 measured alike)
-            auto kern = k_hessian_nms_c0_p23<TW0, TH0>;
+            const int nb23 = g.nb2 + g.nb3, total = nb0 + nb1 + nb23;
+            if (nb0 > 0x3FFF || nb1 > 0x3FFF || nb23 > 0x3FFF) { c->err = "SURF: image too large for the merged detection launch's tile table"; return UVO_INVALID_ARG; }
+            if ((int)c->h_hess_order.size() != total || c->hess_order_key[0] != nb0 || c->hess_order_key[1] != nb1 || c->hess_order_key[2] != nb23) {
+                // block b's kind and tile: the i-th tile of a kind with n tiles sits at position (i + 1/2) / n of the launch
+                std::vector<std::pair<double, uint16_t>> pos;
+                pos.reserve((size_t)total);
+                const int nk[3] = { nb0, nb1, nb23 };
+                for (int k = 0; k < 3; k++) for (int i = 0; i < nk[k]; i++) pos.emplace_back((i + 0.5) / nk[k] + k * 1e-9, (uint16_t)((k << 14) | i));
+                std::sort(pos.begin(), pos.end());
+                c->h_hess_order.resize((size_t)total);
+                for (int b = 0; b < total; b++) c->h_hess_order[(size_t)b] = pos[(size_t)b].second;
+                UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));               // nothing may still read the old table
+                if (c->d_hess_order_cap < (size_t)total) {
+                    if (c->d_hess_order) (void)hipFree(c->d_hess_order);
+                    c->d_hess_order = nullptr; c->d_hess_order_cap = 0;
+                    UVO_HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_hess_order), sizeof(uint16_t) * (size_t)total));
+                    c->d_hess_order_cap = (size_t)total;
+                }
+                UVO_HIP_TRY(c, hipMemcpyAsync(c->d_hess_order, c->h_hess_order.data(), sizeof(uint16_t) * (size_t)total, hipMemcpyHostToDevice, c->stream));
+                UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+                c->hess_order_key[0] = nb0; c->hess_order_key[1] = nb1; c->hess_order_key[2] = nb23;
+            }
+            auto kern = k_hessian_nms_all<TW0, TH0>;
             static bool attr_set = false;
             if (!attr_set) { UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
-            {
-                StageTimer t(c, ST_HESSIAN_O0);
-                hipLaunchKernelGGL(kern, dim3(nb0 + nb23, nimg), dim3(kP23Threads), lds, c->stream, ip, w, h, static_cast<const OctavePat*>(c->d_octpat), thr, sv, nbx0, nb0, g, every);
-                UVO_HIP_TRY(c, hipGetLastError());
-            }
-            StageTimer t(c, ST_HESSIAN_O1);
-            UVO_HIP_TRY(c, (launch_hessian_c<1, 32, 24, 512>(c, nimg, ops[1], thr)));
+            StageTimer t(c, ST_HESSIAN_O0);
+            hipLaunchKernelGGL(kern, dim3(total, nimg), dim3(kP23Threads), lds, c->stream, ip, w, h, static_cast<const OctavePat*>(c->d_octpat), thr, sv,
+                               c->d_hess_order, nbx0, nbx1, g);
+            UVO_HIP_TRY(c, hipGetLastError());
         }
         for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER && !merged; o++) {
             StageTimer t(c, ST_HESSIAN_O0 + o);

@@ -15,8 +15,7 @@ OUT = os.path.join(ROOT, "gpurun_out")
 PROF = os.path.join(ROOT, "profiles")
 T = sys.argv[1] if len(sys.argv) > 1 else "r02"
 KERNELS = {
-    "hessian_o0_o2_o3": "k_hessian_nms_c0_p23",
-    "hessian_o1": "k_hessian_nms_c<1",
+    "hessian_all_octaves": "k_hessian_nms_all",
     "hessian_finish": "k_hessian_finish",
     "descriptor64": "k_descriptor64(",
     "integral_strip_final": "k_integral_strip_final",
