@@ -1709,7 +1709,8 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
         // four octaves (the shipped configuration): one launch for all of them
-        const bool merged = c->p.SURF_OCTAVES_NUMBER == 4;
+        static const bool split_env = getenv("UVO_HESSIAN_SPLIT") != nullptr;       // diagnostic: one launch per octave
+        const bool merged = c->p.SURF_OCTAVES_NUMBER == 4 && !split_env;
         if (merged) {
             ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
             SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
