@@ -110,7 +110,8 @@ def main():
                     der["simd_valu_busy_at_2.1GHz"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / SIMDS / (d1[key] * 2.1), 4)
                     der["duration_us_in_the_counter_pass"] = round(d1[key] / 1e3, 2)
                 if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("SQ_BUSY_CU_CYCLES"):
-                    der["mfma_busy_share_of_busy_cu_cycles"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / c["SQ_BUSY_CU_CYCLES"], 4)
+                    # SQ_VALU_MFMA_BUSY_CYCLES sums the four SIMDs' matrix pipes of a CU, SQ_BUSY_CU_CYCLES counts the CU once
+                    der["mfma_busy_share_of_a_busy_cu_4_pipes"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"]), 4)
                 e["derived"] = der
         if e:
             res["kernels"][key] = e
