@@ -401,7 +401,8 @@ static uvo_status match_launch(Ctx* c, const MatchBatch& mb, int np, int nq_max,
         const int tiles_max = ((nq_max + 127) / 128) * ((nt_max + kMfmaChunk - 1) / kMfmaChunk);
         const int gmax = 768 / np;                              // three workgroups per CU over the whole launch; larger problems loop
         dim3 grid(tiles_max < gmax ? tiles_max : gmax, np);
-        static bool attr_set = false;                          // more than 64 KB of LDS (D = 128) has to be asked for, once per process
+        static bool attr_dev[64] = {false};                   // more than 64 KB of LDS (D = 128) has to be asked for, once per device
+        bool& attr_set = attr_dev[c->device & 63];
         if (!attr_set && match_rows_lds<D>() > 48 * 1024) {
             UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_mfma<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)match_rows_lds<D>()));
             attr_set = true;

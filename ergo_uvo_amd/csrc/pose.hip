@@ -484,8 +484,8 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
     double t_b0 = g_bdbg ? now_us() : 0;
     if (n < 1 || n > kMaxPnpBatch) { m->err = "pnp batch size"; return UVO_INVALID_ARG; }
     const size_t hyp_lds = sizeof(double) * kHypGroups * kHypPerGroup;
-    static std::once_flag attr_once;
-    std::call_once(attr_once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_hyp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds); });
+    static std::once_flag attr_once[64];                                               // once per device
+    std::call_once(attr_once[m->device & 63], [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_hyp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds); });
     int niters0 = iterationsCount > 1 ? iterationsCount : 1;
     PnpBatch b;
     memset(&b, 0, sizeof(b));
@@ -623,8 +623,8 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
         StageTimer t(m, ST_PNP_REFIT, st);
         hipLaunchKernelGGL(k_pnp_mask, dim3(nb2), dim3(1024), 0, st, b2);
         const size_t refit_lds = sizeof(double) * Epnp<BlockPolicy>::kStageDoubles;
-        static std::once_flag refit_once;
-        std::call_once(refit_once, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_refit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)refit_lds); });
+        static std::once_flag refit_once[64];
+        std::call_once(refit_once[m->device & 63], [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_refit), hipFuncAttributeMaxDynamicSharedMemorySize, (int)refit_lds); });
         // the inlier count is known here: it is the winning hypothesis' count (k_pnp_mask repeats the same test)
         static const bool force_seq = getenv("UVO_REFIT_SEQUENTIAL") != nullptr;       // diagnostics: the OpenCV-ordered refit for every job
         bool any_fast = false, any_seq = b2.dbg != 0;

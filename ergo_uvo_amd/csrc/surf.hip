@@ -1678,7 +1678,8 @@ static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float 
     const size_t lds = sizeof(float) * 3 * TW * TH + sizeof(int32_t) * (size_t)THs * STEP * PW + sizeof(unsigned) * NmsLds<TW, TH>::kWords;
     dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
     auto kern = k_hessian_nms_c<O, TW, TH, NT>;
-    static bool attr_set = false;
+    static bool attr_dev[64] = {false};                       // once per device (a process may hold contexts on several)
+    bool& attr_set = attr_dev[c->device & 63];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1748,7 +1749,8 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
                 c->hess_order_key[0] = nb0; c->hess_order_key[1] = nb1; c->hess_order_key[2] = nb23;
             }
             auto kern = k_hessian_nms_all<TW0, TH0>;
-            static bool attr_set = false;
+            static bool attr_dev[64] = {false};
+            bool& attr_set = attr_dev[c->device & 63];
             if (!attr_set) { UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
             StageTimer t(c, ST_HESSIAN_O0);
             hipLaunchKernelGGL(kern, dim3(total, nimg), dim3(kP23Threads), lds, c->stream, ip, w, h, static_cast<const OctavePat*>(c->d_octpat), thr, sv,
@@ -1801,7 +1803,8 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
         } else {
             // orientation assignment, then every descriptor from its rotated window (not the shipped configuration)
             const size_t lds_rot = sizeof(float) * 21 * (kMaxWin + 1);
-            static bool rot_attr = false;
+            static bool rot_attr_dev[64] = {false};
+            bool& rot_attr = rot_attr_dev[c->device & 63];
             if (!rot_attr) { UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_descriptor_rot), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rot)); rot_attr = true; }
             hipLaunchKernelGGL(k_surf_orientation, dim3((c->cap + 3) / 4, nimg), dim3(256), 0, c->stream, da, w, h);
             hipLaunchKernelGGL(k_descriptor_rot, dim3(2048, nimg), dim3(256), lds_rot, c->stream, da, w, h);
