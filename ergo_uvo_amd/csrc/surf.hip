@@ -1569,7 +1569,8 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
 // Both window classes in one launch: blocks [0, nbig) are the persistent waves of the large-window tasks, the rest take one
 // small-window keypoint each.  The large-window part stalls on its per-tap dependency chains, the small-window part on its
 // barriers; resident together they keep the VALU busier than one after the other (and a launch is saved).
-__global__ __launch_bounds__(256) void k_descriptor64(DescArgs a, int w, int h, uint8_t* __restrict__ patch, int nbig)
+// (8 waves per SIMD: the compiler would settle at 66 VGPRs = 7 waves)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_descriptor64(DescArgs a, int w, int h, uint8_t* __restrict__ patch, int nbig)
 {
     // (large-window blocks first: small-window blocks first measured 78 us, alternating blocks 97 us, against 66-68 us)
     if ((int)blockIdx.x < nbig) descriptor64_big(a, w, h, patch, blockIdx.x, nbig);
