@@ -789,3 +789,34 @@ def test_contexts_come_and_go_without_leaking_device_memory(scene_small):
             free0 = free                                # after the first rounds: allocator pools and code objects are in place
         if it > 1:
             assert free0 - free < 64 << 20, (it, free0, free)
+
+
+@pytest.mark.parametrize("W,H", [(641, 363), (644, 360), (1000, 562)])
+def test_stereo_loop_at_odd_geometries_from_device_images(oracle, W, H):
+    """Widths that are not multiples of 8 / 4 (byte-wise integral loads, scalar descriptor taps) and images handed over as device
+    tensors (read in place when their base is 16-byte aligned; a misaligned view is copied): the loop still equals the oracle's."""
+    import torch
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    scene = synth.Scene(77, W)
+    rig = synth.stereo_rig(W)
+    pairs = [synth.stereo_pair(scene, k, W, H) for k in range(3)]
+    c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=1200), 0, W, H, 8192)
+    try:
+        c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        ovo = oracle.StereoVO(oracle.stereo_params(1200), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        flat = torch.empty(2 * W * H + 64, dtype=torch.uint8, device="cuda")
+        for k, (L, R) in enumerate(pairs):
+            off = 0 if k != 1 else 3                                   # pair 1 from a view that is not 16-byte aligned
+            dl = flat[off: off + W * H].view(H, W); dr = flat[off + W * H + 16: off + 2 * W * H + 16].view(H, W)
+            dl.copy_(torch.from_numpy(L)); dr.copy_(torch.from_numpy(R))
+            torch.cuda.synchronize()
+            r, o = c.stereo_step(dl, dr, 0.05), ovo.step(L, R, 0.05)
+            for f in ("valid", "initialized", "n_left", "n_right", "n_stereo_matches", "n_tri_matches", "n_good3d", "n_inliers"):
+                assert getattr(r, f) == getattr(o, f), (k, f, getattr(r, f), getattr(o, f))
+            _assert_kps_equal(c.stereo_get("kps_left"), ovo.get("kps_left"))
+            assert np.array_equal(c.stereo_get("desc_right").view(np.uint32), ovo.get("desc_right").view(np.uint32))
+            if k > 0:
+                assert r.valid == 1 and np.array_equal(c.stereo_get("inliers"), ovo.get("inliers"))
+    finally:
+        c.close()
