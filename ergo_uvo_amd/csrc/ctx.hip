@@ -177,7 +177,7 @@ static void write_trace(uvo_ctx* c)
 
 static uvo_status set_depth(uvo_ctx* c, int depth)
 {
-    if (depth < 1 || depth > 8) { c->err = "pipeline depth must be 1..8"; return UVO_INVALID_ARG; }
+    if (depth < 1 || depth > Ctx::kMaxDepth) { c->err = "pipeline depth must be 1..16"; return UVO_INVALID_ARG; }
     if (c->n_pending != 0) { c->err = "pipeline depth cannot change while pairs are in flight"; return UVO_INVALID_ARG; }
     while ((int)c->lanes.size() > depth) { destroy_one(static_cast<uvo_ctx*>(c->lanes.back())); c->lanes.pop_back(); }
     while ((int)c->lanes.size() < depth) {
@@ -205,8 +205,10 @@ extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w,
     uvo_status st = create_one(p, device, max_w, max_h, max_kpts, out);
     if (st != UVO_OK) return st;
     (*out)->lanes.push_back(*out);
-    if (getenv("UVO_MAX_B")) (*out)->max_b = std::min(8, std::max(1, atoi(getenv("UVO_MAX_B"))));
+    if (getenv("UVO_MAX_B")) (*out)->max_b = std::min(16, std::max(1, atoi(getenv("UVO_MAX_B"))));
     if (getenv("UVO_A_OVERLAP")) (*out)->a_overlap = std::min(8, std::max(0, atoi(getenv("UVO_A_OVERLAP"))));
+    if (getenv("UVO_MAX_B_MONO")) (*out)->max_b_mono = std::min(16, std::max(1, atoi(getenv("UVO_MAX_B_MONO"))));
+    if (getenv("UVO_A_OVERLAP_MONO")) (*out)->a_overlap_mono = std::min(8, std::max(0, atoi(getenv("UVO_A_OVERLAP_MONO"))));
     st = set_depth(*out, 2);                      // two pairs in flight by default (uvo_stereo_set_depth changes it)
     if (st != UVO_OK) { uvo_ctx_destroy(*out); *out = nullptr; }
     return st;
@@ -822,7 +824,8 @@ static void lane_worker(uvo_ctx* L)
             Ctx* m = L->master ? L->master : L;
             std::unique_lock<std::mutex> g(m->b_mu);
             const double tw = g_bdbg ? now_us() : 0;
-            m->b_cv.wait(g, [&] { return m->b_running < m->max_b; });
+            const int limit = L->job.kind == 1 ? m->max_b_mono : m->max_b;                  // the mono pose stage is far longer and thinner (see uvo_ctx.h)
+            m->b_cv.wait(g, [&] { return m->b_running < limit; });
             if (g_bdbg) g_bstat[5] += now_us() - tw;
             m->b_running++;
             g.unlock();
@@ -1322,9 +1325,9 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
     if (L->prev_read_pending) { UVO_HIP_TRY(c, hipStreamWaitEvent(st, L->evPrevRead, 0)); L->prev_read_pending = false; }   // the frame after this lane's last one has read its buffers
     UVO_TRY(wait_for_producer(c, L, mem));
     LANE_TRY(surf_upload(L, 0, img, w, h, stride, mem));
-    if (c->a_overlap > 0 && depth > c->a_overlap) {                                        // as uvo_stereo_submit: at most a_overlap stage As side by side, paced by this thread
-        Ctx* H = c->lanes[(li + depth - c->a_overlap) % depth];
-        if (c->n_pending >= c->a_overlap) (void)hipEventSynchronize(H->evA[1]);
+    if (c->a_overlap_mono > 0 && depth > c->a_overlap_mono) {                              // as uvo_stereo_submit: paced by this thread; one image per frame, so more stage As side by side
+        Ctx* H = c->lanes[(li + depth - c->a_overlap_mono) % depth];
+        if (c->n_pending >= c->a_overlap_mono) (void)hipEventSynchronize(H->evA[1]);
     }
     LANE_TRY(surf_detect(L, 1));                                                           // VO:274
     UVO_HIP_TRY(c, hipEventRecord(L->evDet, st));

@@ -146,6 +146,7 @@ struct Ctx {
     int* h_countsA[2] = {nullptr, nullptr};      // pinned copy of d_counts
     hipEvent_t evAS = nullptr;                   // this lane's "after stereo match" set is written
     int a_overlap = 2;                           // master: stage As (detect .. extract_3Dpoints) allowed side by side (env UVO_A_OVERLAP, 0 = no limit)
+    int a_overlap_mono = 4;                      // the same for mono frames (one image each; env UVO_A_OVERLAP_MONO)
     std::vector<Ctx*> lanes;                     // master only: lanes[0] == this
     Ctx* master = nullptr;                       // children only
     int lane_id = 0;
@@ -156,7 +157,8 @@ struct Ctx {
     struct Pending { bool used = false; };
     static const int kInflightMonoInit = -1, kInflightStereoInit = -2;      // inflight[] entries of the synchronous init frames / pairs (else: the lane)
     Pending pending;                             // this lane's pair
-    int inflight[8]; int n_pending = 0;          // master: lanes of the submitted, not yet collected pairs (FIFO)
+    static const int kMaxDepth = 16;
+    int inflight[kMaxDepth]; int n_pending = 0;          // master: lanes of the submitted, not yet collected pairs (FIFO)
     long long n_submitted = 0, n_collected = 0;
     int last_lane = 0;
     // stage-B worker of this lane
@@ -175,6 +177,8 @@ struct Ctx {
     hipEvent_t evDet = nullptr, evPrevRead = nullptr; bool prev_read_pending = false;
     std::thread worker; std::mutex mu; std::condition_variable cv; bool quit = false;
     std::mutex b_mu; std::condition_variable b_cv; int b_running = 0, max_b = 3;   // master: PnP stages running / allowed at once
+    int max_b_mono = 10;                         // ... and mono pose stages (env UVO_MAX_B_MONO): 2 ms of host-orchestrated, latency-bound kernels each (the
+                                                 // five-point solver keeps one wave per SIMD busy for 0.9 ms), so many of them side by side cost little
 
     // last-step bookkeeping for uvo_stereo_get
     int last_nL = 0, last_nR = 0, last_M = 0, last_T = 0, last_G = 0, last_ninl = 0;

@@ -155,7 +155,7 @@ uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uint8_t* right
  * are identical to uvo_stereo_step's.  Submit paces the pipeline: it may block until the detector stage of the pair submitted two
  * pairs earlier has drained (at most two detector stages run side by side).  The pairs consumed by the init loop (VO:474-520) run synchronously inside
  * uvo_stereo_submit; their results queue like any other, so a caller need not know when the loop initialises.
- * Pipeline depth: 1..8, default 2.  Each unit of depth is one more set of device buffers, two more HIP streams and
+ * Pipeline depth: 1..16, default 2 (the stereo loop is fastest at 6, the mono loop at about 14).  Each unit of depth is one more set of device buffers, two more HIP streams and
  * one more host worker thread; changing it restarts nothing unless the lane holding the previous pair is removed. */
 uvo_status uvo_stereo_set_depth(uvo_ctx* c, int depth);
 uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, int mem);

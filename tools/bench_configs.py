@@ -99,9 +99,9 @@ def main():
         nv += r.valid; ne += r.used_essential
     out["C4_mono_1920x1080_ransac"] = {"kpts": r.n_kps, "matches": r.n_matches, "valid": nv, "essential_used": ne,
                                        "frames_per_s": round(steps / (time.perf_counter() - t0), 1)}
-    # the same frames through uvo_mono_submit / uvo_mono_collect, six in flight
+    # the same frames through uvo_mono_submit / uvo_mono_collect, fourteen in flight (the mono pose stage is long and thin)
     ctx.mono_reset()
-    depth = 6
+    depth = 14
     ctx.stereo_set_depth(depth)
     steps = 600
     sub = 0

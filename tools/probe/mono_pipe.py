@@ -7,7 +7,7 @@ torch.cuda.init()
 import ergo_uvo_amd as uvo
 from ergo_uvo_amd import synth
 W, H = 1920, 1080
-depth = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+depth = int(sys.argv[1]) if len(sys.argv) > 1 else 14
 scene = synth.Scene(synth.SEEDS["C4"], W)
 dmono = [torch.from_numpy(synth.stereo_pair(scene, k, W, H)[0]).cuda() for k in (0, 4, 8, 12)]
 rig = synth.stereo_rig(W)
@@ -27,5 +27,5 @@ for steps in (24, 600):
             ctx.mono_submit(dmono[order[sub % 6]], rng); sub += 1
         nv += ctx.mono_collect(0.2).valid
     dt = time.perf_counter() - t0
-print("depth %d max_b %s: %.1f frames/s, valid %d" % (depth, os.environ.get("UVO_MAX_B", "3"), steps / dt, nv))
+print("depth %d max_b_mono %s a_overlap_mono %s: %.1f frames/s, valid %d" % (depth, os.environ.get("UVO_MAX_B_MONO", "10"), os.environ.get("UVO_A_OVERLAP_MONO", "4"), steps / dt, nv))
 ctx.close()
