@@ -206,6 +206,27 @@ class Context:
         self._check(self._lib.uvo_match_knn2_ratio(self._h, p1, n1, p2, n2, m1, C.c_float(ratio), _p(out), len(out), C.byref(m)))
         return out[:m.value].copy()
 
+    def match_features_hamming(self, descriptors1, descriptors2, ratio=None, matches=None):
+        """The AKAZE / ORB branch of match_features (VO_utility.cpp:520-524): uint8 rows of up to 64 bytes, Hamming distance."""
+        ratio = float(self.params.LOWE_RATIO_THRESHOLD if ratio is None else ratio)
+        d1, d2 = _np(descriptors1, np.uint8), _np(descriptors2, np.uint8)
+        if d1.ndim != 2 or d2.ndim != 2 or d1.shape[1] != d2.shape[1]:
+            raise ValueError("binary descriptors: two uint8 matrices with the same number of columns")
+        prev = 0 if matches is None else len(matches)
+        out = np.zeros(prev + max(len(d1), 1), DM_DTYPE)
+        if prev:
+            out[:prev] = matches
+        m = C.c_int(prev)
+        self._check(self._lib.uvo_match_knn2_ratio_hamming(self._h, _p(d1), len(d1), _p(d2), len(d2), d1.shape[1], 0, C.c_float(ratio), _p(out), len(out), C.byref(m)))
+        return out[:m.value].copy()
+
+    def knn_match_hamming(self, descriptors1, descriptors2):
+        d1, d2 = _np(descriptors1, np.uint8), _np(descriptors2, np.uint8)
+        idx = np.empty((len(d1), 2), np.int32)
+        dist = np.empty((len(d1), 2), np.float32)
+        self._check(self._lib.uvo_match_knn2_hamming(self._h, _p(d1), len(d1), _p(d2), len(d2), d1.shape[1], 0, _p(idx), _p(dist)))
+        return idx, dist
+
     def _check_desc_width(self, *descs):
         dim = 128 if self.params.SURF_EXTENDED else 64
         for d in descs:

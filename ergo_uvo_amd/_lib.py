@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libuvo_hip.so")
 EXPORTS = [
     "uvo_params_default_stereo", "uvo_params_default_mono", "uvo_ctx_create", "uvo_ctx_destroy", "uvo_last_error",
     "uvo_ctx_stream", "uvo_ctx_set_params", "uvo_ctx_set_producer_stream", "uvo_ctx_warning", "uvo_surf_detect", "uvo_integral", "uvo_hessian_layer",
-    "uvo_match_knn2_ratio", "uvo_match_knn2", "uvo_triangulate_points", "uvo_extract_3d_points",
+    "uvo_match_knn2_ratio", "uvo_match_knn2", "uvo_match_knn2_ratio_hamming", "uvo_match_knn2_hamming", "uvo_triangulate_points", "uvo_extract_3d_points",
     "uvo_solve_pnp_ransac", "uvo_reproject_errors", "uvo_rodrigues", "uvo_stereo_set_rig", "uvo_stereo_reset", "uvo_stereo_step",
     "uvo_stereo_set_depth", "uvo_stereo_submit", "uvo_stereo_collect",
     "uvo_stereo_get", "uvo_find_essential_mat", "uvo_recover_pose", "uvo_find_homography", "uvo_decompose_homography_mat",

@@ -427,6 +427,54 @@ extern "C" uvo_status uvo_match_knn2_ratio(uvo_ctx* c, const float* d1, int n1, 
     return UVO_OK;
 }
 
+// The AKAZE / ORB branch of match_features (VO_utility.cpp:520-524): binary descriptors, Hamming distance
+static uvo_status stage_bytes(uvo_ctx* c, int slot, const uint8_t* d, int n, int bytes, int mem, const uint8_t** out)
+{
+    if (n > c->cap) return fail(c, UVO_CAPACITY, "descriptor count exceeds the context's max_kpts");
+    if (mem == UVO_MEM_DEVICE) { *out = d; return UVO_OK; }
+    if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->d_tmp_desc[slot], d, (size_t)bytes * n, hipMemcpyHostToDevice, c->stream));     // cap x 512 bytes of staging
+    *out = reinterpret_cast<const uint8_t*>(c->d_tmp_desc[slot]);
+    return UVO_OK;
+}
+extern "C" uvo_status uvo_match_knn2_hamming(uvo_ctx* c, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, int mem, int* idx, float* dist)
+{
+    if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !idx || !dist) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_match_knn2_hamming"));
+    if (n1 == 0) return UVO_OK;
+    if (n2 == 0) { for (int i = 0; i < 2 * n1; i++) { idx[i] = -1; dist[i] = FLT_MAX; } return UVO_OK; }
+    UVO_TRY(wait_for_producer(c, c, mem));
+    const uint8_t *q, *t;
+    UVO_TRY(stage_bytes(c, 0, d1, n1, bytes, mem, &q));
+    UVO_TRY(stage_bytes(c, 1, d2, n2, bytes, mem, &t));
+    UVO_TRY(match_knn2_hamming(c, q, n1, t, n2, bytes));
+    UVO_HIP_TRY(c, hipMemcpyAsync(idx, c->d_knn_idx, sizeof(int) * 2 * n1, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipMemcpyAsync(dist, c->d_knn_dist, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return UVO_OK;
+}
+extern "C" uvo_status uvo_match_knn2_ratio_hamming(uvo_ctx* c, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, int mem,
+                                                   float ratio, uvo_dmatch* out, int cap, int* m)
+{
+    if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !out || !m || *m < 0) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_match_knn2_ratio_hamming"));
+    if (n1 == 0 || n2 == 0) return UVO_OK;
+    UVO_TRY(wait_for_producer(c, c, mem));
+    const uint8_t *q, *t;
+    UVO_TRY(stage_bytes(c, 0, d1, n1, bytes, mem, &q));
+    UVO_TRY(stage_bytes(c, 1, d2, n2, bytes, mem, &t));
+    UVO_TRY(match_knn2_hamming(c, q, n1, t, n2, bytes));
+    UVO_TRY(match_ratio_compact(c, nullptr, n1, ratio, c->d_matches[0], c->d_nmatch, c->cap));
+    UVO_TRY(read_counts(c));
+    int cnt = c->h_counts[CN_M];
+    if (*m + cnt > cap) return fail(c, UVO_CAPACITY, "uvo_match_knn2_ratio_hamming: output capacity too small");
+    if (cnt) UVO_HIP_TRY(c, hipMemcpyAsync(out + *m, c->d_matches[0], sizeof(uvo_dmatch) * cnt, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *m += cnt;                                       // appended, as VOU:538
+    return UVO_OK;
+}
+
 // ------------------------------------------------------------------------------------------ geometry operators
 extern "C" uvo_status uvo_triangulate_points(uvo_ctx* c, const double* P1, const double* P2,
                                              const uvo_point2f* x1, const uvo_point2f* x2, int n, float* out4xn)

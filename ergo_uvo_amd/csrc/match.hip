@@ -470,4 +470,79 @@ uvo_status match_ratio_compact2(Ctx* c, float ratio, const int* d_nq0, uvo_dmatc
     return UVO_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// The AKAZE / ORB branch of match_features (VO_utility.cpp:520-524): BFMatcher(NORM_HAMMING).knnMatch(k = 2) on binary
+// descriptors of `bytes` bytes (32 for ORB, 61 for AKAZE's MLDB), rows padded with zeros to 64 bytes while they are staged.
+// Integer distances, so every order of evaluation gives OpenCV's values; what has to be reproduced is BatchDistInvoker's insertion
+// order -- of equal distances the lower train index comes first -- which the (distance, index) lexicographic top-2 does.
+//   k_hamming_partial : a thread per query, blockIdx.y = a chunk of 512 train rows staged in LDS: the chunk's best two
+//   k_hamming_merge   : a thread per query merges the chunks' pairs in chunk order
+// ------------------------------------------------------------------------------------------
+static const int kHamChunk = 512;
+struct Ham2 { int d0, i0, d1, i1; };
+__device__ __forceinline__ void ham_top2(int d, int t, Ham2& r)
+{
+    if (d < r.d0 || (d == r.d0 && t < r.i0)) { r.d1 = r.d0; r.i1 = r.i0; r.d0 = d; r.i0 = t; }
+    else if (d < r.d1 || (d == r.d1 && t < r.i1)) { r.d1 = d; r.i1 = t; }
+}
+__global__ __launch_bounds__(256) void k_hamming_partial(const uint8_t* __restrict__ dq, int nq, const uint8_t* __restrict__ dt, int nt, int bytes, Ham2* part)
+{
+    __shared__ uint4 s_rows[kHamChunk * 4];                         // 512 rows x 64 bytes
+    const int q = blockIdx.x * 256 + threadIdx.x, t0 = blockIdx.y * kHamChunk, cnt = min(kHamChunk, nt - t0);
+    for (int e = threadIdx.x; e < cnt * 16; e += 256) {            // a row as 16 words, bytes past `bytes` are zero
+        const int r = e >> 4, wi = e & 15;
+        unsigned v = 0;
+        for (int b = 0; b < 4; b++) { const int o = wi * 4 + b; if (o < bytes) v |= (unsigned)dt[(size_t)(t0 + r) * bytes + o] << (8 * b); }
+        reinterpret_cast<unsigned*>(s_rows)[r * 16 + wi] = v;
+    }
+    unsigned qw[16];
+#pragma unroll
+    for (int wi = 0; wi < 16; wi++) {
+        unsigned v = 0;
+        if (q < nq) for (int b = 0; b < 4; b++) { const int o = wi * 4 + b; if (o < bytes) v |= (unsigned)dq[(size_t)q * bytes + o] << (8 * b); }
+        qw[wi] = v;
+    }
+    __syncthreads();
+    Ham2 best = { 0x7FFFFFFF, -1, 0x7FFFFFFF, -1 };
+    for (int r = 0; r < cnt; r++) {
+        int d = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 tv = s_rows[r * 4 + k];                    // the same address for every lane: a broadcast
+            d += __popc(qw[4*k] ^ tv.x) + __popc(qw[4*k + 1] ^ tv.y) + __popc(qw[4*k + 2] ^ tv.z) + __popc(qw[4*k + 3] ^ tv.w);
+        }
+        ham_top2(d, t0 + r, best);
+    }
+    if (q < nq) part[(size_t)blockIdx.y * nq + q] = best;
+}
+__global__ __launch_bounds__(256) void k_hamming_merge(const Ham2* part, int nq, int nchunks, int* knn_idx, float* knn_dist)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    Ham2 best = { 0x7FFFFFFF, -1, 0x7FFFFFFF, -1 };
+    for (int c = 0; c < nchunks; c++) {
+        const Ham2 p = part[(size_t)c * nq + q];
+        if (p.i0 >= 0) ham_top2(p.d0, p.i0, best);
+        if (p.i1 >= 0) ham_top2(p.d1, p.i1, best);
+    }
+    knn_idx[2*q] = best.i0; knn_idx[2*q + 1] = best.i1;
+    knn_dist[2*q] = best.i0 >= 0 ? (float)best.d0 : FLT_MAX; knn_dist[2*q + 1] = best.i1 >= 0 ? (float)best.d1 : FLT_MAX;
+}
+
+// d_q, d_t: device, n x bytes.  Results in slot 0 of the kNN buffers (match_ratio_compact reads them there); the shortlist buffer
+// of the L2 matcher is the scratch for the chunks' pairs.
+uvo_status match_knn2_hamming(Ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int bytes)
+{
+    if (nq <= 0 || nt <= 0) return UVO_OK;
+    if (nq > c->cap || nt > c->cap) { c->err = "match: descriptor count exceeds the context's max_kpts"; return UVO_CAPACITY; }
+    if (bytes < 1 || bytes > 64) { c->err = "match (Hamming): descriptors of 1..64 bytes (ORB 32, AKAZE 61)"; return UVO_INVALID_ARG; }
+    const int nchunks = (nt + kHamChunk - 1) / kHamChunk;
+    Ham2* part = reinterpret_cast<Ham2*>(c->d_mpart);             // (cap / 512) x cap x 16 B fits the (cap / 128) x cap x 16 B shortlist
+    StageTimer t(c, ST_MATCH);
+    hipLaunchKernelGGL(k_hamming_partial, dim3((nq + 255) / 256, nchunks), dim3(256), 0, c->stream, d_q, nq, d_t, nt, bytes, part);
+    hipLaunchKernelGGL(k_hamming_merge, dim3((nq + 255) / 256), dim3(256), 0, c->stream, part, nq, nchunks, c->d_knn_idx, c->d_knn_dist);
+    UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+
 }  // namespace uvo

@@ -242,6 +242,7 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features = -1);   // integ
 uvo_status surf_hessian_layer_debug(Ctx* c, int octave, int layer, float* det, float* trace);
 // match.hip
 uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, const float* d_t, const int* d_nt, int nt_max);
+uvo_status match_knn2_hamming(Ctx* c, const uint8_t* d_q, int nq, const uint8_t* d_t, int nt, int bytes);
 uvo_status match_knn2_two(Ctx* c, const float* d_q0, const int* d_nq0, const float* d_t0, const int* d_nt0,
                           const float* d_q1, const int* d_nq1, const float* d_t1, const int* d_nt1, int n_max);
 uvo_status match_ratio_compact2(Ctx* c, float ratio, const int* d_nq0, uvo_dmatch* d_out0, int* d_nout0, const GateArgs& g0,

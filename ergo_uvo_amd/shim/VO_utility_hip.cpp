@@ -345,7 +345,25 @@ void match_impl(const Mat& d1, const Mat& d2, vector<DMatch>& matches)
 void match_features(vector<KeyPoint> keypoints1, vector<KeyPoint> keypoints2, Mat descriptors1, Mat descriptors2, vector<DMatch>& matches)
 {
     (void)keypoints1; (void)keypoints2;
-    if (FEATURE_DETECTOR != "SURF") throw uvo_hip::Error(UVO_INVALID_ARG, "match_features: FEATURE_DETECTOR must be \"SURF\"");
+    if (FEATURE_DETECTOR == "AKAZE" || FEATURE_DETECTOR == "ORB") {                      // VOU:520-524: BFMatcher(NORM_HAMMING) on the caller's binary descriptors
+        const Mat& d1 = descriptors1; const Mat& d2 = descriptors2;
+        require(d1.empty() || d1.type() == CV_8UC1, "match_features: binary descriptors must be CV_8U");
+        require(d2.empty() || (d2.type() == CV_8UC1 && (d1.empty() || d2.cols == d1.cols)), "match_features: binary descriptors must be CV_8U with equal widths");
+        const int n1 = d1.rows, n2 = d2.rows, bytes = d1.empty() ? d2.cols : d1.cols;
+        if (n1 == 0) return;
+        vector<uint8_t> a((size_t)n1 * bytes), b((size_t)n2 * bytes);
+        for (int i = 0; i < n1; i++) memcpy(a.data() + (size_t)i * bytes, d1.ptr<uint8_t>(i), (size_t)bytes);
+        for (int i = 0; i < n2; i++) memcpy(b.data() + (size_t)i * bytes, d2.ptr<uint8_t>(i), (size_t)bytes);
+        vector<uvo_dmatch> out((size_t)n1);
+        int m = 0;
+        SHIM_TRY(uvo_match_knn2_ratio_hamming(ctx_now(), a.data(), n1, b.data(), n2, bytes, UVO_MEM_HOST, (float)LOWE_RATIO_THRESHOLD, out.data(), n1, &m),
+                 "uvo_match_knn2_ratio_hamming");
+        const size_t base = matches.size();
+        matches.resize(base + (size_t)m);
+        if (m) memcpy(static_cast<void*>(matches.data() + base), out.data(), sizeof(uvo_dmatch) * m);
+        return;
+    }
+    if (FEATURE_DETECTOR != "SURF") throw uvo_hip::Error(UVO_INVALID_ARG, "match_features: FEATURE_DETECTOR must be \"SURF\" (L2), \"AKAZE\" or \"ORB\" (Hamming)");
     match_impl(descriptors1, descriptors2, matches);
 }
 

@@ -104,6 +104,14 @@ uvo_status uvo_match_knn2_ratio(uvo_ctx* c, const float* d1, int n1, const float
 uvo_status uvo_match_knn2(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int mem,
                           int* idx, float* dist);
 
+/* The AKAZE / ORB branch of the same function (VO_utility.cpp:520-524): BFMatcher(NORM_HAMMING).knnMatch k=2 + Lowe ratio on binary
+ * descriptors of `bytes` bytes per row (1..64: ORB 32, AKAZE 61), u8, `mem`.  DMatch::distance = the number of differing bits.
+ * (The detectors of that branch are not provided: descriptors come from the caller's own AKAZE / ORB.) */
+uvo_status uvo_match_knn2_ratio_hamming(uvo_ctx* c, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, int mem,
+                                        float ratio, uvo_dmatch* out, int cap, int* m);
+uvo_status uvo_match_knn2_hamming(uvo_ctx* c, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, int mem,
+                                  int* idx, float* dist);
+
 /* ---- cv::triangulatePoints as called at visual_odometry.h:355, 631 and VO_utility.cpp:595 ----
  * P1, P2: 3x4 f64 row-major; x1, x2: n Point2f (host); out: 4 x n f32 (host). */
 uvo_status uvo_triangulate_points(uvo_ctx* c, const double* P1, const double* P2,

@@ -63,3 +63,44 @@ int orc_match_knn2_ratio(const float* d1, int n1, const float* d2, int n2, int d
     }
     return overflow ? -1 : 0;
 }
+
+/* ---- VOU:520-524: the AKAZE / ORB branch, BFMatcher(NORM_HAMMING).knnMatch(k = 2).  [UPSTREAM] batchDistHamming: the number of
+ * differing bits over `bytes` bytes, CV_32S, reported in DMatch::distance as float; the same K = 2 insertion as above (strict <, so
+ * of equal distances the lower train index stays first). */
+static int hamming_bytes(const uint8_t* a, const uint8_t* b, int n)
+{
+    int d = 0;
+    for (int i = 0; i < n; i++) d += __builtin_popcount((unsigned)(a[i] ^ b[i]));
+    return d;
+}
+void orc_knn2_hamming(const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, int* idx, float* dist)
+{
+    for (int i = 0; i < n1; i++) {
+        int bd[2] = { 0x7FFFFFFF, 0x7FFFFFFF }; int* ip = idx + 2 * i;
+        ip[0] = ip[1] = -1;
+        for (int j = 0; j < n2; j++) {
+            const int d = hamming_bytes(d1 + (size_t)i * bytes, d2 + (size_t)j * bytes, bytes);
+            if (d < bd[1]) {
+                int k;
+                for (k = 0; k >= 0 && bd[k] > d; k--) { ip[k + 1] = ip[k]; bd[k + 1] = bd[k]; }
+                ip[k + 1] = j; bd[k + 1] = d;
+            }
+        }
+        dist[2 * i] = ip[0] >= 0 ? (float)bd[0] : FLT_MAX; dist[2 * i + 1] = ip[1] >= 0 ? (float)bd[1] : FLT_MAX;
+    }
+}
+int orc_match_knn2_ratio_hamming(const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, float ratio_thresh,
+                                 orc_dmatch* out, int cap, int* m)
+{
+    int overflow = 0;
+    for (int i = 0; i < n1; i++) {
+        int idx[2]; float dist[2];
+        orc_knn2_hamming(d1 + (size_t)i * bytes, 1, d2, n2, bytes, idx, dist);
+        if (idx[0] < 0 || idx[1] < 0) continue;
+        if (dist[0] < ratio_thresh * dist[1]) {
+            if (*m < cap) { out[*m].queryIdx = i; out[*m].trainIdx = idx[0]; out[*m].imgIdx = 0; out[*m].distance = dist[0]; (*m)++; }
+            else overflow = 1;
+        }
+    }
+    return overflow ? -1 : 0;
+}

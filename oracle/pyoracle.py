@@ -176,6 +176,22 @@ def match(d1: np.ndarray, d2: np.ndarray, ratio: float) -> np.ndarray:
 
 
 # ------------------------------------------------------------------ geometry
+def knn2_hamming(d1: np.ndarray, d2: np.ndarray):
+    """BFMatcher(NORM_HAMMING).knnMatch(k = 2) on uint8 rows (VOU:520-524)."""
+    d1 = _c(d1, np.uint8); d2 = _c(d2, np.uint8)
+    idx = np.empty((len(d1), 2), np.int32); dist = np.empty((len(d1), 2), np.float32)
+    lib().orc_knn2_hamming(_p(d1), len(d1), _p(d2), len(d2), d1.shape[1], _p(idx), _p(dist))
+    return idx, dist
+
+
+def match_hamming(d1: np.ndarray, d2: np.ndarray, ratio: float) -> np.ndarray:
+    d1 = _c(d1, np.uint8); d2 = _c(d2, np.uint8)
+    out = np.zeros(max(len(d1), 1), DM_DTYPE)
+    m = C.c_int(0)
+    lib().orc_match_knn2_ratio_hamming(_p(d1), len(d1), _p(d2), len(d2), d1.shape[1], C.c_float(ratio), _p(out), len(out), C.byref(m))
+    return out[:m.value].copy()
+
+
 def triangulate(P1, P2, x1, x2) -> np.ndarray:
     P1 = _c(P1, np.float64); P2 = _c(P2, np.float64)
     x1 = _c(x1, np.float32); x2 = _c(x2, np.float32)

@@ -90,6 +90,10 @@ int  orc_match_knn2_ratio(const float* d1, int n1, const float* d2, int n2, int 
                           orc_dmatch* out, int cap, int* m);
 /* raw knn (for tests): idx[2*n1], dist[2*n1]; idx=-1 when absent */
 void orc_knn2(const float* d1, int n1, const float* d2, int n2, int dim, int* idx, float* dist);
+/* VOU:520-524, the AKAZE / ORB branch: BFMatcher(NORM_HAMMING) on `bytes`-byte binary descriptors */
+void orc_knn2_hamming(const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, int* idx, float* dist);
+int  orc_match_knn2_ratio_hamming(const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, float ratio,
+                                  orc_dmatch* out, int cap, int* m);
 
 /* ---- geometry ([UPSTREAM] calib3d triangulate.cpp, calibration.cpp) ---- */
 void orc_triangulate_points(const double* P1, const double* P2, const orc_point2f* x1, const orc_point2f* x2,

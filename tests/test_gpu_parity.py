@@ -820,3 +820,24 @@ def test_stereo_loop_at_odd_geometries_from_device_images(oracle, W, H):
                 assert r.valid == 1 and np.array_equal(c.stereo_get("inliers"), ovo.get("inliers"))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("bytes_", [32, 61, 64, 7])
+def test_hamming_branch_of_match_features_bit_exact(ctx, oracle, bytes_):
+    """VO_utility.cpp:520-524 (AKAZE / ORB descriptors): BFMatcher(NORM_HAMMING).knnMatch(k = 2) + ratio.  Integer distances tie all
+    the time on random bits, so this is mostly a test of the insertion order (lower train index first) across 512-row chunks."""
+    rng = np.random.default_rng(bytes_)
+    for n1, n2 in ((900, 1300), (1, 1), (257, 1), (3000, 2999), (40, 513)):
+        a = rng.integers(0, 256, (n1, bytes_), dtype=np.uint8)
+        b = rng.integers(0, 256, (n2, bytes_), dtype=np.uint8)
+        if n2 > 600:
+            b[550:560] = b[10:20]                       # exact duplicates on both sides of a chunk boundary
+            a[:10] = b[10:20]                           # distance 0 twice: indices 10.. and 550.. must come out in that order
+        idx, dist = ctx.knn_match_hamming(a, b)
+        oidx, odist = oracle.knn2_hamming(a, b)
+        assert np.array_equal(idx, oidx), (bytes_, n1, n2)
+        assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32))
+        for ratio in (0.8, 0.97):
+            m, om = ctx.match_features_hamming(a, b, ratio), oracle.match_hamming(a, b, ratio)
+            assert np.array_equal(m["queryIdx"], om["queryIdx"]) and np.array_equal(m["trainIdx"], om["trainIdx"])
+            assert np.array_equal(m["distance"].view(np.uint32), om["distance"].view(np.uint32))

@@ -365,3 +365,19 @@ def test_fast_atan2_matches_atan2_to_its_stated_accuracy(oracle):
         a = oracle.lib().orc_fast_atan2(float(y), float(x))
         assert abs(((a - np.degrees(np.arctan2(y, x))) + 180) % 360 - 180) < 0.3          # cv::fastAtan2: accuracy ~0.3 degrees
     assert oracle.lib().orc_fast_atan2(0.0, 0.0) == 0.0 and oracle.lib().orc_fast_atan2(1.0, 0.0) == 90.0
+
+
+def test_hamming_knn_is_a_stable_sort_of_bit_counts(oracle):
+    """VOU:520-524: BFMatcher(NORM_HAMMING) k = 2 = the two smallest popcounts, ties to the lower train index (numpy's stable argsort)."""
+    rng = np.random.default_rng(0)
+    for nb in (32, 61):
+        a = rng.integers(0, 256, (60, nb), dtype=np.uint8); b = rng.integers(0, 256, (90, nb), dtype=np.uint8)
+        b[40:45] = b[3:8]
+        idx, dist = oracle.knn2_hamming(a, b)
+        D = np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+        order = np.argsort(D, axis=1, kind="stable")[:, :2]
+        assert np.array_equal(idx, order)
+        assert np.array_equal(dist, np.take_along_axis(D, order, 1).astype(np.float32))
+        m = oracle.match_hamming(a, b, 0.9)
+        keep = dist[:, 0] < np.float32(0.9) * dist[:, 1]
+        assert np.array_equal(m["queryIdx"], np.nonzero(keep)[0]) and np.array_equal(m["trainIdx"], idx[keep, 0])
