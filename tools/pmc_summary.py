@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 output into profiles/: per-kernel time table (kernel_stats.csv) and the HBM
+"""(Round 1; the round-2 pass is tools/probe/final_profiles_r02.sh + tools/pmc_summary_r02.py.)  Summarise rocprofv3 output into profiles/: per-kernel time table (kernel_stats.csv) and the HBM
 traffic of the dominant kernel from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes
 (MI355X_MICROARCH.md 'HBM': both counters are in KiB; on gfx950 FETCH_SIZE reads exactly half the
 bytes of a wide coalesced stream, other access widths are uncalibrated -> raw and x2 are both kept)."""
