@@ -544,6 +544,16 @@ __global__ __launch_bounds__(kRpThreads) void k_recover_pose(const double* q1, c
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// Host staging in pinned memory: a copy to or from pageable memory is staged by the runtime and blocks the caller (15-25 us each, and
+// the pose stage makes about twenty of them per frame); pinned copies are queued like kernels.  Sized once, used like a vector.
+template <class T>
+struct Pinned {
+    T* p = nullptr; size_t n = 0;
+    bool resize(size_t count) { if (count <= n) return true; if (p) (void)hipHostFree(p); p = nullptr; n = 0; if (hipHostMalloc(reinterpret_cast<void**>(&p), sizeof(T) * count) != hipSuccess) return false; n = count; return true; }
+    T* data() { return p; } const T* data() const { return p; }
+    T& operator[](size_t i) { return p[i]; } const T& operator[](size_t i) const { return p[i]; }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+};
 struct MonoWs {                       // device workspace of the mono stage, owned by the context
     double *q1 = nullptr, *q2 = nullptr;           // normalised points (cap x 2)
     float *src = nullptr, *dst = nullptr;          // pixel points (cap x 2)
@@ -554,10 +564,15 @@ struct MonoWs {                       // device workspace of the mono stage, own
     uint8_t* masks = nullptr;                      // 5 x cap
     int* good = nullptr;                           // 4
     double* best = nullptr;                        // 9
-    std::vector<int> h_subsets, h_nmodels, h_counts;
-    std::vector<double> h_medians, h_models;
+    Pinned<int> h_subsets, h_nmodels, h_counts;
+    Pinned<double> h_medians, h_models;
+    Pinned<double> h_q1, h_q2;                     // normalised points on their way to q1 / q2
+    Pinned<float> h_src, h_dst;                    // pixel points on their way to src / dst
+    Pinned<uint8_t> h_mask;                        // masks in both directions
+    Pinned<int> h_good;                            // recoverPose's four counts
 };
 
+void mono_ws_free(Ctx* c);
 static MonoWs* mono_ws(Ctx* c)
 {
     if (c->mono_ws) return static_cast<MonoWs*>(c->mono_ws);
@@ -573,8 +588,11 @@ static MonoWs* mono_ws(Ctx* c)
               hipMalloc((void**)&w->masks, 5 * cap) == hipSuccess && hipMalloc((void**)&w->good, sizeof(int) * 4) == hipSuccess &&
               hipMalloc((void**)&w->best, sizeof(double) * 9) == hipSuccess;
     if (!ok) { delete w; return nullptr; }
-    w->h_subsets.resize(kMaxHyp * 5); w->h_nmodels.resize(kMaxHyp); w->h_counts.resize(kMaxHyp * 10);
-    w->h_medians.resize(kMaxHyp * 10); w->h_models.resize((size_t)kMaxHyp * 90);
+    ok = w->h_subsets.resize(kMaxHyp * 5) && w->h_nmodels.resize(kMaxHyp) && w->h_counts.resize(kMaxHyp * 10) &&
+         w->h_medians.resize(kMaxHyp * 10) && w->h_models.resize((size_t)kMaxHyp * 90) &&
+         w->h_q1.resize(2 * cap + 2) && w->h_q2.resize(2 * cap + 2) && w->h_src.resize(2 * cap) && w->h_dst.resize(2 * cap) &&
+         w->h_mask.resize(cap) && w->h_good.resize(4);
+    if (!ok) { c->mono_ws = w; mono_ws_free(c); return nullptr; }
     c->mono_ws = w;
     return w;
 }
@@ -584,6 +602,8 @@ void mono_ws_free(Ctx* c)
     if (!w) return;
     void* ptrs[] = { w->q1, w->q2, w->src, w->dst, w->subsets, w->models, w->nmodels, w->counts, w->medians, w->masks, w->good, w->best };
     for (void* p : ptrs) (void)hipFree(p);
+    w->h_subsets.release(); w->h_nmodels.release(); w->h_counts.release(); w->h_medians.release(); w->h_models.release();
+    w->h_q1.release(); w->h_q2.release(); w->h_src.release(); w->h_dst.release(); w->h_mask.release(); w->h_good.release();
     delete w;
     c->mono_ws = nullptr;
 }
@@ -696,7 +716,7 @@ uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f*
     if (n < modelPoints) return UVO_OK;
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     const double ax = 1. / fx, bx = -cx * ax, ay = 1. / fy, by = -cy * ay;
-    std::vector<double> q1(2 * (size_t)n), q2(2 * (size_t)n);
+    Pinned<double>& q1 = w->h_q1; Pinned<double>& q2 = w->h_q2;
     for (int i = 0; i < n; i++) {
         q1[2*i] = p1[i].x * ax + bx; q1[2*i+1] = p1[i].y * ay + by;
         q2[2*i] = p2[i].x * ax + bx; q2[2*i+1] = p2[i].y * ay + by;
@@ -734,8 +754,9 @@ uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f*
     }
     if (n == modelPoints) {
         UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data(), w->nmodels, sizeof(int), hipMemcpyDeviceToHost, st));
-        UVO_HIP_TRY(c, hipMemcpyAsync(E, w->models, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
+        UVO_HIP_TRY(c, hipMemcpyAsync(w->h_models.data(), w->models, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
         UVO_HIP_TRY(c, hipStreamSynchronize(st));
+        memcpy(E, w->h_models.data(), sizeof(double) * 9);
         if (w->h_nmodels[0] <= 0) return UVO_OK;
         memset(mask, 1, n); *ok = 1;
         return UVO_OK;
@@ -777,9 +798,10 @@ uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f*
     hipLaunchKernelGGL(k_model_mask, dim3((n + 255) / 256), dim3(256), 0, st, 0, w->q1, w->q2, nullptr, nullptr, n, best,
                        (float)(final_thr * final_thr), w->masks);
     UVO_HIP_TRY(c, hipGetLastError());
-    UVO_HIP_TRY(c, hipMemcpyAsync(mask, w->masks, n, hipMemcpyDeviceToHost, st));
-    UVO_HIP_TRY(c, hipMemcpyAsync(E, best, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipMemcpyAsync(w->h_mask.data(), w->masks, n, hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipMemcpyAsync(w->h_models.data(), best, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
     UVO_HIP_TRY(c, hipStreamSynchronize(st));
+    memcpy(mask, w->h_mask.data(), (size_t)n); memcpy(E, w->h_models.data(), sizeof(double) * 9);
     if (lmeds) { int good = 0; for (int i = 0; i < n; i++) good += mask[i]; *ok = good >= modelPoints; }
     else *ok = 1;
     return UVO_OK;
@@ -811,7 +833,7 @@ uvo_status mono_recover_pose(Ctx* c, const double* E, const uvo_point2f* p1, con
     if (!w) { c->err = "mono workspace allocation failed"; return UVO_HIP_ERROR; }
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     const double ax = 1. / fx, bx = -cx * ax, ay = 1. / fy, by = -cy * ay;
-    std::vector<double> q1(2 * (size_t)n + 2), q2(2 * (size_t)n + 2);
+    Pinned<double>& q1 = w->h_q1; Pinned<double>& q2 = w->h_q2;
     for (int i = 0; i < n; i++) {
         q1[2*i] = p1[i].x * ax + bx; q1[2*i+1] = p1[i].y * ay + by;
         q2[2*i] = p2[i].x * ax + bx; q2[2*i+1] = p2[i].y * ay + by;
@@ -828,13 +850,15 @@ uvo_status mono_recover_pose(Ctx* c, const double* E, const uvo_point2f* p1, con
         hipStream_t st = c->stream;
         UVO_HIP_TRY(c, hipMemcpyAsync(w->q1, q1.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
         UVO_HIP_TRY(c, hipMemcpyAsync(w->q2, q2.data(), sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
-        UVO_HIP_TRY(c, hipMemcpyAsync(w->masks + 4 * (size_t)c->cap, mask, n, hipMemcpyHostToDevice, st));
+        memcpy(w->h_mask.data(), mask, (size_t)n);
+        UVO_HIP_TRY(c, hipMemcpyAsync(w->masks + 4 * (size_t)c->cap, w->h_mask.data(), n, hipMemcpyHostToDevice, st));
         UVO_HIP_TRY(c, hipMemsetAsync(w->good, 0, sizeof(int) * 4, st));
         hipLaunchKernelGGL(k_recover_pose, dim3((n + kRpThreads - 1) / kRpThreads, 4), dim3(kRpThreads), 0, st, w->q1, w->q2, n, pc,
                            w->masks + 4 * (size_t)c->cap, w->masks, w->good);
         UVO_HIP_TRY(c, hipGetLastError());
-        UVO_HIP_TRY(c, hipMemcpyAsync(good, w->good, sizeof(good), hipMemcpyDeviceToHost, st));
+        UVO_HIP_TRY(c, hipMemcpyAsync(w->h_good.data(), w->good, sizeof(good), hipMemcpyDeviceToHost, st));
         UVO_HIP_TRY(c, hipStreamSynchronize(st));
+        memcpy(good, w->h_good.data(), sizeof(good));
     }
     int best;
     if (good[0] >= good[1] && good[0] >= good[2] && good[0] >= good[3]) best = 0;
@@ -844,8 +868,9 @@ uvo_status mono_recover_pose(Ctx* c, const double* E, const uvo_point2f* p1, con
     memcpy(R, Rc[best], sizeof(double) * 9);
     for (int i = 0; i < 3; i++) t[i] = sg[best] * tt[i];
     if (n > 0) {
-        UVO_HIP_TRY(c, hipMemcpyAsync(mask, w->masks + (size_t)best * n, n, hipMemcpyDeviceToHost, c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(w->h_mask.data(), w->masks + (size_t)best * n, n, hipMemcpyDeviceToHost, c->stream));
         UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        memcpy(mask, w->h_mask.data(), (size_t)n);
     }
     *good_out = good[best];
     return UVO_OK;
@@ -1000,7 +1025,7 @@ uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f
     if (thr <= 0) thr = 3;
     const int modelPoints = 4;
     if (n < modelPoints) return UVO_OK;
-    std::vector<float> src(2 * (size_t)n), dst(2 * (size_t)n);
+    Pinned<float>& src = w->h_src; Pinned<float>& dst = w->h_dst;
     for (int i = 0; i < n; i++) { src[2*i] = p1[i].x; src[2*i+1] = p1[i].y; dst[2*i] = p2[i].x; dst[2*i+1] = p2[i].y; }
     double scratch[171]; int iscratch[18];
     int result = 0;
@@ -1062,9 +1087,10 @@ uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f
                 hipLaunchKernelGGL(k_model_mask, dim3((n + 255) / 256), dim3(256), 0, st, 1, nullptr, nullptr, w->src, w->dst, n, best,
                                    (float)(final_thr * final_thr), w->masks);
                 UVO_HIP_TRY(c, hipGetLastError());
-                UVO_HIP_TRY(c, hipMemcpyAsync(mask, w->masks, n, hipMemcpyDeviceToHost, st));
-                UVO_HIP_TRY(c, hipMemcpyAsync(H, best, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
+                UVO_HIP_TRY(c, hipMemcpyAsync(w->h_mask.data(), w->masks, n, hipMemcpyDeviceToHost, st));
+                UVO_HIP_TRY(c, hipMemcpyAsync(w->h_models.data(), best, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
                 UVO_HIP_TRY(c, hipStreamSynchronize(st));
+                memcpy(mask, w->h_mask.data(), (size_t)n); memcpy(H, w->h_models.data(), sizeof(double) * 9);
                 if (lmeds) { int good = 0; for (int i = 0; i < n; i++) good += mask[i]; result = good >= modelPoints; }
                 else result = 1;
             }
