@@ -477,7 +477,7 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
     hipStream_t st = m->pnp_stream;
     double t_b0 = g_bdbg ? now_us() : 0;
     if (n < 1 || n > kMaxPnpBatch) { m->err = "pnp batch size"; return UVO_INVALID_ARG; }
-    const size_t hyp_lds = sizeof(double) * kHypGroups * kHypPerGroup;
+    const size_t hyp_lds = sizeof(double) * GroupPolicy<kHypGroups>::kStride * kHypPerGroup;
     static std::once_flag attr_once[64];                                               // once per device
     std::call_once(attr_once[m->device & 63], [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_hyp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds); });
     int niters0 = iterationsCount > 1 ? iterationsCount : 1;

@@ -15,9 +15,12 @@ namespace uvo {
 
 // GroupPolicy<G>: G problems per workgroup, 8 consecutive lanes cooperate on each (blockDim = 8*G,
 // which must be ONE wave so that sync() is cheap).  Arrays live in LDS interleaved by group.
+// The interleave stride is G + 1, not G: the lanes of a group walk rows of 12 doubles, and 12 rows x 8 groups x 2 banks is a multiple
+// of the 64 LDS banks, so with stride G all six active lanes of a group hit one bank; with G + 1 they spread.
 template <int G>
 struct GroupPolicy {
-    using Arr = SArr<G>;
+    static constexpr int kStride = G + 1;
+    using Arr = SArr<kStride>;
     static constexpr bool kStaged = false;
     __device__ static __forceinline__ int tid() { return threadIdx.x & 7; }
     __device__ static __forceinline__ int nth() { return 8; }
