@@ -175,3 +175,25 @@ def test_mono_relative_pose_through_the_shim_matches_oracle(oracle, tmp_path, me
     assert (bool(success), bool(ue_out), nin) == (ok, ue, len(in1))
     assert np.array_equal(Rt[:9].view(np.uint64), Ro.ravel().view(np.uint64)) and np.array_equal(Rt[9:].view(np.uint64), to.view(np.uint64))
     assert np.array_equal(pts[:, :2], in1) and np.array_equal(pts[:, 2:], in2)
+
+
+@pytest.mark.gpu
+def test_shim_match_features_hamming_branch(oracle, tmp_path):
+    """match_features with FEATURE_DETECTOR = "ORB" (VO_utility.cpp:520-524) through the C++ surface: CV_8U descriptors, Hamming 2-NN +
+    ratio, appended after what the vector already holds."""
+    _build()
+    rng = np.random.default_rng(4)
+    n1, n2, nb, ratio = 700, 900, 32, 0.9
+    a = rng.integers(0, 256, (n1, nb), dtype=np.uint8); b = rng.integers(0, 256, (n2, nb), dtype=np.uint8)
+    b[600:640] = b[20:60]                                # duplicated train rows: those queries fail the ratio test on a tie
+    a[:200] = b[100:300]; a[:200, 0] ^= 0x11            # two bits away from one train row each: clear winners
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    inp.write_bytes(struct.pack("<iiif", n1, n2, nb, ratio) + a.tobytes() + b.tobytes())
+    res = subprocess.run([os.path.join(ROOT, "tests", "cpp", "build", "shim_match_binary"), str(inp), str(outp)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    raw = outp.read_bytes()
+    m = struct.unpack("<i", raw[:4])[0]
+    rec = np.frombuffer(raw[4:], np.dtype([("q", "<i4"), ("t", "<i4"), ("d", "<f4")]))
+    om = oracle.match_hamming(a, b, ratio)
+    assert m == len(om) >= 200
+    assert np.array_equal(rec["q"], om["queryIdx"]) and np.array_equal(rec["t"], om["trainIdx"]) and np.array_equal(rec["d"], om["distance"])
