@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Secondary measurements for the other BASELINE.json configs (the headline C3 line comes from bench.py):
   C2  stereo 1280x720, ~1500 kpts (min_hessian 5685), pipelined submit/collect and synchronous step
+  C1  substitute for the bag: mono 640x480, the shipped parameters (LMedS)
   C4  mono 1920x1080 + range, ~3000 kpts, min_hessian 6456 (3000 kpts), RANSAC for both E and H: frames two steps apart (essential) and a quarter step apart (homography)
 Prints one JSON object; run on the GPU box:  python tools/bench_configs.py"""
 import json
@@ -118,6 +119,43 @@ def main():
         nv += ctx.mono_collect(0.2).valid
     out["C4_mono_1920x1080_ransac"].update({"frames_per_s_pipelined": round(steps / (time.perf_counter() - t0), 1), "valid_pipelined": nv,
                                             "pipelined_steps": steps})
+    ctx.close()
+    # ---------------- C1 substitute: 640x480 mono, the shipped parameters (LMedS for E and H, min_hessian 50) ----------------
+    W1, H1 = 640, 480
+    scene = synth.Scene(synth.SEEDS["C1"], W1)
+    rig1 = synth.stereo_rig(W1)
+    ks = [0, 2, 4, 2, 0, 0.25, 0.5, 0.25]
+    frames = {k: synth.mono_frame(scene, k, W1, H1) for k in sorted(set(ks))}
+    dev = {k: torch.from_numpy(m).cuda() for k, m in frames.items()}
+    dmono = [dev[k] for k in ks]
+    R0, C0 = synth.camera_pose(0)
+    rng = scene.depth_at_center(C0, R0)
+    ctx = uvo.Context(uvo.Params.mono(), 0, W1, H1, 8192)
+    ctx.mono_set_camera(rig1.K_left)
+    for i in range(8):
+        r = ctx.mono_step(dmono[i % len(ks)], rng, 0.2)
+    steps = 96
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    nv = ne = 0
+    for i in range(steps):
+        r = ctx.mono_step(dmono[i % len(ks)], rng, 0.2)
+        nv += r.valid; ne += r.used_essential
+    out["C1_substitute_mono_640x480_lmeds"] = {"kpts": r.n_kps, "matches": r.n_matches, "valid": nv, "essential_used": ne,
+                                               "frames_per_s": round(steps / (time.perf_counter() - t0), 1)}
+    ctx.mono_reset()
+    depth = 14
+    ctx.stereo_set_depth(depth)
+    steps = 600
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        nv = sub = 0
+        n = 28 if rep == 0 else steps
+        for i in range(n):
+            while sub < n and sub - i < depth:
+                ctx.mono_submit(dmono[sub % len(ks)], rng); sub += 1
+            nv += ctx.mono_collect(0.2).valid
+        dt = time.perf_counter() - t0
+    out["C1_substitute_mono_640x480_lmeds"].update({"frames_per_s_pipelined": round(steps / dt, 1), "valid_pipelined": nv})
     ctx.close()
     print(json.dumps(out))
 
