@@ -74,34 +74,58 @@ def ping_pong(n_frames: int):
 
 def self_launch(n: int) -> int:
     """`python bench.py --gpus N` without torchrun: start N fresh child ranks (one process per GPU) with RANK / LOCAL_RANK /
-    WORLD_SIZE / MASTER_* set.  The parent has made no GPU call and never execs; rank 0's child prints the JSON line on the
-    inherited stdout.  Returns the worst child exit code."""
-    import socket
+    WORLD_SIZE set.  The parent has made no GPU call and never execs; rank 0's child prints the JSON line on the inherited
+    stdout.  The ranks meet through a file store in a private temporary directory (UVO_RDZV_FILE -> init_method file://...), so
+    no TCP port has to be guessed.  Returns the worst child exit code."""
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else subprocess.DEVNULL))
-    # a rank that dies before the rendezvous would leave the others waiting for it: when one fails, the rest are ended (by PID)
+    import tempfile
     import time as _time
     rc = 0
-    live = list(procs)
-    while live:
-        for p in list(live):
-            code = p.poll()
-            if code is None:
-                continue
-            live.remove(p)
-            rc = max(rc, abs(code))
-            if code != 0:
-                for q in live:
-                    q.terminate()
-        _time.sleep(0.05)
+    with tempfile.TemporaryDirectory(prefix="uvo_rdzv_") as tmp:
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       UVO_RDZV_FILE=os.path.join(tmp, "store"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=None if r == 0 else subprocess.DEVNULL))
+        # a rank that dies before the rendezvous would leave the others waiting for it: when one fails, the rest are ended (by PID)
+        live = list(procs)
+        while live:
+            for p in list(live):
+                code = p.poll()
+                if code is None:
+                    continue
+                live.remove(p)
+                rc = max(rc, abs(code))
+                if code != 0:
+                    for q in live:
+                        q.terminate()
+            _time.sleep(0.05)
     return rc
+
+
+def hbm_copy_peak_gbs(torch, seconds: float = 0.05, nbytes: int = 1 << 30) -> float:
+    """Device-to-device copy rate of this GPU, read + write bytes per second ("peak from the box at run time"):
+    a 1 GiB buffer copied back and forth for ~`seconds`, timed with events on the stream the copies run on."""
+    a = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    b = torch.empty_like(a)
+    b.copy_(a); a.copy_(b)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps, ms = 4, 0.0
+    while True:
+        e0.record()
+        for _ in range(reps):
+            b.copy_(a)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1)
+        if ms >= seconds * 1e3 or reps >= 4096:
+            break
+        reps *= 2
+    del a, b
+    torch.cuda.empty_cache()
+    return 2.0 * nbytes * reps / (ms * 1e-3) / 1e9
 
 
 def main():
@@ -117,6 +141,11 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend of the pose-record gather "
                     "(nccl = RCCL; gloo only for rehearsing N ranks on fewer devices)")
     ap.add_argument("--share-devices", action="store_true", help="rehearsal: ranks may share a device (LOCAL_RANK modulo the device count)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank, so that --gpus 1 "
+                    "runs the N-rank path's collectives (RCCL communicator of one rank)")
+    ap.add_argument("--no-pin", action="store_true", help="do not give each rank its own slice of the host's cores")
+    ap.add_argument("--timed-only", action="store_true", help="diagnostics: stop after the timed region (no latency / roofline / CPU legs), "
+                    "so that a UVO_TRACE file holds the timed pairs")
     ap.add_argument("--dump-records", default=None, help="rank 0 writes the gathered [world, steps, 16] pose records to this .npy")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -128,14 +157,32 @@ def main():
     from ergo_uvo_amd import synth, multirank
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # host budget of a rank: its own slice of the cores, taken before the first GPU call so that the HIP runtime's threads and the
+    # lane workers inherit it (one polling submitter + <= max_b polling PnP workers per rank; the other workers sleep on events)
+    host_cores_all = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    my_cores = [] if args.no_pin else multirank.pin_rank_to_cores(local_rank % max(local_world, 1), local_world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    n_dev = torch.cuda.device_count()
     if args.share_devices:
-        local_rank %= torch.cuda.device_count()
+        local_rank %= n_dev
+    elif local_rank >= n_dev:
+        raise SystemExit(f"rank with LOCAL_RANK={local_rank} but only {n_dev} device(s) visible (--share-devices rehearses N ranks on fewer)")
     torch.cuda.set_device(local_rank)
-    rank, world = multirank.init(args.backend, local_rank)    # "nccl" is RCCL on ROCm
+    rank, world = multirank.init(args.backend, local_rank, force=args.force_dist)    # "nccl" is RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank) if args.backend == "nccl" else None     # where the gathered records travel from
+    dist_on = dist.is_initialized()
+    dev = torch.device("cuda", local_rank) if (args.backend == "nccl" and dist_on) else None     # where the gathered records travel from
+    # every rank must be a different rank on (unless rehearsing) a different device: gathered once, checked by rank 0
+    props = torch.cuda.get_device_properties(local_rank)
+    dev_key = hash(str(getattr(props, "uuid", "")) + str(getattr(props, "pci_bus_id", "")) + str(getattr(props, "pci_device_id", ""))) & 0x7FFFFFFF
+    who = multirank.gather_ints([rank, local_rank, dev_key, os.getpid()], dev)
+    if rank == 0:
+        assert sorted(who[:, 0].tolist()) == list(range(world)), f"ranks seen: {who[:, 0].tolist()}"
+        assert len(set(who[:, 3].tolist())) == world, "ranks share a process"
+        if not args.share_devices:
+            assert len(set(who[:, 1].tolist())) == world, f"ranks share a device: local ranks {who[:, 1].tolist()}"
 
     # ---- synthetic workload (seeded; one independent stream per rank) ----
     seed = synth.SEEDS["C3"] if world == 1 else multirank.stream_seed(synth.SEEDS["C5"], rank)
@@ -154,16 +201,23 @@ def main():
 
     def step():
         k = next(order)
+        ks_seen.append(k)
         L, R = dev_frames[k]
         return ctx.stereo_step(L, R, 0.05)
 
+    ks_seen = []                                   # frame index of every pair handed to the VO loop, in order
+
     def submit():
         k = next(order)
+        ks_seen.append(k)
         L, R = dev_frames[k]
         ctx.stereo_submit(L, R)
 
     # warm-up: the first step is consumed by the VO init phase (synchronous by definition); the remaining ones go through the
     # same submit/collect pipeline as the timed region, so every lane's buffers, streams and worker thread have been used
+    # device-to-device copy rate of this GPU (roofline.peak_measured), before the warm-up (placing it here rather than at process
+    # start was measured not to matter for a 20-step run: 3500 vs 3515 pairs/s -- the clocks are not what a short run waits for)
+    hbm_measured = hbm_copy_peak_gbs(torch)
     n_warm = max(args.warmup, 2)
     for _ in range(2):
         r = step()
@@ -179,6 +233,8 @@ def main():
         torch.cuda.synchronize()
 
     fence()
+    cpu0 = time.process_time()
+    n_before_timed = len(ks_seen)
     t0 = time.perf_counter()
     n_valid = 0
     kp_sum = 0
@@ -195,13 +251,26 @@ def main():
         multirank.fill_record(records, i, rank, i, r)
     allrec = multirank.gather_records(torch.from_numpy(records), dev)  # pose records of all streams: one RCCL all-gather (N > 1)
     fence()
-    dt = multirank.max_over_ranks(time.perf_counter() - t0, dev)
+    dt_local = time.perf_counter() - t0
+    busy_threads = (time.process_time() - cpu0) / max(dt_local, 1e-9)  # host threads this rank kept busy on average (CPU seconds per second)
+    dt = multirank.max_over_ranks(dt_local, dev)
     assert [int(v) for v in allrec[:, 0, 0].tolist()] == list(range(world))
+    ks_timed = ks_seen[n_before_timed - 1:n_before_timed + args.steps]   # [previous frame, then the K timed frames]
+    if dist_on and world == 1:                                         # --force-dist: the collective must hand back exactly what went in
+        assert allrec.shape[0] == 1 and np.array_equal(allrec[0].cpu().numpy().view(np.uint64), records.view(np.uint64)), "1-rank gather changed the records"
     total_pairs = args.steps * world
     value = total_pairs / dt
 
     if rank == 0 and args.dump_records:
         np.save(args.dump_records, allrec.cpu().numpy())
+
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"value": round(value, 3), "unit": "pairs/s", "steps": args.steps, "warmup": args.warmup, "timed_only": True}), flush=True)
+        if dist_on:
+            multirank.barrier(); dist.destroy_process_group()
+        ctx.close()
+        return
 
     # ---- the same K steps with the images in (pageable) host memory: upload of both images inside the timed region ----
     # (SURVEY 8(d) figure (ii); reported beside `value`, never as `value`)
@@ -245,13 +314,21 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed counter passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/probe/
         # final_profiles_r02.sh, FETCH_SIZE doubled per MI355X_MICROARCH.md): the newest summary that has the kernel
-        traffic = None
-        for name, pick in (("r02_pmc_stage_kernels.json", lambda d: d["kernels"]["hessian_all_octaves"]["hbm_bytes_fetch_x2"]),):
-            try:
-                traffic = int(pick(json.load(open(os.path.join(ROOT, "profiles", name)))))
-                break
-            except Exception:
-                continue
+        # Counters cannot be read from inside this process; the figure is the one of the newest committed counter summary whose
+        # `kernel_source_sha` matches the detector source being run (tools/pmc_summary_r03.py writes it) -- null when the profile
+        # predates the kernel, never a stale number.
+        traffic, traffic_source = None, None
+        try:
+            import hashlib
+            sha = hashlib.sha256(open(os.path.join(ROOT, "ergo_uvo_amd", "csrc", "surf.hip"), "rb").read()).hexdigest()[:16]
+            for name in ("r03_pmc_stage_kernels.json",):
+                d = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if d.get("kernel_source_sha", {}).get("surf.hip") == sha:
+                    traffic = int(d["kernels"]["hessian_all_octaves"]["hbm_bytes_fetch_x2"])
+                    traffic_source = f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; surf.hip sha256 {sha})"
+                    break
+        except Exception:
+            pass
         # the all-pairs contraction of the matcher against the f32 MFMA peak (F = 2 Nq Nt 64 per call)
         mm_ms, mm_n = tm["match_top2"]
         f_pair = 2.0 * 64 * (rl.n_left * rl.n_right + rl.n_stereo_matches * rl.n_left)
@@ -313,9 +390,31 @@ def main():
                     max_rel = max(max_rel, rel)
                     if rel > 1e-4:
                         bad.append(f"pair {i}: {name} differs by {rel:.3g} relative")
+            # ---- the records the TIMED submit/collect loop produced, against the oracle's result for the same frame transition
+            # (a pair's pose depends on the previous pair only through its "after stereo match" set, so every (previous frame ->
+            # frame) transition of the ping-pong order has one answer; the oracle's leg above visits all of them)
+            want = {}
+            for i in range(1, len(ks)):
+                want.setdefault((ks[i - 1], ks[i]), ores[i])
+            timed_checked, timed_rel = 0, 0.0
+            for i in range(args.steps):
+                o = want.get((ks_timed[i], ks_timed[i + 1]))
+                if o is None:
+                    continue
+                timed_checked += 1
+                row = records[i]
+                if int(row[2]) != o.valid or int(row[3]) != o.n_inliers:
+                    bad.append(f"timed step {i}: valid/n_inliers {int(row[2])}/{int(row[3])} != {o.valid}/{o.n_inliers}")
+                for name, sl in (("rvec", slice(4, 7)), ("tvec", slice(7, 10)), ("t_prev_curr", slice(10, 13))):
+                    x, y = row[sl], np.array(list(getattr(o, name)))
+                    rel = float(np.linalg.norm(x - y) / max(np.linalg.norm(y), 1e-300))
+                    timed_rel = max(timed_rel, rel)
+                    if rel > 1e-4:
+                        bad.append(f"timed step {i}: {name} differs by {rel:.3g} relative")
             parity = {"parity_checked": not bad, "parity": {"against": "oracle/ (CPU restatement; parity vs OpenCV unpinned)", "pairs": len(ks),
                       "compared": "gate counts, keypoint/match/3-D point counts, PnP inlier sets (bitwise), rvec/tvec/t_prev_curr (<= 1e-4 rel.)",
-                      "max_pose_rel_diff": max_rel, "mismatches": bad[:8]}}
+                      "max_pose_rel_diff": max_rel, "timed_loop_records_checked": timed_checked, "timed_loop_max_pose_rel_diff": timed_rel,
+                      "mismatches": bad[:8]}}
 
         out = {
             "metric": "stereo frame-pairs/sec (detect+match+pose) @1920x1080, 3k kpts",
@@ -330,7 +429,9 @@ def main():
             "value_h2d_inclusive": None if h2d_value is None else round(h2d_value, 3),
             "roofline": {"bound": "hbm", "kernel": "k_hessian_nms_all (the four octaves, 3 middle layers each, 2 images per launch)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                         "peak_measured": round(hbm_measured, 1), "frac_of_measured": round(achieved / hbm_measured, 5),
+                         "peak_measured_what": "device-to-device copy of 1 GiB on this GPU at bench start, read + write bytes per second",
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5)},
             "roofline_desc": {"bound": "hbm", "kernel": "descriptor stage of a pair (k_big_sort, k_descriptor64: small- and large-window blocks in one launch, k_descriptor64_big_finish)",
                               "achieved": round(desc_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(desc_gbs / HBM_PEAK_GBS, 6),
@@ -347,9 +448,13 @@ def main():
             "algorithmic_bytes_per_pair": int(algorithmic_bytes_pair(WIDTH, HEIGHT, 3000, b_desc)),
             "stage_ms": stage_ms, "stage_launches_per_step": stage_calls,
             "cpu_baseline": cpu,
+            "host": {"cores_visible": host_cores_all, "cores_of_this_rank": len(my_cores), "pinned": bool(my_cores) and world > 1,
+                     "threads_per_rank": f"1 submitter (polls) + {args.depth} lane workers (sleep on stage A's event; <= 3 at a time poll inside the PnP stage)",
+                     "busy_host_threads_rank0": round(busy_threads, 2),
+                     "collectives": ("none (single process)" if not dist_on else f"{args.backend}: all_gather_into_tensor of the pose records, all_reduce(MAX) of the time, barriers; {world} rank(s)")},
         }
         out.update(parity)
-    if world > 1:
+    if dist_on:
         multirank.barrier()
         dist.destroy_process_group()
     ctx.close()

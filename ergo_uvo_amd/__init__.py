@@ -123,6 +123,17 @@ class Context:
         if st != 0:
             raise UvoError(st, (self._lib.uvo_last_error(self._h) or b"").decode())
 
+    def _release_collected(self, pending_before: int):
+        """Drop the keep-alive entry of a pair / frame only if the C call really dequeued it (a collect refused with "nothing
+        submitted" or "wrong kind" leaves the queue alone, and the images of the oldest entry may still be read in place)."""
+        if self._lib.uvo_ctx_pending(self._h) < pending_before and self._inflight:
+            self._inflight.popleft()
+
+    def _drained(self):
+        """reset / set_rig / set_depth drain the C pipeline: nothing reads the submitted tensors any more."""
+        if self._lib.uvo_ctx_pending(self._h) == 0:
+            self._inflight.clear()
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.uvo_ctx_destroy(self._h)
@@ -189,10 +200,11 @@ class Context:
         self._check(self._lib.uvo_hessian_layer(self._h, octave, layer, _p(det), _p(tr)))
         return det, tr
 
-    def match_features(self, descriptors1, descriptors2, ratio=None, matches=None):
-        """match_features (VO_utility.cpp:515-543); appends to `matches` like the reference."""
+    def match_features(self, descriptors1, descriptors2, ratio=None, matches=None, dim=None):
+        """match_features (VO_utility.cpp:515-543); appends to `matches` like the reference.  dim = 128: the "SIFT" arm of the
+        L2 branch (VO_utility.cpp:525-529), rows of 128 floats whatever SURF_EXTENDED says."""
         ratio = float(self.params.LOWE_RATIO_THRESHOLD if ratio is None else ratio)
-        self._check_desc_width(descriptors1, descriptors2)
+        self._check_desc_width(descriptors1, descriptors2, dim=dim)
         n1, n2 = int(descriptors1.shape[0]), int(descriptors2.shape[0])
         p1, m1, k1 = _ptr_mem(descriptors1, np.float32)
         p2, m2, k2 = _ptr_mem(descriptors2, np.float32)
@@ -203,7 +215,10 @@ class Context:
         if prev:
             out[:prev] = matches
         m = C.c_int(prev)
-        self._check(self._lib.uvo_match_knn2_ratio(self._h, p1, n1, p2, n2, m1, C.c_float(ratio), _p(out), len(out), C.byref(m)))
+        if dim is None:
+            self._check(self._lib.uvo_match_knn2_ratio(self._h, p1, n1, p2, n2, m1, C.c_float(ratio), _p(out), len(out), C.byref(m)))
+        else:
+            self._check(self._lib.uvo_match_knn2_ratio_dim(self._h, p1, n1, p2, n2, int(dim), m1, C.c_float(ratio), _p(out), len(out), C.byref(m)))
         return out[:m.value].copy()
 
     def match_features_hamming(self, descriptors1, descriptors2, ratio=None, matches=None):
@@ -227,20 +242,23 @@ class Context:
         self._check(self._lib.uvo_match_knn2_hamming(self._h, _p(d1), len(d1), _p(d2), len(d2), d1.shape[1], 0, _p(idx), _p(dist)))
         return idx, dist
 
-    def _check_desc_width(self, *descs):
-        dim = 128 if self.params.SURF_EXTENDED else 64
+    def _check_desc_width(self, *descs, dim=None):
+        dim = dim or (128 if self.params.SURF_EXTENDED else 64)
         for d in descs:
             if d.ndim != 2 or int(d.shape[1]) != dim:
                 raise ValueError("descriptor rows must have %d elements (SURF_EXTENDED = %d in this context's parameters)" % (dim, int(self.params.SURF_EXTENDED)))
 
-    def knn_match(self, descriptors1, descriptors2):
-        self._check_desc_width(descriptors1, descriptors2)
+    def knn_match(self, descriptors1, descriptors2, dim=None):
+        self._check_desc_width(descriptors1, descriptors2, dim=dim)
         n1, n2 = int(descriptors1.shape[0]), int(descriptors2.shape[0])
         p1, m1, k1 = _ptr_mem(descriptors1, np.float32)
         p2, m2, k2 = _ptr_mem(descriptors2, np.float32)
         idx = np.empty((n1, 2), np.int32)
         dist = np.empty((n1, 2), np.float32)
-        self._check(self._lib.uvo_match_knn2(self._h, p1, n1, p2, n2, m1, _p(idx), _p(dist)))
+        if dim is None:
+            self._check(self._lib.uvo_match_knn2(self._h, p1, n1, p2, n2, m1, _p(idx), _p(dist)))
+        else:
+            self._check(self._lib.uvo_match_knn2_dim(self._h, p1, n1, p2, n2, int(dim), m1, _p(idx), _p(dist)))
         return idx, dist
 
     def triangulatePoints(self, P1, P2, pts1, pts2):
@@ -296,9 +314,11 @@ class Context:
     def stereo_set_rig(self, K_left, K_right, R_right, t_right):
         a = [_np(x, np.float64) for x in (K_left, K_right, R_right, t_right)]
         self._check(self._lib.uvo_stereo_set_rig(self._h, *[_p(x) for x in a]))
+        self._drained()
 
     def stereo_reset(self):
         self._check(self._lib.uvo_stereo_reset(self._h))
+        self._drained()
 
     def stereo_step(self, left, right, dt: float = 0.05) -> StereoResult:
         h, w = left.shape[-2], left.shape[-1]
@@ -363,6 +383,7 @@ class Context:
     def stereo_set_depth(self, depth):
         """Number of consecutive pairs that may be in flight between stereo_submit and stereo_collect (default 2)."""
         self._check(self._lib.uvo_stereo_set_depth(self._h, int(depth)))
+        self._drained()
 
     def stereo_submit(self, left, right):
         """Enqueue detect..extract_3Dpoints of a pair (no host sync); at most two pairs in flight."""
@@ -378,11 +399,11 @@ class Context:
     def stereo_collect(self, dt: float = 0.05) -> StereoResult:
         """Finish the oldest submitted pair (PnP-RANSAC + pose); same result as stereo_step."""
         r = StereoResult()
+        before = self._lib.uvo_ctx_pending(self._h)
         try:
             self._check(self._lib.uvo_stereo_collect(self._h, C.c_double(dt), C.byref(r)))
         finally:
-            if self._inflight:
-                self._inflight.popleft()
+            self._release_collected(before)
         return r
 
     def stereo_get(self, what: str):
@@ -457,6 +478,7 @@ class Context:
     def mono_set_camera(self, K):
         K = _np(K, np.float64)
         self._check(self._lib.uvo_mono_set_camera(self._h, _p(K)))
+        self._drained()
 
     def mono_step(self, img, range_=1.0, dt: float = 0.05) -> MonoResult:
         h, w = img.shape[-2], img.shape[-1]
@@ -476,15 +498,16 @@ class Context:
 
     def mono_collect(self, dt: float = 0.05) -> MonoResult:
         r = MonoResult()
+        before = self._lib.uvo_ctx_pending(self._h)
         try:
             self._check(self._lib.uvo_mono_collect(self._h, C.c_double(dt), C.byref(r)))
         finally:
-            if self._inflight:
-                self._inflight.popleft()
+            self._release_collected(before)
         return r
 
     def mono_reset(self):
         self._check(self._lib.uvo_mono_reset(self._h))
+        self._drained()
 
     def mono_get(self, what: str):
         spec = {"kps": KP_DTYPE, "matches": DM_DTYPE, "mask": np.dtype("u1"), "good_pts": np.dtype(("f8", 3))}[what]

@@ -15,8 +15,8 @@ LIB_PATH = os.path.join(_HERE, "lib", "libuvo_hip.so")
 
 EXPORTS = [
     "uvo_params_default_stereo", "uvo_params_default_mono", "uvo_ctx_create", "uvo_ctx_destroy", "uvo_last_error",
-    "uvo_ctx_stream", "uvo_ctx_set_params", "uvo_ctx_set_producer_stream", "uvo_ctx_warning", "uvo_surf_detect", "uvo_integral", "uvo_hessian_layer",
-    "uvo_match_knn2_ratio", "uvo_match_knn2", "uvo_match_knn2_ratio_hamming", "uvo_match_knn2_hamming", "uvo_triangulate_points", "uvo_extract_3d_points",
+    "uvo_ctx_stream", "uvo_ctx_set_params", "uvo_ctx_set_producer_stream", "uvo_ctx_warning", "uvo_ctx_pending", "uvo_surf_detect", "uvo_integral", "uvo_hessian_layer",
+    "uvo_match_knn2_ratio", "uvo_match_knn2", "uvo_match_knn2_ratio_dim", "uvo_match_knn2_dim", "uvo_match_knn2_ratio_hamming", "uvo_match_knn2_hamming", "uvo_triangulate_points", "uvo_extract_3d_points",
     "uvo_solve_pnp_ransac", "uvo_reproject_errors", "uvo_rodrigues", "uvo_stereo_set_rig", "uvo_stereo_reset", "uvo_stereo_step",
     "uvo_stereo_set_depth", "uvo_stereo_submit", "uvo_stereo_collect",
     "uvo_stereo_get", "uvo_find_essential_mat", "uvo_recover_pose", "uvo_find_homography", "uvo_decompose_homography_mat",
@@ -58,6 +58,8 @@ def lib() -> C.CDLL:
         _lib.uvo_ctx_warning.argtypes = [C.c_void_p]
         _lib.uvo_ctx_set_producer_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib.uvo_decode_image.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.uvo_ctx_pending.restype = C.c_int
+        _lib.uvo_ctx_pending.argtypes = [C.c_void_p]
         _lib.uvo_ctx_destroy.argtypes = [C.c_void_p]
         _lib.uvo_ctx_destroy.restype = None
         _lib.uvo_timing_name.restype = C.c_char_p

@@ -129,7 +129,9 @@ static uvo_status grow(Ctx* c, void** p, size_t* cap, size_t need, bool pinned)
 
 // Parses the headers and decodes every coefficient into ws->h_coef (natural order, component after component,
 // blocks in raster order of the MCU-padded component).  Host only.
-static uvo_status jpeg_entropy_decode(Ctx* c, CodecWs* ws, const uint8_t* data, size_t n, Jpeg* j)
+// headers_only: stop at the first scan header, after every check of the frame, table and scan headers (the size query of
+// uvo_decode_image): nothing is allocated and no coefficient is decoded.
+static uvo_status jpeg_entropy_decode(Ctx* c, CodecWs* ws, const uint8_t* data, size_t n, Jpeg* j, bool headers_only = false)
 {
     auto bad = [&](const char* m) { c->err = std::string("JPEG: ") + m; return UVO_INVALID_ARG; };
     if (n < 4 || data[0] != 0xFF || data[1] != 0xD8) return bad("not a JPEG stream (no SOI)");
@@ -192,8 +194,10 @@ static uvo_status jpeg_entropy_decode(Ctx* c, CodecWs* ws, const uint8_t* data, 
                 off += (size_t)q.bw * q.bh;
             }
             j->total_blocks = off;
-            UVO_TRY(grow(c, reinterpret_cast<void**>(&ws->h_coef), &ws->coef_cap, off * 64 * sizeof(int16_t), true));
-            memset(ws->h_coef, 0, off * 64 * sizeof(int16_t));
+            if (!headers_only) {
+                UVO_TRY(grow(c, reinterpret_cast<void**>(&ws->h_coef), &ws->coef_cap, off * 64 * sizeof(int16_t), true));
+                memset(ws->h_coef, 0, off * 64 * sizeof(int16_t));
+            }
             have_sof = true;
             break;
         }
@@ -207,6 +211,7 @@ static uvo_status jpeg_entropy_decode(Ctx* c, CodecWs* ws, const uint8_t* data, 
                     if (j->comp[k].id == s[1 + 2 * i]) { j->comp[k].td = s[2 + 2 * i] >> 4; j->comp[k].ta = s[2 + 2 * i] & 15; }
             for (int k = 0; k < j->ncomp; k++) if (j->comp[k].td > 3 || j->comp[k].ta > 3 || !j->dc[j->comp[k].td].present || !j->ac[j->comp[k].ta].present) return bad("scan refers to a missing Huffman table");
             for (int k = 0; k < j->ncomp; k++) if (!j->dc[j->comp[k].td].dc_symbols_ok()) return bad("bad DC Huffman table (category above 15)");
+            if (headers_only) return UVO_OK;
             BitReader b; b.p = data + pos + len; b.end = data + n;
             int left = j->restart;
             for (int my = 0; my < j->mcuy; my++)
@@ -257,9 +262,10 @@ struct IdctArgs { IdctComp comp[3]; int ncomp; size_t total_blocks; };
 
 #define UVO_DESCALE(x, n) ((int)((unsigned)(x) + (1u << ((n) - 1))) >> (n))
 __device__ __forceinline__ uint8_t jpeg_range_limit(int x)
-{
-    x = (x + 128) & 1023;                                     // libjpeg's range_limit table: clamp(x + 128), wrapping beyond +-512
-    return (uint8_t)(x < 256 ? x : (x < 512 ? 255 : 0));
+{   // libjpeg's post-IDCT range_limit table read at x & 1023 (jdmaster.c prepare_range_limit_table): [0,128) -> v + 128,
+    // [128,512) -> 255, [512,896) -> 0, [896,1024) -> v - 896: clamp(x + 128) for |x| < 512, the table's wrap beyond
+    const int v = x & 1023;
+    return (uint8_t)(v < 128 ? v + 128 : (v < 512 ? 255 : (v < 896 ? 0 : v - 896)));
 }
 // jidctint.c's butterfly on eight values (in place); both passes use it with different descaling
 // (every add / multiply modulo 2^32: a damaged stream with out-of-range coefficients gives some picture, never undefined behaviour)
@@ -423,6 +429,17 @@ uvo_status codec_decode(Ctx* c, const uint8_t* data, size_t n, int bayer, const 
     }
     // j.quant lives on this stack frame and is still being copied: wait for the upload before returning
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return UVO_OK;
+}
+
+// Size and channel count of what codec_decode would return, from the headers alone (no entropy decoding, no device work)
+uvo_status codec_peek(Ctx* c, const uint8_t* data, size_t n, int bayer, int* w, int* h, int* channels)
+{
+    Jpeg j;
+    memset(j.quant, 0, sizeof(j.quant));
+    UVO_TRY(jpeg_entropy_decode(c, nullptr, data, n, &j, true));
+    if (bayer && j.ncomp != 1) { c->err = "a bayer-format message must decode to one channel"; return UVO_INVALID_ARG; }
+    *w = j.w; *h = j.h; *channels = bayer ? 3 : j.ncomp;
     return UVO_OK;
 }
 

@@ -59,6 +59,7 @@ static void make_desc_weights(float* DW)
 }
 
 static void lane_worker(uvo_ctx* L);
+static uvo_status prime_lanes(uvo_ctx* c, int w, int h);
 extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* out);
 static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok);
 static void destroy_one(uvo_ctx* c);
@@ -110,16 +111,28 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     A(dalloc(&c->d_mpart, 2 * nchunks * cap)); A(dalloc(&c->d_mscratch, 2 * (nchunks + 4))); A(dalloc(&c->d_knn_idx, 2 * cap * 2)); A(dalloc(&c->d_knn_dist, 2 * cap * 2));
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
     A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_tmp_idx, cap));
+    if (const char* ww = getenv("UVO_WORKER_WAIT")) c->worker_wait = !strcmp(ww, "spin") ? 0 : (!strcmp(ww, "block-all") ? 2 : 1);
+    A(hipEventCreateWithFlags(&c->evBlock, hipEventDisableTiming | hipEventBlockingSync));
     for (int i = 0; i < 2; i++) {
         A(dalloc(&c->d_good_pts[i], cap * 3)); A(dalloc(&c->d_good_idx[i], cap));
         A(dalloc(&c->d_opts[i], cap * 3)); A(dalloc(&c->d_ipts[i], cap));
-        A(hipEventCreateWithFlags(&c->evA[i], hipEventDisableTiming));
+        // evA[0] is the event the lane's worker waits on (sleeping unless UVO_WORKER_WAIT=spin), evA[1] the one the submitting thread polls
+        A(hipEventCreateWithFlags(&c->evA[i], hipEventDisableTiming | ((i == 0 && c->worker_wait != 0) ? hipEventBlockingSync : 0)));
         A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsA[i]), sizeof(int) * CN_TOTAL));
     }
     A(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
     A(hipEventCreateWithFlags(&c->evProducer, hipEventDisableTiming));
     A(hipEventCreateWithFlags(&c->evDet, hipEventDisableTiming)); A(hipEventCreateWithFlags(&c->evPrevRead, hipEventDisableTiming));
-    A(hipStreamCreateWithFlags(&c->pnp_stream, hipStreamNonBlocking));
+    {   // the PnP stage is a few 1..8-workgroup kernels on a pair's critical path: its stream gets the highest priority, so that the
+        // dispatcher takes its packets ahead of queued chip-filling detection tiles of other lanes (UVO_PNP_PRIORITY=0: default priority)
+        int least = 0, greatest = 0;
+        const char* pe = getenv("UVO_PNP_PRIORITY");
+        const bool want = !pe || atoi(pe) != 0;
+        if (want && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+            A(hipStreamCreateWithPriority(&c->pnp_stream, hipStreamNonBlocking, greatest));
+        else
+            A(hipStreamCreateWithFlags(&c->pnp_stream, hipStreamNonBlocking));
+    }
     A(dalloc(&c->d_countsB, (size_t)4)); A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsB), sizeof(int) * 4));
     A(dalloc(&c->d_counts, (size_t)CN_TOTAL));
     A(dalloc(&c->d_subsets, (size_t)kMaxHyp * 5)); A(dalloc(&c->d_models, (size_t)kMaxHyp * 6)); A(dalloc(&c->d_hcount, (size_t)kMaxHyp));
@@ -196,6 +209,7 @@ static uvo_status set_depth(uvo_ctx* c, int depth)
             c->warning = "GPU_MAX_HW_QUEUES = " + std::to_string(nq) + " with " + std::to_string(depth) + " pipeline lanes (two HIP streams each): lanes share "
                          "hardware queues and the pipeline runs well below its rate; set GPU_MAX_HW_QUEUES >= " + std::to_string(2 * depth) + " before the HIP runtime starts";
     }
+    if (c->primed_w > 0) UVO_TRY(prime_lanes(c, c->primed_w, c->primed_h));                 // lanes added to a running sequence
     if (c->prev_lane >= depth || c->next_lane >= depth) { c->vo_initialized = false; c->init_matches.clear(); c->prev_lane = 0; c->next_lane = 0; c->prev_sync = true; }
     return UVO_OK;
 }
@@ -268,6 +282,7 @@ static void destroy_one(uvo_ctx* c)
     for (int i = 0; i < 2; i++) { (void)hipHostFree(c->h_countsA[i]); if (c->evA[i]) (void)hipEventDestroy(c->evA[i]); }
     if (c->pnp_stream) (void)hipStreamDestroy(c->pnp_stream);
     if (c->evAS) (void)hipEventDestroy(c->evAS);
+    if (c->evBlock) (void)hipEventDestroy(c->evBlock);
     if (c->evProducer) (void)hipEventDestroy(c->evProducer);
     for (auto& r : c->trace) for (int k = 0; k < 6; k++) if (r.ev[k]) (void)hipEventDestroy(r.ev[k]);
     if (c->evDet) (void)hipEventDestroy(c->evDet);
@@ -299,6 +314,7 @@ extern "C" uvo_status uvo_ctx_set_producer_stream(uvo_ctx* c, void* hip_stream, 
     return UVO_OK;
 }
 extern "C" const char* uvo_ctx_warning(const uvo_ctx* c) { return c ? c->warning.c_str() : ""; }
+extern "C" int uvo_ctx_pending(const uvo_ctx* c) { return c ? c->n_pending : 0; }
 
 // UVO_MEM_DEVICE inputs: order lane L's next reads after the work queued so far on the declared producer stream
 static uvo_status wait_for_producer(uvo_ctx* m, Ctx* L, int mem)
@@ -317,6 +333,15 @@ static uvo_status need_idle(uvo_ctx* c, const char* who)
 }
 
 static uvo_status fail(uvo_ctx* c, uvo_status s, const char* msg) { c->err = msg; return s; }
+
+namespace uvo {
+hipError_t host_sync(Ctx* c, hipStream_t st)
+{
+    if (c->worker_wait < 2) return hipStreamSynchronize(st);
+    hipError_t e = hipEventRecord(c->evBlock, st);
+    return e == hipSuccess ? hipEventSynchronize(c->evBlock) : e;
+}
+}
 
 // ------------------------------------------------------------------------------------------ SURF
 static uvo_status read_counts(uvo_ctx* c)
@@ -427,10 +452,30 @@ extern "C" uvo_status uvo_match_knn2_ratio(uvo_ctx* c, const float* d1, int n1, 
     return UVO_OK;
 }
 
+// match_features' L2 arm for descriptors that are not this context's SURF rows (VO_utility.cpp:525-529 sends "SIFT" -- 128 floats
+// per row whatever SURF_EXTENDED says -- to the same BFMatcher(NORM_L2)): the row width is given per call.
+namespace { struct DimScope { uvo_ctx* c; DimScope(uvo_ctx* c_, int d) : c(c_) { c->match_dim = d; } ~DimScope() { c->match_dim = 0; } }; }
+extern "C" uvo_status uvo_match_knn2_dim(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int dim, int mem, int* idx, float* dist)
+{
+    if (!c) return UVO_INVALID_ARG;
+    if (dim != 64 && dim != 128) return fail(c, UVO_INVALID_ARG, "uvo_match_knn2_dim: rows of 64 or 128 floats");
+    DimScope ds(c, dim);
+    return uvo_match_knn2(c, d1, n1, d2, n2, mem, idx, dist);
+}
+extern "C" uvo_status uvo_match_knn2_ratio_dim(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int dim, int mem,
+                                               float ratio, uvo_dmatch* out, int cap, int* m)
+{
+    if (!c) return UVO_INVALID_ARG;
+    if (dim != 64 && dim != 128) return fail(c, UVO_INVALID_ARG, "uvo_match_knn2_ratio_dim: rows of 64 or 128 floats");
+    DimScope ds(c, dim);
+    return uvo_match_knn2_ratio(c, d1, n1, d2, n2, mem, ratio, out, cap, m);
+}
+
 // The AKAZE / ORB branch of match_features (VO_utility.cpp:520-524): binary descriptors, Hamming distance
 static uvo_status stage_bytes(uvo_ctx* c, int slot, const uint8_t* d, int n, int bytes, int mem, const uint8_t** out)
 {
     if (n > c->cap) return fail(c, UVO_CAPACITY, "descriptor count exceeds the context's max_kpts");
+    if (bytes < 1 || bytes > 64) return fail(c, UVO_INVALID_ARG, "binary descriptor rows of 1..64 bytes");
     if (mem == UVO_MEM_DEVICE) { *out = d; return UVO_OK; }
     if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->d_tmp_desc[slot], d, (size_t)bytes * n, hipMemcpyHostToDevice, c->stream));     // cap x 512 bytes of staging
     *out = reinterpret_cast<const uint8_t*>(c->d_tmp_desc[slot]);
@@ -439,6 +484,7 @@ static uvo_status stage_bytes(uvo_ctx* c, int slot, const uint8_t* d, int n, int
 extern "C" uvo_status uvo_match_knn2_hamming(uvo_ctx* c, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, int mem, int* idx, float* dist)
 {
     if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !idx || !dist) return UVO_INVALID_ARG;
+    if (bytes < 1 || bytes > 64) return fail(c, UVO_INVALID_ARG, "uvo_match_knn2_hamming: descriptor rows of 1..64 bytes");    // before anything is staged
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_match_knn2_hamming"));
     if (n1 == 0) return UVO_OK;
@@ -457,6 +503,7 @@ extern "C" uvo_status uvo_match_knn2_ratio_hamming(uvo_ctx* c, const uint8_t* d1
                                                    float ratio, uvo_dmatch* out, int cap, int* m)
 {
     if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !out || !m || *m < 0) return UVO_INVALID_ARG;
+    if (bytes < 1 || bytes > 64) return fail(c, UVO_INVALID_ARG, "uvo_match_knn2_ratio_hamming: descriptor rows of 1..64 bytes");   // before anything is staged
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_match_knn2_ratio_hamming"));
     if (n1 == 0 || n2 == 0) return UVO_OK;
@@ -717,6 +764,37 @@ static uvo_status stereo_init_step(uvo_ctx* c, uvo_stereo_result* out)
     return UVO_OK;
 }
 
+// First use of a pipeline lane costs what every first use costs -- the hardware queues behind its two HIP streams are created at
+// their first submission, the per-image-size detector tables are built and uploaded (two allocations, four host syncs) -- and a
+// caller that times its first pairs through a deep pipeline pays it once per lane inside that loop.  The synchronous init phase
+// of a sequence is where the image size becomes known: every lane is prepared there, once per size.
+// A kernel with 128 bytes of private (scratch) memory per lane -- at least what any kernel of the pipeline needs (k_pnp_refit_fast:
+// 112, k_pnp_refit: 32, k_match_resolve: 20; hipcc -Rpass-analysis=kernel-resource-usage).  The runtime sets a hardware queue's scratch
+// up at the first dispatch that needs it, with the host in the loop: measured as +130 us on a lane's first matcher tail and +220 us
+// on its first PnP refit (UVO_TRACE of a 20-pair run whose warm-up had not reached the lane).
+__global__ void k_prime(int* sink, int n)
+{
+    volatile int priv[32];
+    for (int i = 0; i < 32; i++) priv[i] = i * n;
+    int acc = 0;
+    for (int i = 0; i < 32; i++) acc += priv[(i * 7 + n) & 31];
+    if (n < 0) *sink = acc;                               // never taken: n >= 0
+}
+static uvo_status prime_lanes(uvo_ctx* c, int w, int h)
+{
+    for (Ctx* l : c->lanes) {
+        if (l->primed_w == w && l->primed_h == h) continue;
+        uvo_status st = surf_prepare(l, w, h);
+        if (st != UVO_OK) { if (l != c) c->err = l->err; return st; }
+        hipLaunchKernelGGL(k_prime, dim3(1), dim3(64), 0, l->stream, l->d_countsB, 1);
+        hipLaunchKernelGGL(k_prime, dim3(1), dim3(64), 0, l->pnp_stream, l->d_countsB, 1);
+        UVO_HIP_TRY(c, hipStreamSynchronize(l->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(l->pnp_stream));
+        l->primed_w = w; l->primed_h = h;
+    }
+    return UVO_OK;
+}
+
 // Stage A of one pair (VO:548-632): detect, stereo match, triangular match, triangulation,
 // extract_3Dpoints -- all enqueued on the lane's stream without a host sync; the counters are copied to the
 // lane's pinned mirror, an event marks completion and the lane's worker thread takes over for stage B.
@@ -738,6 +816,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
         UVO_TRY(surf_upload(c, 1, right, w, h, stride, mem));
         UVO_TRY(surf_detect(c, 2));
         UVO_TRY(stereo_init_step(c, &res));
+        UVO_TRY(prime_lanes(c, w, h));
         c->stereo_init_results.push_back(res);
         c->inflight[c->n_pending++] = Ctx::kInflightStereoInit; c->n_submitted++;
         c->next_lane = 0;
@@ -1070,10 +1149,11 @@ extern "C" uvo_status uvo_decode_image(uvo_ctx* c, const uint8_t* data, size_t n
     UVO_TRY(need_idle(c, "uvo_decode_image"));
     const std::string fmt = format ? format : "";
     if (fmt.find("png") != std::string::npos) return fail(c, UVO_INVALID_ARG, "uvo_decode_image: PNG payloads are not supported (JPEG only)");
+    const int bayer = fmt.find("bayer") != std::string::npos ? 1 : 0;
+    if (!out) return codec_peek(c, data, n, bayer, w, h, channels);      // size query: the headers only, nothing is decoded
     const uint8_t* d_res = nullptr;
-    UVO_TRY(codec_decode(c, data, n, fmt.find("bayer") != std::string::npos ? 1 : 0, &d_res, w, h, channels));
+    UVO_TRY(codec_decode(c, data, n, bayer, &d_res, w, h, channels));
     const size_t bytes = (size_t)*w * *h * *channels;
-    if (!out) return UVO_OK;                                  // size query
     if (bytes > cap_bytes) return fail(c, UVO_CAPACITY, "uvo_decode_image: output capacity too small");
     UVO_HIP_TRY(c, hipMemcpyAsync(out, d_res, bytes, out_mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1361,6 +1441,7 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
         c->inflight[c->n_pending++] = Ctx::kInflightMonoInit; c->n_submitted++;                // a synchronous init frame
         c->prev_lane = 0; c->next_lane = 1 % depth;
         UVO_HIP_TRY(c, hipEventRecord(c->evDet, c->stream));                               // lane 0 holds the frame the next one matches against
+        UVO_TRY(prime_lanes(c, w, h));
         return UVO_OK;
     }
     const int li = c->next_lane;
@@ -1423,7 +1504,7 @@ static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok)
     hipStream_t st = L->stream;
     L->mono_kps.resize(n);
     if (n && !hip_ok(hipMemcpyAsync(L->mono_kps.data(), L->det[0].kps, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, st))) return;
-    if (n < p.MIN_NUM_FEATURES) { (void)hip_ok(hipStreamSynchronize(st)); return; }       // VO:276-284
+    if (n < p.MIN_NUM_FEATURES) { (void)hip_ok(host_sync(L, st)); return; }       // VO:276-284
     if (M > cap) { j.st = UVO_CAPACITY; j.err = "match count exceeds max_kpts"; return; }
     j.mres.n_matches = M;
     L->mono_matches.resize(M);
@@ -1433,7 +1514,7 @@ static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok)
         if (!hip_ok(hipMemcpyAsync(k1.data(), L->d_x1, sizeof(uvo_point2f) * M, hipMemcpyDeviceToHost, st))) return;
         if (!hip_ok(hipMemcpyAsync(k2.data(), L->d_x2, sizeof(uvo_point2f) * M, hipMemcpyDeviceToHost, st))) return;
     }
-    if (!hip_ok(hipStreamSynchronize(st))) return;
+    if (!hip_ok(host_sync(L, st))) return;
     if (M < p.MIN_NUM_FEATURES) return;                                                    // VO:299-307
     int use_essential = uvo_select_estimation_method(k1.data(), k2.data(), M, p.DISTANCE);   // VO:310-317
     int n_in = 0, success = 0;
@@ -1466,7 +1547,7 @@ static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok)
             G = L->h_counts[CN_G];
             L->mono_good_pts.resize((size_t)3 * G);
             if (G && !hip_ok(hipMemcpyAsync(L->mono_good_pts.data(), L->d_good_pts[0], sizeof(double) * 3 * G, hipMemcpyDeviceToHost, st))) return;
-            if (!hip_ok(hipStreamSynchronize(st))) return;
+            if (!hip_ok(host_sync(L, st))) return;
         }
         j.mres.n_good3d = G;
         if (G < p.MIN_NUM_3DPOINTS) valid = 0;                                             // VO:358

@@ -746,7 +746,7 @@ uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f*
     UVO_HIP_TRY(c, hipGetLastError());
     if (getenv("UVO_DBG_PHASE")) {
         long long clk[8];
-        UVO_HIP_TRY(c, hipStreamSynchronize(st));
+        UVO_HIP_TRY(c, host_sync(c, st));
         UVO_HIP_TRY(c, hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_fp_clk), sizeof(clk)));
         fprintf(stderr, "[uvo] five-point phases (us): svd %.1f polys %.1f lu %.1f detB %.1f roots %.1f solveZ %.1f | nsub %d\n",
                 (clk[1]-clk[0])*0.01, (clk[2]-clk[1])*0.01, (clk[3]-clk[2])*0.01, (clk[4]-clk[3])*0.01, (clk[5]-clk[4])*0.01,
@@ -755,7 +755,7 @@ uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f*
     if (n == modelPoints) {
         UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data(), w->nmodels, sizeof(int), hipMemcpyDeviceToHost, st));
         UVO_HIP_TRY(c, hipMemcpyAsync(w->h_models.data(), w->models, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
-        UVO_HIP_TRY(c, hipStreamSynchronize(st));
+        UVO_HIP_TRY(c, host_sync(c, st));
         memcpy(E, w->h_models.data(), sizeof(double) * 9);
         if (w->h_nmodels[0] <= 0) return UVO_OK;
         memset(mask, 1, n); *ok = 1;
@@ -769,7 +769,7 @@ uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f*
     UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data(), w->nmodels, sizeof(int) * first, hipMemcpyDeviceToHost, st));
     if (lmeds) UVO_HIP_TRY(c, hipMemcpyAsync(w->h_medians.data(), w->medians, sizeof(double) * 10 * first, hipMemcpyDeviceToHost, st));
     else UVO_HIP_TRY(c, hipMemcpyAsync(w->h_counts.data(), w->counts, sizeof(int) * 10 * first, hipMemcpyDeviceToHost, st));
-    UVO_HIP_TRY(c, hipStreamSynchronize(st));
+    UVO_HIP_TRY(c, host_sync(c, st));
     Winner win;
     if (lmeds) win = replay_lmeds(w->h_nmodels.data(), w->h_medians.data(), 10, nsub);
     else {
@@ -784,7 +784,7 @@ uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f*
             UVO_HIP_TRY(c, hipGetLastError());
             UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data() + first, w->nmodels + first, sizeof(int) * rest, hipMemcpyDeviceToHost, st));
             UVO_HIP_TRY(c, hipMemcpyAsync(w->h_counts.data() + (size_t)10 * first, w->counts + (size_t)10 * first, sizeof(int) * 10 * rest, hipMemcpyDeviceToHost, st));
-            UVO_HIP_TRY(c, hipStreamSynchronize(st));
+            UVO_HIP_TRY(c, host_sync(c, st));
             win = replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 10, nsub, niters, n, modelPoints, prob);
         }
     }
@@ -800,7 +800,7 @@ uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f*
     UVO_HIP_TRY(c, hipGetLastError());
     UVO_HIP_TRY(c, hipMemcpyAsync(w->h_mask.data(), w->masks, n, hipMemcpyDeviceToHost, st));
     UVO_HIP_TRY(c, hipMemcpyAsync(w->h_models.data(), best, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
-    UVO_HIP_TRY(c, hipStreamSynchronize(st));
+    UVO_HIP_TRY(c, host_sync(c, st));
     memcpy(mask, w->h_mask.data(), (size_t)n); memcpy(E, w->h_models.data(), sizeof(double) * 9);
     if (lmeds) { int good = 0; for (int i = 0; i < n; i++) good += mask[i]; *ok = good >= modelPoints; }
     else *ok = 1;
@@ -857,7 +857,7 @@ uvo_status mono_recover_pose(Ctx* c, const double* E, const uvo_point2f* p1, con
                            w->masks + 4 * (size_t)c->cap, w->masks, w->good);
         UVO_HIP_TRY(c, hipGetLastError());
         UVO_HIP_TRY(c, hipMemcpyAsync(w->h_good.data(), w->good, sizeof(good), hipMemcpyDeviceToHost, st));
-        UVO_HIP_TRY(c, hipStreamSynchronize(st));
+        UVO_HIP_TRY(c, host_sync(c, st));
         memcpy(good, w->h_good.data(), sizeof(good));
     }
     int best;
@@ -1058,7 +1058,7 @@ uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f
             UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data(), w->nmodels, sizeof(int) * first, hipMemcpyDeviceToHost, st));
             if (lmeds) UVO_HIP_TRY(c, hipMemcpyAsync(w->h_medians.data(), w->medians, sizeof(double) * first, hipMemcpyDeviceToHost, st));
             else UVO_HIP_TRY(c, hipMemcpyAsync(w->h_counts.data(), w->counts, sizeof(int) * first, hipMemcpyDeviceToHost, st));
-            UVO_HIP_TRY(c, hipStreamSynchronize(st));
+            UVO_HIP_TRY(c, host_sync(c, st));
             Winner win;
             if (lmeds) win = replay_lmeds(w->h_nmodels.data(), w->h_medians.data(), 1, nsub);
             else {
@@ -1073,7 +1073,7 @@ uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f
                     UVO_HIP_TRY(c, hipGetLastError());
                     UVO_HIP_TRY(c, hipMemcpyAsync(w->h_nmodels.data() + first, w->nmodels + first, sizeof(int) * rest, hipMemcpyDeviceToHost, st));
                     UVO_HIP_TRY(c, hipMemcpyAsync(w->h_counts.data() + first, w->counts + first, sizeof(int) * rest, hipMemcpyDeviceToHost, st));
-                    UVO_HIP_TRY(c, hipStreamSynchronize(st));
+                    UVO_HIP_TRY(c, host_sync(c, st));
                     win = replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 1, nsub, niters, n, modelPoints, confidence);
                 }
             }
@@ -1089,7 +1089,7 @@ uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f
                 UVO_HIP_TRY(c, hipGetLastError());
                 UVO_HIP_TRY(c, hipMemcpyAsync(w->h_mask.data(), w->masks, n, hipMemcpyDeviceToHost, st));
                 UVO_HIP_TRY(c, hipMemcpyAsync(w->h_models.data(), best, sizeof(double) * 9, hipMemcpyDeviceToHost, st));
-                UVO_HIP_TRY(c, hipStreamSynchronize(st));
+                UVO_HIP_TRY(c, host_sync(c, st));
                 memcpy(mask, w->h_mask.data(), (size_t)n); memcpy(H, w->h_models.data(), sizeof(double) * 9);
                 if (lmeds) { int good = 0; for (int i = 0; i < n; i++) good += mask[i]; result = good >= modelPoints; }
                 else result = 1;
@@ -1239,7 +1239,7 @@ uvo_status mono_recover_pose_homography(Ctx* c, const double* H, const uvo_point
         if (n > 0) {
             UVO_TRY(pose_triangulate(c, proj_std, P, nullptr, n));
             UVO_HIP_TRY(c, hipMemcpyAsync(p4.data(), c->d_pts4, sizeof(float4) * n, hipMemcpyDeviceToHost, st));
-            UVO_HIP_TRY(c, hipStreamSynchronize(st));
+            UVO_HIP_TRY(c, host_sync(c, st));
         }
         for (int j = 0; j < n; j++) {                       // convert_from_homogeneous_coords (VOU:71-83): col / w in float
             float inv = (float)(1.0 / (double)p4[j].w);

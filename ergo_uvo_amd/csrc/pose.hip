@@ -567,7 +567,7 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
             if (sc[slot_of[s_]].G == modelPoints) UVO_HIP_TRY(m, hipMemcpyAsync(c->h_pose, c->d_models, sizeof(double) * 6, hipMemcpyDeviceToHost, st));
         }
         if (tr) (void)hipEventRecord(tr->ev[4], st);
-        UVO_HIP_TRY(m, hipStreamSynchronize(st));
+        UVO_HIP_TRY(m, host_sync(m, st));
         // replay of RANSACPointSetRegistrator::run's sequential scan over the counts that exist so far, per job
         for (int s_ = 0; s_ < nb; s_++) {
             Scan& q = sc[slot_of[s_]];
@@ -633,7 +633,7 @@ uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G,
     if (nb2 > 0) need_sync = true;
     if (tr) (void)hipEventRecord(tr->ev[5], st);
     if (g_bdbg) { g_bstat[2] += now_us() - t_b0; t_b0 = now_us(); }
-    if (need_sync) UVO_HIP_TRY(m, hipStreamSynchronize(st));
+    if (need_sync) UVO_HIP_TRY(m, host_sync(m, st));
     if (g_bdbg) { g_bstat[3] += now_us() - t_b0; g_bstat[4] += 1; }
     for (int s = 0; s < nb2; s++) {
         Ctx* c = lanes[idx2[s]];

@@ -1690,65 +1690,97 @@ static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float 
     return hipGetLastError();
 }
 
-uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
+// Geometry of the merged detection launch (all four octaves in one grid) for a w x h image
+struct MergedGrid { int nbx0, nb0, nbx1, nb1, nb23, total; P23Grid g; };
+static const int kMergedTW0 = 64, kMergedTH0 = 32, kMergedTW1 = 32;
+static MergedGrid merged_grid(const OctavePat* ops)
 {
-    const int w = c->img_w, h = c->img_h;
+    constexpr int TW0 = kMergedTW0, TH0 = kMergedTH0, TW1 = kMergedTW1, TH1 = kO1TileRows;
+    MergedGrid m;
+    m.nbx0 = (ops[0].cols + TW0 - 3) / (TW0 - 2); m.nb0 = m.nbx0 * ((ops[0].rows + TH0 - 3) / (TH0 - 2));
+    m.nbx1 = (ops[1].cols + TW1 - 3) / (TW1 - 2); m.nb1 = m.nbx1 * ((ops[1].rows + TH1 - 3) / (TH1 - 2));
+    m.g.nbx2 = (ops[2].cols + 32 - 3) / (32 - 2); m.g.nb2 = m.g.nbx2 * ((ops[2].rows + 16 - 3) / (16 - 2));
+    m.g.nbx3 = (ops[3].cols + 16 - 3) / (16 - 2); m.g.nb3 = m.g.nbx3 * ((ops[3].rows + 16 - 3) / (16 - 2));
+    m.nb23 = m.g.nb2 + m.g.nb3; m.total = m.nb0 + m.nb1 + m.nb23;
+    return m;
+}
+static bool merged_launch(const Ctx* c)
+{
+    static const bool split_env = getenv("UVO_HESSIAN_SPLIT") != nullptr;       // diagnostic: one launch per octave
+    return c->p.SURF_OCTAVES_NUMBER == 4 && !split_env;
+}
+
+// Everything the detector keeps per image SIZE (and octave count) on this lane: the octave patterns for k_hessian_finish and the
+// block order of the merged detection launch.  Idempotent; surf_detect calls it for the image at hand, and the pipeline calls it
+// for every lane as soon as the stream's image size is known, so that a lane's first pair does not pay two allocations, two
+// uploads and four host syncs inside somebody's timed loop.
+uvo_status surf_prepare(Ctx* c, int w, int h)
+{
     if (c->p.SURF_OCTAVES_NUMBER < 1 || c->p.SURF_OCTAVES_NUMBER > 4 || c->p.SURF_OCTAVES_LAYERS != 3) {
         c->err = "SURF: supported nOctaves 1..4, nOctaveLayers 3";
         return UVO_INVALID_ARG;
     }
+    OctavePat ops[4];
+    memset(ops, 0, sizeof(ops));
+    for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER; o++) make_octave(o, c->p.SURF_OCTAVES_LAYERS, w, h, &ops[o]);
+    if (!c->d_octpat) UVO_HIP_TRY(c, hipMalloc(&c->d_octpat, sizeof(ops)));
+    if (c->h_octpat.size() != sizeof(ops) || memcmp(c->h_octpat.data(), ops, sizeof(ops)) != 0) {      // new image size or octave count
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));          // nothing may still read the old table or the staging copy
+        c->h_octpat.assign(reinterpret_cast<const unsigned char*>(ops), reinterpret_cast<const unsigned char*>(ops) + sizeof(ops));
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_octpat, c->h_octpat.data(), sizeof(ops), hipMemcpyHostToDevice, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (!merged_launch(c)) return UVO_OK;
+    const MergedGrid m = merged_grid(ops);
+    const int nb0 = m.nb0, nb1 = m.nb1, nb23 = m.nb23, total = m.total;
+    if (nb0 > 0x3FFF || nb1 > 0x3FFF || nb23 > 0x3FFF) { c->err = "SURF: image too large for the merged detection launch's tile table"; return UVO_INVALID_ARG; }
+    if ((int)c->h_hess_order.size() != total || c->hess_order_key[0] != nb0 || c->hess_order_key[1] != nb1 || c->hess_order_key[2] != nb23) {
+        // block b's kind and tile: the i-th tile of a kind with n tiles sits at position (i + 1/2) / n of the launch
+        std::vector<std::pair<double, uint16_t>> pos;
+        pos.reserve((size_t)total);
+        const int nk[3] = { nb0, nb1, nb23 };
+        for (int k = 0; k < 3; k++) for (int i = 0; i < nk[k]; i++) pos.emplace_back((i + 0.5) / nk[k] + k * 1e-9, (uint16_t)((k << 14) | i));
+        std::sort(pos.begin(), pos.end());
+        c->h_hess_order.resize((size_t)total);
+        for (int b = 0; b < total; b++) c->h_hess_order[(size_t)b] = pos[(size_t)b].second;
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));               // nothing may still read the old table
+        if (c->d_hess_order_cap < (size_t)total) {
+            if (c->d_hess_order) (void)hipFree(c->d_hess_order);
+            c->d_hess_order = nullptr; c->d_hess_order_cap = 0;
+            UVO_HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_hess_order), sizeof(uint16_t) * (size_t)total));
+            c->d_hess_order_cap = (size_t)total;
+        }
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_hess_order, c->h_hess_order.data(), sizeof(uint16_t) * (size_t)total, hipMemcpyHostToDevice, c->stream));
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->hess_order_key[0] = nb0; c->hess_order_key[1] = nb1; c->hess_order_key[2] = nb23;
+    }
+    return UVO_OK;
+}
+
+uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
+{
+    const int w = c->img_w, h = c->img_h;
+    UVO_TRY(surf_prepare(c, w, h));
     UVO_TRY(surf_integral(c, nimg));
     const float thr = (float)c->p.SURF_MIN_HESSIAN;
     {
         OctavePat ops[4];
         memset(ops, 0, sizeof(ops));
         for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER; o++) make_octave(o, c->p.SURF_OCTAVES_LAYERS, w, h, &ops[o]);
-        if (!c->d_octpat) UVO_HIP_TRY(c, hipMalloc(&c->d_octpat, sizeof(ops)));
-        if (c->h_octpat.size() != sizeof(ops) || memcmp(c->h_octpat.data(), ops, sizeof(ops)) != 0) {      // new image size or octave count
-            UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));          // nothing may still read the old table or the staging copy
-            c->h_octpat.assign(reinterpret_cast<const unsigned char*>(ops), reinterpret_cast<const unsigned char*>(ops) + sizeof(ops));
-            UVO_HIP_TRY(c, hipMemcpyAsync(c->d_octpat, c->h_octpat.data(), sizeof(ops), hipMemcpyHostToDevice, c->stream));
-            UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        }
         // four octaves (the shipped configuration): one launch for all of them
-        static const bool split_env = getenv("UVO_HESSIAN_SPLIT") != nullptr;       // diagnostic: one launch per octave
-        const bool merged = c->p.SURF_OCTAVES_NUMBER == 4 && !split_env;
+        const bool merged = merged_launch(c);
         if (merged) {
             ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
             SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
-            constexpr int TW0 = 64, TH0 = 32, TW1 = 32, TH1 = kO1TileRows;
+            constexpr int TW0 = kMergedTW0, TH0 = kMergedTH0, TW1 = kMergedTW1, TH1 = kO1TileRows;
             constexpr int THs0 = (TH0 - 1) * OctC<0>::STEP + (OctC<0>::HI - OctC<0>::LO) + 1, THs1 = (TH1 - 1) * OctC<1>::STEP + (OctC<1>::HI - OctC<1>::LO) + 1;
             constexpr size_t lds0 = sizeof(float) * 3 * TW0 * TH0 + sizeof(int32_t) * (size_t)THs0 * OctC<0>::STEP * OctTile<0, TW0>::PW + sizeof(unsigned) * NmsLds<TW0, TH0>::kWords;
             constexpr size_t lds1 = sizeof(float) * 3 * TW1 * TH1 + sizeof(int32_t) * (size_t)THs1 * OctC<1>::STEP * OctTile<1, TW1>::PW + sizeof(unsigned) * NmsLds<TW1, TH1>::kWords;
             constexpr size_t lds = lds0 > lds1 ? lds0 : lds1;
             static_assert(lds <= 54600, "three blocks of the merged detection launch must fit a CU's 160 KB of LDS");
-            const int nbx0 = (ops[0].cols + TW0 - 3) / (TW0 - 2), nb0 = nbx0 * ((ops[0].rows + TH0 - 3) / (TH0 - 2));
-            const int nbx1 = (ops[1].cols + TW1 - 3) / (TW1 - 2), nb1 = nbx1 * ((ops[1].rows + TH1 - 3) / (TH1 - 2));
-            P23Grid g;
-            g.nbx2 = (ops[2].cols + 32 - 3) / (32 - 2); g.nb2 = g.nbx2 * ((ops[2].rows + 16 - 3) / (16 - 2));
-            g.nbx3 = (ops[3].cols + 16 - 3) / (16 - 2); g.nb3 = g.nbx3 * ((ops[3].rows + 16 - 3) / (16 - 2));
-            const int nb23 = g.nb2 + g.nb3, total = nb0 + nb1 + nb23;
-            if (nb0 > 0x3FFF || nb1 > 0x3FFF || nb23 > 0x3FFF) { c->err = "SURF: image too large for the merged detection launch's tile table"; return UVO_INVALID_ARG; }
-            if ((int)c->h_hess_order.size() != total || c->hess_order_key[0] != nb0 || c->hess_order_key[1] != nb1 || c->hess_order_key[2] != nb23) {
-                // block b's kind and tile: the i-th tile of a kind with n tiles sits at position (i + 1/2) / n of the launch
-                std::vector<std::pair<double, uint16_t>> pos;
-                pos.reserve((size_t)total);
-                const int nk[3] = { nb0, nb1, nb23 };
-                for (int k = 0; k < 3; k++) for (int i = 0; i < nk[k]; i++) pos.emplace_back((i + 0.5) / nk[k] + k * 1e-9, (uint16_t)((k << 14) | i));
-                std::sort(pos.begin(), pos.end());
-                c->h_hess_order.resize((size_t)total);
-                for (int b = 0; b < total; b++) c->h_hess_order[(size_t)b] = pos[(size_t)b].second;
-                UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));               // nothing may still read the old table
-                if (c->d_hess_order_cap < (size_t)total) {
-                    if (c->d_hess_order) (void)hipFree(c->d_hess_order);
-                    c->d_hess_order = nullptr; c->d_hess_order_cap = 0;
-                    UVO_HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_hess_order), sizeof(uint16_t) * (size_t)total));
-                    c->d_hess_order_cap = (size_t)total;
-                }
-                UVO_HIP_TRY(c, hipMemcpyAsync(c->d_hess_order, c->h_hess_order.data(), sizeof(uint16_t) * (size_t)total, hipMemcpyHostToDevice, c->stream));
-                UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-                c->hess_order_key[0] = nb0; c->hess_order_key[1] = nb1; c->hess_order_key[2] = nb23;
-            }
+            const MergedGrid mg = merged_grid(ops);
+            const int nbx0 = mg.nbx0, nbx1 = mg.nbx1, total = mg.total;
+            const P23Grid g = mg.g;
             auto kern = k_hessian_nms_all<TW0, TH0>;
             static bool attr_dev[64] = {false};
             bool& attr_set = attr_dev[c->device & 63];

@@ -143,6 +143,14 @@ struct Ctx {
                                                  // blocks on (hipEventSynchronize), [1] its twin for other lanes' hipStreamWaitEvent -- the runtime holds
                                                  // an event's lock while a host thread waits on it, so a stream wait on the SAME event blocked the
                                                  // submitting thread until the event completed (133 us per pair at C3)
+    // How the lane's worker thread waits for the device (env UVO_WORKER_WAIT = spin | block | block-all; default block):
+    //   0 spin      -- every wait polls (lowest latency, one busy host thread per waiting worker: up to `depth` per context)
+    //   1 block     -- the long wait for the end of stage A (evA[0], created with hipEventBlockingSync) sleeps on the interrupt; the two
+    //                  short syncs inside the PnP stage poll.  With N ranks on one node this keeps a rank at one spinning submitter
+    //                  + at most max_b polling workers instead of 1 + depth
+    //   2 block-all -- the PnP stage's syncs sleep as well (evBlock); for hosts with fewer cores than threads
+    int worker_wait = 1;
+    hipEvent_t evBlock = nullptr;                // hipEventBlockingSync marker for host_sync()
     int* h_countsA[2] = {nullptr, nullptr};      // pinned copy of d_counts
     hipEvent_t evAS = nullptr;                   // this lane's "after stereo match" set is written
     int a_overlap = 2;                           // master: stage As (detect .. extract_3Dpoints) allowed side by side (env UVO_A_OVERLAP, 0 = no limit)
@@ -150,6 +158,7 @@ struct Ctx {
     std::vector<Ctx*> lanes;                     // master only: lanes[0] == this
     Ctx* master = nullptr;                       // children only
     int lane_id = 0;
+    int primed_w = 0, primed_h = 0;              // image size this lane's streams and detector tables are ready for (prime_lanes)
     int as_w = 0;                                // the as-buffer this lane writes next
     int prev_lane = 0, prev_buf = 0;             // master: where the previous pair's as-set lives
     bool prev_sync = true;                       // master: that set was written synchronously (init step), no event to wait for
@@ -203,7 +212,8 @@ struct Ctx {
     std::vector<TraceRec> trace; int trace_cur = -1; long long trace_count = 0;
     bool trace_on = false;
 
-    int desc_dim() const { return p.SURF_EXTENDED ? 128 : 64; }      // SURF::descriptorSize(): floats per descriptor row
+    int match_dim = 0;                           // uvo_match_knn2*_dim: row width of the standalone matcher for the duration of one call (0 = SURF's)
+    int desc_dim() const { return match_dim ? match_dim : (p.SURF_EXTENDED ? 128 : 64); }      // SURF::descriptorSize(): floats per descriptor row
 
     // ---- timing ----
     bool timing = false;
@@ -233,10 +243,14 @@ void range_push(const char* name);
 void range_pop();
 struct Range { explicit Range(const char* name) { range_push(name); } ~Range() { range_pop(); } Range(const Range&) = delete; Range& operator=(const Range&) = delete; };
 
+// Wait on the host for everything queued on `st` so far, the way lane `c`'s worker_wait says (polling or sleeping)
+hipError_t host_sync(Ctx* c, hipStream_t st);
+
 // surf.hip
 uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int stride, int mem);
 uvo_status surf_integral(Ctx* c, int nimg);
 uvo_status surf_build_area_tables(Ctx* c);
+uvo_status surf_prepare(Ctx* c, int w, int h);                           // per-image-size tables of this lane (idempotent)
 uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features = -1);   // integral -> ... -> sorted kps + descriptors in c->det[];
                                                                         // gate_min_features >= 0: also evaluate VO:556 into d_counts[CN_NQA]
 uvo_status surf_hessian_layer_debug(Ctx* c, int octave, int layer, float* det, float* trace);
@@ -271,6 +285,7 @@ uvo_status pre_get_image(Ctx* c, const uint8_t* rgb, int w, int h, int stride, i
 // codec.hip
 void codec_ws_free(Ctx* c);
 uvo_status codec_decode(Ctx* c, const uint8_t* data, size_t n, int bayer, const uint8_t** d_out, int* w, int* h, int* channels);
+uvo_status codec_peek(Ctx* c, const uint8_t* data, size_t n, int bayer, int* w, int* h, int* channels);
 uvo_status codec_bayer(Ctx* c, const uint8_t* bayer, int w, int h, int stride, int mem, const uint8_t** d_out);
 // mono.hip
 void mono_ws_free(Ctx* c);

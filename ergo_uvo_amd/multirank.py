@@ -19,15 +19,39 @@ def stream_seed(base_seed: int, rank: int) -> int:
     return base_seed + rank
 
 
-def init(backend: str, device_index: int | None = None) -> tuple[int, int]:
+def pin_rank_to_cores(local_rank: int, local_world: int) -> list[int]:
+    """Give this rank its own slice of the host's cores (call before the first GPU call, so the HIP runtime's helper threads and
+    the pipeline's lane workers inherit it): rank r of n gets cores [r*k, (r+1)*k) of the sorted set this process may run on,
+    k = cores // n.  Returns the cores now in force (unchanged when there are fewer cores than ranks, or on platforms without
+    sched_setaffinity).  A rank runs 1 submitting thread (polls) + `depth` lane workers, of which at most max_b (3) poll at a
+    time; unpinned, the ranks' pollers migrate over each other's cores."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return []
+    k = len(cores) // max(local_world, 1)
+    if local_world > 1 and k >= 1:
+        mine = cores[local_rank * k:(local_rank + 1) * k]
+        os.sched_setaffinity(0, set(mine))
+        return mine
+    return cores
+
+
+def init(backend: str, device_index: int | None = None, force: bool = False) -> tuple[int, int]:
+    """One process per GPU.  The process group exists only when there is more than one rank -- or when `force` asks for it, so
+    that a single GPU can run the very collectives of the N-rank path (RCCL communicator of one rank: `bench.py --force-dist`)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+    if (world > 1 or force) and not dist.is_initialized():
         kw = {}
         if backend == "nccl" and device_index is not None:
             kw["device_id"] = torch.device("cuda", device_index)
+        rdzv = os.environ.get("UVO_RDZV_FILE")                 # bench.py's own launcher: a file store, no port to guess
+        if rdzv:
+            kw["init_method"] = "file://" + rdzv
+        else:                                                  # torchrun / the driver: MASTER_ADDR / MASTER_PORT from the environment
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world
 
@@ -53,7 +77,7 @@ def fill_record(records, i: int, stream: int, step: int, res) -> None:
 
 def gather_records(records: torch.Tensor, device: torch.device | None = None) -> torch.Tensor:
     """[steps, RECORD_WIDTH] per rank -> [world, steps, RECORD_WIDTH] on every rank (one all-gather)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return records.unsqueeze(0)
     mine = records.to(device) if device is not None else records
     world = dist.get_world_size()
@@ -64,13 +88,24 @@ def gather_records(records: torch.Tensor, device: torch.device | None = None) ->
 
 
 def max_over_ranks(seconds: float, device: torch.device | None = None) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
+def gather_ints(values: list[int], device: torch.device | None = None) -> torch.Tensor:
+    """[k] ints per rank -> [world, k] on every rank (rank 0 checks that it sees N distinct ranks on N distinct devices)."""
+    mine = torch.tensor(values, dtype=torch.int64, device=device)
+    if not dist.is_initialized():
+        return mine.unsqueeze(0).cpu()
+    out = torch.empty((dist.get_world_size() * mine.numel(),), dtype=torch.int64, device=mine.device)
+    dist.all_gather_into_tensor(out, mine)
+    return out.view(dist.get_world_size(), -1).cpu()
+
+
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    """A process group of one rank (force) still runs the collective."""
+    if dist.is_initialized():
         dist.barrier()

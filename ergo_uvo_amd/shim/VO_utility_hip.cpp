@@ -317,25 +317,25 @@ void detect_features(Mat img, vector<KeyPoint>& keypoints, Mat& descriptors)
 }
 
 namespace {
-vector<float> tight_descriptors(const Mat& d, const char* what)
+vector<float> tight_descriptors(const Mat& d, const char* what, int dsize)
 {
-    const int dsize = SURF_EXTENDED ? 128 : 64;      // the rows detect_features produced under the same parameters
     require(d.empty() || (d.type() == CV_32FC1 && d.cols == dsize), what);
     vector<float> v((size_t)d.rows * dsize);
     for (int i = 0; i < d.rows; i++) memcpy(v.data() + (size_t)i * dsize, d.ptr<float>(i), sizeof(float) * dsize);
     return v;
 }
 // BFMatcher(NORM_L2).knnMatch(k = 2) + Lowe ratio; results are APPENDED to `matches` as the reference's push_back does
-void match_impl(const Mat& d1, const Mat& d2, vector<DMatch>& matches)
+// dsize: SURF rows (64, or 128 with SURF_EXTENDED: what detect_features produced under the same parameters) or SIFT rows (128)
+void match_impl(const Mat& d1, const Mat& d2, vector<DMatch>& matches, int dsize)
 {
-    vector<float> a = tight_descriptors(d1, "match_features: descriptors1 must be CV_32F with SURF's descriptor size (64, or 128 with SURF_EXTENDED) columns");
-    vector<float> b = tight_descriptors(d2, "match_features: descriptors2 must be CV_32F with SURF's descriptor size (64, or 128 with SURF_EXTENDED) columns");
+    vector<float> a = tight_descriptors(d1, "match_features: descriptors1 must be CV_32F with the detector's descriptor size (SURF: 64, or 128 with SURF_EXTENDED; SIFT: 128) columns", dsize);
+    vector<float> b = tight_descriptors(d2, "match_features: descriptors2 must be CV_32F with the detector's descriptor size (SURF: 64, or 128 with SURF_EXTENDED; SIFT: 128) columns", dsize);
     const int n1 = d1.rows, n2 = d2.rows;
     if (n1 == 0) return;
     vector<uvo_dmatch> out((size_t)n1);
     int m = 0;
-    SHIM_TRY(uvo_match_knn2_ratio(ctx_now(), a.data(), n1, b.data(), n2, UVO_MEM_HOST, (float)LOWE_RATIO_THRESHOLD, out.data(), n1, &m),
-             "uvo_match_knn2_ratio");
+    SHIM_TRY(uvo_match_knn2_ratio_dim(ctx_now(), a.data(), n1, b.data(), n2, dsize, UVO_MEM_HOST, (float)LOWE_RATIO_THRESHOLD, out.data(), n1, &m),
+             "uvo_match_knn2_ratio_dim");
     const size_t base = matches.size();
     matches.resize(base + (size_t)m);
     if (m) memcpy(static_cast<void*>(matches.data() + base), out.data(), sizeof(uvo_dmatch) * m);
@@ -363,15 +363,17 @@ void match_features(vector<KeyPoint> keypoints1, vector<KeyPoint> keypoints2, Ma
         if (m) memcpy(static_cast<void*>(matches.data() + base), out.data(), sizeof(uvo_dmatch) * m);
         return;
     }
-    if (FEATURE_DETECTOR != "SURF") throw uvo_hip::Error(UVO_INVALID_ARG, "match_features: FEATURE_DETECTOR must be \"SURF\" (L2), \"AKAZE\" or \"ORB\" (Hamming)");
-    match_impl(descriptors1, descriptors2, matches);
+    // VOU:525-529: "SURF" and "SIFT" share BFMatcher(NORM_L2); any other name matches nothing in the reference (knn_matches stays empty)
+    if (FEATURE_DETECTOR == "SIFT") { match_impl(descriptors1, descriptors2, matches, 128); return; }
+    if (FEATURE_DETECTOR != "SURF") return;
+    match_impl(descriptors1, descriptors2, matches, SURF_EXTENDED ? 128 : 64);
 }
 
 void match_features(vector<KeyPoint> keypoints1, vector<KeyPoint> keypoints2, Mat descriptors1, Mat descriptors2, vector<DMatch>& matches,
                     vector<Point2f>& keypoints1_conv, vector<Point2f>& keypoints2_conv)
 {
     const size_t base = matches.size();
-    match_impl(descriptors1, descriptors2, matches);
+    match_impl(descriptors1, descriptors2, matches, descriptors1.empty() ? (SURF_EXTENDED ? 128 : 64) : descriptors1.cols);     // VOU:551-552: NORM_L2 whatever the detector
     for (size_t i = base; i < matches.size(); i++) {
         keypoints1_conv.push_back(keypoints1.at((size_t)matches[i].queryIdx).pt);      // query is keypoints1
         keypoints2_conv.push_back(keypoints2.at((size_t)matches[i].trainIdx).pt);      // train is keypoints2

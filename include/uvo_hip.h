@@ -82,12 +82,16 @@ uvo_status  uvo_ctx_set_producer_stream(uvo_ctx* c, void* hip_stream, int enable
 /* Non-fatal advice about the process environment noticed at context creation ("" when there is none), e.g. a pipeline
  * deeper than two lanes with GPU_MAX_HW_QUEUES left at the ROCm default of 4 (lanes then share hardware queues). */
 const char* uvo_ctx_warning(const uvo_ctx* c);
+/* Entries submitted (uvo_stereo_submit / uvo_mono_submit, init pairs included) and not yet collected.  A collect that fails
+ * with "nothing submitted" or "wrong kind" leaves it unchanged; every other collect, successful or not, dequeues one. */
+int         uvo_ctx_pending(const uvo_ctx* c);
 
 /* ---- detect_features, SURF branch (VO_utility.h:100 -> VO_utility.cpp:114-119) ----
  * gray: 8-bit single channel, `stride` bytes per row.  kps/desc are host buffers of capacity `cap`, either may be NULL;
  * desc is n x 64 f32, or n x 128 when the context's SURF_EXTENDED is set.  SURF_UPRIGHT = 0 runs the orientation assignment
  * and samples the descriptor window rotated (keypoint.angle = the orientation, 270 when upright).  Overwrites outputs (as
- * detectAndCompute does).  The matcher and the stereo / mono steps work on 64-element rows: they refuse SURF_EXTENDED. */
+ * detectAndCompute does).  The matcher, the gathers and the stereo / mono steps take the row width from the context's
+ * SURF_EXTENDED (64 or 128 floats) end to end. */
 uvo_status uvo_surf_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem,
                            uvo_keypoint* kps, float* desc, int cap, int* n);
 /* test hooks into the detector's first stages (host outputs): integral image (h+1)x(w+1) s32 of the
@@ -103,6 +107,12 @@ uvo_status uvo_match_knn2_ratio(uvo_ctx* c, const float* d1, int n1, const float
 /* raw 2-NN (host outputs idx[2*n1], dist[2*n1]; idx = -1 when the train set is too small) */
 uvo_status uvo_match_knn2(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int mem,
                           int* idx, float* dist);
+/* The same two operators on rows of `dim` floats (64 or 128) whatever the context's SURF_EXTENDED says: match_features sends
+ * FEATURE_DETECTOR == "SIFT" descriptors (128 floats per row) to the same BFMatcher(NORM_L2) (VO_utility.cpp:525-529). */
+uvo_status uvo_match_knn2_ratio_dim(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int dim, int mem,
+                                    float ratio, uvo_dmatch* out, int cap, int* m);
+uvo_status uvo_match_knn2_dim(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int dim, int mem,
+                              int* idx, float* dist);
 
 /* The AKAZE / ORB branch of the same function (VO_utility.cpp:520-524): BFMatcher(NORM_HAMMING).knnMatch k=2 + Lowe ratio on binary
  * descriptors of `bytes` bytes per row (1..64: ORB 32, AKAZE 61), u8, `mem`.  DMatch::distance = the number of differing bits.

@@ -96,12 +96,14 @@ typedef uint32_t wi;
 
 static uint8_t range_limit(int32_t x)
 {
-    /* range_limit[x & RANGE_MASK] with the table centred on 128: clamp(x + 128, 0, 255) for every |x| < 512; beyond that the
-     * table wraps (jdmaster.c prepare_range_limit_table) */
-    x = (x + 128) & 1023;
-    if (x < 256) return (uint8_t)x;
-    if (x < 512) return 255;                                 /* 256 .. 511: saturated high */
-    return 0;                                                /* 512 .. 1023: the negative half, saturated low */
+    /* IDCT_range_limit[x & RANGE_MASK] as jdmaster.c prepare_range_limit_table lays the post-IDCT table out (RANGE_MASK = 1023,
+     * the table is centred on 128): v = x & 1023:  [0, 128) -> v + 128;  [128, 512) -> 255;  [512, 896) -> 0;  [896, 1024) ->
+     * v - 896.  Equal to clamp(x + 128, 0, 255) for -512 <= x < 512; beyond that it wraps, which only damaged streams reach. */
+    const int32_t v = x & 1023;
+    if (v < 128) return (uint8_t)(v + 128);
+    if (v < 512) return 255;
+    if (v < 896) return 0;
+    return (uint8_t)(v - 896);
 }
 
 void orc_jpeg_idct_islow(const int16_t* coef /* natural order */, const uint16_t* quant /* natural order */, uint8_t* out, int stride)

@@ -2,6 +2,7 @@
 // function surface: FEATURE_DETECTOR = "ORB", CV_8U descriptor matrices, results appended to `matches`.
 //   usage: shim_match_binary <input.bin> <output.bin>
 //   input : int32 n1, n2, bytes; f32 ratio; n1 x bytes u8; n2 x bytes u8
+//           bytes < 0: the "SIFT" arm of the L2 branch instead (VO_utility.cpp:525-529): FEATURE_DETECTOR = "SIFT", rows of -bytes f32
 //   output: int32 m; m x (queryIdx, trainIdx i32, distance f32)
 #include <cstdio>
 #include <vector>
@@ -15,12 +16,15 @@ int main(int argc, char** argv)
     if (!f) return 2;
     int hdr[3]; float ratio;
     if (fread(hdr, sizeof(int), 3, f) != 3 || fread(&ratio, sizeof(float), 1, f) != 1) return 2;
-    const int n1 = hdr[0], n2 = hdr[1], nb = hdr[2];
-    Mat d1(n1, nb, CV_8UC1), d2(n2, nb, CV_8UC1);
-    for (int i = 0; i < n1; i++) if (fread(d1.ptr<unsigned char>(i), 1, (size_t)nb, f) != (size_t)nb) return 2;
-    for (int i = 0; i < n2; i++) if (fread(d2.ptr<unsigned char>(i), 1, (size_t)nb, f) != (size_t)nb) return 2;
+    const int n1 = hdr[0], n2 = hdr[1];
+    const bool sift = hdr[2] < 0;
+    const int nb = sift ? -hdr[2] : hdr[2];
+    Mat d1(n1, nb, sift ? CV_32FC1 : CV_8UC1), d2(n2, nb, sift ? CV_32FC1 : CV_8UC1);
+    const size_t rowb = (size_t)nb * (sift ? sizeof(float) : 1);
+    for (int i = 0; i < n1; i++) if (fread(d1.ptr<unsigned char>(i), 1, rowb, f) != rowb) return 2;
+    for (int i = 0; i < n2; i++) if (fread(d2.ptr<unsigned char>(i), 1, rowb, f) != rowb) return 2;
     fclose(f);
-    FEATURE_DETECTOR = "ORB";
+    FEATURE_DETECTOR = sift ? "SIFT" : "ORB";
     LOWE_RATIO_THRESHOLD = ratio;
     try {
         std::vector<KeyPoint> k1((size_t)n1), k2((size_t)n2);

@@ -20,6 +20,50 @@ def picture(rng, h, w, c):
     return np.clip(a, 0, 255).astype(np.uint8)
 
 
+def inflate_quant(data: bytes, factor: int) -> bytes:
+    """The same entropy-coded data with every 8-bit quantisation step multiplied by `factor` (capped at 255): the dequantised
+    coefficients overshoot, so the IDCT output leaves [-128, 383] and libjpeg's post-IDCT range_limit table is read in its
+    saturated and wrapped parts (jdmaster.c prepare_range_limit_table) -- what a damaged or hostile stream does."""
+    b = bytearray(data)
+    i = 2
+    while i + 4 <= len(b) and b[i] == 0xFF:
+        m, ln = b[i + 1], (b[i + 2] << 8) | b[i + 3]
+        if m == 0xDB:
+            j = i + 4
+            while j < i + 2 + ln:
+                assert b[j] >> 4 == 0, "8-bit tables only"
+                for k in range(j + 1, j + 65):
+                    b[k] = min(255, b[k] * factor)
+                j += 65
+        if m == 0xDA:
+            break
+        i += 2 + ln
+    return bytes(b)
+
+
+def decode_scalar(data: bytes):
+    """libjpeg-turbo's decode with its SIMD extensions off (JSIMD_FORCENONE=1, read when the library initialises, hence a child
+    process): jidctint.c + the range_limit table, the algorithm the oracle and the HIP kernel restate.  On in-range streams the
+    SIMD IDCT gives the same bytes (the ten ordinary cases above are decoded with SIMD on); on these overshooting streams it
+    does not -- it dequantises with 16-bit wrap-around and saturates instead of reading the table -- so "what libjpeg decodes"
+    from a hostile stream depends on the CPU it runs on, and the scalar path is the one pinned here."""
+    import subprocess
+    import sys
+    code = ("import io,sys,numpy as np\nfrom PIL import Image\n"
+            "a=np.asarray(Image.open(io.BytesIO(sys.stdin.buffer.read())))\n"
+            "sys.stdout.buffer.write(np.array(a.shape+(0,)*(3-a.ndim),np.int32).tobytes()+a.tobytes())")
+    r = subprocess.run([sys.executable, "-c", code], input=data, stdout=subprocess.PIPE, check=True, env=dict(os.environ, JSIMD_FORCENONE="1"))
+    shp = [int(v) for v in np.frombuffer(r.stdout[:12], np.int32) if v]
+    return np.frombuffer(r.stdout[12:], np.uint8).reshape(shp).copy()
+
+
+def harsh_picture(rng, h, w, c):
+    a = rng.integers(0, 2, (h // 4 + 1, w // 4 + 1, c)) * 255
+    a = np.kron(a, np.ones((4, 4, 1)))[:h, :w]
+    a = a + rng.normal(size=(h, w, c)) * 30
+    return np.clip(a, 0, 255).astype(np.uint8)
+
+
 def main():
     assert features.check("libjpeg_turbo"), "Pillow without libjpeg-turbo"
     rng = np.random.default_rng(20250911)
@@ -37,6 +81,17 @@ def main():
         dec = np.asarray(Image.open(io.BytesIO(data)))
         out[name + "_jpeg"] = np.frombuffer(data, np.uint8)
         out[name + "_rgb"] = dec                      # RGB order (cv::imdecode returns the same bytes as BGR)
+    # streams whose IDCT output overshoots far beyond a sample's range (v in [384, 511] must read 255, not 0)
+    sat = [("sat_c420_x6", 40, 56, 3, dict(quality=50, subsampling=2), 6), ("sat_c444_x12", 24, 24, 3, dict(quality=60, subsampling=0), 12),
+           ("sat_grey_x9", 32, 40, 1, dict(quality=40), 9), ("sat_c422_x255", 16, 32, 3, dict(quality=90, subsampling=1), 255)]
+    for name, h, w, c, kw, factor in sat:
+        img = harsh_picture(rng, h, w, c)
+        b = io.BytesIO()
+        Image.fromarray(img[..., 0] if c == 1 else img).save(b, "JPEG", **kw)
+        data = inflate_quant(b.getvalue(), factor)
+        out[name + "_jpeg"] = np.frombuffer(data, np.uint8)
+        out[name + "_rgb"] = decode_scalar(data)
+    out["names"] = np.array([c[0] for c in cases] + [c[0] for c in sat])
     np.savez(os.path.join(HERE, "jpeg_cases.npz"), **out)
     print("wrote jpeg_cases.npz:", sum(v.nbytes for v in out.values() if hasattr(v, "nbytes")), "bytes")
 

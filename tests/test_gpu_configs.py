@@ -165,8 +165,10 @@ def _run_mono_config(oracle, seed, W, H, params_kw, oparams, ks, depth=6):
 
 
 def test_c4_mono_1080p_ransac_e_and_h_parity(oracle):
-    """BASELINE configs[3]: RANSAC for both estimators; two-step frames take the essential branch, quarter-step frames the
-    homography branch (select_estimation_method, VOU:725-748)."""
+    """BASELINE configs[3], the 1.0-px VARIANT (thresholds 1.0 / 1.0 / 3.0 instead of the shipped 0.1 / 0.1 / 0.1, so that the
+    homography branch produces valid poses on this synthetic scene): RANSAC for both estimators; two-step frames take the
+    essential branch, quarter-step frames the homography branch (select_estimation_method, VOU:725-748).  The contract's own
+    thresholds are test_c4_mono_1080p_contract_thresholds_parity below."""
     from ergo_uvo_amd import synth
     kw = dict(SURF_MIN_HESSIAN=6456, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8, ESSENTIAL_THRESHOLD=1.0,
               HOMOGRAPHY_THRESHOLD=1.0, REPROJECTION_TOLERANCE=3.0)
@@ -181,6 +183,29 @@ def test_c4_mono_1080p_ransac_e_and_h_parity(oracle):
     assert sum(r.used_essential for r in pub) >= 4 and sum(1 - r.used_essential for r in pub) >= 3       # both branches scored
 
 
+def test_c4_mono_1080p_contract_thresholds_parity(oracle):
+    """BASELINE configs[3] at the contract's parameters ("the mono column but with methods = 8"):
+    essential_threshold 0.1, homography_threshold 0.1, reprojection_tolerance 0.1 (uvo/config/mono_VO_parameters.yaml:21, 26,
+    30), RANSAC for both estimators.  At 0.1 px the adaptive iteration count stays in the hundreds to thousands, so the
+    five-point and the DLT kernels run whole rounds of hypotheses.  On this synthetic scene the two-step frames (parallax) are
+    solved by the essential branch; the quarter-step frames start on the homography branch (median displacement < DISTANCE),
+    fail VO_utility.cpp:164's inlier-fraction gate, switch to the essential matrix and fail it too after recoverPose's
+    cheirality filter -- "BOTH METHODS FAILED", success = 0, the node keeps its previous motion: there both RANSACs are run and
+    scored on the same frame, and what is compared is the masks and the gate ladder."""
+    from ergo_uvo_amd import synth
+    kw = dict(SURF_MIN_HESSIAN=6456, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8)
+    op = oracle.mono_params(6456, method=8)
+    for f, v in (("ESSENTIAL_THRESHOLD", 0.1), ("HOMOGRAPHY_THRESHOLD", 0.1), ("REPROJECTION_TOLERANCE", 0.1)):
+        assert getattr(op, f) == v                                      # the shipped values
+    ks = [-2, 0, 2, 0, 0.25, 0.5, 0.25, 2, 4]
+    want = _run_mono_config(oracle, synth.SEEDS["C4"], 1920, 1080, kw, op, ks)
+    res = [w[0] for w in want]
+    pub = [r for r in res if r.published]
+    assert len(pub) == len(ks) - 1
+    assert sum(r.valid for r in pub) >= 5 and sum(1 - r.success for r in pub) >= 3      # parallax frames solved; quarter-step frames: both methods scored, both gated out
+    assert all(r.n_inliers >= 1000 for r in pub)
+
+
 def test_c1_substitute_mono_640x480_shipped_lmeds_parity(oracle):
     """BASELINE configs[0] cannot be run (bag and OpenCV absent); its substitute: 640x480, the shipped mono parameters."""
     from ergo_uvo_amd import synth
@@ -191,12 +216,9 @@ def test_c1_substitute_mono_640x480_shipped_lmeds_parity(oracle):
     assert any(r.used_essential for r in pub) and any(not r.used_essential for r in pub)
 
 
-def test_c5_self_launched_two_ranks_match_single_gpu_streams(tmp_path):
-    """BASELINE configs[4] rehearsed on the one device of the GPU box: `python bench.py --gpus 2` starts its two ranks itself
-    (no torchrun); both ranks share device 0 and gather over gloo (RCCL refuses two ranks on one device), everything else --
-    one independent stream per rank, seed 20250910 + rank, one gather of the pose records at the end of the timed region -- is
-    the path the 8-GPU run takes.  The gathered record of rank r must equal the single-GPU result of stream r bit for bit
-    (SURVEY 8(e))."""
+def _bench_ranks_vs_single_gpu_streams(tmp_path, n, extra, base_seed_key):
+    """Runs `python bench.py --gpus n ...` as a child (bench.py starts its own ranks; none of them execs) and checks the gathered
+    record of rank r against the synchronous single-GPU result of stream r, bit for bit.  Returns the JSON line."""
     import json
     import os
     import subprocess
@@ -208,28 +230,57 @@ def test_c5_self_launched_two_ranks_match_single_gpu_streams(tmp_path):
     import bench
     steps, warm, frames = 6, 3, 2
     rec_path = str(tmp_path / "records.npy")
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-devices", "--steps", str(steps),
-                        "--warmup", str(warm), "--frames", str(frames), "--no-cpu-baseline", "--dump-records", rec_path],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "UVO_RDZV_FILE")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", str(steps), "--warmup", str(warm),
+                        "--frames", str(frames), "--no-cpu-baseline", "--dump-records", rec_path] + extra,
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1100)
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["config"]["valid_steps"] == steps
+    assert line["n_gpus"] == n and line["scaling"] == "weak" and line["config"]["valid_steps"] == steps
     rec = np.load(rec_path)
-    assert rec.shape == (2, steps, multirank.RECORD_WIDTH)
+    assert rec.shape == (n, steps, multirank.RECORD_WIDTH)
     W, H = bench.WIDTH, bench.HEIGHT
     rig = synth.stereo_rig(W)
-    for r in range(2):
-        scene = synth.Scene(multirank.stream_seed(synth.SEEDS["C5"], r), W)
-        pairs = [synth.stereo_pair(scene, k, W, H) for k in range(frames)]
-        ctx = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=bench.MIN_HESSIAN_C3), 0, W, H, 8192)
-        try:
+    ctx = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=bench.MIN_HESSIAN_C3), 0, W, H, 8192)
+    try:
+        for r in range(n):
+            seed = synth.SEEDS[base_seed_key] if base_seed_key == "C3" else multirank.stream_seed(synth.SEEDS["C5"], r)
+            scene = synth.Scene(seed, W)
+            pairs = [synth.stereo_pair(scene, k, W, H) for k in range(frames)]
             ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
             order = bench.ping_pong(frames)
             want = np.zeros((warm + steps, multirank.RECORD_WIDTH))
             for i in range(warm + steps):
                 multirank.fill_record(want, i, r, i - warm, ctx.stereo_step(*pairs[next(order)], 0.05))
-        finally:
-            ctx.close()
-        assert np.array_equal(rec[r].view(np.uint64), want[warm:].view(np.uint64)), r
-    assert not np.array_equal(rec[0, :, 7:10], rec[1, :, 7:10])          # different streams
+            assert np.array_equal(rec[r].view(np.uint64), want[warm:].view(np.uint64)), r
+    finally:
+        ctx.close()
+    if n > 1:
+        assert not np.array_equal(rec[0, :, 7:10], rec[1, :, 7:10])          # different streams
+    return line
+
+
+def test_c5_self_launched_two_ranks_match_single_gpu_streams(tmp_path):
+    """BASELINE configs[4] rehearsed on the one device of the GPU box: `python bench.py --gpus 2` starts its two ranks itself
+    (no torchrun); both ranks share device 0 and gather over gloo (RCCL refuses two ranks on one device), everything else --
+    one independent stream per rank, seed 20250910 + rank, one gather of the pose records at the end of the timed region -- is
+    the path the 8-GPU run takes."""
+    line = _bench_ranks_vs_single_gpu_streams(tmp_path, 2, ["--backend", "gloo", "--share-devices"], "C5")
+    assert line["host"]["collectives"].startswith("gloo") and line["host"]["pinned"]
+
+
+def test_c5_one_rank_rccl_communicator_runs_the_collectives(tmp_path):
+    """The RCCL leg of configs[4] on the one GPU there is: `--gpus 1 --backend nccl --force-dist` builds a communicator of one
+    rank on the device and runs the very calls of the N-rank path -- all_gather_into_tensor of the device-resident pose
+    records, all_reduce(MAX) of the time, the barriers -- so the 8-GPU run is not the first time they execute.  The gathered
+    record must be the local one bit for bit (bench.py asserts it too) and equal to the synchronous single-GPU run."""
+    line = _bench_ranks_vs_single_gpu_streams(tmp_path, 1, ["--backend", "nccl", "--force-dist"], "C3")
+    assert line["host"]["collectives"].startswith("nccl") and "1 rank" in line["host"]["collectives"]
+
+
+def test_c5_five_ranks_on_one_device_match_single_gpu_streams(tmp_path):
+    """As many ranks as the GPU box allows next to this process (its guard admits six GPU processes): five self-launched ranks,
+    seeds 20250910..14, depth 2, share device 0 over gloo; each gathered stream must equal its single-GPU run.  (The eight-rank
+    form of the same path runs on CPU in tests/test_multirank.py.)"""
+    line = _bench_ranks_vs_single_gpu_streams(tmp_path, 5, ["--backend", "gloo", "--share-devices", "--depth", "2"], "C5")
+    assert line["host"]["cores_of_this_rank"] >= 1

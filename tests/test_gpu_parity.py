@@ -841,3 +841,32 @@ def test_hamming_branch_of_match_features_bit_exact(ctx, oracle, bytes_):
             m, om = ctx.match_features_hamming(a, b, ratio), oracle.match_hamming(a, b, ratio)
             assert np.array_equal(m["queryIdx"], om["queryIdx"]) and np.array_equal(m["trainIdx"], om["trainIdx"])
             assert np.array_equal(m["distance"].view(np.uint32), om["distance"].view(np.uint32))
+
+
+def test_sift_arm_of_the_l2_branch_bit_exact(ctx, oracle):
+    """VO_utility.cpp:525-529: "SIFT" descriptors go to the same BFMatcher(NORM_L2) as SURF's; they are 128 floats per row whatever
+    SURF_EXTENDED says (this context's own rows are 64 wide).  SIFT rows are small non-negative integers stored as floats, so equal
+    distances -- ties -- are common: the order of insertion (lower train index first) is what is compared, and the distances bitwise."""
+    rng = np.random.default_rng(128)
+
+    def rows(n, base=None):
+        a = np.abs(rng.normal(size=(n, 128))) ** 2 if base is None else np.clip(base + rng.normal(size=base.shape) * 5.0, 0, None)
+        a = a / np.maximum(np.linalg.norm(a, axis=1, keepdims=True), 1e-9) * 512.0
+        return np.clip(np.rint(a), 0, 255).astype(np.float32)
+
+    for n1, n2 in ((1200, 1500), (1, 2), (130, 129), (3000, 2950)):
+        b = rows(n2)
+        a = rows(n1)
+        if n2 > 600:
+            a[:400] = rows(400, base=b[100:500].astype(np.float64))
+            b[520:530] = b[100:110]                     # duplicated train rows across a 128-row chunk boundary
+        idx, dist = ctx.knn_match(a, b, dim=128)
+        oidx, odist = oracle.knn2(a, b)
+        assert np.array_equal(idx, oidx), (n1, n2)
+        assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32))
+        for ratio in (0.7, 0.8):
+            m, om = ctx.match_features(a, b, ratio, dim=128), oracle.match(a, b, ratio)
+            assert np.array_equal(m["queryIdx"], om["queryIdx"]) and np.array_equal(m["trainIdx"], om["trainIdx"])
+            assert np.array_equal(m["distance"].view(np.uint32), om["distance"].view(np.uint32))
+    with pytest.raises(Exception):
+        ctx.knn_match(np.zeros((4, 96), np.float32), np.zeros((4, 96), np.float32), dim=96)

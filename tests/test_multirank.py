@@ -1,10 +1,13 @@
-"""N > 1 path on CPU: two gloo ranks, one independent stereo stream each (driven here by the CPU oracle,
+"""N > 1 path on CPU: two and eight gloo ranks, one independent stereo stream each (driven here by the CPU oracle,
 since the HIP path needs a GPU); the gathered record of rank r must equal the single-process result of
-stream r bit for bit, and the max-over-ranks timing reduction must work."""
+stream r bit for bit, and the max-over-ranks timing reduction must work.  Also: a forced process group of ONE
+rank runs the same collectives (what `bench.py --gpus 1 --force-dist` does over RCCL), ranks rendezvous through a
+file store, and the per-rank core slices are disjoint."""
 import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -34,41 +37,54 @@ def _worker(rank, world, port, q):
         raise
 
 
-def _worker_body(rank, world, port, q):
-    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker_body(rank, world, rdzv, q):
+    # rendezvous the way bench.py's own launcher does it: a file store, no port to guess
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), UVO_RDZV_FILE=rdzv)
+    for k in ("MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
     sys.path.insert(0, ROOT)
     from ergo_uvo_amd import multirank
-    r, w = multirank.init("gloo")
+    cores = multirank.pin_rank_to_cores(rank, world)
+    r, w = multirank.init("gloo", force=True)
     assert (r, w) == (rank, world)
     recs = _run_stream(rank)
     multirank.barrier()
     allrec = multirank.gather_records(recs)
     tmax = multirank.max_over_ranks(1.0 + rank)
-    q.put((rank, allrec.numpy().copy(), tmax))
+    who = multirank.gather_ints([rank, os.getpid()] + [len(cores), cores[0] if cores else -1])
+    q.put((rank, allrec.numpy().copy(), tmax, who.numpy().copy()))
     multirank.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_gloo_gather_matches_single_process():
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_gloo_ranks_gather_matches_single_process(world, tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 400)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    rdzv = str(tmp_path / "store")
+    procs = [ctx.Process(target=_worker, args=(r, world, rdzv, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
-    for _ in range(2):
-        rank, allrec, tmax = q.get(timeout=240)
+    for _ in range(world):
+        rank, allrec, tmax, who = q.get(timeout=600)
         assert not isinstance(allrec, str), allrec
-        got[rank] = (allrec, tmax)
+        got[rank] = (allrec, tmax, who)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    want = np.stack([_run_stream(s).numpy() for s in range(2)])
-    for rank in range(2):
-        allrec, tmax = got[rank]
-        assert allrec.shape == (2, STEPS, 16)
+    want = np.stack([_run_stream(s).numpy() for s in range(world)])
+    ncores = len(os.sched_getaffinity(0))
+    for rank in range(world):
+        allrec, tmax, who = got[rank]
+        assert allrec.shape == (world, STEPS, 16)
         assert np.array_equal(allrec.view(np.uint64), want.view(np.uint64))       # stream i == single-process stream i, bitwise
-        assert tmax == 2.0                                                        # MAX over ranks
-    assert want[0, 1, 2] == 1 and want[1, 1, 2] == 1                              # both streams track after the init pair
-    assert not np.array_equal(want[0, 1, 7:10], want[1, 1, 7:10])                 # and they are different streams
+        assert tmax == float(world)                                               # MAX over ranks
+        assert who[:, 0].tolist() == list(range(world)) and len(set(who[:, 1].tolist())) == world     # N distinct ranks, N processes
+        if world > 1 and ncores >= world:                                         # disjoint, equal core slices
+            k = ncores // world
+            assert who[:, 2].tolist() == [k] * world and len(set(who[:, 3].tolist())) == world
+    assert want[0, 1, 2] == 1                                                     # the streams track after the init pair
+    if world > 1:
+        assert want[1, 1, 2] == 1
+        assert not np.array_equal(want[0, 1, 7:10], want[1, 1, 7:10])             # and they are different streams

@@ -197,3 +197,36 @@ def test_shim_match_features_hamming_branch(oracle, tmp_path):
     om = oracle.match_hamming(a, b, ratio)
     assert m == len(om) >= 200
     assert np.array_equal(rec["q"], om["queryIdx"]) and np.array_equal(rec["t"], om["trainIdx"]) and np.array_equal(rec["d"], om["distance"])
+
+
+def sift_like_rows(rng, n, base=None, noise=6.0):
+    """Rows shaped like cv::SIFT's CV_32F output: 128 non-negative integers (0..255) of norm ~512, stored as floats."""
+    a = np.abs(rng.normal(size=(n, 128))) ** 2 if base is None else base + rng.normal(size=base.shape) * noise
+    a = np.clip(a, 0, None)
+    a = a / np.linalg.norm(a, axis=1, keepdims=True) * 512.0
+    return np.clip(np.rint(a), 0, 255).astype(np.float32)
+
+
+@pytest.mark.gpu
+def test_shim_match_features_sift_arm_of_the_l2_branch(tmp_path, oracle):
+    """VO_utility.cpp:525-529: FEATURE_DETECTOR == "SIFT" shares BFMatcher(NORM_L2) with "SURF"; the rows are 128 floats whatever
+    SURF_EXTENDED says (here it is false, so the context's own rows are 64 wide)."""
+    import struct
+    import subprocess
+    rng = np.random.default_rng(77)
+    n1, n2, ratio = 1500, 1700, 0.8
+    b = sift_like_rows(rng, n2)
+    a = sift_like_rows(rng, n1)
+    a[:900] = sift_like_rows(rng, 900, base=b[200:1100].astype(np.float64))       # noisy copies: clear winners
+    b[1500:1540] = b[300:340]                                                      # duplicated train rows: ties fail the ratio test
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    inp.write_bytes(struct.pack("<iiif", n1, n2, -128, ratio) + a.tobytes() + b.tobytes())
+    res = subprocess.run([os.path.join(ROOT, "tests", "cpp", "build", "shim_match_binary"), str(inp), str(outp)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    raw = outp.read_bytes()
+    m = struct.unpack("<i", raw[:4])[0]
+    rec = np.frombuffer(raw[4:], np.dtype([("q", "<i4"), ("t", "<i4"), ("d", "<f4")]))
+    om = oracle.match(a, b, ratio)
+    assert m == len(om) >= 800
+    assert np.array_equal(rec["q"], om["queryIdx"]) and np.array_equal(rec["t"], om["trainIdx"])
+    assert np.array_equal(rec["d"].view(np.uint32), om["distance"].view(np.uint32))

@@ -86,40 +86,47 @@ def main():
     order = list(range(len(ks)))
     R0, C0 = synth.camera_pose(0)
     rng = scene.depth_at_center(C0, R0)
-    p = uvo.Params.mono(SURF_MIN_HESSIAN=6456, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8,
-                        ESSENTIAL_THRESHOLD=1.0, HOMOGRAPHY_THRESHOLD=1.0, REPROJECTION_TOLERANCE=3.0)
-    ctx = uvo.Context(p, 0, W, H, 8192)
-    ctx.mono_set_camera(rig.K_left)
-    for i in range(8):
-        r = ctx.mono_step(dmono[order[i % len(order)]], rng, 0.2)
-    steps = 96
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    nv = ne = 0
-    for i in range(steps):
-        r = ctx.mono_step(dmono[order[i % len(order)]], rng, 0.2)
-        nv += r.valid; ne += r.used_essential
-    out["C4_mono_1920x1080_ransac"] = {"kpts": r.n_kps, "matches": r.n_matches, "valid": nv, "essential_used": ne,
-                                       "frames_per_s": round(steps / (time.perf_counter() - t0), 1)}
-    # the same frames through uvo_mono_submit / uvo_mono_collect, fourteen in flight (the mono pose stage is long and thin)
-    ctx.mono_reset()
-    depth = 14
-    ctx.stereo_set_depth(depth)
-    steps = 600
-    sub = 0
-    for i in range(24):
-        while sub < 24 and sub - i < depth:
-            ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
-        r = ctx.mono_collect(0.2)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    nv = 0
-    sub = 0
-    for i in range(steps):
-        while sub < steps and sub - i < depth:
-            ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
-        nv += ctx.mono_collect(0.2).valid
-    out["C4_mono_1920x1080_ransac"].update({"frames_per_s_pipelined": round(steps / (time.perf_counter() - t0), 1), "valid_pipelined": nv,
-                                            "pipelined_steps": steps})
-    ctx.close()
+    def run_c4(p, key, note):
+        ctx = uvo.Context(p, 0, W, H, 8192)
+        ctx.mono_set_camera(rig.K_left)
+        for i in range(8):
+            r = ctx.mono_step(dmono[order[i % len(order)]], rng, 0.2)
+        steps = 96
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        nv = ne = ns = 0
+        for i in range(steps):
+            r = ctx.mono_step(dmono[order[i % len(order)]], rng, 0.2)
+            nv += r.valid; ne += r.used_essential; ns += r.success
+        out[key] = {"note": note, "kpts": r.n_kps, "matches": r.n_matches, "valid": nv, "success": ns, "essential_used": ne,
+                    "frames_per_s": round(steps / (time.perf_counter() - t0), 1)}
+        # per-stage time of the pose kernels when whole rounds of hypotheses run (HIP events; synchronous frames)
+        # the same frames through uvo_mono_submit / uvo_mono_collect, fourteen in flight (the mono pose stage is long and thin)
+        ctx.mono_reset()
+        depth = 14
+        ctx.stereo_set_depth(depth)
+        steps = 600
+        sub = 0
+        for i in range(24):
+            while sub < 24 and sub - i < depth:
+                ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
+            r = ctx.mono_collect(0.2)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        nv = 0
+        sub = 0
+        for i in range(steps):
+            while sub < steps and sub - i < depth:
+                ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
+            nv += ctx.mono_collect(0.2).valid
+        out[key].update({"frames_per_s_pipelined": round(steps / (time.perf_counter() - t0), 1), "valid_pipelined": nv, "pipelined_steps": steps})
+        ctx.close()
+
+    # the contract's parameters (the shipped mono column with methods = 8): 0.1 / 0.1 / 0.1 px
+    run_c4(uvo.Params.mono(SURF_MIN_HESSIAN=6456, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8), "C4_mono_1920x1080_ransac",
+           "contract thresholds: essential 0.1, homography 0.1, reprojection 0.1 (mono_VO_parameters.yaml:21,26,30); quarter-step frames run both RANSACs and fail the gates (success 0)")
+    # the 1.0-px variant of rounds 1-2 (adaptive RANSAC stops after its first round; homography branch yields valid poses)
+    run_c4(uvo.Params.mono(SURF_MIN_HESSIAN=6456, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8,
+                           ESSENTIAL_THRESHOLD=1.0, HOMOGRAPHY_THRESHOLD=1.0, REPROJECTION_TOLERANCE=3.0), "C4_variant_1px_mono_1920x1080_ransac",
+           "NOT the contract's thresholds: 1.0 / 1.0 / 3.0 px")
     # ---------------- C1 substitute: 640x480 mono, the shipped parameters (LMedS for E and H, min_hessian 50) ----------------
     W1, H1 = 640, 480
     scene = synth.Scene(synth.SEEDS["C1"], W1)
