@@ -1362,6 +1362,171 @@ __global__ __launch_bounds__(256) void k_descriptor_rot(DescArgs a, int w, int h
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The horizontal pass of resizeArea_ for ONE destination column of ONE window, by one wave (round 3).
+//   buf[i] = sum over the column's taps c of WIN[i][c] * alpha_c,  WIN[i][c] = img(clamp(start_y - c), clamp(start_x + i)),
+// accumulated in OpenCV's tap order.  Everything about the task is the same for every lane, so it lives in scalar registers:
+// the image is read through a buffer resource whose row offset is the SGPR `soffset` of the load (no per-tap address VALU, no
+// 64-bit adds: sub, max, min, mul on the scalar unit), the first and the last tap are peeled (their weights differ), the middle
+// taps all carry a_mid and run in batches of eight loads in flight, and the tail of the last batch is branched over rather than
+// loaded and masked.  Round 2's loop spent 16.7 VALU and 22 SALU instructions per useful tap (address add, two scalar selects
+// per tap for the weight, sixteen loads per batch whatever the tap count): the scalar unit -- one per CU -- was 73 % busy.
+// A lane owns PX adjacent pixels of each of Q chunks of 64 * PX columns: PX = 4 (aligned dword loads; Q = 1..3 covers the 739-pixel
+// windows), PX = 2 and PX = 1 for windows up to 127 / 64 pixels so that small windows do not idle three quarters of the lanes.
+// ------------------------------------------------------------------------------------------
+static const int kTapBatch = 16;           // image rows a lane of descriptor64_big has in flight
+static const int kPatchStride = 448;       // bytes of patch scratch per keypoint (441 used)
+__device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a < b ? x : y on scalar registers (the compiler turns the C expression into VALU selects on copies of the operands)
+__device__ __forceinline__ int ssel_lt(int a, int b, int x, int y)
+{
+    int r;
+    asm volatile("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(r) : "s"(a), "s"(b), "s"(x), "s"(y) : "scc");
+    return r;
+}
+__device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+typedef __amdgpu_buffer_rsrc_t ImgRsrc;
+__device__ __forceinline__ ImgRsrc img_rsrc(const uint8_t* img, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, bytes, 0x00020000);      // raw buffer, dword data format (gfx9 family)
+}
+struct ColTask { int y0, n, h1, w; float a_first, a_mid, a_last; };      // tap t reads row clamp(y0 - t, 0, h1); n >= 1 taps
+
+template <int PX> __device__ __forceinline__ unsigned px_load(ImgRsrc rs, int voff, int soff);
+template <> __device__ __forceinline__ unsigned px_load<1>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b8(rs, voff, soff, 0); }
+template <> __device__ __forceinline__ unsigned px_load<2>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0); }
+template <> __device__ __forceinline__ unsigned px_load<4>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0); }
+
+template <int PX, int Q>
+struct AreaCol {
+    ImgRsrc rs; int w, h1;
+    int x[Q], voff[Q];
+    float acc[Q][PX];
+    // The window's in-image columns are [xlo, xhi) = [max(start_x, 0), min(start_x + win, w)); lane l owns the pixels
+    // xa + PX * (l + 64 q) .., xa = xlo rounded down to PX
+    __device__ __forceinline__ AreaCol(ImgRsrc rs_, int w_, int h_, int lane, int xa) : rs(rs_), w(w_), h1(h_ - 1)
+    {
+#pragma unroll
+        for (int q = 0; q < Q; q++) { x[q] = xa + PX * (lane + 64 * q); voff[q] = x[q] < w - PX ? x[q] : w - PX; }      // loads stay inside the row whatever the lane
+    }
+    __device__ __forceinline__ void load(const ColTask& t, int tap, unsigned (&v)[Q]) const
+    {
+        int y = t.y0 - tap; y = y > 0 ? y : 0; y = y < h1 ? y : h1;
+        const int soff = y * w;
+#pragma unroll
+        for (int q = 0; q < Q; q++) v[q] = px_load<PX>(rs, voff[q], soff);
+    }
+    __device__ __forceinline__ void first(const unsigned (&v)[Q], float alpha)      // 0.f + v * a == v * a
+    {
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+#pragma unroll
+            for (int p = 0; p < PX; p++) acc[q][p] = (float)(int)((v[q] >> (8 * p)) & 255u) * alpha;
+    }
+    __device__ __forceinline__ void accum(const unsigned (&v)[Q], float alpha)
+    {
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+#pragma unroll
+            for (int p = 0; p < PX; p++) acc[q][p] += (float)(int)((v[q] >> (8 * p)) & 255u) * alpha;
+    }
+    // exactly N taps, everything static: N loads go out, then N sums (Q = 1: the columns of windows up to ~250 pixels)
+    template <int N> __device__ __forceinline__ void taps_static(const ColTask& t)
+    {
+        unsigned v[N][Q];
+#pragma unroll
+        for (int i = 0; i < N; i++) load(t, i, v[i]);
+        first(v[0], t.a_first);
+#pragma unroll
+        for (int i = 1; i < N - 1; i++) accum(v[i], t.a_mid);
+        if (N > 1) accum(v[N - 1], t.a_last);
+    }
+    // any tap count: first and last tap peeled, the middle taps in batches of B loads per chunk; a batch is always loaded whole
+    // (a tap index past the column reads the last tap's row again -- it is in flight already) and a tap past the column
+    // gets weight +0, which leaves the non-negative sums unchanged: no branch, no conditionally defined register
+    __device__ __forceinline__ void taps_any(const ColTask& t)
+    {
+        constexpr int B = Q == 1 ? 8 : (Q == 2 ? 7 : 4);
+        const int last = t.n - 1;
+        unsigned v0[Q], vl[Q], v[B][Q];
+        load(t, 0, v0);
+        load(t, last > 0 ? last : 0, vl);
+        first(v0, t.n > 0 ? t.a_first : 0.f);
+        for (int tap = 1; tap < last; tap += B) {
+#pragma unroll
+            for (int i = 0; i < B; i++) load(t, tap + i < last ? tap + i : last, v[i]);
+#pragma unroll
+            for (int i = 0; i < B; i++) accum(v[i], tap + i < last ? t.a_mid : 0.f);
+        }
+        accum(vl, last > 0 ? t.a_last : 0.f);
+    }
+    // one column, the variant by its tap count
+    __device__ __forceinline__ void taps(const ColTask& t)
+    {
+        if (Q == 1) {
+            switch (t.n) {
+            case 1: taps_static<1>(t); break;   case 2: taps_static<2>(t); break;   case 3: taps_static<3>(t); break;
+            case 4: taps_static<4>(t); break;   case 5: taps_static<5>(t); break;   case 6: taps_static<6>(t); break;
+            case 7: taps_static<7>(t); break;   case 8: taps_static<8>(t); break;   case 9: taps_static<9>(t); break;
+            case 10: taps_static<10>(t); break; case 11: taps_static<11>(t); break; case 12: taps_static<12>(t); break;
+            case 13: taps_static<13>(t); break; case 14: taps_static<14>(t); break;
+            default: taps_any(t); break;
+            }
+        } else taps_any(t);
+    }
+    // The sums land at row[(x - start_x) + sh], sh = start_x & 3, which makes every lane's PX floats one aligned LDS store; window
+    // rows left / right of the image replicate the border column's sum (WIN clamps x).  The caller reads row[i + sh] for i in
+    // [0, win).  `row` holds at least win + 8 floats.
+    __device__ __forceinline__ void store(int lane, int start_x, int win_size, float* __restrict__ row) const
+    {
+        const int xlo = start_x > 0 ? start_x : 0, xhi = start_x + win_size < w ? start_x + win_size : w;
+        const int sh = start_x & 3;
+        float* dst = row + sh - start_x;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            if (x[q] < xhi) {
+                if (PX == 4) *reinterpret_cast<float4*>(dst + x[q]) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+                else if (PX == 2) *reinterpret_cast<float2*>(dst + x[q]) = make_float2(acc[q][0], acc[q][1]);
+                else dst[x[q]] = acc[q][0];
+            }
+        }
+        const int ilo = xlo - start_x, ihi = xhi - start_x;
+        if (ilo > 0) { const float b = row[sh + ilo]; for (int i = lane; i < ilo; i += 64) row[sh + i] = b; }
+        if (ihi < win_size) { const float b = row[sh + ihi - 1]; for (int i = ihi + lane; i < win_size; i += 64) row[sh + i] = b; }
+    }
+};
+
+template <int PX, int Q>
+__device__ __forceinline__ void area_column(ImgRsrc rs, int lane, int start_x, int win_size, const ColTask& t, float* __restrict__ row)
+{
+    const int xlo = start_x > 0 ? start_x : 0;
+    AreaCol<PX, Q> c(rs, t.w, t.h1 + 1, lane, xlo & ~(PX - 1));
+    c.taps(t);
+    c.store(lane, start_x, win_size, row);
+}
+// the column's entry of the window's resize table, held one entry per lane (entry lane % 21), as scalars; and its tap range
+__device__ __forceinline__ ColTask col_task(const AreaTab& ty, int dx, int start_y, int w, int h)
+{
+    const int sx1 = __builtin_amdgcn_readlane(ty.sx1, dx), sx2 = __builtin_amdgcn_readlane(ty.sx2, dx);
+    const float a_first = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_first), dx));
+    const float a_mid = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_mid), dx));
+    const float a_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_last), dx));
+    const bool has_first = __builtin_amdgcn_readlane((int)ty.has_first, dx) != 0, has_last = __builtin_amdgcn_readlane((int)ty.has_last, dx) != 0;
+    const int c_begin = has_first ? sx1 - 1 : sx1, c_end = has_last ? sx2 + 1 : sx2;
+    // resizeArea_'s table entry of tap cc: cc < sx1 ? a_first : (cc < sx2 ? a_mid : a_last), for the first and the last tap; selected
+    // on the bit patterns in scalar registers (written as a lambda over the floats the compiler selected between ADDRESSES of
+    // stack copies and loaded the winner back from scratch: two dependent memory round trips per column)
+    const int bf = sgpr_i(__float_as_int(a_first)), bm = sgpr_i(__float_as_int(a_mid)), bl = sgpr_i(__float_as_int(a_last));
+    ColTask t;
+    t.y0 = start_y - c_begin; t.n = c_end - c_begin; t.h1 = h - 1; t.w = w;
+    t.a_first = __int_as_float(ssel_lt(c_begin, sx1, bf, ssel_lt(c_begin, sx2, bm, bl)));
+    t.a_mid = a_mid;
+    t.a_last = __int_as_float(ssel_lt(c_end - 1, sx1, bf, ssel_lt(c_end - 1, sx2, bm, bl)));
+    return t;
+}
+
 // small windows: one workgroup per keypoint (block bx of nbx of the launch's small-window part)
 __device__ __forceinline__ void descriptor64_small(const DescArgs& a, int w, int h, int bx, int nbx)
 {
@@ -1379,24 +1544,12 @@ __device__ __forceinline__ void descriptor64_small(const DescArgs& a, int w, int
 // buf[i][dx] for every window row i exactly as above, and finishes the 21 outputs PATCH[dy][dx] of its column.  A
 // fixed grid walks the (keypoint, dx) tasks of the list built by k_rank_scatter, so the largest window is spread over
 // 21 workgroups instead of serialising one; k_descriptor64_big_finish turns the patches into descriptors.
-static const int kTapBatch = 16;           // image rows a lane of descriptor64_big has in flight
-static const int kPatchStride = 448;       // bytes of patch scratch per keypoint (441 used)
-__device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// a < b ? x : y on scalar registers (the compiler turns the C expression into VALU selects on copies of the operands)
-__device__ __forceinline__ int ssel_lt(int a, int b, int x, int y)
-{
-    int r;
-    asm volatile("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(r) : "s"(a), "s"(b), "s"(x), "s"(y) : "scc");
-    return r;
-}
-__device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-
 // One task per WAVE (no workgroup barriers: four independent waves per workgroup, 8192 waves resident).  A task is one
 // destination column of a keypoint whose window is wider than kTripleWin, or three adjacent columns of a narrower one (their
 // horizontal passes run one after the other into three thirds of the row buffer, then one vertical pass finishes the 63
 // outputs, a lane each): the per-task work that does not depend on the window -- parameters, tables, the vertical pass,
 // its 21-of-64 lanes -- is shared by three columns where the LDS allows it.
-static const int kBigRow = 740;            // floats of row buffer per wave of the large-window part
+static const int kBigRow = 768;            // floats of row buffer per wave of the large-window part (a 739-pixel window + the 8 floats of slack area_column asks for; 3 x 256 for three-column tasks)
 __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h, uint8_t* __restrict__ patch, int bx, int nbx)
 {
     const int im = blockIdx.y, lane = threadIdx.x & 63, wv = sgpr_i(threadIdx.x >> 6);
@@ -1404,6 +1557,7 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
     extern __shared__ __align__(16) unsigned char smem_desc[];        // shared with the small-window part: 4 x kBigRow floats here
     float* bufrow0 = reinterpret_cast<float*>(smem_desc) + wv * kBigRow;
     const uint8_t* __restrict__ img = a.img[im];
+    const ImgRsrc rs = img_rsrc(img, w * h);
     // Tasks run down the size-sorted list (21 per wide keypoint, then 7 per narrower one) and are dealt to the waves in
     // rounds of alternating direction (round r hands task r*NW + p to wave p, or to wave NW-1-p when r is odd): costs span
     // 1..9 units, and this keeps the per-wave totals within about one task of each other, where a plain stride left the
@@ -1430,7 +1584,7 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
         if (t >= ntask) continue;
         const int e = entry_of(t);
         const int ncols = t < nt1 ? 1 : 3, dx0 = t < nt1 ? t - e * 21 : 3 * ((t - nt1) - (e - nl) * 7);
-        const int bstride = kTripleWin;                       // floats between the column buffers of a three-column task
+        const int bstride = 256;                              // floats between the column buffers of a three-column task (kTripleWin + 8 <= 256)
         // the task is the same for every lane: scalar registers, so that row clamps, row addresses and tap weights are SALU work
         const int win_size = sgpr_i(par.y) & 0xFFFF, start_x = sgpr_i(par.z), start_y = sgpr_i(par.w);
         const int iscale = sgpr_i(par.y) >> 16;               // non-zero: resizeAreaFast_ with this integer scale (k_big_sort)
@@ -1489,6 +1643,15 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
             for (int d = 0; d < ncols; d++) {
                 const int dx = dx0 + d;
                 float* bufrow = bufrow0 + d * bstride;
+                if (vec_ok) {
+                    // rows 4-byte aligned: the shared column core (aligned dword loads, four pixels per lane and chunk of 256 columns)
+                    const ColTask ct = col_task(ty, dx, start_y, w, h);
+                    const int span = xhi - xa;
+                    if (span <= 256) area_column<4, 1>(rs, lane, start_x, win_size, ct, bufrow);
+                    else if (span <= 512) area_column<4, 2>(rs, lane, start_x, win_size, ct, bufrow);
+                    else area_column<4, 3>(rs, lane, start_x, win_size, ct, bufrow);
+                    continue;
+                }
                 AreaTab tx;                                    // the column's entry, the same for every lane: scalar registers
                 tx.sx1 = __builtin_amdgcn_readlane(ty.sx1, dx); tx.sx2 = __builtin_amdgcn_readlane(ty.sx2, dx);
                 tx.a_first = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_first), dx));
@@ -1497,39 +1660,7 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
                 tx.has_first = __builtin_amdgcn_readlane((int)ty.has_first, dx) != 0; tx.has_last = __builtin_amdgcn_readlane((int)ty.has_last, dx) != 0;
                 const int c_begin = tx.has_first ? tx.sx1 - 1 : tx.sx1;
                 const int c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
-                const int ai_first = sgpr_i(__float_as_int(tx.a_first)), ai_mid = sgpr_i(__float_as_int(tx.a_mid)), ai_last = sgpr_i(__float_as_int(tx.a_last));
-                if (vec_ok) {
-                    // four adjacent window rows (image columns) per lane from one aligned 32-bit load per tap
-                    for (int x4 = xa + 4 * lane; x4 < xhi; x4 += 256) {
-                        float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-                        for (int c0 = c_begin; c0 < c_end; c0 += kTapBatch) {  // kTapBatch taps in flight, accumulated in order
-                            unsigned v[kTapBatch];
-#pragma unroll
-                            for (int q = 0; q < kTapBatch; q++) {
-                                int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
-                                v[q] = *reinterpret_cast<const unsigned*>(img + ((unsigned)(y * w) + (unsigned)x4));       // scalar row offset + vector column: one 32-bit add
-                            }
-#pragma unroll
-                            for (int q = 0; q < kTapBatch; q++) {
-                                int cc = c0 + q;
-                                // the tap's weight is the same for every lane: chosen with scalar selects on the bit patterns
-                                const float alpha = __int_as_float(ssel_lt(cc, tx.sx1, ai_first, ssel_lt(cc, tx.sx2, ai_mid, ai_last)));
-                                if (cc < c_end) {
-                                    b0 += (int)(v[q] & 255u) * alpha; b1 += (int)((v[q] >> 8) & 255u) * alpha;
-                                    b2 += (int)((v[q] >> 16) & 255u) * alpha; b3 += (int)(v[q] >> 24) * alpha;
-                                }
-                            }
-                        }
-                        const int i = x4 - start_x;
-                        if (i >= ilo) bufrow[i] = b0;
-                        if (i + 1 >= ilo && i + 1 < ihi) bufrow[i + 1] = b1;
-                        if (i + 2 >= ilo && i + 2 < ihi) bufrow[i + 2] = b2;
-                        if (i + 3 >= ilo && i + 3 < ihi) bufrow[i + 3] = b3;
-                    }
-                    if (ilo > 0) { const float v = bufrow[ilo]; for (int i = lane; i < ilo; i += 64) bufrow[i] = v; }
-                    if (ihi < win_size) { const float v = bufrow[ihi - 1]; for (int i = ihi + lane; i < win_size; i += 64) bufrow[i] = v; }
-                } else
-                for (int i = lane; i < win_size; i += 64) {
+                for (int i = lane; i < win_size; i += 64) {    // image rows not a multiple of four bytes: a pixel per lane and tap
                     int x = start_x + i; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
                     float b = 0.f;
                     // taps fetched eight at a time (independent loads in flight), accumulated in order
@@ -1553,9 +1684,7 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
             __builtin_amdgcn_wave_barrier();
             if (lane < 21 * ncols) {                        // vertical passes of the task's columns, 21 lanes each
                 const int d = lane / 21, dy = lane - d * 21;
-                const float* bufrow = bufrow0 + d * bstride;
-                const int r_begin = ty.has_first ? ty.sx1 - 1 : ty.sx1;
-                const int r_end = ty.has_last ? ty.sx2 + 1 : ty.sx2;
+                const float* bufrow = bufrow0 + d * bstride + (vec_ok ? (start_x & 3) : 0);      // area_column's alignment shift
                 float sum = 0.f;
                 if (ty.has_first) sum += ty.a_first * bufrow[ty.sx1 - 1];            // the loop of resizeArea_'s table, split by weight
                 for (int r = ty.sx1; r < ty.sx2; r++) sum += ty.a_mid * bufrow[r];
@@ -1570,11 +1699,12 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
 // small-window keypoint each.  The large-window part stalls on its per-tap dependency chains, the small-window part on its
 // barriers; resident together they keep the VALU busier than one after the other (and a launch is saved).
 // (8 waves per SIMD: the compiler would settle at 66 VGPRs = 7 waves)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_descriptor64(DescArgs a, int w, int h, uint8_t* __restrict__ patch, int nbig)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_descriptor64(DescArgs a, int w, int h, uint8_t* __restrict__ patch, int nbig, int part)
 {
     // (large-window blocks first: small-window blocks first measured 78 us, alternating blocks 97 us, against 66-68 us)
-    if ((int)blockIdx.x < nbig) descriptor64_big(a, w, h, patch, blockIdx.x, nbig);
-    else descriptor64_small(a, w, h, blockIdx.x - nbig, gridDim.x - nbig);
+    // part (UVO_DESC_PART, measurement only -- the other class of keypoints gets no descriptor): 1 = large windows only, 2 = small only
+    if ((int)blockIdx.x < nbig) { if (part != 2) descriptor64_big(a, w, h, patch, blockIdx.x, nbig); }
+    else if (part != 1) descriptor64_small(a, w, h, blockIdx.x - nbig, gridDim.x - nbig);
 }
 __global__ __launch_bounds__(256) void k_descriptor64_big_finish(DescArgs a, const uint8_t* __restrict__ patch)
 {
@@ -1831,7 +1961,8 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
         hipLaunchKernelGGL(k_big_sort, dim3(nimg), dim3(1024), 0, c->stream, c->d_big_par, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap, c->d_area_iscale);
         if (c->p.SURF_UPRIGHT) {
             const int nbig = 1024;                             // 8192 persistent waves for the large-window tasks (512: 80 us, 768..2048: 66-69 us)
-            hipLaunchKernelGGL(k_descriptor64, dim3(nbig + c->cap, nimg), dim3(256), lds_small > lds_big ? lds_small : lds_big, c->stream, da, w, h, c->d_big_patch, nbig);
+            static const int desc_part = getenv("UVO_DESC_PART") ? atoi(getenv("UVO_DESC_PART")) : 0;      // measurement only
+            hipLaunchKernelGGL(k_descriptor64, dim3(nbig + c->cap, nimg), dim3(256), lds_small > lds_big ? lds_small : lds_big, c->stream, da, w, h, c->d_big_patch, nbig, desc_part);
             hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(1024, nimg), dim3(256), 0, c->stream, da, c->d_big_patch);
         } else {
             // orientation assignment, then every descriptor from its rotated window (not the shipped configuration)
