@@ -197,7 +197,7 @@ def main():
     ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
 
     order = ping_pong(args.frames)
-    records = np.zeros((max(args.steps, 1), multirank.RECORD_WIDTH), dtype=np.float64)
+    results = (uvo.StereoResult * max(args.steps, 1))()      # the timed loop's results land here in place: no per-step conversion on the host
 
     def step():
         k = next(order)
@@ -245,13 +245,13 @@ def main():
     for i in range(args.steps):
         while submitted < args.steps and submitted - i < args.depth:
             submit(); submitted += 1
-        r = ctx.stereo_collect(0.05)
-        n_valid += r.valid
-        kp_sum += r.n_left
-        multirank.fill_record(records, i, rank, i, r)
+        ctx.stereo_collect(0.05, out=results[i])
+    records = multirank.records_from_results(results, rank)            # [steps, 16] float64, one vectorised pass
     allrec = multirank.gather_records(torch.from_numpy(records), dev)  # pose records of all streams: one RCCL all-gather (N > 1)
     fence()
     dt_local = time.perf_counter() - t0
+    n_valid = sum(r.valid for r in results[:args.steps])               # statistics of the run, outside the timed region
+    kp_sum = sum(r.n_left for r in results[:args.steps])
     busy_threads = (time.process_time() - cpu0) / max(dt_local, 1e-9)  # host threads this rank kept busy on average (CPU seconds per second)
     dt = multirank.max_over_ranks(dt_local, dev)
     assert [int(v) for v in allrec[:, 0, 0].tolist()] == list(range(world))

@@ -396,9 +396,10 @@ class Context:
         self._check(self._lib.uvo_stereo_submit(self._h, pl, pr, w, h, w, ml))
         self._inflight.append((kl, kr))             # read asynchronously: alive until the pair is collected
 
-    def stereo_collect(self, dt: float = 0.05) -> StereoResult:
-        """Finish the oldest submitted pair (PnP-RANSAC + pose); same result as stereo_step."""
-        r = StereoResult()
+    def stereo_collect(self, dt: float = 0.05, out: StereoResult | None = None) -> StereoResult:
+        """Finish the oldest submitted pair (PnP-RANSAC + pose); same result as stereo_step.  `out`: the StereoResult to fill
+        (e.g. an element of a preallocated ctypes array, so that a long loop copies nothing on the Python side)."""
+        r = StereoResult() if out is None else out
         before = self._lib.uvo_ctx_pending(self._h)
         try:
             self._check(self._lib.uvo_stereo_collect(self._h, C.c_double(dt), C.byref(r)))

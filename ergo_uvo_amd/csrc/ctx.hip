@@ -59,6 +59,8 @@ static void make_desc_weights(float* DW)
 }
 
 static void lane_worker(uvo_ctx* L);
+__global__ void k_prime(int* sink, int n);
+static void run_stage_b(uvo_ctx* L, bool stage_a_ok);
 static uvo_status prime_lanes(uvo_ctx* c, int w, int h);
 extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* out);
 static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok);
@@ -121,6 +123,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
         A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsA[i]), sizeof(int) * CN_TOTAL));
     }
     A(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
+    A(hipEventCreateWithFlags(&c->evSync, hipEventDisableTiming));
     A(hipEventCreateWithFlags(&c->evProducer, hipEventDisableTiming));
     A(hipEventCreateWithFlags(&c->evDet, hipEventDisableTiming)); A(hipEventCreateWithFlags(&c->evPrevRead, hipEventDisableTiming));
     {   // the PnP stage is a few 1..8-workgroup kernels on a pair's critical path: its stream gets the highest priority, so that the
@@ -141,6 +144,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     A(hipHostMalloc(reinterpret_cast<void**>(&c->h_subsets), sizeof(int) * kMaxHyp * 5));
     A(hipHostMalloc(reinterpret_cast<void**>(&c->h_hcount), sizeof(int) * kMaxHyp));
     A(hipHostMalloc(reinterpret_cast<void**>(&c->h_pose), sizeof(double) * 6));
+    A(dalloc(&c->d_rng_raw, (size_t)1024)); A(hipMalloc(&c->d_spec, 64)); A(hipHostMalloc(&c->h_spec, 64));
 #undef A
     if (e != hipSuccess) { destroy_one(c); return UVO_HIP_ERROR; }
     c->d_cand_n = c->d_counts + CN_CAND0;
@@ -149,6 +153,14 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     c->d_as_n = c->d_counts + CN_AS0;
     c->d_big_n = c->d_counts + CN_BIG0;
     if (surf_build_area_tables(c) != UVO_OK) { destroy_one(c); return UVO_HIP_ERROR; }
+    {   // getSubset's generator is cv::RNG((uint64)-1) for every call: its raw outputs are a constant table
+        std::vector<unsigned> raw(1024);
+        uint64_t state = (uint64_t)-1;
+        for (auto& v : raw) v = rng_next(state);
+        if (hipMemcpy(c->d_rng_raw, raw.data(), sizeof(unsigned) * raw.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(c->d_spec, 0, 64) != hipSuccess) { destroy_one(c); return UVO_HIP_ERROR; }
+        memset(c->h_spec, 0, 64);
+    }
     make_desc_weights(c->h_DW);
     if (hipMemcpy(c->d_DW, c->h_DW, sizeof(float) * 400, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->d_rank, 0, sizeof(int) * cap * 2) != hipSuccess ||
@@ -278,11 +290,12 @@ static void destroy_one(uvo_ctx* c)
                      c->d_hcount, c->d_inliers, c->d_refit, c->d_pose };
     for (void* p : ptrs) (void)hipFree(p);
     (void)hipHostFree(c->h_counts); (void)hipHostFree(c->h_subsets); (void)hipHostFree(c->h_hcount); (void)hipHostFree(c->h_pose);
-    (void)hipHostFree(c->h_countsB);
+    (void)hipHostFree(c->h_countsB); (void)hipHostFree(c->h_spec); (void)hipFree(c->d_rng_raw); (void)hipFree(c->d_spec);
     for (int i = 0; i < 2; i++) { (void)hipHostFree(c->h_countsA[i]); if (c->evA[i]) (void)hipEventDestroy(c->evA[i]); }
     if (c->pnp_stream) (void)hipStreamDestroy(c->pnp_stream);
     if (c->evAS) (void)hipEventDestroy(c->evAS);
     if (c->evBlock) (void)hipEventDestroy(c->evBlock);
+    if (c->evSync) (void)hipEventDestroy(c->evSync);
     if (c->evProducer) (void)hipEventDestroy(c->evProducer);
     for (auto& r : c->trace) for (int k = 0; k < 6; k++) if (r.ev[k]) (void)hipEventDestroy(r.ev[k]);
     if (c->evDet) (void)hipEventDestroy(c->evDet);
@@ -787,9 +800,13 @@ static uvo_status prime_lanes(uvo_ctx* c, int w, int h)
         uvo_status st = surf_prepare(l, w, h);
         if (st != UVO_OK) { if (l != c) c->err = l->err; return st; }
         hipLaunchKernelGGL(k_prime, dim3(1), dim3(64), 0, l->stream, l->d_countsB, 1);
-        hipLaunchKernelGGL(k_prime, dim3(1), dim3(64), 0, l->pnp_stream, l->d_countsB, 1);
         UVO_HIP_TRY(c, hipStreamSynchronize(l->stream));
-        UVO_HIP_TRY(c, hipStreamSynchronize(l->pnp_stream));
+        // the PnP stream from the lane's worker thread, which is the thread that will use it: its first launch and its first wait
+        // (event + stream) also set up the runtime's per-thread state
+        UVO_HIP_TRY(c, hipEventRecord(l->evA[0], l->stream));
+        { std::lock_guard<std::mutex> lk(l->mu); l->job.kind = 2; l->job.state = 1; }
+        l->cv.notify_all();
+        { std::unique_lock<std::mutex> lk(l->mu); l->cv.wait(lk, [&] { return l->job.state == 2; }); l->job.state = 0; }
         l->primed_w = w; l->primed_h = h;
     }
     return UVO_OK;
@@ -892,19 +909,34 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
     LANE_TRY(pose_triangulate_extract3d(L, 0, c->P_eye_left, c->P_right, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap,
                                         L->h_countsA[0]));                                  // the counters land in pinned memory, no copy queued
-    UVO_HIP_TRY(c, hipEventRecord(L->evA[0], st));
-    UVO_HIP_TRY(c, hipEventRecord(L->evA[1], st));                                          // the same point for other streams (see uvo_ctx.h)
+    UVO_HIP_TRY(c, hipEventRecord(L->evA[1], st));                                          // end of stage A, for the pacing of later pairs (see uvo_ctx.h)
     if (tr) UVO_HIP_TRY(c, hipEventRecord(tr->ev[2], st));
+    // the first RANSAC round, speculatively, on this stream (pose.hip): the worker wakes once, when the pose is there
+    // Taken by the synchronous step only (one pair in flight: 0.80 -> 0.77 ms per pair at C3).  With several pairs in flight the
+    // same kernels queued behind a lane's stage A cost the pipeline a quarter of its rate (4370 -> 3200 pairs/s; 4130 on the
+    // lane's PnP stream behind a stream wait), so pipelined pairs keep the worker-driven stage.  UVO_PNP_SPEC: 0 never,
+    // 1 (default) synchronous steps, 3 / 2 every pair on the lane's stream / its PnP stream (measurement only).
+    static const int spec_env = getenv("UVO_PNP_SPEC") ? atoi(getenv("UVO_PNP_SPEC")) : 1;
+    L->spec_queued = (spec_env >= 2 || (spec_env == 1 && c->in_sync_step)) && !c->timing && p.ITERATIONS_COUNT >= 1;
+    hipStream_t sb = st;
+    if (L->spec_queued && spec_env == 2) { sb = L->pnp_stream; UVO_HIP_TRY(c, hipStreamWaitEvent(sb, L->evA[1], 0)); }
+    if (L->spec_queued) LANE_TRY(pose_pnp_spec_launch(L, sb, c->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE, p.MIN_NUM_3DPOINTS));
+    UVO_HIP_TRY(c, hipEventRecord(L->evA[0], sb));                                          // what the lane's worker waits for
     // state carry VO:727-733: this pair's set is the next pair's "prev"
     L->as_w = curr ^ 1;
     c->prev_lane = li; c->prev_buf = curr; c->prev_sync = false;
     c->next_lane = (li + 1) % depth;
     c->inflight[c->n_pending++] = li; c->n_submitted++;
-    {   // hand stage B to the lane's worker
-        std::lock_guard<std::mutex> lk(L->mu);
-        L->job.kind = 0; L->job.state = 1;
+    L->inline_b = c->in_sync_step;
+    if (L->inline_b) {
+        // the synchronous step waits for its own pair: the calling thread polls the stream's end itself and finishes stage B inline
+        // (no worker wake-up, no condition variable: two thread hand-overs less on the pair's critical path)
+        UVO_HIP_TRY(c, hipEventRecord(L->evSync, sb));
+        L->job.kind = 0;
+    } else {   // hand stage B to the lane's worker
+        { std::lock_guard<std::mutex> lk(L->mu); L->job.kind = 0; L->job.state = 1; }
+        L->cv.notify_all();
     }
-    L->cv.notify_all();
     seg(11);                                                                               // matcher .. extract_3Dpoints launches, hand-over
     if (uvo::g_bdbg) { uvo::g_bstat[6] += uvo::now_us() - t_sub; uvo::g_bstat[7] += 1; }
     return UVO_OK;
@@ -929,6 +961,8 @@ static void run_stage_b(uvo_ctx* L, bool stage_a_ok)
         Range rg("uvo:solvePnPRansac");
         PnpResult r;
         Ctx* one[1] = { L };
+        if (L->spec_queued && pose_pnp_spec_accept(L, G, p.ITERATIONS_COUNT, p.CONFIDENCE, &r)) j.st = UVO_OK;      // the device's round, confirmed by the host's scan
+        else
         j.st = pose_pnp_ransac_batch(L, 1, one, &G, m->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE, &r);   // VO:647-648
         if (j.st == UVO_OK) j.st = r.st;
         if (j.st != UVO_OK) j.err = L->err;
@@ -957,6 +991,7 @@ static void lane_worker(uvo_ctx* L)
             m->b_running++;
             g.unlock();
             if (L->job.kind == 1) { const double tb = g_bdbg ? now_us() : 0; run_mono_stage_b(L, stage_a_ok); if (g_bdbg) { g_bstat[1] += now_us() - tb; g_bstat[4] += 1; } }
+            else if (L->job.kind == 2) { hipLaunchKernelGGL(k_prime, dim3(1), dim3(64), 0, L->pnp_stream, L->d_countsB, 1); (void)host_sync(L, L->pnp_stream); }   // prime_lanes
             else run_stage_b(L, stage_a_ok);
             g.lock();
             m->b_running--;
@@ -990,7 +1025,10 @@ extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_resul
     uvo_ctx* L = static_cast<uvo_ctx*>(c->lanes[li]);
     c->last_lane = li;
     L->pending.used = false;
-    {
+    if (L->inline_b) {
+        L->inline_b = false;
+        run_stage_b(L, hipEventSynchronize(L->evSync) == hipSuccess);
+    } else {
         std::unique_lock<std::mutex> lk(L->mu);
         L->cv.wait(lk, [&] { return L->job.state == 2; });
         L->job.state = 0;
@@ -1036,7 +1074,10 @@ extern "C" uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uin
 {
     if (!c || !out) return UVO_INVALID_ARG;
     if (c->n_pending != 0) return fail(c, UVO_INVALID_ARG, "uvo_stereo_step: pairs submitted with uvo_stereo_submit are still in flight");
-    UVO_TRY(uvo_stereo_submit(c, left, right, w, h, stride, mem));
+    c->in_sync_step = true;
+    const uvo_status st = uvo_stereo_submit(c, left, right, w, h, stride, mem);
+    c->in_sync_step = false;
+    UVO_TRY(st);
     return uvo_stereo_collect(c, dt, out);
 }
 

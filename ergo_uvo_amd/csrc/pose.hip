@@ -371,6 +371,217 @@ __global__ __launch_bounds__(kFastThreads) void k_pnp_refit_fast(PnpBatch b)
     if (threadIdx.x == 0) { pose[0] = rvec[0]; pose[1] = rvec[1]; pose[2] = rvec[2]; pose[3] = tvec[0]; pose[4] = tvec[1]; pose[5] = tvec[2]; jb.ninl_host[0] = n; }
 }
 
+// ---------------------------------------------------------------- the first RANSAC round without the host (round 3)
+// The stereo loop used to hand a pair from its device stage to the lane's worker thread for PnP: wake on an event, draw the
+// subsets, launch hypotheses + scoring, wait, replay OpenCV's sequential scan, launch mask + refit, wait -- two host round
+// trips and a thread wake-up (~60 us of a 0.8 ms pair).  With a working odometry the scan is over inside the first 64
+// hypotheses, so that round now runs SPECULATIVELY on the lane's own stream, queued right behind extract_3Dpoints:
+//   k_pnp_hyp_spec    draws its own subsets -- cv::RNG((uint64)-1) is a constant stream, so its raw 32-bit outputs are a table and
+//                     only `% G` and the duplicate test depend on the pair -- and solves the 64 EPnP-5 hypotheses
+//   k_pnp_score_spec  counts inliers per hypothesis; the last workgroup to finish replays the scan on the device
+//   k_pnp_refit_spec  winner's mask, ordered compaction and the workgroup-parallel refit (the bodies of k_pnp_mask and
+//                     k_pnp_refit_fast)
+// The worker then wakes once, replays the scan over the same counts with the host's libm (log / pow decide the adaptive
+// iteration count and must be the reference's) and accepts the device's pose only if the host arrives at the same winner
+// with the scan complete; otherwise -- more hypotheses needed, too few inliers for the fast refit, G == 5, a walk that
+// ran out of table -- the whole stage runs again the old way.  Results are therefore exactly those of the host-driven path.
+static const int kSpecHyp = 64;             // hypotheses of the speculative round (= the host path's first round)
+static const int kRngRaw = 1024;            // raw outputs of cv::RNG((uint64)-1) kept on the device (64 subsets need 320 + redraws)
+struct PnpSpecState { int ticket, state, best, n_best, niters, nhyp, G, pad; };      // state: 0 not run, 1 ran but the host must redo, 2 pose delivered
+struct PnpSpecArgs {
+    const int* cn; int min3d, iters; double conf;
+    const float* opts; const uvo_point2f* ipts; const unsigned* rng_raw;
+    int* subsets; double* models; int* hcount_dev; int* hcount_host;
+    int* inliers; double* ws; int* countsB; double* pose; int* ninl_host;
+    PnpSpecState* st; PnpSpecState* st_host;
+    int cap; double fx, fy, cx, cy; float thr2;
+};
+// the hypotheses the speculative round evaluates for G points: 0 when the pair does not take the path at all
+__device__ __forceinline__ int spec_nhyp(const PnpSpecArgs& a, int G) { return (G > a.min3d && G >= 6) ? (a.iters < kSpecHyp ? a.iters : kSpecHyp) : 0; }
+
+__global__ __launch_bounds__(64) void k_pnp_hyp_spec(PnpSpecArgs a)
+{
+    const int G = a.cn[CN_G];
+    const int nhyp = spec_nhyp(a, G);
+    // state 1 = "the models are there", unless some workgroup raises `pad` (its walk ran out of table); both are reset per pair:
+    // state here, pad by k_pnp_refit_spec, the ticket by the scan
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a.st->G = G; a.st->nhyp = nhyp; a.st->state = nhyp > 0 ? 1 : 0; }
+    if ((int)blockIdx.x * kHypGroups >= nhyp) return;
+    extern __shared__ __align__(16) unsigned char smem[];
+    double* lds = reinterpret_cast<double*>(smem);
+    __shared__ int s_sub[kHypGroups][5];
+    __shared__ int s_ok;
+    const int group = threadIdx.x >> 3, lane = threadIdx.x & 7;
+    const int hyp_raw = blockIdx.x * kHypGroups + group;
+    const int hyp = hyp_raw < nhyp ? hyp_raw : nhyp - 1;
+    if (threadIdx.x == 0) s_ok = 1;
+    // getSubset (ptsetreg.cpp): for every iteration five draws uniform(0, G), a draw equal to an earlier one of the same subset
+    // is redrawn.  The draws are r_j % G of the constant raw stream; hypothesis h starts at draw 5 h + (redraws before it).  Lane h
+    // walks hypothesis h from its assumed start, a wave scan of the redraw counts gives the next assumption, until nothing moves:
+    // the starts become final from the front, one pass when no subset of the round has a duplicate (a sequential walk by one lane
+    // with a dependent load per draw measured ~100 us on the critical path).
+    __shared__ int s_m[kRngRaw];
+    for (int j = threadIdx.x; j < kRngRaw; j += 64) s_m[j] = (int)(a.rng_raw[j] % (unsigned)G);
+    __syncthreads();
+    {
+        const int h = threadIdx.x;                        // one lane per hypothesis of the round (64 = the wave)
+        int D = 0, cur[5], ok = 1;
+        for (int pass = 0; pass < kSpecHyp + 1; pass++) {
+            int pos = 5 * h + D, used = 0;
+            ok = 1;
+            for (int t = 0; t < 5;) {
+                if (pos + used >= kRngRaw) { ok = 0; break; }
+                const int idx = s_m[pos + used++];
+                bool dup = false;
+                for (int u = 0; u < t; u++) dup = dup || cur[u] == idx;
+                if (!dup) cur[t++] = idx;
+            }
+            const int extra = ok ? used - 5 : 0;
+            int incl = extra;                              // inclusive scan over the wave
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (h >= o) incl += v; }
+            const int newD = incl - extra;
+            const bool changed = newD != D;
+            D = newD;
+            if (!__any(changed)) break;
+        }
+        if (h < nhyp && !ok) s_ok = 0;                    // (s_ok was set below before the walk)
+        const int g = h - (int)blockIdx.x * kHypGroups;
+        if (g >= 0 && g < kHypGroups) for (int t = 0; t < 5; t++) s_sub[g][t] = cur[t];
+    }
+    __syncthreads();
+    if (!s_ok) { if (threadIdx.x == 0) a.st->pad = 1; return; }       // the walk ran out of table: the host redoes the stage
+    using P = GroupPolicy<kHypGroups>;
+    using A = P::Arr;
+    A base{lds + group};
+    Epnp<P> e;
+    e.uc = a.cx; e.vc = a.cy; e.fu = a.fx; e.fv = a.fy; e.n = 5;
+    e.clk = nullptr;
+    e.s = base; e.pws = base + EPNP_SMALL; e.us = e.pws + 15; e.alphas = e.us + 10; e.pcs = e.alphas + 20; e.tmp = e.pcs + 45;
+    const double ifx = 1. / a.fx, ify = 1. / a.fy;
+    const int gsub = hyp - (int)blockIdx.x * kHypGroups;
+    if (lane < 5) {
+        const int i = lane, id = s_sub[gsub][i];
+        e.pws[3*i] = a.opts[3*id]; e.pws[3*i + 1] = a.opts[3*id + 1]; e.pws[3*i + 2] = a.opts[3*id + 2];
+        double x = (double)(float)((a.ipts[id].x - a.cx) * ifx), y = (double)(float)((a.ipts[id].y - a.cy) * ify);
+        e.us[2*i] = x * a.fx + a.cx; e.us[2*i + 1] = y * a.fy + a.cy;
+        if (hyp_raw < nhyp) a.subsets[hyp * 5 + i] = id;
+    }
+    __syncthreads();
+    double rvec[3], tvec[3];
+    e.compute_pose(rvec, tvec);
+    if (lane == 0 && hyp_raw < nhyp) {
+        double* m = a.models + (size_t)hyp * 6;
+        m[0] = rvec[0]; m[1] = rvec[1]; m[2] = rvec[2]; m[3] = tvec[0]; m[4] = tvec[1]; m[5] = tvec[2];
+    }
+}
+
+// RANSACUpdateNumIters on the device: ocml's log / pow instead of the host's libm -- which is why the host repeats the scan
+__device__ __forceinline__ int ransac_update_num_iters_dev(double p, double ep, int modelPoints, int maxIters)
+{
+    p = p > 0. ? p : 0.; p = p < 1. ? p : 1.;
+    ep = ep > 0. ? ep : 0.; ep = ep < 1. ? ep : 1.;
+    double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN;
+    double denom = 1. - pow(1. - ep, (double)modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : cv_round_d(num / denom);
+}
+
+__global__ __launch_bounds__(256) void k_pnp_score_spec(PnpSpecArgs a)
+{
+    const int tid = threadIdx.x, hyp = blockIdx.x;
+    const int G = a.st->G, nhyp = a.st->nhyp;
+    if (a.st->state != 1 || a.st->pad != 0 || hyp >= nhyp) return;
+    __shared__ double sR[9], st[3];
+    __shared__ int s_cnt;
+    if (tid == 0) {
+        const double* m = a.models + (size_t)hyp * 6;
+        double R[9]; rodrigues_vec2mat(m, R);
+        for (int k = 0; k < 9; k++) sR[k] = R[k];
+        st[0] = m[3]; st[1] = m[4]; st[2] = m[5];
+        s_cnt = 0;
+    }
+    __syncthreads();
+    double R[9], t[3];
+    for (int k = 0; k < 9; k++) R[k] = sR[k];
+    t[0] = st[0]; t[1] = st[1]; t[2] = st[2];
+    int cnt = 0;
+    for (int i = tid; i < G; i += 256) cnt += pnp_is_inlier(a.opts, a.ipts, i, R, t, a.fx, a.fy, a.cx, a.cy, a.thr2) ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((tid & 63) == 0) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (tid == 0) { a.hcount_host[hyp] = s_cnt; a.hcount_dev[hyp] = s_cnt; }
+}
+
+__global__ __launch_bounds__(kFastThreads) void k_pnp_refit_spec(PnpSpecArgs a)
+{
+    __shared__ double lds[kFastLdsDoubles];
+    __shared__ int wtot[16];
+    __shared__ int s_base;
+    const int tid = threadIdx.x;
+    __shared__ int s_state;
+    if (tid == 0) {
+        // RANSACPointSetRegistrator::run's sequential scan over the round's counts (the scoring kernel has finished)
+        int state = a.st->pad != 0 ? 0 : a.st->state;
+        if (state == 1) {
+            const int modelPoints = 5, G = a.st->G, nhyp = a.st->nhyp;
+            int niters = a.iters > 1 ? a.iters : 1, maxGood = 0, best = -1, iter = 0;
+            for (; iter < niters && iter < nhyp; iter++) {
+                const int good = a.hcount_dev[iter];
+                if (good > (maxGood > modelPoints - 1 ? maxGood : modelPoints - 1)) {
+                    best = iter; maxGood = good;
+                    niters = ransac_update_num_iters_dev(a.conf, (double)(G - good) / G, modelPoints, niters);
+                }
+            }
+            a.st->best = best; a.st->n_best = maxGood; a.st->niters = niters;
+            if (iter >= niters && best >= 0 && maxGood >= kFastRefitMin) state = 2;      // the refit goes ahead
+        }
+        s_state = state;
+    }
+    __syncthreads();
+    const int state = s_state;
+    if (state != 2) {                                       // nothing to refit on the device: tell the host (one store over PCIe)
+        if (tid == 0) { PnpSpecState h = *a.st; h.state = state == 0 ? 0 : 1; h.pad = 0; *a.st_host = h; a.st->pad = 0; }
+        return;
+    }
+    const int n = a.st->G;
+    const double* model = a.models + (size_t)a.st->best * 6;
+    double R[9], t[3];
+    rodrigues_vec2mat(model, R);
+    t[0] = model[3]; t[1] = model[4]; t[2] = model[5];
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    double* pws = a.ws; double* us = a.ws + 3 * (size_t)a.cap;
+    const double ifx = 1. / a.fx, ify = 1. / a.fy;
+    for (int base = 0; base < n; base += kFastThreads) {   // k_pnp_mask's body: ascending inlier list + refit inputs
+        const int i = base + tid;
+        const bool keep = i < n && pnp_is_inlier(a.opts, a.ipts, i, R, t, a.fx, a.fy, a.cx, a.cy, a.thr2);
+        const int pos = block_compact_pos(keep, wtot, &s_base);
+        if (keep) {
+            a.inliers[pos] = i;
+            pws[3*pos] = a.opts[3*i]; pws[3*pos + 1] = a.opts[3*i + 1]; pws[3*pos + 2] = a.opts[3*i + 2];
+            double x = ((double)a.ipts[i].x - a.cx) * ifx, y = ((double)a.ipts[i].y - a.cy) * ify;     // undistortPoints, CV_64FC2
+            us[2*pos] = x * a.fx + a.cx; us[2*pos + 1] = y * a.fy + a.cy;
+        }
+    }
+    __syncthreads();
+    const int ninl = s_base;
+    if (tid == 0) a.countsB[0] = ninl;
+    __syncthreads();
+    EpnpFast e;
+    e.uc = a.cx; e.vc = a.cy; e.fu = a.fx; e.fv = a.fy; e.n = ninl; e.cap = a.cap; e.ws = a.ws; e.lds = lds;
+    e.clk = nullptr;
+    double rvec[3], tvec[3];
+    e.compute_pose(rvec, tvec);
+    if (tid == 0) {
+        a.pose[0] = rvec[0]; a.pose[1] = rvec[1]; a.pose[2] = rvec[2]; a.pose[3] = tvec[0]; a.pose[4] = tvec[1]; a.pose[5] = tvec[2];
+        a.ninl_host[0] = ninl;
+        __threadfence_system();
+        PnpSpecState h = *a.st; h.state = 2; *a.st_host = h;
+    }
+}
+
 // single 5-point solve when npoints == model_points (solvePnPRansac short-cut): reuse k_pnp_hyp with
 // the identity subset.
 
@@ -467,6 +678,60 @@ void range_push(const char* name) { const Roctx& r = roctx(); if (r.push) r.push
 void range_pop() { const Roctx& r = roctx(); if (r.pop) r.pop(); }
 double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 void operator+=(std::atomic<double>& a, double v) { double o = a.load(); while (!a.compare_exchange_weak(o, o + v)) {} }
+
+// the speculative first round of a lane's pair, queued on the lane's own stream behind extract_3Dpoints (see k_pnp_hyp_spec)
+static PnpSpecArgs spec_args(Ctx* c, const double* K, int iters, float reprojectionError, double confidence, int min3d)
+{
+    PnpSpecArgs a;
+    memset(&a, 0, sizeof(a));
+    a.cn = c->d_counts; a.min3d = min3d; a.iters = iters > 1 ? iters : 1; a.conf = confidence;
+    a.opts = c->d_opts[0]; a.ipts = c->d_ipts[0]; a.rng_raw = c->d_rng_raw;
+    a.subsets = c->d_subsets; a.models = c->d_models; a.hcount_dev = c->d_hcount; a.hcount_host = c->h_hcount;
+    a.inliers = c->d_inliers; a.ws = c->d_refit; a.countsB = c->d_countsB; a.pose = c->h_pose; a.ninl_host = c->h_countsB;
+    a.st = static_cast<PnpSpecState*>(c->d_spec); a.st_host = static_cast<PnpSpecState*>(c->h_spec);
+    a.cap = c->cap; a.fx = K[0]; a.fy = K[4]; a.cx = K[2]; a.cy = K[5];
+    const double threshold = reprojectionError;
+    a.thr2 = (float)(threshold * threshold);
+    return a;
+}
+uvo_status pose_pnp_spec_launch(Ctx* c, hipStream_t st, const double* K, int iters, float reprojectionError, double confidence, int min3d)
+{
+    if (iters > kMaxHyp) return UVO_OK;                    // the host path reports it
+    const size_t hyp_lds = sizeof(double) * GroupPolicy<kHypGroups>::kStride * kHypPerGroup;
+    static std::once_flag attr_once[64];
+    std::call_once(attr_once[c->device & 63], [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_hyp_spec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds); });
+    const PnpSpecArgs a = spec_args(c, K, iters, reprojectionError, confidence, min3d);
+    static_cast<PnpSpecState*>(c->h_spec)->state = -1;     // "not reported yet"
+    Ctx::TraceRec* tr = (c->trace_on && c->trace_cur >= 0) ? &c->trace[c->trace_cur] : nullptr;
+    if (tr) { tr->b_used = true; (void)hipEventRecord(tr->ev[3], st); }
+    hipLaunchKernelGGL(k_pnp_hyp_spec, dim3(kSpecHyp / kHypGroups), dim3(64), hyp_lds, st, a);
+    hipLaunchKernelGGL(k_pnp_score_spec, dim3(kSpecHyp), dim3(256), 0, st, a);
+    if (tr) (void)hipEventRecord(tr->ev[4], st);
+    hipLaunchKernelGGL(k_pnp_refit_spec, dim3(1), dim3(kFastThreads), 0, st, a);
+    if (tr) (void)hipEventRecord(tr->ev[5], st);
+    UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+// After the lane's stream has drained: did the speculative round deliver, and does the host's own replay of the scan (its libm)
+// agree?  true: *r holds the stage's result, exactly what pose_pnp_ransac_batch would return.
+bool pose_pnp_spec_accept(Ctx* c, int G, int iters, double confidence, PnpResult* r)
+{
+    const PnpSpecState* h = static_cast<const PnpSpecState*>(c->h_spec);
+    if (h->state != 2 || h->G != G) return false;
+    const int modelPoints = 5, nhyp = h->nhyp;
+    int niters = iters > 1 ? iters : 1, maxGood = 0, best = -1, iter = 0;
+    for (; iter < niters && iter < nhyp; iter++) {
+        const int good = c->h_hcount[iter];
+        if (good > (maxGood > modelPoints - 1 ? maxGood : modelPoints - 1)) {
+            best = iter; maxGood = good;
+            niters = ransac_update_num_iters(confidence, (double)(G - good) / G, modelPoints, niters);
+        }
+    }
+    if (iter < niters || best < 0 || best != h->best || maxGood != h->n_best || c->h_countsB[0] != maxGood) return false;
+    r->st = UVO_OK; r->wrote = 1; r->ok = 1; r->ninl = maxGood;
+    memcpy(r->rvec, c->h_pose, sizeof(double) * 3); memcpy(r->tvec, c->h_pose + 3, sizeof(double) * 3);
+    return true;
+}
 
 // solvePnPRansac for n jobs at once: job i works on the G[i] points already in lanes[i]->d_opts[0] / d_ipts[0] with
 // lanes[i]'s PnP buffers; every launch and both host syncs are shared.  Runs on m->pnp_stream.

@@ -131,6 +131,11 @@ struct Ctx {
     int* d_inliers = nullptr;                    // cap
     double* d_refit = nullptr;                   // refit workspace: pws 3n, us 2n, alphas 4n, pcs 3n, tmp n, M 24n, small
     double* d_pose = nullptr;  double* h_pose = nullptr;             // rvec(3) tvec(3)
+    unsigned* d_rng_raw = nullptr;               // the first raw outputs of cv::RNG((uint64)-1): getSubset's stream (pose.hip, speculative round)
+    void* d_spec = nullptr; void* h_spec = nullptr;                  // PnpSpecState of the lane's pair, device / pinned
+    bool spec_queued = false;                    // this lane's pair has a speculative PnP round queued on `stream`
+    hipEvent_t evSync = nullptr; bool inline_b = false;              // synchronous step: end of the pair's device work, polled by the calling thread, which runs stage B itself
+    bool in_sync_step = false;                   // master: the submit in progress is uvo_stereo_step's (one pair in flight)
 
     // ---- pipeline: stage A (detect .. extract_3Dpoints) on `stream`, stage B (PnP) on `pnp_stream` ----
     // A context is also one LANE of the stereo pipeline.  Lane 0 is the context the caller holds; uvo_stereo_set_depth
@@ -273,6 +278,8 @@ uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, 
 uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const double* R, const double* t, const double* K,
                                  const uvo_point2f* img, double* err);
 struct PnpResult { uvo_status st; int wrote, ok, ninl; double rvec[3], tvec[3]; };
+uvo_status pose_pnp_spec_launch(Ctx* c, hipStream_t st, const double* K, int iters, float reprojectionError, double confidence, int min3d);
+bool pose_pnp_spec_accept(Ctx* c, int G, int iters, double confidence, PnpResult* r);
 uvo_status pose_pnp_ransac_batch(Ctx* m, int n, Ctx* const* lanes, const int* G, const double* K, int iters, float reproj, double conf,
                                  PnpResult* res);
 uvo_status pose_pnp_ransac(Ctx* c, int slot, int G, const double* K, int iters, float reproj, double conf,

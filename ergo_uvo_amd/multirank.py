@@ -75,6 +75,25 @@ def fill_record(records, i: int, stream: int, step: int, res) -> None:
     row[10:13] = res.t_prev_curr
 
 
+def records_from_results(results, stream: int, first_step: int = 0):
+    """A ctypes array of StereoResult (filled in place by Context.stereo_collect(out=...)) -> the [steps, RECORD_WIDTH] float64
+    record matrix of fill_record, in one vectorised pass (the timed loop of bench.py then does no per-step conversion)."""
+    import ctypes
+    import numpy as np
+    n = len(results)
+    dt = np.dtype([("valid", "i4"), ("initialized", "i4"), ("n_left", "i4"), ("n_right", "i4"), ("n_stereo_matches", "i4"),
+                   ("n_tri_matches", "i4"), ("n_good3d", "i4"), ("n_inliers", "i4"), ("rvec", "f8", 3), ("tvec", "f8", 3),
+                   ("t_prev_curr", "f8", 3), ("velocity", "f8", 3)])
+    assert dt.itemsize == ctypes.sizeof(results) // max(n, 1)
+    a = np.frombuffer(results, dtype=dt, count=n)
+    rec = np.zeros((n, RECORD_WIDTH), dtype=np.float64)
+    rec[:, 0] = stream
+    rec[:, 1] = np.arange(first_step, first_step + n)
+    rec[:, 2] = a["valid"]; rec[:, 3] = a["n_inliers"]
+    rec[:, 4:7] = a["rvec"]; rec[:, 7:10] = a["tvec"]; rec[:, 10:13] = a["t_prev_curr"]
+    return rec
+
+
 def gather_records(records: torch.Tensor, device: torch.device | None = None) -> torch.Tensor:
     """[steps, RECORD_WIDTH] per rank -> [world, steps, RECORD_WIDTH] on every rank (one all-gather)."""
     if not dist.is_initialized():
