@@ -11,7 +11,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(_HERE, "lib", "libuvo_hip.so")
+LIB_PATH = os.environ.get("UVO_HIP_LIB") or os.path.join(_HERE, "lib", "libuvo_hip.so")      # UVO_HIP_LIB: another build of the same ABI (A/B measurements)
 
 EXPORTS = [
     "uvo_params_default_stereo", "uvo_params_default_mono", "uvo_ctx_create", "uvo_ctx_destroy", "uvo_last_error",

@@ -126,12 +126,14 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     A(hipEventCreateWithFlags(&c->evSync, hipEventDisableTiming));
     A(hipEventCreateWithFlags(&c->evProducer, hipEventDisableTiming));
     A(hipEventCreateWithFlags(&c->evDet, hipEventDisableTiming)); A(hipEventCreateWithFlags(&c->evPrevRead, hipEventDisableTiming));
-    {   // the PnP stage is a few 1..8-workgroup kernels on a pair's critical path: its stream gets the highest priority, so that the
-        // dispatcher takes its packets ahead of queued chip-filling detection tiles of other lanes (UVO_PNP_PRIORITY=0: default priority)
+    // (Round 3 tried the highest stream priority for the PnP stream, so that its 1..8-workgroup kernels would be dispatched ahead of
+    // queued detection tiles: no effect on a fresh context -- 3792 / 4309 pairs/s with, 3774 / 4308 without, 20- / 600-step forms --
+    // and contexts created later in the same process ran at 60 % of their rate, as if the priority queues were never handed back.
+    // UVO_PNP_PRIORITY=1 brings it back for measurements.)
+    {
         int least = 0, greatest = 0;
         const char* pe = getenv("UVO_PNP_PRIORITY");
-        const bool want = !pe || atoi(pe) != 0;
-        if (want && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        if (pe && atoi(pe) != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
             A(hipStreamCreateWithPriority(&c->pnp_stream, hipStreamNonBlocking, greatest));
         else
             A(hipStreamCreateWithFlags(&c->pnp_stream, hipStreamNonBlocking));

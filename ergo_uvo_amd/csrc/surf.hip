@@ -1023,6 +1023,177 @@ __device__ __forceinline__ void describe_tail(const DescArgs& a, int im, int k, 
     if (tid < dsize) a.desc[im][(size_t)k * dsize + tid] = vec[tid] * s_scale;
 }
 
+// ------------------------------------------------------------------------------------------
+// The horizontal pass of resizeArea_ for ONE destination column of ONE window, by one wave (round 3).
+//   buf[i] = sum over the column's taps c of WIN[i][c] * alpha_c,  WIN[i][c] = img(clamp(start_y - c), clamp(start_x + i)),
+// accumulated in OpenCV's tap order.  Everything about the task is the same for every lane, so it lives in scalar registers:
+// the image is read through a buffer resource whose row offset is the SGPR `soffset` of the load (no per-tap address VALU, no
+// 64-bit adds: sub, max, min, mul on the scalar unit), the first and the last tap are peeled (their weights differ), the middle
+// taps all carry a_mid and run in batches of eight loads in flight, and the tail of the last batch is branched over rather than
+// loaded and masked.  Round 2's loop spent 16.7 VALU and 22 SALU instructions per useful tap (address add, two scalar selects
+// per tap for the weight, sixteen loads per batch whatever the tap count): the scalar unit -- one per CU -- was 73 % busy.
+// A lane owns PX adjacent pixels of each of Q chunks of 64 * PX columns: PX = 4 (aligned dword loads; Q = 1..3 covers the 739-pixel
+// windows), PX = 2 and PX = 1 for windows up to 127 / 64 pixels so that small windows do not idle three quarters of the lanes.
+// ------------------------------------------------------------------------------------------
+static const int kTapBatch = 16;           // image rows a lane of descriptor64_big has in flight
+static const int kPatchStride = 448;       // bytes of patch scratch per keypoint (441 used)
+__device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// a < b ? x : y on scalar registers (the compiler turns the C expression into VALU selects on copies of the operands)
+__device__ __forceinline__ int ssel_lt(int a, int b, int x, int y)
+{
+    int r;
+    asm volatile("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(r) : "s"(a), "s"(b), "s"(x), "s"(y) : "scc");
+    return r;
+}
+__device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+typedef __amdgpu_buffer_rsrc_t ImgRsrc;
+__device__ __forceinline__ ImgRsrc img_rsrc(const uint8_t* img, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, bytes, 0x00020000);      // raw buffer, dword data format (gfx9 family)
+}
+struct ColTask { int y0, n, h1, w; float a_first, a_mid, a_last; };      // tap t reads row clamp(y0 - t, 0, h1); n >= 1 taps
+
+template <int PX> __device__ __forceinline__ unsigned px_load(ImgRsrc rs, int voff, int soff);
+template <> __device__ __forceinline__ unsigned px_load<1>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b8(rs, voff, soff, 0); }
+template <> __device__ __forceinline__ unsigned px_load<2>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0); }
+template <> __device__ __forceinline__ unsigned px_load<4>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0); }
+
+template <int PX, int Q>
+struct AreaCol {
+    ImgRsrc rs; int w, h1;
+    int x[Q], voff[Q];
+    float acc[Q][PX];
+    // The window's in-image columns are [xlo, xhi) = [max(start_x, 0), min(start_x + win, w)); lane l owns the pixels
+    // xa + PX * (l + 64 q) .., xa = xlo rounded down to PX
+    __device__ __forceinline__ AreaCol(ImgRsrc rs_, int w_, int h_, int lane, int xa) : rs(rs_), w(w_), h1(h_ - 1)
+    {
+#pragma unroll
+        for (int q = 0; q < Q; q++) { x[q] = xa + PX * (lane + 64 * q); voff[q] = x[q] < w - PX ? x[q] : w - PX; }      // loads stay inside the row whatever the lane
+    }
+    __device__ __forceinline__ void load(const ColTask& t, int tap, unsigned (&v)[Q]) const
+    {
+        int y = t.y0 - tap; y = y > 0 ? y : 0; y = y < h1 ? y : h1;
+        const int soff = y * w;
+#pragma unroll
+        for (int q = 0; q < Q; q++) v[q] = px_load<PX>(rs, voff[q], soff);
+    }
+    __device__ __forceinline__ void first(const unsigned (&v)[Q], float alpha)      // 0.f + v * a == v * a
+    {
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+#pragma unroll
+            for (int p = 0; p < PX; p++) acc[q][p] = (float)(int)((v[q] >> (8 * p)) & 255u) * alpha;
+    }
+    __device__ __forceinline__ void accum(const unsigned (&v)[Q], float alpha)
+    {
+#pragma unroll
+        for (int q = 0; q < Q; q++)
+#pragma unroll
+            for (int p = 0; p < PX; p++) acc[q][p] += (float)(int)((v[q] >> (8 * p)) & 255u) * alpha;
+    }
+    // exactly N taps, everything static: N loads go out, then N sums (Q = 1: the columns of windows up to ~250 pixels)
+    template <int N> __device__ __forceinline__ void taps_static(const ColTask& t)
+    {
+        unsigned v[N][Q];
+#pragma unroll
+        for (int i = 0; i < N; i++) load(t, i, v[i]);
+        first(v[0], t.a_first);
+#pragma unroll
+        for (int i = 1; i < N - 1; i++) accum(v[i], t.a_mid);
+        if (N > 1) accum(v[N - 1], t.a_last);
+    }
+    // any tap count: first and last tap peeled, the middle taps in batches of B loads per chunk; a batch is always loaded whole
+    // (a tap index past the column reads the last tap's row again -- it is in flight already) and a tap past the column
+    // gets weight +0, which leaves the non-negative sums unchanged: no branch, no conditionally defined register
+    __device__ __forceinline__ void taps_any(const ColTask& t)
+    {
+        constexpr int B = Q == 1 ? 8 : (Q == 2 ? 7 : 4);
+        const int last = t.n - 1;
+        unsigned v0[Q], vl[Q], v[B][Q];
+        load(t, 0, v0);
+        load(t, last > 0 ? last : 0, vl);
+        first(v0, t.n > 0 ? t.a_first : 0.f);
+        for (int tap = 1; tap < last; tap += B) {
+#pragma unroll
+            for (int i = 0; i < B; i++) load(t, tap + i < last ? tap + i : last, v[i]);
+#pragma unroll
+            for (int i = 0; i < B; i++) accum(v[i], tap + i < last ? t.a_mid : 0.f);
+        }
+        accum(vl, last > 0 ? t.a_last : 0.f);
+    }
+    // one column, the variant by its tap count
+    __device__ __forceinline__ void taps(const ColTask& t)
+    {
+        if (Q == 1) {
+            switch (t.n) {
+            case 1: taps_static<1>(t); break;   case 2: taps_static<2>(t); break;   case 3: taps_static<3>(t); break;
+            case 4: taps_static<4>(t); break;   case 5: taps_static<5>(t); break;   case 6: taps_static<6>(t); break;
+            case 7: taps_static<7>(t); break;   case 8: taps_static<8>(t); break;   case 9: taps_static<9>(t); break;
+            case 10: taps_static<10>(t); break; case 11: taps_static<11>(t); break; case 12: taps_static<12>(t); break;
+            case 13: taps_static<13>(t); break; case 14: taps_static<14>(t); break;
+            default: taps_any(t); break;
+            }
+        } else if (Q == 2 && PX == 1) {                 // the small-window part: up to 128 columns a pixel per lane, up to 8 taps
+            switch (t.n) {
+            case 1: taps_static<1>(t); break;   case 2: taps_static<2>(t); break;   case 3: taps_static<3>(t); break;
+            case 4: taps_static<4>(t); break;   case 5: taps_static<5>(t); break;   case 6: taps_static<6>(t); break;
+            case 7: taps_static<7>(t); break;   case 8: taps_static<8>(t); break;
+            default: taps_any(t); break;
+            }
+        } else taps_any(t);
+    }
+    // The sums land at row[(x - start_x) + sh], sh = start_x & 3, which makes every lane's PX floats one aligned LDS store; window
+    // rows left / right of the image replicate the border column's sum (WIN clamps x).  The caller reads row[i + sh] for i in
+    // [0, win).  `row` holds at least win + 8 floats.
+    __device__ __forceinline__ void store(int lane, int start_x, int win_size, float* __restrict__ row) const
+    {
+        const int xlo = start_x > 0 ? start_x : 0, xhi = start_x + win_size < w ? start_x + win_size : w;
+        const int sh = start_x & 3;
+        float* dst = row + sh - start_x;
+#pragma unroll
+        for (int q = 0; q < Q; q++) {
+            if (x[q] < xhi) {
+                if (PX == 4) *reinterpret_cast<float4*>(dst + x[q]) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+                else if (PX == 2) *reinterpret_cast<float2*>(dst + x[q]) = make_float2(acc[q][0], acc[q][1]);
+                else dst[x[q]] = acc[q][0];
+            }
+        }
+        const int ilo = xlo - start_x, ihi = xhi - start_x;
+        if (ilo > 0) { const float b = row[sh + ilo]; for (int i = lane; i < ilo; i += 64) row[sh + i] = b; }
+        if (ihi < win_size) { const float b = row[sh + ihi - 1]; for (int i = ihi + lane; i < win_size; i += 64) row[sh + i] = b; }
+    }
+};
+
+template <int PX, int Q>
+__device__ __forceinline__ void area_column(ImgRsrc rs, int lane, int start_x, int win_size, const ColTask& t, float* __restrict__ row)
+{
+    const int xlo = start_x > 0 ? start_x : 0;
+    AreaCol<PX, Q> c(rs, t.w, t.h1 + 1, lane, xlo & ~(PX - 1));
+    c.taps(t);
+    c.store(lane, start_x, win_size, row);
+}
+// the column's entry of the window's resize table, held one entry per lane (entry lane % 21), as scalars; and its tap range
+__device__ __forceinline__ ColTask col_task(const AreaTab& ty, int dx, int start_y, int w, int h)
+{
+    const int sx1 = __builtin_amdgcn_readlane(ty.sx1, dx), sx2 = __builtin_amdgcn_readlane(ty.sx2, dx);
+    const float a_first = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_first), dx));
+    const float a_mid = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_mid), dx));
+    const float a_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_last), dx));
+    const bool has_first = __builtin_amdgcn_readlane((int)ty.has_first, dx) != 0, has_last = __builtin_amdgcn_readlane((int)ty.has_last, dx) != 0;
+    const int c_begin = has_first ? sx1 - 1 : sx1, c_end = has_last ? sx2 + 1 : sx2;
+    // resizeArea_'s table entry of tap cc: cc < sx1 ? a_first : (cc < sx2 ? a_mid : a_last), for the first and the last tap; selected
+    // on the bit patterns in scalar registers (written as a lambda over the floats the compiler selected between ADDRESSES of
+    // stack copies and loaded the winner back from scratch: two dependent memory round trips per column)
+    const int bf = sgpr_i(__float_as_int(a_first)), bm = sgpr_i(__float_as_int(a_mid)), bl = sgpr_i(__float_as_int(a_last));
+    ColTask t;
+    t.y0 = start_y - c_begin; t.n = c_end - c_begin; t.h1 = h - 1; t.w = w;
+    t.a_first = __int_as_float(ssel_lt(c_begin, sx1, bf, ssel_lt(c_begin, sx2, bm, bl)));
+    t.a_mid = a_mid;
+    t.a_last = __int_as_float(ssel_lt(c_end - 1, sx1, bf, ssel_lt(c_end - 1, sx2, bm, bl)));
+    return t;
+}
+
 // One workgroup per keypoint.  PATCH = cv::resize(WIN, 21x21, INTER_AREA) with
 // WIN[i][j] = img(clamp(start_y - j), clamp(start_x + i)) is evaluated separably, exactly as
 // resizeArea_ does: buf[i][dx] = sum_j WIN[i][j]*alpha_j (lanes run along i = image x, coalesced),
@@ -1038,7 +1209,7 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
     if (win_size > kSmallWin) return;                  // large windows: descriptor64_big
     extern __shared__ __align__(16) unsigned char smem_desc[];
     float* buf = reinterpret_cast<float*>(smem_desc);                 // [21][bp]
-    const int bp = win_size | 1;                                      // odd pitch: the vertical pass walks 21 columns bank-conflict-free
+    const int bp = (win_size + 3) | 1;                                // odd pitch: the vertical pass walks 21 columns bank-conflict-free (+3: area_column's alignment shift)
     __shared__ AreaTab tab[21];
     __shared__ int PATCH[21][21];
     const uint8_t* __restrict__ img = a.img[im];
@@ -1071,79 +1242,31 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
     } else {
         if (tid < 21) tab[tid] = area_tab(tid, win_size, scale);
         __syncthreads();
-        // horizontal pass of resizeArea_ (over WIN columns j = image rows), lanes along WIN rows i = image x
-        const int xlo = start_x > 0 ? start_x : 0, xhi = start_x + win_size < w ? start_x + win_size : w;     // in-image columns
-        const bool vec_ok = (w & 3) == 0 && xlo < xhi;
-        if (vec_ok) {
-            // rows 4-byte aligned: one half-wave per destination column dx, four adjacent window
-            // rows (image columns) per lane from one aligned 32-bit load per tap; taps eight at a time, accumulated in order
-            // (a tap past c_end gets weight +0: b + v*0 == b exactly, the sums being non-negative)
-            const int half = tid >> 5, hl = tid & 31;
-            // window rows left or right of the image replicate the border column (WIN clamps x): copies of the first / last sum
-            const int xa = xlo & ~3, ilo = xlo - start_x, ihi = xhi - start_x;
-            for (int dx = half; dx < 21; dx += 8) {
-                const AreaTab tx = tab[dx];
-                const int c_begin = tx.has_first ? tx.sx1 - 1 : tx.sx1;
-                const int c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
-                float* brow = buf + dx * bp;
-                for (int x4 = xa + 4 * hl; x4 < xhi; x4 += 128) {
-                    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-                    for (int c0 = c_begin; c0 < c_end; c0 += 8) {
-                        unsigned v[8];
-#pragma unroll
-                        for (int q = 0; q < 8; q++) {
-                            int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
-                            v[q] = *reinterpret_cast<const unsigned*>(img + (unsigned)(y * w + x4));
-                        }
-#pragma unroll
-                        for (int q = 0; q < 8; q++) {
-                            const int cc = c0 + q;
-                            float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
-                            alpha = cc < c_end ? alpha : 0.f;
-                            b0 += (int)(v[q] & 255u) * alpha; b1 += (int)((v[q] >> 8) & 255u) * alpha;
-                            b2 += (int)((v[q] >> 16) & 255u) * alpha; b3 += (int)(v[q] >> 24) * alpha;
-                        }
-                    }
-                    const int i = x4 - start_x;
-                    if (i >= ilo) brow[i] = b0;
-                    if (i + 1 >= ilo && i + 1 < ihi) brow[i + 1] = b1;
-                    if (i + 2 >= ilo && i + 2 < ihi) brow[i + 2] = b2;
-                    if (i + 3 >= ilo && i + 3 < ihi) brow[i + 3] = b3;
-                }
-                if (ilo > 0) { const float v = brow[ilo]; for (int i = hl; i < ilo; i += 32) brow[i] = v; }
-                if (ihi < win_size) { const float v = brow[ihi - 1]; for (int i = ihi + hl; i < win_size; i += 32) brow[i] = v; }
+        // horizontal pass of resizeArea_ (over WIN columns j = image rows), lanes along WIN rows i = image x: wave wv takes the
+        // destination columns dx = wv, wv + 4, .. through the shared column core (round 3): a column's taps are the same for
+        // every lane, so row clamps, offsets and weights are scalar work and a lane's pixel costs cvt + mul + add.  (Round 2 ran
+        // a column per half-wave with per-lane tap parameters: ~33 VALU instructions per load.)
+        {
+            const int wv = sgpr_i(tid >> 6), lane = tid & 63;
+            const AreaTab ty = tab[lane % 21];
+            const int xlo = start_x > 0 ? start_x : 0, xhi = start_x + win_size < w ? start_x + win_size : w;
+            const ImgRsrc rs = img_rsrc(img, w * h);
+            const int sx = sgpr_i(start_x), sy = sgpr_i(start_y), ws = sgpr_i(win_size);
+            if (xhi <= xlo) { for (int it = tid; it < 21 * bp; it += 256) buf[it] = 0.f; }        // cannot happen for a keypoint inside the image
+            else if (xhi - xlo <= 64) {
+                AreaCol<1, 1> c(rs, w, h, lane, xlo);
+                for (int dx = wv; dx < 21; dx += 4) { const ColTask ct = col_task(ty, dx, sy, w, h); c.taps(ct); c.store(lane, sx, ws, buf + dx * bp); }
+            } else {
+                AreaCol<1, 2> c(rs, w, h, lane, xlo);
+                for (int dx = wv; dx < 21; dx += 4) { const ColTask ct = col_task(ty, dx, sy, w, h); c.taps(ct); c.store(lane, sx, ws, buf + dx * bp); }
             }
-        } else
-        for (int it = tid; it < 21 * win_size; it += 256) {
-            int dx = it / win_size, i = it - dx * win_size;
-            const AreaTab tx = tab[dx];
-            const int c_begin = tx.has_first ? tx.sx1 - 1 : tx.sx1;
-            const int c_end = tx.has_last ? tx.sx2 + 1 : tx.sx2;
-            int x = start_x + i; x = x > 0 ? x : 0; x = x < w - 1 ? x : w - 1;
-            float b = 0.f;
-            // taps fetched eight at a time (independent loads in flight), accumulated in order
-            for (int c0 = c_begin; c0 < c_end; c0 += 8) {
-                int v[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    int y = start_y - (c0 + q); y = y > 0 ? y : 0; y = y < h - 1 ? y : h - 1;
-                    v[q] = img[(size_t)y * w + x];
-                }
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    int cc = c0 + q;
-                    float alpha = cc < tx.sx1 ? tx.a_first : (cc < tx.sx2 ? tx.a_mid : tx.a_last);
-                    if (cc < c_end) b += v[q] * alpha;
-                }
-            }
-            buf[dx * bp + i] = b;
         }
         __syncthreads();
         // vertical pass (over WIN rows i)
         for (int o = tid; o < 441; o += 256) {
             int dy = o / 21, dx = o - dy * 21;
             const AreaTab ty = tab[dy];
-            const float* col = buf + dx * bp;
+            const float* col = buf + dx * bp + (start_x & 3);
             float sum = 0.f;
             if (ty.has_first) sum += ty.a_first * col[ty.sx1 - 1];                    // the loop of resizeArea_'s table, split by weight
             for (int r = ty.sx1; r < ty.sx2; r++) sum += ty.a_mid * col[r];
@@ -1362,170 +1485,6 @@ __global__ __launch_bounds__(256) void k_descriptor_rot(DescArgs a, int w, int h
     }
 }
 
-
-// ------------------------------------------------------------------------------------------
-// The horizontal pass of resizeArea_ for ONE destination column of ONE window, by one wave (round 3).
-//   buf[i] = sum over the column's taps c of WIN[i][c] * alpha_c,  WIN[i][c] = img(clamp(start_y - c), clamp(start_x + i)),
-// accumulated in OpenCV's tap order.  Everything about the task is the same for every lane, so it lives in scalar registers:
-// the image is read through a buffer resource whose row offset is the SGPR `soffset` of the load (no per-tap address VALU, no
-// 64-bit adds: sub, max, min, mul on the scalar unit), the first and the last tap are peeled (their weights differ), the middle
-// taps all carry a_mid and run in batches of eight loads in flight, and the tail of the last batch is branched over rather than
-// loaded and masked.  Round 2's loop spent 16.7 VALU and 22 SALU instructions per useful tap (address add, two scalar selects
-// per tap for the weight, sixteen loads per batch whatever the tap count): the scalar unit -- one per CU -- was 73 % busy.
-// A lane owns PX adjacent pixels of each of Q chunks of 64 * PX columns: PX = 4 (aligned dword loads; Q = 1..3 covers the 739-pixel
-// windows), PX = 2 and PX = 1 for windows up to 127 / 64 pixels so that small windows do not idle three quarters of the lanes.
-// ------------------------------------------------------------------------------------------
-static const int kTapBatch = 16;           // image rows a lane of descriptor64_big has in flight
-static const int kPatchStride = 448;       // bytes of patch scratch per keypoint (441 used)
-__device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// a < b ? x : y on scalar registers (the compiler turns the C expression into VALU selects on copies of the operands)
-__device__ __forceinline__ int ssel_lt(int a, int b, int x, int y)
-{
-    int r;
-    asm volatile("s_cmp_lt_i32 %1, %2\n\ts_cselect_b32 %0, %3, %4" : "=s"(r) : "s"(a), "s"(b), "s"(x), "s"(y) : "scc");
-    return r;
-}
-__device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
-
-typedef __amdgpu_buffer_rsrc_t ImgRsrc;
-__device__ __forceinline__ ImgRsrc img_rsrc(const uint8_t* img, int bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, bytes, 0x00020000);      // raw buffer, dword data format (gfx9 family)
-}
-struct ColTask { int y0, n, h1, w; float a_first, a_mid, a_last; };      // tap t reads row clamp(y0 - t, 0, h1); n >= 1 taps
-
-template <int PX> __device__ __forceinline__ unsigned px_load(ImgRsrc rs, int voff, int soff);
-template <> __device__ __forceinline__ unsigned px_load<1>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b8(rs, voff, soff, 0); }
-template <> __device__ __forceinline__ unsigned px_load<2>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0); }
-template <> __device__ __forceinline__ unsigned px_load<4>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0); }
-
-template <int PX, int Q>
-struct AreaCol {
-    ImgRsrc rs; int w, h1;
-    int x[Q], voff[Q];
-    float acc[Q][PX];
-    // The window's in-image columns are [xlo, xhi) = [max(start_x, 0), min(start_x + win, w)); lane l owns the pixels
-    // xa + PX * (l + 64 q) .., xa = xlo rounded down to PX
-    __device__ __forceinline__ AreaCol(ImgRsrc rs_, int w_, int h_, int lane, int xa) : rs(rs_), w(w_), h1(h_ - 1)
-    {
-#pragma unroll
-        for (int q = 0; q < Q; q++) { x[q] = xa + PX * (lane + 64 * q); voff[q] = x[q] < w - PX ? x[q] : w - PX; }      // loads stay inside the row whatever the lane
-    }
-    __device__ __forceinline__ void load(const ColTask& t, int tap, unsigned (&v)[Q]) const
-    {
-        int y = t.y0 - tap; y = y > 0 ? y : 0; y = y < h1 ? y : h1;
-        const int soff = y * w;
-#pragma unroll
-        for (int q = 0; q < Q; q++) v[q] = px_load<PX>(rs, voff[q], soff);
-    }
-    __device__ __forceinline__ void first(const unsigned (&v)[Q], float alpha)      // 0.f + v * a == v * a
-    {
-#pragma unroll
-        for (int q = 0; q < Q; q++)
-#pragma unroll
-            for (int p = 0; p < PX; p++) acc[q][p] = (float)(int)((v[q] >> (8 * p)) & 255u) * alpha;
-    }
-    __device__ __forceinline__ void accum(const unsigned (&v)[Q], float alpha)
-    {
-#pragma unroll
-        for (int q = 0; q < Q; q++)
-#pragma unroll
-            for (int p = 0; p < PX; p++) acc[q][p] += (float)(int)((v[q] >> (8 * p)) & 255u) * alpha;
-    }
-    // exactly N taps, everything static: N loads go out, then N sums (Q = 1: the columns of windows up to ~250 pixels)
-    template <int N> __device__ __forceinline__ void taps_static(const ColTask& t)
-    {
-        unsigned v[N][Q];
-#pragma unroll
-        for (int i = 0; i < N; i++) load(t, i, v[i]);
-        first(v[0], t.a_first);
-#pragma unroll
-        for (int i = 1; i < N - 1; i++) accum(v[i], t.a_mid);
-        if (N > 1) accum(v[N - 1], t.a_last);
-    }
-    // any tap count: first and last tap peeled, the middle taps in batches of B loads per chunk; a batch is always loaded whole
-    // (a tap index past the column reads the last tap's row again -- it is in flight already) and a tap past the column
-    // gets weight +0, which leaves the non-negative sums unchanged: no branch, no conditionally defined register
-    __device__ __forceinline__ void taps_any(const ColTask& t)
-    {
-        constexpr int B = Q == 1 ? 8 : (Q == 2 ? 7 : 4);
-        const int last = t.n - 1;
-        unsigned v0[Q], vl[Q], v[B][Q];
-        load(t, 0, v0);
-        load(t, last > 0 ? last : 0, vl);
-        first(v0, t.n > 0 ? t.a_first : 0.f);
-        for (int tap = 1; tap < last; tap += B) {
-#pragma unroll
-            for (int i = 0; i < B; i++) load(t, tap + i < last ? tap + i : last, v[i]);
-#pragma unroll
-            for (int i = 0; i < B; i++) accum(v[i], tap + i < last ? t.a_mid : 0.f);
-        }
-        accum(vl, last > 0 ? t.a_last : 0.f);
-    }
-    // one column, the variant by its tap count
-    __device__ __forceinline__ void taps(const ColTask& t)
-    {
-        if (Q == 1) {
-            switch (t.n) {
-            case 1: taps_static<1>(t); break;   case 2: taps_static<2>(t); break;   case 3: taps_static<3>(t); break;
-            case 4: taps_static<4>(t); break;   case 5: taps_static<5>(t); break;   case 6: taps_static<6>(t); break;
-            case 7: taps_static<7>(t); break;   case 8: taps_static<8>(t); break;   case 9: taps_static<9>(t); break;
-            case 10: taps_static<10>(t); break; case 11: taps_static<11>(t); break; case 12: taps_static<12>(t); break;
-            case 13: taps_static<13>(t); break; case 14: taps_static<14>(t); break;
-            default: taps_any(t); break;
-            }
-        } else taps_any(t);
-    }
-    // The sums land at row[(x - start_x) + sh], sh = start_x & 3, which makes every lane's PX floats one aligned LDS store; window
-    // rows left / right of the image replicate the border column's sum (WIN clamps x).  The caller reads row[i + sh] for i in
-    // [0, win).  `row` holds at least win + 8 floats.
-    __device__ __forceinline__ void store(int lane, int start_x, int win_size, float* __restrict__ row) const
-    {
-        const int xlo = start_x > 0 ? start_x : 0, xhi = start_x + win_size < w ? start_x + win_size : w;
-        const int sh = start_x & 3;
-        float* dst = row + sh - start_x;
-#pragma unroll
-        for (int q = 0; q < Q; q++) {
-            if (x[q] < xhi) {
-                if (PX == 4) *reinterpret_cast<float4*>(dst + x[q]) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
-                else if (PX == 2) *reinterpret_cast<float2*>(dst + x[q]) = make_float2(acc[q][0], acc[q][1]);
-                else dst[x[q]] = acc[q][0];
-            }
-        }
-        const int ilo = xlo - start_x, ihi = xhi - start_x;
-        if (ilo > 0) { const float b = row[sh + ilo]; for (int i = lane; i < ilo; i += 64) row[sh + i] = b; }
-        if (ihi < win_size) { const float b = row[sh + ihi - 1]; for (int i = ihi + lane; i < win_size; i += 64) row[sh + i] = b; }
-    }
-};
-
-template <int PX, int Q>
-__device__ __forceinline__ void area_column(ImgRsrc rs, int lane, int start_x, int win_size, const ColTask& t, float* __restrict__ row)
-{
-    const int xlo = start_x > 0 ? start_x : 0;
-    AreaCol<PX, Q> c(rs, t.w, t.h1 + 1, lane, xlo & ~(PX - 1));
-    c.taps(t);
-    c.store(lane, start_x, win_size, row);
-}
-// the column's entry of the window's resize table, held one entry per lane (entry lane % 21), as scalars; and its tap range
-__device__ __forceinline__ ColTask col_task(const AreaTab& ty, int dx, int start_y, int w, int h)
-{
-    const int sx1 = __builtin_amdgcn_readlane(ty.sx1, dx), sx2 = __builtin_amdgcn_readlane(ty.sx2, dx);
-    const float a_first = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_first), dx));
-    const float a_mid = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_mid), dx));
-    const float a_last = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ty.a_last), dx));
-    const bool has_first = __builtin_amdgcn_readlane((int)ty.has_first, dx) != 0, has_last = __builtin_amdgcn_readlane((int)ty.has_last, dx) != 0;
-    const int c_begin = has_first ? sx1 - 1 : sx1, c_end = has_last ? sx2 + 1 : sx2;
-    // resizeArea_'s table entry of tap cc: cc < sx1 ? a_first : (cc < sx2 ? a_mid : a_last), for the first and the last tap; selected
-    // on the bit patterns in scalar registers (written as a lambda over the floats the compiler selected between ADDRESSES of
-    // stack copies and loaded the winner back from scratch: two dependent memory round trips per column)
-    const int bf = sgpr_i(__float_as_int(a_first)), bm = sgpr_i(__float_as_int(a_mid)), bl = sgpr_i(__float_as_int(a_last));
-    ColTask t;
-    t.y0 = start_y - c_begin; t.n = c_end - c_begin; t.h1 = h - 1; t.w = w;
-    t.a_first = __int_as_float(ssel_lt(c_begin, sx1, bf, ssel_lt(c_begin, sx2, bm, bl)));
-    t.a_mid = a_mid;
-    t.a_last = __int_as_float(ssel_lt(c_end - 1, sx1, bf, ssel_lt(c_end - 1, sx2, bm, bl)));
-    return t;
-}
 
 // small windows: one workgroup per keypoint (block bx of nbx of the launch's small-window part)
 __device__ __forceinline__ void descriptor64_small(const DescArgs& a, int w, int h, int bx, int nbx)
@@ -1916,7 +1875,10 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             bool& attr_set = attr_dev[c->device & 63];
             if (!attr_set) { UVO_HIP_TRY(c, hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set = true; }
             StageTimer t(c, ST_HESSIAN_O0);
-            hipLaunchKernelGGL(kern, dim3(total, nimg), dim3(kP23Threads), lds, c->stream, ip, w, h, static_cast<const OctavePat*>(c->d_octpat), thr, sv,
+            static const size_t lds_pad = getenv("UVO_HESS_LDS") ? (size_t)atoi(getenv("UVO_HESS_LDS")) : 0;      // measurement: fewer blocks per CU
+            const size_t lds_launch = lds_pad > lds ? lds_pad : lds;
+            if (lds_pad > lds) { static bool once = false; if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch); once = true; } }
+            hipLaunchKernelGGL(kern, dim3(total, nimg), dim3(kP23Threads), lds_launch, c->stream, ip, w, h, static_cast<const OctavePat*>(c->d_octpat), thr, sv,
                                c->d_hess_order, nbx0, nbx1, g);
             UVO_HIP_TRY(c, hipGetLastError());
         }
@@ -1957,7 +1919,7 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
         DescArgs da = { { c->img[0], c->img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
                         { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap,      // the sorted list
                         c->d_area_tabs, c->d_area_iscale, c->p.SURF_EXTENDED ? 1 : 0, { c->d_sum[0], c->d_sum[1] }, c->d_ori_w, c->d_counts + CN_ORI_DROP };
-        const size_t lds_small = sizeof(float) * 21 * (kSmallWin | 1), lds_big = sizeof(float) * 4 * kBigRow;
+        const size_t lds_small = sizeof(float) * 21 * ((kSmallWin + 3) | 1), lds_big = sizeof(float) * 4 * kBigRow;
         hipLaunchKernelGGL(k_big_sort, dim3(nimg), dim3(1024), 0, c->stream, c->d_big_par, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap, c->d_area_iscale);
         if (c->p.SURF_UPRIGHT) {
             const int nbig = 1024;                             // 8192 persistent waves for the large-window tasks (512: 80 us, 768..2048: 66-69 us)

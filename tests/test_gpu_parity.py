@@ -870,3 +870,53 @@ def test_sift_arm_of_the_l2_branch_bit_exact(ctx, oracle):
             assert np.array_equal(m["distance"].view(np.uint32), om["distance"].view(np.uint32))
     with pytest.raises(Exception):
         ctx.knn_match(np.zeros((4, 96), np.float32), np.zeros((4, 96), np.float32), dim=96)
+
+
+@pytest.mark.parametrize("kw", [dict(REPROJECTION_ERROR_THRESHOLD=0.03), dict(ITERATIONS_COUNT=30), dict(REPROJECTION_ERROR_THRESHOLD=0.03, ITERATIONS_COUNT=40),
+                                dict(MIN_NUM_3DPOINTS=100000)])
+def test_speculative_pnp_round_and_its_fallbacks(ctx, oracle, scene_small, kw):
+    """uvo_stereo_step queues the first RANSAC round on the device without the host (pose.hip: k_pnp_*_spec) and accepts it only when
+    the host's own replay of the scan agrees; otherwise the stage runs again the worker-driven way.  Cases that must fall back
+    or change the round: a 0.03-px threshold (few inliers: the adaptive count reaches past 64 hypotheses), fewer than 64
+    iterations allowed, both, and a 3-D point gate that never opens.  Every case must give the oracle's inlier sets bit for bit
+    synchronously (speculative path) AND with pairs in flight (worker path), and the two must agree bitwise."""
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    ctx.set_params(uvo.Params.stereo(SURF_MIN_HESSIAN=1500, **kw))
+    op = oracle.stereo_params(1500)
+    for k, v in kw.items():
+        setattr(op, k, v)
+    seq = [scene_small[0], scene_small[1], scene_small[2], scene_small[1], scene_small[0]]
+    ovo = oracle.StereoVO(op, rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+
+    def fields(r):
+        return (r.valid, r.n_good3d, r.n_inliers, tuple(r.rvec), tuple(r.tvec), tuple(r.t_prev_curr))
+
+    try:
+        ctx.stereo_set_depth(1)
+        ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        sync = []
+        for L, R in seq:
+            r = ctx.stereo_step(L, R, 0.05)
+            o = ovo.step(L, R, 0.05)
+            assert (r.valid, r.n_good3d, r.n_inliers) == (o.valid, o.n_good3d, o.n_inliers), kw
+            assert np.array_equal(ctx.stereo_get("inliers"), ovo.get("inliers")), kw
+            for a, b in ((r.rvec, o.rvec), (r.tvec, o.tvec)):
+                a, b = np.array(list(a)), np.array(list(b))
+                assert np.linalg.norm(a - b) <= 1e-4 * max(np.linalg.norm(b), 1e-300) or not o.n_inliers, kw
+            sync.append(fields(r))
+        ctx.stereo_set_depth(3)
+        ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        piped, sub = [], 0
+        ctx.stereo_submit(*seq[0]); sub += 1
+        piped.append(fields(ctx.stereo_collect(0.05)))
+        while len(piped) < len(seq):
+            while sub < len(seq) and sub - len(piped) < 3:
+                ctx.stereo_submit(*seq[sub]); sub += 1
+            piped.append(fields(ctx.stereo_collect(0.05)))
+        assert piped == sync, kw
+    finally:
+        ovo.close()
+        ctx.stereo_set_depth(2)
+        ctx.set_params(uvo.Params.stereo())

@@ -17,155 +17,175 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(only=None):
     import torch
     import ergo_uvo_amd as uvo
     from ergo_uvo_amd import synth
     out = {}
     # ---------------- C2 ----------------
-    W, H = 1280, 720
-    scene = synth.Scene(synth.SEEDS["C2"], W)
-    frames = [synth.stereo_pair(scene, k, W, H) for k in range(4)]
-    dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
-    rig = synth.stereo_rig(W)
-    ctx = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=5685), 0, W, H, 8192)
-    ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
-    order = [0, 1, 2, 3, 2, 1]
-    for i in range(12):
-        r = ctx.stereo_step(*dev[order[i % 6]], 0.05)
-    steps = 300
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    nv = 0
-    for i in range(steps):
-        nv += ctx.stereo_step(*dev[order[i % 6]], 0.05).valid
-    t_sync = time.perf_counter() - t0
-    DEPTH = 6
-    ctx.stereo_set_depth(DEPTH)
-    t0 = time.perf_counter()
-    sub = 0
-    for i in range(steps):
-        while sub < steps and sub - i < DEPTH:
-            ctx.stereo_submit(*dev[order[sub % 6]]); sub += 1
-        r = ctx.stereo_collect(0.05)
-    t_pipe = time.perf_counter() - t0
-    out["C2_stereo_1280x720"] = {"kpts": r.n_left, "valid": nv, "pairs_per_s_sync": round(steps / t_sync, 1),
-                                 "pairs_per_s_pipelined": round(steps / t_pipe, 1)}
-    ctx.close()
-    # ---------------- C3 synchronous latency ----------------
-    W, H = 1920, 1080
-    scene = synth.Scene(synth.SEEDS["C3"], W)
-    frames = [synth.stereo_pair(scene, k, W, H) for k in range(4)]
-    dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
-    rig = synth.stereo_rig(W)
-    ctx = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=6387), 0, W, H, 8192)
-    ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
-    for i in range(12):
-        ctx.stereo_step(*dev[order[i % 6]], 0.05)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for i in range(steps):
-        ctx.stereo_step(*dev[order[i % 6]], 0.05)
-    out["C3_stereo_1920x1080_sync"] = {"pairs_per_s_sync": round(steps / (time.perf_counter() - t0), 1)}
-    # host images (PCIe-inclusive)
-    t0 = time.perf_counter()
-    ctx.stereo_set_depth(6)
-    sub = 0
-    for i in range(steps):
-        while sub < steps and sub - i < 6:
-            ctx.stereo_submit(*frames[order[sub % 6]]); sub += 1
-        ctx.stereo_collect(0.05)
-    out["C3_stereo_1920x1080_host_images"] = {"pairs_per_s_pipelined_pcie_inclusive": round(steps / (time.perf_counter() - t0), 1)}
-    ctx.close()
-    # ---------------- C4 ----------------
-    scene = synth.Scene(synth.SEEDS["C4"], W)
-    # frames two steps apart (parallax: the essential branch) and a quarter step apart (select_estimation_method picks the
-    # homography): both RANSACs are scored, as tests/test_gpu_configs.py checks against the oracle on the same frames
-    ks = [0, 2, 4, 2, 0, 0.25, 0.5, 0.25]
-    frames = {k: synth.mono_frame(scene, k, W, H) for k in sorted(set(ks))}
-    dev = {k: torch.from_numpy(m).cuda() for k, m in frames.items()}
-    dmono = [dev[k] for k in ks]
-    order = list(range(len(ks)))
-    R0, C0 = synth.camera_pose(0)
-    rng = scene.depth_at_center(C0, R0)
-    def run_c4(p, key, note):
-        ctx = uvo.Context(p, 0, W, H, 8192)
-        ctx.mono_set_camera(rig.K_left)
+    if only in (None, "C2"):
+        W, H = 1280, 720
+        scene = synth.Scene(synth.SEEDS["C2"], W)
+        frames = [synth.stereo_pair(scene, k, W, H) for k in range(4)]
+        dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+        rig = synth.stereo_rig(W)
+        ctx = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=5685), 0, W, H, 8192)
+        ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        order = [0, 1, 2, 3, 2, 1]
+        for i in range(12):
+            r = ctx.stereo_step(*dev[order[i % 6]], 0.05)
+        steps = 300
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        nv = 0
+        for i in range(steps):
+            nv += ctx.stereo_step(*dev[order[i % 6]], 0.05).valid
+        t_sync = time.perf_counter() - t0
+        DEPTH = 6
+        ctx.stereo_set_depth(DEPTH)
+        t0 = time.perf_counter()
+        sub = 0
+        for i in range(steps):
+            while sub < steps and sub - i < DEPTH:
+                ctx.stereo_submit(*dev[order[sub % 6]]); sub += 1
+            r = ctx.stereo_collect(0.05)
+        t_pipe = time.perf_counter() - t0
+        out["C2_stereo_1280x720"] = {"kpts": r.n_left, "valid": nv, "pairs_per_s_sync": round(steps / t_sync, 1),
+                                     "pairs_per_s_pipelined": round(steps / t_pipe, 1)}
+        ctx.close()
+    if only in (None, "C3"):
+        # ---------------- C3 synchronous latency ----------------
+        W, H = 1920, 1080
+        order = [0, 1, 2, 3, 2, 1]
+        steps = 300
+        scene = synth.Scene(synth.SEEDS["C3"], W)
+        frames = [synth.stereo_pair(scene, k, W, H) for k in range(4)]
+        dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+        rig = synth.stereo_rig(W)
+        ctx = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=6387), 0, W, H, 8192)
+        ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        for i in range(12):
+            ctx.stereo_step(*dev[order[i % 6]], 0.05)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps):
+            ctx.stereo_step(*dev[order[i % 6]], 0.05)
+        out["C3_stereo_1920x1080_sync"] = {"pairs_per_s_sync": round(steps / (time.perf_counter() - t0), 1)}
+        # host images (PCIe-inclusive)
+        t0 = time.perf_counter()
+        ctx.stereo_set_depth(6)
+        sub = 0
+        for i in range(steps):
+            while sub < steps and sub - i < 6:
+                ctx.stereo_submit(*frames[order[sub % 6]]); sub += 1
+            ctx.stereo_collect(0.05)
+        out["C3_stereo_1920x1080_host_images"] = {"pairs_per_s_pipelined_pcie_inclusive": round(steps / (time.perf_counter() - t0), 1)}
+        ctx.close()
+    if only in (None, "C4", "C4v"):
+        # ---------------- C4 ----------------
+        W, H = 1920, 1080
+        rig = synth.stereo_rig(W)
+        scene = synth.Scene(synth.SEEDS["C4"], W)
+        # frames two steps apart (parallax: the essential branch) and a quarter step apart (select_estimation_method picks the
+        # homography): both RANSACs are scored, as tests/test_gpu_configs.py checks against the oracle on the same frames
+        ks = [0, 2, 4, 2, 0, 0.25, 0.5, 0.25]
+        frames = {k: synth.mono_frame(scene, k, W, H) for k in sorted(set(ks))}
+        dev = {k: torch.from_numpy(m).cuda() for k, m in frames.items()}
+        dmono = [dev[k] for k in ks]
+        order = list(range(len(ks)))
+        R0, C0 = synth.camera_pose(0)
+        rng = scene.depth_at_center(C0, R0)
+        def run_c4(p, key, note):
+            ctx = uvo.Context(p, 0, W, H, 8192)
+            ctx.mono_set_camera(rig.K_left)
+            for i in range(8):
+                r = ctx.mono_step(dmono[order[i % len(order)]], rng, 0.2)
+            steps = 96
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            nv = ne = ns = 0
+            for i in range(steps):
+                r = ctx.mono_step(dmono[order[i % len(order)]], rng, 0.2)
+                nv += r.valid; ne += r.used_essential; ns += r.success
+            out[key] = {"note": note, "kpts": r.n_kps, "matches": r.n_matches, "valid": nv, "success": ns, "essential_used": ne,
+                        "frames_per_s": round(steps / (time.perf_counter() - t0), 1)}
+            # per-stage time of the pose kernels when whole rounds of hypotheses run (HIP events; synchronous frames)
+            # the same frames through uvo_mono_submit / uvo_mono_collect, fourteen in flight (the mono pose stage is long and thin)
+            ctx.mono_reset()
+            depth = 14
+            ctx.stereo_set_depth(depth)
+            steps = 600
+            sub = 0
+            for i in range(24):
+                while sub < 24 and sub - i < depth:
+                    ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
+                r = ctx.mono_collect(0.2)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            nv = 0
+            sub = 0
+            for i in range(steps):
+                while sub < steps and sub - i < depth:
+                    ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
+                nv += ctx.mono_collect(0.2).valid
+            out[key].update({"frames_per_s_pipelined": round(steps / (time.perf_counter() - t0), 1), "valid_pipelined": nv, "pipelined_steps": steps})
+            ctx.close()
+
+        # the contract's parameters (the shipped mono column with methods = 8): 0.1 / 0.1 / 0.1 px
+        if only in (None, "C4"): run_c4(uvo.Params.mono(SURF_MIN_HESSIAN=6456, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8), "C4_mono_1920x1080_ransac",
+               "contract thresholds: essential 0.1, homography 0.1, reprojection 0.1 (mono_VO_parameters.yaml:21,26,30); quarter-step frames run both RANSACs and fail the gates (success 0)")
+        # the 1.0-px variant of rounds 1-2 (adaptive RANSAC stops after its first round; homography branch yields valid poses)
+        if only in (None, "C4v"): run_c4(uvo.Params.mono(SURF_MIN_HESSIAN=6456, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8,
+                               ESSENTIAL_THRESHOLD=1.0, HOMOGRAPHY_THRESHOLD=1.0, REPROJECTION_TOLERANCE=3.0), "C4_variant_1px_mono_1920x1080_ransac",
+               "NOT the contract's thresholds: 1.0 / 1.0 / 3.0 px")
+    if only in (None, "C1"):
+        # ---------------- C1 substitute: 640x480 mono, the shipped parameters (LMedS for E and H, min_hessian 50) ----------------
+        W1, H1 = 640, 480
+        scene = synth.Scene(synth.SEEDS["C1"], W1)
+        rig1 = synth.stereo_rig(W1)
+        ks = [0, 2, 4, 2, 0, 0.25, 0.5, 0.25]
+        frames = {k: synth.mono_frame(scene, k, W1, H1) for k in sorted(set(ks))}
+        dev = {k: torch.from_numpy(m).cuda() for k, m in frames.items()}
+        dmono = [dev[k] for k in ks]
+        R0, C0 = synth.camera_pose(0)
+        rng = scene.depth_at_center(C0, R0)
+        ctx = uvo.Context(uvo.Params.mono(), 0, W1, H1, 8192)
+        ctx.mono_set_camera(rig1.K_left)
         for i in range(8):
-            r = ctx.mono_step(dmono[order[i % len(order)]], rng, 0.2)
+            r = ctx.mono_step(dmono[i % len(ks)], rng, 0.2)
         steps = 96
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        nv = ne = ns = 0
+        nv = ne = 0
         for i in range(steps):
-            r = ctx.mono_step(dmono[order[i % len(order)]], rng, 0.2)
-            nv += r.valid; ne += r.used_essential; ns += r.success
-        out[key] = {"note": note, "kpts": r.n_kps, "matches": r.n_matches, "valid": nv, "success": ns, "essential_used": ne,
-                    "frames_per_s": round(steps / (time.perf_counter() - t0), 1)}
-        # per-stage time of the pose kernels when whole rounds of hypotheses run (HIP events; synchronous frames)
-        # the same frames through uvo_mono_submit / uvo_mono_collect, fourteen in flight (the mono pose stage is long and thin)
+            r = ctx.mono_step(dmono[i % len(ks)], rng, 0.2)
+            nv += r.valid; ne += r.used_essential
+        out["C1_substitute_mono_640x480_lmeds"] = {"kpts": r.n_kps, "matches": r.n_matches, "valid": nv, "essential_used": ne,
+                                                   "frames_per_s": round(steps / (time.perf_counter() - t0), 1)}
         ctx.mono_reset()
         depth = 14
         ctx.stereo_set_depth(depth)
         steps = 600
-        sub = 0
-        for i in range(24):
-            while sub < 24 and sub - i < depth:
-                ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
-            r = ctx.mono_collect(0.2)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        nv = 0
-        sub = 0
-        for i in range(steps):
-            while sub < steps and sub - i < depth:
-                ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
-            nv += ctx.mono_collect(0.2).valid
-        out[key].update({"frames_per_s_pipelined": round(steps / (time.perf_counter() - t0), 1), "valid_pipelined": nv, "pipelined_steps": steps})
+        for rep in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            nv = sub = 0
+            n = 28 if rep == 0 else steps
+            for i in range(n):
+                while sub < n and sub - i < depth:
+                    ctx.mono_submit(dmono[sub % len(ks)], rng); sub += 1
+                nv += ctx.mono_collect(0.2).valid
+            dt = time.perf_counter() - t0
+        out["C1_substitute_mono_640x480_lmeds"].update({"frames_per_s_pipelined": round(steps / dt, 1), "valid_pipelined": nv})
         ctx.close()
-
-    # the contract's parameters (the shipped mono column with methods = 8): 0.1 / 0.1 / 0.1 px
-    run_c4(uvo.Params.mono(SURF_MIN_HESSIAN=6456, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8), "C4_mono_1920x1080_ransac",
-           "contract thresholds: essential 0.1, homography 0.1, reprojection 0.1 (mono_VO_parameters.yaml:21,26,30); quarter-step frames run both RANSACs and fail the gates (success 0)")
-    # the 1.0-px variant of rounds 1-2 (adaptive RANSAC stops after its first round; homography branch yields valid poses)
-    run_c4(uvo.Params.mono(SURF_MIN_HESSIAN=6456, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8,
-                           ESSENTIAL_THRESHOLD=1.0, HOMOGRAPHY_THRESHOLD=1.0, REPROJECTION_TOLERANCE=3.0), "C4_variant_1px_mono_1920x1080_ransac",
-           "NOT the contract's thresholds: 1.0 / 1.0 / 3.0 px")
-    # ---------------- C1 substitute: 640x480 mono, the shipped parameters (LMedS for E and H, min_hessian 50) ----------------
-    W1, H1 = 640, 480
-    scene = synth.Scene(synth.SEEDS["C1"], W1)
-    rig1 = synth.stereo_rig(W1)
-    ks = [0, 2, 4, 2, 0, 0.25, 0.5, 0.25]
-    frames = {k: synth.mono_frame(scene, k, W1, H1) for k in sorted(set(ks))}
-    dev = {k: torch.from_numpy(m).cuda() for k, m in frames.items()}
-    dmono = [dev[k] for k in ks]
-    R0, C0 = synth.camera_pose(0)
-    rng = scene.depth_at_center(C0, R0)
-    ctx = uvo.Context(uvo.Params.mono(), 0, W1, H1, 8192)
-    ctx.mono_set_camera(rig1.K_left)
-    for i in range(8):
-        r = ctx.mono_step(dmono[i % len(ks)], rng, 0.2)
-    steps = 96
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    nv = ne = 0
-    for i in range(steps):
-        r = ctx.mono_step(dmono[i % len(ks)], rng, 0.2)
-        nv += r.valid; ne += r.used_essential
-    out["C1_substitute_mono_640x480_lmeds"] = {"kpts": r.n_kps, "matches": r.n_matches, "valid": nv, "essential_used": ne,
-                                               "frames_per_s": round(steps / (time.perf_counter() - t0), 1)}
-    ctx.mono_reset()
-    depth = 14
-    ctx.stereo_set_depth(depth)
-    steps = 600
-    for rep in range(2):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        nv = sub = 0
-        n = 28 if rep == 0 else steps
-        for i in range(n):
-            while sub < n and sub - i < depth:
-                ctx.mono_submit(dmono[sub % len(ks)], rng); sub += 1
-            nv += ctx.mono_collect(0.2).valid
-        dt = time.perf_counter() - t0
-    out["C1_substitute_mono_640x480_lmeds"].update({"frames_per_s_pipelined": round(steps / dt, 1), "valid_pipelined": nv})
-    ctx.close()
     print(json.dumps(out))
 
 
 if __name__ == "__main__":
-    main()
+    # One configuration per PROCESS: a context created after another one of the same process has been destroyed runs ~10 % below its
+    # rate (its streams no longer get hardware queues of their own), which would depress every configuration but the first.
+    if len(sys.argv) > 1:
+        main(sys.argv[1])
+    else:
+        import subprocess
+        merged = {}
+        for cfg in ("C2", "C3", "C4", "C4v", "C1"):
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), cfg], stdout=subprocess.PIPE, text=True, timeout=900)
+            if p.returncode != 0:
+                raise SystemExit(f"configuration {cfg} failed")
+            merged.update(json.loads(p.stdout.strip().splitlines()[-1]))
+        print(json.dumps(merged))
