@@ -129,7 +129,8 @@ __device__ __forceinline__ int block_compact_pos(bool keep, int* wtot, int* s_ba
 __global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const int* flag, const uvo_point2f* xc,
                                                       const int* n_p, int n_imm, int min_pts,
                                                       int* tmp_idx, double* good_pts, int* good_idx, float* opts, uvo_point2f* ipts,
-                                                      int* counts /* [1] = G */, int* counts_host /* pinned mirror of all the step's counters, or null */)
+                                                      int* counts /* [1] = G */, int* counts_host /* pinned mirror of all the step's counters, or null */,
+                                                      int force_seq /* always take the ordered sums (test hook) */)
 {
     const int n = n_p ? *n_p : n_imm;
     const int tid = threadIdx.x;
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const 
     auto publish = [&](int G) { if (tid == 0) counts[1] = G; if (counts_host && tid < CN_TOTAL) counts_host[tid] = tid == 1 ? G : counts[tid]; };
     __shared__ int wtot[16];
     __shared__ int s_base;
-    __shared__ double s_mean, s_sd3;
+    __shared__ double s_mean, s_sd3, s_rad;
     if (tid == 0) s_base = 0;
     __syncthreads();
     const bool enough = n >= min_pts;                       // VOU:203
@@ -154,6 +155,48 @@ __global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const 
         publish(0);
         return;
     }
+    // MU:35-56 computes mean and variance from a sum and a sum of squares taken in index order; what leaves this kernel is only WHO
+    // passes mean -+ 3 sigma.  Round 3: the two sums are first taken as workgroup tree sums (any order differs from the ordered sums
+    // by at most ~2 n u sum|z|, u = 2^-53), the resulting thresholds get a rigorous error radius, and unless some z lies inside that
+    // radius of a threshold -- then, or when the variance is not safely positive, the ordered chains below decide -- the set that
+    // passes is the ordered sums' set.  (The ordered chains are ~1500 dependent fp64 additions on one lane: 17-24 us of this
+    // single-workgroup kernel; UVO_EXTRACT3D_SEQ=1 / the `force_seq` argument always takes them.)
+    __shared__ int s_need_seq;
+    {
+        __shared__ double red[3][16];
+        double ps = 0, pa = 0, pq = 0;
+        for (int i = tid; i < ngood; i += 1024) { const double z = cam1[3 * tmp_idx[i] + 2]; ps += z; pa += fabs(z); pq += z * z; }
+        for (int o = 32; o > 0; o >>= 1) { ps += __shfl_down(ps, o); pa += __shfl_down(pa, o); pq += __shfl_down(pq, o); }
+        if ((tid & 63) == 0) { red[0][tid >> 6] = ps; red[1][tid >> 6] = pa; red[2][tid >> 6] = pq; }
+        __syncthreads();
+        if (tid == 0) {
+            double S = 0, A = 0, Q = 0;
+            for (int k = 0; k < 16; k++) { S += red[0][k]; A += red[1][k]; Q += red[2][k]; }
+            const double n = (double)ngood, u = 1.1102230246251565e-16;
+            const double mean = S / n, variance = Q / n - mean * mean;
+            const double sd3 = 3.0 * sqrt(variance);
+            // error radii of the ordered-vs-tree difference, generously rounded up (factor 8 in place of the 2 of the textbook bound)
+            const double dS = 8 * n * u * A, dQ = 8 * n * u * Q;
+            const double dmean = dS / n + 4 * u * fabs(mean);
+            const double dvar = dQ / n + 2 * fabs(mean) * dmean + 8 * u * (Q / n + mean * mean);
+            bool safe = force_seq == 0 && variance > 0 && variance > 64 * dvar;         // also false for NaN
+            double rad = 0;
+            if (safe) {
+                const double dsd3 = 3.0 * dvar / sqrt(variance) + 4 * u * sd3;          // d sqrt(v) <= dv / (2 sqrt(v - dv)), rounded up
+                rad = 4 * (dmean + dsd3 + 4 * u * (fabs(mean) + sd3));
+            }
+            s_mean = mean; s_sd3 = sd3; s_rad = rad; s_need_seq = safe ? 0 : 1;
+        }
+        __syncthreads();
+        if (!s_need_seq) {
+            const double hi = s_mean + s_sd3, lo = s_mean - s_sd3, rad = s_rad;
+            bool near = false;
+            for (int i = tid; i < ngood; i += 1024) { const double z = cam1[3 * tmp_idx[i] + 2]; near = near || fabs(z - hi) <= rad || fabs(z - lo) <= rad; }
+            if (near) s_need_seq = 1;                        // (benign race: every writer stores 1)
+        }
+        __syncthreads();
+    }
+    if (s_need_seq)
     {   // MU:35-56: sum and sum of squares in index order.  z and z*z are staged through LDS in chunks; the two sequential chains run
         // on two different waves (one lane each), so each issues one fp64 add per element instead of sharing a SIMD's issue slots
         __shared__ double zbuf[2048], zsq[2048];
@@ -181,6 +224,8 @@ __global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const 
             s_base = 0;
         }
     }
+    __syncthreads();
+    if (tid == 0) s_base = 0;
     __syncthreads();
     const double mean = s_mean, sd3 = s_sd3;
     for (int base = 0; base < ngood; base += 1024) {
@@ -587,6 +632,7 @@ __global__ __launch_bounds__(kFastThreads) void k_pnp_refit_spec(PnpSpecArgs a)
 
 // ---------------------------------------------------------------- host orchestration
 static Cam make_cam(const double* R, const double* t, const double* K);
+static int extract3d_force_seq() { const char* e = getenv("UVO_EXTRACT3D_SEQ"); return e && atoi(e) != 0; }      // read per call: tests flip it
 uvo_status pose_triangulate(Ctx* c, const double* P1, const double* P2, const int* d_n, int n_max)
 {
     if (n_max <= 0) return UVO_OK;
@@ -612,7 +658,7 @@ uvo_status pose_triangulate_extract3d(Ctx* c, int slot, const double* P1, const 
     StageTimer t(c, ST_EXTRACT3D);
     hipLaunchKernelGGL(k_extract3d_b, dim3(1), dim3(1024), 0, c->stream, c->d_cam1, c->d_flag, c->d_xc, d_n, n_max,
                        c->p.MIN_NUM_3DPOINTS, c->d_tmp_idx, c->d_good_pts[slot], c->d_good_idx[slot], c->d_opts[slot], c->d_ipts[slot],
-                       c->d_counts, counts_host);
+                       c->d_counts, counts_host, extract3d_force_seq());
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }
@@ -635,7 +681,7 @@ uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, 
     }
     hipLaunchKernelGGL(k_extract3d_b, dim3(1), dim3(1024), 0, c->stream, c->d_cam1, c->d_flag, c->d_xc, d_n, n_max,
                        c->p.MIN_NUM_3DPOINTS, c->d_tmp_idx, c->d_good_pts[slot], c->d_good_idx[slot], c->d_opts[slot], c->d_ipts[slot],
-                       c->d_counts, counts_host);
+                       c->d_counts, counts_host, extract3d_force_seq());
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }

@@ -266,6 +266,38 @@ def test_extract_3dpoints_bit_exact(ctx, oracle, n, noise):
     assert np.array_equal(pts.view(np.uint64), opts.view(np.uint64))
 
 
+def test_extract_3dpoints_tree_sums_and_ordered_sums_agree(ctx, oracle):
+    """extract_3Dpoints' +-3 sigma filter (MU:35-56): the kernel takes the sum and the sum of squares as tree sums, bounds their distance
+    from the reference's ordered sums, and lets the ordered chains decide only when some depth lies within that radius of a
+    threshold (pose.hip, k_extract3d_b).  Both routes (UVO_EXTRACT3D_SEQ forces the ordered one) and the oracle must keep the same
+    points -- also when all depths are equal (zero variance: the radius test cannot vouch for the tree sums), and for 6 to 3000 points."""
+    import os
+    rig, X, x1, x2, P1, P2 = _synthetic_stereo_points(3000, 17, 0.5)
+    p4_full = oracle.triangulate(P1, P2, x1, x2)
+    cases = []
+    for n in (6, 64, 1025, 3000):
+        cases.append((n, p4_full[:, :n].copy(), "plain"))
+    cases.append((500, p4_full[:, :500].copy(), "plain"))
+    flat = p4_full[:, :300].copy(); flat[2] = flat[3] * 4.0       # every depth 4.0 (in float): zero variance
+    cases.append((300, flat, "flat"))
+    try:
+        for n, p4, tag in cases:
+            args = (x1[:n], x2[:n], np.eye(3), np.zeros(3), rig.R_right, rig.t_right, rig.K_left, rig.K_right, p4)
+            want_pts, want_idx = oracle.extract_3d_points(*args, min_pts=5, tol=1e9 if tag == "flat" else 3.0)
+            for seq in ("0", "1"):
+                os.environ["UVO_EXTRACT3D_SEQ"] = seq
+                if tag == "flat":
+                    import ergo_uvo_amd as uvo
+                    ctx.set_params(uvo.Params.stereo(REPROJECTION_TOLERANCE=1e9))
+                pts, idx = ctx.extract_3Dpoints(*args)
+                if tag == "flat":
+                    ctx.set_params(uvo.Params.stereo())
+                assert np.array_equal(idx, want_idx), (tag, n, seq)
+                assert np.array_equal(pts.view(np.uint64), want_pts.view(np.uint64)), (tag, n, seq)
+    finally:
+        os.environ.pop("UVO_EXTRACT3D_SEQ", None)
+
+
 @pytest.mark.parametrize("n", [1, 257, 3000])
 def test_reproject_errors_bit_exact(ctx, oracle, n):
     rig, X, x1, x2, P1, P2 = _synthetic_stereo_points(n, 29, 0.7)
