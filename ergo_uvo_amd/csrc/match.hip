@@ -110,30 +110,55 @@ __global__ __launch_bounds__(256) void k_match_mfma(MatchBatch mb)
         // B operand: this lane's query; MFMA m of a step consumes k = 16m + 8h + j (j = 0..7) from both operands
         const int q = q0 + n;
         uint4 bhi[M], blo[M];
+        const float4* src = reinterpret_cast<const float4*>(dt);
+        constexpr int kPer = kMfmaChunk * QW / 256, kBatch = 4;
+        static_assert(kPer % kBatch == 0, "staging batches");
+        float4 vv[kBatch];
         {
-            const float4* src = reinterpret_cast<const float4*>(dq + (size_t)min(q, nq - 1) * D);
+            // the query's floats and the first staging batch of the chunk go out together: one memory wait instead of two
+            const float4* qsrc = reinterpret_cast<const float4*>(dq + (size_t)min(q, nq - 1) * D);
+            float4 qraw[2 * M];
 #pragma unroll
-            for (int m = 0; m < M; m++) split_bf16x8(src[4 * m + 2 * h], src[4 * m + 2 * h + 1], bhi[m], blo[m]);
+            for (int m = 0; m < M; m++) { qraw[2 * m] = qsrc[4 * m + 2 * h]; qraw[2 * m + 1] = qsrc[4 * m + 2 * h + 1]; }
+#pragma unroll
+            for (int u = 0; u < kBatch; u++) {
+                const int e = threadIdx.x + 256 * u, r = e / QW, c4 = e % QW;
+                vv[u] = src[(size_t)min(t0 + r, nt - 1) * QW + c4];
+            }
+#pragma unroll
+            for (int m = 0; m < M; m++) split_bf16x8(qraw[2 * m], qraw[2 * m + 1], bhi[m], blo[m]);
         }
         if (threadIdx.x == 0) s_wmax = 0;
         __syncthreads();
         {   // stage the chunk once: 128 rows x D/4 float4, coalesced, split into bf16 hi / lo; rows past the end repeat the last one
-            const float4* src = reinterpret_cast<const float4*>(dt);
-            for (int e = threadIdx.x; e < kMfmaChunk * QW; e += 256) {
-                const int r = e / QW, c4 = e % QW;
-                const float4 v = src[(size_t)min(t0 + r, nt - 1) * QW + c4];
-                uint2 hi, lo;
-                split_bf16(v.x, v.y, hi.x, lo.x); split_bf16(v.z, v.w, hi.y, lo.y);
-                uint2* row = reinterpret_cast<uint2*>(s_rows + r * kRowQuads);
-                row[c4] = hi; row[QW + c4] = lo;
-                // |t|^2 of the row (any summation order will do: the margin absorbs it): its D/4 pieces sit on D/4 adjacent lanes
-                float tn = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, __builtin_fmaf(v.z, v.z, v.w * v.w)));
-                if (QW == 32) tn += __shfl_xor(tn, 16);
-                tn += __shfl_xor(tn, 8); tn += __shfl_xor(tn, 4); tn += __shfl_xor(tn, 2); tn += __shfl_xor(tn, 1);
-                if (c4 == 0) {
-                    const bool valid = t0 + r < nt;
-                    s_tn[r] = valid ? tn : kBig;
-                    if (valid) atomicMax(&s_wmax, __float_as_int(tn));     // non-negative floats order as their bit patterns
+            // four loads in flight per thread before the first split (round 3: the loop used to wait for each of its eight -- sixteen
+            // for 128-wide rows -- loads in turn, eight memory round trips per tile; eight in flight cost a wave per SIMD)
+#pragma unroll 1
+            for (int b0 = 0; b0 < kPer; b0 += kBatch) {
+                if (b0 > 0) {
+#pragma unroll
+                    for (int u = 0; u < kBatch; u++) {
+                        const int e = threadIdx.x + 256 * (b0 + u), r = e / QW, c4 = e % QW;
+                        vv[u] = src[(size_t)min(t0 + r, nt - 1) * QW + c4];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kBatch; u++) {
+                    const int e = threadIdx.x + 256 * (b0 + u), r = e / QW, c4 = e % QW;
+                    const float4 v = vv[u];
+                    uint2 hi, lo;
+                    split_bf16(v.x, v.y, hi.x, lo.x); split_bf16(v.z, v.w, hi.y, lo.y);
+                    uint2* row = reinterpret_cast<uint2*>(s_rows + r * kRowQuads);
+                    row[c4] = hi; row[QW + c4] = lo;
+                    // |t|^2 of the row (any summation order will do: the margin absorbs it): its D/4 pieces sit on D/4 adjacent lanes
+                    float tn = __builtin_fmaf(v.x, v.x, __builtin_fmaf(v.y, v.y, __builtin_fmaf(v.z, v.z, v.w * v.w)));
+                    if (QW == 32) tn += __shfl_xor(tn, 16);
+                    tn += __shfl_xor(tn, 8); tn += __shfl_xor(tn, 4); tn += __shfl_xor(tn, 2); tn += __shfl_xor(tn, 1);
+                    if (c4 == 0) {
+                        const bool valid = t0 + r < nt;
+                        s_tn[r] = valid ? tn : kBig;
+                        if (valid) atomicMax(&s_wmax, __float_as_int(tn));     // non-negative floats order as their bit patterns
+                    }
                 }
             }
         }
@@ -399,7 +424,14 @@ static uvo_status match_launch(Ctx* c, const MatchBatch& mb, int np, int nq_max,
     {
         StageTimer t(c, ST_MATCH);
         const int tiles_max = ((nq_max + 127) / 128) * ((nt_max + kMfmaChunk - 1) / kMfmaChunk);
-        const int gmax = 768 / np;                              // three workgroups per CU over the whole launch; larger problems loop
+        // ~4.5 workgroups per CU over the whole launch, so that the ~1060 tiles of the loop's two 3000 x 3000 problems each get a
+        // workgroup of their own (768: 22.8 us -- a quarter of the workgroups walk two tiles --, 1024: 21.2, 1152: 20.3, 1536: 20.6);
+        // larger problems loop.  A tile's time is its memory round trips: the staging loop used to wait for each of its eight loads
+        // in turn; four in flight, the first batch together with the query's own loads: 20.3 -> 17.8 us (eight in flight: 128
+        // VGPRs, three waves per SIMD, fewer resident workgroups than tiles, 20.3).  Measured without effect: the four 32-row
+        // blocks of a chunk unrolled two at a time (22.5 us before the grid change; all four: 155 VGPRs, two waves per SIMD, 24.7).
+        static const int gtot = getenv("UVO_MATCH_GRID") ? atoi(getenv("UVO_MATCH_GRID")) : 1152;
+        const int gmax = gtot / np;
         dim3 grid(tiles_max < gmax ? tiles_max : gmax, np);
         static bool attr_dev[64] = {false};                   // more than 64 KB of LDS (D = 128) has to be asked for, once per device
         bool& attr_set = attr_dev[c->device & 63];
