@@ -13,7 +13,10 @@
 // Results are byte-identical to libjpeg-turbo's (tests/test_codec.py: fixtures decoded by Pillow's libjpeg-turbo).
 // Baseline / extended-sequential Huffman JPEG, 8 bit, 1 or 3 components, sampling factors 1 or 2, restart markers;
 // progressive and arithmetic-coded files are refused with UVO_INVALID_ARG (cv::imdecode would decode them on the CPU).
+// PNG payloads (round 3; sniffed by signature as cv::imdecode does): zlib inflate and the scanline filters on the host
+// (uvo_png.h), k_png_expand on the device: 1 / 2 / 4 / 8-bit grey, palette and RGB(A) samples -> grey / B G R (A) bytes.
 #include "uvo_ctx.h"
+#include "uvo_png.h"
 #include <string.h>
 #include <vector>
 
@@ -386,10 +389,67 @@ __global__ __launch_bounds__(256) void k_bayer_bggr(const uint8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------ orchestration
+// PNG samples -> what cv::imdecode(IMREAD_UNCHANGED) returns: grey (sub-byte depths scaled as png_set_expand_gray_1_2_4_to_8 does,
+// v * 255 / (2^d - 1)), palette -> B G R, RGB -> B G R, RGBA -> B G R A.  One thread per pixel.
+struct PngArgs { int w, h, depth, ctype, stride; uint8_t pal[256][4]; };
+__global__ __launch_bounds__(256) void k_png_expand(PngArgs a, const uint8_t* __restrict__ rows, uint8_t* __restrict__ out)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.w || y >= a.h) return;
+    const uint8_t* src = rows + (size_t)y * a.stride;
+    if (a.ctype == 2) {
+        uint8_t* d = out + ((size_t)y * a.w + x) * 3;
+        d[0] = src[3 * x + 2]; d[1] = src[3 * x + 1]; d[2] = src[3 * x];
+    } else if (a.ctype == 6) {
+        uint8_t* d = out + ((size_t)y * a.w + x) * 4;
+        d[0] = src[4 * x + 2]; d[1] = src[4 * x + 1]; d[2] = src[4 * x]; d[3] = src[4 * x + 3];
+    } else {
+        int v = src[x];
+        if (a.depth < 8) { const int per = 8 / a.depth, sh = (per - 1 - x % per) * a.depth; v = (src[x / per] >> sh) & ((1 << a.depth) - 1); }
+        if (a.ctype == 0) out[(size_t)y * a.w + x] = (uint8_t)(a.depth < 8 ? v * 255 / ((1 << a.depth) - 1) : v);
+        else { uint8_t* d = out + ((size_t)y * a.w + x) * 3; d[0] = a.pal[v][0]; d[1] = a.pal[v][1]; d[2] = a.pal[v][2]; }
+    }
+}
+
+static uvo_status png_decode(Ctx* c, CodecWs* ws, const uint8_t* data, size_t n, const uint8_t** d_out, int* w, int* h, int* channels)
+{
+    png::Header hd;
+    std::vector<uint8_t> idat;
+    std::string err;
+    if (!png::parse(data, n, &hd, &idat, false, &err)) { c->err = err; return UVO_INVALID_ARG; }
+    const size_t stride = png::row_bytes(hd), raw_bytes = stride * (size_t)hd.h;
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));                     // the pinned staging buffer of the previous call is free again
+    UVO_TRY(grow(c, reinterpret_cast<void**>(&ws->h_coef), &ws->coef_cap, raw_bytes, true));        // (the JPEG path's pinned / device staging buffers, reused)
+    if (!png::scanlines(hd, idat, reinterpret_cast<uint8_t*>(ws->h_coef), &err)) { c->err = err; return UVO_INVALID_ARG; }
+    { void* p = ws->d_coef; size_t cap = ws->coef_cap_dev; UVO_TRY(grow(c, &p, &cap, raw_bytes, false)); ws->d_coef = static_cast<int16_t*>(p); ws->coef_cap_dev = cap; }
+    const int ch = png::channels_out(hd);
+    { void* p = ws->d_out; UVO_TRY(grow(c, &p, &ws->out_cap, (size_t)hd.w * hd.h * ch, false)); ws->d_out = static_cast<uint8_t*>(p); }
+    UVO_HIP_TRY(c, hipMemcpyAsync(ws->d_coef, ws->h_coef, raw_bytes, hipMemcpyHostToDevice, c->stream));
+    PngArgs a;
+    a.w = hd.w; a.h = hd.h; a.depth = hd.depth; a.ctype = hd.ctype; a.stride = (int)stride;
+    memcpy(a.pal, hd.pal, sizeof(a.pal));
+    hipLaunchKernelGGL(k_png_expand, dim3((hd.w + 63) / 64, (hd.h + 3) / 4), dim3(256), 0, c->stream, a, reinterpret_cast<const uint8_t*>(ws->d_coef), ws->d_out);
+    UVO_HIP_TRY(c, hipGetLastError());
+    *w = hd.w; *h = hd.h; *channels = ch; *d_out = ws->d_out;
+    return UVO_OK;
+}
+
 uvo_status codec_decode(Ctx* c, const uint8_t* data, size_t n, int bayer, const uint8_t** d_out, int* w, int* h, int* channels)
 {
     if (!c->codec_ws) c->codec_ws = new CodecWs();
     CodecWs* ws = static_cast<CodecWs*>(c->codec_ws);
+    if (png::is_png(data, n)) {
+        UVO_TRY(png_decode(c, ws, data, n, d_out, w, h, channels));
+        if (bayer) {
+            if (*channels != 1) { c->err = "a bayer-format message must decode to one channel"; return UVO_INVALID_ARG; }
+            { void* p = ws->d_out2; UVO_TRY(grow(c, &p, &ws->out2_cap, (size_t)*w * *h * 3, false)); ws->d_out2 = static_cast<uint8_t*>(p); }
+            hipLaunchKernelGGL(k_bayer_bggr, dim3((*w + 63) / 64, (*h + 3) / 4), dim3(256), 0, c->stream, ws->d_out, *w, *h, *w, ws->d_out2);
+            UVO_HIP_TRY(c, hipGetLastError());
+            *channels = 3; *d_out = ws->d_out2;
+        }
+        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return UVO_OK;
+    }
     Jpeg j;
     memset(j.quant, 0, sizeof(j.quant));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));                     // the pinned coefficient buffer of the previous call is free again
@@ -435,6 +495,14 @@ uvo_status codec_decode(Ctx* c, const uint8_t* data, size_t n, int bayer, const 
 // Size and channel count of what codec_decode would return, from the headers alone (no entropy decoding, no device work)
 uvo_status codec_peek(Ctx* c, const uint8_t* data, size_t n, int bayer, int* w, int* h, int* channels)
 {
+    if (png::is_png(data, n)) {
+        png::Header hd; std::string err;
+        if (!png::parse(data, n, &hd, nullptr, true, &err)) { c->err = err; return UVO_INVALID_ARG; }
+        const int ch = png::channels_out(hd);
+        if (bayer && ch != 1) { c->err = "a bayer-format message must decode to one channel"; return UVO_INVALID_ARG; }
+        *w = hd.w; *h = hd.h; *channels = bayer ? 3 : ch;
+        return UVO_OK;
+    }
     Jpeg j;
     memset(j.quant, 0, sizeof(j.quant));
     UVO_TRY(jpeg_entropy_decode(c, nullptr, data, n, &j, true));

@@ -1191,7 +1191,6 @@ extern "C" uvo_status uvo_decode_image(uvo_ctx* c, const uint8_t* data, size_t n
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_decode_image"));
     const std::string fmt = format ? format : "";
-    if (fmt.find("png") != std::string::npos) return fail(c, UVO_INVALID_ARG, "uvo_decode_image: PNG payloads are not supported (JPEG only)");
     const int bayer = fmt.find("bayer") != std::string::npos ? 1 : 0;
     if (!out) return codec_peek(c, data, n, bayer, w, h, channels);      // size query: the headers only, nothing is decoded
     const uint8_t* d_res = nullptr;

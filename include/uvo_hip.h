@@ -243,11 +243,15 @@ uvo_status uvo_get_image(uvo_ctx* c, const uint8_t* rgb, int w, int h, int strid
 
 /* ---- compressed-image ingest: from_ros_to_cv_image (math_utility.h -> uvo_libraries/src/math_utility.cpp:154-173) =
  * cv_bridge::toCvCopy(sensor_msgs/CompressedImage) -> cv::imdecode, then cv::cvtColor(COLOR_BayerBGGR2BGR) when the message's
- * `format` contains "bayer".  data: the message payload (a baseline / sequential Huffman JPEG, 8 bit, 1 or 3 components,
- * sampling factors <= 2; progressive, arithmetic-coded and PNG payloads are refused with UVO_INVALID_ARG).  The entropy
- * decoding runs on the host, dequantisation + IDCT + chroma upsampling + colour conversion (+ demosaicing) on the device,
- * byte-identical to libjpeg's defaults (JDCT_ISLOW, fancy upsampling).  out: h x w x channels u8 (BGR order for 3 channels) in host
- * or device memory per out_mem; out = NULL only reports the size.  Feed the result to uvo_get_image. */
+ * `format` contains "bayer".  data: the message payload, recognised by its signature as cv::imdecode does:
+ *   JPEG  baseline / sequential Huffman, 8 bit, 1 or 3 components, sampling factors <= 2 (progressive and arithmetic-coded files are
+ *         refused with UVO_INVALID_ARG).  Entropy decoding on the host; dequantisation + IDCT + chroma upsampling + colour
+ *         conversion on the device, byte-identical to libjpeg's defaults (JDCT_ISLOW, fancy upsampling).
+ *   PNG   non-interlaced; grey and palette at 1 / 2 / 4 / 8 bits, RGB and RGBA at 8 bits -> 1, 3, 3, 4 channels as
+ *         imdecode(IMREAD_UNCHANGED) returns them (16-bit samples, grey + alpha, palettes with tRNS and Adam7 are refused).  zlib
+ *         inflate and the scanline filters on the host, sample expansion and channel order on the device.
+ * A "bayer" message is demosaiced on the device after decoding.  out: h x w x channels u8 (B G R [A] order) in host or device
+ * memory per out_mem; out = NULL only reports the size (headers only, nothing is decoded).  Feed the result to uvo_get_image. */
 uvo_status uvo_decode_image(uvo_ctx* c, const uint8_t* data, size_t n, const char* format, uint8_t* out, size_t cap_bytes, int out_mem,
                             int* w, int* h, int* channels);
 /* cv::cvtColor(src, dst, COLOR_BayerBGGR2BGR) of an 8-bit mosaic (bilinear; borders copy their neighbour) */

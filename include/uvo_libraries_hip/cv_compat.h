@@ -30,7 +30,7 @@ namespace uvocv {
 // depth codes and type packing as in opencv2/core/hal/interface.h
 constexpr int CV_8U = 0, CV_32S = 4, CV_32F = 5, CV_64F = 6;
 constexpr int make_type(int depth, int cn) { return (depth & 7) + ((cn - 1) << 3); }
-constexpr int CV_8UC1 = make_type(CV_8U, 1), CV_8UC3 = make_type(CV_8U, 3), CV_32SC1 = make_type(CV_32S, 1), CV_32FC1 = make_type(CV_32F, 1),
+constexpr int CV_8UC1 = make_type(CV_8U, 1), CV_8UC3 = make_type(CV_8U, 3), CV_8UC4 = make_type(CV_8U, 4), CV_32SC1 = make_type(CV_32S, 1), CV_32FC1 = make_type(CV_32F, 1),
               CV_32FC2 = make_type(CV_32F, 2), CV_64FC1 = make_type(CV_64F, 1);
 
 struct Point2f { float x = 0, y = 0; Point2f() = default; Point2f(float x_, float y_) : x(x_), y(y_) {} };

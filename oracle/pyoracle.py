@@ -494,6 +494,21 @@ def jpeg_decode(data: bytes) -> np.ndarray:
     return out[..., 0] if ch.value == 1 else out
 
 
+def png_decode(data: bytes) -> np.ndarray:
+    """cv::imdecode(IMREAD_UNCHANGED) of an 8-bit PNG: H x W grey, H x W x 3 BGR (RGB or palette) or H x W x 4 BGRA."""
+    buf = np.frombuffer(data, np.uint8)
+    w, h, ch = C.c_int(0), C.c_int(0), C.c_int(0)
+    lib().orc_png_decode.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    rc = lib().orc_png_decode(_p(buf), len(buf), None, 0, C.byref(w), C.byref(h), C.byref(ch))
+    if rc != 0:
+        raise ValueError(f"png_decode: error {rc}")
+    out = np.empty((h.value, w.value, ch.value), np.uint8)
+    rc = lib().orc_png_decode(_p(buf), len(buf), _p(out), out.nbytes, C.byref(w), C.byref(h), C.byref(ch))
+    if rc != 0:
+        raise ValueError(f"png_decode: error {rc}")
+    return out[..., 0] if ch.value == 1 else out
+
+
 def bayer_bggr2bgr(bayer: np.ndarray) -> np.ndarray:
     bayer = _c(bayer, np.uint8); h, w = bayer.shape
     out = np.empty((h, w, 3), np.uint8)

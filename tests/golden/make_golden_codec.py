@@ -64,6 +64,40 @@ def harsh_picture(rng, h, w, c):
     return np.clip(a, 0, 255).astype(np.uint8)
 
 
+def make_png(rng):
+    """tests/golden/png_cases.npz: PNG streams written by Pillow and the pixels PILLOW's own decoder (zlib) reads back from them,
+    in cv::imdecode(IMREAD_UNCHANGED)'s channel order -- PNG is lossless and its decoding is fixed by the specification, so this
+    pins the oracle's and the product's inflate / filter / expansion code to an independent implementation."""
+    cases = [("grey8", 33, 71, "L", {}), ("rgb8", 64, 48, "RGB", {}), ("rgb8_l9", 121, 97, "RGB", dict(compress_level=9, optimize=True)),
+             ("rgb8_stored", 20, 30, "RGB", dict(compress_level=0)), ("rgba8", 40, 56, "RGBA", {}), ("pal8", 50, 50, "P64", {}),
+             ("pal4", 37, 53, "P11", {}), ("bilevel", 17, 70, "1", {}), ("grey4", 24, 31, "L", dict(bits=4)), ("tiny", 1, 1, "RGB", {}),
+             ("photo", 120, 160, "PHOTO", dict(compress_level=6))]
+    out = {"names": np.array([c[0] for c in cases])}
+    for name, h, w, mode, kw in cases:
+        a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        if mode == "PHOTO":
+            a = np.dstack([picture(rng, h, w, 3), a[..., 3:]]); mode = "RGB"           # smooth content: exercises the Paeth / Average filters
+        img = {"L": lambda: Image.fromarray(a[..., 0]), "RGB": lambda: Image.fromarray(a[..., :3]), "RGBA": lambda: Image.fromarray(a),
+               "P64": lambda: Image.fromarray(a[..., :3]).quantize(64), "P11": lambda: Image.fromarray(a[..., :3]).quantize(11),
+               "1": lambda: Image.fromarray(a[..., 0] > 127)}[mode]()
+        b = io.BytesIO()
+        img.save(b, "PNG", **kw)
+        data = b.getvalue()
+        ref = Image.open(io.BytesIO(data))
+        if ref.mode == "P":
+            px = np.asarray(ref.convert("RGB"))[..., ::-1]
+        elif ref.mode in ("L", "1"):
+            px = np.asarray(ref.convert("L"))
+        elif ref.mode == "RGB":
+            px = np.asarray(ref)[..., ::-1]
+        else:
+            px = np.asarray(ref)[..., [2, 1, 0, 3]]
+        out[name + "_png"] = np.frombuffer(data, np.uint8)
+        out[name + "_px"] = np.ascontiguousarray(px)
+    np.savez(os.path.join(HERE, "png_cases.npz"), **out)
+    print("wrote png_cases.npz:", sum(v.nbytes for v in out.values() if hasattr(v, "nbytes")), "bytes")
+
+
 def main():
     assert features.check("libjpeg_turbo"), "Pillow without libjpeg-turbo"
     rng = np.random.default_rng(20250911)
@@ -93,6 +127,7 @@ def main():
         out[name + "_rgb"] = decode_scalar(data)
     out["names"] = np.array([c[0] for c in cases] + [c[0] for c in sat])
     np.savez(os.path.join(HERE, "jpeg_cases.npz"), **out)
+    make_png(rng)
     print("wrote jpeg_cases.npz:", sum(v.nbytes for v in out.values() if hasattr(v, "nbytes")), "bytes")
 
 

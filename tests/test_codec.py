@@ -4,7 +4,10 @@
 The JPEG decode is the one component whose oracle is PINNED to a real third-party implementation: tests/golden/jpeg_cases.npz
 holds JPEG streams and the pixels libjpeg-turbo (Pillow's) decoded from them; the oracle and the HIP path must reproduce them
 byte for byte.  When Pillow is importable the CPU test also cross-checks a sweep of sizes / samplings / qualities live.
-Bayer demosaicing has no third-party witness here (unpinned, recalled OpenCV behaviour): HIP <-> oracle + analytic cases."""
+Bayer demosaicing has no third-party witness here (unpinned, recalled OpenCV behaviour): HIP <-> oracle + analytic cases.
+PNG payloads (round 3) are lossless and their decoding is fixed by the specification: tests/golden/png_cases.npz holds streams and
+the pixels Pillow's own decoder (zlib) reads from them -- a second third-party pin; the oracle, the host half of the product's
+decoder (compiled for the CPU) and the HIP path must reproduce them byte for byte."""
 import io
 import os
 
@@ -45,6 +48,117 @@ def test_oracle_jpeg_equals_libjpeg_turbo_live(oracle):
                 assert np.array_equal(oracle.jpeg_decode(b.getvalue()), _bgr(ref)), (h, w, ss, q)
                 n += 1
     assert n == 54
+
+
+@pytest.fixture(scope="module")
+def png_cases():
+    return np.load(os.path.join(ROOT, "tests", "golden", "png_cases.npz"))
+
+
+def _png_sweep():
+    """(tag, bytes, expected pixels in imdecode's channel order) for a sweep of sizes, kinds and compression levels, via Pillow."""
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(8)
+    for (h, w) in [(1, 1), (7, 13), (121, 97), (240, 320)]:
+        for mode in ("L", "RGB", "RGBA", "P64", "P11", "1", "L4"):
+            for kw in ({}, dict(compress_level=0), dict(compress_level=9, optimize=True)):
+                a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+                if kw:
+                    a[..., :3] = (a[..., :3] // 32) * 32
+                img = {"L": lambda: PIL.fromarray(a[..., 0]), "L4": lambda: PIL.fromarray(a[..., 0]), "RGB": lambda: PIL.fromarray(a[..., :3]),
+                       "RGBA": lambda: PIL.fromarray(a), "P64": lambda: PIL.fromarray(a[..., :3]).quantize(64),
+                       "P11": lambda: PIL.fromarray(a[..., :3]).quantize(11), "1": lambda: PIL.fromarray(a[..., 0] > 127)}[mode]()
+                b = io.BytesIO()
+                img.save(b, "PNG", **(dict(kw, bits=4) if mode == "L4" else kw))
+                ref = PIL.open(io.BytesIO(b.getvalue()))
+                if ref.mode == "P":
+                    px = np.asarray(ref.convert("RGB"))[..., ::-1]
+                elif ref.mode in ("L", "1"):
+                    px = np.asarray(ref.convert("L"))
+                elif ref.mode == "RGB":
+                    px = np.asarray(ref)[..., ::-1]
+                else:
+                    px = np.asarray(ref)[..., [2, 1, 0, 3]]
+                yield (h, w, mode, tuple(kw.items())), b.getvalue(), np.ascontiguousarray(px)
+
+
+def test_oracle_png_equals_pillow_fixture_and_live(png_cases, oracle):
+    for name in png_cases["names"]:
+        got = oracle.png_decode(bytes(png_cases[f"{name}_png"]))
+        assert got.shape == png_cases[f"{name}_px"].shape and np.array_equal(got, png_cases[f"{name}_px"]), name
+    n = 0
+    for tag, data, px in _png_sweep():
+        got = oracle.png_decode(data)
+        assert got.shape == px.shape and np.array_equal(got, px), tag
+        n += 1
+    assert n == 84
+
+
+def _png_with(data: bytes, **ihdr):
+    """the same PNG with IHDR fields replaced (and the chunk's CRC recomputed)"""
+    import struct
+    import zlib
+    b = bytearray(data)
+    off = {"depth": 24, "ctype": 25, "interlace": 28}
+    for k, v in ihdr.items():
+        b[off[k]] = v
+    b[29:33] = struct.pack(">I", zlib.crc32(bytes(b[12:29])))
+    return bytes(b)
+
+
+def test_oracle_png_refusals(png_cases, oracle):
+    rgb = bytes(png_cases["rgb8_png"])
+    for bad in (_png_with(rgb, interlace=1), _png_with(rgb, depth=16), _png_with(rgb, ctype=4), rgb[:len(rgb) // 2],
+                rgb[:60] + bytes([rgb[60] ^ 0x40]) + rgb[61:]):
+        with pytest.raises(ValueError):
+            oracle.png_decode(bad)
+
+
+def test_product_png_host_half_on_cpu(png_cases, tmp_path):
+    """ergo_uvo_amd/csrc/uvo_png.h (container, inflate, filters) is plain C++: compiled with g++ and run here, its unfiltered
+    samples must be the ones Pillow reads (8-bit kinds compared sample for sample; sub-byte kinds after unpacking)."""
+    import shutil
+    import struct
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "png_host")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-o", exe, os.path.join(ROOT, "tests", "cpp", "png_host.cpp")])
+    PIL = pytest.importorskip("PIL.Image")
+
+    def run(data):
+        (tmp_path / "a.png").write_bytes(data)
+        r = subprocess.run([exe, str(tmp_path / "a.png"), str(tmp_path / "a.bin")], capture_output=True, text=True)
+        if r.returncode != 0:
+            return None, r.stderr
+        raw = (tmp_path / "a.bin").read_bytes()
+        w, h, depth, ctype, stride = struct.unpack("<5i", raw[:20])
+        return (w, h, depth, ctype, np.frombuffer(raw[20:], np.uint8).reshape(h, stride)), ""
+
+    n = 0
+    for tag, data, px in _png_sweep():
+        got, err = run(data)
+        assert got is not None, (tag, err)
+        w, h, depth, ctype, rows = got
+        ref = PIL.open(io.BytesIO(data))
+        if depth == 8:
+            assert np.array_equal(rows, np.asarray(ref).reshape(h, -1)), tag               # palette images: the indices
+        else:
+            per = 8 // depth
+            x = np.arange(w)
+            samples = (rows[:, x // per] >> ((per - 1 - x % per) * depth)) & ((1 << depth) - 1)
+            want = np.asarray(ref).astype(np.uint8) if ref.mode in ("P", "1") else None
+            if want is not None:
+                assert np.array_equal(samples, want), tag
+            else:                                                                               # 4-bit grey: Pillow hands back the expanded value
+                assert np.array_equal(samples * 255 // ((1 << depth) - 1), np.asarray(ref.convert("L"))), tag
+        n += 1
+    assert n == 84
+    rgb = bytes(png_cases["rgb8_png"])
+    for bad, word in ((_png_with(rgb, interlace=1), "interlaced"), (_png_with(rgb, depth=16), "16-bit"), (_png_with(rgb, ctype=4), "alpha"),
+                      (rgb[:len(rgb) // 2], "truncated"), (rgb[:60] + bytes([rgb[60] ^ 0x40]) + rgb[61:], "CRC")):
+        got, err = run(bad)
+        assert got is None and word in err, (word, err)
 
 
 def test_oracle_refuses_what_it_does_not_decode(cases, oracle):
@@ -119,8 +233,34 @@ def test_hip_jpeg_full_hd_and_feeds_get_image(ctx, oracle):
     assert np.array_equal(a, oracle.get_image(want, 640, Ks, np.zeros(4), newK, True, 3))
     with pytest.raises(uvo.UvoError):
         ctx.decode_image(b"not a jpeg at all")
-    with pytest.raises(uvo.UvoError):
-        ctx.decode_image(b.getvalue(), "rgb8; png compressed")
+
+
+@pytest.mark.gpu
+def test_hip_png_equals_pillow_fixture_and_live(png_cases, ctx, oracle):
+    """PNG payloads through uvo_decode_image: host inflate + filters, k_png_expand on the device; the size query parses headers only."""
+    import ergo_uvo_amd as uvo
+    for name in png_cases["names"]:
+        got = ctx.decode_image(bytes(png_cases[f"{name}_png"]), "rgb8; png compressed")
+        assert got.shape == png_cases[f"{name}_px"].shape and np.array_equal(got, png_cases[f"{name}_px"]), name
+    for tag, data, px in _png_sweep():
+        got = ctx.decode_image(data, "png")
+        assert got.shape == px.shape and np.array_equal(got, px), tag
+    # full HD, into device memory, and a bayer mosaic carried as a grey PNG (MU:161-164)
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(21)
+    rgb = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    rgb[200:800] = (rgb[200:800] // 64) * 64
+    b = io.BytesIO(); PIL.fromarray(rgb).save(b, "PNG", compress_level=3)
+    dev = ctx.decode_image(b.getvalue(), "rgb8; png compressed", device_out=True)
+    assert np.array_equal(dev.cpu().numpy(), rgb[..., ::-1])
+    mosaic = rng.integers(0, 256, (96, 130), dtype=np.uint8)
+    b = io.BytesIO(); PIL.fromarray(mosaic).save(b, "PNG")
+    assert np.array_equal(ctx.decode_image(b.getvalue(), "bayer_bggr8; png compressed bayer_bggr8"), oracle.bayer_bggr2bgr(mosaic))
+    good = bytes(png_cases["rgb8_png"])
+    for bad in (_png_with(good, interlace=1), _png_with(good, depth=16), _png_with(good, ctype=4), good[:len(good) // 2],
+                good[:60] + bytes([good[60] ^ 0x40]) + good[61:]):
+        with pytest.raises(uvo.UvoError):
+            ctx.decode_image(bad, "rgb8; png compressed")
 
 
 @pytest.mark.gpu
