@@ -284,3 +284,37 @@ def test_c5_five_ranks_on_one_device_match_single_gpu_streams(tmp_path):
     form of the same path runs on CPU in tests/test_multirank.py.)"""
     line = _bench_ranks_vs_single_gpu_streams(tmp_path, 5, ["--backend", "gloo", "--share-devices", "--depth", "2"], "C5")
     assert line["host"]["cores_of_this_rank"] >= 1
+
+
+def test_submit_blocks_for_at_most_a_detector_stage():
+    """uvo_stereo_submit paces the pipeline on the calling thread: before it queues a pair's kernels it waits (polling) for the end
+    of the stage A submitted two pairs earlier, so a "submit" may hold its caller for up to about one
+    stage A -- ~0.5 ms at C3 -- and never for a pair's whole latency.  A node that calls it from a 20 Hz loop
+    (visual_odometry.h:526-530) has 50 ms per frame.  Pinned here: over a pipelined C3 run no submit call takes longer than 5 ms,
+    the median is below 1 ms, and collect() after a full pipeline returns the oldest pair without a long wait."""
+    import time
+    import torch
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    import bench
+    W, H = bench.WIDTH, bench.HEIGHT
+    scene = synth.Scene(synth.SEEDS["C3"], W)
+    dev = [tuple(torch.from_numpy(x).cuda() for x in synth.stereo_pair(scene, k, W, H)) for k in range(3)]
+    rig = synth.stereo_rig(W)
+    ctx = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=bench.MIN_HESSIAN_C3), 0, W, H, 8192)
+    try:
+        ctx.stereo_set_depth(6)
+        ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        order = [0, 1, 2, 1]
+        t_sub = []
+        sub = 0
+        n = 120
+        for i in range(n):
+            while sub < n and sub - i < 6:
+                a = time.perf_counter(); ctx.stereo_submit(*dev[order[sub % 4]]); t_sub.append(time.perf_counter() - a); sub += 1
+            ctx.stereo_collect(0.05)
+        t = np.array(t_sub[12:]) * 1e3          # after the synchronous init pair and the first fill
+        assert t.max() < 5.0, t.max()
+        assert np.median(t) < 1.0, np.median(t)
+    finally:
+        ctx.close()
