@@ -185,6 +185,28 @@ class Context:
         self._check(self._lib.uvo_surf_detect(self._h, p, w, h, w, mem, _p(kps), _p(desc), self.max_kpts, C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
+    def sift_detect(self, img, nfeatures=10000, n_octave_layers=3, contrast_threshold=0.03, edge_threshold=10.0, sigma=1.6, cap=None):
+        """detect_features, FEATURE_DETECTOR == "SIFT" (VO_utility.cpp:107-112): SIFT::create(10000, 3, 0.03, 10, 1.6)->detectAndCompute.
+        Returns (keypoints, n x 128 float descriptors)."""
+        h, w = img.shape[-2], img.shape[-1]
+        p, mem, keep = _ptr_mem(img, np.uint8)
+        cap = int(cap if cap is not None else max(self.max_kpts, nfeatures if nfeatures > 0 else 0))
+        n = C.c_int(0)
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 128), np.float32)
+        self._order_after_producer(img)
+        self._check(self._lib.uvo_sift_detect(self._h, p, w, h, w, mem, int(nfeatures), int(n_octave_layers), float(contrast_threshold),
+                                              float(edge_threshold), float(sigma), _p(kps), _p(desc), cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def sift_layer(self, octave: int, layer: int, dog: bool = False):
+        """Test hook: a Gaussian / DoG layer of the last sift_detect (octave 0 = the doubled image)."""
+        w, h = C.c_int(0), C.c_int(0)
+        self._check(self._lib.uvo_sift_layer(self._h, int(octave), int(layer), int(bool(dog)), None, 0, C.byref(w), C.byref(h)))
+        out = np.empty((h.value, w.value), np.float32)
+        self._check(self._lib.uvo_sift_layer(self._h, int(octave), int(layer), int(bool(dog)), _p(out), out.size, C.byref(w), C.byref(h)))
+        return out
+
     def integral(self, img):
         h, w = img.shape
         p, mem, keep = _ptr_mem(img, np.uint8)

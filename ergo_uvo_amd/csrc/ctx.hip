@@ -286,6 +286,7 @@ static void destroy_one(uvo_ctx* c)
     mono_ws_free(c);
     pre_ws_free(c);
     codec_ws_free(c);
+    sift_ws_free(c);
     void* ptrs[] = { c->d_hess_order, c->d_surv, c->d_octpat, c->d_colpart, c->d_DW, c->d_rank, c->d_big_par, c->d_big_patch, c->d_area_tabs, c->d_area_iscale, c->d_ori_w, c->d_mpart, c->d_mscratch, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
                      c->d_flag, c->d_tmp_idx, c->d_good_pts[0], c->d_good_pts[1], c->d_good_idx[0], c->d_good_idx[1], c->d_opts[0], c->d_opts[1],
                      c->d_ipts[0], c->d_ipts[1], c->d_counts, c->d_countsB, c->d_subsets, c->d_models,
@@ -395,6 +396,24 @@ extern "C" uvo_status uvo_surf_detect(uvo_ctx* c, const uint8_t* gray, int w, in
     if (desc && cnt) UVO_HIP_TRY(c, hipMemcpyAsync(desc, c->det[0].desc, sizeof(float) * dsize * cnt, hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return UVO_OK;
+}
+
+extern "C" uvo_status uvo_sift_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int nfeatures, int n_octave_layers,
+                                      double contrast_threshold, double edge_threshold, double sigma, uvo_keypoint* kps, float* desc, int cap, int* n)
+{
+    if (!c || !n || !gray) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_sift_detect"));
+    UVO_TRY(wait_for_producer(c, c, mem));
+    return sift_detect(c, gray, w, h, stride, mem, nfeatures, n_octave_layers, contrast_threshold, edge_threshold, sigma, kps, desc, cap, n);
+}
+
+extern "C" uvo_status uvo_sift_layer(uvo_ctx* c, int octave, int layer, int dog, float* out, int cap_floats, int* w, int* h)
+{
+    if (!c || !w || !h) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_sift_layer"));
+    return sift_layer(c, octave, layer, dog, out, cap_floats, w, h);
 }
 
 extern "C" uvo_status uvo_integral(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int32_t* sum)

@@ -201,6 +201,7 @@ struct Ctx {
     void* mono_ws = nullptr;                     // MonoWs*, allocated on first use
     void* pre_ws = nullptr;                      // PreWs* (get_image), allocated on first use
     void* codec_ws = nullptr;                    // CodecWs* (uvo_decode_image), allocated on first use
+    void* sift_ws = nullptr;                     // SiftWs* (uvo_sift_detect), allocated on first use
     double mono_K[9]; bool mono_cam_set = false, mono_initialized = false, mono_pipelined = false;
     int mono_use_essential = 1;                  // the reference's global `use_essential` (VOH:89)
     double mono_R[9] = {1,0,0,0,1,0,0,0,1}, mono_t[3] = {0,0,0}, mono_SF = 1.0;
@@ -294,6 +295,11 @@ void codec_ws_free(Ctx* c);
 uvo_status codec_decode(Ctx* c, const uint8_t* data, size_t n, int bayer, const uint8_t** d_out, int* w, int* h, int* channels);
 uvo_status codec_peek(Ctx* c, const uint8_t* data, size_t n, int bayer, int* w, int* h, int* channels);
 uvo_status codec_bayer(Ctx* c, const uint8_t* bayer, int w, int h, int stride, int mem, const uint8_t** d_out);
+// sift.hip
+void sift_ws_free(Ctx* c);
+uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int nfeatures, int nL, double contrastThreshold,
+                       double edgeThreshold, double sigma, uvo_keypoint* kps, float* desc, int cap, int* n_out);
+uvo_status sift_layer(Ctx* c, int octave, int layer, int dog, float* out, int cap_floats, int* ow, int* oh);
 // mono.hip
 void mono_ws_free(Ctx* c);
 uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K, int method,

@@ -295,21 +295,27 @@ Mat get_image(const Mat& current_img, const Mat& cameraMatrix, const Mat& distor
     return out;
 }
 
-// VOU:91-126 (SURF branch): SURF::create(...)->detectAndCompute(img, noArray(), keypoints, descriptors)
+// VOU:91-126: the "SURF" branch (SURF::create(...)->detectAndCompute) and the "SIFT" branch (SIFT::create(10000, 3, 0.03, 10, 1.6)->
+// detectAndCompute, VOU:107-112).  "AKAZE" / "ORB" are not served (their detectors are not built).
 void detect_features(Mat img, vector<KeyPoint>& keypoints, Mat& descriptors)
 {
-    if (FEATURE_DETECTOR != "SURF") throw uvo_hip::Error(UVO_INVALID_ARG, "detect_features: FEATURE_DETECTOR must be \"SURF\"");
+    const bool sift = FEATURE_DETECTOR == "SIFT";
+    if (!sift && FEATURE_DETECTOR != "SURF") throw uvo_hip::Error(UVO_INVALID_ARG, "detect_features: FEATURE_DETECTOR must be \"SURF\" or \"SIFT\"");
     require(!img.empty() && img.type() == CV_8UC1, "detect_features: CV_8UC1 image expected");
     uvo_ctx* c = ctx_now();
-    const int cap = g.max_kpts;
+    const int cap = sift ? std::max(g.max_kpts, 10000) : g.max_kpts;       // retainBest(10000) bounds SIFT's output (ties at the cut aside)
     vector<uvo_keypoint> kps((size_t)cap);
-    const int dsize = SURF_EXTENDED ? 128 : 64;      // SURF::descriptorSize()
+    const int dsize = sift ? 128 : (SURF_EXTENDED ? 128 : 64);             // descriptorSize()
     vector<float> desc((size_t)cap * dsize);
     int n = 0;
     // rows may be padded in a real cv::Mat: pass the row pitch
     const int stride = img.rows > 1 ? (int)(img.ptr<uint8_t>(1) - img.ptr<uint8_t>(0)) : img.cols;
-    SHIM_TRY(uvo_surf_detect(c, img.ptr<uint8_t>(0), img.cols, img.rows, stride, UVO_MEM_HOST, kps.data(), desc.data(), cap, &n),
-             "uvo_surf_detect");
+    if (sift)
+        SHIM_TRY(uvo_sift_detect(c, img.ptr<uint8_t>(0), img.cols, img.rows, stride, UVO_MEM_HOST, 10000, 3, 0.03, 10, 1.6, kps.data(), desc.data(), cap, &n),
+                 "uvo_sift_detect");
+    else
+        SHIM_TRY(uvo_surf_detect(c, img.ptr<uint8_t>(0), img.cols, img.rows, stride, UVO_MEM_HOST, kps.data(), desc.data(), cap, &n),
+                 "uvo_surf_detect");
     keypoints.resize((size_t)n);
     if (n) memcpy(static_cast<void*>(keypoints.data()), kps.data(), sizeof(uvo_keypoint) * n);
     descriptors.create(n, dsize, CV_32FC1);

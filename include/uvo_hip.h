@@ -94,6 +94,17 @@ int         uvo_ctx_pending(const uvo_ctx* c);
  * SURF_EXTENDED (64 or 128 floats) end to end. */
 uvo_status uvo_surf_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem,
                            uvo_keypoint* kps, float* desc, int cap, int* n);
+/* ---- detect_features, FEATURE_DETECTOR == "SIFT" (VO_utility.cpp:107-112):
+ *     SIFT::create(10000, 3, 0.03, 10, 1.6)->detectAndCompute(img, noArray(), keypoints, descriptors)
+ * the five arguments of SIFT::create are passed through (nfeatures <= 0 keeps every keypoint).  gray as for uvo_surf_detect.
+ * kps / desc: host buffers (desc: cap x 128 floats, the integer-valued rows cv::SIFT writes as CV_32F); keypoints come out in
+ * KeyPoint_LessThan order (x, y, size, angle ...) after duplicate removal, with OpenCV's packed octave / layer / offset in
+ * `octave`.  A standalone operator: the stereo / mono steps of this library run on SURF (the shipped parameter files). */
+uvo_status uvo_sift_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int nfeatures, int n_octave_layers,
+                           double contrast_threshold, double edge_threshold, double sigma, uvo_keypoint* kps, float* desc, int cap, int* n);
+/* test hook: Gaussian (dog = 0, layers 0 .. n_octave_layers + 2) or difference (dog = 1, layers 0 .. n_octave_layers + 1) layer of
+ * octave `octave` (0 = the doubled image) of the last uvo_sift_detect, row-major floats to a host buffer; out = NULL reports the size */
+uvo_status uvo_sift_layer(uvo_ctx* c, int octave, int layer, int dog, float* out, int cap_floats, int* w, int* h);
 /* test hooks into the detector's first stages (host outputs): integral image (h+1)x(w+1) s32 of the
  * last image given to uvo_surf_detect / uvo_integral, and one Hessian det/trace layer of it */
 uvo_status uvo_integral(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int32_t* sum);

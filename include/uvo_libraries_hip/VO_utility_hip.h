@@ -8,7 +8,8 @@
 // Differences a maintainer should know about:
 //   * the parameter globals are DECLARED here and DEFINED once in the library (the reference defines them in its
 //     header); get_VO_parameters() keeps assigning to them as before, every call below reads their current value;
-//   * FEATURE_DETECTOR must be "SURF" (the AKAZE/ORB/SIFT branches of detect_features are out of scope);
+//   * FEATURE_DETECTOR must be "SURF" or "SIFT" for detect_features (the AKAZE / ORB detectors are not built; match_features
+//     serves all four names);
 //   * OpenCV errors become uvo_hip::Error (a std::runtime_error) carrying the library's message;
 //   * the cv:: calls the stereo/mono loops make directly (triangulatePoints, solvePnPRansac, Rodrigues) have
 //     same-signature replacements in namespace uvo_hip.

@@ -494,6 +494,35 @@ def jpeg_decode(data: bytes) -> np.ndarray:
     return out[..., 0] if ch.value == 1 else out
 
 
+def sift_detect(img: np.ndarray, nfeatures=10000, n_octave_layers=3, contrast_threshold=0.03, edge_threshold=10.0, sigma=1.6, cap=1 << 16,
+                descriptors=True):
+    """SIFT::create(10000, 3, 0.03, 10, 1.6)->detectAndCompute (VO_utility.cpp:107-112), restated: (keypoints, n x 128 descriptors)."""
+    img = _c(img, np.uint8)
+    h, w = img.shape
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, 128), np.float32) if descriptors else None
+    f = lib().orc_sift_detect_and_compute
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+    n = f(_p(img), w, h, w, int(nfeatures), int(n_octave_layers), float(contrast_threshold), float(edge_threshold), float(sigma),
+          _p(kps), _p(desc) if descriptors else None, cap)
+    if n < 0:
+        raise ValueError(f"sift_detect: capacity {cap} too small for {-n} keypoints")
+    return kps[:n].copy(), (desc[:n].copy() if descriptors else None)
+
+
+def sift_gauss_layer(img: np.ndarray, octave: int, layer: int, n_octave_layers=3, sigma=1.6) -> np.ndarray:
+    img = _c(img, np.uint8)
+    h, w = img.shape
+    ow, oh = C.c_int(0), C.c_int(0)
+    f = lib().orc_sift_gauss_layer
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    out = np.zeros((2 * h + 2) * (2 * w + 2), np.float32)
+    n = f(_p(img), w, h, w, int(n_octave_layers), float(sigma), int(octave), int(layer), _p(out), C.byref(ow), C.byref(oh))
+    if n == 0:
+        raise ValueError("sift_gauss_layer: no such layer")
+    return out[:n].reshape(oh.value, ow.value).copy()
+
+
 def png_decode(data: bytes) -> np.ndarray:
     """cv::imdecode(IMREAD_UNCHANGED) of an 8-bit PNG: H x W grey, H x W x 3 BGR (RGB or palette) or H x W x 4 BGRA."""
     buf = np.frombuffer(data, np.uint8)
