@@ -4,7 +4,7 @@
 // createInitialImage (u8 -> float, doubled with INTER_LINEAR, blurred to sigma), buildGaussianPyramid (nOctaveLayers + 3 blurs per
 // octave, INTER_NEAREST halving), buildDoGPyramid, findScaleSpaceExtrema (26-neighbour extrema, adjustLocalExtrema,
 // calcOrientationHist), KeyPointsFilter (duplicates, retainBest), calcSIFTDescriptor -- in the operation order of their scalar paths
-// as oracle/o_sift.c restates them (parity vs OpenCV itself is UNPINNED, see that file's header).
+// (parity vs OpenCV itself is UNPINNED: DESIGN.md section 0; cosf / sinf / powf(2, x) are this library's deterministic double series).
 //
 // Byte / float streaming work, HBM-bound: the doubled base image, the blurs (separable, one thread per pixel, taps in the
 // symmetric filter's order), the differences and the extrema test are coalesced passes over float images that stay in HBM
@@ -79,7 +79,7 @@ void sift_ws_free(Ctx* c)
 // ------------------------------------------------------------------------------------------ device helpers
 __device__ __forceinline__ int reflect101(int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * n - 2 - p; } return p; }
 
-// hal::exp32f, scalar path (oracle/o_sift.c orc_exp32f): table of 2^(i/64) * A0 from the host, polynomial in double
+// hal::exp32f, scalar path: table of 2^(i/64) * A0 from the host, polynomial in double
 __device__ __forceinline__ float sift_exp32f(float x, const float* __restrict__ tab)
 {
     const double exp_prescale = 1.4426950408889634073599246810019 * 64, exp_postscale = 1. / 64, exp_max_val = 3000. * 64;
@@ -96,7 +96,7 @@ __device__ __forceinline__ float sift_exp32f(float x, const float* __restrict__ 
     x0 = (x0 - val0) * exp_postscale;
     return (float)((double)bf * (double)tab[val0 & 63] * ((((x0 + A1) * x0 + A2) * x0 + A3) * x0 + A4));
 }
-__device__ __forceinline__ float sift_exp2f_det(float x)            // 2^x: the Taylor series of e^(frac ln 2) in double (orc_exp2f_det)
+__device__ __forceinline__ float sift_exp2f_det(float x)            // 2^x: the Taylor series of e^(frac ln 2) in double
 {
     const double xd = (double)x, fl = floor(xd), fr = (xd - fl) * 0.69314718055994530942;
     double term = 1, sum = 1;
@@ -517,7 +517,7 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
         if (fin.empty() || fin.back().x != k.x || fin.back().y != k.y || fin.back().size != k.size || fin.back().angle != k.angle) fin.push_back(k);
     if (nfeatures > 0 && (int)fin.size() > nfeatures) {
         // retainBest: everything whose response is at least the nfeatures-th largest, kept in sorted order (OpenCV leaves them in
-        // nth_element's order; oracle/o_sift.c states the same choice)
+        // nth_element's order, which is implementation-defined: DESIGN.md section 6)
         std::vector<float> resp(fin.size());
         for (size_t i = 0; i < fin.size(); i++) resp[i] = fin[i].response;
         std::nth_element(resp.begin(), resp.begin() + (nfeatures - 1), resp.end(), [](float a, float b) { return a > b; });
