@@ -26,6 +26,7 @@ static const int kSiftMaxLayers = 8, kSiftMaxOctaves = 16, kSiftMaxTaps = 64;
 static const int SIFT_IMG_BORDER = 5, SIFT_MAX_INTERP_STEPS = 5, SIFT_ORI_HIST_BINS = 36;
 
 struct SiftCand { int o, layer, r, c; };
+struct SiftSurv { uvo_keypoint kpt; int o, layer, r, c; };
 struct SiftWs {
     int w = 0, h = 0, nL = 0, nOct = 0;
     int ow[kSiftMaxOctaves], oh[kSiftMaxOctaves];
@@ -33,37 +34,41 @@ struct SiftWs {
     float* dog[kSiftMaxOctaves * (kSiftMaxLayers + 2)] = {nullptr};
     float* tmp = nullptr; uint8_t* d_img = nullptr;
     float* d_exptab = nullptr;
-    SiftCand* d_cand = nullptr; uvo_keypoint* d_raw = nullptr; uvo_keypoint* d_kps = nullptr; float* d_desc = nullptr;
-    int* d_cnt = nullptr;         // [0] candidates, [1] raw keypoints
-    int cand_cap = 0, raw_cap = 0, kp_cap = 0;
+    SiftCand* d_cand = nullptr; SiftSurv* d_surv = nullptr; uvo_keypoint* d_raw = nullptr; uvo_keypoint* d_kps = nullptr; float* d_desc = nullptr;
+    uvo_keypoint* d_sorted = nullptr; uvo_keypoint* d_kept = nullptr; int* d_ints = nullptr;      // rank, dup, keep, greater: raw_cap each
+    int* d_cnt = nullptr;         // [0] candidates, [1] raw keypoints, [2] refined extrema, [3] after duplicate removal, [4] final
+    int cand_cap = 0, raw_cap = 0;           // d_kps / d_desc and the filter's arrays hold raw_cap records
 };
 static void sift_ws_release(SiftWs* s)
 {
     for (float*& p : s->gauss) { (void)hipFree(p); p = nullptr; }
     for (float*& p : s->dog) { (void)hipFree(p); p = nullptr; }
-    (void)hipFree(s->tmp); (void)hipFree(s->d_img); (void)hipFree(s->d_cand); (void)hipFree(s->d_raw); (void)hipFree(s->d_kps); (void)hipFree(s->d_desc);
-    (void)hipFree(s->d_cnt); (void)hipFree(s->d_exptab);
-    s->tmp = nullptr; s->d_img = nullptr; s->d_cand = nullptr; s->d_raw = nullptr; s->d_kps = nullptr; s->d_desc = nullptr; s->d_cnt = nullptr; s->d_exptab = nullptr;
-    s->w = s->h = 0; s->cand_cap = s->raw_cap = s->kp_cap = 0;
+    (void)hipFree(s->tmp); (void)hipFree(s->d_img); (void)hipFree(s->d_cand); (void)hipFree(s->d_surv); (void)hipFree(s->d_raw); (void)hipFree(s->d_kps); (void)hipFree(s->d_desc);
+    (void)hipFree(s->d_cnt); (void)hipFree(s->d_exptab); (void)hipFree(s->d_sorted); (void)hipFree(s->d_kept); (void)hipFree(s->d_ints);
+    s->d_sorted = nullptr; s->d_kept = nullptr; s->d_ints = nullptr;
+    s->tmp = nullptr; s->d_img = nullptr; s->d_cand = nullptr; s->d_surv = nullptr; s->d_raw = nullptr; s->d_kps = nullptr; s->d_desc = nullptr; s->d_cnt = nullptr; s->d_exptab = nullptr;
+    s->w = s->h = 0; s->cand_cap = s->raw_cap = 0;
 }
 // the three record lists grow on demand (a 1080p frame has ~13000 keypoints before retainBest, noise images far more per pixel)
-static bool sift_grow(SiftWs* s, int cand, int raw, int kp)
+static bool sift_grow(SiftWs* s, int cand, int raw)
 {
     if (cand > s->cand_cap) {
-        (void)hipFree(s->d_cand); s->d_cand = nullptr; s->cand_cap = 0;
-        if (hipMalloc(reinterpret_cast<void**>(&s->d_cand), sizeof(SiftCand) * (size_t)cand) != hipSuccess) return false;
+        (void)hipFree(s->d_cand); (void)hipFree(s->d_surv); s->d_cand = nullptr; s->d_surv = nullptr; s->cand_cap = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&s->d_cand), sizeof(SiftCand) * (size_t)cand) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&s->d_surv), sizeof(SiftSurv) * (size_t)cand) != hipSuccess) return false;
         s->cand_cap = cand;
     }
     if (raw > s->raw_cap) {
-        (void)hipFree(s->d_raw); s->d_raw = nullptr; s->raw_cap = 0;
-        if (hipMalloc(reinterpret_cast<void**>(&s->d_raw), sizeof(uvo_keypoint) * (size_t)raw) != hipSuccess) return false;
+        raw = (raw + 255) & ~255;
+        (void)hipFree(s->d_raw); (void)hipFree(s->d_kps); (void)hipFree(s->d_desc); (void)hipFree(s->d_sorted); (void)hipFree(s->d_kept); (void)hipFree(s->d_ints);
+        s->d_raw = s->d_kps = s->d_sorted = s->d_kept = nullptr; s->d_desc = nullptr; s->d_ints = nullptr; s->raw_cap = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&s->d_raw), sizeof(uvo_keypoint) * (size_t)raw) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&s->d_kps), sizeof(uvo_keypoint) * (size_t)raw) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&s->d_sorted), sizeof(uvo_keypoint) * (size_t)raw) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&s->d_kept), sizeof(uvo_keypoint) * (size_t)raw) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&s->d_ints), sizeof(int) * 4 * (size_t)raw) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&s->d_desc), sizeof(float) * 128 * (size_t)raw) != hipSuccess) return false;
         s->raw_cap = raw;
-    }
-    if (kp > s->kp_cap) {
-        (void)hipFree(s->d_kps); (void)hipFree(s->d_desc); s->d_kps = nullptr; s->d_desc = nullptr; s->kp_cap = 0;
-        if (hipMalloc(reinterpret_cast<void**>(&s->d_kps), sizeof(uvo_keypoint) * (size_t)kp) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&s->d_desc), sizeof(float) * 128 * (size_t)kp) != hipSuccess) return false;
-        s->kp_cap = kp;
     }
     return true;
 }
@@ -164,6 +169,68 @@ __global__ __launch_bounds__(256) void k_sift_blur(const float* __restrict__ src
     }
     dst[(size_t)y * w + x] = acc;
 }
+// The same blur, both passes in one launch for the radii the default parameters produce (R = 2 .. 16): a 64 x TH tile of outputs per
+// workgroup, its input with an R-wide reflected border staged in LDS once, the row filter from LDS into LDS (each lane four
+// neighbouring outputs from one register window of 4 + 2R inputs, read as 16-byte vectors), the column filter from LDS (each lane
+// eight rows of one column from a window of 8 + 2R), and the difference of Gaussians dst - src written beside dst from the
+// centre value that is already in LDS.  Every output is the expression of k_sift_blur (same taps, same order, no contraction).
+template <int R, int TH>
+__global__ __launch_bounds__(256) void k_sift_blur_tile(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog, int w, int h, SiftTaps t)
+{
+    constexpr int TW = 64, IW = TW + 2 * R, IWP = (IW + 3) & ~3, IH = TH + 2 * R;
+    __shared__ __attribute__((aligned(16))) float s_in[IH * IWP];
+    __shared__ float s_h[IH * TW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    for (int iy = wv; iy < IH; iy += 4) {
+        const float* __restrict__ row = src + (size_t)reflect101(y0 - R + iy, h) * w;
+        s_in[iy * IWP + lane] = row[reflect101(x0 - R + lane, w)];
+        if (lane < 2 * R) s_in[iy * IWP + 64 + lane] = row[reflect101(x0 - R + 64 + lane, w)];
+    }
+    __syncthreads();
+    float k[R + 1];
+#pragma unroll
+    for (int i = 0; i <= R; i++) k[i] = t.k[R + i];
+    {   // rows: 16 lanes x 4 outputs per row, 16 rows per pass
+        const int xq = (tid & 15) * 4;
+        for (int iy = tid >> 4; iy < IH; iy += 16) {
+            float win[4 + 2 * R + 3];
+            const float4* __restrict__ src4 = reinterpret_cast<const float4*>(&s_in[iy * IWP + xq]);
+#pragma unroll
+            for (int q = 0; q < (4 + 2 * R + 3) / 4; q++) { const float4 f = src4[q]; win[4 * q] = f.x; win[4 * q + 1] = f.y; win[4 * q + 2] = f.z; win[4 * q + 3] = f.w; }
+            float acc[4];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                acc[o] = k[0] * win[o + R];
+#pragma unroll
+                for (int i = 1; i <= R; i++) acc[o] += k[i] * (win[o + R + i] + win[o + R - i]);
+            }
+            *reinterpret_cast<float4*>(&s_h[iy * TW + xq]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+    __syncthreads();
+    {   // columns: lane = column, 8 rows per thread
+        constexpr int RPT = TH / 4;
+        const int yq = wv * RPT, x = x0 + lane;
+        float win[RPT + 2 * R];
+#pragma unroll
+        for (int q = 0; q < RPT + 2 * R; q++) win[q] = s_h[(yq + q) * TW + lane];
+        if (x < w) {
+#pragma unroll
+            for (int o = 0; o < RPT; o++) {
+                float acc = k[0] * win[o + R];
+#pragma unroll
+                for (int i = 1; i <= R; i++) acc += k[i] * (win[o + R + i] + win[o + R - i]);
+                const int y = y0 + yq + o;
+                if (y < h) {
+                    dst[(size_t)y * w + x] = acc;
+                    if (dog) dog[(size_t)y * w + x] = acc - s_in[(yq + o + R) * IWP + lane + R];
+                }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_sift_half(const float* __restrict__ src, int sw, float* __restrict__ dst, int w, int h)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -176,31 +243,86 @@ __global__ __launch_bounds__(256) void k_sift_dog(const float* __restrict__ a, c
 }
 
 // ------------------------------------------------------------------------------------------ extrema
-__global__ __launch_bounds__(256) void k_sift_extrema(const float* __restrict__ prev, const float* __restrict__ cur, const float* __restrict__ next,
-                                                      int w, int h, int o, int layer, int threshold, SiftCand* cand, int* cnt, int cap)
+struct SiftPyr { const float* gauss[kSiftMaxOctaves * (kSiftMaxLayers + 3)]; const float* dog[kSiftMaxOctaves * (kSiftMaxLayers + 2)]; int ow[kSiftMaxOctaves], oh[kSiftMaxOctaves]; int nL; };
+struct SiftTiles { int start[kSiftMaxOctaves + 1]; int tx[kSiftMaxOctaves]; int nOct; };
+// findScaleSpaceExtrema's 26-neighbour test, every octave and layer in one launch: a workgroup takes a 64 x 16 tile of one octave and
+// walks up its nL + 2 difference layers, staging each (with a one-pixel border) in LDS once; a thread keeps the 3 x 3 maximum, the
+// 3 x 3 minimum and the centre of its four pixels for the last three layers in registers, and val >= all 26 neighbours is
+// val >= the three maxima (val <= the three minima for a negative val) -- the same decisions as the 26 comparisons.
+__global__ __launch_bounds__(256) void k_sift_extrema_all(SiftPyr p, SiftTiles tl, int threshold, SiftCand* cand, int* cnt, int cap)
 {
-    const int c = blockIdx.x * 256 + threadIdx.x + SIFT_IMG_BORDER, r = blockIdx.y + SIFT_IMG_BORDER;
-    if (c >= w - SIFT_IMG_BORDER || r >= h - SIFT_IMG_BORDER) return;
-    const float val = cur[(size_t)r * w + c];
-    if (!(fabsf(val) > threshold)) return;
-    bool ext = true;
-    for (int dr = -1; dr <= 1 && ext; dr++)
-        for (int dc = -1; dc <= 1 && ext; dc++) {
-            const size_t e = (size_t)(r + dr) * w + (c + dc);
-            const float a = cur[e], b = prev[e], cc = next[e];
-            ext = val > 0 ? (val >= a && val >= b && val >= cc) : (val <= a && val <= b && val <= cc);
+    constexpr int TW = 64, TH = 16, SW = TW + 2, SH = TH + 2, SP = 68;
+    __shared__ float s_t[SH * SP];
+    __shared__ unsigned short s_list[TW * TH * kSiftMaxLayers];        // layer << 10 | ly << 6 | lx: every pixel of the tile in every layer at worst
+    __shared__ int s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    int o = 0;
+    while (o + 1 < tl.nOct && (int)blockIdx.x >= tl.start[o + 1]) o++;
+    const int tile = blockIdx.x - tl.start[o], w = p.ow[o], h = p.oh[o], nL = p.nL;
+    const int x0 = SIFT_IMG_BORDER + (tile % tl.tx[o]) * TW, y0 = SIFT_IMG_BORDER + (tile / tl.tx[o]) * TH;
+    const int tid = threadIdx.x, lx = (tid & 15) * 4, ly = tid >> 4;
+    float mx[3][4], mn[3][4], ce[3][4];
+    constexpr int NST = (SH * SW + 255) / 256;                         // staged values per thread
+    int goff[NST], soff[NST];
+#pragma unroll
+    for (int q = 0; q < NST; q++) {
+        const int e = min(tid + q * 256, SH * SW - 1), sy = e / SW, sx = e - sy * SW;
+        goff[q] = min(y0 - 1 + sy, h - 1) * w + min(x0 - 1 + sx, w - 1);          // (y0 - 1, x0 - 1 >= 4: inside; an octave has < 2^31 pixels)
+        soff[q] = sy * SP + sx;
+    }
+    float pre[NST];
+    {
+        const float* __restrict__ d0 = p.dog[o * (nL + 2)];
+#pragma unroll
+        for (int q = 0; q < NST; q++) pre[q] = d0[goff[q]];
+    }
+    for (int l = 0; l < nL + 2; l++) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NST; q++) if (tid + q * 256 < SH * SW) s_t[soff[q]] = pre[q];
+        if (l + 1 < nL + 2) {                                           // the next layer's loads are in flight while this one is tested
+            const float* __restrict__ d1 = p.dog[o * (nL + 2) + l + 1];
+#pragma unroll
+            for (int q = 0; q < NST; q++) pre[q] = d1[goff[q]];
         }
-    if (!ext) return;
-    const int pos = atomicAdd(cnt, 1);
-    if (pos < cap) cand[pos] = SiftCand{ o, layer, r, c };
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) { mx[0][q] = mx[1][q]; mn[0][q] = mn[1][q]; ce[0][q] = ce[1][q]; mx[1][q] = mx[2][q]; mn[1][q] = mn[2][q]; ce[1][q] = ce[2][q]; }
+        float cmx[6], cmn[6];                                           // column maxima / minima over the three rows, columns lx - 1 .. lx + 4
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const float a = s_t[ly * SP + lx + q], b = s_t[(ly + 1) * SP + lx + q], cc = s_t[(ly + 2) * SP + lx + q];
+            cmx[q] = fmaxf(fmaxf(a, b), cc); cmn[q] = fminf(fminf(a, b), cc);
+            if (q >= 1 && q <= 4) ce[2][q - 1] = b;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { mx[2][q] = fmaxf(fmaxf(cmx[q], cmx[q + 1]), cmx[q + 2]); mn[2][q] = fminf(fminf(cmn[q], cmn[q + 1]), cmn[q + 2]); }
+        if (l >= 2) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int c = x0 + lx + q, r = y0 + ly;
+                const float val = ce[1][q];
+                if (c < w - SIFT_IMG_BORDER && r < h - SIFT_IMG_BORDER && fabsf(val) > threshold) {
+                    const bool ext = val > 0 ? (val >= mx[0][q] && val >= mx[1][q] && val >= mx[2][q]) : (val <= mn[0][q] && val <= mn[1][q] && val <= mn[2][q]);
+                    if (ext) s_list[atomicAdd(&s_n, 1)] = (unsigned short)(((l - 1) << 10) | (ly << 6) | (lx + q));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nloc = s_n;                                               // one reservation in the global list per workgroup (the list is unordered anyway)
+    if (tid == 0 && nloc) s_base = atomicAdd(cnt, nloc);
+    __syncthreads();
+    for (int e = tid; e < nloc; e += 256) {
+        const int v = s_list[e], pos = s_base + e;
+        if (pos < cap) cand[pos] = SiftCand{ o, v >> 10, y0 + ((v >> 6) & 15), x0 + (v & 63) };
+    }
 }
 
-struct SiftPyr { const float* gauss[kSiftMaxOctaves * (kSiftMaxLayers + 3)]; const float* dog[kSiftMaxOctaves * (kSiftMaxLayers + 2)]; int ow[kSiftMaxOctaves], oh[kSiftMaxOctaves]; int nL; };
 
-// adjustLocalExtrema + calcOrientationHist + the peak loop of findScaleSpaceExtrema for one candidate
+// adjustLocalExtrema for one candidate per thread (a handful of dependent 3 x 3 x 3 neighbourhood reads); survivors are appended to a list
 __global__ __launch_bounds__(64) void k_sift_refine(SiftPyr p, const SiftCand* __restrict__ cand, const int* __restrict__ cnt_p, int cand_cap,
-                                                    float contrastThreshold, float edgeThreshold, float sigma, const float* __restrict__ exptab,
-                                                    uvo_keypoint* raw, int* raw_cnt, int raw_cap)
+                                                    float contrastThreshold, float edgeThreshold, float sigma, SiftSurv* surv, int* surv_cnt)
 {
     const int t = blockIdx.x * 64 + threadIdx.x;
     const int ncand = min(*cnt_p, cand_cap);
@@ -254,60 +376,113 @@ __global__ __launch_bounds__(64) void k_sift_refine(SiftPyr p, const SiftCand* _
     kpt.response = fabsf(contr);
     kpt.class_id = -1;
     kpt.angle = -1;
-    // calcOrientationHist on the Gaussian layer the extremum ended in
-    const float scl_octv = kpt.size * 0.5f / (1 << octv);
-    const int radius = cv_round_f(4.5f * scl_octv), n = SIFT_ORI_HIST_BINS;
-    const float osigma = 1.5f * scl_octv, expf_scale = -1.f / (2.f * osigma * osigma);
-    const float* g = p.gauss[octv * (nL + 3) + layer];
-    float temphist[SIFT_ORI_HIST_BINS + 4];
-    float* th = temphist + 2;
-    for (int k = 0; k < n; k++) th[k] = 0.f;
-    for (int ii = -radius; ii <= radius; ii++) {
-        const int y = r + ii;
-        if (y <= 0 || y >= h - 1) continue;
-        for (int jj = -radius; jj <= radius; jj++) {
-            const int x = c + jj;
-            if (x <= 0 || x >= w - 1) continue;
-            const float dx = AT(g, y, x + 1) - AT(g, y, x - 1), dy = AT(g, y - 1, x) - AT(g, y + 1, x);
-            const float wgt = sift_exp32f((ii * ii + jj * jj) * expf_scale, exptab);
-            const float ori = sift_atan2_deg(dy, dx), mag = sqrtf(dx * dx + dy * dy);
-            int bin = cv_round_f((n / 360.f) * ori);
-            if (bin >= n) bin -= n;
-            if (bin < 0) bin += n;
-            th[bin] += wgt * mag;
-        }
-    }
 #undef AT
-    th[-1] = th[n - 1]; th[-2] = th[n - 2]; th[n] = th[0]; th[n + 1] = th[1];
-    float hist[SIFT_ORI_HIST_BINS];
-    for (int k = 0; k < n; k++) hist[k] = (th[k - 2] + th[k + 2]) * (1.f / 16.f) + (th[k - 1] + th[k + 1]) * (4.f / 16.f) + th[k] * (6.f / 16.f);
-    float omax = hist[0];
-    for (int k = 1; k < n; k++) omax = omax > hist[k] ? omax : hist[k];
-    const float mag_thr = omax * 0.8f;
-    for (int j = 0; j < n; j++) {
-        const int l = j > 0 ? j - 1 : n - 1, r2 = j < n - 1 ? j + 1 : 0;
-        if (hist[j] > hist[l] && hist[j] > hist[r2] && hist[j] >= mag_thr) {
-            float bin = j + 0.5f * (hist[l] - hist[r2]) / (hist[l] - 2 * hist[j] + hist[r2]);
-            bin = bin < 0 ? n + bin : (bin >= n ? bin - n : bin);
-            kpt.angle = 360.f - (360.f / n) * bin;
-            if (fabsf(kpt.angle - 360.f) < FLT_EPSILON) kpt.angle = 0.f;
-            const int pos = atomicAdd(raw_cnt, 1);
-            if (pos < raw_cap) raw[pos] = kpt;
+    const int pos = atomicAdd(surv_cnt, 1);                            // at most one per candidate: the candidate list's capacity bounds it
+    if (pos < cand_cap) surv[pos] = SiftSurv{ kpt, octv, layer, r, c };
+}
+
+// calcOrientationHist + the peak loop of findScaleSpaceExtrema, one wave per surviving extremum.  As in the descriptor the bins'
+// sums are ordered (raster order of the window): the lanes evaluate 64 samples at a time (gradient, exp, atan2, sqrt -> bin, vote),
+// pack them in raster order into LDS, and lane b < 36 then walks the packed votes adding the ones of bin b (and +0.0f, which
+// changes nothing, for the others: the votes and the sums are never negative).
+__global__ __launch_bounds__(64) void k_sift_orient(SiftPyr p, const SiftSurv* __restrict__ surv, const int* __restrict__ surv_cnt, int surv_cap,
+                                                    const float* __restrict__ exptab, uvo_keypoint* raw, int* raw_cnt, int raw_cap)
+{
+    __shared__ float s_tab[64];
+    __shared__ __attribute__((aligned(8))) float2 s_vote[64];
+    __shared__ float s_th[SIFT_ORI_HIST_BINS + 4], s_h[SIFT_ORI_HIST_BINS];
+    const int lane = threadIdx.x, n = SIFT_ORI_HIST_BINS, nL = p.nL;
+    const int ns = min(*surv_cnt, surv_cap);
+    s_tab[lane] = exptab[lane];
+    for (int sidx = blockIdx.x; sidx < ns; sidx += gridDim.x) {
+        const SiftSurv sv = surv[sidx];
+        uvo_keypoint kpt = sv.kpt;
+        const int octv = sv.o, w = p.ow[octv], h = p.oh[octv], r = sv.r, c = sv.c;
+        const float scl_octv = kpt.size * 0.5f / (1 << octv);
+        const int radius = cv_round_f(4.5f * scl_octv);
+        const float osigma = 1.5f * scl_octv, expf_scale = -1.f / (2.f * osigma * osigma);
+        const float* __restrict__ g = p.gauss[octv * (nL + 3) + sv.layer];
+        const int side = 2 * radius + 1;
+        const long long total = (long long)side * side;
+        int wi = lane / side, wj = lane - wi * side;
+        float acc = 0.f;                                               // th[lane], lane < 36
+        __syncthreads();
+        for (long long base = 0; base < total; base += 64) {
+            bool pass = false;
+            float vote = 0.f; int bin = 0;
+            if (wi < side) {
+                const int ii = wi - radius, jj = wj - radius, y = r + ii, x = c + jj;
+                if (y > 0 && y < h - 1 && x > 0 && x < w - 1) {
+                    pass = true;
+                    const float dx = g[(size_t)y * w + x + 1] - g[(size_t)y * w + x - 1], dy = g[(size_t)(y - 1) * w + x] - g[(size_t)(y + 1) * w + x];
+                    const float wgt = sift_exp32f((ii * ii + jj * jj) * expf_scale, s_tab);
+                    const float ori = sift_atan2_deg(dy, dx), mag = sqrtf(dx * dx + dy * dy);
+                    bin = cv_round_f((n / 360.f) * ori);
+                    if (bin >= n) bin -= n;
+                    if (bin < 0) bin += n;
+                    vote = wgt * mag;
+                }
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) {
+                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                s_vote[pos] = make_float2(__int_as_float(bin), vote);
+            }
+            __syncthreads();
+            const int cnt = __popcll(m);
+            for (int q = 0; q < cnt; q++) {
+                const float2 bv = s_vote[q];
+                acc += (__float_as_int(bv.x) == lane) ? bv.y : 0.f;
+            }
+            __syncthreads();
+            wj += 64;
+            while (wj >= side) { wj -= side; wi++; }
+        }
+        if (lane < n) s_th[lane + 2] = acc;
+        __syncthreads();
+        if (lane < 2) { s_th[lane] = s_th[n + lane]; s_th[n + 2 + lane] = s_th[2 + lane]; }      // th[-2], th[-1] = th[n-2], th[n-1]; th[n], th[n+1] = th[0], th[1]
+        __syncthreads();
+        if (lane < n) {
+            const float* th = s_th + 2 + lane;
+            s_h[lane] = (th[-2] + th[2]) * (1.f / 16.f) + (th[-1] + th[1]) * (4.f / 16.f) + th[0] * (6.f / 16.f);
+        }
+        __syncthreads();
+        float omax = s_h[0];
+        for (int q = 1; q < n; q++) omax = omax > s_h[q] ? omax : s_h[q];
+        const float mag_thr = omax * 0.8f;
+        if (lane < n) {
+            const int j = lane, l = j > 0 ? j - 1 : n - 1, r2 = j < n - 1 ? j + 1 : 0;
+            const float hj = s_h[j], hl = s_h[l], hr = s_h[r2];
+            if (hj > hl && hj > hr && hj >= mag_thr) {
+                float bin = j + 0.5f * (hl - hr) / (hl - 2 * hj + hr);
+                bin = bin < 0 ? n + bin : (bin >= n ? bin - n : bin);
+                kpt.angle = 360.f - (360.f / n) * bin;
+                if (fabsf(kpt.angle - 360.f) < FLT_EPSILON) kpt.angle = 0.f;
+                const int pos = atomicAdd(raw_cnt, 1);
+                if (pos < raw_cap) raw[pos] = kpt;
+            }
         }
     }
 }
 
-// calcSIFTDescriptor for one keypoint per thread: the votes are float additions into shared bins in sample order, so the window
-// is walked by one thread; the 6 x 6 x 10 histogram lives in LDS (one column per thread of the block)
-static const int kSiftDescThreads = 32, kSiftHist = 6 * 6 * 10;
-__global__ __launch_bounds__(kSiftDescThreads) void k_sift_descriptor(SiftPyr p, const uvo_keypoint* __restrict__ kps, int nk, const float* __restrict__ exptab,
-                                                                     float* __restrict__ desc)
+// calcSIFTDescriptor, one wave per keypoint.  The votes are float additions into shared bins and their order (raster order of the
+// window's samples) is part of the result, but nothing else about a sample is: the lanes evaluate 64 samples at a time (rotation,
+// window test, gradient, exp / atan2 / sqrt, the eight trilinear shares), the ones inside the window are packed in raster order into
+// LDS, and eight lanes then apply one sample's eight shares (eight different bins) per step, sample after sample -- LDS operations of
+// one wave are performed in issue order, so every bin sees its additions in the order the one-thread loop makes them.
+static const int kSiftHist = 6 * 6 * 10;
+__global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyr p, const uvo_keypoint* __restrict__ kps, const int* __restrict__ nk_p, int kp_cap,
+                                                        const float* __restrict__ exptab, float* __restrict__ desc)
 {
-    __shared__ float s_hist[kSiftHist * kSiftDescThreads];
-    const int k = blockIdx.x * kSiftDescThreads + threadIdx.x;
-    if (k >= nk) return;
-    float* hist = s_hist + threadIdx.x;
-#define HI(i) hist[(i) * kSiftDescThreads]
+    __shared__ float s_hist[kSiftHist];
+    __shared__ __attribute__((aligned(16))) float s_val[64 * 8];
+    __shared__ __attribute__((aligned(16))) unsigned short s_bin[64 * 8];
+    __shared__ float s_tab[64];
+    __shared__ __attribute__((aligned(16))) float s_dst[128];
+    __shared__ float s_sq[128];
+    const int lane = threadIdx.x, nk = min(*nk_p, kp_cap);
+    s_tab[lane] = exptab[lane];
+    for (int k = blockIdx.x; k < nk; k += gridDim.x) {
     const uvo_keypoint kp = kps[k];
     const int d = 4, n = 8, nL = p.nL;
     int octave = kp.octave & 255; const int layer = (kp.octave >> 8) & 255;
@@ -315,7 +490,7 @@ __global__ __launch_bounds__(kSiftDescThreads) void k_sift_descriptor(SiftPyr p,
     const float scale = octave >= 0 ? 1.f / (1 << octave) : (float)(1 << -octave);
     const float size = kp.size * scale;
     const int oi = octave + 1;                                        // octave - firstOctave
-    const float* img = p.gauss[oi * (nL + 3) + layer];
+    const float* __restrict__ img = p.gauss[oi * (nL + 3) + layer];
     const int cols = p.ow[oi], rows = p.oh[oi];
     float ori = 360.f - kp.angle;
     if (fabsf(ori - 360.f) < FLT_EPSILON) ori = 0.f;
@@ -329,53 +504,197 @@ __global__ __launch_bounds__(kSiftDescThreads) void k_sift_descriptor(SiftPyr p,
     const int rmax = (int)sqrt(((double)cols) * cols + ((double)rows) * rows);
     radius = radius < rmax ? radius : rmax;
     cos_t /= hist_width; sin_t /= hist_width;
-    for (int e = 0; e < kSiftHist; e++) HI(e) = 0.f;
-    for (int i = -radius; i <= radius; i++)
-        for (int j = -radius; j <= radius; j++) {
+    __syncthreads();                                                  // (the previous keypoint's tail is done with s_hist / s_dst)
+    for (int e = lane; e < kSiftHist; e += 64) s_hist[e] = 0.f;
+    __syncthreads();
+    const int side = 2 * radius + 1;
+    const long long total = (long long)side * side;
+    int wi = lane / side, wj = lane - wi * side;                      // this lane's sample of the current batch: row wi, column wj of the window
+    for (long long base = 0; base < total; base += 64) {
+        bool pass = false;
+        float v[8]; int idx = 0;
+        if (wi < side) {
+            const int i = wi - radius, j = wj - radius;
             const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
             const int r = py + i, c = px + j;
-            if (!(rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1)) continue;
-            const float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1], dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
-            const float wgt = sift_exp32f((c_rot * c_rot + r_rot * r_rot) * exp_scale, exptab);
-            float obin = (sift_atan2_deg(dy, dx) - ori) * bins_per_rad;
-            const float mag = sqrtf(dx * dx + dy * dy) * wgt;
-            const int r0 = cv_floor_d(rbin), c0 = cv_floor_d(cbin);
-            int o0 = cv_floor_d(obin);
-            rbin -= r0; cbin -= c0; obin -= o0;
-            if (o0 < 0) o0 += n;
-            if (o0 >= n) o0 -= n;
-            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-            const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-            const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-            const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-            HI(idx) += v_rco000; HI(idx + 1) += v_rco001;
-            HI(idx + (n + 2)) += v_rco010; HI(idx + (n + 3)) += v_rco011;
-            HI(idx + (d + 2) * (n + 2)) += v_rco100; HI(idx + (d + 2) * (n + 2) + 1) += v_rco101;
-            HI(idx + (d + 3) * (n + 2)) += v_rco110; HI(idx + (d + 3) * (n + 2) + 1) += v_rco111;
+            if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1) {
+                pass = true;
+                const float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1], dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
+                const float wgt = sift_exp32f((c_rot * c_rot + r_rot * r_rot) * exp_scale, s_tab);
+                float obin = (sift_atan2_deg(dy, dx) - ori) * bins_per_rad;
+                const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+                const int r0 = cv_floor_d(rbin), c0 = cv_floor_d(cbin);
+                int o0 = cv_floor_d(obin);
+                rbin -= r0; cbin -= c0; obin -= o0;
+                if (o0 < 0) o0 += n;
+                if (o0 >= n) o0 -= n;
+                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+                const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+                const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+                idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+                v[0] = v_rco000; v[1] = v_rco001; v[2] = v_rco010; v[3] = v_rco011; v[4] = v_rco100; v[5] = v_rco101; v[6] = v_rco110; v[7] = v_rco111;
+            }
         }
-    float* dst = desc + (size_t)k * 128;
-    for (int i = 0; i < d; i++)
-        for (int j = 0; j < d; j++) {
-            const int idx = ((i + 1) * (d + 2) + (j + 1)) * (n + 2);
-            HI(idx) += HI(idx + n);
-            HI(idx + 1) += HI(idx + n + 1);
-            for (int q = 0; q < n; q++) dst[(i * d + j) * n + q] = HI(idx + q);
+        const unsigned long long m = __ballot(pass);
+        if (pass) {
+            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            *reinterpret_cast<float4*>(&s_val[pos * 8]) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(&s_val[pos * 8 + 4]) = make_float4(v[4], v[5], v[6], v[7]);
+            // the eight bins of the shares, in the order of v[]: +0, +1, +(n+2), +(n+3), +(d+2)(n+2), ...
+            const unsigned b0 = (unsigned)idx, b2 = b0 + (n + 2), b4 = b0 + (d + 2) * (n + 2), b6 = b0 + (d + 3) * (n + 2);
+            *reinterpret_cast<uint4*>(&s_bin[pos * 8]) = make_uint4(b0 | ((b0 + 1) << 16), b2 | ((b2 + 1) << 16), b4 | ((b4 + 1) << 16), b6 | ((b6 + 1) << 16));
         }
-#undef HI
-    const int len = d * d * n;
+        __syncthreads();
+        const int cnt = __popcll(m);
+        if (lane < 8) {
+            for (int q = 0; q < cnt; q++) {
+                const int bi = s_bin[q * 8 + lane];
+                s_hist[bi] += s_val[q * 8 + lane];
+            }
+        }
+        __syncthreads();
+        wj += 64;
+        while (wj >= side) { wj -= side; wi++; }
+    }
+    // the wrap of the orientation axis, the 4 x 4 x 8 rows, the two normalisations (sums in element order: one lane)
+    if (lane < 16) {
+        const int idx = ((lane / d + 1) * (d + 2) + (lane % d + 1)) * (n + 2);
+        s_hist[idx] += s_hist[idx + n];
+        s_hist[idx + 1] += s_hist[idx + n + 1];
+    }
+    __syncthreads();
+    for (int e = lane; e < 128; e += 64) {
+        const int cell = e / n, q = e % n;
+        const float val = s_hist[((cell / d + 1) * (d + 2) + (cell % d + 1)) * (n + 2) + q];
+        s_dst[e] = val; s_sq[e] = val * val;
+    }
+    __syncthreads();
     float nrm2 = 0;
-    for (int q = 0; q < len; q++) nrm2 += dst[q] * dst[q];
+    for (int q = 0; q < 128; q++) nrm2 += s_sq[q];                   // every lane the same chain (uniform)
     const float thr = sqrtf(nrm2) * 0.2f;
+    __syncthreads();
+    for (int e = lane; e < 128; e += 64) {
+        const float val = s_dst[e] < thr ? s_dst[e] : thr;
+        s_dst[e] = val; s_sq[e] = val * val;
+    }
+    __syncthreads();
     nrm2 = 0;
-    for (int q = 0; q < len; q++) { const float val = dst[q] < thr ? dst[q] : thr; dst[q] = val; nrm2 += val * val; }
+    for (int q = 0; q < 128; q++) nrm2 += s_sq[q];
     const float sq = sqrtf(nrm2);
     nrm2 = 512.f / (sq > FLT_EPSILON ? sq : FLT_EPSILON);
-    for (int q = 0; q < len; q++) {
-        const int v = cv_round_f(dst[q] * nrm2);                       // saturate_cast<uchar>
-        dst[q] = (float)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    float* dst = desc + (size_t)k * 128;
+    for (int e = lane; e < 128; e += 64) {
+        const int vv = cv_round_f(s_dst[e] * nrm2);                   // saturate_cast<uchar>
+        dst[e] = (float)(vv < 0 ? 0 : (vv > 255 ? 255 : vv));
     }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ KeyPointsFilter on the device
+// removeDuplicatedSorted (sort by KeyPoint_LessThan, drop a keypoint that repeats its predecessor's pt, size and angle), retainBest
+// (keep the responses that are at least the nfeatures-th largest) and the scaling back of firstOctave = -1.  A few thousand
+// records: ranks by counting (every record against every other, the pairs split over the grid and summed with integer atomics).
+__device__ __forceinline__ bool sift_kp_less(const uvo_keypoint& a, const uvo_keypoint& b)      // KeyPoint_LessThan (features2d keypoint.cpp)
+{
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    if (a.size != b.size) return a.size > b.size;
+    if (a.angle != b.angle) return a.angle < b.angle;
+    if (a.response != b.response) return a.response > b.response;
+    if (a.octave != b.octave) return a.octave > b.octave;
+    if (a.class_id != b.class_id) return a.class_id > b.class_id;
+    return false;
+}
+__global__ __launch_bounds__(256) void k_sift_rank(const uvo_keypoint* __restrict__ raw, const int* __restrict__ cnt_p, int cap, int* rank, int* dup)
+{
+    __shared__ float s_key[256];
+    __shared__ uvo_keypoint s_kp[256];
+    const int n = min(*cnt_p, cap), tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+    if ((int)blockIdx.x * 256 >= n) return;
+    const int chunk = (n + gridDim.y - 1) / gridDim.y, j0 = blockIdx.y * chunk, j1 = min(n, j0 + chunk);
+    uvo_keypoint me = raw[min(i, n - 1)];
+    const float kme = me.x;
+    int r = 0, d = 0;
+    for (int jb = j0; jb < j1; jb += 256) {
+        __syncthreads();
+        if (jb + tid < j1) { const uvo_keypoint o = raw[jb + tid]; s_kp[tid] = o; s_key[tid] = o.x; }
+        __syncthreads();
+        const int m = min(256, j1 - jb);
+        int ties = 0;
+        for (int q = 0; q < m; q++) {
+            const float kq = s_key[q];
+            r += kq < kme; ties += kq == kme;
+        }
+        if (ties) {                                                     // the same x: other orientations of one extremum, a repeat, (rarely) a neighbour -- or just i itself
+            for (int q = 0; q < m; q++) {
+                if (s_key[q] != kme || jb + q == i) continue;
+                const uvo_keypoint o = s_kp[q];
+                const bool before = sift_kp_less(o, me) || (!sift_kp_less(me, o) && jb + q < i);
+                r += before;
+                if (before && o.size == me.size && o.angle == me.angle) d = 1;
+            }
+        }
+    }
+    if (i < n) { if (r) atomicAdd(&rank[i], r); if (d) atomicOr(&dup[i], 1); }
+}
+// sorted[rank] = raw; then the keypoints that do not repeat their predecessor, packed in order: kept[], their count to cnt[3]
+__global__ __launch_bounds__(256) void k_sift_place(const uvo_keypoint* __restrict__ raw, const int* __restrict__ cnt_p, int cap, const int* __restrict__ rank,
+                                                    const int* __restrict__ dup, uvo_keypoint* sorted, int* keep)
+{
+    const int n = min(*cnt_p, cap), i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int r = rank[i];
+    sorted[r] = raw[i]; keep[r] = !dup[i];
+}
+// order-preserving compaction by one workgroup: 16 waves, a contiguous segment each; a wave walks its segment 64 records at a time
+// (coalesced) and places the kept ones with ballot / mbcnt, once to count and once to write
+__global__ __launch_bounds__(1024) void k_sift_pack(const uvo_keypoint* __restrict__ src, const int* __restrict__ n_p, int cap, const int* __restrict__ keep,
+                                                    const int* __restrict__ greater, int nfeatures, int scale_back, uvo_keypoint* dst, int* n_out)
+{
+    __shared__ int s_cnt[16];
+    const int n = min(*n_p, cap), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int seg = ((n + 15) / 16 + 63) & ~63, e0 = wv * seg, e1 = min(n, e0 + seg);
+    const bool cut = greater && nfeatures > 0 && n > nfeatures;          // retainBest is a no-op otherwise
+    int total = 0;
+    for (int e = e0 + lane; e - lane < e1; e += 64) {
+        const bool k = e < e1 && (cut ? (greater[e] < nfeatures) : (keep ? keep[e] != 0 : true));
+        total += __popcll(__ballot(k));
+    }
+    if (lane == 0) s_cnt[wv] = total;
+    __syncthreads();
+    int pos = 0, all = 0;
+    for (int q = 0; q < 16; q++) { const int v = s_cnt[q]; pos += q < wv ? v : 0; all += v; }
+    for (int e = e0 + lane; e - lane < e1; e += 64) {
+        const bool k = e < e1 && (cut ? (greater[e] < nfeatures) : (keep ? keep[e] != 0 : true));
+        const unsigned long long m = __ballot(k);
+        if (k) {
+            uvo_keypoint kp = src[e];
+            if (scale_back) { kp.octave = (kp.octave & ~255) | ((kp.octave + -1) & 255); kp.x *= 0.5f; kp.y *= 0.5f; kp.size *= 0.5f; }
+            dst[pos + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = kp;
+        }
+        pos += __popcll(m);
+    }
+    if (tid == 0) *n_out = all;
+}
+// greater[i] = the number of kept keypoints with a larger response (retainBest keeps i when that is below nfeatures)
+__global__ __launch_bounds__(256) void k_sift_greater(const uvo_keypoint* __restrict__ kept, const int* __restrict__ m_p, int cap, int nfeatures, int* greater)
+{
+    __shared__ float s_r[256];
+    const int m = min(*m_p, cap), tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+    if (nfeatures <= 0 || m <= nfeatures || (int)blockIdx.x * 256 >= m) return;
+    const int chunk = (m + gridDim.y - 1) / gridDim.y, j0 = blockIdx.y * chunk, j1 = min(m, j0 + chunk);
+    const float me = kept[min(i, m - 1)].response;
+    int g = 0;
+    for (int jb = j0; jb < j1; jb += 256) {
+        __syncthreads();
+        if (jb + tid < j1) s_r[tid] = kept[jb + tid].response;
+        __syncthreads();
+        const int mm = min(256, j1 - jb);
+        for (int q = 0; q < mm; q++) g += s_r[q] > me;
+    }
+    if (i < m && g) atomicAdd(&greater[i], g);
 }
 
 // ------------------------------------------------------------------------------------------ host
@@ -390,29 +709,35 @@ static int sift_gauss_kernel(double sigma, float* k)              // getGaussian
     for (int i = 0; i < n; i++) k[i] = (float)(t[i] * sum);
     return n;
 }
-static uvo_status sift_blur(Ctx* c, SiftWs* s, const float* src, float* dst, int w, int h, double sigma)
+template <int R>
+static void sift_blur_tile_launch(hipStream_t st, const float* src, float* dst, float* dog, int w, int h, const SiftTaps& t)
+{
+    hipLaunchKernelGGL((k_sift_blur_tile<R, 32>), dim3((w + 63) / 64, (h + 31) / 32), dim3(256), 0, st, src, dst, dog, w, h, t);
+}
+// dst = GaussianBlur(src, sigma); dog (may be null) = dst - src
+static uvo_status sift_blur(Ctx* c, SiftWs* s, const float* src, float* dst, float* dog, int w, int h, double sigma)
 {
     SiftTaps t;
     memset(&t, 0, sizeof(t));
     const int n = sift_gauss_kernel(sigma, t.k);
     t.r = n / 2;
-    dim3 grid((w + 255) / 256, h);
-    hipLaunchKernelGGL(k_sift_blur, grid, dim3(256), 0, c->stream, src, s->tmp, w, h, t, 0);
-    hipLaunchKernelGGL(k_sift_blur, grid, dim3(256), 0, c->stream, static_cast<const float*>(s->tmp), dst, w, h, t, 1);
+    hipStream_t st = c->stream;
+    switch (t.r) {
+#define UVO_SIFT_BLUR_CASE(R) case R: sift_blur_tile_launch<R>(st, src, dst, dog, w, h, t); break;
+        UVO_SIFT_BLUR_CASE(2) UVO_SIFT_BLUR_CASE(3) UVO_SIFT_BLUR_CASE(4) UVO_SIFT_BLUR_CASE(5) UVO_SIFT_BLUR_CASE(6) UVO_SIFT_BLUR_CASE(7) UVO_SIFT_BLUR_CASE(8)
+        UVO_SIFT_BLUR_CASE(9) UVO_SIFT_BLUR_CASE(10) UVO_SIFT_BLUR_CASE(11) UVO_SIFT_BLUR_CASE(12) UVO_SIFT_BLUR_CASE(13) UVO_SIFT_BLUR_CASE(14) UVO_SIFT_BLUR_CASE(15)
+        UVO_SIFT_BLUR_CASE(16)
+#undef UVO_SIFT_BLUR_CASE
+        default: {                                                    // other radii (non-default sigma / layer counts): the two plain passes
+            dim3 grid((w + 255) / 256, h);
+            hipLaunchKernelGGL(k_sift_blur, grid, dim3(256), 0, st, src, s->tmp, w, h, t, 0);
+            hipLaunchKernelGGL(k_sift_blur, grid, dim3(256), 0, st, static_cast<const float*>(s->tmp), dst, w, h, t, 1);
+            const size_t npx = (size_t)w * h;
+            if (dog) hipLaunchKernelGGL(k_sift_dog, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, src, static_cast<const float*>(dst), dog, npx);
+        }
+    }
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
-}
-
-static bool kp_less(const uvo_keypoint& a, const uvo_keypoint& b)       // KeyPoint_LessThan (features2d keypoint.cpp)
-{
-    if (a.x != b.x) return a.x < b.x;
-    if (a.y != b.y) return a.y < b.y;
-    if (a.size != b.size) return a.size > b.size;
-    if (a.angle != b.angle) return a.angle < b.angle;
-    if (a.response != b.response) return a.response > b.response;
-    if (a.octave != b.octave) return a.octave > b.octave;
-    if (a.class_id != b.class_id) return a.class_id > b.class_id;
-    return false;
 }
 
 uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int nfeatures, int nL, double contrastThreshold,
@@ -428,7 +753,7 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
         int ow = 2 * w, oh = 2 * h;
         bool ok = hipMalloc(reinterpret_cast<void**>(&s->tmp), sizeof(float) * (size_t)ow * oh) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&s->d_img), (size_t)w * h) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&s->d_cnt), sizeof(int) * 4) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&s->d_cnt), sizeof(int) * 8) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&s->d_exptab), sizeof(float) * 64) == hipSuccess;
         for (int o = 0; o < nOct && ok; o++) {
             s->ow[o] = ow; s->oh[o] = oh;
@@ -437,7 +762,7 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
             ow /= 2; oh /= 2;
             if (ow < 1 || oh < 1) { ok = ok && o + 1 >= nOct; }
         }
-        ok = ok && sift_grow(s, 8 * c->cap, 4 * c->cap, c->cap);
+        ok = ok && sift_grow(s, 8 * c->cap, 4 * c->cap);
         if (!ok) { sift_ws_release(s); c->err = "uvo_sift_detect: out of device memory for the scale-space pyramid"; return UVO_HIP_ERROR; }
         float tab[64];
         for (int i = 0; i < 64; i++) tab[i] = (float)(pow(2.0, (double)i / 64) * .9670371139572337719125840413672004409288e-2);     // hal::exp32f's table
@@ -450,7 +775,7 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
         UVO_HIP_TRY(c, hipMemcpy2DAsync(s->d_img, w, gray, stride, w, h, mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         d_img = s->d_img;
     }
-    UVO_HIP_TRY(c, hipMemsetAsync(s->d_cnt, 0, sizeof(int) * 4, st));
+    UVO_HIP_TRY(c, hipMemsetAsync(s->d_cnt, 0, sizeof(int) * 8, st));
     // createInitialImage + buildGaussianPyramid + buildDoGPyramid
     double sig[kSiftMaxLayers + 3];
     sig[0] = sigma;
@@ -466,14 +791,10 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
         const int ow = s->ow[o], oh = s->oh[o];
         for (int i = 0; i < nL + 3; i++) {
             float* dst = s->gauss[o * (nL + 3) + i];
-            if (o == 0 && i == 0) UVO_TRY(sift_blur(c, s, base, dst, ow, oh, (double)sig_diff));
+            if (o == 0 && i == 0) UVO_TRY(sift_blur(c, s, base, dst, nullptr, ow, oh, (double)sig_diff));
             else if (i == 0) hipLaunchKernelGGL(k_sift_half, dim3((ow + 255) / 256, oh), dim3(256), 0, st, static_cast<const float*>(s->gauss[(o - 1) * (nL + 3) + nL]), s->ow[o - 1], dst, ow, oh);
-            else UVO_TRY(sift_blur(c, s, s->gauss[o * (nL + 3) + i - 1], dst, ow, oh, sig[i]));
+            else UVO_TRY(sift_blur(c, s, s->gauss[o * (nL + 3) + i - 1], dst, s->dog[o * (nL + 2) + i - 1], ow, oh, sig[i]));     // + buildDoGPyramid's layer i - 1
         }
-        const size_t npx = (size_t)ow * oh;
-        for (int i = 0; i < nL + 2; i++)
-            hipLaunchKernelGGL(k_sift_dog, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, static_cast<const float*>(s->gauss[o * (nL + 3) + i]),
-                               static_cast<const float*>(s->gauss[o * (nL + 3) + i + 1]), s->dog[o * (nL + 2) + i], npx);
     }
     UVO_HIP_TRY(c, hipGetLastError());
     // findScaleSpaceExtrema
@@ -484,62 +805,54 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
     for (int i = 0; i < nOct * (nL + 2); i++) p.dog[i] = s->dog[i];
     for (int o = 0; o < nOct; o++) { p.ow[o] = s->ow[o]; p.oh[o] = s->oh[o]; }
     p.nL = nL;
-    int cnt[4];
+    SiftTiles tl;
+    memset(&tl, 0, sizeof(tl));
+    tl.nOct = nOct;
+    for (int o = 0; o < nOct; o++) {
+        const int ow = s->ow[o] - 2 * SIFT_IMG_BORDER, oh = s->oh[o] - 2 * SIFT_IMG_BORDER;
+        tl.tx[o] = ow > 0 ? (ow + 63) / 64 : 0;
+        tl.start[o + 1] = tl.start[o] + (ow > 0 && oh > 0 ? tl.tx[o] * ((oh + 15) / 16) : 0);
+    }
+    int cnt[8];
     for (int attempt = 0;; attempt++) {
-        for (int o = 0; o < nOct; o++) {
-            const int ow = s->ow[o], oh = s->oh[o];
-            if (ow <= 2 * SIFT_IMG_BORDER || oh <= 2 * SIFT_IMG_BORDER) continue;
-            for (int i = 1; i <= nL; i++)
-                hipLaunchKernelGGL(k_sift_extrema, dim3((ow - 2 * SIFT_IMG_BORDER + 255) / 256, oh - 2 * SIFT_IMG_BORDER), dim3(256), 0, st,
-                                   static_cast<const float*>(s->dog[o * (nL + 2) + i - 1]), static_cast<const float*>(s->dog[o * (nL + 2) + i]),
-                                   static_cast<const float*>(s->dog[o * (nL + 2) + i + 1]), ow, oh, o, i, threshold, s->d_cand, s->d_cnt, s->cand_cap);
-        }
+        const int rc = s->raw_cap;
+        int* d_rank = s->d_ints; int* d_dup = s->d_ints + rc; int* d_keep = s->d_ints + 2 * (size_t)rc; int* d_greater = s->d_ints + 3 * (size_t)rc;
+        UVO_HIP_TRY(c, hipMemsetAsync(s->d_ints, 0, sizeof(int) * 4 * (size_t)rc, st));
+        if (tl.start[nOct] > 0)
+            hipLaunchKernelGGL(k_sift_extrema_all, dim3(tl.start[nOct]), dim3(256), 0, st, p, tl, threshold, s->d_cand, s->d_cnt, s->cand_cap);
         hipLaunchKernelGGL(k_sift_refine, dim3((s->cand_cap + 63) / 64), dim3(64), 0, st, p, static_cast<const SiftCand*>(s->d_cand), static_cast<const int*>(s->d_cnt),
-                           s->cand_cap, (float)contrastThreshold, (float)edgeThreshold, (float)sigma, static_cast<const float*>(s->d_exptab), s->d_raw, s->d_cnt + 1, s->raw_cap);
+                           s->cand_cap, (float)contrastThreshold, (float)edgeThreshold, (float)sigma, s->d_surv, s->d_cnt + 2);
+        hipLaunchKernelGGL(k_sift_orient, dim3(4096), dim3(64), 0, st, p, static_cast<const SiftSurv*>(s->d_surv), static_cast<const int*>(s->d_cnt + 2), s->cand_cap,
+                           static_cast<const float*>(s->d_exptab), s->d_raw, s->d_cnt + 1, rc);
+        // KeyPointsFilter::removeDuplicatedSorted, retainBest(nfeatures), the scaling back of firstOctave = -1
+        hipLaunchKernelGGL(k_sift_rank, dim3(rc / 256, 16), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_raw), static_cast<const int*>(s->d_cnt + 1), rc, d_rank, d_dup);
+        hipLaunchKernelGGL(k_sift_place, dim3(rc / 256), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_raw), static_cast<const int*>(s->d_cnt + 1), rc,
+                           static_cast<const int*>(d_rank), static_cast<const int*>(d_dup), s->d_sorted, d_keep);
+        hipLaunchKernelGGL(k_sift_pack, dim3(1), dim3(1024), 0, st, static_cast<const uvo_keypoint*>(s->d_sorted), static_cast<const int*>(s->d_cnt + 1), rc,
+                           static_cast<const int*>(d_keep), static_cast<const int*>(nullptr), 0, 0, s->d_kept, s->d_cnt + 3);
+        hipLaunchKernelGGL(k_sift_greater, dim3(rc / 256, 16), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_kept), static_cast<const int*>(s->d_cnt + 3), rc, nfeatures, d_greater);
+        hipLaunchKernelGGL(k_sift_pack, dim3(1), dim3(1024), 0, st, static_cast<const uvo_keypoint*>(s->d_kept), static_cast<const int*>(s->d_cnt + 3), rc,
+                           static_cast<const int*>(nullptr), static_cast<const int*>(d_greater), nfeatures, 1, s->d_kps, s->d_cnt + 4);
+        if (desc)
+            hipLaunchKernelGGL(k_sift_descriptor, dim3(16384), dim3(64), 0, st, p, static_cast<const uvo_keypoint*>(s->d_kps), static_cast<const int*>(s->d_cnt + 4), rc,
+                               static_cast<const float*>(s->d_exptab), s->d_desc);
         UVO_HIP_TRY(c, hipGetLastError());
         UVO_HIP_TRY(c, hipMemcpyAsync(cnt, s->d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
         UVO_HIP_TRY(c, hipStreamSynchronize(st));
         if (cnt[0] <= s->cand_cap && cnt[1] <= s->raw_cap) break;
-        // a list overflowed: both counters still counted everything they saw, so one more pass with room for it is enough, unless the
-        // candidate list was cut (then the keypoint count is a lower bound and a third pass may follow)
-        if (attempt >= 3 || !sift_grow(s, cnt[0] + cnt[0] / 4, std::max(cnt[1] + cnt[1] / 4, cnt[0] > s->cand_cap ? cnt[0] : 0), 0)) {
+        // a list overflowed (its counter still counted everything it saw; every kernel clamped to the capacity): the extrema stage runs
+        // again with room for it, unless the candidate list was cut -- then the keypoint count is a lower bound and another pass may follow
+        if (attempt >= 3 || !sift_grow(s, cnt[0] + cnt[0] / 4, std::max(cnt[1] + cnt[1] / 4, cnt[0] > s->cand_cap ? cnt[0] : 0))) {
             c->err = "uvo_sift_detect: out of device memory for the extrema lists"; return UVO_HIP_ERROR;
         }
-        UVO_HIP_TRY(c, hipMemsetAsync(s->d_cnt, 0, sizeof(int) * 4, st));
+        UVO_HIP_TRY(c, hipMemsetAsync(s->d_cnt, 0, sizeof(int) * 8, st));
     }
-    // KeyPointsFilter::removeDuplicatedSorted, retainBest(nfeatures), the scaling back of firstOctave = -1: a few thousand records, on the host
-    std::vector<uvo_keypoint> raw((size_t)cnt[1]);
-    if (cnt[1]) UVO_HIP_TRY(c, hipMemcpy(raw.data(), s->d_raw, sizeof(uvo_keypoint) * raw.size(), hipMemcpyDeviceToHost));
-    std::sort(raw.begin(), raw.end(), kp_less);
-    std::vector<uvo_keypoint> fin;
-    fin.reserve(raw.size());
-    for (const uvo_keypoint& k : raw)
-        if (fin.empty() || fin.back().x != k.x || fin.back().y != k.y || fin.back().size != k.size || fin.back().angle != k.angle) fin.push_back(k);
-    if (nfeatures > 0 && (int)fin.size() > nfeatures) {
-        // retainBest: everything whose response is at least the nfeatures-th largest, kept in sorted order (OpenCV leaves them in
-        // nth_element's order, which is implementation-defined: DESIGN.md section 6)
-        std::vector<float> resp(fin.size());
-        for (size_t i = 0; i < fin.size(); i++) resp[i] = fin[i].response;
-        std::nth_element(resp.begin(), resp.begin() + (nfeatures - 1), resp.end(), [](float a, float b) { return a > b; });
-        const float amb = resp[(size_t)nfeatures - 1];
-        size_t m = 0;
-        for (size_t i = 0; i < fin.size(); i++) if (fin[i].response >= amb) fin[m++] = fin[i];
-        fin.resize(m);
-    }
-    for (uvo_keypoint& k : fin) { k.octave = (k.octave & ~255) | ((k.octave + -1) & 255); k.x *= 0.5f; k.y *= 0.5f; k.size *= 0.5f; }
-    const int nk = (int)fin.size();
+    const int nk = cnt[4];
     *n_out = nk;
     if ((kps || desc) && nk > cap) { c->err = "uvo_sift_detect: output capacity too small"; return UVO_CAPACITY; }
-    if (desc && !sift_grow(s, 0, 0, nk)) { c->err = "uvo_sift_detect: out of device memory for the descriptors"; return UVO_HIP_ERROR; }
-    if (kps && nk) memcpy(kps, fin.data(), sizeof(uvo_keypoint) * (size_t)nk);
-    if (desc && nk) {
-        UVO_HIP_TRY(c, hipMemcpyAsync(s->d_kps, fin.data(), sizeof(uvo_keypoint) * (size_t)nk, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_sift_descriptor, dim3((nk + kSiftDescThreads - 1) / kSiftDescThreads), dim3(kSiftDescThreads), 0, st, p,
-                           static_cast<const uvo_keypoint*>(s->d_kps), nk, static_cast<const float*>(s->d_exptab), s->d_desc);
-        UVO_HIP_TRY(c, hipGetLastError());
-        UVO_HIP_TRY(c, hipMemcpyAsync(desc, s->d_desc, sizeof(float) * 128 * (size_t)nk, hipMemcpyDeviceToHost, st));
-        UVO_HIP_TRY(c, hipStreamSynchronize(st));                      // (fin's upload is done too)
-    }
+    if (kps && nk) UVO_HIP_TRY(c, hipMemcpyAsync(kps, s->d_kps, sizeof(uvo_keypoint) * (size_t)nk, hipMemcpyDeviceToHost, st));
+    if (desc && nk) UVO_HIP_TRY(c, hipMemcpyAsync(desc, s->d_desc, sizeof(float) * 128 * (size_t)nk, hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipStreamSynchronize(st));
     return UVO_OK;
 }
 
