@@ -27,6 +27,7 @@ static const int SIFT_IMG_BORDER = 5, SIFT_MAX_INTERP_STEPS = 5, SIFT_ORI_HIST_B
 
 struct SiftCand { int o, layer, r, c; };
 struct SiftSurv { uvo_keypoint kpt; int o, layer, r, c; };
+struct SiftPyr { const float* gauss[kSiftMaxOctaves * (kSiftMaxLayers + 3)]; const float* dog[kSiftMaxOctaves * (kSiftMaxLayers + 2)]; int ow[kSiftMaxOctaves], oh[kSiftMaxOctaves]; int nL; };
 struct SiftWs {
     int w = 0, h = 0, nL = 0, nOct = 0;
     int ow[kSiftMaxOctaves], oh[kSiftMaxOctaves];
@@ -34,6 +35,7 @@ struct SiftWs {
     float* dog[kSiftMaxOctaves * (kSiftMaxLayers + 2)] = {nullptr};
     float* tmp = nullptr; uint8_t* d_img = nullptr;
     float* d_exptab = nullptr;
+    float* d_taps = nullptr; int* d_radii = nullptr; double taps_sigma = 0; int taps_nL = 0;     // the layers' filter taps, for k_sift_tail
     SiftCand* d_cand = nullptr; SiftSurv* d_surv = nullptr; uvo_keypoint* d_raw = nullptr; uvo_keypoint* d_kps = nullptr; float* d_desc = nullptr;
     uvo_keypoint* d_sorted = nullptr; uvo_keypoint* d_kept = nullptr; int* d_ints = nullptr;      // rank, dup, keep, greater: raw_cap each
     int* d_cnt = nullptr;         // [0] candidates, [1] raw keypoints, [2] refined extrema, [3] after duplicate removal, [4] final
@@ -44,7 +46,7 @@ static void sift_ws_release(SiftWs* s)
     for (float*& p : s->gauss) { (void)hipFree(p); p = nullptr; }
     for (float*& p : s->dog) { (void)hipFree(p); p = nullptr; }
     (void)hipFree(s->tmp); (void)hipFree(s->d_img); (void)hipFree(s->d_cand); (void)hipFree(s->d_surv); (void)hipFree(s->d_raw); (void)hipFree(s->d_kps); (void)hipFree(s->d_desc);
-    (void)hipFree(s->d_cnt); (void)hipFree(s->d_exptab); (void)hipFree(s->d_sorted); (void)hipFree(s->d_kept); (void)hipFree(s->d_ints);
+    (void)hipFree(s->d_cnt); (void)hipFree(s->d_exptab); (void)hipFree(s->d_taps); (void)hipFree(s->d_radii); s->d_taps = nullptr; s->d_radii = nullptr; s->taps_sigma = 0; (void)hipFree(s->d_sorted); (void)hipFree(s->d_kept); (void)hipFree(s->d_ints);
     s->d_sorted = nullptr; s->d_kept = nullptr; s->d_ints = nullptr;
     s->tmp = nullptr; s->d_img = nullptr; s->d_cand = nullptr; s->d_surv = nullptr; s->d_raw = nullptr; s->d_kps = nullptr; s->d_desc = nullptr; s->d_cnt = nullptr; s->d_exptab = nullptr;
     s->w = s->h = 0; s->cand_cap = s->raw_cap = 0;
@@ -231,6 +233,46 @@ __global__ __launch_bounds__(256) void k_sift_blur_tile(const float* __restrict_
     }
 }
 
+// The small octaves (at most 4096 pixels a layer) in ONE launch by one workgroup: the halving, the nL + 2 blurs (two plain passes
+// through a scratch image) and the differences of every such octave, one after the other.  They are 30-odd dependent launches of a
+// few microseconds each otherwise, most of it dispatch latency; the arithmetic per pixel is k_sift_blur's.
+__global__ __launch_bounds__(1024) void k_sift_tail(SiftPyr p, const float* __restrict__ taps, const int* __restrict__ radii, int o_first, int nOct)
+{
+    __shared__ float s_a[4096], s_b[4096], s_t[4096];                   // the layer being blurred, its successor, the row-filtered image
+    __shared__ float s_k[kSiftMaxTaps];
+    const int tid = threadIdx.x, nL = p.nL;
+    float* cur = s_a; float* nxt = s_b;
+    for (int o = o_first; o < nOct; o++) {
+        const int w = p.ow[o], h = p.oh[o], pw = p.ow[o - 1], n = w * h;
+        float* g0 = const_cast<float*>(p.gauss[o * (nL + 3)]);
+        const float* prev = p.gauss[(o - 1) * (nL + 3) + nL];           // (written by an earlier launch, or by this workgroup before a barrier)
+        __syncthreads();
+        for (int e = tid; e < n; e += 1024) { const int y = e / w, x = e - y * w; const float v = prev[(size_t)(2 * y) * pw + 2 * x]; cur[e] = v; g0[e] = v; }      // INTER_NEAREST
+        for (int i = 1; i < nL + 3; i++) {
+            float* dst = const_cast<float*>(p.gauss[o * (nL + 3) + i]);
+            float* dg = const_cast<float*>(p.dog[o * (nL + 2) + i - 1]);
+            const int r = radii[i];
+            if (tid < kSiftMaxTaps) s_k[tid] = taps[i * kSiftMaxTaps + tid];
+            __syncthreads();
+            for (int e = tid; e < n; e += 1024) {
+                const int y = e / w, x = e - y * w;
+                const float* row = cur + y * w;
+                float acc = s_k[r] * row[x];
+                for (int t = 1; t <= r; t++) acc += s_k[r + t] * (row[reflect101(x + t, w)] + row[reflect101(x - t, w)]);
+                s_t[e] = acc;
+            }
+            __syncthreads();
+            for (int e = tid; e < n; e += 1024) {
+                const int y = e / w, x = e - y * w;
+                float acc = s_k[r] * s_t[e];
+                for (int t = 1; t <= r; t++) acc += s_k[r + t] * (s_t[reflect101(y + t, h) * w + x] + s_t[reflect101(y - t, h) * w + x]);
+                nxt[e] = acc; dst[e] = acc; dg[e] = acc - cur[e];
+            }
+            __syncthreads();
+            float* sw = cur; cur = nxt; nxt = sw;
+        }
+    }
+}
 __global__ __launch_bounds__(256) void k_sift_half(const float* __restrict__ src, int sw, float* __restrict__ dst, int w, int h)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -243,7 +285,6 @@ __global__ __launch_bounds__(256) void k_sift_dog(const float* __restrict__ a, c
 }
 
 // ------------------------------------------------------------------------------------------ extrema
-struct SiftPyr { const float* gauss[kSiftMaxOctaves * (kSiftMaxLayers + 3)]; const float* dog[kSiftMaxOctaves * (kSiftMaxLayers + 2)]; int ow[kSiftMaxOctaves], oh[kSiftMaxOctaves]; int nL; };
 struct SiftTiles { int start[kSiftMaxOctaves + 1]; int tx[kSiftMaxOctaves]; int nOct; };
 // findScaleSpaceExtrema's 26-neighbour test, every octave and layer in one launch: a workgroup takes a 64 x 16 tile of one octave and
 // walks up its nL + 2 difference layers, staging each (with a one-pixel border) in LDS once; a thread keeps the 3 x 3 maximum, the
@@ -471,6 +512,9 @@ __global__ __launch_bounds__(64) void k_sift_orient(SiftPyr p, const SiftSurv* _
 // LDS, and eight lanes then apply one sample's eight shares (eight different bins) per step, sample after sample -- LDS operations of
 // one wave are performed in issue order, so every bin sees its additions in the order the one-thread loop makes them.
 static const int kSiftHist = 6 * 6 * 10;
+#ifndef UVO_SIFT_LDS_FADD
+#define UVO_SIFT_LDS_FADD 0      // ds_add_f32 is bit-identical but measured 999 us against 520 for the read-add-write of eight lanes
+#endif
 __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyr p, const uvo_keypoint* __restrict__ kps, const int* __restrict__ nk_p, int kp_cap,
                                                         const float* __restrict__ exptab, float* __restrict__ desc)
 {
@@ -480,6 +524,7 @@ __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyr p, const uvo_key
     __shared__ float s_tab[64];
     __shared__ __attribute__((aligned(16))) float s_dst[128];
     __shared__ float s_sq[128];
+    __shared__ int s_pend[128];                                        // queued samples (row << 16 | column), raster order
     const int lane = threadIdx.x, nk = min(*nk_p, kp_cap);
     s_tab[lane] = exptab[lane];
     for (int k = blockIdx.x; k < nk; k += gridDim.x) {
@@ -510,53 +555,90 @@ __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyr p, const uvo_key
     const int side = 2 * radius + 1;
     const long long total = (long long)side * side;
     int wi = lane / side, wj = lane - wi * side;                      // this lane's sample of the current batch: row wi, column wj of the window
-    for (long long base = 0; base < total; base += 64) {
-        bool pass = false;
-        float v[8]; int idx = 0;
-        if (wi < side) {
-            const int i = wi - radius, j = wj - radius;
+    // Two steps, because about half of the window's square lies outside the rotated 5 x 5 cell area: the cheap part (rotation and
+    // window test) runs on every sample and queues the ones inside, in raster order; the expensive part (gradient, exp, atan2, sqrt,
+    // shares) runs on 64 queued samples at a time, every lane busy.
+    int npend = 0;
+    for (long long base = 0; base < total || npend > 0; base += 64) {
+        if (base < total) {
+            bool pass = false;
+            if (wi < side) {
+                const int i = wi - radius, j = wj - radius;
+                const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
+                const float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
+                const int r = py + i, c = px + j;
+                pass = rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1;
+            }
+            const unsigned long long m = __ballot(pass);
+            if (pass) s_pend[npend + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (wi << 16) | wj;
+            npend += __popcll(m);
+            wj += 64;
+            while (wj >= side) { wj -= side; wi++; }
+            if (npend < 64 && base + 64 < total) continue;
+        }
+        __syncthreads();
+        const int cnt = npend < 64 ? npend : 64;
+        if (lane < cnt) {
+            const int pk = s_pend[lane], i = (pk >> 16) - radius, j = (pk & 0xFFFF) - radius;
             const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
             const int r = py + i, c = px + j;
-            if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < rows - 1 && c > 0 && c < cols - 1) {
-                pass = true;
-                const float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1], dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
-                const float wgt = sift_exp32f((c_rot * c_rot + r_rot * r_rot) * exp_scale, s_tab);
-                float obin = (sift_atan2_deg(dy, dx) - ori) * bins_per_rad;
-                const float mag = sqrtf(dx * dx + dy * dy) * wgt;
-                const int r0 = cv_floor_d(rbin), c0 = cv_floor_d(cbin);
-                int o0 = cv_floor_d(obin);
-                rbin -= r0; cbin -= c0; obin -= o0;
-                if (o0 < 0) o0 += n;
-                if (o0 >= n) o0 -= n;
-                const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
-                const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
-                const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
-                const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
-                idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-                v[0] = v_rco000; v[1] = v_rco001; v[2] = v_rco010; v[3] = v_rco011; v[4] = v_rco100; v[5] = v_rco101; v[6] = v_rco110; v[7] = v_rco111;
-            }
-        }
-        const unsigned long long m = __ballot(pass);
-        if (pass) {
-            const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            *reinterpret_cast<float4*>(&s_val[pos * 8]) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(&s_val[pos * 8 + 4]) = make_float4(v[4], v[5], v[6], v[7]);
-            // the eight bins of the shares, in the order of v[]: +0, +1, +(n+2), +(n+3), +(d+2)(n+2), ...
+            const float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1], dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
+            const float wgt = sift_exp32f((c_rot * c_rot + r_rot * r_rot) * exp_scale, s_tab);
+            float obin = (sift_atan2_deg(dy, dx) - ori) * bins_per_rad;
+            const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+            const int r0 = cv_floor_d(rbin), c0 = cv_floor_d(cbin);
+            int o0 = cv_floor_d(obin);
+            rbin -= r0; cbin -= c0; obin -= o0;
+            if (o0 < 0) o0 += n;
+            if (o0 >= n) o0 -= n;
+            const float v_r1 = mag * rbin, v_r0 = mag - v_r1;
+            const float v_rc11 = v_r1 * cbin, v_rc10 = v_r1 - v_rc11, v_rc01 = v_r0 * cbin, v_rc00 = v_r0 - v_rc01;
+            const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
+            const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
+            const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
+            *reinterpret_cast<float4*>(&s_val[lane * 8]) = make_float4(v_rco000, v_rco001, v_rco010, v_rco011);
+            *reinterpret_cast<float4*>(&s_val[lane * 8 + 4]) = make_float4(v_rco100, v_rco101, v_rco110, v_rco111);
+            // the eight bins of the shares, in that order: +0, +1, +(n+2), +(n+3), +(d+2)(n+2), ...
             const unsigned b0 = (unsigned)idx, b2 = b0 + (n + 2), b4 = b0 + (d + 2) * (n + 2), b6 = b0 + (d + 3) * (n + 2);
-            *reinterpret_cast<uint4*>(&s_bin[pos * 8]) = make_uint4(b0 | ((b0 + 1) << 16), b2 | ((b2 + 1) << 16), b4 | ((b4 + 1) << 16), b6 | ((b6 + 1) << 16));
+            *reinterpret_cast<uint4*>(&s_bin[lane * 8]) = make_uint4(b0 | ((b0 + 1) << 16), b2 | ((b2 + 1) << 16), b4 | ((b4 + 1) << 16), b6 | ((b6 + 1) << 16));
         }
+        const int rest = npend - cnt;                                  // < 64: what the last cheap step queued beyond the 64 taken now
+        const int keep = lane < rest ? s_pend[64 + lane] : 0;
         __syncthreads();
-        const int cnt = __popcll(m);
+        if (lane < rest) s_pend[lane] = keep;
+        npend = rest;
         if (lane < 8) {
-            for (int q = 0; q < cnt; q++) {
-                const int bi = s_bin[q * 8 + lane];
-                s_hist[bi] += s_val[q * 8 + lane];
+#if UVO_SIFT_LDS_FADD
+            // ds_add_f32: the addition is done by the LDS unit (IEEE single add, one rounding), no round trip through the lane
+            for (int q = 0; q < cnt; q++)
+                __hip_atomic_fetch_add(&s_hist[s_bin[q * 8 + lane]], s_val[q * 8 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+            // a sample's eight bins are distinct, and while the next sample has the same eight (the same cell and orientation bin: runs
+            // of a few samples along a window row) nobody else touches them: the running sums stay in the lanes, every addition is
+            // still written through, and the read (the one round trip of the chain) happens only when the bins change
+            int cur = -1; float acc = 0.f;
+            int q = 0;
+            for (; q + 4 <= cnt; q += 4) {
+                int bi[4]; float vv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { bi[u] = s_bin[(q + u) * 8 + lane]; vv[u] = s_val[(q + u) * 8 + lane]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (bi[u] != cur) { acc = s_hist[bi[u]]; cur = bi[u]; }
+                    acc += vv[u];
+                    s_hist[cur] = acc;
+                }
             }
+            for (; q < cnt; q++) {
+                const int b1 = s_bin[q * 8 + lane];
+                if (b1 != cur) { acc = s_hist[b1]; cur = b1; }
+                acc += s_val[q * 8 + lane];
+                s_hist[cur] = acc;
+            }
+#endif
         }
         __syncthreads();
-        wj += 64;
-        while (wj >= side) { wj -= side; wi++; }
     }
     // the wrap of the orientation axis, the 4 x 4 x 8 rows, the two normalisations (sums in element order: one lane)
     if (lane < 16) {
@@ -609,7 +691,7 @@ __device__ __forceinline__ bool sift_kp_less(const uvo_keypoint& a, const uvo_ke
 }
 __global__ __launch_bounds__(256) void k_sift_rank(const uvo_keypoint* __restrict__ raw, const int* __restrict__ cnt_p, int cap, int* rank, int* dup)
 {
-    __shared__ float s_key[256];
+    __shared__ __attribute__((aligned(16))) float s_key[256];
     __shared__ uvo_keypoint s_kp[256];
     const int n = min(*cnt_p, cap), tid = threadIdx.x, i = blockIdx.x * 256 + tid;
     if ((int)blockIdx.x * 256 >= n) return;
@@ -620,12 +702,14 @@ __global__ __launch_bounds__(256) void k_sift_rank(const uvo_keypoint* __restric
     for (int jb = j0; jb < j1; jb += 256) {
         __syncthreads();
         if (jb + tid < j1) { const uvo_keypoint o = raw[jb + tid]; s_kp[tid] = o; s_key[tid] = o.x; }
+        else s_key[tid] = __int_as_float(0x7fc00000);                  // NaN: neither below nor equal
         __syncthreads();
         const int m = min(256, j1 - jb);
         int ties = 0;
-        for (int q = 0; q < m; q++) {
-            const float kq = s_key[q];
-            r += kq < kme; ties += kq == kme;
+        for (int q = 0; q < 256; q += 4) {
+            const float4 k4 = *reinterpret_cast<const float4*>(&s_key[q]);
+            r += (k4.x < kme) + (k4.y < kme) + (k4.z < kme) + (k4.w < kme);
+            ties += (k4.x == kme) + (k4.y == kme) + (k4.z == kme) + (k4.w == kme);
         }
         if (ties) {                                                     // the same x: other orientations of one extremum, a repeat, (rarely) a neighbour -- or just i itself
             for (int q = 0; q < m; q++) {
@@ -754,7 +838,9 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
         bool ok = hipMalloc(reinterpret_cast<void**>(&s->tmp), sizeof(float) * (size_t)ow * oh) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&s->d_img), (size_t)w * h) == hipSuccess &&
                   hipMalloc(reinterpret_cast<void**>(&s->d_cnt), sizeof(int) * 8) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&s->d_exptab), sizeof(float) * 64) == hipSuccess;
+                  hipMalloc(reinterpret_cast<void**>(&s->d_exptab), sizeof(float) * 64) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&s->d_taps), sizeof(float) * kSiftMaxTaps * (kSiftMaxLayers + 3)) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&s->d_radii), sizeof(int) * (kSiftMaxLayers + 3)) == hipSuccess;
         for (int o = 0; o < nOct && ok; o++) {
             s->ow[o] = ow; s->oh[o] = oh;
             for (int i = 0; i < nL + 3 && ok; i++) ok = hipMalloc(reinterpret_cast<void**>(&s->gauss[o * (nL + 3) + i]), sizeof(float) * (size_t)ow * oh) == hipSuccess;
@@ -787,7 +873,24 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
     hipLaunchKernelGGL(k_sift_resize2x, dim3((2 * w + 255) / 256, 2 * h), dim3(256), 0, st, d_img, w, h, base);
     const float sd2 = (float)sigma * (float)sigma - 0.5f * 0.5f * 4;
     const float sig_diff = sqrtf(sd2 > 0.01f ? sd2 : 0.01f);
-    for (int o = 0; o < nOct; o++) {
+    SiftPyr p;
+    memset(&p, 0, sizeof(p));
+    for (int i = 0; i < nOct * (nL + 3); i++) p.gauss[i] = s->gauss[i];
+    for (int i = 0; i < nOct * (nL + 2); i++) p.dog[i] = s->dog[i];
+    for (int o = 0; o < nOct; o++) { p.ow[o] = s->ow[o]; p.oh[o] = s->oh[o]; }
+    p.nL = nL;
+    int o_tail = nOct;                                                  // the first octave of k_sift_tail's range
+    for (int o = nOct - 1; o >= 1 && (size_t)s->ow[o] * s->oh[o] <= 4096; o--) o_tail = o;
+    if (o_tail < nOct && (s->taps_sigma != sigma || s->taps_nL != nL)) {
+        float taps[kSiftMaxTaps * (kSiftMaxLayers + 3)]; int radii[kSiftMaxLayers + 3];
+        memset(taps, 0, sizeof(taps)); memset(radii, 0, sizeof(radii));
+        for (int i = 1; i < nL + 3; i++) radii[i] = sift_gauss_kernel(sig[i], taps + i * kSiftMaxTaps) / 2;
+        UVO_HIP_TRY(c, hipStreamSynchronize(st));                      // (a launch of the previous call may still read the old taps)
+        UVO_HIP_TRY(c, hipMemcpy(s->d_taps, taps, sizeof(taps), hipMemcpyHostToDevice));
+        UVO_HIP_TRY(c, hipMemcpy(s->d_radii, radii, sizeof(radii), hipMemcpyHostToDevice));
+        s->taps_sigma = sigma; s->taps_nL = nL;
+    }
+    for (int o = 0; o < o_tail; o++) {
         const int ow = s->ow[o], oh = s->oh[o];
         for (int i = 0; i < nL + 3; i++) {
             float* dst = s->gauss[o * (nL + 3) + i];
@@ -796,15 +899,11 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
             else UVO_TRY(sift_blur(c, s, s->gauss[o * (nL + 3) + i - 1], dst, s->dog[o * (nL + 2) + i - 1], ow, oh, sig[i]));     // + buildDoGPyramid's layer i - 1
         }
     }
+    if (o_tail < nOct)
+        hipLaunchKernelGGL(k_sift_tail, dim3(1), dim3(1024), 0, st, p, static_cast<const float*>(s->d_taps), static_cast<const int*>(s->d_radii), o_tail, nOct);
     UVO_HIP_TRY(c, hipGetLastError());
     // findScaleSpaceExtrema
     const int threshold = cv_floor_d(0.5 * contrastThreshold / nL * 255);
-    SiftPyr p;
-    memset(&p, 0, sizeof(p));
-    for (int i = 0; i < nOct * (nL + 3); i++) p.gauss[i] = s->gauss[i];
-    for (int i = 0; i < nOct * (nL + 2); i++) p.dog[i] = s->dog[i];
-    for (int o = 0; o < nOct; o++) { p.ow[o] = s->ow[o]; p.oh[o] = s->oh[o]; }
-    p.nL = nL;
     SiftTiles tl;
     memset(&tl, 0, sizeof(tl));
     tl.nOct = nOct;
