@@ -156,17 +156,20 @@ __global__ __launch_bounds__(256) void k_sift_resize2x(const uint8_t* __restrict
     dst[(size_t)y * (2 * w) + x] = h0 * b0 + h1 * b1;
 }
 struct SiftTaps { float k[kSiftMaxTaps]; int r; };
-// SymmRowFilter / SymmColumnFilter: s = k0 x0 + sum_i ki (x+i + x-i), BORDER_REFLECT_101
+// GaussianBlur on floats through the filter engine: kernels wider than 5 taps get the generic RowFilter (s = k[0] x[-r]; s += k[t] x[-r+t],
+// left to right) and, being symmetrical, SymmColumnFilter (s = k0 x0; s += ki (x[+i] + x[-i])); BORDER_REFLECT_101
 __global__ __launch_bounds__(256) void k_sift_blur(const float* __restrict__ src, float* __restrict__ dst, int w, int h, SiftTaps t, int vertical)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= w) return;
     const int r = t.r;
-    float acc = t.k[r] * src[(size_t)y * w + x];
-    if (!vertical) {
+    float acc;
+    if (!vertical) {                                                  // RowFilter: the taps left to right
         const float* s = src + (size_t)y * w;
-        for (int i = 1; i <= r; i++) acc += t.k[r + i] * (s[reflect101(x + i, w)] + s[reflect101(x - i, w)]);
-    } else {
+        acc = t.k[0] * s[reflect101(x - r, w)];
+        for (int i = 1; i <= 2 * r; i++) acc += t.k[i] * s[reflect101(x - r + i, w)];
+    } else {                                                          // SymmColumnFilter: centre, then the pairs
+        acc = t.k[r] * src[(size_t)y * w + x];
         for (int i = 1; i <= r; i++) acc += t.k[r + i] * (src[(size_t)reflect101(y + i, h) * w + x] + src[(size_t)reflect101(y - i, h) * w + x]);
     }
     dst[(size_t)y * w + x] = acc;
@@ -175,7 +178,8 @@ __global__ __launch_bounds__(256) void k_sift_blur(const float* __restrict__ src
 // workgroup, its input with an R-wide reflected border staged in LDS once, the row filter from LDS into LDS (each lane four
 // neighbouring outputs from one register window of 4 + 2R inputs, read as 16-byte vectors), the column filter from LDS (each lane
 // eight rows of one column from a window of 8 + 2R), and the difference of Gaussians dst - src written beside dst from the
-// centre value that is already in LDS.  Every output is the expression of k_sift_blur (same taps, same order, no contraction).
+// centre value that is already in LDS.  Every output is the expression of k_sift_blur (same taps, same order, no contraction): the
+// row filter left to right, the column filter centre first and then the pairs.
 template <int R, int TH>
 __global__ __launch_bounds__(256) void k_sift_blur_tile(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog, int w, int h, SiftTaps t)
 {
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void k_sift_blur_tile(const float* __restrict_
         if (lane < 2 * R) s_in[iy * IWP + 64 + lane] = row[reflect101(x0 - R + 64 + lane, w)];
     }
     __syncthreads();
-    float k[R + 1];
+    float k[R + 1];                                                     // k[i] = the tap at distance i from the centre (the kernel is symmetrical)
 #pragma unroll
     for (int i = 0; i <= R; i++) k[i] = t.k[R + i];
     {   // rows: 16 lanes x 4 outputs per row, 16 rows per pass
@@ -202,10 +206,10 @@ __global__ __launch_bounds__(256) void k_sift_blur_tile(const float* __restrict_
             for (int q = 0; q < (4 + 2 * R + 3) / 4; q++) { const float4 f = src4[q]; win[4 * q] = f.x; win[4 * q + 1] = f.y; win[4 * q + 2] = f.z; win[4 * q + 3] = f.w; }
             float acc[4];
 #pragma unroll
-            for (int o = 0; o < 4; o++) {
-                acc[o] = k[0] * win[o + R];
+            for (int o = 0; o < 4; o++) {                               // RowFilter: left to right, no pairing
+                acc[o] = k[R] * win[o];
 #pragma unroll
-                for (int i = 1; i <= R; i++) acc[o] += k[i] * (win[o + R + i] + win[o + R - i]);
+                for (int i = 1; i <= 2 * R; i++) acc[o] += k[i < R ? R - i : i - R] * win[o + i];
             }
             *reinterpret_cast<float4*>(&s_h[iy * TW + xq]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
         }
@@ -257,8 +261,8 @@ __global__ __launch_bounds__(1024) void k_sift_tail(SiftPyr p, const float* __re
             for (int e = tid; e < n; e += 1024) {
                 const int y = e / w, x = e - y * w;
                 const float* row = cur + y * w;
-                float acc = s_k[r] * row[x];
-                for (int t = 1; t <= r; t++) acc += s_k[r + t] * (row[reflect101(x + t, w)] + row[reflect101(x - t, w)]);
+                float acc = s_k[0] * row[reflect101(x - r, w)];
+                for (int t = 1; t <= 2 * r; t++) acc += s_k[t] * row[reflect101(x - r + t, w)];
                 s_t[e] = acc;
             }
             __syncthreads();

@@ -91,7 +91,10 @@ int orc_sift_gauss_kernel(double sigma, float* k /* >= 64 */)
 }
 static int reflect101(int p, int n) { if (n == 1) return 0; while (p < 0 || p >= n) { if (p < 0) p = -p; else p = 2 * n - 2 - p; } return p; }
 
-/* GaussianBlur(src, dst, Size(), sigma) on floats: SymmRowFilter then SymmColumnFilter, each s = k0 x0 + sum_i ki (x+i + x-i), BORDER_REFLECT_101 */
+/* GaussianBlur(src, dst, Size(), sigma) on floats = sepFilter2D through the filter engine (filter.dispatch.cpp, getLinearRowFilter /
+ * getLinearColumnFilter): kernels wider than 5 get the GENERIC RowFilter<float, float> -- s = k[0] x[-r]; s += k[t] x[-r+t], left to
+ * right, no pairing -- and, the kernel being symmetrical, SymmColumnFilter -- s = k0 x0 (+ delta = 0); s += ki (x[+i] + x[-i]).
+ * (SIFT's sigmas give 11 .. 27 taps; SymmRowSmallFilter only serves ksize <= 5.)  BORDER_REFLECT_101. */
 static void gaussian_blur(const img_t* src, img_t* dst, double sigma)
 {
     float k[64];
@@ -100,8 +103,8 @@ static void gaussian_blur(const img_t* src, img_t* dst, double sigma)
     for (int y = 0; y < h; y++) {
         const float* s = src->d + (size_t)y * w;
         for (int x = 0; x < w; x++) {
-            float acc = k[r] * s[x];
-            for (int i = 1; i <= r; i++) acc += k[r + i] * (s[reflect101(x + i, w)] + s[reflect101(x - i, w)]);
+            float acc = k[0] * s[reflect101(x - r, w)];
+            for (int t = 1; t < n; t++) acc += k[t] * s[reflect101(x - r + t, w)];
             tmp[(size_t)y * w + x] = acc;
         }
     }
