@@ -29,6 +29,13 @@ CHILD = textwrap.dedent(r"""
         assert d3.shape[1] == (128 if ext else 64)
     m = orc.match(desc, desc2, 0.8)
     assert len(m) > 10
+    # SIFT (o_sift.c): odd sizes, a tiny image whose upper octaves are a few pixels, dense noise (refinements that wander off), a cut list
+    ks, ds = orc.sift_detect(frames[0][0])
+    assert len(ks) > 50 and ds.shape == (len(ks), 128)
+    orc.sift_detect(frames[0][0][:131, :203].copy(), nfeatures=40)
+    orc.sift_detect(frames[0][0][:17, :23].copy())
+    orc.sift_detect(np.random.default_rng(5).integers(0, 256, (64, 90), dtype=np.uint8), nfeatures=0, n_octave_layers=2, sigma=1.2)
+    orc.sift_gauss_layer(frames[0][0][:40, :56].copy(), 3, 5)
     orc.knn2(desc[:1], desc2[:1])
     vo = orc.StereoVO(orc.stereo_params(400), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
     for l, r in frames:
