@@ -192,12 +192,12 @@ class Context:
         p, mem, keep = _ptr_mem(img, np.uint8)
         cap = int(cap if cap is not None else max(self.max_kpts, nfeatures if nfeatures > 0 else 0))
         n = C.c_int(0)
-        kps = np.zeros(cap, KP_DTYPE)
-        desc = np.zeros((cap, 128), np.float32)
+        kps = np.empty(cap, KP_DTYPE)                     # fresh buffers, returned as views of their first n rows (no second 5 MB copy)
+        desc = np.empty((cap, 128), np.float32)
         self._order_after_producer(img)
         self._check(self._lib.uvo_sift_detect(self._h, p, w, h, w, mem, int(nfeatures), int(n_octave_layers), float(contrast_threshold),
                                               float(edge_threshold), float(sigma), _p(kps), _p(desc), cap, C.byref(n)))
-        return kps[:n.value].copy(), desc[:n.value].copy()
+        return kps[:n.value], desc[:n.value]
 
     def sift_layer(self, octave: int, layer: int, dog: bool = False):
         """Test hook: a Gaussian / DoG layer of the last sift_detect (octave 0 = the doubled image)."""

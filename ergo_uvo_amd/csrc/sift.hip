@@ -188,10 +188,26 @@ __global__ __launch_bounds__(256) void k_sift_blur_tile(const float* __restrict_
     __shared__ float s_h[IH * TW];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    for (int iy = wv; iy < IH; iy += 4) {
-        const float* __restrict__ row = src + (size_t)reflect101(y0 - R + iy, h) * w;
-        s_in[iy * IWP + lane] = row[reflect101(x0 - R + lane, w)];
-        if (lane < 2 * R) s_in[iy * IWP + 64 + lane] = row[reflect101(x0 - R + 64 + lane, w)];
+    {   // a wave stages rows wv, wv + 4, ...: every load of the tile is issued before the first LDS store (one memory round trip per
+        // workgroup instead of one per row); the reflected column indices do not depend on the row
+        constexpr int NROW = (IH + 3) / 4;
+        const int ca = reflect101(x0 - R + lane, w), cb = reflect101(x0 - R + 64 + lane, w);
+        float va[NROW], vb[NROW];
+#pragma unroll
+        for (int q = 0; q < NROW; q++) {
+            const int iy = wv + 4 * q;
+            const float* __restrict__ row = src + (size_t)reflect101(y0 - R + min(iy, IH - 1), h) * w;
+            va[q] = row[ca];
+            vb[q] = lane < 2 * R ? row[cb] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < NROW; q++) {
+            const int iy = wv + 4 * q;
+            if (iy < IH) {
+                s_in[iy * IWP + lane] = va[q];
+                if (lane < 2 * R) s_in[iy * IWP + 64 + lane] = vb[q];
+            }
+        }
     }
     __syncthreads();
     float k[R + 1];                                                     // k[i] = the tap at distance i from the centre (the kernel is symmetrical)
