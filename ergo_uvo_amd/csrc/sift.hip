@@ -313,7 +313,7 @@ struct SiftTiles { int start[kSiftMaxOctaves + 1]; int tx[kSiftMaxOctaves]; int 
 __global__ __launch_bounds__(256) void k_sift_extrema_all(SiftPyr p, SiftTiles tl, int threshold, SiftCand* cand, int* cnt, int cap)
 {
     constexpr int TW = 64, TH = 16, SW = TW + 2, SH = TH + 2, SP = 68;
-    __shared__ float s_t[SH * SP];
+    __shared__ __attribute__((aligned(16))) float s_t[SH * SP];
     __shared__ unsigned short s_list[TW * TH * kSiftMaxLayers];        // layer << 10 | ly << 6 | lx: every pixel of the tile in every layer at worst
     __shared__ int s_n, s_base;
     if (threadIdx.x == 0) s_n = 0;
@@ -350,9 +350,16 @@ __global__ __launch_bounds__(256) void k_sift_extrema_all(SiftPyr p, SiftTiles t
 #pragma unroll
         for (int q = 0; q < 4; q++) { mx[0][q] = mx[1][q]; mn[0][q] = mn[1][q]; ce[0][q] = ce[1][q]; mx[1][q] = mx[2][q]; mn[1][q] = mn[2][q]; ce[1][q] = ce[2][q]; }
         float cmx[6], cmn[6];                                           // column maxima / minima over the three rows, columns lx - 1 .. lx + 4
+        float rw[3][6];                                                 // (16-byte + 8-byte reads: a lane's six values of a row are contiguous)
+#pragma unroll
+        for (int rr = 0; rr < 3; rr++) {
+            const float4 f4 = *reinterpret_cast<const float4*>(&s_t[(ly + rr) * SP + lx]);
+            const float2 f2 = *reinterpret_cast<const float2*>(&s_t[(ly + rr) * SP + lx + 4]);
+            rw[rr][0] = f4.x; rw[rr][1] = f4.y; rw[rr][2] = f4.z; rw[rr][3] = f4.w; rw[rr][4] = f2.x; rw[rr][5] = f2.y;
+        }
 #pragma unroll
         for (int q = 0; q < 6; q++) {
-            const float a = s_t[ly * SP + lx + q], b = s_t[(ly + 1) * SP + lx + q], cc = s_t[(ly + 2) * SP + lx + q];
+            const float a = rw[0][q], b = rw[1][q], cc = rw[2][q];
             cmx[q] = fmaxf(fmaxf(a, b), cc); cmn[q] = fminf(fminf(a, b), cc);
             if (q >= 1 && q <= 4) ce[2][q - 1] = b;
         }
@@ -446,11 +453,12 @@ __global__ __launch_bounds__(64) void k_sift_refine(SiftPyr p, const SiftCand* _
 // sums are ordered (raster order of the window): the lanes evaluate 64 samples at a time (gradient, exp, atan2, sqrt -> bin, vote),
 // pack them in raster order into LDS, and lane b < 36 then walks the packed votes adding the ones of bin b (and +0.0f, which
 // changes nothing, for the others: the votes and the sums are never negative).
+static const int kOriNB = 4;
 __global__ __launch_bounds__(64) void k_sift_orient(SiftPyr p, const SiftSurv* __restrict__ surv, const int* __restrict__ surv_cnt, int surv_cap,
                                                     const float* __restrict__ exptab, uvo_keypoint* raw, int* raw_cnt, int raw_cap)
 {
     __shared__ float s_tab[64];
-    __shared__ __attribute__((aligned(8))) float2 s_vote[64];
+    __shared__ __attribute__((aligned(8))) float2 s_vote[64 * kOriNB + 8];
     __shared__ float s_th[SIFT_ORI_HIST_BINS + 4], s_h[SIFT_ORI_HIST_BINS];
     const int lane = threadIdx.x, n = SIFT_ORI_HIST_BINS, nL = p.nL;
     const int ns = min(*surv_cnt, surv_cap);
@@ -465,39 +473,53 @@ __global__ __launch_bounds__(64) void k_sift_orient(SiftPyr p, const SiftSurv* _
         const float* __restrict__ g = p.gauss[octv * (nL + 3) + sv.layer];
         const int side = 2 * radius + 1;
         const long long total = (long long)side * side;
-        int wi = lane / side, wj = lane - wi * side;
         float acc = 0.f;                                               // th[lane], lane < 36
+        int wi = lane / side, wj = lane - wi * side;
         __syncthreads();
-        for (long long base = 0; base < total; base += 64) {
-            bool pass = false;
-            float vote = 0.f; int bin = 0;
-            if (wi < side) {
+        // kOriNB x 64 samples per step, a lane taking samples t, t + 64, ...: their gradient loads go out together (one memory round
+        // trip and one pair of barriers per kOriNB x 64 samples), the votes are packed batch after batch, i.e. still in raster order
+        for (long long base = 0; base < total; base += 64 * kOriNB) {
+            float gx1[kOriNB], gx0[kOriNB], gy0[kOriNB], gy1[kOriNB]; int d2[kOriNB]; bool pass[kOriNB];
+#pragma unroll
+            for (int u = 0; u < kOriNB; u++) {
                 const int ii = wi - radius, jj = wj - radius, y = r + ii, x = c + jj;
-                if (y > 0 && y < h - 1 && x > 0 && x < w - 1) {
-                    pass = true;
-                    const float dx = g[(size_t)y * w + x + 1] - g[(size_t)y * w + x - 1], dy = g[(size_t)(y - 1) * w + x] - g[(size_t)(y + 1) * w + x];
-                    const float wgt = sift_exp32f((ii * ii + jj * jj) * expf_scale, s_tab);
+                pass[u] = wi < side && y > 0 && y < h - 1 && x > 0 && x < w - 1;
+                wj += 64;
+                while (wj >= side) { wj -= side; wi++; }
+                d2[u] = ii * ii + jj * jj;
+                const size_t e = pass[u] ? (size_t)y * w + x : (size_t)w + 1;
+                gx1[u] = g[e + 1]; gx0[u] = g[e - 1]; gy0[u] = g[e - w]; gy1[u] = g[e + w];
+            }
+            int filled = 0;
+#pragma unroll
+            for (int u = 0; u < kOriNB; u++) {
+                float vote = 0.f; int bin = 0;
+                if (pass[u]) {
+                    const float dx = gx1[u] - gx0[u], dy = gy0[u] - gy1[u];
+                    const float wgt = sift_exp32f(d2[u] * expf_scale, s_tab);
                     const float ori = sift_atan2_deg(dy, dx), mag = sqrtf(dx * dx + dy * dy);
                     bin = cv_round_f((n / 360.f) * ori);
                     if (bin >= n) bin -= n;
                     if (bin < 0) bin += n;
                     vote = wgt * mag;
                 }
+                const unsigned long long m = __ballot(pass[u]);
+                if (pass[u]) {
+                    const int pos = filled + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    s_vote[pos] = make_float2(__int_as_float(bin), vote);
+                }
+                filled += __popcll(m);
             }
-            const unsigned long long m = __ballot(pass);
-            if (pass) {
-                const int pos = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-                s_vote[pos] = make_float2(__int_as_float(bin), vote);
+            if (lane < 8) s_vote[filled + lane] = make_float2(__int_as_float(-1), 0.f);      // pad to a multiple of eight: bin -1 is nobody's
+            __syncthreads();
+            for (int q = 0; q < filled; q += 8) {                       // eight votes per LDS round trip
+                float2 bv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) bv[u] = s_vote[q + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc += (__float_as_int(bv[u].x) == lane) ? bv[u].y : 0.f;
             }
             __syncthreads();
-            const int cnt = __popcll(m);
-            for (int q = 0; q < cnt; q++) {
-                const float2 bv = s_vote[q];
-                acc += (__float_as_int(bv.x) == lane) ? bv.y : 0.f;
-            }
-            __syncthreads();
-            wj += 64;
-            while (wj >= side) { wj -= side; wi++; }
         }
         if (lane < n) s_th[lane + 2] = acc;
         __syncthreads();
@@ -532,15 +554,14 @@ __global__ __launch_bounds__(64) void k_sift_orient(SiftPyr p, const SiftSurv* _
 // LDS, and eight lanes then apply one sample's eight shares (eight different bins) per step, sample after sample -- LDS operations of
 // one wave are performed in issue order, so every bin sees its additions in the order the one-thread loop makes them.
 static const int kSiftHist = 6 * 6 * 10;
-#ifndef UVO_SIFT_LDS_FADD
-#define UVO_SIFT_LDS_FADD 0      // ds_add_f32 is bit-identical but measured 999 us against 520 for the read-add-write of eight lanes
+#ifndef UVO_SIFT_EXPERIMENT
+#define UVO_SIFT_EXPERIMENT 0            // timing experiments only: 1 = no ordered additions, 2 = no gradient / exp / atan2 / sqrt
 #endif
 __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyr p, const uvo_keypoint* __restrict__ kps, const int* __restrict__ nk_p, int kp_cap,
                                                         const float* __restrict__ exptab, float* __restrict__ desc)
 {
     __shared__ float s_hist[kSiftHist];
-    __shared__ __attribute__((aligned(16))) float s_val[64 * 8];
-    __shared__ __attribute__((aligned(16))) unsigned short s_bin[64 * 8];
+    __shared__ __attribute__((aligned(16))) float2 s_rec[8][64 + 4];    // [share][queued sample] = (bin, value): a lane of the ordered part reads ITS share of four samples as two 16-byte vectors
     __shared__ float s_tab[64];
     __shared__ __attribute__((aligned(16))) float s_dst[128];
     __shared__ float s_sq[128];
@@ -603,10 +624,14 @@ __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyr p, const uvo_key
             const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
             const int r = py + i, c = px + j;
+#if UVO_SIFT_EXPERIMENT == 2
+            float obin = 0.3f * i + 0.2f * j; const float mag = 1.f + c_rot;
+#else
             const float dx = img[(size_t)r * cols + c + 1] - img[(size_t)r * cols + c - 1], dy = img[(size_t)(r - 1) * cols + c] - img[(size_t)(r + 1) * cols + c];
             const float wgt = sift_exp32f((c_rot * c_rot + r_rot * r_rot) * exp_scale, s_tab);
             float obin = (sift_atan2_deg(dy, dx) - ori) * bins_per_rad;
             const float mag = sqrtf(dx * dx + dy * dy) * wgt;
+#endif
             const int r0 = cv_floor_d(rbin), c0 = cv_floor_d(cbin);
             int o0 = cv_floor_d(obin);
             rbin -= r0; cbin -= c0; obin -= o0;
@@ -617,46 +642,48 @@ __global__ __launch_bounds__(64) void k_sift_descriptor(SiftPyr p, const uvo_key
             const float v_rco111 = v_rc11 * obin, v_rco110 = v_rc11 - v_rco111, v_rco101 = v_rc10 * obin, v_rco100 = v_rc10 - v_rco101;
             const float v_rco011 = v_rc01 * obin, v_rco010 = v_rc01 - v_rco011, v_rco001 = v_rc00 * obin, v_rco000 = v_rc00 - v_rco001;
             const int idx = ((r0 + 1) * (d + 2) + c0 + 1) * (n + 2) + o0;
-            *reinterpret_cast<float4*>(&s_val[lane * 8]) = make_float4(v_rco000, v_rco001, v_rco010, v_rco011);
-            *reinterpret_cast<float4*>(&s_val[lane * 8 + 4]) = make_float4(v_rco100, v_rco101, v_rco110, v_rco111);
-            // the eight bins of the shares, in that order: +0, +1, +(n+2), +(n+3), +(d+2)(n+2), ...
-            const unsigned b0 = (unsigned)idx, b2 = b0 + (n + 2), b4 = b0 + (d + 2) * (n + 2), b6 = b0 + (d + 3) * (n + 2);
-            *reinterpret_cast<uint4*>(&s_bin[lane * 8]) = make_uint4(b0 | ((b0 + 1) << 16), b2 | ((b2 + 1) << 16), b4 | ((b4 + 1) << 16), b6 | ((b6 + 1) << 16));
+            // the eight bins of the shares: +0, +1, +(n+2), +(n+3), +(d+2)(n+2), ...
+            const int b0 = idx, b2 = b0 + (n + 2), b4 = b0 + (d + 2) * (n + 2), b6 = b0 + (d + 3) * (n + 2);
+            s_rec[0][lane] = make_float2(__int_as_float(4 * b0), v_rco000); s_rec[1][lane] = make_float2(__int_as_float(4 * b0 + 4), v_rco001);
+            s_rec[2][lane] = make_float2(__int_as_float(4 * b2), v_rco010); s_rec[3][lane] = make_float2(__int_as_float(4 * b2 + 4), v_rco011);
+            s_rec[4][lane] = make_float2(__int_as_float(4 * b4), v_rco100); s_rec[5][lane] = make_float2(__int_as_float(4 * b4 + 4), v_rco101);
+            s_rec[6][lane] = make_float2(__int_as_float(4 * b6), v_rco110); s_rec[7][lane] = make_float2(__int_as_float(4 * b6 + 4), v_rco111);
+        } else if (lane < cnt + 4) {
+            // padding up to a multiple of four samples: +0 into the histogram's last element (cell (5, 5): never read)
+#pragma unroll
+            for (int cs = 0; cs < 8; cs++) s_rec[cs][lane] = make_float2(__int_as_float((kSiftHist - 1) * 4), 0.f);
         }
         const int rest = npend - cnt;                                  // < 64: what the last cheap step queued beyond the 64 taken now
         const int keep = lane < rest ? s_pend[64 + lane] : 0;
         __syncthreads();
         if (lane < rest) s_pend[lane] = keep;
         npend = rest;
-        if (lane < 8) {
-#if UVO_SIFT_LDS_FADD
-            // ds_add_f32: the addition is done by the LDS unit (IEEE single add, one rounding), no round trip through the lane
-            for (int q = 0; q < cnt; q++)
-                __hip_atomic_fetch_add(&s_hist[s_bin[q * 8 + lane]], s_val[q * 8 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-            // a sample's eight bins are distinct, and while the next sample has the same eight (the same cell and orientation bin: runs
-            // of a few samples along a window row) nobody else touches them: the running sums stay in the lanes, every addition is
-            // still written through, and the read (the one round trip of the chain) happens only when the bins change
-            int cur = -1; float acc = 0.f;
-            int q = 0;
-            for (; q + 4 <= cnt; q += 4) {
-                int bi[4]; float vv[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { bi[u] = s_bin[(q + u) * 8 + lane]; vv[u] = s_val[(q + u) * 8 + lane]; }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (bi[u] != cur) { acc = s_hist[bi[u]]; cur = bi[u]; }
-                    acc += vv[u];
-                    s_hist[cur] = acc;
+        if (lane < 8 && UVO_SIFT_EXPERIMENT != 1) {
+            // The ordered part: lane c applies share c of sample after sample.  A sample's eight bins are distinct, and while the next
+            // sample has the same eight (the same cell and orientation bin: runs of a few samples along a window row) nobody else
+            // touches them, so the running sums stay in the lanes; when the bins change (for all eight lanes at once) the sums are
+            // written back and the new bins read -- LDS operations of a wave are performed in issue order, so a bin written by one
+            // lane and read by another at the change is current.  What bounds the kernel is the LDS instruction rate of a CU with 25
+            // such waves, hence two 16-byte reads per four samples and a write + a read per change instead of four operations a sample.
+            const float4* __restrict__ rp = reinterpret_cast<const float4*>(&s_rec[lane][0]);
+            // records carry byte offsets into s_hist; the lanes' bins all change at the same sample (bin = idx + a constant per
+            // share), so the test is made once, on lane 0's, by the scalar unit; the sums start on the never-read last element
+            const char* hb = reinterpret_cast<const char*>(s_hist);
+            int cur = (kSiftHist - 1) * 4, scur = cur; float acc = 0.f;
+            auto step = [&](float bf, float v) {
+                const int bi = __float_as_int(bf), sbi = __builtin_amdgcn_readfirstlane(bi);
+                if (sbi != scur) {
+                    *reinterpret_cast<float*>(const_cast<char*>(hb) + cur) = acc;
+                    acc = *reinterpret_cast<const float*>(hb + bi);
+                    cur = bi; scur = sbi;
                 }
+                acc += v;
+            };
+            for (int q = 0; q < cnt; q += 4) {
+                const float4 ra = rp[q / 2], rb = rp[q / 2 + 1];
+                step(ra.x, ra.y); step(ra.z, ra.w); step(rb.x, rb.y); step(rb.z, rb.w);
             }
-            for (; q < cnt; q++) {
-                const int b1 = s_bin[q * 8 + lane];
-                if (b1 != cur) { acc = s_hist[b1]; cur = b1; }
-                acc += s_val[q * 8 + lane];
-                s_hist[cur] = acc;
-            }
-#endif
+            *reinterpret_cast<float*>(const_cast<char*>(hb) + cur) = acc;
         }
         __syncthreads();
     }
@@ -726,11 +753,14 @@ __global__ __launch_bounds__(256) void k_sift_rank(const uvo_keypoint* __restric
         __syncthreads();
         const int m = min(256, j1 - jb);
         int ties = 0;
+        int r0 = 0, r1 = 0, r2 = 0, r3 = 0;                              // four chains instead of one
+#pragma unroll 4
         for (int q = 0; q < 256; q += 4) {
             const float4 k4 = *reinterpret_cast<const float4*>(&s_key[q]);
-            r += (k4.x < kme) + (k4.y < kme) + (k4.z < kme) + (k4.w < kme);
-            ties += (k4.x == kme) + (k4.y == kme) + (k4.z == kme) + (k4.w == kme);
+            r0 += k4.x < kme; r1 += k4.y < kme; r2 += k4.z < kme; r3 += k4.w < kme;
+            ties |= (k4.x == kme) | (k4.y == kme) | (k4.z == kme) | (k4.w == kme);
         }
+        r += (r0 + r1) + (r2 + r3);
         if (ties) {                                                     // the same x: other orientations of one extremum, a repeat, (rarely) a neighbour -- or just i itself
             for (int q = 0; q < m; q++) {
                 if (s_key[q] != kme || jb + q == i) continue;
@@ -941,7 +971,7 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
             hipLaunchKernelGGL(k_sift_extrema_all, dim3(tl.start[nOct]), dim3(256), 0, st, p, tl, threshold, s->d_cand, s->d_cnt, s->cand_cap);
         hipLaunchKernelGGL(k_sift_refine, dim3((s->cand_cap + 63) / 64), dim3(64), 0, st, p, static_cast<const SiftCand*>(s->d_cand), static_cast<const int*>(s->d_cnt),
                            s->cand_cap, (float)contrastThreshold, (float)edgeThreshold, (float)sigma, s->d_surv, s->d_cnt + 2);
-        hipLaunchKernelGGL(k_sift_orient, dim3(4096), dim3(64), 0, st, p, static_cast<const SiftSurv*>(s->d_surv), static_cast<const int*>(s->d_cnt + 2), s->cand_cap,
+        hipLaunchKernelGGL(k_sift_orient, dim3(8192), dim3(64), 0, st, p, static_cast<const SiftSurv*>(s->d_surv), static_cast<const int*>(s->d_cnt + 2), s->cand_cap,
                            static_cast<const float*>(s->d_exptab), s->d_raw, s->d_cnt + 1, rc);
         // KeyPointsFilter::removeDuplicatedSorted, retainBest(nfeatures), the scaling back of firstOctave = -1
         hipLaunchKernelGGL(k_sift_rank, dim3(rc / 256, 16), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_raw), static_cast<const int*>(s->d_cnt + 1), rc, d_rank, d_dup);
