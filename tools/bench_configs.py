@@ -2,6 +2,7 @@
 """Secondary measurements for the other BASELINE.json configs (the headline C3 line comes from bench.py):
   C2  stereo 1280x720, ~1500 kpts (min_hessian 5685), pipelined submit/collect and synchronous step
   C1  substitute for the bag: mono 640x480, the shipped parameters (LMedS)
+  N4  detect_features' SIFT branch at 1920x1080 (frames/s)
   C4  mono 1920x1080 + range, ~3000 kpts, min_hessian 6456 (3000 kpts), RANSAC for both E and H: frames two steps apart (essential) and a quarter step apart (homography)
 Prints one JSON object; run on the GPU box:  python tools/bench_configs.py"""
 import json
@@ -172,6 +173,21 @@ def main(only=None):
             dt = time.perf_counter() - t0
         out["C1_substitute_mono_640x480_lmeds"].update({"frames_per_s_pipelined": round(steps / dt, 1), "valid_pipelined": nv})
         ctx.close()
+    if only in (None, "SIFT"):
+        # ---------------- N4: detect_features with FEATURE_DETECTOR = "SIFT" (VO_utility.cpp:107-112), image resident in HBM ----------------
+        W, H = 1920, 1080
+        img = torch.from_numpy(synth.stereo_pair(synth.Scene(synth.SEEDS["C3"], W), 0, W, H)[0]).cuda()
+        ctx = uvo.Context(uvo.Params.stereo(), 0, W, H, 8192)
+        for _ in range(3):
+            k, d = ctx.sift_detect(img)
+        steps = 50
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            k, d = ctx.sift_detect(img)
+        dt = (time.perf_counter() - t0) / steps
+        out["N4_sift_detect_1920x1080"] = {"note": "SIFT::create(10000, 3, 0.03, 10, 1.6)->detectAndCompute; keypoints and 128-float rows copied to host buffers inside the timed region",
+                                           "kpts": int(len(k)), "ms_per_frame": round(dt * 1e3, 3), "frames_per_s": round(1 / dt, 1)}
+        ctx.close()
     print(json.dumps(out))
 
 
@@ -183,7 +199,7 @@ if __name__ == "__main__":
     else:
         import subprocess
         merged = {}
-        for cfg in ("C2", "C3", "C4", "C4v", "C1"):
+        for cfg in ("C2", "C3", "C4", "C4v", "C1", "SIFT"):
             p = subprocess.run([sys.executable, os.path.abspath(__file__), cfg], stdout=subprocess.PIPE, text=True, timeout=900)
             if p.returncode != 0:
                 raise SystemExit(f"configuration {cfg} failed")
