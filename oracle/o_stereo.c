@@ -29,7 +29,9 @@ struct orc_stereo {
     float* points4D; int nT;
     double* good_pts; int* good_idx; int G;
     int* inliers; int n_inl;
+    int use_sift;              /* FEATURE_DETECTOR == "SIFT" (the reference's global, VOH:25) */
 };
+void orc_stereo_use_sift(orc_stereo* s, int on) { s->use_sift = on; }
 
 /* VOU:9-15 compute_projection_matrix: K * [R|t] ([UPSTREAM] gemm small-matrix case, len 3) */
 static void compute_projection_matrix(const double* R, const double* t, const double* K, double* P)
@@ -73,6 +75,10 @@ void orc_stereo_destroy(orc_stereo* s)
 
 static int detect(orc_stereo* s, const uint8_t* img, int w, int h, int stride, orc_keypoint* kps, float* desc)
 {
+    if (s->use_sift) {          /* VOU:107-112: SIFT::create(10000, 3, 0.03, 10, 1.6)->detectAndCompute */
+        int n = orc_sift_detect_and_compute(img, w, h, stride, 10000, 3, 0.03, 10, 1.6, kps, desc, s->cap);
+        return n < 0 ? s->cap : n;
+    }
     /* VOU:114-119 */
     orc_surf_params sp = { (double)s->p.SURF_MIN_HESSIAN, s->p.SURF_OCTAVES_NUMBER, s->p.SURF_OCTAVES_LAYERS,
                            s->p.SURF_EXTENDED, s->p.SURF_UPRIGHT };
@@ -95,7 +101,7 @@ static void gather_descriptors(const float* src, int nsrc, const int* idx, int n
     }
 }
 /* SURF::descriptorSize(): 64, or 128 with `extended` */
-static int desc_dim(const orc_stereo* s) { return s->p.SURF_EXTENDED ? 128 : 64; }
+static int desc_dim(const orc_stereo* s) { return s->use_sift || s->p.SURF_EXTENDED ? 128 : 64; }
 
 int orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
                     double dt, orc_stereo_result* out)

@@ -260,8 +260,15 @@ class StereoVO:
     def __init__(self, params: VoParams, K_left, K_right, R_right, t_right, max_kpts=20000):
         self._keep = [_c(x, np.float64) for x in (K_left, K_right, R_right, t_right)]
         self.cap = max_kpts
+        self._extended = bool(params.SURF_EXTENDED)
         self.dim = 128 if params.SURF_EXTENDED else 64
         self.h = lib().orc_stereo_create(C.byref(params), *[_p(x) for x in self._keep], max_kpts)
+
+    def use_sift(self, on=True):
+        """FEATURE_DETECTOR = "SIFT": the loop's detect_features / match_features take their SIFT branches (VOU:107-112, 525-529)."""
+        lib().orc_stereo_use_sift.argtypes = [C.c_void_p, C.c_int]
+        lib().orc_stereo_use_sift(self.h, int(bool(on)))
+        self.dim = 128 if on else (128 if self._extended else 64)
 
     def step(self, left, right, dt=0.05) -> StereoResult:
         left = _c(left, np.uint8); right = _c(right, np.uint8)

@@ -155,6 +155,10 @@ typedef struct {
 orc_stereo* orc_stereo_create(const orc_vo_params* p, const double* K_left, const double* K_right,
                               const double* R_right, const double* t_right, int max_kpts);
 void        orc_stereo_destroy(orc_stereo* s);
+void        orc_stereo_use_sift(orc_stereo* s, int on);    /* FEATURE_DETECTOR = "SIFT" instead of "SURF" (detect_features VOU:107-112, match_features VOU:525-529) */
+/* o_sift.c: SIFT::create(nfeatures, nOctaveLayers, contrastThreshold, edgeThreshold, sigma)->detectAndCompute; desc: cap x 128 floats or NULL */
+int         orc_sift_detect_and_compute(const uint8_t* img, int w, int h, int stride, int nfeatures, int nOctaveLayers, double contrastThreshold,
+                                        double edgeThreshold, double sigma, orc_keypoint* kps, float* desc, int cap);
 int         orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
                             double dt, orc_stereo_result* out);
 /* introspection for parity tests: last step's intermediate arrays */

@@ -4,7 +4,7 @@
 // record bit for bit with the CPU oracle's stereo state machine.
 //
 //   usage: shim_stereo_node <input.bin> <output.bin>
-//   input : int32 W, H, nframes, min_hessian; f64 K_left[9], K_right[9], R_right[9], t_right[3]; then nframes x (L, R) u8
+//   input : int32 W, H, nframes, min_hessian (< 0: FEATURE_DETECTOR = "SIFT"); f64 K_left[9], K_right[9], R_right[9], t_right[3]; then nframes x (L, R) u8
 //   output: per frame 8 x int32 (valid, initialized, nL, nR, n_stereo, n_tri, G, n_inliers) + 9 x f64 (rvec, tvec, t_prev_curr)
 #include <cstdio>
 #include <cstdlib>
@@ -26,7 +26,8 @@ int main(int argc, char** argv)
     int hdr[4]; double cam[30];
     if (fread(hdr, sizeof(int), 4, f) != 4 || fread(cam, sizeof(double), 30, f) != 30) { fprintf(stderr, "short header\n"); return 2; }
     const int W = hdr[0], H = hdr[1], nframes = hdr[2];
-    SURF_MIN_HESSIAN = hdr[3];                                      // get_VO_parameters would set the globals
+    if (hdr[3] < 0) FEATURE_DETECTOR = "SIFT";                        // min_hessian < 0: the loop on SIFT features (VOU:107-112, 525-529)
+    else SURF_MIN_HESSIAN = hdr[3];                                 // get_VO_parameters would set the globals
     Mat K_left = mat64(cam, 3, 3), K_right = mat64(cam + 9, 3, 3), R_right = mat64(cam + 18, 3, 3), t_right = mat64(cam + 27, 3, 1);
     Mat R_eye = Mat::eye(3, 3, CV_64FC1), t_zeros = Mat::zeros(3, 1, CV_64FC1), distCoeffs;
     Mat P_eye_left = compute_projection_matrix(R_eye, t_zeros, K_left);            // VO:460

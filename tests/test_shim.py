@@ -117,6 +117,40 @@ def test_stereo_node_loop_through_the_shim_matches_oracle(oracle, scene_small, t
 
 
 @pytest.mark.gpu
+def test_stereo_node_loop_on_sift_features_through_the_shim_matches_oracle(oracle, scene_small, tmp_path):
+    """FEATURE_DETECTOR = "SIFT" (the reference's global): the same node loop, detect_features and match_features taking their SIFT
+    branches (VO_utility.cpp:107-112, 525-529), against the oracle's state machine switched to the same detector."""
+    from ergo_uvo_amd import synth
+    _build()
+    rig = synth.stereo_rig(640)
+    seq = [scene_small[k] for k in (0, 1, 2, 1)]
+    H, W = seq[0][0].shape
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<4i", W, H, len(seq), -1))
+        for m in (rig.K_left, rig.K_right, rig.R_right, rig.t_right):
+            f.write(np.ascontiguousarray(m, np.float64).tobytes())
+        for L, R in seq:
+            f.write(np.ascontiguousarray(L).tobytes()); f.write(np.ascontiguousarray(R).tobytes())
+    res = subprocess.run([DRIVER, str(inp), str(outp)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    rec = np.fromfile(outp, np.dtype([("i", "<i4", 8), ("d", "<f8", 9)]))
+    assert len(rec) == len(seq)
+    ovo = oracle.StereoVO(oracle.stereo_params(1500), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    ovo.use_sift()
+    nvalid = 0
+    for k, (L, R) in enumerate(seq):
+        o = ovo.step(L, R, 0.05)
+        want = [o.valid, o.initialized, o.n_left, o.n_right, o.n_stereo_matches, o.n_tri_matches, o.n_good3d, o.n_inliers]
+        assert list(rec["i"][k]) == want, (k, list(rec["i"][k]), want)
+        d = np.array(list(o.rvec) + list(o.tvec) + list(o.t_prev_curr))
+        for a, b in zip(rec["d"][k].reshape(3, 3), d.reshape(3, 3)):
+            assert np.linalg.norm(a - b) <= 1e-4 * max(np.linalg.norm(b), 1e-12), (k, rec["d"][k], d)
+        nvalid += o.valid
+    assert nvalid == len(seq) - 1 and rec["i"][-1][2] > 1000          # valid poses from > 1000 SIFT keypoints per image
+
+
+@pytest.mark.gpu
 def test_get_image_through_the_shim_matches_oracle(oracle, tmp_path):
     _build()
     rng = np.random.default_rng(9)
