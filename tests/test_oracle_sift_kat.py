@@ -155,3 +155,81 @@ def test_descriptor_follows_the_image_under_a_quarter_turn(oracle, scene_small):
             hits += 1
             assert np.linalg.norm(dr[j[0]] - d[i]) < 0.35 * 512
     assert len(strong) > 40 and hits >= 0.6 * len(strong)
+
+
+def test_pyramid_against_scipy(oracle, scene_small):
+    """An independent statement of the pyramid: scipy.ndimage.correlate1d with mode='mirror' (= BORDER_REFLECT_101) and the same taps,
+    in float64, layer after layer as buildGaussianPyramid chains them.  The oracle accumulates in float (in OpenCV's order), so the
+    comparison is to 2e-3 on a 0..255 scale, far below anything a wrong border, tap count, sigma or chaining would leave."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    img = np.ascontiguousarray(scene_small[0][0][40:168, 100:292])
+    lib = oracle.lib()
+    lib.orc_sift_gauss_kernel.argtypes = [C.c_double, C.c_void_p]
+    lib.orc_sift_layer_sigmas.argtypes = [C.c_int, C.c_double, C.c_void_p]
+
+    def blur(a, sigma):
+        k = (C.c_float * 64)()
+        n = lib.orc_sift_gauss_kernel(float(sigma), k)
+        taps = np.array(k[:n], np.float64)
+        return ndi.correlate1d(ndi.correlate1d(a, taps, axis=1, mode="mirror"), taps, axis=0, mode="mirror")
+
+    # createInitialImage: bilinear doubling with OpenCV's half-pixel convention, then the blur that brings sigma 1.0 to 1.6
+    h, w = img.shape
+    def lin(n_dst, n_src):
+        f = (np.arange(n_dst) + 0.5) * 0.5 - 0.5
+        s = np.floor(f).astype(int); f = f - s
+        f[s < 0] = 0; s[s < 0] = 0
+        f[s + 1 >= n_src] = 0; s[s + 1 >= n_src] = n_src - 1
+        return s, np.minimum(s + 1, n_src - 1), f
+    sx, sx1, fx = lin(2 * w, w); sy, sy1, fy = lin(2 * h, h)
+    a = img.astype(np.float64)
+    hor = a[:, sx] * (1 - fx) + a[:, sx1] * fx
+    dbl = hor[sy] * (1 - fy)[:, None] + hor[sy1] * fy[:, None]
+    sig = (C.c_double * 8)()
+    lib.orc_sift_layer_sigmas(3, 1.6, sig)
+    g = blur(dbl, np.sqrt(1.6 ** 2 - 4 * 0.5 ** 2))
+    for o in range(3):
+        layers = [g]
+        for i in range(1, 6):
+            layers.append(blur(layers[-1], sig[i]))
+        for i, ref in enumerate(layers):
+            got = oracle.sift_gauss_layer(img, o, i)
+            assert got.shape == ref.shape
+            assert np.max(np.abs(got - ref)) < 2e-3, (o, i, float(np.max(np.abs(got - ref))))
+        g = layers[3][::2, ::2]                           # the next octave starts from layer nOctaveLayers, every second pixel
+
+
+def test_extrema_against_a_numpy_statement(oracle):
+    """Every keypoint's (octave, layer, row, column) must be a 26-neighbour extremum of the DoG stack above the contrast pre-threshold
+    -- or reachable from one by adjustLocalExtrema's at most five unit steps -- and every strong, well-conditioned extremum must be
+    represented: the stack is rebuilt from the oracle's own Gaussian layers, the extremum test is scipy's maximum / minimum filter."""
+    ndi = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(11)
+    y, x = np.mgrid[0:96, 0:128]
+    img = np.full((96, 128), 70.0)
+    for _ in range(25):
+        s = rng.uniform(1.5, 5.0)
+        img += rng.uniform(50, 120) * np.exp(-((x - rng.uniform(12, 116)) ** 2 + (y - rng.uniform(12, 84)) ** 2) / (2 * s * s))
+    img = np.clip(img, 0, 255).astype(np.uint8)
+    kp, _ = oracle.sift_detect(img, descriptors=False)
+    assert len(kp) > 15
+    octv = (kp["octave"] & 255).astype(np.int64); octv[octv >= 128] -= 256
+    layer = (kp["octave"] >> 8) & 255
+    stacks = {}
+    for o in sorted(set((octv + 1).tolist())):
+        g = np.stack([oracle.sift_gauss_layer(img, int(o), l) for l in range(6)])
+        d = g[1:] - g[:-1]                                 # float32 differences, as buildDoGPyramid
+        mx = ndi.maximum_filter(d, size=3, mode="nearest"); mn = ndi.minimum_filter(d, size=3, mode="nearest")
+        ext = (np.abs(d) > 1) & (((d > 0) & (d >= mx)) | ((d < 0) & (d <= mn)))       # threshold = floor(0.5 * 0.03 / 3 * 255) = 1
+        ext[0] = ext[-1] = False
+        ext[:, :5] = ext[:, -5:] = False; ext[:, :, :5] = ext[:, :, -5:] = False      # SIFT_IMG_BORDER
+        stacks[int(o)] = ext
+    for i in range(len(kp)):
+        o = int(octv[i] + 1)
+        scale = 2.0 ** octv[i]
+        c, r, l = kp["x"][i] / scale, kp["y"][i] / scale, int(layer[i])
+        ext = stacks[o]
+        l0, l1 = max(l - 5, 1), min(l + 5, 3)
+        r0, r1 = int(max(np.floor(r) - 6, 0)), int(np.ceil(r) + 7)
+        c0, c1 = int(max(np.floor(c) - 6, 0)), int(np.ceil(c) + 7)
+        assert ext[l0:l1 + 1, r0:r1, c0:c1].any(), (i, kp[i])
