@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void k_sift_blur_tile(const float* __restrict_
     }
 }
 
-// The small octaves (at most 4096 pixels a layer) in ONE launch by one workgroup: the halving, the nL + 2 blurs (two plain passes
+// The small octaves (at most 2048 pixels a layer; the arrays hold 4096) in ONE launch by one workgroup: the halving, the nL + 2 blurs (two plain passes
 // through a scratch image) and the differences of every such octave, one after the other.  They are 30-odd dependent launches of a
 // few microseconds each otherwise, most of it dispatch latency; the arithmetic per pixel is k_sift_blur's.
 __global__ __launch_bounds__(1024) void k_sift_tail(SiftPyr p, const float* __restrict__ taps, const int* __restrict__ radii, int o_first, int nOct)
@@ -277,15 +277,30 @@ __global__ __launch_bounds__(1024) void k_sift_tail(SiftPyr p, const float* __re
             for (int e = tid; e < n; e += 1024) {
                 const int y = e / w, x = e - y * w;
                 const float* row = cur + y * w;
-                float acc = s_k[0] * row[reflect101(x - r, w)];
-                for (int t = 1; t <= 2 * r; t++) acc += s_k[t] * row[reflect101(x - r + t, w)];
+                float acc;
+                if (r < w) {                                            // one reflection is enough (uniform): |p|, then 2(w - 1) - p
+                    int q = x - r; q = q < 0 ? -q : q;
+                    acc = s_k[0] * row[q];
+                    for (int t = 1; t <= 2 * r; t++) { q = x - r + t; q = q < 0 ? -q : q; q = q >= w ? 2 * w - 2 - q : q; acc += s_k[t] * row[q]; }
+                } else {
+                    acc = s_k[0] * row[reflect101(x - r, w)];
+                    for (int t = 1; t <= 2 * r; t++) acc += s_k[t] * row[reflect101(x - r + t, w)];
+                }
                 s_t[e] = acc;
             }
             __syncthreads();
             for (int e = tid; e < n; e += 1024) {
                 const int y = e / w, x = e - y * w;
                 float acc = s_k[r] * s_t[e];
-                for (int t = 1; t <= r; t++) acc += s_k[r + t] * (s_t[reflect101(y + t, h) * w + x] + s_t[reflect101(y - t, h) * w + x]);
+                if (r < h) {
+                    for (int t = 1; t <= r; t++) {
+                        int qa = y + t, qb = y - t;
+                        qa = qa >= h ? 2 * h - 2 - qa : qa; qb = qb < 0 ? -qb : qb;
+                        acc += s_k[r + t] * (s_t[qa * w + x] + s_t[qb * w + x]);
+                    }
+                } else {
+                    for (int t = 1; t <= r; t++) acc += s_k[r + t] * (s_t[reflect101(y + t, h) * w + x] + s_t[reflect101(y - t, h) * w + x]);
+                }
                 nxt[e] = acc; dst[e] = acc; dg[e] = acc - cur[e];
             }
             __syncthreads();
@@ -930,7 +945,7 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
     for (int o = 0; o < nOct; o++) { p.ow[o] = s->ow[o]; p.oh[o] = s->oh[o]; }
     p.nL = nL;
     int o_tail = nOct;                                                  // the first octave of k_sift_tail's range
-    for (int o = nOct - 1; o >= 1 && (size_t)s->ow[o] * s->oh[o] <= 4096; o--) o_tail = o;
+    for (int o = nOct - 1; o >= 1 && (size_t)s->ow[o] * s->oh[o] <= 2048; o--) o_tail = o;
     if (o_tail < nOct && (s->taps_sigma != sigma || s->taps_nL != nL)) {
         float taps[kSiftMaxTaps * (kSiftMaxLayers + 3)]; int radii[kSiftMaxLayers + 3];
         memset(taps, 0, sizeof(taps)); memset(radii, 0, sizeof(radii));
@@ -974,12 +989,12 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
         hipLaunchKernelGGL(k_sift_orient, dim3(8192), dim3(64), 0, st, p, static_cast<const SiftSurv*>(s->d_surv), static_cast<const int*>(s->d_cnt + 2), s->cand_cap,
                            static_cast<const float*>(s->d_exptab), s->d_raw, s->d_cnt + 1, rc);
         // KeyPointsFilter::removeDuplicatedSorted, retainBest(nfeatures), the scaling back of firstOctave = -1
-        hipLaunchKernelGGL(k_sift_rank, dim3(rc / 256, 16), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_raw), static_cast<const int*>(s->d_cnt + 1), rc, d_rank, d_dup);
+        hipLaunchKernelGGL(k_sift_rank, dim3(rc / 256, 64), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_raw), static_cast<const int*>(s->d_cnt + 1), rc, d_rank, d_dup);
         hipLaunchKernelGGL(k_sift_place, dim3(rc / 256), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_raw), static_cast<const int*>(s->d_cnt + 1), rc,
                            static_cast<const int*>(d_rank), static_cast<const int*>(d_dup), s->d_sorted, d_keep);
         hipLaunchKernelGGL(k_sift_pack, dim3(1), dim3(1024), 0, st, static_cast<const uvo_keypoint*>(s->d_sorted), static_cast<const int*>(s->d_cnt + 1), rc,
                            static_cast<const int*>(d_keep), static_cast<const int*>(nullptr), 0, 0, s->d_kept, s->d_cnt + 3);
-        hipLaunchKernelGGL(k_sift_greater, dim3(rc / 256, 16), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_kept), static_cast<const int*>(s->d_cnt + 3), rc, nfeatures, d_greater);
+        hipLaunchKernelGGL(k_sift_greater, dim3(rc / 256, 64), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_kept), static_cast<const int*>(s->d_cnt + 3), rc, nfeatures, d_greater);
         hipLaunchKernelGGL(k_sift_pack, dim3(1), dim3(1024), 0, st, static_cast<const uvo_keypoint*>(s->d_kept), static_cast<const int*>(s->d_cnt + 3), rc,
                            static_cast<const int*>(nullptr), static_cast<const int*>(d_greater), nfeatures, 1, s->d_kps, s->d_cnt + 4);
         if (desc)
