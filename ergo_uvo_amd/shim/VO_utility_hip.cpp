@@ -303,7 +303,7 @@ void detect_features(Mat img, vector<KeyPoint>& keypoints, Mat& descriptors)
     if (!sift && FEATURE_DETECTOR != "SURF") throw uvo_hip::Error(UVO_INVALID_ARG, "detect_features: FEATURE_DETECTOR must be \"SURF\" or \"SIFT\"");
     require(!img.empty() && img.type() == CV_8UC1, "detect_features: CV_8UC1 image expected");
     uvo_ctx* c = ctx_now();
-    const int cap = sift ? std::max(g.max_kpts, 10000) : g.max_kpts;       // retainBest(10000) bounds SIFT's output (ties at the cut aside)
+    const int cap = sift ? std::max(g.max_kpts, 10000) + 1024 : g.max_kpts;       // retainBest(10000) bounds SIFT's output, ties at the cut aside (room for them)
     vector<uvo_keypoint> kps((size_t)cap);
     const int dsize = sift ? 128 : (SURF_EXTENDED ? 128 : 64);             // descriptorSize()
     vector<float> desc((size_t)cap * dsize);
