@@ -6,12 +6,19 @@
 // calcOrientationHist), KeyPointsFilter (duplicates, retainBest), calcSIFTDescriptor -- in the operation order of their scalar paths
 // (parity vs OpenCV itself is UNPINNED: DESIGN.md section 0; cosf / sinf / powf(2, x) are this library's deterministic double series).
 //
-// Byte / float streaming work, HBM-bound: the doubled base image, the blurs (separable, one thread per pixel, taps in the
-// symmetric filter's order), the differences and the extrema test are coalesced passes over float images that stay in HBM
-// (0.5 GB of pyramid at 1080p).  The per-extremum work (refinement, 36-bin orientation histogram) and the per-keypoint
-// descriptor (4 x 4 x 8 trilinear histogram, votes added in sample order) are sequential by definition of their float sums: a
-// thread per extremum / keypoint.  Sorting, duplicate removal and retainBest (a few thousand 28-byte records) run on the host.
-// A standalone operator (uvo_sift_detect): the stereo / mono loops of this library run on SURF.
+// Layout on the device (DESIGN.md section 7 has the per-kernel figures and counters):
+//   pyramid      float images that stay in HBM (0.5 GB at 1080p).  A blur is ONE launch: a 64 x 32 tile with its reflected border staged
+//                in LDS (every load issued before the first store), the row filter (RowFilter: taps left to right) LDS -> LDS, the
+//                column filter (SymmColumnFilter: centre, then the pairs) LDS -> HBM, and the difference of Gaussians beside it.
+//                The octaves of <= 2048 pixels are built by one workgroup from LDS in one launch.
+//   extrema      every octave and layer in one launch (3 x 3 max / min per layer, one list reservation per workgroup); refinement
+//                a thread per candidate
+//   orientation  a wave per extremum, descriptor a wave per keypoint: the float sums into the histograms are ordered (raster order of
+//                the window), everything else about a sample is parallel -- samples are evaluated 64 at a time and their votes
+//                applied in order by the lanes that own the bins (orientation) / the shares (descriptor)
+//   filter       sort by KeyPoint_LessThan, duplicate removal, retainBest: ranks by counting, on the device
+// One host synchronisation (the counts), then the copy of the results.  A standalone operator (uvo_sift_detect): the fused stereo /
+// mono steps of this library run on SURF; the reference's loop written against the function surface runs on it (shim).
 #include "uvo_ctx.h"
 #include "uvo_math.h"
 #include <algorithm>
