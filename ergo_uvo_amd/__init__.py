@@ -169,6 +169,11 @@ class Context:
             import torch
             self._check(self._lib.uvo_ctx_set_producer_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream or None), 1))
 
+    def set_feature_detector(self, name: str):
+        """The reference's global FEATURE_DETECTOR for the fused steps: "SURF" (default) or "SIFT"."""
+        self._check(self._lib.uvo_ctx_set_feature_detector(self._h, name.encode()))
+        self._feature_sift = name == "SIFT"
+
     def set_params(self, params: Params):
         self.params = params
         self._check(self._lib.uvo_ctx_set_params(self._h, C.byref(params)))
@@ -430,8 +435,8 @@ class Context:
         return r
 
     def stereo_get(self, what: str):
-        spec = {"kps_left": KP_DTYPE, "kps_right": KP_DTYPE, "desc_left": np.dtype(("f4", 128 if self.params.SURF_EXTENDED else 64)),
-                "desc_right": np.dtype(("f4", 128 if self.params.SURF_EXTENDED else 64)), "matches_stereo": DM_DTYPE, "matches_tri": DM_DTYPE,
+        spec = {"kps_left": KP_DTYPE, "kps_right": KP_DTYPE, "desc_left": np.dtype(("f4", 128 if (self.params.SURF_EXTENDED or getattr(self, "_feature_sift", False)) else 64)),
+                "desc_right": np.dtype(("f4", 128 if (self.params.SURF_EXTENDED or getattr(self, "_feature_sift", False)) else 64)), "matches_stereo": DM_DTYPE, "matches_tri": DM_DTYPE,
                 "points4d": np.dtype(("f4", 4)), "good_pts": np.dtype(("f8", 3)), "good_idx": np.dtype("i4"),
                 "inliers": np.dtype("i4")}[what]
         buf = np.zeros(self.max_kpts, spec)

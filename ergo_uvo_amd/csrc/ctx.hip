@@ -377,6 +377,24 @@ static uvo_status check_cand_overflow(uvo_ctx* c, int nimg)
     return UVO_OK;
 }
 
+// detect_features inside the fused steps: the SURF branch (VOU:114-119) or, when the context's feature detector is "SIFT", VOU:107-112
+static uvo_status detect_dispatch(Ctx* c, int nimg, int gate_min_features = -1)
+{
+    return c->use_sift() ? sift_detect_lane(c, nimg, gate_min_features) : surf_detect(c, nimg, gate_min_features);
+}
+
+extern "C" uvo_status uvo_ctx_set_feature_detector(uvo_ctx* c, const char* name)
+{
+    if (!c || !name) return UVO_INVALID_ARG;
+    const bool sift = strcmp(name, "SIFT") == 0;
+    if (!sift && strcmp(name, "SURF") != 0) return fail(c, UVO_INVALID_ARG, "uvo_ctx_set_feature_detector: \"SURF\" or \"SIFT\" (the AKAZE / ORB detectors are not built)");
+    if (c->n_pending != 0) return fail(c, UVO_INVALID_ARG, "the feature detector cannot change while pairs are in flight");
+    if ((sift ? 1 : 0) != c->feature_sift && (c->vo_initialized || c->mono_initialized))
+        return fail(c, UVO_INVALID_ARG, "the feature detector changes the descriptors: the previous frame's set held by the running VO loop would not match (uvo_stereo_reset / uvo_mono_reset first)");
+    c->feature_sift = sift ? 1 : 0;
+    return UVO_OK;
+}
+
 extern "C" uvo_status uvo_surf_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem,
                                       uvo_keypoint* kps, float* desc, int cap, int* n)
 {
@@ -852,7 +870,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
         UVO_TRY(wait_for_producer(c, c, mem));
         UVO_TRY(surf_upload(c, 0, left, w, h, stride, mem));
         UVO_TRY(surf_upload(c, 1, right, w, h, stride, mem));
-        UVO_TRY(surf_detect(c, 2));
+        UVO_TRY(detect_dispatch(c, 2));
         UVO_TRY(stereo_init_step(c, &res));
         UVO_TRY(prime_lanes(c, w, h));
         c->stereo_init_results.push_back(res);
@@ -896,7 +914,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
         if (c->n_pending >= c->a_overlap) (void)hipEventSynchronize(H->evA[1]);
     }
     seg(9);                                                                                // the a_overlap wait
-    { Range r("uvo:detect_features x2"); LANE_TRY(surf_detect(L, 2, p.MIN_NUM_FEATURES)); }        // VO:548-549, and the VO:556 gate
+    { Range r("uvo:detect_features x2"); LANE_TRY(detect_dispatch(L, 2, p.MIN_NUM_FEATURES)); }    // VO:548-549, and the VO:556 gate
     seg(10);                                                                               // detector launches
     if (tr) UVO_HIP_TRY(c, hipEventRecord(tr->ev[1], L->stream));
     const int cap = c->cap, curr = L->as_w, prev = c->prev_buf;
@@ -1372,7 +1390,7 @@ extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h
     c->mono_matches.clear(); c->mono_mask.clear(); c->mono_good_pts.clear();
     UVO_TRY(wait_for_producer(c, c, mem));
     UVO_TRY(surf_upload(c, 0, img, w, h, stride, mem));
-    UVO_TRY(surf_detect(c, 1));                                                            // VO:238 / VO:274
+    UVO_TRY(detect_dispatch(c, 1));                                                        // VO:238 / VO:274
     UVO_TRY(read_counts(c));
     UVO_TRY(check_cand_overflow(c, 1));
     const int n = c->h_counts[CN_NL];
@@ -1519,7 +1537,7 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
         Ctx* H = c->lanes[(li + depth - c->a_overlap_mono) % depth];
         if (c->n_pending >= c->a_overlap_mono) (void)hipEventSynchronize(H->evA[1]);
     }
-    LANE_TRY(surf_detect(L, 1));                                                           // VO:274
+    LANE_TRY(detect_dispatch(L, 1));                                                       // VO:274
     UVO_HIP_TRY(c, hipEventRecord(L->evDet, st));
     int* cn = L->d_counts;
     const int cap = c->cap;

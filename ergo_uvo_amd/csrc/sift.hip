@@ -83,11 +83,13 @@ static bool sift_grow(SiftWs* s, int cand, int raw)
 }
 void sift_ws_free(Ctx* c)
 {
-    SiftWs* s = static_cast<SiftWs*>(c->sift_ws);
-    if (!s) return;
-    sift_ws_release(s);
-    delete s;
-    c->sift_ws = nullptr;
+    for (int i = 0; i < 2; i++) {
+        SiftWs* s = static_cast<SiftWs*>(c->sift_ws[i]);
+        if (!s) continue;
+        sift_ws_release(s);
+        delete s;
+        c->sift_ws[i] = nullptr;
+    }
 }
 
 // ------------------------------------------------------------------------------------------ device helpers
@@ -807,7 +809,7 @@ __global__ __launch_bounds__(256) void k_sift_place(const uvo_keypoint* __restri
 // order-preserving compaction by one workgroup: 16 waves, a contiguous segment each; a wave walks its segment 64 records at a time
 // (coalesced) and places the kept ones with ballot / mbcnt, once to count and once to write
 __global__ __launch_bounds__(1024) void k_sift_pack(const uvo_keypoint* __restrict__ src, const int* __restrict__ n_p, int cap, const int* __restrict__ keep,
-                                                    const int* __restrict__ greater, int nfeatures, int scale_back, uvo_keypoint* dst, int* n_out)
+                                                    const int* __restrict__ greater, int nfeatures, int scale_back, uvo_keypoint* dst, int dst_cap, int* n_out)
 {
     __shared__ int s_cnt[16];
     const int n = min(*n_p, cap), tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -828,7 +830,8 @@ __global__ __launch_bounds__(1024) void k_sift_pack(const uvo_keypoint* __restri
         if (k) {
             uvo_keypoint kp = src[e];
             if (scale_back) { kp.octave = (kp.octave & ~255) | ((kp.octave + -1) & 255); kp.x *= 0.5f; kp.y *= 0.5f; kp.size *= 0.5f; }
-            dst[pos + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = kp;
+            const int at = pos + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (at < dst_cap) dst[at] = kp;
         }
         pos += __popcll(m);
     }
@@ -896,45 +899,45 @@ static uvo_status sift_blur(Ctx* c, SiftWs* s, const float* src, float* dst, flo
     return UVO_OK;
 }
 
-uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int nfeatures, int nL, double contrastThreshold,
-                       double edgeThreshold, double sigma, uvo_keypoint* kps, float* desc, int cap, int* n_out)
+// ---- the detector in three host steps: workspace, pyramid, keypoints.  Everything is queued on c->stream; nothing here waits for the
+// device except the (re)allocation of a workspace and a change of the small octaves' taps.
+static uvo_status sift_ensure(Ctx* c, int slot, int w, int h, int nL, SiftWs** out)
 {
-    if (nL < 1 || nL > kSiftMaxLayers || w < 16 || h < 16 || w > c->max_w || h > c->max_h || sigma <= 0.5) { c->err = "uvo_sift_detect: nOctaveLayers 1..8, sigma > 0.5, image within the context's size"; return UVO_INVALID_ARG; }
-    if (!c->sift_ws) c->sift_ws = new SiftWs();
-    SiftWs* s = static_cast<SiftWs*>(c->sift_ws);
+    if (!c->sift_ws[slot]) c->sift_ws[slot] = new SiftWs();
+    SiftWs* s = static_cast<SiftWs*>(c->sift_ws[slot]);
+    *out = s;
+    if (s->w == w && s->h == h && s->nL == nL) return UVO_OK;
     const int nOct = std::min(kSiftMaxOctaves, std::max(1, cv_round_d(log((double)(2 * std::min(w, h))) / log(2.) - 2) + 1));    // firstOctave = -1
-    if (s->w != w || s->h != h || s->nL != nL) {
-        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        sift_ws_release(s);
-        int ow = 2 * w, oh = 2 * h;
-        bool ok = hipMalloc(reinterpret_cast<void**>(&s->tmp), sizeof(float) * (size_t)ow * oh) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&s->d_img), (size_t)w * h) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&s->d_cnt), sizeof(int) * 8) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&s->d_exptab), sizeof(float) * 64) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&s->d_taps), sizeof(float) * kSiftMaxTaps * (kSiftMaxLayers + 3)) == hipSuccess &&
-                  hipMalloc(reinterpret_cast<void**>(&s->d_radii), sizeof(int) * (kSiftMaxLayers + 3)) == hipSuccess;
-        for (int o = 0; o < nOct && ok; o++) {
-            s->ow[o] = ow; s->oh[o] = oh;
-            for (int i = 0; i < nL + 3 && ok; i++) ok = hipMalloc(reinterpret_cast<void**>(&s->gauss[o * (nL + 3) + i]), sizeof(float) * (size_t)ow * oh) == hipSuccess;
-            for (int i = 0; i < nL + 2 && ok; i++) ok = hipMalloc(reinterpret_cast<void**>(&s->dog[o * (nL + 2) + i]), sizeof(float) * (size_t)ow * oh) == hipSuccess;
-            ow /= 2; oh /= 2;
-            if (ow < 1 || oh < 1) { ok = ok && o + 1 >= nOct; }
-        }
-        ok = ok && sift_grow(s, 8 * c->cap, 4 * c->cap);
-        if (!ok) { sift_ws_release(s); c->err = "uvo_sift_detect: out of device memory for the scale-space pyramid"; return UVO_HIP_ERROR; }
-        float tab[64];
-        for (int i = 0; i < 64; i++) tab[i] = (float)(pow(2.0, (double)i / 64) * .9670371139572337719125840413672004409288e-2);     // hal::exp32f's table
-        UVO_HIP_TRY(c, hipMemcpy(s->d_exptab, tab, sizeof(tab), hipMemcpyHostToDevice));
-        s->w = w; s->h = h; s->nL = nL; s->nOct = nOct;
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    sift_ws_release(s);
+    int ow = 2 * w, oh = 2 * h;
+    bool ok = hipMalloc(reinterpret_cast<void**>(&s->tmp), sizeof(float) * (size_t)ow * oh) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&s->d_img), (size_t)w * h) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&s->d_cnt), sizeof(int) * 8) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&s->d_exptab), sizeof(float) * 64) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&s->d_taps), sizeof(float) * kSiftMaxTaps * (kSiftMaxLayers + 3)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void**>(&s->d_radii), sizeof(int) * (kSiftMaxLayers + 3)) == hipSuccess;
+    for (int o = 0; o < nOct && ok; o++) {
+        s->ow[o] = ow; s->oh[o] = oh;
+        for (int i = 0; i < nL + 3 && ok; i++) ok = hipMalloc(reinterpret_cast<void**>(&s->gauss[o * (nL + 3) + i]), sizeof(float) * (size_t)ow * oh) == hipSuccess;
+        for (int i = 0; i < nL + 2 && ok; i++) ok = hipMalloc(reinterpret_cast<void**>(&s->dog[o * (nL + 2) + i]), sizeof(float) * (size_t)ow * oh) == hipSuccess;
+        ow /= 2; oh /= 2;
+        if (ow < 1 || oh < 1) { ok = ok && o + 1 >= nOct; }
     }
+    ok = ok && sift_grow(s, 8 * c->cap, 4 * c->cap);
+    if (!ok) { sift_ws_release(s); c->err = "uvo_sift_detect: out of device memory for the scale-space pyramid"; return UVO_HIP_ERROR; }
+    float tab[64];
+    for (int i = 0; i < 64; i++) tab[i] = (float)(pow(2.0, (double)i / 64) * .9670371139572337719125840413672004409288e-2);     // hal::exp32f's table
+    UVO_HIP_TRY(c, hipMemcpy(s->d_exptab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    s->w = w; s->h = h; s->nL = nL; s->nOct = nOct;
+    return UVO_OK;
+}
+
+// createInitialImage + buildGaussianPyramid + buildDoGPyramid of the tight device image d_img
+static uvo_status sift_pyramid(Ctx* c, SiftWs* s, const uint8_t* d_img, double sigma, SiftPyr* pp)
+{
     hipStream_t st = c->stream;
-    const uint8_t* d_img = gray;
-    if (!(mem == UVO_MEM_DEVICE && stride == w)) {
-        UVO_HIP_TRY(c, hipMemcpy2DAsync(s->d_img, w, gray, stride, w, h, mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-        d_img = s->d_img;
-    }
-    UVO_HIP_TRY(c, hipMemsetAsync(s->d_cnt, 0, sizeof(int) * 8, st));
-    // createInitialImage + buildGaussianPyramid + buildDoGPyramid
+    const int w = s->w, h = s->h, nL = s->nL, nOct = s->nOct;
     double sig[kSiftMaxLayers + 3];
     sig[0] = sigma;
     {
@@ -945,7 +948,7 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
     hipLaunchKernelGGL(k_sift_resize2x, dim3((2 * w + 255) / 256, 2 * h), dim3(256), 0, st, d_img, w, h, base);
     const float sd2 = (float)sigma * (float)sigma - 0.5f * 0.5f * 4;
     const float sig_diff = sqrtf(sd2 > 0.01f ? sd2 : 0.01f);
-    SiftPyr p;
+    SiftPyr& p = *pp;
     memset(&p, 0, sizeof(p));
     for (int i = 0; i < nOct * (nL + 3); i++) p.gauss[i] = s->gauss[i];
     for (int i = 0; i < nOct * (nL + 2); i++) p.dog[i] = s->dog[i];
@@ -974,7 +977,17 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
     if (o_tail < nOct)
         hipLaunchKernelGGL(k_sift_tail, dim3(1), dim3(1024), 0, st, p, static_cast<const float*>(s->d_taps), static_cast<const int*>(s->d_radii), o_tail, nOct);
     UVO_HIP_TRY(c, hipGetLastError());
-    // findScaleSpaceExtrema
+    return UVO_OK;
+}
+
+// findScaleSpaceExtrema, KeyPointsFilter, calcDescriptors: out_kps / out_desc (device, out_cap rows; out_desc may be null) and the
+// count *out_n (device; it may exceed out_cap, nothing is written past it).  s->d_cnt[0..2] keep the list lengths for the caller's
+// overflow check (every kernel clamps to the capacities).
+static uvo_status sift_keypoints(Ctx* c, SiftWs* s, const SiftPyr& p, int nfeatures, double contrastThreshold, double edgeThreshold, double sigma,
+                                 uvo_keypoint* out_kps, float* out_desc, int out_cap, int* out_n)
+{
+    hipStream_t st = c->stream;
+    const int nL = s->nL, nOct = s->nOct;
     const int threshold = cv_floor_d(0.5 * contrastThreshold / nL * 255);
     SiftTiles tl;
     memset(&tl, 0, sizeof(tl));
@@ -984,30 +997,49 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
         tl.tx[o] = ow > 0 ? (ow + 63) / 64 : 0;
         tl.start[o + 1] = tl.start[o] + (ow > 0 && oh > 0 ? tl.tx[o] * ((oh + 15) / 16) : 0);
     }
+    const int rc = s->raw_cap;
+    int* d_rank = s->d_ints; int* d_dup = s->d_ints + rc; int* d_keep = s->d_ints + 2 * (size_t)rc; int* d_greater = s->d_ints + 3 * (size_t)rc;
+    UVO_HIP_TRY(c, hipMemsetAsync(s->d_cnt, 0, sizeof(int) * 8, st));
+    UVO_HIP_TRY(c, hipMemsetAsync(s->d_ints, 0, sizeof(int) * 4 * (size_t)rc, st));
+    if (tl.start[nOct] > 0)
+        hipLaunchKernelGGL(k_sift_extrema_all, dim3(tl.start[nOct]), dim3(256), 0, st, p, tl, threshold, s->d_cand, s->d_cnt, s->cand_cap);
+    hipLaunchKernelGGL(k_sift_refine, dim3((s->cand_cap + 63) / 64), dim3(64), 0, st, p, static_cast<const SiftCand*>(s->d_cand), static_cast<const int*>(s->d_cnt),
+                       s->cand_cap, (float)contrastThreshold, (float)edgeThreshold, (float)sigma, s->d_surv, s->d_cnt + 2);
+    hipLaunchKernelGGL(k_sift_orient, dim3(8192), dim3(64), 0, st, p, static_cast<const SiftSurv*>(s->d_surv), static_cast<const int*>(s->d_cnt + 2), s->cand_cap,
+                       static_cast<const float*>(s->d_exptab), s->d_raw, s->d_cnt + 1, rc);
+    // KeyPointsFilter::removeDuplicatedSorted, retainBest(nfeatures), the scaling back of firstOctave = -1
+    hipLaunchKernelGGL(k_sift_rank, dim3(rc / 256, 64), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_raw), static_cast<const int*>(s->d_cnt + 1), rc, d_rank, d_dup);
+    hipLaunchKernelGGL(k_sift_place, dim3(rc / 256), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_raw), static_cast<const int*>(s->d_cnt + 1), rc,
+                       static_cast<const int*>(d_rank), static_cast<const int*>(d_dup), s->d_sorted, d_keep);
+    hipLaunchKernelGGL(k_sift_pack, dim3(1), dim3(1024), 0, st, static_cast<const uvo_keypoint*>(s->d_sorted), static_cast<const int*>(s->d_cnt + 1), rc,
+                       static_cast<const int*>(d_keep), static_cast<const int*>(nullptr), 0, 0, s->d_kept, rc, s->d_cnt + 3);
+    hipLaunchKernelGGL(k_sift_greater, dim3(rc / 256, 64), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_kept), static_cast<const int*>(s->d_cnt + 3), rc, nfeatures, d_greater);
+    hipLaunchKernelGGL(k_sift_pack, dim3(1), dim3(1024), 0, st, static_cast<const uvo_keypoint*>(s->d_kept), static_cast<const int*>(s->d_cnt + 3), rc,
+                       static_cast<const int*>(nullptr), static_cast<const int*>(d_greater), nfeatures, 1, out_kps, out_cap, out_n);
+    if (out_desc)
+        hipLaunchKernelGGL(k_sift_descriptor, dim3(16384), dim3(64), 0, st, p, static_cast<const uvo_keypoint*>(out_kps), static_cast<const int*>(out_n), out_cap,
+                           static_cast<const float*>(s->d_exptab), out_desc);
+    UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+
+uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int nfeatures, int nL, double contrastThreshold,
+                       double edgeThreshold, double sigma, uvo_keypoint* kps, float* desc, int cap, int* n_out)
+{
+    if (nL < 1 || nL > kSiftMaxLayers || w < 16 || h < 16 || w > c->max_w || h > c->max_h || sigma <= 0.5) { c->err = "uvo_sift_detect: nOctaveLayers 1..8, sigma > 0.5, image within the context's size"; return UVO_INVALID_ARG; }
+    SiftWs* s = nullptr;
+    UVO_TRY(sift_ensure(c, 0, w, h, nL, &s));
+    hipStream_t st = c->stream;
+    const uint8_t* d_img = gray;
+    if (!(mem == UVO_MEM_DEVICE && stride == w)) {
+        UVO_HIP_TRY(c, hipMemcpy2DAsync(s->d_img, w, gray, stride, w, h, mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        d_img = s->d_img;
+    }
+    SiftPyr p;
+    UVO_TRY(sift_pyramid(c, s, d_img, sigma, &p));
     int cnt[8];
     for (int attempt = 0;; attempt++) {
-        const int rc = s->raw_cap;
-        int* d_rank = s->d_ints; int* d_dup = s->d_ints + rc; int* d_keep = s->d_ints + 2 * (size_t)rc; int* d_greater = s->d_ints + 3 * (size_t)rc;
-        UVO_HIP_TRY(c, hipMemsetAsync(s->d_ints, 0, sizeof(int) * 4 * (size_t)rc, st));
-        if (tl.start[nOct] > 0)
-            hipLaunchKernelGGL(k_sift_extrema_all, dim3(tl.start[nOct]), dim3(256), 0, st, p, tl, threshold, s->d_cand, s->d_cnt, s->cand_cap);
-        hipLaunchKernelGGL(k_sift_refine, dim3((s->cand_cap + 63) / 64), dim3(64), 0, st, p, static_cast<const SiftCand*>(s->d_cand), static_cast<const int*>(s->d_cnt),
-                           s->cand_cap, (float)contrastThreshold, (float)edgeThreshold, (float)sigma, s->d_surv, s->d_cnt + 2);
-        hipLaunchKernelGGL(k_sift_orient, dim3(8192), dim3(64), 0, st, p, static_cast<const SiftSurv*>(s->d_surv), static_cast<const int*>(s->d_cnt + 2), s->cand_cap,
-                           static_cast<const float*>(s->d_exptab), s->d_raw, s->d_cnt + 1, rc);
-        // KeyPointsFilter::removeDuplicatedSorted, retainBest(nfeatures), the scaling back of firstOctave = -1
-        hipLaunchKernelGGL(k_sift_rank, dim3(rc / 256, 64), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_raw), static_cast<const int*>(s->d_cnt + 1), rc, d_rank, d_dup);
-        hipLaunchKernelGGL(k_sift_place, dim3(rc / 256), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_raw), static_cast<const int*>(s->d_cnt + 1), rc,
-                           static_cast<const int*>(d_rank), static_cast<const int*>(d_dup), s->d_sorted, d_keep);
-        hipLaunchKernelGGL(k_sift_pack, dim3(1), dim3(1024), 0, st, static_cast<const uvo_keypoint*>(s->d_sorted), static_cast<const int*>(s->d_cnt + 1), rc,
-                           static_cast<const int*>(d_keep), static_cast<const int*>(nullptr), 0, 0, s->d_kept, s->d_cnt + 3);
-        hipLaunchKernelGGL(k_sift_greater, dim3(rc / 256, 64), dim3(256), 0, st, static_cast<const uvo_keypoint*>(s->d_kept), static_cast<const int*>(s->d_cnt + 3), rc, nfeatures, d_greater);
-        hipLaunchKernelGGL(k_sift_pack, dim3(1), dim3(1024), 0, st, static_cast<const uvo_keypoint*>(s->d_kept), static_cast<const int*>(s->d_cnt + 3), rc,
-                           static_cast<const int*>(nullptr), static_cast<const int*>(d_greater), nfeatures, 1, s->d_kps, s->d_cnt + 4);
-        if (desc)
-            hipLaunchKernelGGL(k_sift_descriptor, dim3(16384), dim3(64), 0, st, p, static_cast<const uvo_keypoint*>(s->d_kps), static_cast<const int*>(s->d_cnt + 4), rc,
-                               static_cast<const float*>(s->d_exptab), s->d_desc);
-        UVO_HIP_TRY(c, hipGetLastError());
+        UVO_TRY(sift_keypoints(c, s, p, nfeatures, contrastThreshold, edgeThreshold, sigma, s->d_kps, desc ? s->d_desc : nullptr, s->raw_cap, s->d_cnt + 4));
         UVO_HIP_TRY(c, hipMemcpyAsync(cnt, s->d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
         UVO_HIP_TRY(c, hipStreamSynchronize(st));
         if (cnt[0] <= s->cand_cap && cnt[1] <= s->raw_cap) break;
@@ -1016,7 +1048,6 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
         if (attempt >= 3 || !sift_grow(s, cnt[0] + cnt[0] / 4, std::max(cnt[1] + cnt[1] / 4, cnt[0] > s->cand_cap ? cnt[0] : 0))) {
             c->err = "uvo_sift_detect: out of device memory for the extrema lists"; return UVO_HIP_ERROR;
         }
-        UVO_HIP_TRY(c, hipMemsetAsync(s->d_cnt, 0, sizeof(int) * 8, st));
     }
     const int nk = cnt[4];
     *n_out = nk;
@@ -1027,10 +1058,54 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
     return UVO_OK;
 }
 
+// ---- detect_features' SIFT branch inside the fused stereo / mono steps (the context's feature detector is "SIFT"): the images are
+// c->img[0 .. nimg-1] (surf_upload), the results land where the SURF detector puts its own -- c->det[i].kps / desc (128 floats per
+// row), the counts in d_counts[CN_NL + i] -- and nothing waits for the device: the lists are sized once (16 / 4 times max_kpts); a
+// frame that overflows them, or yields more keypoints than max_kpts, is reported through d_counts[CN_CAND0 + i] > max_kpts, the
+// signal the SURF path uses for the same condition.
+__global__ void k_sift_publish(const int* __restrict__ cnt0, int cand_cap0, int raw_cap0, const int* __restrict__ cnt1, int cand_cap1, int raw_cap1,
+                               int* cn, int cap, int nimg, int gate_min_features)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int i = 0; i < nimg; i++) {
+        const int* cnt = i ? cnt1 : cnt0;
+        const bool over = cnt[0] > (i ? cand_cap1 : cand_cap0) || cnt[1] > (i ? raw_cap1 : raw_cap0);
+        const int n = cn[CN_NL + i];
+        cn[CN_CAND0 + i] = over ? cap + 1 : n;
+        cn[CN_NL + i] = n < cap ? n : cap;
+    }
+    if (gate_min_features >= 0 && nimg == 2)                           // VO:556: both images need >= MIN_NUM_FEATURES keypoints, else no stereo matching
+        cn[CN_NQA] = (cn[CN_NL] >= gate_min_features && cn[CN_NR] >= gate_min_features) ? cn[CN_NL] : 0;
+}
+uvo_status sift_detect_lane(Ctx* c, int nimg, int gate_min_features)
+{
+    const int w = c->img_w, h = c->img_h;
+    if (w < 16 || h < 16) { c->err = "SIFT: image too small"; return UVO_INVALID_ARG; }
+    SiftWs* ws[2] = { nullptr, nullptr };
+    for (int i = 0; i < nimg; i++) {
+        UVO_TRY(sift_ensure(c, i, w, h, 3, &ws[i]));
+        if (ws[i]->cand_cap < 16 * c->cap || ws[i]->raw_cap < 4 * c->cap) {
+            UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (!sift_grow(ws[i], 16 * c->cap, 4 * c->cap)) { c->err = "SIFT: out of device memory for the extrema lists"; return UVO_HIP_ERROR; }
+        }
+    }
+    for (int i = 0; i < nimg; i++) {
+        SiftPyr p;
+        const uint8_t* d_img = c->img[i];
+        UVO_TRY(sift_pyramid(c, ws[i], d_img, 1.6, &p));
+        UVO_TRY(sift_keypoints(c, ws[i], p, 10000, 0.03, 10, 1.6, c->det[i].kps, c->det[i].desc, c->cap, c->d_counts + CN_NL + i));   // VOU:109
+    }
+    SiftWs* s1 = ws[nimg > 1 ? 1 : 0];
+    hipLaunchKernelGGL(k_sift_publish, dim3(1), dim3(64), 0, c->stream, static_cast<const int*>(ws[0]->d_cnt), ws[0]->cand_cap, ws[0]->raw_cap,
+                       static_cast<const int*>(s1->d_cnt), s1->cand_cap, s1->raw_cap, c->d_counts, c->cap, nimg, gate_min_features);
+    UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+
 // test hook: one Gaussian (dog = 0) or difference-of-Gaussians (dog = 1) layer of the last uvo_sift_detect, to a host buffer
 uvo_status sift_layer(Ctx* c, int octave, int layer, int dog, float* out, int cap_floats, int* ow, int* oh)
 {
-    SiftWs* s = static_cast<SiftWs*>(c->sift_ws);
+    SiftWs* s = static_cast<SiftWs*>(c->sift_ws[0]);
     if (!s || !s->w) { c->err = "uvo_sift_layer: no uvo_sift_detect has run on this context"; return UVO_INVALID_ARG; }
     if (octave < 0 || octave >= s->nOct || layer < 0 || layer >= s->nL + (dog ? 2 : 3)) { c->err = "uvo_sift_layer: no such layer"; return UVO_INVALID_ARG; }
     *ow = s->ow[octave]; *oh = s->oh[octave];

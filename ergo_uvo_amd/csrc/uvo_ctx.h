@@ -201,7 +201,8 @@ struct Ctx {
     void* mono_ws = nullptr;                     // MonoWs*, allocated on first use
     void* pre_ws = nullptr;                      // PreWs* (get_image), allocated on first use
     void* codec_ws = nullptr;                    // CodecWs* (uvo_decode_image), allocated on first use
-    void* sift_ws = nullptr;                     // SiftWs* (uvo_sift_detect), allocated on first use
+    void* sift_ws[2] = {nullptr, nullptr};       // SiftWs* per image slot (uvo_sift_detect uses slot 0), allocated on first use
+    int feature_sift = 0;                        // the reference's global FEATURE_DETECTOR == "SIFT" (uvo_ctx_set_feature_detector); read from the master context
     double mono_K[9]; bool mono_cam_set = false, mono_initialized = false, mono_pipelined = false;
     int mono_use_essential = 1;                  // the reference's global `use_essential` (VOH:89)
     double mono_R[9] = {1,0,0,0,1,0,0,0,1}, mono_t[3] = {0,0,0}, mono_SF = 1.0;
@@ -219,7 +220,8 @@ struct Ctx {
     bool trace_on = false;
 
     int match_dim = 0;                           // uvo_match_knn2*_dim: row width of the standalone matcher for the duration of one call (0 = SURF's)
-    int desc_dim() const { return match_dim ? match_dim : (p.SURF_EXTENDED ? 128 : 64); }      // SURF::descriptorSize(): floats per descriptor row
+    bool use_sift() const { return (master ? master : this)->feature_sift != 0; }
+    int desc_dim() const { return match_dim ? match_dim : (use_sift() || p.SURF_EXTENDED ? 128 : 64); }      // SURF::descriptorSize(): floats per descriptor row
 
     // ---- timing ----
     bool timing = false;
@@ -300,6 +302,7 @@ void sift_ws_free(Ctx* c);
 uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int nfeatures, int nL, double contrastThreshold,
                        double edgeThreshold, double sigma, uvo_keypoint* kps, float* desc, int cap, int* n_out);
 uvo_status sift_layer(Ctx* c, int octave, int layer, int dog, float* out, int cap_floats, int* ow, int* oh);
+uvo_status sift_detect_lane(Ctx* c, int nimg, int gate_min_features);      // SIFT in place of surf_detect inside the fused steps
 // mono.hip
 void mono_ws_free(Ctx* c);
 uvo_status mono_find_essential(Ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K, int method,

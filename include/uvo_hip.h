@@ -86,6 +86,13 @@ const char* uvo_ctx_warning(const uvo_ctx* c);
  * with "nothing submitted" or "wrong kind" leaves it unchanged; every other collect, successful or not, dequeues one. */
 int         uvo_ctx_pending(const uvo_ctx* c);
 
+/* The reference's global FEATURE_DETECTOR (VO_utility.h:25, /vo_params/feature_detector) for the fused steps: "SURF" (default) or
+ * "SIFT" -- uvo_stereo_step / submit and uvo_mono_step / submit then take detect_features' SIFT branch (VO_utility.cpp:107-112,
+ * SIFT::create(10000, 3, 0.03, 10, 1.6)) and match 128-float rows (VO_utility.cpp:525-529); everything after the matcher is unchanged.
+ * Refused while pairs are in flight or a VO sequence is running (reset first).  A frame with more than max_kpts SIFT keypoints is a
+ * UVO_CAPACITY error, as for SURF: create the context with max_kpts >= 10000 + ties for 1080p frames. */
+uvo_status uvo_ctx_set_feature_detector(uvo_ctx* c, const char* name);
+
 /* ---- detect_features, SURF branch (VO_utility.h:100 -> VO_utility.cpp:114-119) ----
  * gray: 8-bit single channel, `stride` bytes per row.  kps/desc are host buffers of capacity `cap`, either may be NULL;
  * desc is n x 64 f32, or n x 128 when the context's SURF_EXTENDED is set.  SURF_UPRIGHT = 0 runs the orientation assignment

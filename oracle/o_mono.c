@@ -155,7 +155,7 @@ double orc_compute_scale_factor(float distance, const double* pts_nx3, int n)
 struct orc_mono {
     orc_vo_params p;
     double K[9];
-    int cap, vo_initialized, use_essential;
+    int cap, vo_initialized, use_essential, use_sift;      /* use_sift: FEATURE_DETECTOR == "SIFT" (VOH:25) */
     orc_keypoint* prev_kps; float* prev_desc; int n_prev;
     double R[9], t[3], SF;
     /* last-step intermediates */
@@ -185,24 +185,28 @@ void orc_mono_destroy(orc_mono* s)
     free(s->prev_kps); free(s->prev_desc); free(s->kps); free(s->desc); free(s->matches); free(s->mask); free(s->good_pts); free(s);
 }
 
+void orc_mono_use_sift(orc_mono* s, int on) { s->use_sift = on; }
+
 int orc_mono_step(orc_mono* s, const uint8_t* img, int w, int h, int stride, double range, double dt, orc_mono_result* out)
 {
     const orc_vo_params* p = &s->p;
     memset(out, 0, sizeof(*out));
     s->n_matches = s->n_inl = s->G = 0;
     orc_surf_params sp = { (double)p->SURF_MIN_HESSIAN, p->SURF_OCTAVES_NUMBER, p->SURF_OCTAVES_LAYERS, p->SURF_EXTENDED, p->SURF_UPRIGHT };
-    int n = orc_surf_detect_and_compute(img, w, h, stride, &sp, s->kps, s->desc, s->cap);
+    const int ddim = s->use_sift || p->SURF_EXTENDED ? 128 : 64;
+    int n = s->use_sift ? orc_sift_detect_and_compute(img, w, h, stride, 10000, 3, 0.03, 10, 1.6, s->kps, s->desc, s->cap)      /* VOU:107-112 */
+                        : orc_surf_detect_and_compute(img, w, h, stride, &sp, s->kps, s->desc, s->cap);
     if (n < 0) n = s->cap;
     s->n_kps = n; out->n_kps = n;
     if (!s->vo_initialized) {                                            /* VO:227-245 */
-        memcpy(s->prev_kps, s->kps, sizeof(orc_keypoint)*(size_t)n); memcpy(s->prev_desc, s->desc, sizeof(float)*(p->SURF_EXTENDED ? 128 : 64)*(size_t)n); s->n_prev = n;
+        memcpy(s->prev_kps, s->kps, sizeof(orc_keypoint)*(size_t)n); memcpy(s->prev_desc, s->desc, sizeof(float)*ddim*(size_t)n); s->n_prev = n;
         if (n >= p->MIN_NUM_FEATURES) s->vo_initialized = 1;
         return 0;
     }
     out->initialized = 1;
-#define ROLL_STATE() do { memcpy(s->prev_kps, s->kps, sizeof(orc_keypoint)*(size_t)n); memcpy(s->prev_desc, s->desc, sizeof(float)*(p->SURF_EXTENDED ? 128 : 64)*(size_t)n); s->n_prev = n; } while (0)
+#define ROLL_STATE() do { memcpy(s->prev_kps, s->kps, sizeof(orc_keypoint)*(size_t)n); memcpy(s->prev_desc, s->desc, sizeof(float)*ddim*(size_t)n); s->n_prev = n; } while (0)
     if (n < p->MIN_NUM_FEATURES) { ROLL_STATE(); return 0; }             /* VO:276-284 */
-    orc_match_knn2_ratio(s->prev_desc, s->n_prev, s->desc, n, p->SURF_EXTENDED ? 128 : 64, (float)p->LOWE_RATIO_THRESHOLD, s->matches, s->cap, &s->n_matches);   /* VO:287 */
+    orc_match_knn2_ratio(s->prev_desc, s->n_prev, s->desc, n, ddim, (float)p->LOWE_RATIO_THRESHOLD, s->matches, s->cap, &s->n_matches);   /* VO:287 */
     int M = s->n_matches;
     out->n_matches = M;
     if (M < p->MIN_NUM_FEATURES) { ROLL_STATE(); return 0; }             /* VO:299-307 */

@@ -402,6 +402,11 @@ class MonoVO:
         lib().orc_mono_create.restype = C.c_void_p
         self.h = C.c_void_p(lib().orc_mono_create(C.byref(params), _p(self._K), max_kpts))
 
+    def use_sift(self, on=True):
+        """FEATURE_DETECTOR = "SIFT" for the mono loop (VOU:107-112, 525-529)."""
+        lib().orc_mono_use_sift.argtypes = [C.c_void_p, C.c_int]
+        lib().orc_mono_use_sift(self.h, int(bool(on)))
+
     def step(self, img, rng=1.0, dt=0.05) -> MonoResult:
         img = _c(img, np.uint8)
         h, w = img.shape

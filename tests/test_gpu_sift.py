@@ -167,3 +167,126 @@ def test_shim_detect_features_sift_and_surf_branches(tmp_path, oracle):
     assert rc == 0 and desc.shape[1] == 64 and len(kps) > 100
     rc, err, _ = _shim_detect(tmp_path, img, "AKAZE")
     assert rc == 4 and "FEATURE_DETECTOR" in err
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# FEATURE_DETECTOR = "SIFT" inside the fused steps (uvo_ctx_set_feature_detector): uvo_stereo_step / submit / collect and uvo_mono_step
+# take detect_features' SIFT branch and match 128-float rows; the oracle's state machines are switched to the same detector.
+@pytest.fixture()
+def sctx():
+    import ergo_uvo_amd as uvo
+    c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=1500), 0, 640, 360, 8192)
+    c.set_feature_detector("SIFT")
+    yield c
+    c.close()
+
+
+def _stereo_fields(r):
+    return (r.valid, r.initialized, r.n_left, r.n_right, r.n_stereo_matches, r.n_tri_matches, r.n_good3d, r.n_inliers)
+
+
+def test_fused_stereo_step_on_sift_matches_oracle(sctx, oracle, scene_small):
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    seq = [scene_small[k] for k in (0, 1, 2, 1, 0)]
+    sctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    ovo = oracle.StereoVO(oracle.stereo_params(1500), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    ovo.use_sift()
+    sync = []
+    for k, (L, R) in enumerate(seq):
+        r = sctx.stereo_step(L, R, 0.05)
+        o = ovo.step(L, R, 0.05)
+        assert _stereo_fields(r) == _stereo_fields(o), (k, _stereo_fields(r), _stereo_fields(o))
+        for what in ("kps_left", "kps_right", "desc_left", "desc_right", "matches_stereo", "matches_tri", "good_idx", "inliers"):
+            a, b = sctx.stereo_get(what), ovo.get(what)
+            assert same(a, b), (k, what, a.shape, b.shape)
+        for a, b in ((r.rvec, o.rvec), (r.tvec, o.tvec), (r.t_prev_curr, o.t_prev_curr)):
+            a, b = np.array(list(a)), np.array(list(b))
+            assert np.linalg.norm(a - b) <= 1e-4 * max(np.linalg.norm(b), 1e-12), (k, a, b)
+        sync.append((_stereo_fields(r), tuple(r.rvec), tuple(r.tvec), tuple(r.t_prev_curr)))
+    assert sum(f[0][0] for f in sync) == len(seq) - 1 and sync[-1][0][2] > 1000 and sctx.stereo_get("desc_left").shape[1] == 128
+    # the same sequence with several pairs in flight
+    for depth in (3, 2):
+        sctx.stereo_set_depth(depth)
+        sctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        piped, sub = [], 0
+        sctx.stereo_submit(*seq[0]); sub += 1
+        r = sctx.stereo_collect(0.05); piped.append((_stereo_fields(r), tuple(r.rvec), tuple(r.tvec), tuple(r.t_prev_curr)))
+        while len(piped) < len(seq):
+            while sub < len(seq) and sub - len(piped) < depth:
+                sctx.stereo_submit(*seq[sub]); sub += 1
+            r = sctx.stereo_collect(0.05); piped.append((_stereo_fields(r), tuple(r.rvec), tuple(r.tvec), tuple(r.t_prev_curr)))
+        assert piped == sync, depth
+
+
+def test_fused_mono_step_on_sift_matches_oracle(oracle, mono_small):
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    p = uvo.Params.mono(SURF_MIN_HESSIAN=400, ESSENTIAL_OUTLIER_METHOD=8, HOMOGRAPHY_OUTLIER_METHOD=8)
+    c = uvo.Context(p, 0, 640, 360, 8192)
+    try:
+        c.set_feature_detector("SIFT")
+        c.mono_set_camera(rig.K_left)
+        ovo = oracle.MonoVO(oracle.mono_params(400, 8), rig.K_left)
+        ovo.use_sift()
+        nvalid = 0
+        for k, img in enumerate([mono_small[i] for i in (0, 1, 2, 1)]):
+            r = c.mono_step(img, 4.0, 0.05)
+            o = ovo.step(img, 4.0, 0.05)
+            for f in ("valid", "initialized", "n_kps", "n_matches", "n_inliers"):
+                assert getattr(r, f) == getattr(o, f), (k, f, getattr(r, f), getattr(o, f))
+            assert same(c.mono_get("kps"), ovo.get("kps")) and same(c.mono_get("matches"), ovo.get("matches")) and same(c.mono_get("mask"), ovo.get("mask"))
+            nvalid += r.valid
+        assert nvalid >= 2 and r.n_kps > 1000
+    finally:
+        c.close()
+
+
+def test_feature_detector_switch_refusals(scene_small):
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=1500), 0, 640, 360, 1024)       # room for 1024 keypoints: SIFT finds ~1500 here
+    try:
+        with pytest.raises(uvo.UvoError, match="SURF.*SIFT"):
+            c.set_feature_detector("ORB")
+        c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        c.set_feature_detector("SIFT")
+        with pytest.raises(uvo.UvoError, match="max_kpts"):
+            c.stereo_step(*scene_small[0], 0.05)
+        c.stereo_reset()
+        c.set_feature_detector("SURF")
+        c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        assert c.stereo_step(*scene_small[0], 0.05).n_left > 100
+        assert c.stereo_step(*scene_small[1], 0.05).valid == 1
+        with pytest.raises(uvo.UvoError, match="reset"):
+            c.set_feature_detector("SIFT")                                              # a sequence is running on SURF descriptors
+    finally:
+        c.close()
+
+
+def test_fused_stereo_step_on_sift_1280x720(oracle):
+    """A larger geometry through the same path (several thousand keypoints per image, every octave kind of the pyramid in use)."""
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    W, H = 1280, 720
+    scene = synth.Scene(11, W)
+    rig = synth.stereo_rig(W)
+    seq = [synth.stereo_pair(scene, k, W, H) for k in (0, 1, 2)]
+    c = uvo.Context(uvo.Params.stereo(), 0, W, H, 12288)
+    try:
+        c.set_feature_detector("SIFT")
+        c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        ovo = oracle.StereoVO(oracle.stereo_params(1500), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        ovo.use_sift()
+        for k, (L, R) in enumerate(seq):
+            r = c.stereo_step(L, R, 0.05)
+            o = ovo.step(L, R, 0.05)
+            assert _stereo_fields(r) == _stereo_fields(o), (k, _stereo_fields(r), _stereo_fields(o))
+            assert same(c.stereo_get("inliers"), ovo.get("inliers")) and same(c.stereo_get("matches_tri"), ovo.get("matches_tri"))
+            a, b = np.array(list(r.tvec)), np.array(list(o.tvec))
+            assert np.linalg.norm(a - b) <= 1e-4 * max(np.linalg.norm(b), 1e-12)
+        assert r.valid == 1 and r.n_left > 3000
+    finally:
+        c.close()

@@ -188,6 +188,41 @@ def main(only=None):
         out["N4_sift_detect_1920x1080"] = {"note": "SIFT::create(10000, 3, 0.03, 10, 1.6)->detectAndCompute; keypoints and 128-float rows copied to host buffers inside the timed region",
                                            "kpts": int(len(k)), "ms_per_frame": round(dt * 1e3, 3), "frames_per_s": round(1 / dt, 1)}
         ctx.close()
+    if only in (None, "SIFTVO"):
+        # ---------------- N4: the stereo loop with FEATURE_DETECTOR = "SIFT" in the fused steps (C3's frames, 10 000 keypoints per image) ----------------
+        W, H = 1920, 1080
+        scene = synth.Scene(synth.SEEDS["C3"], W)
+        frames = [synth.stereo_pair(scene, k, W, H) for k in range(4)]
+        dev = [(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()) for L, R in frames]
+        rig = synth.stereo_rig(W)
+        ctx = uvo.Context(uvo.Params.stereo(), 0, W, H, 12288)
+        ctx.set_feature_detector("SIFT")
+        ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        order = [0, 1, 2, 3, 2, 1]
+        for i in range(6):
+            r = ctx.stereo_step(*dev[order[i % 6]], 0.05)
+        steps = 60
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        nv = 0
+        for i in range(steps):
+            r = ctx.stereo_step(*dev[order[i % 6]], 0.05); nv += r.valid
+        t_sync = time.perf_counter() - t0
+        DEPTH = 4
+        ctx.stereo_set_depth(DEPTH)
+        ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        ctx.stereo_submit(*dev[0]); ctx.stereo_collect(0.05)
+        for i in range(DEPTH):                                  # lanes allocate their SIFT workspaces on first use
+            ctx.stereo_submit(*dev[order[(i + 1) % 6]]); ctx.stereo_collect(0.05)
+        t0 = time.perf_counter()
+        sub = 0; nvp = 0
+        for i in range(steps):
+            while sub < steps and sub - i < DEPTH:
+                ctx.stereo_submit(*dev[order[sub % 6]]); sub += 1
+            nvp += ctx.stereo_collect(0.05).valid
+        t_pipe = time.perf_counter() - t0
+        out["N4_stereo_loop_on_sift_1920x1080"] = {"kpts": r.n_left, "stereo_matches": r.n_stereo_matches, "inliers": r.n_inliers, "valid": nv, "valid_pipelined": nvp,
+                                                   "pairs_per_s_sync": round(steps / t_sync, 1), "pairs_per_s_pipelined_depth4": round(steps / t_pipe, 1)}
+        ctx.close()
     print(json.dumps(out))
 
 
@@ -199,7 +234,7 @@ if __name__ == "__main__":
     else:
         import subprocess
         merged = {}
-        for cfg in ("C2", "C3", "C4", "C4v", "C1", "SIFT"):
+        for cfg in ("C2", "C3", "C4", "C4v", "C1", "SIFT", "SIFTVO"):
             p = subprocess.run([sys.executable, os.path.abspath(__file__), cfg], stdout=subprocess.PIPE, text=True, timeout=900)
             if p.returncode != 0:
                 raise SystemExit(f"configuration {cfg} failed")
