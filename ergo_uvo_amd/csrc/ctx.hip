@@ -873,6 +873,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
         UVO_TRY(detect_dispatch(c, 2));
         UVO_TRY(stereo_init_step(c, &res));
         UVO_TRY(prime_lanes(c, w, h));
+        if (c->use_sift()) for (Ctx* l : c->lanes) { uvo_status st_ = sift_prepare_lane(l, w, h, 2); if (st_ != UVO_OK) { if (l != c) c->err = l->err; return st_; } }
         c->stereo_init_results.push_back(res);
         c->inflight[c->n_pending++] = Ctx::kInflightStereoInit; c->n_submitted++;
         c->next_lane = 0;
@@ -1521,6 +1522,7 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
         c->prev_lane = 0; c->next_lane = 1 % depth;
         UVO_HIP_TRY(c, hipEventRecord(c->evDet, c->stream));                               // lane 0 holds the frame the next one matches against
         UVO_TRY(prime_lanes(c, w, h));
+        if (c->use_sift()) for (Ctx* l : c->lanes) { uvo_status st_ = sift_prepare_lane(l, w, h, 1); if (st_ != UVO_OK) { if (l != c) c->err = l->err; return st_; } }
         return UVO_OK;
     }
     const int li = c->next_lane;

@@ -1077,18 +1077,25 @@ __global__ void k_sift_publish(const int* __restrict__ cnt0, int cand_cap0, int 
     if (gate_min_features >= 0 && nimg == 2)                           // VO:556: both images need >= MIN_NUM_FEATURES keypoints, else no stereo matching
         cn[CN_NQA] = (cn[CN_NL] >= gate_min_features && cn[CN_NR] >= gate_min_features) ? cn[CN_NL] : 0;
 }
+// the lane's workspaces and lists at their pipeline sizes (allocation synchronises the device: done when a sequence starts, not in it)
+uvo_status sift_prepare_lane(Ctx* c, int w, int h, int nimg)
+{
+    for (int i = 0; i < nimg; i++) {
+        SiftWs* s = nullptr;
+        UVO_TRY(sift_ensure(c, i, w, h, 3, &s));
+        if (s->cand_cap < 16 * c->cap || s->raw_cap < 4 * c->cap) {
+            UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (!sift_grow(s, 16 * c->cap, 4 * c->cap)) { c->err = "SIFT: out of device memory for the extrema lists"; return UVO_HIP_ERROR; }
+        }
+    }
+    return UVO_OK;
+}
 uvo_status sift_detect_lane(Ctx* c, int nimg, int gate_min_features)
 {
     const int w = c->img_w, h = c->img_h;
     if (w < 16 || h < 16) { c->err = "SIFT: image too small"; return UVO_INVALID_ARG; }
-    SiftWs* ws[2] = { nullptr, nullptr };
-    for (int i = 0; i < nimg; i++) {
-        UVO_TRY(sift_ensure(c, i, w, h, 3, &ws[i]));
-        if (ws[i]->cand_cap < 16 * c->cap || ws[i]->raw_cap < 4 * c->cap) {
-            UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (!sift_grow(ws[i], 16 * c->cap, 4 * c->cap)) { c->err = "SIFT: out of device memory for the extrema lists"; return UVO_HIP_ERROR; }
-        }
-    }
+    UVO_TRY(sift_prepare_lane(c, w, h, nimg));                          // (a no-op once the lane is primed)
+    SiftWs* ws[2] = { static_cast<SiftWs*>(c->sift_ws[0]), static_cast<SiftWs*>(c->sift_ws[1]) };
     for (int i = 0; i < nimg; i++) {
         SiftPyr p;
         const uint8_t* d_img = c->img[i];

@@ -302,6 +302,7 @@ void sift_ws_free(Ctx* c);
 uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int nfeatures, int nL, double contrastThreshold,
                        double edgeThreshold, double sigma, uvo_keypoint* kps, float* desc, int cap, int* n_out);
 uvo_status sift_layer(Ctx* c, int octave, int layer, int dog, float* out, int cap_floats, int* ow, int* oh);
+uvo_status sift_prepare_lane(Ctx* c, int w, int h, int nimg);
 uvo_status sift_detect_lane(Ctx* c, int nimg, int gate_min_features);      // SIFT in place of surf_detect inside the fused steps
 // mono.hip
 void mono_ws_free(Ctx* c);

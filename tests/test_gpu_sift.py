@@ -239,6 +239,24 @@ def test_fused_mono_step_on_sift_matches_oracle(oracle, mono_small):
             assert same(c.mono_get("kps"), ovo.get("kps")) and same(c.mono_get("matches"), ovo.get("matches")) and same(c.mono_get("mask"), ovo.get("mask"))
             nvalid += r.valid
         assert nvalid >= 2 and r.n_kps > 1000
+        # the same frames with three in flight (uvo_mono_submit / collect)
+        seq = [mono_small[i] for i in (0, 1, 2, 1, 0, 2)]
+        fields = ("published", "valid", "initialized", "used_essential", "success", "n_kps", "n_matches", "n_inliers", "n_good3d", "n_front")
+        c.mono_reset()
+        want = []
+        for img in seq:
+            r = c.mono_step(img, 4.0, 0.2)
+            want.append((tuple(getattr(r, f) for f in fields), tuple(r.R), tuple(r.t), c.mono_get("mask").copy()))
+        c.mono_reset()
+        c.stereo_set_depth(3)
+        got, sub = [], 0
+        for i in range(len(seq)):
+            while sub < len(seq) and sub - i < 3:
+                c.mono_submit(seq[sub], 4.0); sub += 1
+            r = c.mono_collect(0.2)
+            got.append((tuple(getattr(r, f) for f in fields), tuple(r.R), tuple(r.t), c.mono_get("mask").copy()))
+        for k, (a, b) in enumerate(zip(want, got)):
+            assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2] and np.array_equal(a[3], b[3]), k
     finally:
         c.close()
 
