@@ -308,3 +308,25 @@ def test_fused_stereo_step_on_sift_1280x720(oracle):
         assert r.valid == 1 and r.n_left > 3000
     finally:
         c.close()
+
+
+def test_fused_sift_pipeline_soak_is_periodic(sctx, scene_small):
+    """300 pairs through four lanes on SIFT features, frames in a period-4 order: a pair's result depends on its frames and on the
+    previous pair's "after stereo match" set only, so from the second period on every result must repeat the one a period earlier,
+    bit for bit (a race between lanes, a stale workspace or a list overflow would break the repetition)."""
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    order = [0, 1, 2, 1]
+    n = 300
+    sctx.stereo_set_depth(4)
+    sctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    res, sub = [], 0
+    sctx.stereo_submit(*scene_small[order[0]]); sub += 1
+    r = sctx.stereo_collect(0.05); res.append((_stereo_fields(r), tuple(r.rvec), tuple(r.tvec)))
+    while len(res) < n:
+        while sub < n and sub - len(res) < 4:
+            sctx.stereo_submit(*scene_small[order[sub % 4]]); sub += 1
+        r = sctx.stereo_collect(0.05); res.append((_stereo_fields(r), tuple(r.rvec), tuple(r.tvec)))
+    assert all(f[0][0] == 1 for f in res[1:])
+    for i in range(8, n):
+        assert res[i] == res[i - 4], i

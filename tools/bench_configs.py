@@ -207,7 +207,7 @@ def main(only=None):
         for i in range(steps):
             r = ctx.stereo_step(*dev[order[i % 6]], 0.05); nv += r.valid
         t_sync = time.perf_counter() - t0
-        DEPTH = 4
+        DEPTH = int(os.environ.get("UVO_SIFTVO_DEPTH", "4"))
         ctx.stereo_set_depth(DEPTH)
         ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
         ctx.stereo_submit(*dev[0]); ctx.stereo_collect(0.05)
@@ -221,7 +221,7 @@ def main(only=None):
             nvp += ctx.stereo_collect(0.05).valid
         t_pipe = time.perf_counter() - t0
         out["N4_stereo_loop_on_sift_1920x1080"] = {"kpts": r.n_left, "stereo_matches": r.n_stereo_matches, "inliers": r.n_inliers, "valid": nv, "valid_pipelined": nvp,
-                                                   "pairs_per_s_sync": round(steps / t_sync, 1), "pairs_per_s_pipelined_depth4": round(steps / t_pipe, 1)}
+                                                   "pairs_per_s_sync": round(steps / t_sync, 1), "pipeline_depth": DEPTH, "pairs_per_s_pipelined": round(steps / t_pipe, 1)}
         ctx.close()
     print(json.dumps(out))
 
