@@ -933,6 +933,25 @@ static uvo_status sift_ensure(Ctx* c, int slot, int w, int h, int nL, SiftWs** o
     return UVO_OK;
 }
 
+// the layers' filter taps in device memory, for k_sift_tail (they change with sigma and the layer count only)
+static uvo_status sift_upload_taps(Ctx* c, SiftWs* s, double sigma)
+{
+    const int nL = s->nL;
+    if (s->taps_sigma == sigma && s->taps_nL == nL) return UVO_OK;
+    float taps[kSiftMaxTaps * (kSiftMaxLayers + 3)]; int radii[kSiftMaxLayers + 3];
+    memset(taps, 0, sizeof(taps)); memset(radii, 0, sizeof(radii));
+    const double k = pow(2., 1. / nL);
+    for (int i = 1; i < nL + 3; i++) {
+        const double sp = pow(k, (double)(i - 1)) * sigma, stt = sp * k;
+        radii[i] = sift_gauss_kernel(sqrt(stt * stt - sp * sp), taps + i * kSiftMaxTaps) / 2;
+    }
+    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));                   // (a launch of the previous call may still read the old taps)
+    UVO_HIP_TRY(c, hipMemcpy(s->d_taps, taps, sizeof(taps), hipMemcpyHostToDevice));
+    UVO_HIP_TRY(c, hipMemcpy(s->d_radii, radii, sizeof(radii), hipMemcpyHostToDevice));
+    s->taps_sigma = sigma; s->taps_nL = nL;
+    return UVO_OK;
+}
+
 // createInitialImage + buildGaussianPyramid + buildDoGPyramid of the tight device image d_img
 static uvo_status sift_pyramid(Ctx* c, SiftWs* s, const uint8_t* d_img, double sigma, SiftPyr* pp)
 {
@@ -956,15 +975,7 @@ static uvo_status sift_pyramid(Ctx* c, SiftWs* s, const uint8_t* d_img, double s
     p.nL = nL;
     int o_tail = nOct;                                                  // the first octave of k_sift_tail's range
     for (int o = nOct - 1; o >= 1 && (size_t)s->ow[o] * s->oh[o] <= 2048; o--) o_tail = o;
-    if (o_tail < nOct && (s->taps_sigma != sigma || s->taps_nL != nL)) {
-        float taps[kSiftMaxTaps * (kSiftMaxLayers + 3)]; int radii[kSiftMaxLayers + 3];
-        memset(taps, 0, sizeof(taps)); memset(radii, 0, sizeof(radii));
-        for (int i = 1; i < nL + 3; i++) radii[i] = sift_gauss_kernel(sig[i], taps + i * kSiftMaxTaps) / 2;
-        UVO_HIP_TRY(c, hipStreamSynchronize(st));                      // (a launch of the previous call may still read the old taps)
-        UVO_HIP_TRY(c, hipMemcpy(s->d_taps, taps, sizeof(taps), hipMemcpyHostToDevice));
-        UVO_HIP_TRY(c, hipMemcpy(s->d_radii, radii, sizeof(radii), hipMemcpyHostToDevice));
-        s->taps_sigma = sigma; s->taps_nL = nL;
-    }
+    if (o_tail < nOct) UVO_TRY(sift_upload_taps(c, s, sigma));
     for (int o = 0; o < o_tail; o++) {
         const int ow = s->ow[o], oh = s->oh[o];
         for (int i = 0; i < nL + 3; i++) {
@@ -1087,6 +1098,7 @@ uvo_status sift_prepare_lane(Ctx* c, int w, int h, int nimg)
             UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (!sift_grow(s, 16 * c->cap, 4 * c->cap)) { c->err = "SIFT: out of device memory for the extrema lists"; return UVO_HIP_ERROR; }
         }
+        UVO_TRY(sift_upload_taps(c, s, 1.6));
     }
     return UVO_OK;
 }
