@@ -67,6 +67,19 @@ def test_oracle_integral_and_surf(cvfix, inputs, oracle):
         assert np.array_equal(d.view(np.uint32), cvfix[f"surf_{name}_desc"].view(np.uint32))
 
 
+def test_oracle_sift(cvfix, inputs, oracle):
+    """detect_features' SIFT branch (VOU:107-112) and match_features' SIFT arm (VOU:525-529) as the real cv::SIFT / BFMatcher gave them."""
+    if "sift_left0_desc" not in cvfix.files:
+        pytest.skip("the fixture predates the SIFT branch of tools/opencv_oracle/opencv_oracle.cpp")
+    for name in ("left0", "right0"):
+        k, d = oracle.sift_detect(inputs[name])
+        _same_kps(k, cvfix, f"sift_{name}_kps")
+        assert np.array_equal(d, cvfix[f"sift_{name}_desc"])
+    m = oracle.match(cvfix["sift_left0_desc"], cvfix["sift_right0_desc"], float(inputs["lowe_ratio"]))
+    assert np.array_equal(np.c_[m["queryIdx"], m["trainIdx"]], cvfix["sift_ratio_matches"])
+    assert np.array_equal(m["distance"].view(np.uint32), cvfix["sift_ratio_dist"].view(np.uint32))
+
+
 def test_oracle_matcher(cvfix, inputs, oracle):
     d1, d2 = cvfix["surf_left0_desc"], cvfix["surf_right0_desc"]
     idx, dist = oracle.knn2(d1, d2)
@@ -126,6 +139,11 @@ def test_hip_against_opencv(cvfix, inputs):
             k, d = c.detect_features(inputs[name])
             _same_kps(k, cvfix, f"surf_{name}_kps")
             assert np.array_equal(d.view(np.uint32), cvfix[f"surf_{name}_desc"].view(np.uint32))
+        if "sift_left0_desc" in cvfix.files:
+            for name in ("left0", "right0"):
+                k, d = c.sift_detect(inputs[name])
+                _same_kps(k, cvfix, f"sift_{name}_kps")
+                assert np.array_equal(d, cvfix[f"sift_{name}_desc"])
         idx, dist = c.knn_match(cvfix["surf_left0_desc"], cvfix["surf_right0_desc"])
         assert np.array_equal(idx, cvfix["knn_idx"]) and np.array_equal(dist.view(np.uint32), cvfix["knn_dist"].view(np.uint32))
         m = c.match_features(cvfix["surf_left0_desc"], cvfix["surf_right0_desc"], float(inputs["lowe_ratio"]))

@@ -74,6 +74,31 @@ int main(int argc, char** argv)
         out[std::string("surf_") + names[k] + "_desc"] = from_mat(desc[k]);
         if (k == 0) { Mat sum; integral(img, sum, CV_32S); out["integral_left0"] = from_mat(sum); }      // surf.cpp: integral(img, sum, CV_32S)
     }
+    // ---------------- detect_features, SIFT branch: VOU:107-112 ----------------
+    // (retainBest leaves the keypoints in std::nth_element's order when more than 10000 survive; the inputs stay below that, so the
+    //  order is KeyPoint_LessThan's, the one removeDuplicatedSorted establishes)
+    {
+        Mat sdesc[2]; std::vector<KeyPoint> skps[2];
+        for (int k = 0; k < 2; k++) {
+            Mat img = mat_u8(in.at(names[k]));
+            Ptr<SIFT> detector = SIFT::create(10000, 3, 0.03, 10, 1.6);
+            detector->detectAndCompute(img, noArray(), skps[k], sdesc[k]);
+            put_keypoints(out, std::string("sift_") + names[k] + "_kps", skps[k]);
+            out[std::string("sift_") + names[k] + "_desc"] = from_mat(sdesc[k]);
+        }
+        // match_features with FEATURE_DETECTOR == "SIFT" (VOU:525-529): the same BFMatcher(NORM_L2), 128-float rows
+        Ptr<DescriptorMatcher> matcher = DescriptorMatcher::create(DescriptorMatcher::BRUTEFORCE);
+        std::vector<std::vector<DMatch>> knn;
+        matcher->knnMatch(sdesc[0], sdesc[1], knn, 2);
+        std::vector<int32_t> good; std::vector<float> gd;
+        const float ratio = (float)scalar(in, "lowe_ratio");
+        for (size_t i = 0; i < knn.size(); i++)
+            if (knn[i].size() >= 2 && knn[i][0].distance < ratio * knn[i][1].distance) {
+                good.push_back(knn[i][0].queryIdx); good.push_back(knn[i][0].trainIdx); gd.push_back(knn[i][0].distance);
+            }
+        out["sift_ratio_matches"] = npz::make(good.data(), { good.size() / 2, 2 });
+        out["sift_ratio_dist"] = npz::make(gd.data(), { gd.size() });
+    }
     // ---------------- match_features: VOU:515-543 (BFMatcher(NORM_L2).knnMatch k = 2, ratio test) ----------------
     {
         Ptr<DescriptorMatcher> matcher = DescriptorMatcher::create(DescriptorMatcher::BRUTEFORCE);        // VOU:526: NORM_L2 for SURF
