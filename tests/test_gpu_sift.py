@@ -330,3 +330,27 @@ def test_fused_sift_pipeline_soak_is_periodic(sctx, scene_small):
     assert all(f[0][0] == 1 for f in res[1:])
     for i in range(8, n):
         assert res[i] == res[i - 4], i
+
+
+def test_fused_stereo_step_on_sift_odd_geometry(oracle, scene_small):
+    """Odd width and height (no octave has a width that is a multiple of four, the stereo rig's principal point off the crop's
+    centre): the same loop on a 417 x 243 window of the frames."""
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    seq = [(np.ascontiguousarray(L[50:293, 100:517]), np.ascontiguousarray(R[50:293, 100:517])) for L, R in (scene_small[0], scene_small[1], scene_small[2])]
+    c = uvo.Context(uvo.Params.stereo(), 0, 417, 243, 8192)
+    try:
+        c.set_feature_detector("SIFT")
+        c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        ovo = oracle.StereoVO(oracle.stereo_params(1500), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        ovo.use_sift()
+        for k, (L, R) in enumerate(seq):
+            r = c.stereo_step(L, R, 0.05)
+            o = ovo.step(L, R, 0.05)
+            assert _stereo_fields(r) == _stereo_fields(o), (k, _stereo_fields(r), _stereo_fields(o))
+            for what in ("kps_left", "desc_right", "matches_stereo", "matches_tri", "inliers"):
+                assert same(c.stereo_get(what), ovo.get(what)), (k, what)
+        assert r.n_left > 300 and r.n_stereo_matches > 100
+    finally:
+        c.close()
