@@ -1037,7 +1037,11 @@ static uvo_status sift_keypoints(Ctx* c, SiftWs* s, const SiftPyr& p, int nfeatu
 uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int nfeatures, int nL, double contrastThreshold,
                        double edgeThreshold, double sigma, uvo_keypoint* kps, float* desc, int cap, int* n_out)
 {
-    if (nL < 1 || nL > kSiftMaxLayers || w < 16 || h < 16 || w > c->max_w || h > c->max_h || sigma <= 0.5) { c->err = "uvo_sift_detect: nOctaveLayers 1..8, sigma > 0.5, image within the context's size"; return UVO_INVALID_ARG; }
+    if (nL < 1 || nL > kSiftMaxLayers || w < 16 || h < 16 || w > c->max_w || h > c->max_h || stride < w || sigma <= 0.5) { c->err = "uvo_sift_detect: nOctaveLayers 1..8, sigma > 0.5, image within the context's size, stride >= width"; return UVO_INVALID_ARG; }
+    {   // the widest blur (layer nOctaveLayers + 2) must fit the tap arrays: GaussianBlur takes cvRound(8 sigma_i + 1) | 1 taps, 63 are held
+        const double k = pow(2., 1. / nL), sp = pow(k, (double)(nL + 1)) * sigma, stt = sp * k;
+        if ((cv_round_d(sqrt(stt * stt - sp * sp) * 8 + 1) | 1) > kSiftMaxTaps - 1) { c->err = "uvo_sift_detect: sigma / nOctaveLayers need a blur of more than 63 taps"; return UVO_INVALID_ARG; }
+    }
     SiftWs* s = nullptr;
     UVO_TRY(sift_ensure(c, 0, w, h, nL, &s));
     hipStream_t st = c->stream;

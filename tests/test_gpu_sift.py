@@ -134,6 +134,8 @@ def test_sift_refusals(ctx):
         ctx.sift_detect(img, n_octave_layers=0)
     with pytest.raises(Exception):
         ctx.sift_detect(img, sigma=0.4)
+    with pytest.raises(Exception, match="63 taps"):
+        ctx.sift_detect(img, n_octave_layers=1)           # its last blur has sigma 11: 91 taps
     with pytest.raises(Exception):
         ctx.sift_detect(np.zeros((8, 8), np.uint8))
     k, d = ctx.sift_detect(img)                           # still usable afterwards
