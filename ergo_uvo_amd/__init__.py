@@ -180,7 +180,10 @@ class Context:
 
     # ------------------------------------------------------------------ uvo_libraries mirror
     def detect_features(self, img):
-        """detect_features(img, keypoints, descriptors), SURF branch (VO_utility.cpp:114-119)."""
+        """detect_features(img, keypoints, descriptors): the SURF branch (VO_utility.cpp:114-119), or the SIFT branch (VO_utility.cpp:107-112)
+        when set_feature_detector("SIFT") was called -- the reference switches on its global FEATURE_DETECTOR."""
+        if getattr(self, "_feature_sift", False):
+            return self.sift_detect(img)
         h, w = img.shape[-2], img.shape[-1]
         p, mem, keep = _ptr_mem(img, np.uint8)
         n = C.c_int(0)

@@ -275,6 +275,8 @@ def test_feature_detector_switch_refusals(scene_small):
         c.set_feature_detector("SIFT")
         with pytest.raises(uvo.UvoError, match="max_kpts"):
             c.stereo_step(*scene_small[0], 0.05)
+        k, d = c.detect_features(scene_small[0][0])          # the mirror of detect_features follows the switch (and is not bound by max_kpts)
+        assert d.shape[1] == 128 and len(k) > 1024
         c.stereo_reset()
         c.set_feature_detector("SURF")
         c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
