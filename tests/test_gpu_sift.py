@@ -286,6 +286,17 @@ def test_feature_detector_switch_refusals(scene_small):
             c.set_feature_detector("SIFT")                                              # a sequence is running on SURF descriptors
     finally:
         c.close()
+    # lists too small for the frame (64 keypoints of room: 1024 candidates, 256 oriented keypoints): the same error, nothing written past them
+    c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=1500), 0, 640, 360, 64)
+    try:
+        c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        c.set_feature_detector("SIFT")
+        with pytest.raises(uvo.UvoError, match="max_kpts"):
+            c.stereo_step(*scene_small[0], 0.05)
+        k, d = c.detect_features(scene_small[0][0])          # the standalone operator grows its lists instead
+        assert len(k) > 1024
+    finally:
+        c.close()
 
 
 def test_fused_stereo_step_on_sift_1280x720(oracle):
