@@ -43,6 +43,7 @@ struct SiftWs {
     float* tmp = nullptr; uint8_t* d_img = nullptr;
     float* d_exptab = nullptr;
     float* d_taps = nullptr; int* d_radii = nullptr; double taps_sigma = 0; int taps_nL = 0;     // the layers' filter taps, for k_sift_tail
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // slot 1 in the synchronous step: the lane's second stream (sift_detect_lane)
     SiftCand* d_cand = nullptr; SiftSurv* d_surv = nullptr; uvo_keypoint* d_raw = nullptr; uvo_keypoint* d_kps = nullptr; float* d_desc = nullptr;
     uvo_keypoint* d_sorted = nullptr; uvo_keypoint* d_kept = nullptr; int* d_ints = nullptr;      // rank, dup, keep, greater: raw_cap each
     int* d_cnt = nullptr;         // [0] candidates, [1] raw keypoints, [2] refined extrema, [3] after duplicate removal, [4] final
@@ -86,6 +87,8 @@ void sift_ws_free(Ctx* c)
     for (int i = 0; i < 2; i++) {
         SiftWs* s = static_cast<SiftWs*>(c->sift_ws[i]);
         if (!s) continue;
+        if (s->ev_fork) (void)hipEventDestroy(s->ev_fork);
+        if (s->ev_join) (void)hipEventDestroy(s->ev_join);
         sift_ws_release(s);
         delete s;
         c->sift_ws[i] = nullptr;
@@ -874,13 +877,12 @@ static void sift_blur_tile_launch(hipStream_t st, const float* src, float* dst, 
     hipLaunchKernelGGL((k_sift_blur_tile<R, 32>), dim3((w + 63) / 64, (h + 31) / 32), dim3(256), 0, st, src, dst, dog, w, h, t);
 }
 // dst = GaussianBlur(src, sigma); dog (may be null) = dst - src
-static uvo_status sift_blur(Ctx* c, SiftWs* s, const float* src, float* dst, float* dog, int w, int h, double sigma)
+static uvo_status sift_blur(Ctx* c, SiftWs* s, hipStream_t st, const float* src, float* dst, float* dog, int w, int h, double sigma)
 {
     SiftTaps t;
     memset(&t, 0, sizeof(t));
     const int n = sift_gauss_kernel(sigma, t.k);
     t.r = n / 2;
-    hipStream_t st = c->stream;
     switch (t.r) {
 #define UVO_SIFT_BLUR_CASE(R) case R: sift_blur_tile_launch<R>(st, src, dst, dog, w, h, t); break;
         UVO_SIFT_BLUR_CASE(2) UVO_SIFT_BLUR_CASE(3) UVO_SIFT_BLUR_CASE(4) UVO_SIFT_BLUR_CASE(5) UVO_SIFT_BLUR_CASE(6) UVO_SIFT_BLUR_CASE(7) UVO_SIFT_BLUR_CASE(8)
@@ -953,9 +955,8 @@ static uvo_status sift_upload_taps(Ctx* c, SiftWs* s, double sigma)
 }
 
 // createInitialImage + buildGaussianPyramid + buildDoGPyramid of the tight device image d_img
-static uvo_status sift_pyramid(Ctx* c, SiftWs* s, const uint8_t* d_img, double sigma, SiftPyr* pp)
+static uvo_status sift_pyramid(Ctx* c, SiftWs* s, hipStream_t st, const uint8_t* d_img, double sigma, SiftPyr* pp)
 {
-    hipStream_t st = c->stream;
     const int w = s->w, h = s->h, nL = s->nL, nOct = s->nOct;
     double sig[kSiftMaxLayers + 3];
     sig[0] = sigma;
@@ -980,9 +981,9 @@ static uvo_status sift_pyramid(Ctx* c, SiftWs* s, const uint8_t* d_img, double s
         const int ow = s->ow[o], oh = s->oh[o];
         for (int i = 0; i < nL + 3; i++) {
             float* dst = s->gauss[o * (nL + 3) + i];
-            if (o == 0 && i == 0) UVO_TRY(sift_blur(c, s, base, dst, nullptr, ow, oh, (double)sig_diff));
+            if (o == 0 && i == 0) UVO_TRY(sift_blur(c, s, st, base, dst, nullptr, ow, oh, (double)sig_diff));
             else if (i == 0) hipLaunchKernelGGL(k_sift_half, dim3((ow + 255) / 256, oh), dim3(256), 0, st, static_cast<const float*>(s->gauss[(o - 1) * (nL + 3) + nL]), s->ow[o - 1], dst, ow, oh);
-            else UVO_TRY(sift_blur(c, s, s->gauss[o * (nL + 3) + i - 1], dst, s->dog[o * (nL + 2) + i - 1], ow, oh, sig[i]));     // + buildDoGPyramid's layer i - 1
+            else UVO_TRY(sift_blur(c, s, st, s->gauss[o * (nL + 3) + i - 1], dst, s->dog[o * (nL + 2) + i - 1], ow, oh, sig[i]));     // + buildDoGPyramid's layer i - 1
         }
     }
     if (o_tail < nOct)
@@ -994,10 +995,9 @@ static uvo_status sift_pyramid(Ctx* c, SiftWs* s, const uint8_t* d_img, double s
 // findScaleSpaceExtrema, KeyPointsFilter, calcDescriptors: out_kps / out_desc (device, out_cap rows; out_desc may be null) and the
 // count *out_n (device; it may exceed out_cap, nothing is written past it).  s->d_cnt[0..2] keep the list lengths for the caller's
 // overflow check (every kernel clamps to the capacities).
-static uvo_status sift_keypoints(Ctx* c, SiftWs* s, const SiftPyr& p, int nfeatures, double contrastThreshold, double edgeThreshold, double sigma,
+static uvo_status sift_keypoints(Ctx* c, SiftWs* s, hipStream_t st, const SiftPyr& p, int nfeatures, double contrastThreshold, double edgeThreshold, double sigma,
                                  uvo_keypoint* out_kps, float* out_desc, int out_cap, int* out_n)
 {
-    hipStream_t st = c->stream;
     const int nL = s->nL, nOct = s->nOct;
     const int threshold = cv_floor_d(0.5 * contrastThreshold / nL * 255);
     SiftTiles tl;
@@ -1051,10 +1051,10 @@ uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, in
         d_img = s->d_img;
     }
     SiftPyr p;
-    UVO_TRY(sift_pyramid(c, s, d_img, sigma, &p));
+    UVO_TRY(sift_pyramid(c, s, st, d_img, sigma, &p));
     int cnt[8];
     for (int attempt = 0;; attempt++) {
-        UVO_TRY(sift_keypoints(c, s, p, nfeatures, contrastThreshold, edgeThreshold, sigma, s->d_kps, desc ? s->d_desc : nullptr, s->raw_cap, s->d_cnt + 4));
+        UVO_TRY(sift_keypoints(c, s, st, p, nfeatures, contrastThreshold, edgeThreshold, sigma, s->d_kps, desc ? s->d_desc : nullptr, s->raw_cap, s->d_cnt + 4));
         UVO_HIP_TRY(c, hipMemcpyAsync(cnt, s->d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
         UVO_HIP_TRY(c, hipStreamSynchronize(st));
         if (cnt[0] <= s->cand_cap && cnt[1] <= s->raw_cap) break;
@@ -1112,11 +1112,27 @@ uvo_status sift_detect_lane(Ctx* c, int nimg, int gate_min_features)
     if (w < 16 || h < 16) { c->err = "SIFT: image too small"; return UVO_INVALID_ARG; }
     UVO_TRY(sift_prepare_lane(c, w, h, nimg));                          // (a no-op once the lane is primed)
     SiftWs* ws[2] = { static_cast<SiftWs*>(c->sift_ws[0]), static_cast<SiftWs*>(c->sift_ws[1]) };
+    // One pair in flight (the synchronous step): the right image's detector runs beside the left one's on the lane's second stream, the
+    // latency-bound stretches of one under the chip-filling ones of the other (two events: fork after the uploads, join before the
+    // counters are published).  With several pairs in flight the lanes overlap each other and a queue parked on an event wait costs
+    // the others, so everything stays on the lane's stream.
+    const Ctx* m = c->master ? c->master : c;
+    const bool fork = nimg == 2 && m->in_sync_step && c->pnp_stream != nullptr && !c->timing;
+    hipStream_t streams[2] = { c->stream, fork ? c->pnp_stream : c->stream };
+    if (fork) {
+        SiftWs* f = ws[1];
+        if (!f->ev_fork) { UVO_HIP_TRY(c, hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming)); UVO_HIP_TRY(c, hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming)); }
+        UVO_HIP_TRY(c, hipEventRecord(f->ev_fork, c->stream));
+        UVO_HIP_TRY(c, hipStreamWaitEvent(streams[1], f->ev_fork, 0));
+    }
     for (int i = 0; i < nimg; i++) {
         SiftPyr p;
-        const uint8_t* d_img = c->img[i];
-        UVO_TRY(sift_pyramid(c, ws[i], d_img, 1.6, &p));
-        UVO_TRY(sift_keypoints(c, ws[i], p, 10000, 0.03, 10, 1.6, c->det[i].kps, c->det[i].desc, c->cap, c->d_counts + CN_NL + i));   // VOU:109
+        UVO_TRY(sift_pyramid(c, ws[i], streams[i], c->img[i], 1.6, &p));
+        UVO_TRY(sift_keypoints(c, ws[i], streams[i], p, 10000, 0.03, 10, 1.6, c->det[i].kps, c->det[i].desc, c->cap, c->d_counts + CN_NL + i));   // VOU:109
+    }
+    if (fork) {
+        UVO_HIP_TRY(c, hipEventRecord(ws[1]->ev_join, streams[1]));
+        UVO_HIP_TRY(c, hipStreamWaitEvent(c->stream, ws[1]->ev_join, 0));
     }
     SiftWs* s1 = ws[nimg > 1 ? 1 : 0];
     hipLaunchKernelGGL(k_sift_publish, dim3(1), dim3(64), 0, c->stream, static_cast<const int*>(ws[0]->d_cnt), ws[0]->cand_cap, ws[0]->raw_cap,
