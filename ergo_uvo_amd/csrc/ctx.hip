@@ -391,6 +391,10 @@ extern "C" uvo_status uvo_ctx_set_feature_detector(uvo_ctx* c, const char* name)
     if (c->n_pending != 0) return fail(c, UVO_INVALID_ARG, "the feature detector cannot change while pairs are in flight");
     if ((sift ? 1 : 0) != c->feature_sift && (c->vo_initialized || c->mono_initialized))
         return fail(c, UVO_INVALID_ARG, "the feature detector changes the descriptors: the previous frame's set held by the running VO loop would not match (uvo_stereo_reset / uvo_mono_reset first)");
+    if (!sift && c->feature_sift) {                                     // back to SURF: the lanes' scale-space workspaces (0.5 GB per image slot) go
+        (void)hipSetDevice(c->device);
+        for (Ctx* l : c->lanes) { if (l->stream) (void)hipStreamSynchronize(l->stream); if (l->pnp_stream) (void)hipStreamSynchronize(l->pnp_stream); sift_ws_free(l); }
+    }
     c->feature_sift = sift ? 1 : 0;
     return UVO_OK;
 }
