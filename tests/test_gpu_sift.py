@@ -369,3 +369,42 @@ def test_fused_stereo_step_on_sift_odd_geometry(oracle, scene_small):
         assert r.n_left > 300 and r.n_stereo_matches > 100
     finally:
         c.close()
+
+
+def test_failure_paths_through_the_pipeline_on_sift(sctx, oracle, scene_small):
+    """The gate ladder (VO:556/567/626/634/665) with SIFT features: frames without features in the middle of a sequence, the state kept
+    on failure and the empty "after stereo match" sets handed on -- synchronously, with several pairs in flight, and in the oracle
+    (the SURF twin of this test is test_gpu_parity.py::test_failure_paths_through_the_pipeline)."""
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    blank = (np.full_like(scene_small[0][0], 90), np.full_like(scene_small[0][1], 90))
+    half = (scene_small[1][0], blank[1])                      # features on the left only: VO:556 fails on the right count
+    seq = [scene_small[0], scene_small[1], blank, scene_small[2], scene_small[1], half, scene_small[0], scene_small[1], scene_small[2]]
+
+    def fields(r):
+        return (r.valid, r.initialized, r.n_left, r.n_right, r.n_stereo_matches, r.n_tri_matches, r.n_good3d, r.n_inliers,
+                tuple(r.rvec), tuple(r.tvec), tuple(r.t_prev_curr), tuple(r.velocity))
+
+    ovo = oracle.StereoVO(oracle.stereo_params(1500), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    ovo.use_sift()
+    want = [fields(ovo.step(L, R, 0.05)) for L, R in seq]
+    assert [w[0] for w in want] == [0, 1, 0, 0, 1, 0, 0, 1, 1]       # init, ok, blank, no prev set, ok, half-blank, no prev set, ok, ok
+    sctx.stereo_set_depth(1)
+    sctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+    sync = [fields(sctx.stereo_step(L, R, 0.05)) for L, R in seq]
+    for g, e in zip(sync, want):
+        assert g[:8] == e[:8], (g[:8], e[:8])
+        for a, b in zip(g[8:], e[8:]):
+            a, b = np.array(a), np.array(b)
+            assert np.linalg.norm(a - b) <= 1e-4 * max(np.linalg.norm(b), 1e-12), (a, b)
+    for depth in (2, 4):
+        sctx.stereo_set_depth(depth)
+        sctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
+        piped, sub = [], 0
+        sctx.stereo_submit(*seq[0]); sub += 1
+        piped.append(fields(sctx.stereo_collect(0.05)))
+        while len(piped) < len(seq):
+            while sub < len(seq) and sub - len(piped) < depth:
+                sctx.stereo_submit(*seq[sub]); sub += 1
+            piped.append(fields(sctx.stereo_collect(0.05)))
+        assert piped == sync, depth
