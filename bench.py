@@ -104,6 +104,34 @@ def self_launch(n: int) -> int:
     return rc
 
 
+def summarise_trace(tr) -> dict:
+    """uvo_trace_read's rows (every pipelined pair of the timed blocks) -> the figures that locate a stall: device durations of a
+    pair's stage A (detect .. extract_3Dpoints) and PnP stage, the device-side gap between them, the cadence of stage-A ends, and
+    on the host the submitting thread's pacing wait and call time and the lane worker's wait for a PnP slot and stage-B time."""
+    def stats(v, idx=None):
+        v = np.asarray(v, np.float64)
+        if v.size == 0:
+            return None
+        out = {"p50": round(float(np.median(v)), 4), "max": round(float(v.max()), 4)}
+        if idx is not None:
+            out["argmax_pair"] = int(idx[int(v.argmax())])
+        return out
+    dev, host, pair = tr["dev_ms"].astype(np.float64), tr["host_ms"], tr["pair"]
+    b = tr["b_used"] != 0
+    out = {"pairs": int(len(tr)),
+           "dev_stage_a_ms": stats(dev[:, 2] - dev[:, 0], pair), "dev_detector_ms": stats(dev[:, 1] - dev[:, 0], pair),
+           "dev_pnp_stage_ms": stats(dev[b, 5] - dev[b, 3], pair[b]), "dev_a_end_to_pnp_begin_ms": stats(dev[b, 3] - dev[b, 2], pair[b]),
+           "dev_pair_latency_ms": stats(dev[b, 5] - dev[b, 0], pair[b]),
+           "dev_a_end_cadence_ms": stats(np.diff(dev[:, 2]), pair[1:]),
+           "host_pacing_wait_ms": stats(host[:, 1] - host[:, 0], pair), "host_submit_call_ms": stats(host[:, 2] - host[:, 0], pair),
+           "host_pnp_slot_wait_ms": stats(host[b, 4] - host[b, 3], pair[b]), "host_stage_b_ms": stats(host[b, 5] - host[b, 4], pair[b]),
+           "per_lane_p50_ms": {int(l): {"stage_a": round(float(np.median((dev[:, 2] - dev[:, 0])[tr["lane"] == l])), 4),
+                                        "pnp_stage": (round(float(np.median((dev[:, 5] - dev[:, 3])[(tr["lane"] == l) & b])), 4) if ((tr["lane"] == l) & b).any() else None)}
+                               for l in sorted(set(tr["lane"].tolist()))},
+           "what": "HIP events on the lanes' streams / steady clock on the host, every pair of the timed blocks (include/uvo_hip.h: uvo_trace_row)"}
+    return out
+
+
 def hbm_copy_peak_gbs(torch, seconds: float = 0.05, nbytes: int = 1 << 30) -> float:
     """Device-to-device copy rate of this GPU, read + write bytes per second ("peak from the box at run time"):
     a 1 GiB buffer copied back and forth for ~`seconds`, timed with events on the stream the copies run on."""
@@ -143,7 +171,10 @@ def main():
     ap.add_argument("--share-devices", action="store_true", help="rehearsal: ranks may share a device (LOCAL_RANK modulo the device count)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank, so that --gpus 1 "
                     "runs the N-rank path's collectives (RCCL communicator of one rank)")
-    ap.add_argument("--no-pin", action="store_true", help="do not give each rank its own slice of the host's cores")
+    ap.add_argument("--no-pin", action="store_true", help="do not pin the rank to the cores next to its GPU")
+    ap.add_argument("--blocks", type=int, default=7, help="the timed region (K steps between two fences) is run this many times in a row; "
+                    "`value` is the median block, the first / slowest / fastest are reported beside it")
+    ap.add_argument("--no-trace", action="store_true", help="do not record the per-pair pipeline trace (on by default for --steps <= 64)")
     ap.add_argument("--timed-only", action="store_true", help="diagnostics: stop after the timed region (no latency / roofline / CPU legs), "
                     "so that a UVO_TRACE file holds the timed pairs")
     ap.add_argument("--dump-records", default=None, help="rank 0 writes the gathered [world, steps, 16] pose records to this .npy")
@@ -161,7 +192,8 @@ def main():
     # lane workers inherit it (one polling submitter + <= max_b polling PnP workers per rank; the other workers sleep on events)
     host_cores_all = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    my_cores = [] if args.no_pin else multirank.pin_rank_to_cores(local_rank % max(local_world, 1), local_world)
+    pin = {"cores": [], "source": "off"} if args.no_pin else multirank.pin_rank(local_rank, local_world, share_devices=args.share_devices)
+    my_cores = pin["cores"]
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     n_dev = torch.cuda.device_count()
@@ -176,13 +208,17 @@ def main():
     dev = torch.device("cuda", local_rank) if (args.backend == "nccl" and dist_on) else None     # where the gathered records travel from
     # every rank must be a different rank on (unless rehearsing) a different device: gathered once, checked by rank 0
     props = torch.cuda.get_device_properties(local_rank)
-    dev_key = hash(str(getattr(props, "uuid", "")) + str(getattr(props, "pci_bus_id", "")) + str(getattr(props, "pci_device_id", ""))) & 0x7FFFFFFF
-    who = multirank.gather_ints([rank, local_rank, dev_key, os.getpid()], dev)
+    import zlib
+    dev_id = f"{getattr(props, 'uuid', '')}|{getattr(props, 'pci_domain_id', '')}:{getattr(props, 'pci_bus_id', '')}:{getattr(props, 'pci_device_id', '')}"
+    dev_key = zlib.crc32(dev_id.encode())                       # stable across processes (Python's hash() is salted per process)
+    pin["pci_match"] = multirank.pin_matches_device(pin, props)
+    who = multirank.gather_ints([rank, local_rank, dev_key, os.getpid(), pin.get("numa_node", -1) if pin.get("numa_node") is not None else -1, len(my_cores)], dev)
     if rank == 0:
         assert sorted(who[:, 0].tolist()) == list(range(world)), f"ranks seen: {who[:, 0].tolist()}"
         assert len(set(who[:, 3].tolist())) == world, "ranks share a process"
         if not args.share_devices:
             assert len(set(who[:, 1].tolist())) == world, f"ranks share a device: local ranks {who[:, 1].tolist()}"
+            assert len(set(who[:, 2].tolist())) == world, f"ranks share a device: device keys {who[:, 2].tolist()} (uuid / PCI address of each rank's cuda device)"
 
     # ---- synthetic workload (seeded; one independent stream per rank) ----
     seed = synth.SEEDS["C3"] if world == 1 else multirank.stream_seed(synth.SEEDS["C5"], rank)
@@ -197,7 +233,6 @@ def main():
     ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
 
     order = ping_pong(args.frames)
-    results = (uvo.StereoResult * max(args.steps, 1))()      # the timed loop's results land here in place: no per-step conversion on the host
 
     def step():
         k = next(order)
@@ -218,55 +253,109 @@ def main():
     # device-to-device copy rate of this GPU (roofline.peak_measured), before the warm-up (placing it here rather than at process
     # start was measured not to matter for a 20-step run: 3500 vs 3515 pairs/s -- the clocks are not what a short run waits for)
     hbm_measured = hbm_copy_peak_gbs(torch)
-    n_warm = max(args.warmup, 2)
-    for _ in range(2):
-        r = step()
-    sub = 0
-    for i in range(n_warm - 2):
-        while sub < n_warm - 2 and sub - i < args.depth:
-            submit(); sub += 1
-        r = ctx.stereo_collect(0.05)
+    import gc
 
     def fence():
         torch.cuda.synchronize()
         multirank.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    cpu0 = time.process_time()
-    n_before_timed = len(ks_seen)
-    t0 = time.perf_counter()
-    n_valid = 0
-    kp_sum = 0
-    # one image stream, `depth` consecutive pairs in flight on separate pipeline lanes (own buffers, HIP streams and
-    # PnP worker thread each); a pair only waits for the previous pair's "after stereo match" set.  Every pair's
-    # result is identical to the synchronous uvo_stereo_step's (tests/test_gpu_parity.py).
-    submitted = 0
-    for i in range(args.steps):
-        while submitted < args.steps and submitted - i < args.depth:
-            submit(); submitted += 1
-        ctx.stereo_collect(0.05, out=results[i])
-    records = multirank.records_from_results(results, rank)            # [steps, 16] float64, one vectorised pass
-    allrec = multirank.gather_records(torch.from_numpy(records), dev)  # pose records of all streams: one RCCL all-gather (N > 1)
-    fence()
-    dt_local = time.perf_counter() - t0
-    n_valid = sum(r.valid for r in results[:args.steps])               # statistics of the run, outside the timed region
+    def timed_block(n_steps, results, stamps):
+        """The timed region of the contract: fence, exactly n_steps pairs through the submit/collect pipeline (one image stream,
+        `depth` consecutive pairs in flight on separate lanes -- own buffers, HIP streams and PnP worker thread each; a pair only
+        waits for the previous pair's "after stereo match" set; every result is identical to the synchronous uvo_stereo_step's,
+        tests/test_gpu_parity.py), the records of all streams gathered (one RCCL all-gather when N > 1), fence.  stamps[i] = host
+        clock right after the i-th collect returned (stamps[-1] = region start).  -> (seconds on this rank, records, gathered)."""
+        fence()
+        t0 = time.perf_counter()
+        submitted = 0
+        for i in range(n_steps):
+            while submitted < n_steps and submitted - i < args.depth:
+                submit(); submitted += 1
+            ctx.stereo_collect(0.05, out=results[i])
+            stamps[i] = time.perf_counter()
+        records = multirank.records_from_results(results, rank)            # [steps, 16] float64, one vectorised pass
+        allrec = multirank.gather_records(torch.from_numpy(records), dev)  # pose records of all streams
+        fence()
+        dt_local = time.perf_counter() - t0
+        stamps[n_steps] = t0
+        return dt_local, records, allrec
+
+    # warm-up: the first pairs are consumed by the VO init phase (synchronous by definition); the remaining ones go through the very
+    # function the timed blocks run -- pipeline, record conversion, gather, fences -- so that every lane (buffers, streams, worker
+    # thread) and every host code path of the timed region has run before the clock starts.  At least 2 x depth pipelined pairs,
+    # whatever --warmup says (with --warmup 5 and six lanes, three lanes used to meet their first pair inside the timed region).
+    n_warm = max(args.warmup, 2)
+    for _ in range(2):
+        r = step()
+    n_pipe_warm = max(n_warm - 2, 2 * args.depth)
+    warm_results = (uvo.StereoResult * n_pipe_warm)()
+    warm_stamps = [0.0] * (n_pipe_warm + 1)
+    timed_block(n_pipe_warm, warm_results, warm_stamps)
+    multirank.max_over_ranks(0.0, dev)
+    del warm_results
+
+    trace_on = (not args.no_trace) and args.steps <= 64 and not args.timed_only
+    if trace_on:
+        ctx.trace_enable(True)
+    n_blocks = max(args.blocks, 1)
+    block_dt, block_local, block_cpu, block_stamps = [], [], [], []
+    all_results, all_records, all_allrec, block_first_k = [], [], [], []
+    gc.collect(); gc.freeze(); gc.disable()                                # no collector pause inside a 10 ms window
+    try:
+        for b in range(n_blocks):
+            res_b = (uvo.StereoResult * max(args.steps, 1))()              # the block's results land here in place
+            stamps = [0.0] * (args.steps + 1)
+            block_first_k.append(len(ks_seen))
+            cpu0 = time.process_time()
+            dt_local, records, allrec = timed_block(args.steps, res_b, stamps)
+            block_cpu.append((time.process_time() - cpu0) / max(dt_local, 1e-9))
+            block_local.append(dt_local)
+            block_dt.append(multirank.max_over_ranks(dt_local, dev))      # the contract's MAX over ranks, per block
+            block_stamps.append(stamps); all_results.append(res_b); all_records.append(records); all_allrec.append(allrec)
+    finally:
+        gc.enable()
+    order_b = sorted(range(n_blocks), key=lambda b: block_dt[b])
+    med = order_b[(n_blocks - 1) // 2]                                     # the median block (lower median when the count is even)
+    dt, dt_local = block_dt[med], block_local[med]
+    results, records, allrec = all_results[med], all_records[med], all_allrec[med]
+    n_before_timed = block_first_k[med]
+    busy_threads = block_cpu[med]                                          # host threads this rank kept busy on average (CPU seconds per second)
+    n_valid = sum(r.valid for rb in all_results for r in rb[:args.steps])  # statistics of the run, outside the timed regions
     kp_sum = sum(r.n_left for r in results[:args.steps])
-    busy_threads = (time.process_time() - cpu0) / max(dt_local, 1e-9)  # host threads this rank kept busy on average (CPU seconds per second)
-    dt = multirank.max_over_ranks(dt_local, dev)
     assert [int(v) for v in allrec[:, 0, 0].tolist()] == list(range(world))
-    ks_timed = ks_seen[n_before_timed - 1:n_before_timed + args.steps]   # [previous frame, then the K timed frames]
-    if dist_on and world == 1:                                         # --force-dist: the collective must hand back exactly what went in
+    ks_timed = ks_seen[n_before_timed - 1:n_before_timed + args.steps]     # [previous frame, then the K timed frames] of the median block
+    if dist_on and world == 1:                                             # --force-dist: the collective must hand back exactly what went in
         assert allrec.shape[0] == 1 and np.array_equal(allrec[0].cpu().numpy().view(np.uint64), records.view(np.uint64)), "1-rank gather changed the records"
     total_pairs = args.steps * world
     value = total_pairs / dt
+    block_values = [total_pairs / d for d in block_dt]
+    # every rank's own rate in the median block (an imbalance between the GPUs of a node shows here; `value` uses the slowest)
+    per_rank = multirank.gather_ints([int(round(args.steps / block_local[med] * 1000))], dev)[:, 0].tolist()
+    # gaps between consecutive collects of every block (host clock): a stall inside a timed window shows as one large gap
+    gaps = []
+    for b, stamps in enumerate(block_stamps):
+        prev_t = stamps[args.steps]
+        for i in range(args.steps):
+            gaps.append(((stamps[i] - prev_t) * 1e3, b, i)); prev_t = stamps[i]
+    gs = sorted(g[0] for g in gaps)
+    worst = max(gaps)
+    collect_gap_ms = {"p50": round(gs[len(gs) // 2], 4), "p99": round(gs[min(len(gs) - 1, int(len(gs) * 0.99))], 4), "max": round(worst[0], 4),
+                      "argmax": {"block": worst[1], "step": worst[2]}, "first_of_block_p50": round(sorted(g[0] for g in gaps if g[2] == 0)[n_blocks // 2], 4),
+                      "what": "host clock between consecutive uvo_stereo_collect returns over all blocks; the first gap of a block is the pipeline fill"}
+    trace_summary = None
+    if trace_on:
+        tr = ctx.trace_read()
+        ctx.trace_enable(False)
+        trace_summary = summarise_trace(tr)
 
     if rank == 0 and args.dump_records:
         np.save(args.dump_records, allrec.cpu().numpy())
 
     if args.timed_only:
         if rank == 0:
-            print(json.dumps({"value": round(value, 3), "unit": "pairs/s", "steps": args.steps, "warmup": args.warmup, "timed_only": True}), flush=True)
+            print(json.dumps({"value": round(value, 3), "unit": "pairs/s", "steps": args.steps, "warmup": args.warmup, "timed_only": True,
+                              "blocks": n_blocks, "block_values": [round(v, 1) for v in block_values], "collect_gap_ms": collect_gap_ms}), flush=True)
         if dist_on:
             multirank.barrier(); dist.destroy_process_group()
         ctx.close()
@@ -424,8 +513,16 @@ def main():
             "config": {"workload": "C3: stereo UVO synthetic 1920x1080 pair, ~3000 SURF kpts/image, EPnP PnP-RANSAC"
                                    if world == 1 else "C5: one independent 1920x1080 stereo stream per GPU",
                        "min_hessian": min_hessian, "kpts_per_image": round(kp_sum / max(args.steps, 1), 1),
-                       "valid_steps": n_valid, "frames": args.frames, "parallelism": f"streams{world}", "pipeline": f"submit/collect, {args.depth} pairs in flight per image stream"},
+                       "valid_steps": n_valid, "valid_steps_of": args.steps * n_blocks, "frames": args.frames, "parallelism": f"streams{world}", "pipeline": f"submit/collect, {args.depth} pairs in flight per image stream"},
             "value_device_resident": round(value, 3),
+            # the timed region (fence, K steps, gather, fence) run `blocks` times in a row in this process: `value` / `ms_per_step` are
+            # the MEDIAN block's, every block's rate is listed in run order
+            "blocks": n_blocks, "value_is": "median block", "value_first_block": round(block_values[0], 3),
+            "value_min": round(min(block_values), 3), "value_max": round(max(block_values), 3), "block_values": [round(v, 1) for v in block_values],
+            "warmup_pipelined_pairs": n_pipe_warm,
+            "collect_gap_ms": collect_gap_ms, "pipeline_trace": trace_summary,
+            "per_rank_value": [v / 1000.0 for v in per_rank], "ranks_seen": sorted(who[:, 0].tolist()),
+            "rccl_ranks_seen": (len(set(who[:, 0].tolist())) if (dist_on and args.backend == "nccl") else 0),
             "value_h2d_inclusive": None if h2d_value is None else round(h2d_value, 3),
             "roofline": {"bound": "hbm", "kernel": "k_hessian_nms_all (the four octaves, 3 middle layers each, 2 images per launch)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -448,7 +545,9 @@ def main():
             "algorithmic_bytes_per_pair": int(algorithmic_bytes_pair(WIDTH, HEIGHT, 3000, b_desc)),
             "stage_ms": stage_ms, "stage_launches_per_step": stage_calls,
             "cpu_baseline": cpu,
-            "host": {"cores_visible": host_cores_all, "cores_of_this_rank": len(my_cores), "pinned": bool(my_cores) and world > 1,
+            "host": {"cores_visible": host_cores_all, "cores_of_this_rank": len(my_cores), "pinned": len(my_cores) < host_cores_all and bool(my_cores),
+                     "pin_source": pin.get("source"), "numa_node": pin.get("numa_node"), "gpu_pci": pin.get("pci"), "pin_matches_opened_device": pin.get("pci_match"),
+                     "numa_nodes_of_ranks": who[:, 4].tolist(), "cores_of_ranks": who[:, 5].tolist(), "gc": "frozen and disabled during the timed blocks",
                      "threads_per_rank": f"1 submitter (polls) + {args.depth} lane workers (sleep on stage A's event; <= 3 at a time poll inside the PnP stage)",
                      "busy_host_threads_rank0": round(busy_threads, 2),
                      "collectives": ("none (single process)" if not dist_on else f"{args.backend}: all_gather_into_tensor of the pose records, all_reduce(MAX) of the time, barriers; {world} rank(s)")},

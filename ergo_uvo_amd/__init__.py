@@ -102,6 +102,9 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+TRACE_DTYPE = np.dtype([("pair", "i8"), ("lane", "i4"), ("b_used", "i4"), ("dev_ms", "f4", 6), ("host_ms", "f8", 6)], align=True)   # uvo_trace_row
+
+
 class Context:
     """One uvo_ctx: one GPU, one HIP stream, all device workspaces."""
 
@@ -184,6 +187,10 @@ class Context:
         when set_feature_detector("SIFT") was called -- the reference switches on its global FEATURE_DETECTOR."""
         if getattr(self, "_feature_sift", False):
             return self.sift_detect(img)
+        return self.surf_detect(img)
+
+    def surf_detect(self, img):
+        """uvo_surf_detect: the SURF operator itself (64- or, with SURF_EXTENDED, 128-float rows), whatever set_feature_detector says."""
         h, w = img.shape[-2], img.shape[-1]
         p, mem, keep = _ptr_mem(img, np.uint8)
         n = C.c_int(0)
@@ -276,7 +283,8 @@ class Context:
         dim = dim or (128 if self.params.SURF_EXTENDED else 64)
         for d in descs:
             if d.ndim != 2 or int(d.shape[1]) != dim:
-                raise ValueError("descriptor rows must have %d elements (SURF_EXTENDED = %d in this context's parameters)" % (dim, int(self.params.SURF_EXTENDED)))
+                raise ValueError("descriptor rows must have %d elements: without `dim` the standalone matchers take this context's SURF rows "
+                                 "(SURF_EXTENDED = %d), whatever detector the fused steps use; pass dim=128 for SIFT rows" % (dim, int(self.params.SURF_EXTENDED)))
 
     def knn_match(self, descriptors1, descriptors2, dim=None):
         self._check_desc_width(descriptors1, descriptors2, dim=dim)
@@ -560,6 +568,19 @@ class Context:
             self._lib.uvo_timing_get(self._h, i, C.byref(ms), C.byref(n))
             out[self._lib.uvo_timing_name(self._h, i).decode()] = (ms.value, n.value)
         return out
+
+    # ------------------------------------------------------------------ pipeline trace
+    def trace_enable(self, on: bool = True):
+        """Record device and host timestamps of every pipelined pair's phases (uvo_trace_enable; clears the ring)."""
+        self._check(self._lib.uvo_trace_enable(self._h, int(on)))
+
+    def trace_read(self):
+        """-> structured array (TRACE_DTYPE) of the traced pairs, oldest first (uvo_trace_read; nothing may be in flight)."""
+        buf = np.zeros(256 * 16, TRACE_DTYPE)
+        n = self._lib.uvo_trace_read(self._h, _p(buf), len(buf))
+        if n < 0:
+            raise UvoError(1, "uvo_trace_read: pairs in flight")
+        return buf[:min(n, len(buf))].copy()
 
 
 def resize_camera_matrix(original_width: int, original_height: int, desired_width: int, K, dist4):

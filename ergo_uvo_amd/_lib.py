@@ -21,7 +21,7 @@ EXPORTS = [
     "uvo_stereo_set_depth", "uvo_stereo_submit", "uvo_stereo_collect",
     "uvo_stereo_get", "uvo_find_essential_mat", "uvo_recover_pose", "uvo_find_homography", "uvo_decompose_homography_mat",
     "uvo_recover_pose_homography", "uvo_select_estimation_method", "uvo_estimate_relative_pose", "uvo_mono_set_camera",
-    "uvo_mono_reset", "uvo_mono_step", "uvo_mono_submit", "uvo_mono_collect", "uvo_mono_get", "uvo_get_image", "uvo_decode_image", "uvo_bayer_bggr2bgr", "uvo_resize_camera_matrix", "uvo_timing_enable", "uvo_timing_count", "uvo_timing_name", "uvo_timing_get", "uvo_timing_reset",
+    "uvo_mono_reset", "uvo_mono_step", "uvo_mono_submit", "uvo_mono_collect", "uvo_mono_get", "uvo_get_image", "uvo_decode_image", "uvo_bayer_bggr2bgr", "uvo_resize_camera_matrix", "uvo_timing_enable", "uvo_timing_count", "uvo_timing_name", "uvo_timing_get", "uvo_timing_reset", "uvo_trace_enable", "uvo_trace_read",
 ]
 
 
@@ -66,6 +66,9 @@ def lib() -> C.CDLL:
         _lib.uvo_ctx_destroy.restype = None
         _lib.uvo_timing_name.restype = C.c_char_p
         _lib.uvo_timing_name.argtypes = [C.c_void_p, C.c_int]
+        _lib.uvo_trace_read.restype = C.c_int
+        _lib.uvo_trace_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _lib.uvo_trace_enable.argtypes = [C.c_void_p, C.c_int]
         for name in EXPORTS:
             getattr(_lib, name)  # fail loudly if the ABI and the header drift apart
     return _lib

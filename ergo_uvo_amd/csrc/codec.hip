@@ -404,8 +404,9 @@ __global__ __launch_bounds__(256) void k_png_expand(PngArgs a, const uint8_t* __
         uint8_t* d = out + ((size_t)y * a.w + x) * 4;
         d[0] = src[4 * x + 2]; d[1] = src[4 * x + 1]; d[2] = src[4 * x]; d[3] = src[4 * x + 3];
     } else {
-        int v = src[x];
+        int v;                                                // (a packed row is ~w * depth / 8 bytes: src[x] would read past the last one)
         if (a.depth < 8) { const int per = 8 / a.depth, sh = (per - 1 - x % per) * a.depth; v = (src[x / per] >> sh) & ((1 << a.depth) - 1); }
+        else v = src[x];
         if (a.ctype == 0) out[(size_t)y * a.w + x] = (uint8_t)(a.depth < 8 ? v * 255 / ((1 << a.depth) - 1) : v);
         else { uint8_t* d = out + ((size_t)y * a.w + x) * 3; d[0] = a.pal[v][0]; d[1] = a.pal[v][1]; d[2] = a.pal[v][2]; }
     }

@@ -65,6 +65,16 @@ static uvo_status prime_lanes(uvo_ctx* c, int w, int h);
 extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* out);
 static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok);
 static void destroy_one(uvo_ctx* c);
+// the ring of timing events behind UVO_TRACE / uvo_trace_enable (a lane's, created once)
+static hipError_t trace_alloc(Ctx* c)
+{
+    if (c->trace.empty()) {
+        c->trace.resize(Ctx::kTraceRing);
+        for (auto& r : c->trace) for (int k = 0; k < 6; k++) { hipError_t e = hipEventCreate(&r.ev[k]); if (e != hipSuccess) return e; }
+    }
+    c->trace_on = true;
+    return hipSuccess;
+}
 
 // one set of buffers, streams and a stage-B worker thread: the caller's context, or a further pipeline lane of it
 // parameters the implementation cannot honour are refused, never silently replaced (the reference passes them to OpenCV)
@@ -167,11 +177,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     if (hipMemcpy(c->d_DW, c->h_DW, sizeof(float) * 400, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(c->d_rank, 0, sizeof(int) * cap * 2) != hipSuccess ||
         hipMemset(c->d_counts, 0, sizeof(int) * CN_TOTAL) != hipSuccess) { destroy_one(c); return UVO_HIP_ERROR; }
-    if (getenv("UVO_TRACE")) {
-        c->trace.resize(Ctx::kTraceRing);
-        for (auto& r : c->trace) for (int k = 0; k < 6; k++) if (hipEventCreate(&r.ev[k]) != hipSuccess) { destroy_one(c); return UVO_HIP_ERROR; }
-        c->trace_on = true;
-    }
+    if (getenv("UVO_TRACE") && trace_alloc(c) != hipSuccess) { destroy_one(c); return UVO_HIP_ERROR; }
     c->worker = std::thread(lane_worker, c);
     *out = c;
     return UVO_OK;
@@ -212,6 +218,7 @@ static uvo_status set_depth(uvo_ctx* c, int depth)
         uvo_status st = create_one(&c->p, c->device, c->max_w, c->max_h, c->cap, &l);
         if (st != UVO_OK) { c->err = "could not allocate a further pipeline lane"; return st; }
         l->master = c; l->lane_id = (int)c->lanes.size(); l->timing = c->timing;
+        if (c->trace_on && !l->trace_on && trace_alloc(l) != hipSuccess) { destroy_one(l); c->err = "could not allocate a further pipeline lane"; return UVO_HIP_ERROR; }
         c->lanes.push_back(l);
     }
     // the previous pair's "after stereo match" set may live in a lane that no longer exists: restart the sequence
@@ -468,9 +475,15 @@ static uvo_status stage_desc(uvo_ctx* c, int slot, const float* d, int n, int me
     return UVO_OK;
 }
 
+// Row width of the standalone matchers for the duration of one call.  The entries without a `dim` argument match THIS CONTEXT'S SURF
+// rows -- SURF::descriptorSize() = 64, or 128 with SURF_EXTENDED -- whatever detector the fused steps are switched to
+// (uvo_ctx_set_feature_detector): their callers hand over n x 64 buffers, and the width of the loops' detector is not theirs.
+namespace { struct DimScope { uvo_ctx* c; int prev; DimScope(uvo_ctx* c_, int d) : c(c_), prev(c_->match_dim) { if (!prev) c->match_dim = d; } ~DimScope() { c->match_dim = prev; } };
+            int surf_dim(const uvo_ctx* c) { return c->p.SURF_EXTENDED ? 128 : 64; } }
 extern "C" uvo_status uvo_match_knn2(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int mem, int* idx, float* dist)
 {
     if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !idx || !dist) return UVO_INVALID_ARG;
+    DimScope surf_rows(c, surf_dim(c));
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_match_knn2"));
     if (n1 == 0) return UVO_OK;
@@ -490,6 +503,7 @@ extern "C" uvo_status uvo_match_knn2_ratio(uvo_ctx* c, const float* d1, int n1, 
                                            float ratio, uvo_dmatch* out, int cap, int* m)
 {
     if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !out || !m || *m < 0) return UVO_INVALID_ARG;
+    DimScope surf_rows(c, surf_dim(c));
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_match_knn2_ratio"));
     if (n1 == 0 || n2 == 0) return UVO_OK;          // knnMatch on an empty query/train set yields no matches
@@ -510,7 +524,6 @@ extern "C" uvo_status uvo_match_knn2_ratio(uvo_ctx* c, const float* d1, int n1, 
 
 // match_features' L2 arm for descriptors that are not this context's SURF rows (VO_utility.cpp:525-529 sends "SIFT" -- 128 floats
 // per row whatever SURF_EXTENDED says -- to the same BFMatcher(NORM_L2)): the row width is given per call.
-namespace { struct DimScope { uvo_ctx* c; DimScope(uvo_ctx* c_, int d) : c(c_) { c->match_dim = d; } ~DimScope() { c->match_dim = 0; } }; }
 extern "C" uvo_status uvo_match_knn2_dim(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int dim, int mem, int* idx, float* dist)
 {
     if (!c) return UVO_INVALID_ARG;
@@ -895,6 +908,8 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     if (L->trace_on) {
         L->trace_cur = (int)(L->trace_count++ % Ctx::kTraceRing);
         tr = &L->trace[L->trace_cur]; tr->pair = c->n_submitted; tr->b_used = false;
+        for (double& v : tr->host_us) v = 0;
+        tr->host_us[0] = uvo::now_us();
         UVO_HIP_TRY(c, hipEventRecord(tr->ev[0], L->stream));
     }
     UVO_TRY(wait_for_producer(c, L, mem));
@@ -919,6 +934,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
         if (c->n_pending >= c->a_overlap) (void)hipEventSynchronize(H->evA[1]);
     }
     seg(9);                                                                                // the a_overlap wait
+    if (tr) tr->host_us[1] = uvo::now_us();
     { Range r("uvo:detect_features x2"); LANE_TRY(detect_dispatch(L, 2, p.MIN_NUM_FEATURES)); }    // VO:548-549, and the VO:556 gate
     seg(10);                                                                               // detector launches
     if (tr) UVO_HIP_TRY(c, hipEventRecord(tr->ev[1], L->stream));
@@ -972,6 +988,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     c->next_lane = (li + 1) % depth;
     c->inflight[c->n_pending++] = li; c->n_submitted++;
     L->inline_b = c->in_sync_step;
+    if (tr) tr->host_us[2] = uvo::now_us();
     if (L->inline_b) {
         // the synchronous step waits for its own pair: the calling thread polls the stream's end itself and finishes stage B inline
         // (no worker wake-up, no condition variable: two thread hand-overs less on the pair's critical path)
@@ -1025,6 +1042,8 @@ static void lane_worker(uvo_ctx* L)
         const double t0 = g_bdbg ? now_us() : 0;
         const bool stage_a_ok = hipEventSynchronize(L->evA[0]) == hipSuccess;
         if (g_bdbg) g_bstat[0] += now_us() - t0;
+        Ctx::TraceRec* wtr = (L->trace_on && L->trace_cur >= 0 && L->job.kind == 0) ? &L->trace[L->trace_cur] : nullptr;
+        if (wtr) wtr->host_us[3] = now_us();
         {   // at most max_b PnP stages at a time over all lanes: their thin, latency-bound kernels slow down and are slowed by stage A's
             Ctx* m = L->master ? L->master : L;
             std::unique_lock<std::mutex> g(m->b_mu);
@@ -1034,9 +1053,11 @@ static void lane_worker(uvo_ctx* L)
             if (g_bdbg) g_bstat[5] += now_us() - tw;
             m->b_running++;
             g.unlock();
+            if (wtr) wtr->host_us[4] = now_us();
             if (L->job.kind == 1) { const double tb = g_bdbg ? now_us() : 0; run_mono_stage_b(L, stage_a_ok); if (g_bdbg) { g_bstat[1] += now_us() - tb; g_bstat[4] += 1; } }
             else if (L->job.kind == 2) { hipLaunchKernelGGL(k_prime, dim3(1), dim3(64), 0, L->pnp_stream, L->d_countsB, 1); (void)host_sync(L, L->pnp_stream); }   // prime_lanes
             else run_stage_b(L, stage_a_ok);
+            if (wtr) wtr->host_us[5] = now_us();
             g.lock();
             m->b_running--;
             m->b_cv.notify_one();
@@ -1710,6 +1731,46 @@ extern "C" int uvo_mono_get(uvo_ctx* c, const char* what, void* out, int cap_byt
     if (nb > (size_t)cap_bytes) return -count;
     if (nb) memcpy(out, src, nb);
     return count;
+}
+
+// ------------------------------------------------------------------------------------------ pipeline trace
+// The UVO_TRACE machinery through the ABI: device timestamps (hipEvents on the lane's streams) and host timestamps (steady clock) of
+// every pipelined pair's phases, kept in a ring of 256 pairs per lane.
+extern "C" uvo_status uvo_trace_enable(uvo_ctx* c, int on)
+{
+    if (!c) return UVO_INVALID_ARG;
+    if (c->n_pending != 0) { c->err = "the pipeline trace cannot change while pairs are in flight"; return UVO_INVALID_ARG; }
+    (void)hipSetDevice(c->device);
+    for (Ctx* l : c->lanes) {
+        if (on) { UVO_HIP_TRY(c, trace_alloc(l)); for (auto& r : l->trace) r.pair = -1; l->trace_count = 0; l->trace_cur = -1; }
+        else l->trace_on = false;
+    }
+    return UVO_OK;
+}
+extern "C" int uvo_trace_read(uvo_ctx* c, uvo_trace_row* rows, int cap)
+{
+    if (!c || (cap > 0 && !rows) || c->n_pending != 0) return -1;
+    (void)hipSetDevice(c->device);
+    for (Ctx* l : c->lanes) { if (l->stream) (void)hipStreamSynchronize(l->stream); if (l->pnp_stream) (void)hipStreamSynchronize(l->pnp_stream); }
+    hipEvent_t ref = nullptr; long long ref_pair = -1; double ref_host = 0;
+    for (Ctx* l : c->lanes) for (auto& r : l->trace) if (r.pair >= 0 && (ref_pair < 0 || r.pair < ref_pair)) { ref = r.ev[0]; ref_pair = r.pair; ref_host = r.host_us[0]; }
+    if (!ref) return 0;
+    int n = 0;
+    for (Ctx* l : c->lanes) for (auto& r : l->trace) {
+        if (r.pair < 0) continue;
+        if (n < cap) {
+            uvo_trace_row& w = rows[n];
+            w.pair = r.pair; w.lane = l->lane_id; w.b_used = r.b_used ? 1 : 0;
+            for (int k = 0; k < 6; k++) {
+                w.dev_ms[k] = -1.f;
+                if (k < 3 || r.b_used) (void)hipEventElapsedTime(&w.dev_ms[k], ref, r.ev[k]);
+                w.host_ms[k] = r.host_us[k] > 0 ? (r.host_us[k] - ref_host) * 1e-3 : -1.0;
+            }
+        }
+        n++;
+    }
+    std::sort(rows, rows + std::min(n, cap), [](const uvo_trace_row& a, const uvo_trace_row& b) { return a.pair < b.pair; });
+    return n;
 }
 
 // ------------------------------------------------------------------------------------------ timing

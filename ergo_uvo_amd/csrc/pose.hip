@@ -742,12 +742,13 @@ static PnpSpecArgs spec_args(Ctx* c, const double* K, int iters, float reproject
 }
 uvo_status pose_pnp_spec_launch(Ctx* c, hipStream_t st, const double* K, int iters, float reprojectionError, double confidence, int min3d)
 {
+    static_cast<PnpSpecState*>(c->h_spec)->state = -1;     // "not reported yet": also when nothing is queued below, so that the accept
+                                                           // step never reads the previous pair's round
     if (iters > kMaxHyp) return UVO_OK;                    // the host path reports it
     const size_t hyp_lds = sizeof(double) * GroupPolicy<kHypGroups>::kStride * kHypPerGroup;
     static std::once_flag attr_once[64];
     std::call_once(attr_once[c->device & 63], [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_pnp_hyp_spec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)hyp_lds); });
     const PnpSpecArgs a = spec_args(c, K, iters, reprojectionError, confidence, min3d);
-    static_cast<PnpSpecState*>(c->h_spec)->state = -1;     // "not reported yet"
     Ctx::TraceRec* tr = (c->trace_on && c->trace_cur >= 0) ? &c->trace[c->trace_cur] : nullptr;
     if (tr) { tr->b_used = true; (void)hipEventRecord(tr->ev[3], st); }
     hipLaunchKernelGGL(k_pnp_hyp_spec, dim3(kSpecHyp / kHypGroups), dim3(64), hyp_lds, st, a);

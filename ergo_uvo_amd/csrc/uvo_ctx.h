@@ -215,9 +215,11 @@ struct Ctx {
     // ---- UVO_TRACE=<file>: device timestamps of every pipelined pair's phases (hipEvents with timing), written as CSV by
     // uvo_ctx_destroy: pair, lane, A begin, detection end, A end, B begin, B hypotheses scored, B end (ms since the first) ----
     static const int kTraceRing = 256;
-    struct TraceRec { long long pair = -1; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool b_used = false; };
+    struct TraceRec { long long pair = -1; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool b_used = false;
+                      double host_us[6] = {0, 0, 0, 0, 0, 0}; };     // steady clock: submit entered, pacing wait over, submit returned, worker past stage A's event,
+                                                                    // worker holds a PnP slot, stage B done
     std::vector<TraceRec> trace; int trace_cur = -1; long long trace_count = 0;
-    bool trace_on = false;
+    bool trace_on = false;                       // UVO_TRACE=<file> at creation, or uvo_trace_enable (the events are created at first use)
 
     int match_dim = 0;                           // uvo_match_knn2*_dim: row width of the standalone matcher for the duration of one call (0 = SURF's)
     bool use_sift() const { return (master ? master : this)->feature_sift != 0; }

@@ -150,10 +150,10 @@ inline bool inflate(const uint8_t* z, size_t zn, uint8_t* out, size_t cap, size_
 inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 inline uint32_t crc32(const uint8_t* p, size_t n)
 {
-    static uint32_t tab[256]; static bool init = false;
-    if (!init) { for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u))); tab[i] = c; } init = true; }
+    struct Table { uint32_t t[256]; Table() { for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u))); t[i] = c; } } };
+    static const Table tab;                         // function-local static: initialised once, thread-safe (several contexts decode at once)
     uint32_t c = 0xFFFFFFFFu;
-    for (size_t i = 0; i < n; i++) c = tab[(c ^ p[i]) & 255] ^ (c >> 8);
+    for (size_t i = 0; i < n; i++) c = tab.t[(c ^ p[i]) & 255] ^ (c >> 8);
     return c ^ 0xFFFFFFFFu;
 }
 inline bool is_png(const uint8_t* d, size_t n) { static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n' }; return n >= 8 && memcmp(d, sig, 8) == 0; }

@@ -19,22 +19,101 @@ def stream_seed(base_seed: int, rank: int) -> int:
     return base_seed + rank
 
 
-def pin_rank_to_cores(local_rank: int, local_world: int) -> list[int]:
-    """Give this rank its own slice of the host's cores (call before the first GPU call, so the HIP runtime's helper threads and
-    the pipeline's lane workers inherit it): rank r of n gets cores [r*k, (r+1)*k) of the sorted set this process may run on,
-    k = cores // n.  Returns the cores now in force (unchanged when there are fewer cores than ranks, or on platforms without
-    sched_setaffinity).  A rank runs 1 submitting thread (polls) + `depth` lane workers, of which at most max_b (3) poll at a
-    time; unpinned, the ranks' pollers migrate over each other's cores."""
+def _parse_cpulist(text: str) -> list[int]:
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def visible_gpus(sys_root: str = "/sys", dev_root: str = "/dev", env=None) -> list[dict]:
+    """The GPUs this process's HIP runtime will enumerate, in its order, WITHOUT touching the GPU: KFD topology nodes with SIMDs
+    (`/sys/class/kfd/kfd/topology/nodes/*/properties`) whose render node can be opened, filtered by ROCR_VISIBLE_DEVICES and then
+    HIP_VISIBLE_DEVICES when those are plain index lists.  Each entry: {"pci": "dddd:bb:dd.f", "numa_node": int | None,
+    "cpus": [...]} from the PCI device's `numa_node` / `local_cpulist`.  Empty when the topology cannot be read (no amdgpu)."""
+    env = os.environ if env is None else env
+    base = os.path.join(sys_root, "class/kfd/kfd/topology/nodes")
     try:
-        cores = sorted(os.sched_getaffinity(0))
-    except AttributeError:
+        nodes = sorted((int(n) for n in os.listdir(base) if n.isdigit()))
+    except OSError:
         return []
-    k = len(cores) // max(local_world, 1)
+    gpus = []
+    for n in nodes:
+        try:
+            props = dict(line.split()[:2] for line in open(os.path.join(base, str(n), "properties")) if len(line.split()) >= 2)
+        except OSError:
+            continue                                     # a node of another container's GPU: not readable, not ours
+        if int(props.get("simd_count", "0")) == 0:
+            continue                                     # a CPU node
+        minor = int(props.get("drm_render_minor", "-1"))
+        if minor >= 0 and not os.access(os.path.join(dev_root, "dri", f"renderD{minor}"), os.R_OK | os.W_OK):
+            continue                                     # not handed to this container: ROCr skips it too
+        loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+        pci = f"{dom:04x}:{(loc >> 8) & 0xFF:02x}:{(loc >> 3) & 0x1F:02x}.{loc & 7:x}"
+        g = {"pci": pci, "numa_node": None, "cpus": [], "kfd_node": n}
+        try:
+            g["numa_node"] = int(open(os.path.join(sys_root, "bus/pci/devices", pci, "numa_node")).read())
+            g["cpus"] = _parse_cpulist(open(os.path.join(sys_root, "bus/pci/devices", pci, "local_cpulist")).read())
+        except (OSError, ValueError):
+            pass
+        gpus.append(g)
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if v is None or v == "":
+            continue
+        try:
+            idx = [int(x) for x in v.split(",") if x.strip() != ""]
+        except ValueError:
+            return []                                    # UUID forms: do not guess
+        gpus = [gpus[i] for i in idx if 0 <= i < len(gpus)]
+    return gpus
+
+
+def pin_rank(local_rank: int, local_world: int, share_devices: bool = False, gpus: list[dict] | None = None) -> dict:
+    """Pin this rank -- before its first GPU call, so that the HIP runtime's helper threads and the pipeline's lane workers inherit
+    it -- to the host cores NEXT TO ITS GPU: the `local_cpulist` of the device LOCAL_RANK will open (the NUMA node the card hangs
+    off, `/sys/bus/pci/devices/<addr>/numa_node`); ranks whose GPUs share a node split that node's cores evenly, in rank order.
+    Falls back to an index slice of the allowed cores (rank r of n: cores [r*k, (r+1)*k)) when the topology cannot be read.
+    Returns {"cores", "source", "numa_node", "pci"}.  A rank runs 1 submitting thread (polls) + `depth` lane workers of which at
+    most max_b (3) poll at a time."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return {"cores": [], "source": "unsupported", "numa_node": None, "pci": None}
+    out = {"cores": allowed, "source": "unpinned", "numa_node": None, "pci": None}
+    local_world = max(local_world, 1)
+    gpus = visible_gpus() if gpus is None else gpus
+    if gpus and (share_devices or local_rank < len(gpus)):
+        mine = gpus[local_rank % len(gpus)]
+        near = [c for c in mine["cpus"] if c in set(allowed)]
+        # the ranks that will sit on the same NUMA node (their devices are LOCAL_RANK modulo the device count), in rank order
+        same = [r for r in range(local_world) if (share_devices or r < len(gpus)) and gpus[r % len(gpus)]["numa_node"] == mine["numa_node"]]
+        k = len(near) // max(len(same), 1)
+        if near and k >= 1 and local_rank in same:
+            j = same.index(local_rank)
+            cores = near[j * k:(j + 1) * k]
+            os.sched_setaffinity(0, set(cores))
+            return {"cores": cores, "source": "numa node of the GPU (kfd topology + pci local_cpulist)", "numa_node": mine["numa_node"], "pci": mine["pci"]}
+    k = len(allowed) // local_world
     if local_world > 1 and k >= 1:
-        mine = cores[local_rank * k:(local_rank + 1) * k]
-        os.sched_setaffinity(0, set(mine))
-        return mine
-    return cores
+        cores = allowed[(local_rank % local_world) * k:(local_rank % local_world + 1) * k]
+        os.sched_setaffinity(0, set(cores))
+        out.update(cores=cores, source="index slice of the allowed cores (GPU topology not readable)")
+    return out
+
+
+def pin_matches_device(pin: dict, props) -> bool | None:
+    """After the GPU is initialised: is the device this rank opened the one pin_rank assumed (PCI address)?  None = nothing to compare."""
+    if not pin.get("pci"):
+        return None
+    try:
+        got = f"{int(getattr(props, 'pci_domain_id')):04x}:{int(getattr(props, 'pci_bus_id')):02x}:{int(getattr(props, 'pci_device_id')):02x}"
+    except (AttributeError, TypeError, ValueError):
+        return None
+    return pin["pci"].startswith(got)
 
 
 def init(backend: str, device_index: int | None = None, force: bool = False) -> tuple[int, int]:

@@ -290,6 +290,18 @@ const char* uvo_timing_name(uvo_ctx* c, int i);
 uvo_status uvo_timing_get(uvo_ctx* c, int i, double* ms, long long* launches);
 uvo_status uvo_timing_reset(uvo_ctx* c);
 
+
+/* ---- pipeline trace (diagnostics; bench.py reports it for short runs): per pipelined pair, when its phases ran.
+ * dev_ms: HIP-event times on the lane's streams -- stage A begins (the pair's first kernel may start), detector done, stage A done
+ * (VO:548-632), PnP stage begins, hypotheses scored, PnP stage done (VO:647-648) -- in ms after the first traced pair's stage-A
+ * begin; the last three are -1 when the pair's gates skipped solvePnPRansac.  host_ms: the submitting thread entered
+ * uvo_stereo_submit, its pacing wait ended, it returned; the lane's worker saw stage A's end, got a PnP slot, finished -- steady
+ * clock, ms after the first traced pair's submit (-1: not reached).  The ring keeps the last 256 pairs per lane. */
+typedef struct uvo_trace_row { long long pair; int lane; int b_used; float dev_ms[6]; double host_ms[6]; } uvo_trace_row;
+uvo_status uvo_trace_enable(uvo_ctx* c, int on);           /* not while pairs are in flight; enabling clears the ring */
+int        uvo_trace_read(uvo_ctx* c, uvo_trace_row* rows, int cap);   /* waits for the device; rows sorted by pair; returns the
+                                                                         number of traced pairs (may exceed cap), -1 on misuse */
+
 #ifdef __cplusplus
 }
 #endif

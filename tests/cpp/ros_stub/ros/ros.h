@@ -6,6 +6,7 @@
 #include <string>
 #include "XmlRpcValue.h"
 #define ROS_ERROR(...) std::fprintf(stderr, __VA_ARGS__)
+#define ROS_WARN(...) std::fprintf(stderr, __VA_ARGS__)
 namespace ros {
 void init(int& argc, char** argv, const std::string& name);
 bool ok();

@@ -299,6 +299,34 @@ def test_feature_detector_switch_refusals(scene_small):
         c.close()
 
 
+def test_standalone_surf_operators_keep_their_row_width_when_the_loops_run_on_sift(scene_small):
+    """with FEATURE_DETECTOR = "SIFT" the fused steps use 128-float rows, but uvo_surf_detect / uvo_match_knn2 /
+    uvo_match_knn2_ratio (no `dim`) are this context's SURF operators: n x 64 buffers in, the same answers as before the switch."""
+    import ergo_uvo_amd as uvo
+    c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=1500), 0, 640, 360, 4096)
+    try:
+        L, R = scene_small[0]
+        k1, d1 = c.surf_detect(L)
+        k2, d2 = c.surf_detect(R)
+        assert d1.shape[1] == 64 and len(k1) > 100
+        idx0, dist0 = c.knn_match(d1, d2)
+        m0 = c.match_features(d1, d2)
+        c.set_feature_detector("SIFT")
+        k1s, d1s = c.surf_detect(L)
+        assert np.array_equal(k1s, k1) and np.array_equal(d1s, d1)
+        idx1, dist1 = c.knn_match(d1, d2)                       # would have staged 128 * n floats out of n x 64 buffers
+        assert np.array_equal(idx1, idx0) and np.array_equal(dist1, dist0)
+        assert np.array_equal(c.match_features(d1, d2), m0)
+        ks, ds = c.detect_features(L)                            # the reference's detect_features follows the switch
+        assert ds.shape[1] == 128
+        with pytest.raises(ValueError, match="dim=128"):
+            c.knn_match(ds, ds)
+        i128, _ = c.knn_match(ds[:500], ds[:500], dim=128)
+        assert np.array_equal(i128[:, 0], np.arange(500)) or (i128[:, 0] != np.arange(500)).sum() < 5      # a row's nearest row is itself (or an exact duplicate)
+    finally:
+        c.close()
+
+
 def test_fused_stereo_step_on_sift_1280x720(oracle):
     """A larger geometry through the same path (several thousand keypoints per image, every octave kind of the pyramid in use)."""
     import ergo_uvo_amd as uvo

@@ -44,7 +44,7 @@ def _worker_body(rank, world, rdzv, q):
         os.environ.pop(k, None)
     sys.path.insert(0, ROOT)
     from ergo_uvo_amd import multirank
-    cores = multirank.pin_rank_to_cores(rank, world)
+    cores = multirank.pin_rank(rank, world, gpus=[])["cores"]        # no GPU topology on the CPU test host: index slices
     r, w = multirank.init("gloo", force=True)
     assert (r, w) == (rank, world)
     recs = _run_stream(rank)
@@ -88,3 +88,71 @@ def test_gloo_ranks_gather_matches_single_process(world, tmp_path):
     if world > 1:
         assert want[1, 1, 2] == 1
         assert not np.array_equal(want[0, 1, 7:10], want[1, 1, 7:10])             # and they are different streams
+
+
+def _fake_topology(root, gpus_per_node=4, nodes=2, cores_per_node=16, hidden=()):
+    """A sysfs / dev tree shaped like an 8-GPU host: KFD nodes 0..nodes-1 are CPUs, the rest GPUs (render minors 128..),
+    each GPU's PCI device carrying numa_node / local_cpulist.  `hidden`: GPU ordinals whose render node is absent (another
+    container's cards)."""
+    base = root / "sys/class/kfd/kfd/topology/nodes"
+    for n in range(nodes):
+        (base / str(n)).mkdir(parents=True)
+        (base / str(n) / "properties").write_text("cpu_cores_count %d\nsimd_count 0\n" % cores_per_node)
+    (root / "dev/dri").mkdir(parents=True)
+    g = 0
+    for n in range(nodes):
+        for _ in range(gpus_per_node):
+            bus = 0x05 + 0x10 * g
+            d = base / str(nodes + g)
+            d.mkdir(parents=True)
+            d.joinpath("properties").write_text("cpu_cores_count 0\nsimd_count 1024\ndomain 0\nlocation_id %d\ndrm_render_minor %d\n" % (bus << 8, 128 + g))
+            pci = root / "sys/bus/pci/devices" / ("0000:%02x:00.0" % bus)
+            pci.mkdir(parents=True)
+            pci.joinpath("numa_node").write_text("%d\n" % n)
+            pci.joinpath("local_cpulist").write_text("%d-%d\n" % (n * cores_per_node, (n + 1) * cores_per_node - 1))
+            if g not in hidden:
+                (root / "dev/dri" / ("renderD%d" % (128 + g))).write_text("")
+            g += 1
+
+
+def test_ranks_are_pinned_to_the_numa_node_of_their_gpu(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    from ergo_uvo_amd import multirank
+    _fake_topology(tmp_path)
+    gpus = multirank.visible_gpus(str(tmp_path / "sys"), str(tmp_path / "dev"), env={})
+    assert [g["pci"] for g in gpus] == ["0000:%02x:00.0" % (0x05 + 0x10 * i) for i in range(8)]
+    assert [g["numa_node"] for g in gpus] == [0, 0, 0, 0, 1, 1, 1, 1]
+    # HIP_VISIBLE_DEVICES reorders / filters; a container that was handed one card sees only that one
+    assert [g["numa_node"] for g in multirank.visible_gpus(str(tmp_path / "sys"), str(tmp_path / "dev"), env={"HIP_VISIBLE_DEVICES": "5,1"})] == [1, 0]
+    assert multirank.visible_gpus(str(tmp_path / "sys"), str(tmp_path / "dev"), env={"ROCR_VISIBLE_DEVICES": "GPU-abc"}) == []
+    one = tmp_path / "one"
+    _fake_topology(one, hidden=(0, 1, 2, 3, 4, 6, 7))
+    g1 = multirank.visible_gpus(str(one / "sys"), str(one / "dev"), env={})
+    assert len(g1) == 1 and g1[0]["numa_node"] == 1 and g1[0]["cpus"] == list(range(16, 32))
+
+    # pin_rank on the fake 2 x 16-core host: no real affinity call (the test machine has other cores)
+    calls = []
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(32)))
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: calls.append(sorted(cores)))
+    pins = [multirank.pin_rank(r, 8, gpus=gpus) for r in range(8)]
+    assert [p["numa_node"] for p in pins] == [0, 0, 0, 0, 1, 1, 1, 1]
+    assert [p["cores"] for p in pins] == [list(range(4 * r, 4 * r + 4)) for r in range(8)] == calls       # 4 ranks split each node's 16 cores
+    # one rank on a one-card box: the whole node next to the card, not the whole machine
+    calls.clear()
+    p = multirank.pin_rank(0, 1, gpus=g1)
+    assert p["cores"] == list(range(16, 32)) and calls == [list(range(16, 32))] and p["pci"] == "0000:55:00.0"
+    # five rehearsal ranks sharing the one card split its node
+    calls.clear()
+    pins = [multirank.pin_rank(r, 5, share_devices=True, gpus=g1) for r in range(5)]
+    assert [len(p["cores"]) for p in pins] == [3] * 5 and len({c for p in pins for c in p["cores"]}) == 15
+    # topology unreadable: index slices as before, and a single rank stays unpinned
+    calls.clear()
+    pins = [multirank.pin_rank(r, 4, gpus=[]) for r in range(4)]
+    assert [p["cores"] for p in pins] == [list(range(8 * r, 8 * r + 8)) for r in range(4)]
+    assert multirank.pin_rank(0, 1, gpus=[])["source"] == "unpinned"
+
+    class Props: pci_domain_id, pci_bus_id, pci_device_id = 0, 0x55, 0
+    assert multirank.pin_matches_device(p, Props) is True
+    Props.pci_bus_id = 0x15
+    assert multirank.pin_matches_device(p, Props) is False
+    assert multirank.pin_matches_device({"pci": None}, Props) is None

@@ -364,15 +364,35 @@ def test_parameter_tree_survives_damaged_yaml_under_sanitizers(tmp_path):
 
 
 def test_ros_adapter_meets_a_compiler():
-    """ergo_uvo_amd/ros/UVO_node_hip.cpp is built only where ROS is, which is nowhere in this pipeline.  tests/cpp/ros_stub/ declares the
-    handful of roscpp / message / message_filters names it uses (NOT ROS: see its README), so that the file is at least parsed and
-    type-checked against this repository's own headers; a real catkin build remains untested."""
-    src = os.path.join(ROOT, "ergo_uvo_amd", "ros", "UVO_node_hip.cpp")
-    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-DUVO_NO_OPENCV", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
-           "-I", os.path.join(ROOT, "tests", "cpp", "ros_stub"), src]
+    """ergo_uvo_amd/ros/ (visual_odometry.h: `class visual_odometry_node`, and the bootstrap UVO_node_hip.cpp) is built only where ROS
+    is, which is nowhere in this pipeline.  tests/cpp/ros_stub/ declares the handful of roscpp / message / message_filters names it
+    uses (NOT ROS: see its README), so that the files are at least parsed and type-checked against this repository's own headers; a
+    real catkin build remains untested."""
+    ros_dir = os.path.join(ROOT, "ergo_uvo_amd", "ros")
+    src = os.path.join(ros_dir, "UVO_node_hip.cpp")
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-DUVO_NO_OPENCV", "-Wall", "-Wextra", "-Wno-unused-variable", "-Wno-unused-but-set-variable",
+           "-I", ros_dir, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp", "ros_stub"), src]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
     assert res.returncode == 0, res.stderr
-    # the check bites: the same command on a copy with one of this repository's own member names misspelt fails
-    bad = open(src).read().replace("core->range_callback(", "core->range_calback(")
-    res = subprocess.run(cmd[:-1] + ["-x", "c++", "-"], input=bad, capture_output=True, text=True, timeout=120, cwd=os.path.dirname(src))
+    # the check bites: the same command on a copy of the header with one of this repository's own member names misspelt fails
+    hdr = os.path.join(ros_dir, "visual_odometry.h")
+    bad = open(hdr).read().replace("core->range_callback(", "core->range_calback(") + "\nint main() { visual_odometry_node n; n.visual_odometry_workflow(\"mono\"); }\n"
+    res = subprocess.run(cmd[:-1] + ["-x", "c++", "-"], input=bad, capture_output=True, text=True, timeout=120, cwd=ros_dir)
     assert res.returncode != 0 and "range_calback" in res.stderr
+
+
+def test_reference_main_compiles_against_the_adapter_unchanged():
+    """the reference's bootstrap (uvo/src/UVO_node.cpp:9-29) names `visual_odometry_node`, its default constructor
+    and `visual_odometry_workflow(string)` from `<visual_odometry.h>`.  With ergo_uvo_amd/ros first on the include path that file -- compiled
+    WHERE IT LIES under /root/reference, not copied -- must meet the adapter's class without an edit.  (Skipped where the reference is absent.)"""
+    ref_main = "/root/reference/uvo/src/UVO_node.cpp"
+    if not os.path.exists(ref_main):
+        pytest.skip("the reference checkout is not on this machine")
+    ros_dir = os.path.join(ROOT, "ergo_uvo_amd", "ros")
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-DUVO_NO_OPENCV", "-I", ros_dir, "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "tests", "cpp", "ros_stub"), ref_main]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    # and it is the adapter's class it met: without ergo_uvo_amd/ros on the path the same file does not find its header
+    res = subprocess.run([c for c in cmd if c != ros_dir], capture_output=True, text=True, timeout=120)
+    assert res.returncode != 0 and "visual_odometry.h" in res.stderr
