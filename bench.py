@@ -321,7 +321,8 @@ def main():
     results, records, allrec = all_results[med], all_records[med], all_allrec[med]
     n_before_timed = block_first_k[med]
     busy_threads = block_cpu[med]                                          # host threads this rank kept busy on average (CPU seconds per second)
-    n_valid = sum(r.valid for rb in all_results for r in rb[:args.steps])  # statistics of the run, outside the timed regions
+    n_valid = sum(r.valid for r in results[:args.steps])                   # statistics of the run, outside the timed regions
+    n_valid_all = sum(r.valid for rb in all_results for r in rb[:args.steps])
     kp_sum = sum(r.n_left for r in results[:args.steps])
     assert [int(v) for v in allrec[:, 0, 0].tolist()] == list(range(world))
     ks_timed = ks_seen[n_before_timed - 1:n_before_timed + args.steps]     # [previous frame, then the K timed frames] of the median block
@@ -513,13 +514,13 @@ def main():
             "config": {"workload": "C3: stereo UVO synthetic 1920x1080 pair, ~3000 SURF kpts/image, EPnP PnP-RANSAC"
                                    if world == 1 else "C5: one independent 1920x1080 stereo stream per GPU",
                        "min_hessian": min_hessian, "kpts_per_image": round(kp_sum / max(args.steps, 1), 1),
-                       "valid_steps": n_valid, "valid_steps_of": args.steps * n_blocks, "frames": args.frames, "parallelism": f"streams{world}", "pipeline": f"submit/collect, {args.depth} pairs in flight per image stream"},
+                       "valid_steps": n_valid, "valid_steps_all_blocks": [n_valid_all, args.steps * n_blocks], "frames": args.frames, "parallelism": f"streams{world}", "pipeline": f"submit/collect, {args.depth} pairs in flight per image stream"},
             "value_device_resident": round(value, 3),
             # the timed region (fence, K steps, gather, fence) run `blocks` times in a row in this process: `value` / `ms_per_step` are
             # the MEDIAN block's, every block's rate is listed in run order
             "blocks": n_blocks, "value_is": "median block", "value_first_block": round(block_values[0], 3),
             "value_min": round(min(block_values), 3), "value_max": round(max(block_values), 3), "block_values": [round(v, 1) for v in block_values],
-            "warmup_pipelined_pairs": n_pipe_warm,
+            "warmup_pipelined_pairs": n_pipe_warm, "median_block": med, "pairs_before_median_block": n_before_timed,
             "collect_gap_ms": collect_gap_ms, "pipeline_trace": trace_summary,
             "per_rank_value": [v / 1000.0 for v in per_rank], "ranks_seen": sorted(who[:, 0].tolist()),
             "rccl_ranks_seen": (len(set(who[:, 0].tolist())) if (dist_on and args.backend == "nccl") else 0),

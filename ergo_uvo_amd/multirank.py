@@ -29,6 +29,17 @@ def _parse_cpulist(text: str) -> list[int]:
     return out
 
 
+def _by_physical_core(cpus: list[int], sys_root: str = "/sys") -> list[int]:
+    """Hardware threads ordered so that the siblings of one physical core are adjacent (cpu0, cpu128, cpu1, cpu129, ... on a
+    64-core SMT-2 socket): a slice of the list is then a set of WHOLE cores, and two ranks never share one."""
+    def first_sibling(c):
+        try:
+            return min(_parse_cpulist(open(os.path.join(sys_root, "devices/system/cpu", f"cpu{c}", "topology/thread_siblings_list")).read()))
+        except (OSError, ValueError):
+            return c
+    return sorted(cpus, key=lambda c: (first_sibling(c), c))
+
+
 def visible_gpus(sys_root: str = "/sys", dev_root: str = "/dev", env=None) -> list[dict]:
     """The GPUs this process's HIP runtime will enumerate, in its order, WITHOUT touching the GPU: KFD topology nodes with SIMDs
     (`/sys/class/kfd/kfd/topology/nodes/*/properties`) whose render node can be opened, filtered by ROCR_VISIBLE_DEVICES and then
@@ -56,7 +67,7 @@ def visible_gpus(sys_root: str = "/sys", dev_root: str = "/dev", env=None) -> li
         g = {"pci": pci, "numa_node": None, "cpus": [], "kfd_node": n}
         try:
             g["numa_node"] = int(open(os.path.join(sys_root, "bus/pci/devices", pci, "numa_node")).read())
-            g["cpus"] = _parse_cpulist(open(os.path.join(sys_root, "bus/pci/devices", pci, "local_cpulist")).read())
+            g["cpus"] = _by_physical_core(_parse_cpulist(open(os.path.join(sys_root, "bus/pci/devices", pci, "local_cpulist")).read()), sys_root)
         except (OSError, ValueError):
             pass
         gpus.append(g)

@@ -237,8 +237,10 @@ def _bench_ranks_vs_single_gpu_streams(tmp_path, n, extra, base_seed_key):
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads(p.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == n and line["scaling"] == "weak" and line["config"]["valid_steps"] == steps
-    rec = np.load(rec_path)
+    rec = np.load(rec_path)                                   # the records of the median timed block
     assert rec.shape == (n, steps, multirank.RECORD_WIDTH)
+    warm = line["pairs_before_median_block"]                  # pairs the stream had seen before that block (init, warm-up, earlier blocks)
+    assert warm >= 2 + 2 * 2 and line["blocks"] >= 1 and len(line["block_values"]) == line["blocks"] and len(line["per_rank_value"]) == n
     W, H = bench.WIDTH, bench.HEIGHT
     rig = synth.stereo_rig(W)
     ctx = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=bench.MIN_HESSIAN_C3), 0, W, H, 8192)
@@ -251,7 +253,7 @@ def _bench_ranks_vs_single_gpu_streams(tmp_path, n, extra, base_seed_key):
             order = bench.ping_pong(frames)
             want = np.zeros((warm + steps, multirank.RECORD_WIDTH))
             for i in range(warm + steps):
-                multirank.fill_record(want, i, r, i - warm, ctx.stereo_step(*pairs[next(order)], 0.05))
+                multirank.fill_record(want, i, r, max(i - warm, 0), ctx.stereo_step(*pairs[next(order)], 0.05))
             assert np.array_equal(rec[r].view(np.uint64), want[warm:].view(np.uint64)), r
     finally:
         ctx.close()
@@ -275,7 +277,8 @@ def test_c5_one_rank_rccl_communicator_runs_the_collectives(tmp_path):
     records, all_reduce(MAX) of the time, the barriers -- so the 8-GPU run is not the first time they execute.  The gathered
     record must be the local one bit for bit (bench.py asserts it too) and equal to the synchronous single-GPU run."""
     line = _bench_ranks_vs_single_gpu_streams(tmp_path, 1, ["--backend", "nccl", "--force-dist"], "C3")
-    assert line["host"]["collectives"].startswith("nccl") and "1 rank" in line["host"]["collectives"]
+    assert line["host"]["collectives"].startswith("nccl") and "1 rank" in line["host"]["collectives"] and line["rccl_ranks_seen"] == 1
+    assert line["host"]["pin_matches_opened_device"] in (True, None)                   # the rank sits next to the card it opened
 
 
 def test_c5_five_ranks_on_one_device_match_single_gpu_streams(tmp_path):
@@ -284,6 +287,10 @@ def test_c5_five_ranks_on_one_device_match_single_gpu_streams(tmp_path):
     form of the same path runs on CPU in tests/test_multirank.py.)"""
     line = _bench_ranks_vs_single_gpu_streams(tmp_path, 5, ["--backend", "gloo", "--share-devices", "--depth", "2"], "C5")
     assert line["host"]["cores_of_this_rank"] >= 1
+    # `--gpus 8 --backend gloo --share-devices --depth 2` is NOT run here: the GPU box's process guard admits six processes on the
+    # card at once (this test process + 5 ranks), and a ninth would have the run killed ("process guard").
+    assert line["ranks_seen"] == [0, 1, 2, 3, 4] and line["rccl_ranks_seen"] == 0 and len(set(line["host"]["numa_nodes_of_ranks"])) == 1
+    assert sum(line["host"]["cores_of_ranks"]) <= line["host"]["cores_visible"]         # the five ranks split the card's NUMA node
 
 
 def test_submit_blocks_for_at_most_a_detector_stage():

@@ -110,6 +110,12 @@ def _fake_topology(root, gpus_per_node=4, nodes=2, cores_per_node=16, hidden=())
             pci.mkdir(parents=True)
             pci.joinpath("numa_node").write_text("%d\n" % n)
             pci.joinpath("local_cpulist").write_text("%d-%d\n" % (n * cores_per_node, (n + 1) * cores_per_node - 1))
+            for c in range(n * cores_per_node, (n + 1) * cores_per_node):      # SMT-2: cpu c and cpu c + half a node are one core
+                half = cores_per_node // 2
+                lo = n * cores_per_node + (c - n * cores_per_node) % half
+                t = root / "sys/devices/system/cpu" / ("cpu%d" % c) / "topology"
+                t.mkdir(parents=True, exist_ok=True)
+                t.joinpath("thread_siblings_list").write_text("%d,%d\n" % (lo, lo + half))
             if g not in hidden:
                 (root / "dev/dri" / ("renderD%d" % (128 + g))).write_text("")
             g += 1
@@ -128,7 +134,8 @@ def test_ranks_are_pinned_to_the_numa_node_of_their_gpu(tmp_path, monkeypatch):
     one = tmp_path / "one"
     _fake_topology(one, hidden=(0, 1, 2, 3, 4, 6, 7))
     g1 = multirank.visible_gpus(str(one / "sys"), str(one / "dev"), env={})
-    assert len(g1) == 1 and g1[0]["numa_node"] == 1 and g1[0]["cpus"] == list(range(16, 32))
+    smt = lambda base: [base + c // 2 + 8 * (c % 2) for c in range(16)]          # a node's threads, siblings adjacent: 0, 8, 1, 9, ...
+    assert len(g1) == 1 and g1[0]["numa_node"] == 1 and g1[0]["cpus"] == smt(16)
 
     # pin_rank on the fake 2 x 16-core host: no real affinity call (the test machine has other cores)
     calls = []
@@ -136,11 +143,12 @@ def test_ranks_are_pinned_to_the_numa_node_of_their_gpu(tmp_path, monkeypatch):
     monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: calls.append(sorted(cores)))
     pins = [multirank.pin_rank(r, 8, gpus=gpus) for r in range(8)]
     assert [p["numa_node"] for p in pins] == [0, 0, 0, 0, 1, 1, 1, 1]
-    assert [p["cores"] for p in pins] == [list(range(4 * r, 4 * r + 4)) for r in range(8)] == calls       # 4 ranks split each node's 16 cores
+    assert [p["cores"] for p in pins] == [smt(16 * (r // 4))[4 * (r % 4):4 * (r % 4) + 4] for r in range(8)]   # 4 ranks split each node's 16 threads ...
+    assert pins[0]["cores"] == [0, 8, 1, 9] and [sorted(p["cores"]) for p in pins] == calls                    # ... into whole cores (both SMT siblings)
     # one rank on a one-card box: the whole node next to the card, not the whole machine
     calls.clear()
     p = multirank.pin_rank(0, 1, gpus=g1)
-    assert p["cores"] == list(range(16, 32)) and calls == [list(range(16, 32))] and p["pci"] == "0000:55:00.0"
+    assert sorted(p["cores"]) == list(range(16, 32)) and calls == [list(range(16, 32))] and p["pci"] == "0000:55:00.0"
     # five rehearsal ranks sharing the one card split its node
     calls.clear()
     pins = [multirank.pin_rank(r, 5, share_devices=True, gpus=g1) for r in range(5)]
