@@ -76,6 +76,39 @@ static hipError_t trace_alloc(Ctx* c)
     return hipSuccess;
 }
 
+// HIP streams are parked, not destroyed, and a parked stream goes back to the ROLE it had (stage-A or PnP stream of lane i).
+// Measured in round 3: a context created after another one of the same process had been destroyed ran ~10 % below its rate.  Round 4
+// (tools/probe/ctx_reuse.py, five contexts in a row, pairs/s): create / destroy 4440 4047 4052 4094 4160; streams parked in one
+// free list 4435 3880 4417 3859 4406 -- the same twelve streams, handed out in the reverse order by every second context, are 13 %
+// slower: the runtime binds a stream to a hardware queue (and the driver that queue to a pipe of the command processor) when the
+// stream is first used and never rebalances, so WHICH stream serves which role decides which roles share a pipe.  Parked per role,
+// every context of a process gets the first one's binding.  UVO_STREAM_POOL=0 restores create / destroy (measurement).
+namespace {
+std::mutex g_pool_mu;
+hipStream_t g_pool[64][2][uvo::Ctx::kMaxDepth];            // [device][role: 0 stage A, 1 PnP][lane]
+bool pool_on() { static const bool on = !(getenv("UVO_STREAM_POOL") && atoi(getenv("UVO_STREAM_POOL")) == 0); return on; }
+hipError_t stream_acquire(int device, int role, int lane, hipStream_t* out)
+{
+    if (pool_on() && lane >= 0 && lane < uvo::Ctx::kMaxDepth) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        hipStream_t& slot = g_pool[device & 63][role][lane];
+        if (slot) { *out = slot; slot = nullptr; return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+void stream_release(int device, int role, int lane, hipStream_t s)
+{
+    if (!s) return;
+    (void)hipStreamSynchronize(s);
+    if (pool_on() && lane >= 0 && lane < uvo::Ctx::kMaxDepth) {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        hipStream_t& slot = g_pool[device & 63][role][lane];
+        if (!slot) { slot = s; return; }                    // (two live contexts of one process: the second one's streams are its own)
+    }
+    (void)hipStreamDestroy(s);
+}
+}  // namespace
+
 // one set of buffers, streams and a stage-B worker thread: the caller's context, or a further pipeline lane of it
 // parameters the implementation cannot honour are refused, never silently replaced (the reference passes them to OpenCV)
 static const char* unsupported_params(const uvo_params* p)
@@ -86,7 +119,7 @@ static const char* unsupported_params(const uvo_params* p)
     return nullptr;
 }
 
-static uvo_status create_one(const uvo_params* p, int device, int max_w, int max_h, int max_kpts, uvo_ctx** out)
+static uvo_status create_one(const uvo_params* p, int device, int max_w, int max_h, int max_kpts, uvo_ctx** out, int lane = 0)
 {
     if (!out) return UVO_INVALID_ARG;
     *out = nullptr;
@@ -96,7 +129,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     if (hipSetDevice(device) != hipSuccess) return UVO_HIP_ERROR;
     uvo_ctx* c = new (std::nothrow) uvo_ctx();
     if (!c) return UVO_HIP_ERROR;
-    c->p = *p; c->device = device; c->max_w = max_w; c->max_h = max_h; c->cap = max_kpts;
+    c->p = *p; c->device = device; c->max_w = max_w; c->max_h = max_h; c->cap = max_kpts; c->lane_id = lane;
     const size_t cap = (size_t)max_kpts;
     const size_t npx = (size_t)max_w * max_h, nsum = (size_t)(max_w + 1) * (max_h + 1);
     const int nstrip = (max_h + 7) / 8;                          // integral image: strips of 8 rows (surf.hip)
@@ -104,7 +137,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     const size_t nchunks = (cap + 127) / 128;                   // matcher shortlist: (cap/128) x cap float4 (match.hip)
     hipError_t e = hipSuccess;
 #define A(expr) do { if (e == hipSuccess) e = (expr); } while (0)
-    A(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    A(stream_acquire(device, 0, lane, &c->stream));
     A(hipEventCreate(&c->ev0)); A(hipEventCreate(&c->ev1));
     c->plane_pw = ((max_w + 1 + 3) / 4 + 1 + 1) & ~1;            // even: the integral kernel stores pairs of plane entries
     c->plane_stride = c->plane_pw * ((max_h + 1 + 3) / 4 + 1);
@@ -146,7 +179,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
         if (pe && atoi(pe) != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
             A(hipStreamCreateWithPriority(&c->pnp_stream, hipStreamNonBlocking, greatest));
         else
-            A(hipStreamCreateWithFlags(&c->pnp_stream, hipStreamNonBlocking));
+            A(stream_acquire(device, 1, lane, &c->pnp_stream));
     }
     A(dalloc(&c->d_countsB, (size_t)4)); A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsB), sizeof(int) * 4));
     A(dalloc(&c->d_counts, (size_t)CN_TOTAL));
@@ -215,7 +248,7 @@ static uvo_status set_depth(uvo_ctx* c, int depth)
     while ((int)c->lanes.size() > depth) { destroy_one(static_cast<uvo_ctx*>(c->lanes.back())); c->lanes.pop_back(); }
     while ((int)c->lanes.size() < depth) {
         uvo_ctx* l = nullptr;
-        uvo_status st = create_one(&c->p, c->device, c->max_w, c->max_h, c->cap, &l);
+        uvo_status st = create_one(&c->p, c->device, c->max_w, c->max_h, c->cap, &l, (int)c->lanes.size());
         if (st != UVO_OK) { c->err = "could not allocate a further pipeline lane"; return st; }
         l->master = c; l->lane_id = (int)c->lanes.size(); l->timing = c->timing;
         if (c->trace_on && !l->trace_on && trace_alloc(l) != hipSuccess) { destroy_one(l); c->err = "could not allocate a further pipeline lane"; return UVO_HIP_ERROR; }
@@ -235,8 +268,34 @@ static uvo_status set_depth(uvo_ctx* c, int depth)
     return UVO_OK;
 }
 
+// Measurement (UVO_STREAM_ORDER = 1 | 2, with UVO_PIPELINE_DEPTH lanes): create and first-use the pool's streams in another order
+// than lane by lane -- 1: every stage-A stream, then every PnP stream; 2: the PnP streams first -- to see what the binding of
+// streams to hardware queues is worth.
+static void precreate_streams(int device)
+{
+    static const int order = getenv("UVO_STREAM_ORDER") ? atoi(getenv("UVO_STREAM_ORDER")) : 0;
+    if (order < 1 || order > 2 || !pool_on()) return;
+    const int depth = getenv("UVO_PIPELINE_DEPTH") ? std::min((int)uvo::Ctx::kMaxDepth, std::max(1, atoi(getenv("UVO_PIPELINE_DEPTH")))) : 6;
+    if (hipSetDevice(device) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    int* sink = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&sink), 64) != hipSuccess) return;
+    for (int pass = 0; pass < 2; pass++) {
+        const int role = order == 1 ? pass : 1 - pass;
+        for (int l = 0; l < depth; l++) {
+            hipStream_t& slot = g_pool[device & 63][role][l];
+            if (slot) continue;
+            if (hipStreamCreateWithFlags(&slot, hipStreamNonBlocking) != hipSuccess) { slot = nullptr; continue; }
+            hipLaunchKernelGGL(k_prime, dim3(1), dim3(64), 0, slot, sink, 1);
+            (void)hipStreamSynchronize(slot);
+        }
+    }
+    (void)hipFree(sink);
+}
+
 extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w, int max_h, int max_kpts, uvo_ctx** out)
 {
+    precreate_streams(device);
     uvo_status st = create_one(p, device, max_w, max_h, max_kpts, out);
     if (st != UVO_OK) return st;
     (*out)->lanes.push_back(*out);
@@ -302,7 +361,11 @@ static void destroy_one(uvo_ctx* c)
     (void)hipHostFree(c->h_counts); (void)hipHostFree(c->h_subsets); (void)hipHostFree(c->h_hcount); (void)hipHostFree(c->h_pose);
     (void)hipHostFree(c->h_countsB); (void)hipHostFree(c->h_spec); (void)hipFree(c->d_rng_raw); (void)hipFree(c->d_spec);
     for (int i = 0; i < 2; i++) { (void)hipHostFree(c->h_countsA[i]); if (c->evA[i]) (void)hipEventDestroy(c->evA[i]); }
-    if (c->pnp_stream) (void)hipStreamDestroy(c->pnp_stream);
+    {
+        const char* pe = getenv("UVO_PNP_PRIORITY");
+        if (c->pnp_stream && pe && atoi(pe) != 0) (void)hipStreamDestroy(c->pnp_stream);      // a priority stream is not pooled
+        else stream_release(c->device, 1, c->lane_id, c->pnp_stream);
+    }
     if (c->evAS) (void)hipEventDestroy(c->evAS);
     if (c->evBlock) (void)hipEventDestroy(c->evBlock);
     if (c->evSync) (void)hipEventDestroy(c->evSync);
@@ -312,7 +375,7 @@ static void destroy_one(uvo_ctx* c)
     if (c->evPrevRead) (void)hipEventDestroy(c->evPrevRead);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    stream_release(c->device, 0, c->lane_id, c->stream);
     delete c;
 }
 

@@ -9,9 +9,9 @@
 
 #define CHK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { std::printf("%s: %s\n", #e, hipGetErrorString(_e)); return 1; } } while (0)
 
-enum Op { ADD_U32, ADD3_U32, CVT_F32_I32, MUL_F32, PK_MUL_F32, ADD_F32, CVT_F64_F32, ADD_F64, CVT_F32_F64, FMA_F64, MUL_F64, CVT_F64_I32, LDS_READ_B32, LDS_READ2_B32, N_OPS };
+enum Op { ADD_U32, ADD3_U32, CVT_F32_I32, MUL_F32, PK_MUL_F32, ADD_F32, CVT_F64_F32, ADD_F64, CVT_F32_F64, FMA_F64, MUL_F64, CVT_F64_I32, LDS_READ_B32, LDS_READ2_B32, SAD_U32, FMA_F32, PK_FMA_F32, SUB_U32, N_OPS };
 static const char* kNames[N_OPS] = { "v_add_u32", "v_add3_u32", "v_cvt_f32_i32", "v_mul_f32", "v_pk_mul_f32 (2 products)", "v_add_f32", "v_cvt_f64_f32", "v_add_f64",
-                                      "v_cvt_f32_f64", "v_fma_f64", "v_mul_f64", "v_cvt_f64_i32", "ds_read_b32", "ds_read2_b32" };
+                                      "v_cvt_f32_f64", "v_fma_f64", "v_mul_f64", "v_cvt_f64_i32", "ds_read_b32", "ds_read2_b32", "v_sad_u32", "v_fma_f32", "v_pk_fma_f32 (2 fmas)", "v_sub_u32" };
 
 template <int OP>
 __global__ void k_rate(long long* out, int iters, float seed)
@@ -41,6 +41,10 @@ __global__ void k_rate(long long* out, int iters, float seed)
                 else if constexpr (OP == FMA_F64) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(d[k]) : "v"(d[(k + 1) & 7]));
                 else if constexpr (OP == MUL_F64) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(d[k]) : "v"(d[(k + 1) & 7]));
                 else if constexpr (OP == CVT_F64_I32) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(d[k]) : "v"(n[k]));
+                else if constexpr (OP == SAD_U32) asm volatile("v_sad_u32 %0, %0, %1, %2" : "+v"(n[k]) : "v"(n[(k + 1) & 7]), "s"(0x4B000000));
+                else if constexpr (OP == FMA_F32) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(f[k]) : "v"(seed));
+                else if constexpr (OP == PK_FMA_F32) asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(p[k]));
+                else if constexpr (OP == SUB_U32) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(n[k]) : "v"(n[(k + 1) & 7]));
                 else if constexpr (OP == LDS_READ_B32) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(n[k]) : "v"(lane_addr), "n"(k * 256));
                 else if constexpr (OP == LDS_READ2_B32) { long long v; asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(lane_addr), "n"(k * 2), "n"(k * 2 + 64)); n[k] = (int)v; }
             }
@@ -74,7 +78,8 @@ int main()
 {
     long long* d_out = nullptr;
     CHK(hipMalloc(&d_out, 16));
-    for (int waves : { 1, 4, 8, 16 }) {
+    // (one wave only: with several waves per SIMD the oldest wave issues first and thread 0's clock shows no contention)
+    for (int waves : { 1 }) {
         if (run<ADD_F32>(d_out, waves)) return 1;
         if (run<ADD_U32>(d_out, waves)) return 1;
         if (run<ADD3_U32>(d_out, waves)) return 1;
@@ -89,6 +94,10 @@ int main()
         if (run<CVT_F64_I32>(d_out, waves)) return 1;
         if (run<LDS_READ_B32>(d_out, waves)) return 1;
         if (run<LDS_READ2_B32>(d_out, waves)) return 1;
+        if (run<SAD_U32>(d_out, waves)) return 1;
+        if (run<FMA_F32>(d_out, waves)) return 1;
+        if (run<PK_FMA_F32>(d_out, waves)) return 1;
+        if (run<SUB_U32>(d_out, waves)) return 1;
     }
     return 0;
 }
