@@ -379,36 +379,61 @@ struct __attribute__((packed, aligned(4))) SumQuad { int32_t a, b, c, d; };     
 // `skip_thr` (in scope at the expansion): when dx*dy <= skip_thr the determinant cannot exceed the threshold either
 // (det = fl(dx*dy - fl(0.81f*dxy*dxy)) <= dx*dy), so Dxy's 16 corners are not read and the sample gets kDetBelow: it can
 // neither be a maximum nor beat one, and k_hessian_finish evaluates it exactly if it ends up in a keypoint's neighbourhood.
+// Arithmetic of one box, restated for the instruction mix of gfx950 (tools/probe/issue_rate_probe.hip: v_cvt_f32_i32 7.9 cycles per
+// wave-instruction, v_cvt_f64_f32 8.6, v_cvt_f32_f64 8.4 against 4.8-5.4 for adds, subtractions, v_sad_u32 and v_pk_fma_f32 with its
+// two products) -- OpenCV's value `(float)v * w` for the box sum v, bit for bit:
+//   * v is a sum of pixels, 0 <= v < 2^23 (the largest box, 88 x 147 pixels of 255, is 3.3e6), so the float whose BITS are
+//     v + 0x4B000000 is exactly 2^23 + v, and fma(2^23 + v, w, -(2^23 w)) rounds the exact product v w once: fl(v w) = (float)v * w
+//     (2^23 w is a power-of-two multiple of w, exact; a zero box gives +0 either way: w0 > 0 leads every sum below).  No int -> float
+//     conversion, and two boxes of equal weight share one v_pk_fma_f32.
+//   * the four corners of a box are two differences along the direction the boxes of a filter share an edge in: for Dx
+//     g_k = S(y7, x_k) - S(y2, x_k) >= 0 at the four x_k, and box_j + 2^23-bits = (g_{k+1} + (j+1) M) - (g_k + j M) with
+//     M = 0x4B000000 folded into v_sad_u32's addend (|a - b| + c; the integral is monotone, so |a - b| = a - b): seven integer
+//     instructions per filter instead of nine plus a constant add, twelve for Dxy.
+//   * the double accumulation `d = 0; d += p0; ...` starts from p0 itself (0 + p0 = p0 exactly, p0 >= +0).
+// The sums of three or four such floats in double are exact (their exponents lie within 24 binades), so the order is immaterial to
+// the result; it is kept anyway.
+typedef float uvo_v2f __attribute__((ext_vector_type(2)));
+static constexpr unsigned kBoxMagic = 0x4B000000u;           // bits of 2^23
+__device__ __forceinline__ unsigned sad_u32(int a, int b, unsigned c)      // |a - b| + c (mod 2^32), a, b >= 0
+{
+    unsigned r;
+    asm("v_sad_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+#define UVO_BOX_FMA2(xa, xb, wgt) __builtin_elementwise_fma(uvo_v2f{__uint_as_float(xa), __uint_as_float(xb)}, uvo_v2f{(wgt), (wgt)}, uvo_v2f{-8388608.0f * (wgt), -8388608.0f * (wgt)})
 #define UVO_HESSIAN_DET(SV, det)                                                                          \
     {                                                                                                     \
-        /* Dx: boxes (0,2,3,7,+1) (3,2,6,7,-2) (6,2,9,7,+1) */                                            \
-        int a0 = SV(c2, c0), a3 = SV(c2, c3), a6 = SV(c2, c6), a9 = SV(c2, c9);                           \
-        int b0 = SV(c7, c0), b3 = SV(c7, c3), b6 = SV(c7, c6), b9 = SV(c7, c9);                           \
-        double d = 0;                                                                                     \
-        d += (float)(a0 + b3 - b0 - a3) * wx0;                                                            \
-        d += (float)(a3 + b6 - b3 - a6) * wx1;                                                            \
-        d += (float)(a6 + b9 - b6 - a9) * wx2;                                                            \
+        /* Dx: boxes (0,2,3,7,+1) (3,2,6,7,-2) (6,2,9,7,+1): column differences between rows c2 and c7 */ \
+        const unsigned gx0 = (unsigned)(SV(c7, c0) - SV(c2, c0)), gx3 = sad_u32(SV(c7, c3), SV(c2, c3), kBoxMagic),                       \
+                       gx6 = sad_u32(SV(c7, c6), SV(c2, c6), 2u * kBoxMagic), gx9 = sad_u32(SV(c7, c9), SV(c2, c9), 3u * kBoxMagic);     \
+        /* Dy: boxes (2,0,7,3,+1) (2,3,7,6,-2) (2,6,7,9,+1): row differences between columns c2 and c7 */ \
+        const unsigned gy0 = (unsigned)(SV(c0, c7) - SV(c0, c2)), gy3 = sad_u32(SV(c3, c7), SV(c3, c2), kBoxMagic),                       \
+                       gy6 = sad_u32(SV(c6, c7), SV(c6, c2), 2u * kBoxMagic), gy9 = sad_u32(SV(c9, c7), SV(c9, c2), 3u * kBoxMagic);     \
+        static_assert(wx0 == wx2 && wy0 == wy2 && wx0 == wy0 && wx1 == wy1, "the outer boxes of Dx and Dy share one weight");            \
+        const uvo_v2f px02 = UVO_BOX_FMA2(gx3 - gx0, gx9 - gx6, wx0), py02 = UVO_BOX_FMA2(gy3 - gy0, gy9 - gy6, wy0);                     \
+        const uvo_v2f pxy1 = UVO_BOX_FMA2(gx6 - gx3, gy6 - gy3, wx1);                                                                     \
+        double d = (double)px02.x;                                                                        \
+        d += (double)pxy1.x;                                                                              \
+        d += (double)px02.y;                                                                              \
         const float dx = (float)d;                                                                        \
-        /* Dy: boxes (2,0,7,3,+1) (2,3,7,6,-2) (2,6,7,9,+1) */                                            \
-        int e0 = SV(c0, c2), e3 = SV(c3, c2), e6 = SV(c6, c2), e9 = SV(c9, c2);                           \
-        int f0 = SV(c0, c7), f3 = SV(c3, c7), f6 = SV(c6, c7), f9 = SV(c9, c7);                           \
-        d = 0;                                                                                            \
-        d += (float)(e0 + f3 - e3 - f0) * wy0;                                                            \
-        d += (float)(e3 + f6 - e6 - f3) * wy1;                                                            \
-        d += (float)(e6 + f9 - e9 - f6) * wy2;                                                            \
+        d = (double)py02.x;                                                                               \
+        d += (double)pxy1.y;                                                                              \
+        d += (double)py02.y;                                                                              \
         const float dy = (float)d;                                                                        \
         const float pp_ = dx * dy;                                                                        \
-        if (!(pp_ > skip_thr)) det = kDetBelow; else {                                                 \
-        /* Dxy: boxes (1,1,4,4,+1) (5,1,8,4,-1) (1,5,4,8,-1) (5,5,8,8,+1) */                              \
-        int g11 = SV(c1, c1), g14 = SV(c1, c4), g15 = SV(c1, c5), g18 = SV(c1, c8);                       \
-        int g41 = SV(c4, c1), g44 = SV(c4, c4), g45 = SV(c4, c5), g48 = SV(c4, c8);                       \
-        int g51 = SV(c5, c1), g54 = SV(c5, c4), g55 = SV(c5, c5), g58 = SV(c5, c8);                       \
-        int g81 = SV(c8, c1), g84 = SV(c8, c4), g85 = SV(c8, c5), g88 = SV(c8, c8);                       \
-        d = 0;                                                                                            \
-        d += (float)(g11 + g44 - g41 - g14) * wd0;                                                        \
-        d += (float)(g15 + g48 - g45 - g18) * wd1;                                                        \
-        d += (float)(g51 + g84 - g81 - g54) * wd2;                                                        \
-        d += (float)(g55 + g88 - g85 - g58) * wd3;                                                        \
+        if (!(pp_ > skip_thr)) det = kDetBelow; else {                                                    \
+        /* Dxy: boxes (1,1,4,4,+1) (5,1,8,4,-1) (1,5,4,8,-1) (5,5,8,8,+1): row differences c1..c4 and c5..c8 at the four columns */      \
+        const unsigned u1 = (unsigned)(SV(c4, c1) - SV(c1, c1)), u4 = sad_u32(SV(c4, c4), SV(c1, c4), kBoxMagic);                         \
+        const unsigned u5 = (unsigned)(SV(c4, c5) - SV(c1, c5)), u8 = sad_u32(SV(c4, c8), SV(c1, c8), kBoxMagic);                         \
+        const unsigned t1 = (unsigned)(SV(c8, c1) - SV(c5, c1)), t4 = sad_u32(SV(c8, c4), SV(c5, c4), kBoxMagic);                         \
+        const unsigned t5 = (unsigned)(SV(c8, c5) - SV(c5, c5)), t8 = sad_u32(SV(c8, c8), SV(c5, c8), kBoxMagic);                         \
+        static_assert(wd0 == wd3 && wd1 == wd2 && wd1 == -wd0, "the four boxes of Dxy share one weight up to sign");                      \
+        const uvo_v2f pd03 = UVO_BOX_FMA2(u4 - u1, t8 - t5, wd0), pd12 = UVO_BOX_FMA2(u8 - u5, t4 - t1, wd1);                             \
+        d = (double)pd03.x;                                                                               \
+        d += (double)pd12.x;                                                                              \
+        d += (double)pd12.y;                                                                              \
+        d += (double)pd03.y;                                                                              \
         const float dxy = (float)d;                                                                       \
         det = pp_ - 0.81f * dxy * dxy; }                                                                  \
     }
@@ -443,8 +468,12 @@ __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, f
     UVO_HESSIAN_CONSTS(LC);
     const LayerPat& lp = op.L[L];
     const int tid = threadIdx.x;
-#pragma unroll 2
-    for (int sidx = tid; sidx < TW * TH; sidx += NT) {
+    // a compile-time trip count (the last pass is guarded): the box arithmetic holds inline assembly, which the compiler treats as
+    // convergent and will not unroll behind a run-time remainder
+#pragma unroll
+    for (int it = 0; it < (TW * TH + NT - 1) / NT; it++) {
+        const int sidx = tid + it * NT;
+        if ((it + 1) * NT > TW * TH && sidx >= TW * TH) break;
         const int ry = sidx / TW, rx = sidx - ry * TW;
         const int oi = py0 + ry - OC::margin(L), oj = px0 + rx - OC::margin(L);
         float det = 0.f;
@@ -472,7 +501,10 @@ __device__ __forceinline__ void det_layer_p(const int32_t* __restrict__ planes, 
     UVO_HESSIAN_CONSTS(LC);
     const LayerPat& lp = op.L[L];
     const int tid = threadIdx.x;
-    for (int sidx = tid; sidx < TW * TH; sidx += NT) {
+#pragma unroll
+    for (int it = 0; it < (TW * TH + NT - 1) / NT; it++) {
+        const int sidx = tid + it * NT;
+        if ((it + 1) * NT > TW * TH && sidx >= TW * TH) break;
         const int ry = sidx / TW, rx = sidx - ry * TW;
         const int oi = py0 + ry - OC::margin(L), oj = px0 + rx - OC::margin(L);
         float det = 0.f;
