@@ -486,6 +486,12 @@ __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, f
 #undef SV
 }
 
+typedef __amdgpu_buffer_rsrc_t ImgRsrc;
+__device__ __forceinline__ ImgRsrc img_rsrc(const uint8_t* img, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, bytes, 0x00020000);      // raw buffer, dword data format (gfx9 family)
+}
+
 // The same layer from the de-interleaved planes in global memory (octaves 2 and 3: the integral tile of one
 // workgroup would not fit LDS).  Sample (oi, oj) has its top-left at pixel (STEP*oi, STEP*oj); corner (dy, dx) is in
 // plane (dy & 3, dx & 3) at [STEP/4*oi + dy/4][STEP/4*oj + dx/4]: plane and offsets are compile-time, lanes along oj.
@@ -497,7 +503,11 @@ __device__ __forceinline__ void det_layer_p(const int32_t* __restrict__ planes, 
     constexpr int STEP = OC::STEP, SIZE = OC::size(L), Q = STEP / 4;
     static_assert(STEP % 4 == 0, "plane variant needs a step that is a multiple of 4");
     using LC = LayerC<SIZE>;
-#define SVP(dy, dx) base[(size_t)((((dy) & 3) * 4 + ((dx) & 3)) * pstride + ((dy) >> 2) * pw + ((dx) >> 2))]
+    // The planes are read through a buffer resource: a corner's address is the lane's sample offset (one VGPR) + a scalar offset
+    // (plane and row of the corner: SALU arithmetic on pw / pstride) + the column as the instruction's immediate, instead of a
+    // 64-bit flat address (a VGPR pair and a v_lshl_add_u64) per corner.
+    const ImgRsrc rs = img_rsrc(reinterpret_cast<const uint8_t*>(planes), 16 * pstride * 4);
+#define SVP(dy, dx) (int)__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4 * ((dx) >> 2), 4 * ((((dy) & 3) * 4 + ((dx) & 3)) * pstride + ((dy) >> 2) * pw), 0)
     UVO_HESSIAN_CONSTS(LC);
     const LayerPat& lp = op.L[L];
     const int tid = threadIdx.x;
@@ -509,7 +519,7 @@ __device__ __forceinline__ void det_layer_p(const int32_t* __restrict__ planes, 
         const int oi = py0 + ry - OC::margin(L), oj = px0 + rx - OC::margin(L);
         float det = 0.f;
         if (oi >= 0 && oi < lp.samples_i && oj >= 0 && oj < lp.samples_j) {
-            const int32_t* base = planes + (size_t)(oi * Q) * pw + oj * Q;
+            const int voff = 4 * ((oi * Q) * pw + oj * Q);
             UVO_HESSIAN_DET(SVP, det)
         }
         sdet[((L - 1) * TH + ry) * TW + rx] = det;
@@ -1079,11 +1089,6 @@ __device__ __forceinline__ int ssel_lt(int a, int b, int x, int y)
 }
 __device__ __forceinline__ float sgpr_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 
-typedef __amdgpu_buffer_rsrc_t ImgRsrc;
-__device__ __forceinline__ ImgRsrc img_rsrc(const uint8_t* img, int bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, bytes, 0x00020000);      // raw buffer, dword data format (gfx9 family)
-}
 struct ColTask { int y0, n, h1, w; float a_first, a_mid, a_last; };      // tap t reads row clamp(y0 - t, 0, h1); n >= 1 taps
 
 template <int PX> __device__ __forceinline__ unsigned px_load(ImgRsrc rs, int voff, int soff);
