@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--frames", type=int, default=4, help="distinct synthetic stereo pairs (ping-pong order)")
     ap.add_argument("--depth", type=int, default=int(os.environ.get("UVO_PIPELINE_DEPTH", "6")),
                     help="consecutive pairs in flight per image stream (uvo_stereo_set_depth)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("UVO_BENCH_BATCH", "1")), choices=[1, 2],
+                    help="pairs per launch set (uvo_stereo_set_batch): 2 = consecutive pairs of the stream are queued two at a time")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-oracle baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend of the pose-record gather "
@@ -230,6 +232,7 @@ def main():
     params = uvo.Params.stereo(SURF_MIN_HESSIAN=min_hessian)
     ctx = uvo.Context(params, local_rank, WIDTH, HEIGHT, 8192)
     ctx.stereo_set_depth(args.depth)
+    ctx.stereo_set_batch(args.batch)
     ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
 
     order = ping_pong(args.frames)

@@ -423,6 +423,10 @@ class Context:
         self._check(self._lib.uvo_stereo_set_depth(self._h, int(depth)))
         self._drained()
 
+    def stereo_set_batch(self, pairs: int):
+        """uvo_stereo_set_batch: 2 = consecutive pairs are queued two at a time, one launch per kernel for both (batch consumers)."""
+        self._check(self._lib.uvo_stereo_set_batch(self._h, int(pairs)))
+
     def stereo_submit(self, left, right):
         """Enqueue detect..extract_3Dpoints of a pair (no host sync); at most two pairs in flight."""
         h, w = left.shape[-2], left.shape[-1]

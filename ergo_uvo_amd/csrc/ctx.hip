@@ -65,6 +65,8 @@ static uvo_status prime_lanes(uvo_ctx* c, int w, int h);
 extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* out);
 static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok);
 static void destroy_one(uvo_ctx* c);
+static uvo_status queue_stage_a(uvo_ctx* c, uvo_ctx* A, uvo_ctx* B);
+struct GatherPair;
 // the ring of timing events behind UVO_TRACE / uvo_trace_enable (a lane's, created once)
 static hipError_t trace_alloc(Ctx* c)
 {
@@ -302,10 +304,21 @@ extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w,
     if (getenv("UVO_MAX_B")) (*out)->max_b = std::min(16, std::max(1, atoi(getenv("UVO_MAX_B"))));
     if (getenv("UVO_A_OVERLAP")) (*out)->a_overlap = std::min(8, std::max(0, atoi(getenv("UVO_A_OVERLAP"))));
     if (getenv("UVO_MAX_B_MONO")) (*out)->max_b_mono = std::min(16, std::max(1, atoi(getenv("UVO_MAX_B_MONO"))));
+    if (getenv("UVO_A_OVERLAP2")) (*out)->a_overlap2 = std::min(4, std::max(0, atoi(getenv("UVO_A_OVERLAP2"))));
+    if (getenv("UVO_BATCH")) (*out)->batch = atoi(getenv("UVO_BATCH")) == 2 ? 2 : 1;
     if (getenv("UVO_A_OVERLAP_MONO")) (*out)->a_overlap_mono = std::min(8, std::max(0, atoi(getenv("UVO_A_OVERLAP_MONO"))));
     st = set_depth(*out, 2);                      // two pairs in flight by default (uvo_stereo_set_depth changes it)
     if (st != UVO_OK) { uvo_ctx_destroy(*out); *out = nullptr; }
     return st;
+}
+
+extern "C" uvo_status uvo_stereo_set_batch(uvo_ctx* c, int pairs)
+{
+    if (!c) return UVO_INVALID_ARG;
+    if (pairs != 1 && pairs != 2) { c->err = "uvo_stereo_set_batch: 1 or 2 pairs per launch set"; return UVO_INVALID_ARG; }
+    if (c->n_pending != 0) { c->err = "the launch mode cannot change while pairs are in flight"; return UVO_INVALID_ARG; }
+    c->batch = pairs;
+    return UVO_OK;
 }
 
 extern "C" uvo_status uvo_stereo_set_depth(uvo_ctx* c, int depth)
@@ -764,27 +777,32 @@ __device__ __forceinline__ void gather_after_stereo(int bx, const uvo_dmatch* m,
     for (int v = sub; v < dim / 4; v += 16) reinterpret_cast<float4*>(odL + (size_t)row * dim)[v] = reinterpret_cast<const float4*>(dL + (size_t)q * dim)[v];
     if (sub == 0) { okL[row] = kL[q]; okR[row] = kR[t]; }
 }
-// VO:601-617, 637-640: points of the triangular matches (prev left / prev right by queryIdx, curr left by trainIdx)
+// VO:601-617, 637-640: points of the triangular matches (prev left / prev right by queryIdx, curr left by trainIdx).  pmap (two-pair
+// launch): the previous pair's set is not gathered yet -- its row q is keypoint pmap[q].queryIdx of that pair's left list and
+// pmap[q].trainIdx of its right list (pL, pR are then those lists)
 __device__ __forceinline__ void gather_triangular(int bx, const uvo_dmatch* m, const int* cn, const uvo_keypoint* pL, const uvo_keypoint* pR,
-                                                  const uvo_keypoint* cL, uvo_point2f* x1, uvo_point2f* x2, uvo_point2f* xc)
+                                                  const uvo_keypoint* cL, uvo_point2f* x1, uvo_point2f* x2, uvo_point2f* xc, const uvo_dmatch* pmap)
 {
     const int T = cn[CN_T];
     const int i = bx * 256 + threadIdx.x;
     if (i >= T) return;
     const int q = m[i].queryIdx, t = m[i].trainIdx;
-    x1[i] = uvo_point2f{pL[q].x, pL[q].y};
-    x2[i] = uvo_point2f{pR[q].x, pR[q].y};
+    const int ql = pmap ? pmap[q].queryIdx : q, qr = pmap ? pmap[q].trainIdx : q;
+    x1[i] = uvo_point2f{pL[ql].x, pL[ql].y};
+    x2[i] = uvo_point2f{pR[qr].x, pR[qr].y};
     xc[i] = uvo_point2f{cL[t].x, cL[t].y};
 }
 // both gathers of a stereo step in one launch: blocks [0, n_as) build this pair's "after stereo match" set, the rest the point
-// pairs of the triangular matches
+// pairs of the triangular matches; blockIdx.y: the pair of a two-pair launch
 struct GatherArgs { const uvo_dmatch* m_s; const uvo_dmatch* m_t; const int* cn; const uvo_keypoint* kL; const uvo_keypoint* kR; const float* dL;
                     uvo_keypoint* okL; uvo_keypoint* okR; float* odL; int dim; const uvo_keypoint* pL; const uvo_keypoint* pR;
-                    uvo_point2f* x1; uvo_point2f* x2; uvo_point2f* xc; int n_as; };
-__global__ __launch_bounds__(256) void k_gather_stereo_step(GatherArgs a)
+                    uvo_point2f* x1; uvo_point2f* x2; uvo_point2f* xc; int n_as; const uvo_dmatch* pmap; };
+struct GatherPair { GatherArgs g[2]; };
+__global__ __launch_bounds__(256) void k_gather_stereo_step(GatherPair gp)
 {
+    const GatherArgs& a = gp.g[blockIdx.y];
     if ((int)blockIdx.x < a.n_as) gather_after_stereo(blockIdx.x, a.m_s, a.cn, a.kL, a.kR, a.dL, a.okL, a.okR, a.odL, a.dim);
-    else gather_triangular(blockIdx.x - a.n_as, a.m_t, a.cn, a.pL, a.pR, a.kL, a.x1, a.x2, a.xc);
+    else gather_triangular(blockIdx.x - a.n_as, a.m_t, a.cn, a.pL, a.pR, a.kL, a.x1, a.x2, a.xc, a.pmap);
 }
 __global__ void k_gather_kps_idx(const uvo_keypoint* src, const int* idx, int n, uvo_keypoint* dst)
 {
@@ -959,25 +977,66 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
         c->next_lane = 0;
         return UVO_OK;
     }
+    // ---- plan: lane, buffers, what the pair reads from its predecessor; the sequential state moves on here, in submit order ----
     const int li = c->next_lane;
-    const double t_sub = uvo::g_bdbg ? uvo::now_us() : 0;
     Range r_submit("uvo:stereo_submit");
     uvo_ctx* L = static_cast<uvo_ctx*>(c->lanes[li]);
-    Ctx* P = c->lanes[c->prev_lane];
     L->pending = Ctx::Pending();
     L->pending.used = true;
-#define LANE_TRY(expr) do { uvo_status st_ = (expr); if (st_ != UVO_OK) { if (L != c) c->err = L->err; return st_; } } while (0)
-    Ctx::TraceRec* tr = nullptr;
+    Ctx::StagePlan& pl = L->plan;
+    pl.lane = li; pl.prev_lane = c->prev_lane; pl.prev_buf = c->prev_buf; pl.prev_sync = c->prev_sync; pl.curr = L->as_w;
+    pl.pending_before = c->n_pending; pl.trace_slot = -1;
     if (L->trace_on) {
         L->trace_cur = (int)(L->trace_count++ % Ctx::kTraceRing);
-        tr = &L->trace[L->trace_cur]; tr->pair = c->n_submitted; tr->b_used = false;
+        pl.trace_slot = L->trace_cur;
+        Ctx::TraceRec* tr = &L->trace[L->trace_cur];
+        tr->pair = c->n_submitted; tr->b_used = false;
         for (double& v : tr->host_us) v = 0;
         tr->host_us[0] = uvo::now_us();
-        UVO_HIP_TRY(c, hipEventRecord(tr->ev[0], L->stream));
     }
-    UVO_TRY(wait_for_producer(c, L, mem));
-    LANE_TRY(surf_upload(L, 0, left, w, h, stride, mem));
-    LANE_TRY(surf_upload(L, 1, right, w, h, stride, mem));
+    // a pair joins a two-pair launch when the mode is on and the pair can take that path: upright SURF, not the synchronous step,
+    // no per-stage timing, two lanes at least
+    const bool may_batch = c->batch == 2 && depth >= 2 && !c->in_sync_step && !c->timing && !c->use_sift() && p.SURF_UPRIGHT && p.SURF_OCTAVES_NUMBER == 4;
+    uvo_ctx* S = c->stashed_lane >= 0 ? static_cast<uvo_ctx*>(c->lanes[c->stashed_lane]) : nullptr;      // the pair before, waiting for this one
+    // uploads: a pair's images go to its own lane's buffers (or are read in place); the copies of a two-pair launch are ordered on the
+    // stream that will run the kernels -- the first lane's
+    hipStream_t own = L->stream;
+    if (S && may_batch) L->stream = S->stream;
+    uvo_status up = wait_for_producer(c, L, mem);
+    if (up == UVO_OK) up = surf_upload(L, 0, left, w, h, stride, mem);
+    if (up == UVO_OK) up = surf_upload(L, 1, right, w, h, stride, mem);
+    L->stream = own;
+    if (up != UVO_OK) { if (L != c) c->err = L->err; L->pending.used = false; return up; }
+    // state carry VO:727-733: this pair's set is the next pair's "prev"
+    L->as_w = pl.curr ^ 1;
+    c->prev_lane = li; c->prev_buf = pl.curr; c->prev_sync = false;
+    c->next_lane = (li + 1) % depth;
+    c->inflight[c->n_pending++] = li; c->n_submitted++;
+    L->inline_b = c->in_sync_step;
+    L->job.kind = 0;                                           // a stereo pair (the lane is free: its worker holds no job)
+    if (S && (!may_batch || S->img_w != L->img_w || S->img_h != L->img_h)) { UVO_TRY(queue_stage_a(c, S, nullptr)); S = nullptr; }   // cannot pair up: the waiting pair goes alone
+    if (S) return queue_stage_a(c, S, L);
+    if (may_batch) { c->stashed_lane = li; return UVO_OK; }           // waits for its partner (or for the collect that needs it)
+    return queue_stage_a(c, L, nullptr);
+}
+
+// Stage A of one pair (VO:548-632) -- or of two consecutive pairs, lanes A and B, in one set of launches on A's stream: detect,
+// stereo match, triangular match, gathers, triangulation, extract_3Dpoints -- queued without a host sync; the counters land in each
+// lane's pinned mirror, events mark completion and each lane's worker thread takes over for stage B.
+static uvo_status queue_stage_a(uvo_ctx* c, uvo_ctx* A, uvo_ctx* B)
+{
+    const uvo_params& p = c->p;
+    const int depth = (int)c->lanes.size();
+    const double t_sub = uvo::g_bdbg ? uvo::now_us() : 0;
+    if (c->stashed_lane == A->plan.lane) c->stashed_lane = -1;
+    const Ctx::StagePlan& pa = A->plan;
+    Ctx* P = c->lanes[pa.prev_lane];
+    hipStream_t st = A->stream;
+    Ctx::TraceRec* trA = pa.trace_slot >= 0 ? &A->trace[pa.trace_slot] : nullptr;
+    Ctx::TraceRec* trB = (B && B->plan.trace_slot >= 0) ? &B->trace[B->plan.trace_slot] : nullptr;
+#define LANE_TRY(expr) do { uvo_status st_ = (expr); if (st_ != UVO_OK) { if (A != c) c->err = A->err; return st_; } } while (0)
+    if (trA) UVO_HIP_TRY(c, hipEventRecord(trA->ev[0], st));
+    if (trB) UVO_HIP_TRY(c, hipEventRecord(trB->ev[0], st));
     // Stage A is a run of chip-filling detection kernels followed by thin ones.  Two stage As side by side fill each other's
     // gaps; three or more interleave at kernel granularity, evict each other's LDS-sized workgroups and every one of them
     // slows down (measured with UVO_TRACE: detection 390 us with two, 1050 us with five lanes in stage A).
@@ -991,78 +1050,100 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     // an event that is still pending, so that the kernels sit behind a barrier packet in their hardware queue) was measured at 1200-2200
     // pairs/s against 3800: a queue parked on a barrier slows the other queues down.  evA[1] is the twin of the event the lane's worker
     // blocks on -- the runtime holds an event's lock while a thread waits on it.
-    // (Queueing the light integral kernels ahead of the wait was tried: no gain.)
-    if (c->a_overlap > 0 && depth > c->a_overlap) {
-        Ctx* H = c->lanes[(li + depth - c->a_overlap) % depth];
-        if (c->n_pending >= c->a_overlap) (void)hipEventSynchronize(H->evA[1]);
+    // (Queueing the light integral kernels ahead of the wait was tried: no gain.)  A two-pair launch set counts as one stage A and
+    // waits for the set a_overlap2 sets before it.
+    {
+        const int back = B ? 2 * c->a_overlap2 : c->a_overlap;
+        if (back > 0 && depth > back && pa.pending_before >= back) {
+            Ctx* H = c->lanes[(pa.lane + depth - back) % depth];
+            (void)hipEventSynchronize(H->evA[1]);
+        }
     }
-    seg(9);                                                                                // the a_overlap wait
-    if (tr) tr->host_us[1] = uvo::now_us();
-    { Range r("uvo:detect_features x2"); LANE_TRY(detect_dispatch(L, 2, p.MIN_NUM_FEATURES)); }    // VO:548-549, and the VO:556 gate
+    seg(9);                                                                                // the pacing wait
+    if (trA) trA->host_us[1] = uvo::now_us();
+    if (trB) trB->host_us[1] = uvo::now_us();
+    { Range r("uvo:detect_features x2");                                                   // VO:548-549, and the VO:556 gate
+      if (B) LANE_TRY(surf_detect_lanes(A, B, 2, p.MIN_NUM_FEATURES)); else LANE_TRY(detect_dispatch(A, 2, p.MIN_NUM_FEATURES)); }
     seg(10);                                                                               // detector launches
-    if (tr) UVO_HIP_TRY(c, hipEventRecord(tr->ev[1], L->stream));
-    const int cap = c->cap, curr = L->as_w, prev = c->prev_buf;
-    int* cn = L->d_counts;
+    if (trA) UVO_HIP_TRY(c, hipEventRecord(trA->ev[1], st));
+    if (trB) UVO_HIP_TRY(c, hipEventRecord(trB->ev[1], st));
+    const int cap = c->cap, curr = pa.curr, prev = pa.prev_buf;
+    int* cn = A->d_counts;
     const float ratio = (float)p.LOWE_RATIO_THRESHOLD;
-    hipStream_t st = L->stream;
     // Stereo matching L -> R (VO:558, gated on the device by VO:556) and triangular matching prev-left-after-stereo -> curr-left
     // (VO:592) share their launches: both only need this pair's descriptors and the previous pair's "after stereo match" set
     // (another lane's buffers, behind its event).  The triangular match is computed for every row of that set; whether it is used
-    // is VO:567's decision, taken by the first compaction's gate and read by the second's (cn[CN_NQB]).
+    // is VO:567's decision, taken by the first compaction's gate and read by the second's (cn[CN_NQB]).  In a two-pair launch the
+    // second pair's previous set is the first pair's, which does not exist yet: match_two_pairs goes through the first pair's stereo matches.
     { Range r_ms("uvo:match_features stereo + triangular, select");
-    if (!c->prev_sync && P != L) UVO_HIP_TRY(c, hipStreamWaitEvent(st, P->evAS, 0));
-    LANE_TRY(match_knn2_two(L, L->det[0].desc, cn + CN_NQA, L->det[1].desc, cn + CN_NR,
-                            P->d_as_descL[prev], P->d_as_n + prev, L->det[0].desc, cn + CN_NL, cap));
-    const GateArgs gate_b = { 1, cn, p.MIN_NUM_FEATURES, cap, L->d_as_n + curr, P->d_as_n + prev };       // VO:567
-    const GateArgs gate_c = { 2, cn, p.MIN_NUM_FEATURES, cap, nullptr, nullptr };                           // VO:626
-    LANE_TRY(match_ratio_compact2(L, ratio, cn + CN_NQA, L->d_matches[0], cn + CN_M, gate_b,
-                                  cn + CN_NQB, L->d_matches[1], cn + CN_TRAW, gate_c, cap, cap));
-    {
-        StageTimer t(L, ST_GATHER);
-        GatherArgs ga = { L->d_matches[0], L->d_matches[1], cn, L->det[0].kps, L->det[1].kps, L->det[0].desc,
-                          L->d_as_kpsL[curr], L->d_as_kpsR[curr], L->d_as_descL[curr], L->desc_dim(), P->d_as_kpsL[prev], P->d_as_kpsR[prev],
-                          L->d_x1, L->d_x2, L->d_xc, (cap + 15) / 16 };
-        hipLaunchKernelGGL(k_gather_stereo_step, dim3((cap + 15) / 16 + (cap + 255) / 256), dim3(256), 0, st, ga);
+    if (!pa.prev_sync && P != A) UVO_HIP_TRY(c, hipStreamWaitEvent(st, P->evAS, 0));
+    GatherPair gp;
+    gp.g[0] = GatherArgs{ A->d_matches[0], A->d_matches[1], cn, A->det[0].kps, A->det[1].kps, A->det[0].desc,
+                          A->d_as_kpsL[curr], A->d_as_kpsR[curr], A->d_as_descL[curr], A->desc_dim(), P->d_as_kpsL[prev], P->d_as_kpsR[prev],
+                          A->d_x1, A->d_x2, A->d_xc, (cap + 15) / 16, nullptr };
+    if (!B) {
+        LANE_TRY(match_knn2_two(A, A->det[0].desc, cn + CN_NQA, A->det[1].desc, cn + CN_NR,
+                                P->d_as_descL[prev], P->d_as_n + prev, A->det[0].desc, cn + CN_NL, cap));
+        const GateArgs gate_b = { 1, cn, p.MIN_NUM_FEATURES, cap, A->d_as_n + curr, P->d_as_n + prev };       // VO:567
+        const GateArgs gate_c = { 2, cn, p.MIN_NUM_FEATURES, cap, nullptr, nullptr };                           // VO:626
+        LANE_TRY(match_ratio_compact2(A, ratio, cn + CN_NQA, A->d_matches[0], cn + CN_M, gate_b,
+                                      cn + CN_NQB, A->d_matches[1], cn + CN_TRAW, gate_c, cap, cap));
+        gp.g[1] = gp.g[0];
+    } else {
+        const int currB = B->plan.curr;
+        LANE_TRY(match_two_pairs(A, B, P->d_as_descL[prev], P->d_as_n + prev, P->d_as_n + prev, curr, currB, ratio, p.MIN_NUM_FEATURES));
+        // the second pair's triangular points: rows of the first pair's set, through its stereo matches, from its keypoint lists
+        gp.g[1] = GatherArgs{ B->d_matches[0], B->d_matches[1], B->d_counts, B->det[0].kps, B->det[1].kps, B->det[0].desc,
+                              B->d_as_kpsL[currB], B->d_as_kpsR[currB], B->d_as_descL[currB], B->desc_dim(), A->det[0].kps, A->det[1].kps,
+                              B->d_x1, B->d_x2, B->d_xc, (cap + 15) / 16, A->d_matches[0] };
     }
-    UVO_HIP_TRY(c, hipEventRecord(L->evAS, st));
+    {
+        StageTimer t(A, ST_GATHER);
+        hipLaunchKernelGGL(k_gather_stereo_step, dim3((cap + 15) / 16 + (cap + 255) / 256, B ? 2 : 1), dim3(256), 0, st, gp);
+    }
+    UVO_HIP_TRY(c, hipEventRecord(A->evAS, st));
+    if (B) UVO_HIP_TRY(c, hipEventRecord(B->evAS, st));
     UVO_HIP_TRY(c, hipGetLastError());
     }
     // triangulation + extract_3Dpoints (VO:631-632)
     Range r_tri("uvo:triangulatePoints + extract_3Dpoints");
     const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
-    LANE_TRY(pose_triangulate_extract3d(L, 0, c->P_eye_left, c->P_right, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap,
-                                        L->h_countsA[0]));                                  // the counters land in pinned memory, no copy queued
-    UVO_HIP_TRY(c, hipEventRecord(L->evA[1], st));                                          // end of stage A, for the pacing of later pairs (see uvo_ctx.h)
-    if (tr) UVO_HIP_TRY(c, hipEventRecord(tr->ev[2], st));
+    LANE_TRY(pose_triangulate_extract3d(A, 0, c->P_eye_left, c->P_right, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap,
+                                        A->h_countsA[0], B, B ? B->h_countsA[0] : nullptr));   // the counters land in pinned memory, no copy queued
+    UVO_HIP_TRY(c, hipEventRecord(A->evA[1], st));                                          // end of stage A, for the pacing of later pairs (see uvo_ctx.h)
+    if (B) UVO_HIP_TRY(c, hipEventRecord(B->evA[1], st));
+    if (trA) UVO_HIP_TRY(c, hipEventRecord(trA->ev[2], st));
+    if (trB) UVO_HIP_TRY(c, hipEventRecord(trB->ev[2], st));
     // the first RANSAC round, speculatively, on this stream (pose.hip): the worker wakes once, when the pose is there
     // Taken by the synchronous step only (one pair in flight: 0.80 -> 0.77 ms per pair at C3).  With several pairs in flight the
     // same kernels queued behind a lane's stage A cost the pipeline a quarter of its rate (4370 -> 3200 pairs/s; 4130 on the
     // lane's PnP stream behind a stream wait), so pipelined pairs keep the worker-driven stage.  UVO_PNP_SPEC: 0 never,
     // 1 (default) synchronous steps, 3 / 2 every pair on the lane's stream / its PnP stream (measurement only).
     static const int spec_env = getenv("UVO_PNP_SPEC") ? atoi(getenv("UVO_PNP_SPEC")) : 1;
-    L->spec_queued = (spec_env >= 2 || (spec_env == 1 && c->in_sync_step)) && !c->timing && p.ITERATIONS_COUNT >= 1;
+    A->spec_queued = !B && (spec_env >= 2 || (spec_env == 1 && A->inline_b)) && !c->timing && p.ITERATIONS_COUNT >= 1;
+    if (B) B->spec_queued = false;
     hipStream_t sb = st;
-    if (L->spec_queued && spec_env == 2) { sb = L->pnp_stream; UVO_HIP_TRY(c, hipStreamWaitEvent(sb, L->evA[1], 0)); }
-    if (L->spec_queued) LANE_TRY(pose_pnp_spec_launch(L, sb, c->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE, p.MIN_NUM_3DPOINTS));
-    UVO_HIP_TRY(c, hipEventRecord(L->evA[0], sb));                                          // what the lane's worker waits for
-    // state carry VO:727-733: this pair's set is the next pair's "prev"
-    L->as_w = curr ^ 1;
-    c->prev_lane = li; c->prev_buf = curr; c->prev_sync = false;
-    c->next_lane = (li + 1) % depth;
-    c->inflight[c->n_pending++] = li; c->n_submitted++;
-    L->inline_b = c->in_sync_step;
-    if (tr) tr->host_us[2] = uvo::now_us();
-    if (L->inline_b) {
-        // the synchronous step waits for its own pair: the calling thread polls the stream's end itself and finishes stage B inline
-        // (no worker wake-up, no condition variable: two thread hand-overs less on the pair's critical path)
-        UVO_HIP_TRY(c, hipEventRecord(L->evSync, sb));
-        L->job.kind = 0;
-    } else {   // hand stage B to the lane's worker
-        { std::lock_guard<std::mutex> lk(L->mu); L->job.kind = 0; L->job.state = 1; }
-        L->cv.notify_all();
+    if (A->spec_queued && spec_env == 2) { sb = A->pnp_stream; UVO_HIP_TRY(c, hipStreamWaitEvent(sb, A->evA[1], 0)); }
+    if (A->spec_queued) LANE_TRY(pose_pnp_spec_launch(A, sb, c->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE, p.MIN_NUM_3DPOINTS));
+    UVO_HIP_TRY(c, hipEventRecord(A->evA[0], sb));                                          // what the lane's worker waits for
+    if (B) UVO_HIP_TRY(c, hipEventRecord(B->evA[0], sb));
+    if (trA) trA->host_us[2] = uvo::now_us();
+    if (trB) trB->host_us[2] = uvo::now_us();
+    uvo_ctx* both[2] = { A, B };
+    for (uvo_ctx* L : both) {
+        if (!L) continue;
+        if (L->inline_b) {
+            // the synchronous step waits for its own pair: the calling thread polls the stream's end itself and finishes stage B inline
+            // (no worker wake-up, no condition variable: two thread hand-overs less on the pair's critical path)
+            UVO_HIP_TRY(c, hipEventRecord(L->evSync, sb));
+            L->job.kind = 0;
+        } else {   // hand stage B to the lane's worker
+            { std::lock_guard<std::mutex> lk(L->mu); L->job.kind = 0; L->job.state = 1; }
+            L->cv.notify_all();
+        }
     }
     seg(11);                                                                               // matcher .. extract_3Dpoints launches, hand-over
-    if (uvo::g_bdbg) { uvo::g_bstat[6] += uvo::now_us() - t_sub; uvo::g_bstat[7] += 1; }
+    if (uvo::g_bdbg) { uvo::g_bstat[6] += uvo::now_us() - t_sub; uvo::g_bstat[7] += B ? 2 : 1; }
     return UVO_OK;
 #undef LANE_TRY
 }
@@ -1153,6 +1234,10 @@ extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_resul
     uvo_ctx* L = static_cast<uvo_ctx*>(c->lanes[li]);
     c->last_lane = li;
     L->pending.used = false;
+    if (c->stashed_lane == li) {                               // the pair was waiting for a partner that has not come: it goes alone, now
+        const uvo_status qs = queue_stage_a(c, L, nullptr);
+        if (qs != UVO_OK) return qs;
+    }
     if (L->inline_b) {
         L->inline_b = false;
         run_stage_b(L, hipEventSynchronize(L->evSync) == hipSuccess);

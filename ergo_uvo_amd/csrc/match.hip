@@ -86,7 +86,7 @@ template <int D> static constexpr size_t match_rows_lds() { return sizeof(uint4)
 // part: [chunk][cap] (k0, k1, k2, k3): the four smallest shortlist keys; tnmax[chunk]: max |t|^2 of the chunk's rows
 struct MatchProb { const float* dq; const int* nq_p; int nq_imm; const float* dt; const int* nt_p; int nt_imm;
                    float4* part; float* tnmax; int* knn_idx; float* knn_dist; };
-struct MatchBatch { MatchProb p[2]; int cap; };
+struct MatchBatch { MatchProb p[4]; int cap; };      // up to four problems: the two matches of two consecutive pairs (two-pair launch)
 
 template <int D>
 __global__ __launch_bounds__(256) void k_match_mfma(MatchBatch mb)
@@ -349,8 +349,11 @@ __global__ __launch_bounds__(256) void k_match_resolve(MatchBatch mb)
 
 // ratio test + ordered compaction, one workgroup of 1024 threads; with two problems they are compacted one after the other (the
 // second's query count is the one the first's gate has just written: VO:567 decides whether the triangular matches are used)
-struct CompactProb { const int* knn_idx; const float* knn_dist; const int* nq_p; int nq_imm; uvo_dmatch* out; int* nout; int out_cap; GateArgs g; };
-struct CompactBatch { CompactProb p[2]; int np; float ratio; };
+// qmap (two-pair launch, the second pair's triangular match): query row q of the compaction is row qmap[q].queryIdx of the matcher's
+// query set -- the matcher ran on ALL left descriptors of the pair before (its "after stereo match" set is the subsequence its stereo
+// matches select, which did not exist yet when the launch was queued); a row's two nearest neighbours do not depend on the other rows.
+struct CompactProb { const int* knn_idx; const float* knn_dist; const int* nq_p; int nq_imm; uvo_dmatch* out; int* nout; int out_cap; GateArgs g; const uvo_dmatch* qmap; };
+struct CompactBatch { CompactProb p[4]; int np; float ratio; };
 __global__ __launch_bounds__(1024) void k_match_compact(CompactBatch cb)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -367,8 +370,9 @@ __global__ __launch_bounds__(1024) void k_match_compact(CompactBatch cb)
             int q = base + tid;
             bool keep = false; int i0 = -1; float d0 = 0.f;
             if (q < nq) {
-                i0 = knn_idx[2*q]; int i1 = knn_idx[2*q + 1];
-                d0 = knn_dist[2*q]; float d1 = knn_dist[2*q + 1];
+                const int r = P.qmap ? P.qmap[q].queryIdx : q;
+                i0 = knn_idx[2*r]; int i1 = knn_idx[2*r + 1];
+                d0 = knn_dist[2*r]; float d1 = knn_dist[2*r + 1];
                 keep = i0 >= 0 && i1 >= 0 && d0 < ratio * d1;
             }
             unsigned long long bal = __ballot(keep);
@@ -431,7 +435,7 @@ static uvo_status match_launch(Ctx* c, const MatchBatch& mb, int np, int nq_max,
         // VGPRs, three waves per SIMD, fewer resident workgroups than tiles, 20.3).  Measured without effect: the four 32-row
         // blocks of a chunk unrolled two at a time (22.5 us before the grid change; all four: 155 VGPRs, two waves per SIMD, 24.7).
         static const int gtot = getenv("UVO_MATCH_GRID") ? atoi(getenv("UVO_MATCH_GRID")) : 1152;
-        const int gmax = gtot / np;
+        const int gmax = (np > 2 ? 2 * gtot : gtot) / np;      // four problems (two-pair launch): twice the tiles
         dim3 grid(tiles_max < gmax ? tiles_max : gmax, np);
         static bool attr_dev[64] = {false};                   // more than 64 KB of LDS (D = 128) has to be asked for, once per device
         bool& attr_set = attr_dev[c->device & 63];
@@ -456,7 +460,7 @@ uvo_status match_knn2(Ctx* c, const float* d_q, const int* d_nq, int nq_max, con
     if (nq_max <= 0 || nt_max <= 0) return UVO_OK;
     if (nq_max > c->cap || nt_max > c->cap) { c->err = "match: descriptor count exceeds the context's max_kpts"; return UVO_CAPACITY; }
     MatchBatch mb;
-    mb.p[0] = mb.p[1] = make_prob(c, 0, d_q, d_nq, nq_max, d_t, d_nt, nt_max); mb.cap = c->cap;
+    mb.p[0] = mb.p[1] = mb.p[2] = mb.p[3] = make_prob(c, 0, d_q, d_nq, nq_max, d_t, d_nt, nt_max); mb.cap = c->cap;
     return c->desc_dim() == 128 ? match_launch<128>(c, mb, 1, nq_max, nt_max) : match_launch<64>(c, mb, 1, nq_max, nt_max);
 }
 
@@ -470,8 +474,42 @@ uvo_status match_knn2_two(Ctx* c, const float* d_q0, const int* d_nq0, const flo
     MatchBatch mb;
     mb.p[0] = make_prob(c, 0, d_q0, d_nq0, n_max, d_t0, d_nt0, n_max);
     mb.p[1] = make_prob(c, 1, d_q1, d_nq1, n_max, d_t1, d_nt1, n_max);
+    mb.p[2] = mb.p[3] = mb.p[0];
     mb.cap = c->cap;
     return c->desc_dim() == 128 ? match_launch<128>(c, mb, 2, n_max, n_max) : match_launch<64>(c, mb, 2, n_max, n_max);
+}
+
+// The four matches of two consecutive pairs (lanes a, b of one stream; pair b follows pair a) in one launch each of the shortlist and
+// resolve kernels, then their ratio tests, gates and ordered compactions in one launch (k_match_compact, in dependency order):
+//   a: stereo L_a -> R_a, triangular prev-set -> L_a           (as match_knn2_two / match_ratio_compact2 for lane a)
+//   b: stereo L_b -> R_b, triangular over ALL rows of L_a -> L_b, compacted through a's stereo matches (CompactProb::qmap): row i
+//      of a's "after stereo match" set is row m_a[i].queryIdx of L_a, and that set's length is what a's gate (VO:567) has just written.
+// Kernels go to a's stream; each lane's results land in its own shortlist / kNN / match buffers.
+uvo_status match_two_pairs(Ctx* a, Ctx* b, const float* d_prev_desc, const int* d_prev_n, const int* d_prev_as_n, int curr_a, int curr_b,
+                           float ratio, int min_features)
+{
+    const int cap = a->cap;
+    int* ca = a->d_counts; int* cbn = b->d_counts;
+    MatchBatch mb;
+    mb.p[0] = make_prob(a, 0, a->det[0].desc, ca + CN_NQA, cap, a->det[1].desc, ca + CN_NR, cap);
+    mb.p[1] = make_prob(a, 1, d_prev_desc, d_prev_n, cap, a->det[0].desc, ca + CN_NL, cap);
+    mb.p[2] = make_prob(b, 0, b->det[0].desc, cbn + CN_NQA, cap, b->det[1].desc, cbn + CN_NR, cap);
+    mb.p[3] = make_prob(b, 1, a->det[0].desc, ca + CN_NL, cap, b->det[0].desc, cbn + CN_NL, cap);
+    mb.cap = cap;
+    UVO_TRY(a->desc_dim() == 128 ? match_launch<128>(a, mb, 4, cap, cap) : match_launch<64>(a, mb, 4, cap, cap));
+    CompactBatch cb;
+    const GateArgs ga1 = { 1, ca, min_features, cap, a->d_as_n + curr_a, d_prev_as_n };            // VO:567, pair a
+    const GateArgs ga2 = { 2, ca, min_features, cap, nullptr, nullptr };                            // VO:626
+    const GateArgs gb1 = { 1, cbn, min_features, cap, b->d_as_n + curr_b, a->d_as_n + curr_a };     // pair b: its "previous" set is a's
+    const GateArgs gb2 = { 2, cbn, min_features, cap, nullptr, nullptr };
+    cb.p[0] = CompactProb{ mb.p[0].knn_idx, mb.p[0].knn_dist, ca + CN_NQA, cap, a->d_matches[0], ca + CN_M, cap, ga1, nullptr };
+    cb.p[1] = CompactProb{ mb.p[1].knn_idx, mb.p[1].knn_dist, ca + CN_NQB, cap, a->d_matches[1], ca + CN_TRAW, cap, ga2, nullptr };
+    cb.p[2] = CompactProb{ mb.p[2].knn_idx, mb.p[2].knn_dist, cbn + CN_NQA, cap, b->d_matches[0], cbn + CN_M, cap, gb1, nullptr };
+    cb.p[3] = CompactProb{ mb.p[3].knn_idx, mb.p[3].knn_dist, cbn + CN_NQB, cap, b->d_matches[1], cbn + CN_TRAW, cap, gb2, a->d_matches[0] };
+    cb.np = 4; cb.ratio = ratio;
+    hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(1024), 0, a->stream, cb);
+    UVO_HIP_TRY(a, hipGetLastError());
+    return UVO_OK;
 }
 
 uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio, uvo_dmatch* d_out, int* d_nout, int out_cap,
@@ -481,8 +519,8 @@ uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio,
     CompactBatch cb;
     GateArgs g = { 0, nullptr, 0, 0, nullptr, nullptr };
     if (gate) g = *gate;
-    cb.p[0] = CompactProb{ c->d_knn_idx, c->d_knn_dist, d_nq, nq_max, d_out, d_nout, out_cap, g };
-    cb.p[1] = cb.p[0]; cb.np = 1; cb.ratio = ratio;
+    cb.p[0] = CompactProb{ c->d_knn_idx, c->d_knn_dist, d_nq, nq_max, d_out, d_nout, out_cap, g, nullptr };
+    cb.p[1] = cb.p[2] = cb.p[3] = cb.p[0]; cb.np = 1; cb.ratio = ratio;
     hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(1024), 0, c->stream, cb);
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
@@ -494,8 +532,9 @@ uvo_status match_ratio_compact2(Ctx* c, float ratio, const int* d_nq0, uvo_dmatc
 {
     StageTimer t(c, ST_MATCH_MERGE);
     CompactBatch cb;
-    cb.p[0] = CompactProb{ c->d_knn_idx, c->d_knn_dist, d_nq0, n_max, d_out0, d_nout0, out_cap, g0 };
-    cb.p[1] = CompactProb{ c->d_knn_idx + (size_t)2 * c->cap, c->d_knn_dist + (size_t)2 * c->cap, d_nq1, n_max, d_out1, d_nout1, out_cap, g1 };
+    cb.p[0] = CompactProb{ c->d_knn_idx, c->d_knn_dist, d_nq0, n_max, d_out0, d_nout0, out_cap, g0, nullptr };
+    cb.p[1] = CompactProb{ c->d_knn_idx + (size_t)2 * c->cap, c->d_knn_dist + (size_t)2 * c->cap, d_nq1, n_max, d_out1, d_nout1, out_cap, g1, nullptr };
+    cb.p[2] = cb.p[3] = cb.p[0];
     cb.np = 2; cb.ratio = ratio;
     hipLaunchKernelGGL(k_match_compact, dim3(1), dim3(1024), 0, c->stream, cb);
     UVO_HIP_TRY(c, hipGetLastError());

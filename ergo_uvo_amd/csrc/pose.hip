@@ -61,10 +61,17 @@ __device__ __forceinline__ void extract3d_point(const float4 p, const uvo_point2
 
 // FILTER: the loops call triangulatePoints and extract_3Dpoints back to back on the same point pairs (VO:631-632, VO:355-356);
 // the per-point part of the latter then runs on the point just triangulated instead of in a launch of its own
+// per-lane arguments of the two kernels below: blockIdx.y selects the lane in a two-pair launch (uvo_stereo_submit, batch mode)
+struct TriLane { const uvo_point2f* x1; const uvo_point2f* x2; const int* n_p; float4* out; double* cam1; int* flag; };
+struct TriLanes { TriLane l[2]; };
+struct Ex3Lane { const double* cam1; const int* flag; const uvo_point2f* xc; const int* n_p; int* tmp_idx; double* good_pts; int* good_idx; float* opts;
+                 uvo_point2f* ipts; int* counts /* [1] = G */; int* counts_host /* pinned mirror of all the step's counters, or null */; };
+struct Ex3Lanes { Ex3Lane l[2]; };
 template <bool FILTER>
-__global__ __launch_bounds__(kTriThreads) void k_triangulate(Mat34 P1, Mat34 P2, const uvo_point2f* x1, const uvo_point2f* x2,
-                                                             const int* n_p, int n_imm, float4* out, Cam c1, Cam c2, double tol, double* cam1, int* flag)
+__global__ __launch_bounds__(kTriThreads) void k_triangulate(Mat34 P1, Mat34 P2, TriLanes lanes, int n_imm, Cam c1, Cam c2, double tol)
 {
+    const TriLane& LN = lanes.l[blockIdx.y];
+    const uvo_point2f* x1 = LN.x1; const uvo_point2f* x2 = LN.x2; const int* n_p = LN.n_p; float4* out = LN.out; double* cam1 = LN.cam1; int* flag = LN.flag;
     const int n = n_p ? *n_p : n_imm;
     const int i = blockIdx.x * kTriThreads + threadIdx.x;
     __shared__ double lds[(16 + 16 + 16 + 4 + 4) * kTriThreads];
@@ -126,12 +133,11 @@ __device__ __forceinline__ int block_compact_pos(bool keep, int* wtot, int* s_ba
 
 // stage B (one workgroup): first compaction, mean/variance of z in index order, +-3 sigma filter,
 // second compaction; also gathers the PnP inputs (float object points, current-image points).
-__global__ __launch_bounds__(1024) void k_extract3d_b(const double* cam1, const int* flag, const uvo_point2f* xc,
-                                                      const int* n_p, int n_imm, int min_pts,
-                                                      int* tmp_idx, double* good_pts, int* good_idx, float* opts, uvo_point2f* ipts,
-                                                      int* counts /* [1] = G */, int* counts_host /* pinned mirror of all the step's counters, or null */,
-                                                      int force_seq /* always take the ordered sums (test hook) */)
+__global__ __launch_bounds__(1024) void k_extract3d_b(Ex3Lanes lanes, int n_imm, int min_pts, int force_seq /* always take the ordered sums (test hook) */)
 {
+    const Ex3Lane& LN = lanes.l[blockIdx.y];
+    const double* cam1 = LN.cam1; const int* flag = LN.flag; const uvo_point2f* xc = LN.xc; const int* n_p = LN.n_p; int* tmp_idx = LN.tmp_idx;
+    double* good_pts = LN.good_pts; int* good_idx = LN.good_idx; float* opts = LN.opts; uvo_point2f* ipts = LN.ipts; int* counts = LN.counts; int* counts_host = LN.counts_host;
     const int n = n_p ? *n_p : n_imm;
     const int tid = threadIdx.x;
     // the last kernel of the loops' device stage: it leaves the counters where the host reads them (no copy to queue behind it)
@@ -633,32 +639,39 @@ __global__ __launch_bounds__(kFastThreads) void k_pnp_refit_spec(PnpSpecArgs a)
 // ---------------------------------------------------------------- host orchestration
 static Cam make_cam(const double* R, const double* t, const double* K);
 static int extract3d_force_seq() { const char* e = getenv("UVO_EXTRACT3D_SEQ"); return e && atoi(e) != 0; }      // read per call: tests flip it
+static TriLane tri_lane(Ctx* c, const int* d_n, bool filter) { return TriLane{ c->d_x1, c->d_x2, d_n, c->d_pts4, filter ? c->d_cam1 : nullptr, filter ? c->d_flag : nullptr }; }
+static Ex3Lane ex3_lane(Ctx* c, int slot, const int* d_n, int* counts_host)
+{
+    return Ex3Lane{ c->d_cam1, c->d_flag, c->d_xc, d_n, c->d_tmp_idx, c->d_good_pts[slot], c->d_good_idx[slot], c->d_opts[slot], c->d_ipts[slot], c->d_counts, counts_host };
+}
 uvo_status pose_triangulate(Ctx* c, const double* P1, const double* P2, const int* d_n, int n_max)
 {
     if (n_max <= 0) return UVO_OK;
     Mat34 a, b; memcpy(a.v, P1, sizeof(a.v)); memcpy(b.v, P2, sizeof(b.v));
     StageTimer t(c, ST_TRIANGULATE);
-    hipLaunchKernelGGL(k_triangulate<false>, dim3((n_max + kTriThreads - 1) / kTriThreads), dim3(kTriThreads), 0, c->stream,
-                       a, b, c->d_x1, c->d_x2, d_n, n_max, c->d_pts4, Cam(), Cam(), 0.0, nullptr, nullptr);
+    TriLanes tl; tl.l[0] = tl.l[1] = tri_lane(c, d_n, false);
+    hipLaunchKernelGGL(k_triangulate<false>, dim3((n_max + kTriThreads - 1) / kTriThreads), dim3(kTriThreads), 0, c->stream, a, b, tl, n_max, Cam(), Cam(), 0.0);
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }
-// triangulatePoints + extract_3Dpoints on the same point pairs (d_x1, d_x2), as both loops call them: two launches instead of three
+// triangulatePoints + extract_3Dpoints on the same point pairs (d_x1, d_x2), as both loops call them: two launches instead of three.
+// c2 != nullptr: the same for a second lane's pair in the same two launches (its count is c2's CN_T, its mirror counts_host2); the
+// kernels go to c's stream.
 uvo_status pose_triangulate_extract3d(Ctx* c, int slot, const double* P1, const double* P2, const double* R1, const double* t1,
                                       const double* R2, const double* t2, const double* K1, const double* K2, const int* d_n, int n_max,
-                                      int* counts_host)
+                                      int* counts_host, Ctx* c2, int* counts_host2)
 {
+    const int nl = c2 ? 2 : 1;
     if (n_max > 0) {
         Mat34 a, b; memcpy(a.v, P1, sizeof(a.v)); memcpy(b.v, P2, sizeof(b.v));
         StageTimer t(c, ST_TRIANGULATE);
-        hipLaunchKernelGGL(k_triangulate<true>, dim3((n_max + kTriThreads - 1) / kTriThreads), dim3(kTriThreads), 0, c->stream,
-                           a, b, c->d_x1, c->d_x2, d_n, n_max, c->d_pts4, make_cam(R1, t1, K1), make_cam(R2, t2, K2),
-                           c->p.REPROJECTION_TOLERANCE, c->d_cam1, c->d_flag);
+        TriLanes tl; tl.l[0] = tri_lane(c, d_n, true); tl.l[1] = c2 ? tri_lane(c2, c2->d_counts + CN_T, true) : tl.l[0];
+        hipLaunchKernelGGL(k_triangulate<true>, dim3((n_max + kTriThreads - 1) / kTriThreads, nl), dim3(kTriThreads), 0, c->stream,
+                           a, b, tl, n_max, make_cam(R1, t1, K1), make_cam(R2, t2, K2), c->p.REPROJECTION_TOLERANCE);
     }
     StageTimer t(c, ST_EXTRACT3D);
-    hipLaunchKernelGGL(k_extract3d_b, dim3(1), dim3(1024), 0, c->stream, c->d_cam1, c->d_flag, c->d_xc, d_n, n_max,
-                       c->p.MIN_NUM_3DPOINTS, c->d_tmp_idx, c->d_good_pts[slot], c->d_good_idx[slot], c->d_opts[slot], c->d_ipts[slot],
-                       c->d_counts, counts_host, extract3d_force_seq());
+    Ex3Lanes el; el.l[0] = ex3_lane(c, slot, d_n, counts_host); el.l[1] = c2 ? ex3_lane(c2, slot, c2->d_counts + CN_T, counts_host2) : el.l[0];
+    hipLaunchKernelGGL(k_extract3d_b, dim3(1, nl), dim3(1024), 0, c->stream, el, n_max, c->p.MIN_NUM_3DPOINTS, extract3d_force_seq());
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }
@@ -679,9 +692,8 @@ uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, 
         hipLaunchKernelGGL(k_extract3d_a, dim3((n_max + 255) / 256), dim3(256), 0, c->stream, c->d_pts4, c->d_x1, c->d_x2,
                            make_cam(R1, t1, K1), make_cam(R2, t2, K2), c->p.REPROJECTION_TOLERANCE, d_n, n_max, c->d_cam1, c->d_flag);
     }
-    hipLaunchKernelGGL(k_extract3d_b, dim3(1), dim3(1024), 0, c->stream, c->d_cam1, c->d_flag, c->d_xc, d_n, n_max,
-                       c->p.MIN_NUM_3DPOINTS, c->d_tmp_idx, c->d_good_pts[slot], c->d_good_idx[slot], c->d_opts[slot], c->d_ipts[slot],
-                       c->d_counts, counts_host, extract3d_force_seq());
+    Ex3Lanes el; el.l[0] = el.l[1] = ex3_lane(c, slot, d_n, counts_host);
+    hipLaunchKernelGGL(k_extract3d_b, dim3(1), dim3(1024), 0, c->stream, el, n_max, c->p.MIN_NUM_3DPOINTS, extract3d_force_seq());
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }

@@ -29,6 +29,25 @@ namespace uvo {
 // S[4i + ry][4j + rx] at [i][j].  The step-4 / step-8 sample walks of octaves 2 and 3 become unit / two-element
 // strides in them (coalesced), where the row-major image gives one useful word per 16 or 32 bytes.
 struct ImgPair { const uint8_t* img[2]; int32_t* sum[2]; int32_t* planes[2]; int pw, pstride; int* cand_n; int* big_n; int* surv_n; };
+struct AreaTab;
+struct CandOut { uvo_keypoint* cand[2]; int* count; int cap; };
+struct SurvOut { Survivor* list; int* count; int cap; };
+struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* out[2]; int* out_n[2]; int* rank; int cap;
+                  int4* big_par; int* big_n; int* gate_nqa; int gate_min_features; };
+struct DescArgs { const uint8_t* img[2]; uvo_keypoint* kps[2]; float* desc[2]; const int* n[2]; const float* DW;
+                  const int4* big_par; const int* big_n; const int* big_large; int cap;
+                  const AreaTab* tabs; const int* iscale;        // [kMaxWin + 1][21] resize tables, [kMaxWin + 1] integer scale (0: general path)
+                  int extended;                                  // SURF_EXTENDED: 128 elements per descriptor row (8 sums per cell)
+                  const int32_t* sum[2]; const float* ori_w; int* ori_drop; };   // orientation assignment (SURF_UPRIGHT = false): integral images, sample weights
+// Everything of the detector that belongs to ONE pipeline lane (one stereo pair: two images).  Every kernel of the stage takes a
+// LanePair and indexes it with the high bit of its image index -- blockIdx.y (or .z / .x where the kernel counts images there)
+// runs over 2 * nimg in a two-pair launch: the detector stages of two consecutive pairs of the stream, on two lanes' buffers, in
+// ONE launch each (uvo_stereo_submit, batch mode: the thin kernels -- scans, rank sort, finish passes -- take as long for four
+// images as for two).  A single pair is a LanePair whose entries are the same.
+struct LaneArgs { ImgPair ip; int32_t* part; SurvOut sv; CandOut out; SortArgs sa; DescArgs da; uint8_t* patch; const int4* big_in; int4* big_out; int* big_large; };
+struct LanePair { LaneArgs a[2]; };
+#define UVO_LANE_IM(idx) ((int)(idx) & 1)
+#define UVO_LANE_OF(lp, idx) ((lp).a[(int)(idx) >> 1])
 // The integral image in three launches that move 4 + 4 + 33 MB for a 1080p pair (image twice, result once):
 //   k_integral_strip_sums   a workgroup per strip of 8 image rows: row prefixes in registers, their column sums over the strip
 //   k_integral_strip_scan   exclusive scan of those sums over the strips (a 135 x 1921 matrix at 1080p)
@@ -88,9 +107,10 @@ __device__ __forceinline__ void strip_row_prefix(const uint8_t* img, int w, int 
 }
 __device__ __forceinline__ int packed_px(unsigned lo, unsigned hi, int k) { return (int)(((k < 4 ? lo : hi) >> (8 * (k & 3))) & 255u); }
 
-__global__ __launch_bounds__(256) void k_integral_strip_sums(ImgPair ip, int w, int h, int32_t* part, int cstride, int nstrip)
+__global__ __launch_bounds__(256) void k_integral_strip_sums(LanePair lp, int w, int h, int cstride, int nstrip)
 {
-    const int strip = blockIdx.x, im = blockIdx.y, tid = threadIdx.x;
+    const LaneArgs& LA = UVO_LANE_OF(lp, blockIdx.y); const ImgPair& ip = LA.ip; int32_t* part = LA.part;
+    const int strip = blockIdx.x, im = UVO_LANE_IM(blockIdx.y), tid = threadIdx.x;
     __shared__ int wt[kStripRows][4];
     int carry[kStripRows];
 #pragma unroll
@@ -114,9 +134,10 @@ __global__ __launch_bounds__(256) void k_integral_strip_sums(ImgPair ip, int w, 
 }
 
 // part[im][s][x] <- sum of part[im][0 .. s-1][x]: 32 columns x 8 groups of strips per workgroup
-__global__ __launch_bounds__(256) void k_integral_strip_scan(int32_t* part, int cstride, int nstrip, int w)
+__global__ __launch_bounds__(256) void k_integral_strip_scan(LanePair lp, int cstride, int nstrip, int w)
 {
-    const int tid = threadIdx.x, xl = tid & 31, g = tid >> 5, x = blockIdx.x * 32 + xl, im = blockIdx.y;
+    int32_t* part = UVO_LANE_OF(lp, blockIdx.y).part;
+    const int tid = threadIdx.x, xl = tid & 31, g = tid >> 5, x = blockIdx.x * 32 + xl, im = UVO_LANE_IM(blockIdx.y);
     __shared__ int gsum[8][32];
     const int per = (nstrip + 7) / 8, s0 = g * per, s1 = min(nstrip, s0 + per);
     int32_t* p = part + (size_t)im * nstrip * cstride + x;
@@ -133,9 +154,10 @@ __global__ __launch_bounds__(256) void k_integral_strip_scan(int32_t* part, int 
     for (int sI = s0; sI < s1; sI++) { const int v = p[(size_t)sI * cstride]; p[(size_t)sI * cstride] = acc; acc += v; }
 }
 
-__global__ __launch_bounds__(256) void k_integral_strip_final(ImgPair ip, int w, int h, const int32_t* part, int cstride, int nstrip)
+__global__ __launch_bounds__(256) void k_integral_strip_final(LanePair lp, int w, int h, int cstride, int nstrip)
 {
-    const int strip = blockIdx.x, im = blockIdx.y, tid = threadIdx.x;
+    const LaneArgs& LA = UVO_LANE_OF(lp, blockIdx.y); const ImgPair& ip = LA.ip; const int32_t* part = LA.part;
+    const int strip = blockIdx.x, im = UVO_LANE_IM(blockIdx.y), tid = threadIdx.x;
     const int sw = w + 1, y0 = strip * kStripRows;
     __shared__ int wt[kStripRows][4];
     __shared__ __align__(16) int rowbuf[kStripRows / 2][kStripCols];
@@ -290,7 +312,6 @@ __device__ __forceinline__ void solve3f(const float a[3][3], const float b[3], f
               b[0]*(a[1][0]*a[2][1] - a[1][1]*a[2][0]));
 }
 
-struct CandOut { uvo_keypoint* cand[2]; int* count; int cap; };
 
 // findMaximaInLayer's tail for one 3x3x3 maximum: centre, interpolateKeypoint, SURFInvoker's size check
 // (the caller appends).  `trace` is dx + dy of the centre sample.
@@ -538,7 +559,6 @@ __device__ __forceinline__ void det_layer_p(const int32_t* __restrict__ planes, 
 // out of the detection kernels also keeps them at ~60 VGPRs.  The comparisons made are the same ones, so the keypoints
 // are the same.
 // ------------------------------------------------------------------------------------------
-struct SurvOut { Survivor* list; int* count; int cap; };
 
 // LDS of nms_survivors: the workgroup's survivor list, its length and its base in the global list.  Survivors are strict 3 x 3
 // maxima of their own layer, so no two are adjacent: at most ceil((TW-2)/2) x ceil((TH-2)/2) per layer, in three layers.
@@ -609,8 +629,9 @@ __device__ __forceinline__ void nms_survivors(const float* __restrict__ sdet, un
 // arithmetic, as k_hessian_layer_debug); lane 0 makes the comparison against them and runs findMaximaInLayer's tail.  The
 // workgroup's keypoints are collected in LDS and appended with one atomic per image.
 static const int kFinishPerWg = 16;
-__global__ __launch_bounds__(256) void k_hessian_finish(SurvOut sv, const OctavePat* __restrict__ ops, ImgPair ip, int w, int h, CandOut out)
+__global__ __launch_bounds__(256) void k_hessian_finish(LanePair lp, const OctavePat* __restrict__ ops, int w, int h)
 {
+    const LaneArgs& LA = lp.a[blockIdx.y]; const SurvOut& sv = LA.sv; const ImgPair& ip = LA.ip; const CandOut& out = LA.out;
     __shared__ uvo_keypoint s_kp[2][kFinishPerWg];
     __shared__ int s_cnt[2], s_base[2];
     const int grp = threadIdx.x >> 4, k = threadIdx.x & 15;
@@ -755,19 +776,21 @@ __device__ __forceinline__ void hessian_nms_c_tile(const ImgPair& ip, int w, int
     nms_survivors<TW, TH, NT>(sdet, reinterpret_cast<unsigned*>(stile + THs * STEP * PW), op, thr, px0, py0, im, sv);
 }
 template <int O, int TW, int TH, int NT>
-__global__ __launch_bounds__(NT) void k_hessian_nms_c(ImgPair ip, int w, int h, OctavePat op, float thr, SurvOut sv)
+__global__ __launch_bounds__(NT) void k_hessian_nms_c(LanePair lp, int w, int h, OctavePat op, float thr)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    hessian_nms_c_tile<O, TW, TH, NT>(ip, w, h, op, thr, sv, blockIdx.x, blockIdx.y, blockIdx.z, smem);
+    const LaneArgs& LA = UVO_LANE_OF(lp, blockIdx.z);
+    hessian_nms_c_tile<O, TW, TH, NT>(LA.ip, w, h, op, thr, LA.sv, blockIdx.x, blockIdx.y, UVO_LANE_IM(blockIdx.z), smem);
 }
 
 // Octaves 2 and 3: det layers from the de-interleaved planes, det planes in LDS, survivors as above.
 template <int O, int TW, int TH, int NT>
-__global__ __launch_bounds__(NT) void k_hessian_nms_p(ImgPair ip, int w, int h, OctavePat op, float thr, SurvOut sv)
+__global__ __launch_bounds__(NT) void k_hessian_nms_p(LanePair lp, int w, int h, OctavePat op, float thr)
 {
     __shared__ float sdet[3 * TH * TW];
     __shared__ unsigned s_list[NmsLds<TW, TH>::kWords];
-    const int im = blockIdx.z;
+    const LaneArgs& LA = UVO_LANE_OF(lp, blockIdx.z); const ImgPair& ip = LA.ip; const SurvOut& sv = LA.sv;
+    const int im = UVO_LANE_IM(blockIdx.z);
     const int px0 = blockIdx.x * (TW - 2) - 1, py0 = blockIdx.y * (TH - 2) - 1;
     det_layer_p<O, 1, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0, thr);
     det_layer_p<O, 2, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0, thr);
@@ -811,11 +834,12 @@ static const int kP23SdetFloats = 3 * 16 * 32;
 // patterns come from the device copy of the table (four of them exceed the 4 KB of kernel arguments).
 static const int kO1TileRows = 18;             // sample rows of an octave-1 tile in the merged launch
 template <int TW, int TH>
-__global__ __launch_bounds__(kP23Threads) void k_hessian_nms_all(ImgPair ip, int w, int h, const OctavePat* __restrict__ ops, float thr, SurvOut sv,
+__global__ __launch_bounds__(kP23Threads) void k_hessian_nms_all(LanePair lp, int w, int h, const OctavePat* __restrict__ ops, float thr,
                                                                  const uint16_t* __restrict__ order, int nbx0, int nbx1, P23Grid g)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int im = blockIdx.y;
+    const LaneArgs& LA = UVO_LANE_OF(lp, blockIdx.y); const ImgPair& ip = LA.ip; const SurvOut& sv = LA.sv;
+    const int im = UVO_LANE_IM(blockIdx.y);
     const unsigned e = order[blockIdx.x];
     const int kind = e >> 14, idx = e & 0x3FFF;
     if (kind == 0) hessian_nms_c_tile<0, TW, TH, kP23Threads>(ip, w, h, ops[0], thr, sv, idx % nbx0, idx / nbx0, im, smem);
@@ -863,8 +887,6 @@ __device__ __forceinline__ SortKey make_sort_key(const uvo_keypoint& kp)
     return k;
 }
 
-struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* out[2]; int* out_n[2]; int* rank; int cap;
-                  int4* big_par; int* big_n; int* gate_nqa; int gate_min_features; };
 static const int kSmallWin = 128;       // descriptor windows up to this size use the small-LDS kernel
 static const int kMaxWin = 740;         // (int)(21 * 264 * 1.2f / 9) = 739: the window of the largest octave-3 keypoint
 // Large windows are listed in append order by k_rank_scatter and then sorted by descending window size (a (keypoint,
@@ -872,10 +894,11 @@ static const int kMaxWin = 740;         // (int)(21 * 264 * 1.2f / 9) = 739: the
 // which the task dealing of that kernel relies on.  Counting sort, one workgroup per image.
 static const int kBigBins = 1024;
 static const int kTripleWin = 246;     // windows up to this size: three destination columns per task (3 x 246 floats share the 740-float row buffer)
-__global__ __launch_bounds__(1024) void k_big_sort(const int4* __restrict__ in, int4* __restrict__ out, const int* __restrict__ big_n, int* __restrict__ big_large, int cap,
-                                                   const int* __restrict__ iscale_tab)
+__global__ __launch_bounds__(1024) void k_big_sort(LanePair lp, int cap, const int* __restrict__ iscale_tab)
 {
-    const int im = blockIdx.x, tid = threadIdx.x;
+    const LaneArgs& LA = UVO_LANE_OF(lp, blockIdx.x);
+    const int4* __restrict__ in = LA.big_in; int4* __restrict__ out = LA.big_out; const int* __restrict__ big_n = LA.da.big_n; int* __restrict__ big_large = LA.big_large;
+    const int im = UVO_LANE_IM(blockIdx.x), tid = threadIdx.x;
     const int n = min(big_n[im], cap);
     __shared__ int hist[kBigBins], scan[kBigBins];
     hist[tid] = 0;
@@ -906,9 +929,10 @@ __global__ __launch_bounds__(1024) void k_big_sort(const int4* __restrict__ in, 
 }
 static const int kSortChunk = 128;     // compared-against keypoints per workgroup: small, so that ~600 workgroups share the work
 
-__global__ __launch_bounds__(256) void k_rank_partial(SortArgs a)
+__global__ __launch_bounds__(256) void k_rank_partial(LanePair lp)
 {
-    const int im = blockIdx.y, tid = threadIdx.x;
+    const SortArgs& a = UVO_LANE_OF(lp, blockIdx.y).sa;
+    const int im = UVO_LANE_IM(blockIdx.y), tid = threadIdx.x;
     const int n = min(a.cand_n[im], a.cap);
     __shared__ SortKey tile[kSortChunk];
     __shared__ unsigned long long tile_k1[kSortChunk];
@@ -941,9 +965,10 @@ __global__ __launch_bounds__(256) void k_rank_partial(SortArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void k_rank_scatter(SortArgs a)
+__global__ __launch_bounds__(256) void k_rank_scatter(LanePair lp)
 {
-    const int im = blockIdx.y;
+    const SortArgs& a = UVO_LANE_OF(lp, blockIdx.y).sa;
+    const int im = UVO_LANE_IM(blockIdx.y);
     const int n = min(a.cand_n[im], a.cap);
     const int me = blockIdx.x * 256 + threadIdx.x;
     bool big = false;
@@ -1010,11 +1035,6 @@ __host__ __device__ __forceinline__ AreaTab area_tab(int dx, int ssize, double s
 
 __device__ __forceinline__ uint8_t sat_u8(float v) { int iv = cv_round_f(v); return (uint8_t)(iv < 0 ? 0 : iv > 255 ? 255 : iv); }
 
-struct DescArgs { const uint8_t* img[2]; uvo_keypoint* kps[2]; float* desc[2]; const int* n[2]; const float* DW;
-                  const int4* big_par; const int* big_n; const int* big_large; int cap;
-                  const AreaTab* tabs; const int* iscale;        // [kMaxWin + 1][21] resize tables, [kMaxWin + 1] integer scale (0: general path)
-                  int extended;                                  // SURF_EXTENDED: 128 elements per descriptor row (8 sums per cell)
-                  const int32_t* sum[2]; const float* ori_w; int* ori_drop; };   // orientation assignment (SURF_UPRIGHT = false): integral images, sample weights
 
 // PATCH (21 x 21, shared) -> gradients, 4x4 cells of 4 (extended: 8) sums, normalisation -> row k of a.desc[im]; 256 threads,
 // PATCH already synchronised
@@ -1526,7 +1546,7 @@ __global__ __launch_bounds__(256) void k_descriptor_rot(DescArgs a, int w, int h
 // small windows: one workgroup per keypoint (block bx of nbx of the launch's small-window part)
 __device__ __forceinline__ void descriptor64_small(const DescArgs& a, int w, int h, int bx, int nbx)
 {
-    const int im = blockIdx.y;
+    const int im = UVO_LANE_IM(blockIdx.y);
     const int n = *a.n[im];
     // one workgroup per keypoint when the grid has max_kpts of them (measured faster than a smaller grid walking the list:
     // the hardware hands the next keypoint to whichever CU frees up); the loop covers smaller grids
@@ -1548,7 +1568,7 @@ __device__ __forceinline__ void descriptor64_small(const DescArgs& a, int w, int
 static const int kBigRow = 768;            // floats of row buffer per wave of the large-window part (a 739-pixel window + the 8 floats of slack area_column asks for; 3 x 256 for three-column tasks)
 __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h, uint8_t* __restrict__ patch, int bx, int nbx)
 {
-    const int im = blockIdx.y, lane = threadIdx.x & 63, wv = sgpr_i(threadIdx.x >> 6);
+    const int im = UVO_LANE_IM(blockIdx.y), lane = threadIdx.x & 63, wv = sgpr_i(threadIdx.x >> 6);
     const int nb = a.big_n[im], nl = min(a.big_large[im], nb);        // the sorted list: nl wide windows first
     extern __shared__ __align__(16) unsigned char smem_desc[];        // shared with the small-window part: 4 x kBigRow floats here
     float* bufrow0 = reinterpret_cast<float*>(smem_desc) + wv * kBigRow;
@@ -1695,16 +1715,18 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
 // small-window keypoint each.  The large-window part stalls on its per-tap dependency chains, the small-window part on its
 // barriers; resident together they keep the VALU busier than one after the other (and a launch is saved).
 // (8 waves per SIMD: the compiler would settle at 66 VGPRs = 7 waves)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_descriptor64(DescArgs a, int w, int h, uint8_t* __restrict__ patch, int nbig, int part)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_descriptor64(LanePair lp, int w, int h, int nbig, int part)
 {
+    const LaneArgs& LA = UVO_LANE_OF(lp, blockIdx.y); const DescArgs& a = LA.da; uint8_t* __restrict__ patch = LA.patch;
     // (large-window blocks first: small-window blocks first measured 78 us, alternating blocks 97 us, against 66-68 us)
     // part (UVO_DESC_PART, measurement only -- the other class of keypoints gets no descriptor): 1 = large windows only, 2 = small only
     if ((int)blockIdx.x < nbig) { if (part != 2) descriptor64_big(a, w, h, patch, blockIdx.x, nbig); }
     else if (part != 1) descriptor64_small(a, w, h, blockIdx.x - nbig, gridDim.x - nbig);
 }
-__global__ __launch_bounds__(256) void k_descriptor64_big_finish(DescArgs a, const uint8_t* __restrict__ patch)
+__global__ __launch_bounds__(256) void k_descriptor64_big_finish(LanePair lp)
 {
-    const int im = blockIdx.y, tid = threadIdx.x;
+    const LaneArgs& LA = UVO_LANE_OF(lp, blockIdx.y); const DescArgs& a = LA.da; const uint8_t* __restrict__ patch = LA.patch;
+    const int im = UVO_LANE_IM(blockIdx.y), tid = threadIdx.x;
     const int nb = a.big_n[im];
     __shared__ int PATCH[21][21];
     for (int e = blockIdx.x; e < nb; e += gridDim.x) {
@@ -1768,42 +1790,64 @@ uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int 
     return UVO_OK;
 }
 
-uvo_status surf_integral(Ctx* c, int nimg)
+// what the detector's kernels need of lane c (see LaneArgs); gate_min_features >= 0: the rank scatter also evaluates VO:556
+static LaneArgs lane_args(Ctx* c, int nimg, int gate_min_features)
+{
+    LaneArgs a;
+    a.ip = ImgPair{ { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
+    a.part = c->d_colpart;
+    a.sv = SurvOut{ c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
+    a.out = CandOut{ { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
+    a.sa = SortArgs{ { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, { c->det[0].kps, c->det[1].kps }, { c->det[0].n, c->det[1].n }, c->d_rank, c->cap, c->d_big_par, c->d_big_n,
+                     gate_min_features >= 0 && nimg == 2 ? c->d_counts + CN_NQA : nullptr, gate_min_features };
+    a.da = DescArgs{ { c->img[0], c->img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc }, { c->det[0].n, c->det[1].n }, c->d_DW,
+                     c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap,      // the sorted list
+                     c->d_area_tabs, c->d_area_iscale, c->p.SURF_EXTENDED ? 1 : 0, { c->d_sum[0], c->d_sum[1] }, c->d_ori_w, c->d_counts + CN_ORI_DROP };
+    a.patch = c->d_big_patch;
+    a.big_in = c->d_big_par; a.big_out = c->d_big_par + (size_t)2 * c->cap; a.big_large = c->d_counts + CN_BIGL0;
+    return a;
+}
+// one lane, or the two lanes of a two-pair launch (c2; both hold image pairs of the same size, kernels go to c's stream)
+static LanePair lane_pair(Ctx* c, Ctx* c2, int nimg, int gate_min_features)
+{
+    LanePair lp;
+    lp.a[0] = lane_args(c, nimg, gate_min_features);
+    lp.a[1] = c2 ? lane_args(c2, nimg, gate_min_features) : lp.a[0];
+    return lp;
+}
+
+static uvo_status surf_integral_lanes(Ctx* c, const LanePair& lp, int nim)       // nim: images over all lanes of the launch
 {
     const int w = c->img_w, h = c->img_h, sw = w + 1;
-    ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
     const int nstrip = (h + kStripRows - 1) / kStripRows, cstride = c->colpart_stride;
     StageTimer t(c, ST_INTEGRAL);
-    hipLaunchKernelGGL(k_integral_strip_sums, dim3(nstrip, nimg), dim3(256), 0, c->stream, ip, w, h, c->d_colpart, cstride, nstrip);
-    hipLaunchKernelGGL(k_integral_strip_scan, dim3((sw + 31) / 32, nimg), dim3(256), 0, c->stream, c->d_colpart, cstride, nstrip, w);
-    hipLaunchKernelGGL(k_integral_strip_final, dim3(nstrip, nimg), dim3(256), 0, c->stream, ip, w, h, c->d_colpart, cstride, nstrip);
+    hipLaunchKernelGGL(k_integral_strip_sums, dim3(nstrip, nim), dim3(256), 0, c->stream, lp, w, h, cstride, nstrip);
+    hipLaunchKernelGGL(k_integral_strip_scan, dim3((sw + 31) / 32, nim), dim3(256), 0, c->stream, lp, cstride, nstrip, w);
+    hipLaunchKernelGGL(k_integral_strip_final, dim3(nstrip, nim), dim3(256), 0, c->stream, lp, w, h, cstride, nstrip);
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }
+uvo_status surf_integral(Ctx* c, int nimg) { return surf_integral_lanes(c, lane_pair(c, nullptr, nimg, -1), nimg); }
 
 template <int O, int TW, int TH, int NT>
-static hipError_t launch_hessian_p(Ctx* c, int nimg, const OctavePat& op, float thr)
+static hipError_t launch_hessian_p(Ctx* c, const LanePair& lp, int nim, const OctavePat& op, float thr)
 {
     const int w = c->img_w, h = c->img_h;
-    ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
-    SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
-    dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
-    hipLaunchKernelGGL((k_hessian_nms_p<O, TW, TH, NT>), grid, dim3(NT), 0, c->stream, ip, w, h, op, thr, sv);
+    dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nim);
+    hipLaunchKernelGGL((k_hessian_nms_p<O, TW, TH, NT>), grid, dim3(NT), 0, c->stream, lp, w, h, op, thr);
     return hipGetLastError();
 }
 
 template <int O, int TW, int TH, int NT>
-static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float thr)
+static hipError_t launch_hessian_c(Ctx* c, const LanePair& lp, int nim, const OctavePat& op, float thr)
 {
     using OC = OctC<O>;
     constexpr int STEP = OC::STEP;
     constexpr int THs = (TH - 1) * STEP + (OC::HI - OC::LO) + 1;
     constexpr int PW = OctTile<O, TW>::PW;
     const int w = c->img_w, h = c->img_h;
-    ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
-    SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
     const size_t lds = sizeof(float) * 3 * TW * TH + sizeof(int32_t) * (size_t)THs * STEP * PW + sizeof(unsigned) * NmsLds<TW, TH>::kWords;
-    dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nimg);
+    dim3 grid((op.cols + TW - 3) / (TW - 2), (op.rows + TH - 3) / (TH - 2), nim);
     auto kern = k_hessian_nms_c<O, TW, TH, NT>;
     static bool attr_dev[64] = {false};                       // once per device (a process may hold contexts on several)
     bool& attr_set = attr_dev[c->device & 63];
@@ -1812,7 +1856,7 @@ static hipError_t launch_hessian_c(Ctx* c, int nimg, const OctavePat& op, float 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, c->stream, ip, w, h, op, thr, sv);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, c->stream, lp, w, h, op, thr);
     return hipGetLastError();
 }
 
@@ -1883,11 +1927,16 @@ uvo_status surf_prepare(Ctx* c, int w, int h)
     return UVO_OK;
 }
 
-uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
+// c2 != nullptr: the detector stages of TWO lanes (two consecutive stereo pairs of one stream, same image size) in one launch
+// each, queued on c's stream; results land in each lane's own buffers exactly as two calls would leave them.
+uvo_status surf_detect_lanes(Ctx* c, Ctx* c2, int nimg, int gate_min_features)
 {
     const int w = c->img_w, h = c->img_h;
+    if (c2 && (nimg != 2 || c2->img_w != w || c2->img_h != h || !c->p.SURF_UPRIGHT)) { c->err = "two-pair launch: upright SURF on two image pairs of one size"; return UVO_INVALID_ARG; }
     UVO_TRY(surf_prepare(c, w, h));
-    UVO_TRY(surf_integral(c, nimg));
+    const LanePair lp = lane_pair(c, c2, nimg, gate_min_features);
+    const int nim = c2 ? 2 * nimg : nimg, nlanes = c2 ? 2 : 1;
+    UVO_TRY(surf_integral_lanes(c, lp, nim));
     const float thr = (float)c->p.SURF_MIN_HESSIAN;
     {
         OctavePat ops[4];
@@ -1896,8 +1945,6 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
         // four octaves (the shipped configuration): one launch for all of them
         const bool merged = merged_launch(c);
         if (merged) {
-            ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
-            SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
             constexpr int TW0 = kMergedTW0, TH0 = kMergedTH0, TW1 = kMergedTW1, TH1 = kO1TileRows;
             constexpr int THs0 = (TH0 - 1) * OctC<0>::STEP + (OctC<0>::HI - OctC<0>::LO) + 1, THs1 = (TH1 - 1) * OctC<1>::STEP + (OctC<1>::HI - OctC<1>::LO) + 1;
             constexpr size_t lds0 = sizeof(float) * 3 * TW0 * TH0 + sizeof(int32_t) * (size_t)THs0 * OctC<0>::STEP * OctTile<0, TW0>::PW + sizeof(unsigned) * NmsLds<TW0, TH0>::kWords;
@@ -1915,7 +1962,7 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             static const size_t lds_pad = getenv("UVO_HESS_LDS") ? (size_t)atoi(getenv("UVO_HESS_LDS")) : 0;      // measurement: fewer blocks per CU
             const size_t lds_launch = lds_pad > lds ? lds_pad : lds;
             if (lds_pad > lds) { static bool once = false; if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch); once = true; } }
-            hipLaunchKernelGGL(kern, dim3(total, nimg), dim3(kP23Threads), lds_launch, c->stream, ip, w, h, static_cast<const OctavePat*>(c->d_octpat), thr, sv,
+            hipLaunchKernelGGL(kern, dim3(total, nim), dim3(kP23Threads), lds_launch, c->stream, lp, w, h, static_cast<const OctavePat*>(c->d_octpat), thr,
                                c->d_hess_order, nbx0, nbx1, g);
             UVO_HIP_TRY(c, hipGetLastError());
         }
@@ -1926,45 +1973,37 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
             // tile shapes chosen by pipelined throughput (tools/probe/ab.sh): octave 0 64 x 24 samples = 40 KB of LDS (18 KB det planes,
             // 19 KB integral tile, 3 KB survivor list), octave 1 32 x 24 = 59 KB (9 KB + 48 KB: the 54-pixel templates make the halo
             // most of the tile)
-            if (o == 0)      e = launch_hessian_c<0, 64, 24, 512>(c, nimg, op, thr);
-            else if (o == 1) e = launch_hessian_c<1, 32, 24, 512>(c, nimg, op, thr);
-            else if (o == 2) e = launch_hessian_p<2, 32, 16, 512>(c, nimg, op, thr);
-            else             e = launch_hessian_p<3, 16, 16, 256>(c, nimg, op, thr);
+            if (o == 0)      e = launch_hessian_c<0, 64, 24, 512>(c, lp, nim, op, thr);
+            else if (o == 1) e = launch_hessian_c<1, 32, 24, 512>(c, lp, nim, op, thr);
+            else if (o == 2) e = launch_hessian_p<2, 32, 16, 512>(c, lp, nim, op, thr);
+            else             e = launch_hessian_p<3, 16, 16, 256>(c, lp, nim, op, thr);
             UVO_HIP_TRY(c, e);
         }
         {   // the survivors of every octave: outer-layer determinants, last comparison, keypoints
             StageTimer t(c, ST_HESSIAN_O0 + c->p.SURF_OCTAVES_NUMBER - 1);
-            ImgPair ip = { { c->img[0], c->img[1] }, { c->d_sum[0], c->d_sum[1] }, { c->d_planes[0], c->d_planes[1] }, c->plane_pw, c->plane_stride, c->d_cand_n, c->d_big_n, c->d_counts + CN_SURV };
-            SurvOut sv = { c->d_surv, c->d_counts + CN_SURV, c->surv_cap };
-            CandOut out = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, c->cap };
-            hipLaunchKernelGGL(k_hessian_finish, dim3((c->surv_cap + kFinishPerWg - 1) / kFinishPerWg), dim3(256), 0, c->stream, sv, static_cast<const OctavePat*>(c->d_octpat), ip, w, h, out);
+            hipLaunchKernelGGL(k_hessian_finish, dim3((c->surv_cap + kFinishPerWg - 1) / kFinishPerWg, nlanes), dim3(256), 0, c->stream, lp, static_cast<const OctavePat*>(c->d_octpat), w, h);
             UVO_HIP_TRY(c, hipGetLastError());
         }
     }
     {
         StageTimer t(c, ST_SORT);
-        SortArgs sa = { { c->d_cand[0], c->d_cand[1] }, c->d_cand_n, { c->det[0].kps, c->det[1].kps },
-                        { c->det[0].n, c->det[1].n }, c->d_rank, c->cap, c->d_big_par, c->d_big_n,
-                        gate_min_features >= 0 && nimg == 2 ? c->d_counts + CN_NQA : nullptr, gate_min_features };
         const int tiles_max = ((c->cap + 255) / 256) * ((c->cap + kSortChunk - 1) / kSortChunk);
-        hipLaunchKernelGGL(k_rank_partial, dim3(tiles_max < 512 ? tiles_max : 512, nimg), dim3(256), 0, c->stream, sa);
-        hipLaunchKernelGGL(k_rank_scatter, dim3((c->cap + 255) / 256, nimg), dim3(256), 0, c->stream, sa);
+        hipLaunchKernelGGL(k_rank_partial, dim3(tiles_max < 512 ? tiles_max : 512, nim), dim3(256), 0, c->stream, lp);
+        hipLaunchKernelGGL(k_rank_scatter, dim3((c->cap + 255) / 256, nim), dim3(256), 0, c->stream, lp);
         UVO_HIP_TRY(c, hipGetLastError());
     }
     {
         StageTimer t(c, ST_DESCRIPTOR);
-        DescArgs da = { { c->img[0], c->img[1] }, { c->det[0].kps, c->det[1].kps }, { c->det[0].desc, c->det[1].desc },
-                        { c->det[0].n, c->det[1].n }, c->d_DW, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap,      // the sorted list
-                        c->d_area_tabs, c->d_area_iscale, c->p.SURF_EXTENDED ? 1 : 0, { c->d_sum[0], c->d_sum[1] }, c->d_ori_w, c->d_counts + CN_ORI_DROP };
         const size_t lds_small = sizeof(float) * 21 * ((kSmallWin + 3) | 1), lds_big = sizeof(float) * 4 * kBigRow;
-        hipLaunchKernelGGL(k_big_sort, dim3(nimg), dim3(1024), 0, c->stream, c->d_big_par, c->d_big_par + (size_t)2 * c->cap, c->d_big_n, c->d_counts + CN_BIGL0, c->cap, c->d_area_iscale);
+        hipLaunchKernelGGL(k_big_sort, dim3(nim), dim3(1024), 0, c->stream, lp, c->cap, c->d_area_iscale);
         if (c->p.SURF_UPRIGHT) {
             const int nbig = 1024;                             // 8192 persistent waves for the large-window tasks (512: 80 us, 768..2048: 66-69 us)
             static const int desc_part = getenv("UVO_DESC_PART") ? atoi(getenv("UVO_DESC_PART")) : 0;      // measurement only
-            hipLaunchKernelGGL(k_descriptor64, dim3(nbig + c->cap, nimg), dim3(256), lds_small > lds_big ? lds_small : lds_big, c->stream, da, w, h, c->d_big_patch, nbig, desc_part);
-            hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(1024, nimg), dim3(256), 0, c->stream, da, c->d_big_patch);
+            hipLaunchKernelGGL(k_descriptor64, dim3(nbig + c->cap, nim), dim3(256), lds_small > lds_big ? lds_small : lds_big, c->stream, lp, w, h, nbig, desc_part);
+            hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(1024, nim), dim3(256), 0, c->stream, lp);
         } else {
             // orientation assignment, then every descriptor from its rotated window (not the shipped configuration)
+            const DescArgs& da = lp.a[0].da;
             const size_t lds_rot = sizeof(float) * 21 * (kMaxWin + 1);
             static bool rot_attr_dev[64] = {false};
             bool& rot_attr = rot_attr_dev[c->device & 63];
@@ -1976,6 +2015,7 @@ uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features)
     }
     return UVO_OK;
 }
+uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features) { return surf_detect_lanes(c, nullptr, nimg, gate_min_features); }
 
 uvo_status surf_hessian_layer_debug(Ctx* c, int octave, int layer, float* det, float* trace)
 {

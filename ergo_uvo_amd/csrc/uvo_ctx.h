@@ -160,6 +160,14 @@ struct Ctx {
     hipEvent_t evAS = nullptr;                   // this lane's "after stereo match" set is written
     int a_overlap = 2;                           // master: stage As (detect .. extract_3Dpoints) allowed side by side (env UVO_A_OVERLAP, 0 = no limit)
     int a_overlap_mono = 4;                      // the same for mono frames (one image each; env UVO_A_OVERLAP_MONO)
+    // Two-pair launches (uvo_stereo_set_batch(c, 2); env UVO_BATCH): uvo_stereo_submit holds every first pair of two back until the
+    // next one arrives and queues the stage As of both -- lanes i and i + 1 -- as ONE set of launches on lane i's stream.  A pair
+    // waiting alone is queued by the first collect that needs it.  Results are those of single launches, pair for pair.
+    int batch = 1;                               // master: pairs per launch set (1 or 2)
+    int a_overlap2 = 2;                          // master: two-pair launch sets allowed side by side (env UVO_A_OVERLAP2)
+    struct StagePlan { int lane = -1, prev_lane = 0, prev_buf = 0, curr = 0, pending_before = 0; bool prev_sync = true; int trace_slot = -1; };
+    StagePlan plan;                              // lane: this lane's pair as uvo_stereo_submit planned it
+    int stashed_lane = -1;                       // master: lane of the pair that waits for its partner (-1: none)
     std::vector<Ctx*> lanes;                     // master only: lanes[0] == this
     Ctx* master = nullptr;                       // children only
     int lane_id = 0;
@@ -261,7 +269,8 @@ uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int 
 uvo_status surf_integral(Ctx* c, int nimg);
 uvo_status surf_build_area_tables(Ctx* c);
 uvo_status surf_prepare(Ctx* c, int w, int h);                           // per-image-size tables of this lane (idempotent)
-uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features = -1);   // integral -> ... -> sorted kps + descriptors in c->det[];
+uvo_status surf_detect(Ctx* c, int nimg, int gate_min_features = -1);
+uvo_status surf_detect_lanes(Ctx* c, Ctx* c2, int nimg, int gate_min_features);     // c2: a second lane's pair in the same launches (or nullptr)   // integral -> ... -> sorted kps + descriptors in c->det[];
                                                                         // gate_min_features >= 0: also evaluate VO:556 into d_counts[CN_NQA]
 uvo_status surf_hessian_layer_debug(Ctx* c, int octave, int layer, float* det, float* trace);
 // match.hip
@@ -271,13 +280,16 @@ uvo_status match_knn2_two(Ctx* c, const float* d_q0, const int* d_nq0, const flo
                           const float* d_q1, const int* d_nq1, const float* d_t1, const int* d_nt1, int n_max);
 uvo_status match_ratio_compact2(Ctx* c, float ratio, const int* d_nq0, uvo_dmatch* d_out0, int* d_nout0, const GateArgs& g0,
                                 const int* d_nq1, uvo_dmatch* d_out1, int* d_nout1, const GateArgs& g1, int n_max, int out_cap);
+uvo_status match_two_pairs(Ctx* a, Ctx* b, const float* d_prev_desc, const int* d_prev_n, const int* d_prev_as_n, int curr_a, int curr_b,
+                           float ratio, int min_features);
 uvo_status match_ratio_compact(Ctx* c, const int* d_nq, int nq_max, float ratio, uvo_dmatch* d_out, int* d_nout, int out_cap,
                                const GateArgs* gate = nullptr);
 // pose.hip
 uvo_status pose_triangulate(Ctx* c, const double* P1, const double* P2, const int* d_n, int n_max);
 uvo_status pose_triangulate_extract3d(Ctx* c, int slot, const double* P1, const double* P2, const double* R1, const double* t1,
                                       const double* R2, const double* t2, const double* K1, const double* K2, const int* d_n, int n_max,
-                                      int* counts_host = nullptr);     // counts_host: pinned mirror of d_counts written by the last kernel
+                                      int* counts_host = nullptr,      // counts_host: pinned mirror of d_counts written by the last kernel
+                                      Ctx* c2 = nullptr, int* counts_host2 = nullptr);   // c2: a second lane's pair in the same launches
 uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, const double* R2, const double* t2,
                           const double* K1, const double* K2, const int* d_n, int n_max);
 uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const double* R, const double* t, const double* K,
