@@ -1,0 +1,86 @@
+#!/bin/bash
+# tools/probe/gpu.sh -- the measurement steps behind DESIGN.md's numbers, one script instead of a file per GPU call:
+#   gpurun -- 'tools/probe/gpu.sh <step> [args] [-- <step> [args]] ...'
+# Steps (outputs under gpurun_out/; a failing step stops the chain):
+#   tests [pytest args]         python -m pytest <args, default: tests -m gpu> -x -q            -> <tag>_tests.log
+#   bench [bench.py args]       one bench.py line (stdout)                                       
+#   bench20 [n]                 the driver's form n times (--steps 20 --warmup 5), value + blocks
+#   ab <steps>                  previous build (ergo_uvo_amd/lib_ab/libuvo_hip_old.so) against the current one, interleaved
+#   sweep <steps>               overlap / depth / PnP-slot settings of the one-pair pipeline
+#   batch <steps>               one- and two-pair launch sets over depth / overlap settings
+#   prof <tag> [sync|pipe|batch2]  rocprofv3 --kernel-trace --stats of a synchronous run / the pipelined bench / two-pair launch sets
+#   hess-split <tag>            per-octave detection kernels (UVO_HESSIAN_SPLIT=1) and the merged launch, old build and new
+#   pmc <tag> <kernel pattern> [split]   counter passes (separate --pmc runs: SQ set 1, SQ set 2, FETCH_SIZE, WRITE_SIZE) of a synchronous run
+#   ctx-reuse [pairs]           five contexts in a row, stream pool on and off
+#   rates                       issue-rate probe (built by hipcc here if missing)
+#   topo                        what the rank pinning reads on this box
+#   configs                     tools/bench_configs.py
+#   final <tag>                 the closing pass of a round: bench (600 steps and the driver's form), kernel stats, counters, configs
+# TAG=<name> prefixes the output files (default r04).
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-$(dirname $0)/../..}
+mkdir -p gpurun_out
+TAG=${TAG:-r04}
+OLD=$PWD/ergo_uvo_amd/lib_ab/libuvo_hip_old.so
+line() { python -c "import sys,json,os; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-34s' % os.environ.get('LBL',''), d['value'], d.get('block_values'))"; }
+brun() { python bench.py --blocks 5 --timed-only "$@" 2>/dev/null | LBL="${LBL:-$*}" line; }
+step() {
+  s=$1; shift
+  case $s in
+    tests)   if [ $# -eq 0 ]; then set -- tests -m gpu; fi
+             timeout -k 10 1100 python -m pytest "$@" -x -q > gpurun_out/${TAG}_tests.log 2>&1; rc=$?; tail -4 gpurun_out/${TAG}_tests.log; return $rc ;;
+    bench)   python bench.py "$@" ;;
+    bench20) for i in $(seq ${1:-3}); do python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('20/5:', d['value'], 'first', d['value_first_block'], d['block_values'], 'gap max', d['collect_gap_ms']['max'], d['collect_gap_ms']['argmax'])" || return 1; done ;;
+    ab)      for rep in 1 2; do UVO_HIP_LIB=$OLD LBL=old brun --steps ${1:-300} || return 1; LBL=new brun --steps ${1:-300} || return 1; done ;;
+    sweep)   n=${1:-300}
+             LBL=default brun --steps $n --depth 6; UVO_A_OVERLAP=3 LBL="A_OVERLAP=3 depth 6" brun --steps $n --depth 6; UVO_A_OVERLAP=3 LBL="A_OVERLAP=3 depth 8" brun --steps $n --depth 8
+             UVO_MAX_B=4 LBL="MAX_B=4" brun --steps $n --depth 6; UVO_MAX_B=2 LBL="MAX_B=2" brun --steps $n --depth 6
+             LBL="depth 8" brun --steps $n --depth 8; LBL="depth 7" brun --steps $n --depth 7; LBL=default brun --steps $n --depth 6 ;;
+    batch)   n=${1:-300}
+             LBL="batch 1 depth 6" brun --steps $n --batch 1 --depth 6; LBL="batch 2 depth 6" brun --steps $n --batch 2 --depth 6; LBL="batch 2 depth 8" brun --steps $n --batch 2 --depth 8
+             UVO_A_OVERLAP2=1 LBL="batch 2 depth 6 A_OVERLAP2=1" brun --steps $n --batch 2 --depth 6; UVO_A_OVERLAP2=1 LBL="batch 2 depth 4 A_OVERLAP2=1" brun --steps $n --batch 2 --depth 4
+             LBL="batch 1 depth 6" brun --steps $n --batch 1 --depth 6 ;;
+    prof)    t=$1; kind=${2:-sync}
+             case $kind in
+               sync)   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${t}_sync -- python3 tools/prof_stereo.py 24 > gpurun_out/prof_${t}_sync.log 2>&1 || return 1; python tools/probe/kstats.py prof_${t}_sync 26 ;;
+               pipe)   rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${t}_pipe -- python3 bench.py --steps 200 --blocks 1 --timed-only > gpurun_out/prof_${t}_pipe.log 2>&1 || return 1; python tools/probe/kstats.py prof_${t}_pipe 26 ;;
+               batch2) UVO_A_OVERLAP2=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${t}_batch2 -- python3 bench.py --steps 60 --blocks 1 --timed-only --batch 2 > gpurun_out/prof_${t}_batch2.log 2>&1 || return 1; python tools/probe/kstats.py prof_${t}_batch2 26 ;;
+             esac ;;
+    hess-split) t=$1
+             for v in old new; do
+               if [ $v = old ]; then export UVO_HIP_LIB=$OLD; else unset UVO_HIP_LIB; fi
+               UVO_HESSIAN_SPLIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${t}_${v}_split -- python3 tools/prof_stereo.py 24 > gpurun_out/prof_${t}_${v}_split.log 2>&1 || return 1
+               rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${t}_${v}_merged -- python3 tools/prof_stereo.py 24 > gpurun_out/prof_${t}_${v}_merged.log 2>&1 || return 1
+               echo "== $v, one launch per octave"; python tools/probe/kstats.py prof_${t}_${v}_split 30 | grep -i hessian
+               echo "== $v, merged launch"; python tools/probe/kstats.py prof_${t}_${v}_merged 30 | grep -i hessian
+             done; unset UVO_HIP_LIB ;;
+    pmc)     t=$1; pat=$2; [ "$3" = split ] && export UVO_HESSIAN_SPLIT=1
+             rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d gpurun_out/pmc_${t}_sq1 -- python3 tools/prof_stereo.py 6 > gpurun_out/pmc_${t}_sq1.log 2>&1 || return 1
+             rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VALU_CVT SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmc_${t}_sq2 -- python3 tools/prof_stereo.py 6 > gpurun_out/pmc_${t}_sq2.log 2>&1 || return 1
+             rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${t}_fetch -- python3 tools/prof_stereo.py 6 > gpurun_out/pmc_${t}_fetch.log 2>&1 || return 1
+             rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_${t}_write -- python3 tools/prof_stereo.py 6 > gpurun_out/pmc_${t}_write.log 2>&1 || return 1
+             unset UVO_HESSIAN_SPLIT
+             for p in sq1 sq2 fetch write; do python tools/probe/pmc_quick.py pmc_${t}_${p} "$pat" 2; done ;;
+    ctx-reuse) python tools/probe/ctx_reuse.py ${1:-400} 2>/dev/null | grep pool; UVO_STREAM_POOL=0 python tools/probe/ctx_reuse.py ${1:-400} 2>/dev/null | grep pool ;;
+    rates)   [ -x tools/probe/issue_rate_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probe/issue_rate_probe.hip -o tools/probe/issue_rate_probe || return 1
+             tools/probe/issue_rate_probe ;;
+    topo)    for n in /sys/class/kfd/kfd/topology/nodes/*; do echo "== $n"; grep -E "simd_count|cpu_cores_count|location_id|domain|drm_render_minor" $n/properties 2>&1; done
+             ls -la /dev/dri /dev/kfd 2>&1; nproc; cat /sys/devices/system/node/node*/cpulist 2>&1; env | grep -E "VISIBLE|ROCR|HIP_|GPU_"
+             python3 -c "import sys; sys.path.insert(0, '.'); from ergo_uvo_amd import multirank; print(multirank.visible_gpus())" ;;
+    configs) python tools/bench_configs.py > gpurun_out/bench_${TAG}_configs.json 2> gpurun_out/bench_${TAG}_configs.err || { tail -5 gpurun_out/bench_${TAG}_configs.err; return 1; }; cat gpurun_out/bench_${TAG}_configs.json ;;
+    final)   t=${1:-$TAG}
+             python bench.py > gpurun_out/bench_${t}_final.json 2> gpurun_out/bench_${t}_final.err || return 1; tail -c 300 gpurun_out/bench_${t}_final.json; echo
+             python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${t}_20steps.json 2> gpurun_out/bench_${t}_20steps.err || return 1
+             python bench.py --gpus 1 --backend nccl --force-dist --steps 200 --no-cpu-baseline > gpurun_out/bench_${t}_1rank_rccl.json 2> gpurun_out/bench_${t}_1rank_rccl.err || return 1
+             step prof $t sync || return 1; step prof $t pipe || return 1
+             step pmc $t k_hessian_nms_all || return 1 ;;
+    *) echo "unknown step $s"; return 2 ;;
+  esac
+}
+args=()
+for a in "$@" --; do
+  if [ "$a" = -- ]; then
+    if [ ${#args[@]} -gt 0 ]; then echo "### ${args[*]}"; step "${args[@]}" || { echo "step '${args[*]}' failed"; exit 1; }; fi
+    args=()
+  else args+=("$a"); fi
+done
