@@ -302,7 +302,7 @@ extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w,
     if (st != UVO_OK) return st;
     (*out)->lanes.push_back(*out);
     if (getenv("UVO_MAX_B")) (*out)->max_b = std::min(16, std::max(1, atoi(getenv("UVO_MAX_B"))));
-    if (getenv("UVO_A_OVERLAP")) (*out)->a_overlap = std::min(8, std::max(0, atoi(getenv("UVO_A_OVERLAP"))));
+    if (getenv("UVO_A_OVERLAP")) (*out)->a_overlap = std::min(16, std::max(0, atoi(getenv("UVO_A_OVERLAP"))));
     if (getenv("UVO_MAX_B_MONO")) (*out)->max_b_mono = std::min(16, std::max(1, atoi(getenv("UVO_MAX_B_MONO"))));
     if (getenv("UVO_A_OVERLAP2")) (*out)->a_overlap2 = std::min(4, std::max(0, atoi(getenv("UVO_A_OVERLAP2"))));
     if (getenv("UVO_BATCH")) (*out)->batch = atoi(getenv("UVO_BATCH")) == 2 ? 2 : 1;
