@@ -13,8 +13,13 @@ extract_3Dpoints, EPnP PnP-RANSAC + refit, pose inversion, on one synthetic 1920
 timed region.  With N ranks every rank runs its own independent stream (configs[4]; weak scaling)
 and the per-step pose records are all-gathered over RCCL at the end of the timed region.
 
+The timed region of the contract -- fence, exactly K steps, gather, fence -- is run `--blocks` (7) times in a row in the same
+process; `value` / `ms_per_step` are the MEDIAN block's (MAX over ranks per block), the first / slowest / fastest block and every
+block's rate are listed beside it, with the gaps between consecutive collects (`collect_gap_ms`) and, for K <= 64, the device and
+host timestamps of every pair's phases (`pipeline_trace`), so that a stall inside one 10 ms window shows where it was.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant
-kernel (hessian_nms octave 0: algorithmic bytes of SURVEY.md 8(d) / HIP-event time measured here)
+kernel (k_hessian_nms_all: algorithmic bytes of SURVEY.md 8(d) / HIP-event time measured here)
 and `cpu_baseline` (the CPU oracle, 1 thread, on a bounded sample of the same workload).
 """
 from __future__ import annotations
@@ -405,8 +410,8 @@ def main():
         avg_ms = ms / max(n, 1)
         alg_bytes = algorithmic_bytes_hessian_launch(WIDTH, HEIGHT, 2)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed counter passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/probe/
-        # final_profiles_r02.sh, FETCH_SIZE doubled per MI355X_MICROARCH.md): the newest summary that has the kernel
+        # HBM bytes per launch from the committed counter passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of `tools/probe/gpu.sh
+        # final`, FETCH_SIZE doubled per MI355X_MICROARCH.md): the newest summary that has the kernel
         # Counters cannot be read from inside this process; the figure is the one of the newest committed counter summary whose
         # `kernel_source_sha` matches the detector source being run (tools/pmc_summary_r03.py writes it) -- null when the profile
         # predates the kernel, never a stale number.
@@ -414,7 +419,7 @@ def main():
         try:
             import hashlib
             sha = hashlib.sha256(open(os.path.join(ROOT, "ergo_uvo_amd", "csrc", "surf.hip"), "rb").read()).hexdigest()[:16]
-            for name in ("r03_pmc_stage_kernels.json",):
+            for name in ("r04_pmc_stage_kernels.json", "r03_pmc_stage_kernels.json"):
                 d = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if d.get("kernel_source_sha", {}).get("surf.hip") == sha:
                     traffic = int(d["kernels"]["hessian_all_octaves"]["hbm_bytes_fetch_x2"])
