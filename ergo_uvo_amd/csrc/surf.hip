@@ -31,7 +31,11 @@ namespace uvo {
 struct ImgPair { const uint8_t* img[2]; int32_t* sum[2]; int32_t* planes[2]; int pw, pstride; int* cand_n; int* big_n; int* surv_n; };
 struct AreaTab;
 struct CandOut { uvo_keypoint* cand[2]; int* count; int cap; };
+// NMS survivors of a frame: one shared list, a workgroup appends its tile's survivors behind ONE atomic.  (Round 4 also built per-tile
+// slots without any atomic: the detection launch gained 0.5 us per tile, k_hessian_finish lost 14 us walking a sparse, unevenly filled
+// structure -- tiles in textured regions hold several times the average -- and the list came back.)
 struct SurvOut { Survivor* list; int* count; int cap; };
+static_assert(sizeof(Survivor) == 128, "a survivor record is 32 words");
 struct SortArgs { const uvo_keypoint* cand[2]; const int* cand_n; uvo_keypoint* out[2]; int* out_n[2]; int* rank; int cap;
                   int4* big_par; int* big_n; int* gate_nqa; int gate_min_features; };
 struct DescArgs { const uint8_t* img[2]; uvo_keypoint* kps[2]; float* desc[2]; const int* n[2]; const float* DW;
@@ -423,7 +427,11 @@ __device__ __forceinline__ unsigned sad_u32(int a, int b, unsigned c)      // |a
     return r;
 }
 #define UVO_BOX_FMA2(xa, xb, wgt) __builtin_elementwise_fma(uvo_v2f{__uint_as_float(xa), __uint_as_float(xb)}, uvo_v2f{(wgt), (wgt)}, uvo_v2f{-8388608.0f * (wgt), -8388608.0f * (wgt)})
-#define UVO_HESSIAN_DET(SV, det)                                                                          \
+// threadIdx.x behind an opaque (empty) volatile asm: what a tile's code derives from it stays inside the merged launch's tile loop instead of
+// being hoisted out of it as loop-invariant (all three kinds' tile-invariant addresses live at once: 111-156 VGPRs instead of 58)
+__device__ __forceinline__ int lane_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+// first half: dx * dy of one sample and layer (Dx and Dy: sixteen corners)
+#define UVO_HESSIAN_PP(SV, pp_out)                                                                        \
     {                                                                                                     \
         /* Dx: boxes (0,2,3,7,+1) (3,2,6,7,-2) (6,2,9,7,+1): column differences between rows c2 and c7 */ \
         const unsigned gx0 = (unsigned)(SV(c7, c0) - SV(c2, c0)), gx3 = sad_u32(SV(c7, c3), SV(c2, c3), kBoxMagic),                       \
@@ -442,8 +450,11 @@ __device__ __forceinline__ unsigned sad_u32(int a, int b, unsigned c)      // |a
         d += (double)pxy1.y;                                                                              \
         d += (double)py02.y;                                                                              \
         const float dy = (float)d;                                                                        \
-        const float pp_ = dx * dy;                                                                        \
-        if (!(pp_ > skip_thr)) det = kDetBelow; else {                                                    \
+        pp_out = dx * dy;                                                                                 \
+    }
+// second half: Dxy (sixteen more corners) and the determinant, for a sample whose dx * dy can still beat the threshold
+#define UVO_HESSIAN_DXY(SV, pp_in, det)                                                                   \
+    {                                                                                                     \
         /* Dxy: boxes (1,1,4,4,+1) (5,1,8,4,-1) (1,5,4,8,-1) (5,5,8,8,+1): row differences c1..c4 and c5..c8 at the four columns */      \
         const unsigned u1 = (unsigned)(SV(c4, c1) - SV(c1, c1)), u4 = sad_u32(SV(c4, c4), SV(c1, c4), kBoxMagic);                         \
         const unsigned u5 = (unsigned)(SV(c4, c5) - SV(c1, c5)), u8 = sad_u32(SV(c4, c8), SV(c1, c8), kBoxMagic);                         \
@@ -451,12 +462,18 @@ __device__ __forceinline__ unsigned sad_u32(int a, int b, unsigned c)      // |a
         const unsigned t5 = (unsigned)(SV(c8, c5) - SV(c5, c5)), t8 = sad_u32(SV(c8, c8), SV(c5, c8), kBoxMagic);                         \
         static_assert(wd0 == wd3 && wd1 == wd2 && wd1 == -wd0, "the four boxes of Dxy share one weight up to sign");                      \
         const uvo_v2f pd03 = UVO_BOX_FMA2(u4 - u1, t8 - t5, wd0), pd12 = UVO_BOX_FMA2(u8 - u5, t4 - t1, wd1);                             \
-        d = (double)pd03.x;                                                                               \
+        double d = (double)pd03.x;                                                                        \
         d += (double)pd12.x;                                                                              \
         d += (double)pd12.y;                                                                              \
         d += (double)pd03.y;                                                                              \
         const float dxy = (float)d;                                                                       \
-        det = pp_ - 0.81f * dxy * dxy; }                                                                  \
+        det = (pp_in) - 0.81f * dxy * dxy;                                                                \
+    }
+#define UVO_HESSIAN_DET(SV, det)                                                                          \
+    {                                                                                                     \
+        float pp_;                                                                                        \
+        UVO_HESSIAN_PP(SV, pp_)                                                                           \
+        if (!(pp_ > skip_thr)) det = kDetBelow; else UVO_HESSIAN_DXY(SV, pp_, det)                        \
     }
 #define UVO_HESSIAN_CONSTS(LC)                                                                            \
     constexpr int c0 = LC::r(0), c1 = LC::r(1), c2 = LC::r(2), c3 = LC::r(3), c4 = LC::r(4), c5 = LC::r(5), \
@@ -488,7 +505,7 @@ __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, f
 #define SV(dy, dx) base[((OFFL + (dy)) * STEP + ((OFFL + (dx)) % STEP)) * PW + (OFFL + (dx)) / STEP]
     UVO_HESSIAN_CONSTS(LC);
     const LayerPat& lp = op.L[L];
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     // a compile-time trip count (the last pass is guarded): the box arithmetic holds inline assembly, which the compiler treats as
     // convergent and will not unroll behind a run-time remainder
 #pragma unroll
@@ -548,6 +565,72 @@ __device__ __forceinline__ void det_layer_p(const int32_t* __restrict__ planes, 
 #undef SVP
 }
 
+// The three middle layers of a plane-octave sample in TWO memory round trips instead of six (the merged launch): first the sixteen
+// Dx / Dy corners of all three layers -- 48 independent buffer loads per lane, issued together -- then, for the layers whose dx * dy
+// can still beat the threshold, their Dxy corners together.  A plane tile used to live ~13 us in its workgroup slot, almost all of it
+// waiting for six dependent batches of loads.  The loads are unconditional (an out-of-range sample's address is out of the buffer's
+// range: the resource returns 0) and the in-range test selects afterwards.
+template <int O, int L>
+__device__ __forceinline__ float plane_pp(ImgRsrc rs, int voff, int pw, int pstride)
+{
+    using LC = LayerC<OctC<O>::size(L)>;
+#define SVP(dy, dx) (int)__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4 * ((dx) >> 2), 4 * ((((dy) & 3) * 4 + ((dx) & 3)) * pstride + ((dy) >> 2) * pw), 0)
+    UVO_HESSIAN_CONSTS(LC);
+    float pp;
+    UVO_HESSIAN_PP(SVP, pp)
+    return pp;
+}
+template <int O, int L>
+__device__ __forceinline__ float plane_det(ImgRsrc rs, int voff, int pw, int pstride, float pp)
+{
+    using LC = LayerC<OctC<O>::size(L)>;
+    UVO_HESSIAN_CONSTS(LC);
+    float det;
+    UVO_HESSIAN_DXY(SVP, pp, det)
+#undef SVP
+    return det;
+}
+template <int O, int TW, int TH, int NT>
+__device__ __forceinline__ void det_layers_p3(const int32_t* __restrict__ planes, int pw, int pstride, float* __restrict__ sdet,
+                                              const OctavePat& op, int px0, int py0, float skip_thr)
+{
+    using OC = OctC<O>;
+    constexpr int Q = OC::STEP / 4;
+    const ImgRsrc rs = img_rsrc(reinterpret_cast<const uint8_t*>(planes), 16 * pstride * 4);
+    const int tid = lane_tid();
+#pragma unroll
+    for (int it = 0; it < (TW * TH + NT - 1) / NT; it++) {
+        const int sidx = tid + it * NT;
+        if ((it + 1) * NT > TW * TH && sidx >= TW * TH) break;
+        const int ry = sidx / TW, rx = sidx - ry * TW;
+        bool ok[3]; int voff[3]; float pp[3], det[3];
+#pragma unroll
+        for (int l = 0; l < 3; l++) {
+            const int m = l == 0 ? OC::margin(1) : l == 1 ? OC::margin(2) : OC::margin(3);
+            const LayerPat& lp = op.L[l + 1];
+            const int oi = py0 + ry - m, oj = px0 + rx - m;
+            ok[l] = oi >= 0 && oi < lp.samples_i && oj >= 0 && oj < lp.samples_j;
+            voff[l] = ok[l] ? 4 * ((oi * Q) * pw + oj * Q) : 0x7FFFFFF0;      // past the buffer: its loads return 0
+        }
+        pp[0] = plane_pp<O, 1>(rs, voff[0], pw, pstride);
+        pp[1] = plane_pp<O, 2>(rs, voff[1], pw, pstride);
+        pp[2] = plane_pp<O, 3>(rs, voff[2], pw, pstride);
+        const bool n0 = ok[0] && pp[0] > skip_thr, n1 = ok[1] && pp[1] > skip_thr, n2 = ok[2] && pp[2] > skip_thr;
+        det[0] = ok[0] ? kDetBelow : 0.f; det[1] = ok[1] ? kDetBelow : 0.f; det[2] = ok[2] ? kDetBelow : 0.f;
+        if (n0 || n1 || n2) {
+            // (a layer that does not need its Dxy reads past the buffer instead: one instruction stream, no divergence between the layers)
+            const float d0 = plane_det<O, 1>(rs, n0 ? voff[0] : 0x7FFFFFF0, pw, pstride, pp[0]);
+            const float d1 = plane_det<O, 2>(rs, n1 ? voff[1] : 0x7FFFFFF0, pw, pstride, pp[1]);
+            const float d2 = plane_det<O, 3>(rs, n2 ? voff[2] : 0x7FFFFFF0, pw, pstride, pp[2]);
+            if (n0) det[0] = d0;
+            if (n1) det[1] = d1;
+            if (n2) det[2] = d2;
+        }
+#pragma unroll
+        for (int l = 0; l < 3; l++) sdet[(l * TH + ry) * TW + rx] = det[l];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Non-maximum suppression with lazy outer layers, in two kernels.  findMaximaInLayer needs, for each middle layer
 // L = 1..3, the 3 x 3 x 3 neighbourhood in layers L-1, L, L+1.  Layers 1..3 are centres and are computed for every
@@ -565,26 +648,44 @@ __device__ __forceinline__ void det_layer_p(const int32_t* __restrict__ planes, 
 template <int TW, int TH>
 struct NmsLds { static constexpr int kList = 3 * ((TW - 1) / 2) * ((TH - 1) / 2), kWords = kList + 2; };
 
+// the survivor count of a tile starts at zero: called before the barrier that precedes nms_survivors (one barrier less per tile: under
+// three workgroups per CU a barrier costs the wait for the slowest of eight time-sliced waves)
+template <int TW, int TH>
+__device__ __forceinline__ void nms_zero(unsigned* s_list) { if (lane_tid() == 0) reinterpret_cast<int*>(s_list + NmsLds<TW, TH>::kList)[0] = 0; }
 template <int TW, int TH, int NT>
 __device__ __forceinline__ void nms_survivors(const float* __restrict__ sdet, unsigned* __restrict__ s_list, const OctavePat& op, float thr,
                                               int px0, int py0, int im, const SurvOut& sv)
 {
-    const int tid = threadIdx.x;
-    int* s_n = reinterpret_cast<int*>(s_list + NmsLds<TW, TH>::kList);       // [0] count, [1] base
-    if (tid == 0) s_n[0] = 0;
-    __syncthreads();
-#pragma unroll 1
-    for (int L = 1; L <= 3; L++) {
-        const LayerPat& lp = op.L[L];
-        if (lp.samples_i == 0 || op.L[L + 1].samples_i == 0) continue;
-        const int m = op.nms_margin[L - 1];
-        for (int idx = tid; idx < (TW - 2) * (TH - 2); idx += NT) {
-            const int ry = idx / (TW - 2) + 1, rx = idx - (ry - 1) * (TW - 2) + 1;
-            const int i = py0 + ry, j = px0 + rx;
-            if (i < m || i >= op.rows - m || j < m || j >= op.cols - m) continue;
-            const float* d2 = sdet + ((L - 1) * TH + ry) * TW + rx;
-            const float val0 = d2[0];
+    const int tid = lane_tid();
+    int* s_n = reinterpret_cast<int*>(s_list + NmsLds<TW, TH>::kList);       // [0] count (zeroed by the caller before its last barrier: nms_zero), [1] base
+    // the centre values of every sample this thread tests -- three layers x ITER samples -- are read first (independent LDS
+    // reads in flight together), then compared: read one at a time, each behind its own bounds tests and branch, the scan took 3 of
+    // a tile's 12 us in a workgroup whose SIMDs are shared with two other tiles' box sums (tools/probe/hess_stamps.py)
+    // Thread tid looks at column tid % TW of rows tid / TW + k NT / TW (TW is a power of two): a sample's det value is at
+    // sdet[tid + constant], no index arithmetic per sample -- the workgroup shares its SIMDs with two other tiles' box sums, so every
+    // instruction of this scan costs three.
+    static_assert((TW & (TW - 1)) == 0 && NT % TW == 0, "tile width: a power of two that divides the workgroup");
+    constexpr int RP = NT / TW, ITER = (TH - 2 + RP - 1) / RP;
+    const int rx = tid & (TW - 1), r0 = tid / TW;
+    const int j = px0 + rx;
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        const int L = l + 1;
+        const int m = op.nms_margin[l];
+        const bool col_ok = op.L[L].samples_i != 0 && op.L[L + 1].samples_i != 0 && rx >= 1 && rx <= TW - 2 && j >= m && j < op.cols - m;
+        float v0[ITER];                                          // a layer's centre values first (independent LDS reads), then the tests
+#pragma unroll
+        for (int u = 0; u < ITER; u++) {
+            const int ry = r0 + u * RP + 1, i = py0 + ry;
+            const bool in = col_ok && ry <= TH - 2 && i >= m && i < op.rows - m;
+            v0[u] = in ? sdet[tid + TW + u * NT + l * TH * TW] : kDetBelow;
+        }
+#pragma unroll
+        for (int u = 0; u < ITER; u++) {
+            const float val0 = v0[u];
             if (!(val0 > thr)) continue;
+            const int ry = r0 + u * RP + 1;
+            const float* d2 = sdet + (l * TH + ry) * TW + rx;
             bool is_max = val0 > d2[-TW-1] && val0 > d2[-TW] && val0 > d2[-TW+1] && val0 > d2[-1] && val0 > d2[1] &&
                           val0 > d2[TW-1] && val0 > d2[TW] && val0 > d2[TW+1];
             const float* d1 = d2 - TH * TW;
@@ -599,28 +700,29 @@ __device__ __forceinline__ void nms_survivors(const float* __restrict__ sdet, un
         }
     }
     __syncthreads();
-    // one global atomic per workgroup (a device-scope increment of one address costs ~7 ns chip-wide, and its wave a round trip)
     const int nloc = s_n[0];
+    // one global atomic per workgroup (a device-scope increment of one address costs ~7 ns chip-wide, and its wave a round trip)
     if (nloc == 0) return;
     if (tid == 0) s_n[1] = atomicAdd(sv.count, nloc);
     __syncthreads();
     const int base = s_n[1];
-    for (int t = tid; t < nloc; t += NT) {
+    // a record is 32 words (im, octave, L, i, j, 27 neighbourhood values): 32 lanes write one word each (one thread per survivor
+    // writing its 128 bytes took ~1 us of a tile's life)
+    for (int e = tid; e < nloc * 32; e += NT) {
+        const int t = e >> 5, wd = e & 31;
         if (base + t >= sv.cap) continue;             // k_hessian_finish turns the overflow into the capacity error
-        const unsigned e = s_list[t];
-        const int L = e & 255u, ry = (e >> 8) & 255u, rx = e >> 16;
-        const float* d2 = sdet + ((L - 1) * TH + ry) * TW + rx;
-        const float* d1 = d2 - TH * TW;
-        const float* d3 = d2 + TH * TW;
         Survivor* r = sv.list + base + t;
-        r->im = im; r->octave = op.octave; r->L = L; r->i = py0 + ry; r->j = px0 + rx;
-        const int nb[9] = { -TW-1, -TW, -TW+1, -1, 0, 1, TW-1, TW, TW+1 };
-#pragma unroll
-        for (int b = 0; b < 9; b++) {
-            r->n9[b] = L >= 2 ? d1[nb[b]] : 0.f;
-            r->n9[9 + b] = d2[nb[b]];
-            r->n9[18 + b] = L <= 2 ? d3[nb[b]] : 0.f;
+        const unsigned ent = s_list[t];
+        const int L = ent & 255u, ry = (ent >> 8) & 255u, rx = ent >> 16;
+        int val;
+        if (wd < 5) val = wd == 0 ? im : wd == 1 ? op.octave : wd == 2 ? L : wd == 3 ? py0 + ry : px0 + rx;
+        else {
+            const int q = wd - 5, row = q / 9, nb9 = q - row * 9;                  // row 0: layer L-1, 1: L, 2: L+1
+            const float* d = sdet + ((L - 2 + row) * TH + ry + nb9 / 3 - 1) * TW + rx + nb9 % 3 - 1;
+            const bool have = (row == 0 && L >= 2) || row == 1 || (row == 2 && L <= 2);
+            val = have ? __float_as_int(*d) : 0;
         }
+        reinterpret_cast<int*>(r)[wd] = val;
     }
 }
 
@@ -717,6 +819,14 @@ __global__ __launch_bounds__(256) void k_hessian_finish(LanePair lp, const Octav
     }
 }
 
+// UVO_HESS_STAMPS=<file> (measurement): wall-clock stamps (100 MHz) of every workgroup's phases in the last detection launch --
+// start, integral tile in LDS, box sums done, end -- with the tile kind, written as CSV when the context goes
+__device__ long long* g_hess_stamps = nullptr;
+__device__ __forceinline__ void hess_stamp(int k, long long v = -1)
+{
+    long long* st = g_hess_stamps;
+    if (st && threadIdx.x == 0) st[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = v >= 0 ? v : (long long)wall_clock64();
+}
 // One tile of octave 0 or 1 (tile bx, by of image im): the body of k_hessian_nms_c and of the octave-0 blocks of k_hessian_nms_c0_p23
 template <int O, int TW, int TH, int NT>
 __device__ __forceinline__ void hessian_nms_c_tile(const ImgPair& ip, int w, int h, const OctavePat& op, float thr, const SurvOut& sv,
@@ -727,7 +837,7 @@ __device__ __forceinline__ void hessian_nms_c_tile(const ImgPair& ip, int w, int
     constexpr int TWs = OctTile<O, TW>::TWs;
     constexpr int THs = (TH - 1) * STEP + (OC::HI - OC::LO) + 1;
     constexpr int PW = OctTile<O, TW>::PW;
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     const int sw = w + 1;
     const int32_t* __restrict__ gsum = ip.sum[im];
     float* sdet = reinterpret_cast<float*>(smem);                    // [3][TH][TW]: layers 1..3
@@ -768,11 +878,14 @@ __device__ __forceinline__ void hessian_nms_c_tile(const ImgPair& ip, int w, int
             }
         }
     }
+    nms_zero<TW, TH>(reinterpret_cast<unsigned*>(stile + THs * STEP * PW));
     __syncthreads();
+    hess_stamp(1);
     det_layer_c<O, 1, TW, TH, NT>(stile, sdet, op, px0, py0, thr);
     det_layer_c<O, 2, TW, TH, NT>(stile, sdet, op, px0, py0, thr);
     det_layer_c<O, 3, TW, TH, NT>(stile, sdet, op, px0, py0, thr);
     __syncthreads();
+    hess_stamp(2);
     nms_survivors<TW, TH, NT>(sdet, reinterpret_cast<unsigned*>(stile + THs * STEP * PW), op, thr, px0, py0, im, sv);
 }
 template <int O, int TW, int TH, int NT>
@@ -795,6 +908,7 @@ __global__ __launch_bounds__(NT) void k_hessian_nms_p(LanePair lp, int w, int h,
     det_layer_p<O, 1, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0, thr);
     det_layer_p<O, 2, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0, thr);
     det_layer_p<O, 3, TW, TH, NT>(ip.planes[im], ip.pw, ip.pstride, sdet, op, px0, py0, thr);
+    nms_zero<TW, TH>(s_list);
     __syncthreads();
     nms_survivors<TW, TH, NT>(sdet, s_list, op, thr, px0, py0, im, sv);
 }
@@ -810,18 +924,18 @@ __device__ __forceinline__ void hessian_nms_p23_tile(const ImgPair& ip, const Oc
     static_assert(TW3 * TH3 <= TW2 * TH2 && NmsLds<TW3, TH3>::kWords <= NmsLds<TW2, TH2>::kWords, "octave 3 reuses octave 2's LDS");
     if (b < g.nb2) {
         const int px0 = (b % g.nbx2) * (TW2 - 2) - 1, py0 = (b / g.nbx2) * (TH2 - 2) - 1;
-        det_layer_p<2, 1, TW2, TH2, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op2, px0, py0, thr);
-        det_layer_p<2, 2, TW2, TH2, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op2, px0, py0, thr);
-        det_layer_p<2, 3, TW2, TH2, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op2, px0, py0, thr);
+        det_layers_p3<2, TW2, TH2, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op2, px0, py0, thr);
+        nms_zero<TW2, TH2>(s_list);
         __syncthreads();
+        hess_stamp(2);
         nms_survivors<TW2, TH2, kP23Threads>(sdet, s_list, op2, thr, px0, py0, im, sv);
     } else {
         b -= g.nb2;
         const int px0 = (b % g.nbx3) * (TW3 - 2) - 1, py0 = (b / g.nbx3) * (TH3 - 2) - 1;
-        det_layer_p<3, 1, TW3, TH3, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op3, px0, py0, thr);
-        det_layer_p<3, 2, TW3, TH3, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op3, px0, py0, thr);
-        det_layer_p<3, 3, TW3, TH3, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op3, px0, py0, thr);
+        det_layers_p3<3, TW3, TH3, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op3, px0, py0, thr);
+        nms_zero<TW3, TH3>(s_list);
         __syncthreads();
+        hess_stamp(2);
         nms_survivors<TW3, TH3, kP23Threads>(sdet, s_list, op3, thr, px0, py0, im, sv);
     }
 }
@@ -833,21 +947,27 @@ static const int kP23SdetFloats = 3 * 16 * 32;
 // three blocks per CU -- the octave-0 / plane mix runs as fast with three as with four, 63 us, but not with two, 81 us).  The
 // patterns come from the device copy of the table (four of them exceed the 4 KB of kernel arguments).
 static const int kO1TileRows = 18;             // sample rows of an octave-1 tile in the merged launch
+struct HessGrid { int nbx0, nb0, nbx1, nb1; P23Grid g; };          // tiles per kind
+// (Measured and not kept, round 4: two to four consecutive tiles of a kind per workgroup, to save the ~1.9 us a workgroup slot's
+// turn-over costs per tile -- 93 / 103 / 105 us against 84: a slot bound to a fixed run of tiles loses the balance that "whichever
+// slot frees up takes the next tile" gives; the same lesson as the resident-workgroup queues)
 template <int TW, int TH>
 __global__ __launch_bounds__(kP23Threads) void k_hessian_nms_all(LanePair lp, int w, int h, const OctavePat* __restrict__ ops, float thr,
-                                                                 const uint16_t* __restrict__ order, int nbx0, int nbx1, P23Grid g)
+                                                                 const uint16_t* __restrict__ order, HessGrid hg)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const LaneArgs& LA = UVO_LANE_OF(lp, blockIdx.y); const ImgPair& ip = LA.ip; const SurvOut& sv = LA.sv;
     const int im = UVO_LANE_IM(blockIdx.y);
     const unsigned e = order[blockIdx.x];
     const int kind = e >> 14, idx = e & 0x3FFF;
-    if (kind == 0) hessian_nms_c_tile<0, TW, TH, kP23Threads>(ip, w, h, ops[0], thr, sv, idx % nbx0, idx / nbx0, im, smem);
-    else if (kind == 1) hessian_nms_c_tile<1, 32, kO1TileRows, kP23Threads>(ip, w, h, ops[1], thr, sv, idx % nbx1, idx / nbx1, im, smem);
+    hess_stamp(0); hess_stamp(4, kind == 2 ? (idx < hg.g.nb2 ? 2 : 3) : kind);
+    if (kind == 0) hessian_nms_c_tile<0, TW, TH, kP23Threads>(ip, w, h, ops[0], thr, sv, idx % hg.nbx0, idx / hg.nbx0, im, smem);
+    else if (kind == 1) hessian_nms_c_tile<1, 32, kO1TileRows, kP23Threads>(ip, w, h, ops[1], thr, sv, idx % hg.nbx1, idx / hg.nbx1, im, smem);
     else {
         float* sdet = reinterpret_cast<float*>(smem);
-        hessian_nms_p23_tile(ip, ops[2], ops[3], thr, sv, g, idx, im, sdet, reinterpret_cast<unsigned*>(sdet + kP23SdetFloats));
+        hessian_nms_p23_tile(ip, ops[2], ops[3], thr, sv, hg.g, idx, im, sdet, reinterpret_cast<unsigned*>(sdet + kP23SdetFloats));
     }
+    hess_stamp(3);
 }
 
 // debug / parity hook: one det+trace layer written to global planes (rows x cols)
@@ -1904,23 +2024,23 @@ uvo_status surf_prepare(Ctx* c, int w, int h)
     const MergedGrid m = merged_grid(ops);
     const int nb0 = m.nb0, nb1 = m.nb1, nb23 = m.nb23, total = m.total;
     if (nb0 > 0x3FFF || nb1 > 0x3FFF || nb23 > 0x3FFF) { c->err = "SURF: image too large for the merged detection launch's tile table"; return UVO_INVALID_ARG; }
-    if ((int)c->h_hess_order.size() != total || c->hess_order_key[0] != nb0 || c->hess_order_key[1] != nb1 || c->hess_order_key[2] != nb23) {
+    const int ng[3] = { nb0, nb1, nb23 }, ngroups = total;
+    if ((int)c->h_hess_order.size() != ngroups || c->hess_order_key[0] != nb0 || c->hess_order_key[1] != nb1 || c->hess_order_key[2] != nb23) {
         // block b's kind and tile: the i-th tile of a kind with n tiles sits at position (i + 1/2) / n of the launch
         std::vector<std::pair<double, uint16_t>> pos;
-        pos.reserve((size_t)total);
-        const int nk[3] = { nb0, nb1, nb23 };
-        for (int k = 0; k < 3; k++) for (int i = 0; i < nk[k]; i++) pos.emplace_back((i + 0.5) / nk[k] + k * 1e-9, (uint16_t)((k << 14) | i));
+        pos.reserve((size_t)ngroups);
+        for (int k = 0; k < 3; k++) for (int i = 0; i < ng[k]; i++) pos.emplace_back((i + 0.5) / ng[k] + k * 1e-9, (uint16_t)((k << 14) | i));
         std::sort(pos.begin(), pos.end());
-        c->h_hess_order.resize((size_t)total);
-        for (int b = 0; b < total; b++) c->h_hess_order[(size_t)b] = pos[(size_t)b].second;
+        c->h_hess_order.resize((size_t)ngroups);
+        for (int b = 0; b < ngroups; b++) c->h_hess_order[(size_t)b] = pos[(size_t)b].second;
         UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));               // nothing may still read the old table
-        if (c->d_hess_order_cap < (size_t)total) {
+        if (c->d_hess_order_cap < (size_t)ngroups) {
             if (c->d_hess_order) (void)hipFree(c->d_hess_order);
             c->d_hess_order = nullptr; c->d_hess_order_cap = 0;
-            UVO_HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_hess_order), sizeof(uint16_t) * (size_t)total));
-            c->d_hess_order_cap = (size_t)total;
+            UVO_HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_hess_order), sizeof(uint16_t) * (size_t)ngroups));
+            c->d_hess_order_cap = (size_t)ngroups;
         }
-        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_hess_order, c->h_hess_order.data(), sizeof(uint16_t) * (size_t)total, hipMemcpyHostToDevice, c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_hess_order, c->h_hess_order.data(), sizeof(uint16_t) * (size_t)ngroups, hipMemcpyHostToDevice, c->stream));
         UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->hess_order_key[0] = nb0; c->hess_order_key[1] = nb1; c->hess_order_key[2] = nb23;
     }
@@ -1934,6 +2054,7 @@ uvo_status surf_detect_lanes(Ctx* c, Ctx* c2, int nimg, int gate_min_features)
     const int w = c->img_w, h = c->img_h;
     if (c2 && (nimg != 2 || c2->img_w != w || c2->img_h != h || !c->p.SURF_UPRIGHT)) { c->err = "two-pair launch: upright SURF on two image pairs of one size"; return UVO_INVALID_ARG; }
     UVO_TRY(surf_prepare(c, w, h));
+    if (c2) { const uvo_status st2 = surf_prepare(c2, w, h); if (st2 != UVO_OK) { c->err = c2->err; return st2; } }
     const LanePair lp = lane_pair(c, c2, nimg, gate_min_features);
     const int nim = c2 ? 2 * nimg : nimg, nlanes = c2 ? 2 : 1;
     UVO_TRY(surf_integral_lanes(c, lp, nim));
@@ -1952,8 +2073,8 @@ uvo_status surf_detect_lanes(Ctx* c, Ctx* c2, int nimg, int gate_min_features)
             constexpr size_t lds = lds0 > lds1 ? lds0 : lds1;
             static_assert(lds <= 54600, "three blocks of the merged detection launch must fit a CU's 160 KB of LDS");
             const MergedGrid mg = merged_grid(ops);
-            const int nbx0 = mg.nbx0, nbx1 = mg.nbx1, total = mg.total;
-            const P23Grid g = mg.g;
+            const HessGrid hg = { mg.nbx0, mg.nb0, mg.nbx1, mg.nb1, mg.g };
+            const int total = mg.total;
             auto kern = k_hessian_nms_all<TW0, TH0>;
             static bool attr_dev[64] = {false};
             bool& attr_set = attr_dev[c->device & 63];
@@ -1962,8 +2083,24 @@ uvo_status surf_detect_lanes(Ctx* c, Ctx* c2, int nimg, int gate_min_features)
             static const size_t lds_pad = getenv("UVO_HESS_LDS") ? (size_t)atoi(getenv("UVO_HESS_LDS")) : 0;      // measurement: fewer blocks per CU
             const size_t lds_launch = lds_pad > lds ? lds_pad : lds;
             if (lds_pad > lds) { static bool once = false; if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch); once = true; } }
+            static const char* stamps_path = getenv("UVO_HESS_STAMPS");
+            static long long* d_stamps = nullptr; static size_t stamps_n = 0;
+            if (stamps_path && c->lane_id == 0 && !c->master) {
+                if (!d_stamps) { stamps_n = (size_t)total * 4 * 8; (void)hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(long long) * stamps_n); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hess_stamps), &d_stamps, sizeof(d_stamps)); }
+                (void)hipMemsetAsync(d_stamps, 0, sizeof(long long) * stamps_n, c->stream);
+            }
             hipLaunchKernelGGL(kern, dim3(total, nim), dim3(kP23Threads), lds_launch, c->stream, lp, w, h, static_cast<const OctavePat*>(c->d_octpat), thr,
-                               c->d_hess_order, nbx0, nbx1, g);
+                               c->d_hess_order, hg);
+            if (stamps_path && d_stamps && c->lane_id == 0 && !c->master) {        // (measurement: synchronous, every launch rewrites the file)
+                std::vector<long long> hs(stamps_n);
+                (void)hipStreamSynchronize(c->stream);
+                (void)hipMemcpy(hs.data(), d_stamps, sizeof(long long) * stamps_n, hipMemcpyDeviceToHost);
+                if (FILE* f = fopen(stamps_path, "w")) {
+                    fprintf(f, "block,im,kind,t_start,t_filled,t_det,t_end\n");
+                    for (int y = 0; y < nim; y++) for (int b = 0; b < total; b++) { const long long* r = hs.data() + ((size_t)y * total + b) * 8; fprintf(f, "%d,%d,%lld,%lld,%lld,%lld,%lld\n", b, y, r[4], r[0], r[1], r[2], r[3]); }
+                    fclose(f);
+                }
+            }
             UVO_HIP_TRY(c, hipGetLastError());
         }
         for (int o = 0; o < c->p.SURF_OCTAVES_NUMBER && !merged; o++) {
