@@ -181,7 +181,8 @@ def main():
     ap.add_argument("--no-pin", action="store_true", help="do not pin the rank to the cores next to its GPU")
     ap.add_argument("--blocks", type=int, default=7, help="the timed region (K steps between two fences) is run this many times in a row; "
                     "`value` is the median block, the first / slowest / fastest are reported beside it")
-    ap.add_argument("--no-trace", action="store_true", help="do not record the per-pair pipeline trace (on by default for --steps <= 64)")
+    ap.add_argument("--no-trace", action="store_true", help="do not record the per-pair pipeline trace (for --steps <= 64 one more, untimed-for-value block runs with it)")
+    ap.add_argument("--trace-all", action="store_true", help="trace every timed block instead (costs the 20-step form ~2.4 %)")
     ap.add_argument("--timed-only", action="store_true", help="diagnostics: stop after the timed region (no latency / roofline / CPU legs), "
                     "so that a UVO_TRACE file holds the timed pairs")
     ap.add_argument("--dump-records", default=None, help="rank 0 writes the gathered [world, steps, 16] pose records to this .npy")
@@ -303,8 +304,12 @@ def main():
     multirank.max_over_ranks(0.0, dev)
     del warm_results
 
+    # The per-pair pipeline trace (HIP timing events on the lanes' streams + host stamps) costs the submitting thread ~6 us per pair --
+    # 2.4 % of the driver's 20-step form (3830 with it, 3920 without, same box) -- so the timed blocks run WITHOUT it (their stalls, if
+    # any, are located by the per-collect host stamps, collect_gap_ms) and one more block of the same shape, not part of `value`, runs
+    # with it for runs of <= 64 steps (--trace-all: every block traced, as round 4's first bench lines were)
     trace_on = (not args.no_trace) and args.steps <= 64 and not args.timed_only
-    if trace_on:
+    if trace_on and args.trace_all:
         ctx.trace_enable(True)
     n_blocks = max(args.blocks, 1)
     block_dt, block_local, block_cpu, block_stamps = [], [], [], []
@@ -354,9 +359,17 @@ def main():
                       "what": "host clock between consecutive uvo_stereo_collect returns over all blocks; the first gap of a block is the pipeline fill"}
     trace_summary = None
     if trace_on:
+        if not args.trace_all:                                             # the diagnostic block: same shape, traced, not part of `value`
+            ctx.trace_enable(True)
+            res_t = (uvo.StereoResult * max(args.steps, 1))()
+            dt_t, _, _ = timed_block(args.steps, res_t, [0.0] * (args.steps + 1))
+            dt_t = multirank.max_over_ranks(dt_t, dev)
         tr = ctx.trace_read()
         ctx.trace_enable(False)
         trace_summary = summarise_trace(tr)
+        trace_summary["traced"] = "every timed block" if args.trace_all else "one more block after the timed ones (not part of `value`)"
+        if not args.trace_all:
+            trace_summary["traced_block_value"] = round(total_pairs / dt_t, 3)
 
     if rank == 0 and args.dump_records:
         np.save(args.dump_records, allrec.cpu().numpy())

@@ -648,6 +648,14 @@ __device__ __forceinline__ void det_layers_p3(const int32_t* __restrict__ planes
 template <int TW, int TH>
 struct NmsLds { static constexpr int kList = 3 * ((TW - 1) / 2) * ((TH - 1) / 2), kWords = kList + 2; };
 
+// UVO_HESS_STAMPS=<file> (measurement): wall-clock stamps (100 MHz) of every workgroup's phases in the last detection launch --
+// start, integral tile in LDS, box sums done, end -- with the tile kind, written as CSV when the context goes
+__device__ long long* g_hess_stamps = nullptr;
+__device__ __forceinline__ void hess_stamp(int k, long long v = -1)
+{
+    long long* st = g_hess_stamps;
+    if (st && threadIdx.x == 0) st[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = v >= 0 ? v : (long long)wall_clock64();
+}
 // the survivor count of a tile starts at zero: called before the barrier that precedes nms_survivors (one barrier less per tile: under
 // three workgroups per CU a barrier costs the wait for the slowest of eight time-sliced waves)
 template <int TW, int TH>
@@ -658,53 +666,58 @@ __device__ __forceinline__ void nms_survivors(const float* __restrict__ sdet, un
 {
     const int tid = lane_tid();
     int* s_n = reinterpret_cast<int*>(s_list + NmsLds<TW, TH>::kList);       // [0] count (zeroed by the caller before its last barrier: nms_zero), [1] base
-    // the centre values of every sample this thread tests -- three layers x ITER samples -- are read first (independent LDS
-    // reads in flight together), then compared: read one at a time, each behind its own bounds tests and branch, the scan took 3 of
-    // a tile's 12 us in a workgroup whose SIMDs are shared with two other tiles' box sums (tools/probe/hess_stamps.py)
-    // Thread tid looks at column tid % TW of rows tid / TW + k NT / TW (TW is a power of two): a sample's det value is at
-    // sdet[tid + constant], no index arithmetic per sample -- the workgroup shares its SIMDs with two other tiles' box sums, so every
-    // instruction of this scan costs three.
-    static_assert((TW & (TW - 1)) == 0 && NT % TW == 0, "tile width: a power of two that divides the workgroup");
-    constexpr int RP = NT / TW, ITER = (TH - 2 + RP - 1) / RP;
-    const int rx = tid & (TW - 1), r0 = tid / TW;
+    // Strict 3 x 3 x 3 maxima by separable maxima instead of up to 26 comparisons per candidate behind a divergent branch (in-kernel
+    // stamps: the scan was 1.9 of an octave-0 tile's 11 us, the wave executing the whole neighbourhood test for every sample position
+    // at which ANY of its lanes beat the threshold).  Thread tid owns column tid % TW (TW a power of two) and ITER consecutive rows:
+    // it reads its column's ITER + 2 values of every layer once (LDS, immediate offsets), takes the vertical 3-maxima, and gets its
+    // left and right neighbours' from the adjacent lanes (DPP wave shifts: adjacent lanes are adjacent columns).  val0 is a strict
+    // maximum of its layer iff it exceeds max(above, below, left column's 3-max, right column's 3-max), and of an adjacent layer
+    // iff it exceeds max(own, left, right column's 3-max) there: the same comparisons, so the same survivors.
+    static_assert((TW & (TW - 1)) == 0 && NT % TW == 0 && TW <= 64, "tile width: a power of two that divides the workgroup, a row within a wave");
+    constexpr int G = NT / TW, ITER = (TH - 2 + G - 1) / G;
+    const int rx = tid & (TW - 1), g = tid / TW;
     const int j = px0 + rx;
+    float col[3][ITER + 2];
+#pragma unroll
+    for (int l = 0; l < 3; l++)
+#pragma unroll
+        for (int k = 0; k < ITER + 2; k++) col[l][k] = sdet[(l * TH + min(g * ITER + k, TH - 1)) * TW + rx];
+    float m3[3][ITER], m3l[3][ITER], m3r[3][ITER];
+#pragma unroll
+    for (int l = 0; l < 3; l++)
+#pragma unroll
+        for (int k = 0; k < ITER; k++) {
+            const float v = fmaxf(fmaxf(col[l][k], col[l][k + 1]), col[l][k + 2]);
+            m3[l][k] = v;
+            // value of lane - 1 / lane + 1 (wave_shr:1 / wave_shl:1; a lane without a source keeps its own value: halo columns only)
+            m3l[l][k] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xF, 0xF, false));
+            m3r[l][k] = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xF, 0xF, false));
+        }
 #pragma unroll
     for (int l = 0; l < 3; l++) {
         const int L = l + 1;
         const int m = op.nms_margin[l];
         const bool col_ok = op.L[L].samples_i != 0 && op.L[L + 1].samples_i != 0 && rx >= 1 && rx <= TW - 2 && j >= m && j < op.cols - m;
-        float v0[ITER];                                          // a layer's centre values first (independent LDS reads), then the tests
 #pragma unroll
-        for (int u = 0; u < ITER; u++) {
-            const int ry = r0 + u * RP + 1, i = py0 + ry;
-            const bool in = col_ok && ry <= TH - 2 && i >= m && i < op.rows - m;
-            v0[u] = in ? sdet[tid + TW + u * NT + l * TH * TW] : kDetBelow;
-        }
-#pragma unroll
-        for (int u = 0; u < ITER; u++) {
-            const float val0 = v0[u];
-            if (!(val0 > thr)) continue;
-            const int ry = r0 + u * RP + 1;
-            const float* d2 = sdet + (l * TH + ry) * TW + rx;
-            bool is_max = val0 > d2[-TW-1] && val0 > d2[-TW] && val0 > d2[-TW+1] && val0 > d2[-1] && val0 > d2[1] &&
-                          val0 > d2[TW-1] && val0 > d2[TW] && val0 > d2[TW+1];
-            const float* d1 = d2 - TH * TW;
-            const float* d3 = d2 + TH * TW;
-            if (is_max && L <= 2)
-                is_max = val0 > d3[-TW-1] && val0 > d3[-TW] && val0 > d3[-TW+1] && val0 > d3[-1] && val0 > d3[0] && val0 > d3[1] &&
-                         val0 > d3[TW-1] && val0 > d3[TW] && val0 > d3[TW+1];
-            if (is_max && L >= 2)
-                is_max = val0 > d1[-TW-1] && val0 > d1[-TW] && val0 > d1[-TW+1] && val0 > d1[-1] && val0 > d1[0] && val0 > d1[1] &&
-                         val0 > d1[TW-1] && val0 > d1[TW] && val0 > d1[TW+1];
+        for (int k = 0; k < ITER; k++) {
+            const int ry = g * ITER + k + 1, i = py0 + ry;
+            const float val0 = col[l][k + 1];
+            float nb = fmaxf(fmaxf(col[l][k], col[l][k + 2]), fmaxf(m3l[l][k], m3r[l][k]));           // the eight in-layer neighbours
+            if (L <= 2) nb = fmaxf(nb, fmaxf(m3[l + 1][k], fmaxf(m3l[l + 1][k], m3r[l + 1][k])));      // the nine of the layer above
+            if (L >= 2) nb = fmaxf(nb, fmaxf(m3[l - 1][k], fmaxf(m3l[l - 1][k], m3r[l - 1][k])));      // the nine of the layer below
+            const bool is_max = col_ok && ry <= TH - 2 && i >= m && i < op.rows - m && val0 > thr && val0 > nb;
             if (is_max) s_list[atomicAdd(&s_n[0], 1)] = (unsigned)L | ((unsigned)ry << 8) | ((unsigned)rx << 16);
         }
     }
+    hess_stamp(5);
     __syncthreads();
+    hess_stamp(6);
     const int nloc = s_n[0];
     // one global atomic per workgroup (a device-scope increment of one address costs ~7 ns chip-wide, and its wave a round trip)
     if (nloc == 0) return;
     if (tid == 0) s_n[1] = atomicAdd(sv.count, nloc);
     __syncthreads();
+    hess_stamp(7);
     const int base = s_n[1];
     // a record is 32 words (im, octave, L, i, j, 27 neighbourhood values): 32 lanes write one word each (one thread per survivor
     // writing its 128 bytes took ~1 us of a tile's life)
@@ -819,14 +832,6 @@ __global__ __launch_bounds__(256) void k_hessian_finish(LanePair lp, const Octav
     }
 }
 
-// UVO_HESS_STAMPS=<file> (measurement): wall-clock stamps (100 MHz) of every workgroup's phases in the last detection launch --
-// start, integral tile in LDS, box sums done, end -- with the tile kind, written as CSV when the context goes
-__device__ long long* g_hess_stamps = nullptr;
-__device__ __forceinline__ void hess_stamp(int k, long long v = -1)
-{
-    long long* st = g_hess_stamps;
-    if (st && threadIdx.x == 0) st[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = v >= 0 ? v : (long long)wall_clock64();
-}
 // One tile of octave 0 or 1 (tile bx, by of image im): the body of k_hessian_nms_c and of the octave-0 blocks of k_hessian_nms_c0_p23
 template <int O, int TW, int TH, int NT>
 __device__ __forceinline__ void hessian_nms_c_tile(const ImgPair& ip, int w, int h, const OctavePat& op, float thr, const SurvOut& sv,
@@ -2096,8 +2101,8 @@ uvo_status surf_detect_lanes(Ctx* c, Ctx* c2, int nimg, int gate_min_features)
                 (void)hipStreamSynchronize(c->stream);
                 (void)hipMemcpy(hs.data(), d_stamps, sizeof(long long) * stamps_n, hipMemcpyDeviceToHost);
                 if (FILE* f = fopen(stamps_path, "w")) {
-                    fprintf(f, "block,im,kind,t_start,t_filled,t_det,t_end\n");
-                    for (int y = 0; y < nim; y++) for (int b = 0; b < total; b++) { const long long* r = hs.data() + ((size_t)y * total + b) * 8; fprintf(f, "%d,%d,%lld,%lld,%lld,%lld,%lld\n", b, y, r[4], r[0], r[1], r[2], r[3]); }
+                    fprintf(f, "block,im,kind,t_start,t_filled,t_det,t_end,t_scan,t_scanbar,t_atomic\n");
+                    for (int y = 0; y < nim; y++) for (int b = 0; b < total; b++) { const long long* r = hs.data() + ((size_t)y * total + b) * 8; fprintf(f, "%d,%d,%lld,%lld,%lld,%lld,%lld,%lld,%lld,%lld\n", b, y, r[4], r[0], r[1], r[2], r[3], r[5], r[6], r[7]); }
                     fclose(f);
                 }
             }

@@ -4,7 +4,7 @@
 # Steps (outputs under gpurun_out/; a failing step stops the chain):
 #   tests [pytest args]         python -m pytest <args, default: tests -m gpu> -x -q            -> <tag>_tests.log
 #   bench [bench.py args]       one bench.py line (stdout)                                       
-#   bench20 [n]                 the driver's form n times (--steps 20 --warmup 5), value + blocks
+#   bench20 [n] [bench args]    the driver's form n times (--steps 20 --warmup 5 + args, e.g. --no-trace), value + blocks
 #   ab <steps>                  previous build (ergo_uvo_amd/lib_ab/libuvo_hip_old.so) against the current one, interleaved
 #   sweep <steps>               overlap / depth / PnP-slot settings of the one-pair pipeline
 #   batch <steps>               one- and two-pair launch sets over depth / overlap settings
@@ -12,6 +12,7 @@
 #   hess-split <tag>            per-octave detection kernels (UVO_HESSIAN_SPLIT=1) and the merged launch, old build and new
 #   pmc <tag> <kernel pattern> [split]   counter passes (separate --pmc runs: SQ set 1, SQ set 2, FETCH_SIZE, WRITE_SIZE) of a synchronous run
 #   ctx-reuse [pairs]           five contexts in a row, stream pool on and off
+#   stamps                      phases of the detection launch's workgroups (UVO_HESS_STAMPS -> tools/probe/hess_stamps.py)
 #   rates                       issue-rate probe (built by hipcc here if missing)
 #   topo                        what the rank pinning reads on this box
 #   configs                     tools/bench_configs.py
@@ -30,7 +31,7 @@ step() {
     tests)   if [ $# -eq 0 ]; then set -- tests -m gpu; fi
              timeout -k 10 1100 python -m pytest "$@" -x -q > gpurun_out/${TAG}_tests.log 2>&1; rc=$?; tail -4 gpurun_out/${TAG}_tests.log; return $rc ;;
     bench)   python bench.py "$@" ;;
-    bench20) for i in $(seq ${1:-3}); do python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('20/5:', d['value'], 'first', d['value_first_block'], d['block_values'], 'gap max', d['collect_gap_ms']['max'], d['collect_gap_ms']['argmax'])" || return 1; done ;;
+    bench20) n=${1:-3}; shift; for i in $(seq $n); do python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('20/5:', d['value'], 'first', d['value_first_block'], d['block_values'], 'gap max', d['collect_gap_ms']['max'], d['collect_gap_ms']['argmax'])" || return 1; done ;;
     ab)      for rep in 1 2; do UVO_HIP_LIB=$OLD LBL=old brun --steps ${1:-300} || return 1; LBL=new brun --steps ${1:-300} || return 1; done ;;
     sweep)   n=${1:-300}
              LBL=default brun --steps $n --depth 6; UVO_A_OVERLAP=3 LBL="A_OVERLAP=3 depth 6" brun --steps $n --depth 6; UVO_A_OVERLAP=3 LBL="A_OVERLAP=3 depth 8" brun --steps $n --depth 8
@@ -62,6 +63,7 @@ step() {
              unset UVO_HESSIAN_SPLIT
              for p in sq1 sq2 fetch write; do python tools/probe/pmc_quick.py pmc_${t}_${p} "$pat" 2; done ;;
     ctx-reuse) python tools/probe/ctx_reuse.py ${1:-400} 2>/dev/null | grep pool; UVO_STREAM_POOL=0 python tools/probe/ctx_reuse.py ${1:-400} 2>/dev/null | grep pool ;;
+    stamps)  UVO_HESS_STAMPS=gpurun_out/${TAG}_hess_stamps.csv python tools/prof_stereo.py 8 > /dev/null 2>&1; python tools/probe/hess_stamps.py gpurun_out/${TAG}_hess_stamps.csv ;;
     rates)   [ -x tools/probe/issue_rate_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probe/issue_rate_probe.hip -o tools/probe/issue_rate_probe || return 1
              tools/probe/issue_rate_probe ;;
     topo)    for n in /sys/class/kfd/kfd/topology/nodes/*; do echo "== $n"; grep -E "simd_count|cpu_cores_count|location_id|domain|drm_render_minor" $n/properties 2>&1; done
