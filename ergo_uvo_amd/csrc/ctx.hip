@@ -151,20 +151,22 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
         A(dalloc(&c->d_cand[i], cap)); A(dalloc(&c->det[i].kps, cap)); A(dalloc(&c->det[i].desc, cap * 128));      // 128: SURF_EXTENDED rows
         A(dalloc(&c->d_tmp_desc[i], cap * 128)); A(dalloc(&c->d_matches[i], cap));
         A(dalloc(&c->d_as_kpsL[i], cap)); A(dalloc(&c->d_as_kpsR[i], cap)); A(dalloc(&c->d_as_descL[i], cap * 128));
+        A(dalloc(&c->d_as_pts4[i], cap)); A(dalloc(&c->d_as_cam1[i], cap * 3)); A(dalloc(&c->d_as_flag[i], cap));
     }
     c->surv_cap = 4 * (int)cap; A(dalloc(&c->d_surv, (size_t)c->surv_cap));
     A(dalloc(&c->d_colpart, (size_t)2 * nstrip * c->colpart_stride));
     A(dalloc(&c->d_DW, 400)); A(dalloc(&c->d_rank, cap * 2)); A(dalloc(&c->d_big_par, cap * 4)); A(dalloc(&c->d_big_patch, cap * 2 * 448));
     A(dalloc(&c->d_mpart, 2 * nchunks * cap)); A(dalloc(&c->d_mscratch, 2 * (nchunks + 4))); A(dalloc(&c->d_knn_idx, 2 * cap * 2)); A(dalloc(&c->d_knn_dist, 2 * cap * 2));
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
-    A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_tmp_idx, cap));
+    A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_tmp_idx, cap)); A(dalloc(&c->d_tmp_row, cap));
     if (const char* ww = getenv("UVO_WORKER_WAIT")) c->worker_wait = !strcmp(ww, "spin") ? 0 : (!strcmp(ww, "block-all") ? 2 : 1);
     A(hipEventCreateWithFlags(&c->evBlock, hipEventDisableTiming | hipEventBlockingSync));
+    A(hipEventCreateWithFlags(&c->evPoll, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
         A(dalloc(&c->d_good_pts[i], cap * 3)); A(dalloc(&c->d_good_idx[i], cap));
         A(dalloc(&c->d_opts[i], cap * 3)); A(dalloc(&c->d_ipts[i], cap));
         // evA[0] is the event the lane's worker waits on (sleeping unless UVO_WORKER_WAIT=spin), evA[1] the one the submitting thread polls
-        A(hipEventCreateWithFlags(&c->evA[i], hipEventDisableTiming | ((i == 0 && c->worker_wait != 0) ? hipEventBlockingSync : 0)));
+        A(hipEventCreateWithFlags(&c->evA[i], hipEventDisableTiming | ((i == 0 && c->worker_wait == 2) ? hipEventBlockingSync : 0)));
         A(hipHostMalloc(reinterpret_cast<void**>(&c->h_countsA[i]), sizeof(int) * CN_TOTAL));
     }
     A(hipEventCreateWithFlags(&c->evAS, hipEventDisableTiming));
@@ -360,6 +362,7 @@ static void destroy_one(uvo_ctx* c)
         (void)hipFree(c->d_img[i]); (void)hipFree(c->d_sum_base[i]); (void)hipFree(c->d_planes[i]); (void)hipFree(c->d_cand[i]); (void)hipFree(c->det[i].kps);
         (void)hipFree(c->det[i].desc); (void)hipFree(c->d_tmp_desc[i]); (void)hipFree(c->d_matches[i]);
         (void)hipFree(c->d_as_kpsL[i]); (void)hipFree(c->d_as_kpsR[i]); (void)hipFree(c->d_as_descL[i]);
+        (void)hipFree(c->d_as_pts4[i]); (void)hipFree(c->d_as_cam1[i]); (void)hipFree(c->d_as_flag[i]);
     }
     if (c->pnp_stream) (void)hipStreamSynchronize(c->pnp_stream);
     mono_ws_free(c);
@@ -367,7 +370,7 @@ static void destroy_one(uvo_ctx* c)
     codec_ws_free(c);
     sift_ws_free(c);
     void* ptrs[] = { c->d_hess_order, c->d_surv, c->d_octpat, c->d_colpart, c->d_DW, c->d_rank, c->d_big_par, c->d_big_patch, c->d_area_tabs, c->d_area_iscale, c->d_ori_w, c->d_mpart, c->d_mscratch, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
-                     c->d_flag, c->d_tmp_idx, c->d_good_pts[0], c->d_good_pts[1], c->d_good_idx[0], c->d_good_idx[1], c->d_opts[0], c->d_opts[1],
+                     c->d_flag, c->d_tmp_idx, c->d_tmp_row, c->d_good_pts[0], c->d_good_pts[1], c->d_good_idx[0], c->d_good_idx[1], c->d_opts[0], c->d_opts[1],
                      c->d_ipts[0], c->d_ipts[1], c->d_counts, c->d_countsB, c->d_subsets, c->d_models,
                      c->d_hcount, c->d_inliers, c->d_refit, c->d_pose };
     for (void* p : ptrs) (void)hipFree(p);
@@ -381,6 +384,7 @@ static void destroy_one(uvo_ctx* c)
     }
     if (c->evAS) (void)hipEventDestroy(c->evAS);
     if (c->evBlock) (void)hipEventDestroy(c->evBlock);
+    if (c->evPoll) (void)hipEventDestroy(c->evPoll);
     if (c->evSync) (void)hipEventDestroy(c->evSync);
     if (c->evProducer) (void)hipEventDestroy(c->evProducer);
     for (auto& r : c->trace) for (int k = 0; k < 6; k++) if (r.ev[k]) (void)hipEventDestroy(r.ev[k]);
@@ -434,9 +438,22 @@ static uvo_status need_idle(uvo_ctx* c, const char* who)
 static uvo_status fail(uvo_ctx* c, uvo_status s, const char* msg) { c->err = msg; return s; }
 
 namespace uvo {
+// Host waits of the pipelines' hot paths poll with queries of their own.  hipStreamSynchronize / hipEventSynchronize spin for ~100 us and
+// then sleep on the signal's interrupt, and on this stack about one such sleep in a hundred wakes 2-4 ms late (round 4: pipeline_trace
+// showed 3.3 and 4.4 ms between the end of a stage A and its worker's first PnP launch; the driver's round-3 record of 1990 pairs/s
+// was one of those inside a 10 ms window).  A query never sleeps.
+static inline void poll_pause() { for (int i = 0; i < 40; i++) __builtin_ia32_pause(); }
+hipError_t poll_event(hipEvent_t ev)
+{
+    hipError_t e;
+    while ((e = hipEventQuery(ev)) == hipErrorNotReady) poll_pause();
+    return e;
+}
 hipError_t host_sync(Ctx* c, hipStream_t st)
 {
-    if (c->worker_wait < 2) return hipStreamSynchronize(st);
+    // (an event of the lane's own and hipEventQuery -- a load of the signal; hipStreamQuery in a loop cost the 600-step form 6 % and put
+    // millisecond gaps back: p99 of the collect gaps 0.95 ms against 0.33)
+    if (c->worker_wait < 2) { const hipError_t e = hipEventRecord(c->evPoll, st); return e == hipSuccess ? poll_event(c->evPoll) : e; }
     hipError_t e = hipEventRecord(c->evBlock, st);
     return e == hipSuccess ? hipEventSynchronize(c->evBlock) : e;
 }
@@ -907,6 +924,10 @@ static uvo_status stereo_init_step(uvo_ctx* c, uvo_stereo_result* out)
         hipLaunchKernelGGL(k_gather_kps_idx, dim3((total + 255) / 256), dim3(256), 0, c->stream, c->det[1].kps, d_idx, total, c->d_as_kpsR[b]);
         UVO_HIP_TRY(c, hipMemcpyAsync(c->d_as_n + b, &total, sizeof(int), hipMemcpyHostToDevice, c->stream));
         UVO_HIP_TRY(c, hipMemcpyAsync(c->d_matches[0], c->init_matches.data(), sizeof(uvo_dmatch) * total, hipMemcpyHostToDevice, c->stream));
+        {   // the set's rows, triangulated for the pair that follows (every later pair does this in the tail of its stage A)
+            const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
+            UVO_TRY(pose_as_triangulate(c, c->stream, b, nullptr, total, c->P_eye_left, c->P_right, I, z, c->R_right, c->t_right, c->K_left, c->K_right));
+        }
         UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
         UVO_HIP_TRY(c, hipGetLastError());
     }
@@ -941,6 +962,7 @@ static uvo_status prime_lanes(uvo_ctx* c, int w, int h)
         // the PnP stream from the lane's worker thread, which is the thread that will use it: its first launch and its first wait
         // (event + stream) also set up the runtime's per-thread state
         UVO_HIP_TRY(c, hipEventRecord(l->evA[0], l->stream));
+        l->t_handover_us = 0;
         { std::lock_guard<std::mutex> lk(l->mu); l->job.kind = 2; l->job.state = 1; }
         l->cv.notify_all();
         { std::unique_lock<std::mutex> lk(l->mu); l->cv.wait(lk, [&] { return l->job.state == 2; }); l->job.state = 0; }
@@ -1056,7 +1078,7 @@ static uvo_status queue_stage_a(uvo_ctx* c, uvo_ctx* A, uvo_ctx* B)
         const int back = B ? 2 * c->a_overlap2 : c->a_overlap;
         if (back > 0 && depth > back && pa.pending_before >= back) {
             Ctx* H = c->lanes[(pa.lane + depth - back) % depth];
-            (void)hipEventSynchronize(H->evA[1]);
+            (void)uvo::poll_event(H->evA[1]);
         }
     }
     seg(9);                                                                                // the pacing wait
@@ -1097,19 +1119,29 @@ static uvo_status queue_stage_a(uvo_ctx* c, uvo_ctx* A, uvo_ctx* B)
                               B->d_as_kpsL[currB], B->d_as_kpsR[currB], B->d_as_descL[currB], B->desc_dim(), A->det[0].kps, A->det[1].kps,
                               B->d_x1, B->d_x2, B->d_xc, (cap + 15) / 16, A->d_matches[0] };
     }
-    {
-        StageTimer t(A, ST_GATHER);
-        hipLaunchKernelGGL(k_gather_stereo_step, dim3((cap + 15) / 16 + (cap + 255) / 256, B ? 2 : 1), dim3(256), 0, st, gp);
-    }
-    UVO_HIP_TRY(c, hipEventRecord(A->evAS, st));
-    if (B) UVO_HIP_TRY(c, hipEventRecord(B->evAS, st));
-    UVO_HIP_TRY(c, hipGetLastError());
-    }
-    // triangulation + extract_3Dpoints (VO:631-632)
-    Range r_tri("uvo:triangulatePoints + extract_3Dpoints");
     const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
-    LANE_TRY(pose_triangulate_extract3d(A, 0, c->P_eye_left, c->P_right, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap,
-                                        A->h_countsA[0], B, B ? B->h_countsA[0] : nullptr));   // the counters land in pinned memory, no copy queued
+    if (B) {
+        {
+            StageTimer t(A, ST_GATHER);
+            hipLaunchKernelGGL(k_gather_stereo_step, dim3((cap + 15) / 16 + (cap + 255) / 256, 2), dim3(256), 0, st, gp);
+        }
+        UVO_HIP_TRY(c, hipGetLastError());
+        // triangulation + extract_3Dpoints (VO:631-632) of both pairs on the point pairs just gathered; the rows of the second pair's set
+        // for a pair that follows alone (the first pair's set is read by the second only)
+        Range r_tri("uvo:triangulatePoints + extract_3Dpoints");
+        LANE_TRY(pose_triangulate_extract3d(A, 0, c->P_eye_left, c->P_right, I, z, c->R_right, c->t_right, c->K_left, c->K_right, cn + CN_T, cap,
+                                            A->h_countsA[0], B, B->h_countsA[0]));              // the counters land in pinned memory, no copy queued
+        LANE_TRY(pose_as_triangulate(B, st, B->plan.curr, B->d_as_n + B->plan.curr, cap, c->P_eye_left, c->P_right, I, z, c->R_right, c->t_right, c->K_left, c->K_right));
+        UVO_HIP_TRY(c, hipEventRecord(A->evAS, st));
+        UVO_HIP_TRY(c, hipEventRecord(B->evAS, st));
+    } else {
+        // one launch: this pair's set (VO:569-579) and its rows triangulated for the next pair; extract_3Dpoints (VO:632) on the rows of
+        // the previous pair's set that the triangular matches select (VO:631's points, triangulated in that pair's tail)
+        Range r_tri("uvo:select + triangulatePoints + extract_3Dpoints");
+        LANE_TRY(pose_stereo_tail(A, P, prev, curr, 0, c->P_eye_left, c->P_right, I, z, c->R_right, c->t_right, c->K_left, c->K_right, A->h_countsA[0]));
+        UVO_HIP_TRY(c, hipEventRecord(A->evAS, st));
+    }
+    }
     UVO_HIP_TRY(c, hipEventRecord(A->evA[1], st));                                          // end of stage A, for the pacing of later pairs (see uvo_ctx.h)
     if (B) UVO_HIP_TRY(c, hipEventRecord(B->evA[1], st));
     if (trA) UVO_HIP_TRY(c, hipEventRecord(trA->ev[2], st));
@@ -1138,6 +1170,7 @@ static uvo_status queue_stage_a(uvo_ctx* c, uvo_ctx* A, uvo_ctx* B)
             UVO_HIP_TRY(c, hipEventRecord(L->evSync, sb));
             L->job.kind = 0;
         } else {   // hand stage B to the lane's worker
+            L->t_handover_us = uvo::now_us();
             { std::lock_guard<std::mutex> lk(L->mu); L->job.kind = 0; L->job.state = 1; }
             L->cv.notify_all();
         }
@@ -1174,6 +1207,27 @@ static void run_stage_b(uvo_ctx* L, bool stage_a_ok)
         else { j.wrote = r.wrote; j.ok = r.ok; j.ninl = r.ninl; memcpy(j.rvec, r.rvec, sizeof(j.rvec)); memcpy(j.tvec, r.tvec, sizeof(j.tvec)); }
     }
 }
+// The lane worker's long wait, for the end of its pair's stage A (uvo_ctx.h: worker_wait).
+static bool wait_stage_a(uvo_ctx* L)
+{
+    if (L->worker_wait == 2) return hipEventSynchronize(L->evA[0]) == hipSuccess;       // sleeps on the interrupt (hipEventBlockingSync)
+    if (L->worker_wait == 0) return uvo::poll_event(L->evA[0]) == hipSuccess;
+    Ctx* m = L->master ? L->master : L;
+    const double t0 = L->t_handover_us, mean = m->stage_a_mean_us.load(std::memory_order_relaxed);
+    for (;;) {
+        const hipError_t e = hipEventQuery(L->evA[0]);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) return false;
+        const double left = t0 + 0.8 * mean - now_us();                 // sleep through the first four fifths of an average stage A ..
+        if (left > 60.0) std::this_thread::sleep_for(std::chrono::microseconds((long long)(left < 400.0 ? left - 40.0 : 360.0)));
+        else for (int i = 0; i < 40; i++) __builtin_ia32_pause();        // .. and poll over the rest (a query every microsecond or two)
+    }
+    if (t0 > 0) {
+        const double d = now_us() - t0;
+        m->stage_a_mean_us.store(mean == 0.0 ? d : mean + 0.125 * (d - mean), std::memory_order_relaxed);
+    }
+    return true;
+}
 static void lane_worker(uvo_ctx* L)
 {
     (void)hipSetDevice(L->device);
@@ -1184,7 +1238,7 @@ static void lane_worker(uvo_ctx* L)
         lk.unlock();
         // stage A's end is awaited before a PnP slot is taken, so a slot is never held idle
         const double t0 = g_bdbg ? now_us() : 0;
-        const bool stage_a_ok = hipEventSynchronize(L->evA[0]) == hipSuccess;
+        const bool stage_a_ok = wait_stage_a(L);
         if (g_bdbg) g_bstat[0] += now_us() - t0;
         Ctx::TraceRec* wtr = (L->trace_on && L->trace_cur >= 0 && L->job.kind == 0) ? &L->trace[L->trace_cur] : nullptr;
         if (wtr) wtr->host_us[3] = now_us();
@@ -1240,7 +1294,7 @@ extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_resul
     }
     if (L->inline_b) {
         L->inline_b = false;
-        run_stage_b(L, hipEventSynchronize(L->evSync) == hipSuccess);
+        run_stage_b(L, uvo::poll_event(L->evSync) == hipSuccess);
     } else {
         std::unique_lock<std::mutex> lk(L->mu);
         L->cv.wait(lk, [&] { return L->job.state == 2; });
@@ -1710,7 +1764,7 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
     LANE_TRY(surf_upload(L, 0, img, w, h, stride, mem));
     if (c->a_overlap_mono > 0 && depth > c->a_overlap_mono) {                              // as uvo_stereo_submit: paced by this thread; one image per frame, so more stage As side by side
         Ctx* H = c->lanes[(li + depth - c->a_overlap_mono) % depth];
-        if (c->n_pending >= c->a_overlap_mono) (void)hipEventSynchronize(H->evA[1]);
+        if (c->n_pending >= c->a_overlap_mono) (void)uvo::poll_event(H->evA[1]);
     }
     LANE_TRY(detect_dispatch(L, 1));                                                       // VO:274
     UVO_HIP_TRY(c, hipEventRecord(L->evDet, st));
@@ -1729,6 +1783,7 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
     UVO_HIP_TRY(c, hipEventRecord(L->evA[1], st));                                          // the same point for other streams (see uvo_ctx.h)
     c->prev_lane = li; c->next_lane = (li + 1) % depth;
     c->inflight[c->n_pending++] = li; c->n_submitted++;
+    L->t_handover_us = uvo::now_us();
     {
         std::lock_guard<std::mutex> lk(L->mu);
         L->job.kind = 1; L->job.range = range; L->job.state = 1;

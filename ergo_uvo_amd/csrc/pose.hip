@@ -65,20 +65,20 @@ __device__ __forceinline__ void extract3d_point(const float4 p, const uvo_point2
 struct TriLane { const uvo_point2f* x1; const uvo_point2f* x2; const int* n_p; float4* out; double* cam1; int* flag; };
 struct TriLanes { TriLane l[2]; };
 struct Ex3Lane { const double* cam1; const int* flag; const uvo_point2f* xc; const int* n_p; int* tmp_idx; double* good_pts; int* good_idx; float* opts;
-                 uvo_point2f* ipts; int* counts /* [1] = G */; int* counts_host /* pinned mirror of all the step's counters, or null */; };
+                 uvo_point2f* ipts; int* counts /* [1] = G */; int* counts_host /* pinned mirror of all the step's counters, or null */;
+                 // the stereo loop's tail (k_stereo_tail): point i is row map[i].queryIdx of cam1 / flag / pts4 (the previous pair's set, triangulated
+                 // row by row in that pair's own tail) and its current-image point is keypoint map[i].trainIdx of cL; null: point i is row i
+                 const uvo_dmatch* map; const uvo_keypoint* cL; const float4* pts4; float4* out_pts4; int* tmp_row; };
 struct Ex3Lanes { Ex3Lane l[2]; };
-template <bool FILTER>
-__global__ __launch_bounds__(kTriThreads) void k_triangulate(Mat34 P1, Mat34 P2, TriLanes lanes, int n_imm, Cam c1, Cam c2, double tol)
+// cv::triangulatePoints for one point pair, by thread threadIdx.x < TT of its workgroup (the 4x4 Jacobi SVD's operands live in
+// LDS, one column of `lds` per thread)
+static const int kTriLdsDoubles = (16 + 16 + 16 + 4 + 4) * kTriThreads;
+template <int TT = kTriThreads>
+__device__ __forceinline__ float4 triangulate_point(const Mat34& P1, const Mat34& P2, const uvo_point2f a, const uvo_point2f b, double* lds)
 {
-    const TriLane& LN = lanes.l[blockIdx.y];
-    const uvo_point2f* x1 = LN.x1; const uvo_point2f* x2 = LN.x2; const int* n_p = LN.n_p; float4* out = LN.out; double* cam1 = LN.cam1; int* flag = LN.flag;
-    const int n = n_p ? *n_p : n_imm;
-    const int i = blockIdx.x * kTriThreads + threadIdx.x;
-    __shared__ double lds[(16 + 16 + 16 + 4 + 4) * kTriThreads];
-    if (i >= n) return;
-    using A = SArr<kTriThreads>;
+    using A = SArr<TT>;
     A Am{lds + threadIdx.x}, At = Am + 16, Vt = Am + 32, W = Am + 48, Wt = Am + 52;
-    const double xa = x1[i].x, ya = x1[i].y, xb = x2[i].x, yb = x2[i].y;
+    const double xa = a.x, ya = a.y, xb = b.x, yb = b.y;
     for (int k = 0; k < 4; k++) {
         Am[0*4 + k] = xa * P1.v[2*4 + k] - P1.v[0*4 + k];
         Am[1*4 + k] = ya * P1.v[2*4 + k] - P1.v[1*4 + k];
@@ -86,7 +86,18 @@ __global__ __launch_bounds__(kTriThreads) void k_triangulate(Mat34 P1, Mat34 P2,
         Am[3*4 + k] = yb * P2.v[2*4 + k] - P2.v[1*4 + k];
     }
     svd_square<4>(Am, At, W, Vt, Wt);
-    const float4 X = make_float4((float)Vt[12], (float)Vt[13], (float)Vt[14], (float)Vt[15]);
+    return make_float4((float)Vt[12], (float)Vt[13], (float)Vt[14], (float)Vt[15]);
+}
+template <bool FILTER>
+__global__ __launch_bounds__(kTriThreads) void k_triangulate(Mat34 P1, Mat34 P2, TriLanes lanes, int n_imm, Cam c1, Cam c2, double tol)
+{
+    const TriLane& LN = lanes.l[blockIdx.y];
+    const uvo_point2f* x1 = LN.x1; const uvo_point2f* x2 = LN.x2; const int* n_p = LN.n_p; float4* out = LN.out; double* cam1 = LN.cam1; int* flag = LN.flag;
+    const int n = n_p ? *n_p : n_imm;
+    const int i = blockIdx.x * kTriThreads + threadIdx.x;
+    __shared__ double lds[kTriLdsDoubles];
+    if (i >= n) return;
+    const float4 X = triangulate_point(P1, P2, x1[i], x2[i], lds);
     out[i] = X;
     if (FILTER) extract3d_point(X, x1[i], x2[i], c1, c2, tol, cam1, flag, i);
 }
@@ -131,53 +142,53 @@ __device__ __forceinline__ int block_compact_pos(bool keep, int* wtot, int* s_ba
     return off + before;
 }
 
-// stage B (one workgroup): first compaction, mean/variance of z in index order, +-3 sigma filter,
+// stage B (one workgroup of 1024 threads): first compaction, mean/variance of z in index order, +-3 sigma filter,
 // second compaction; also gathers the PnP inputs (float object points, current-image points).
-__global__ __launch_bounds__(1024) void k_extract3d_b(Ex3Lanes lanes, int n_imm, int min_pts, int force_seq /* always take the ordered sums (test hook) */)
+struct Ex3Smem { int wtot[16]; int s_base; int s_need_seq; double s_mean, s_sd3, s_rad, s_sumsq; double red[3][16]; double zbuf[2048], zsq[2048]; };
+__device__ __forceinline__ void extract3d_block(const Ex3Lane& LN, int n_imm, int min_pts, int force_seq /* always take the ordered sums (test hook) */, Ex3Smem& sm)
 {
-    const Ex3Lane& LN = lanes.l[blockIdx.y];
     const double* cam1 = LN.cam1; const int* flag = LN.flag; const uvo_point2f* xc = LN.xc; const int* n_p = LN.n_p; int* tmp_idx = LN.tmp_idx;
     double* good_pts = LN.good_pts; int* good_idx = LN.good_idx; float* opts = LN.opts; uvo_point2f* ipts = LN.ipts; int* counts = LN.counts; int* counts_host = LN.counts_host;
+    const uvo_dmatch* map = LN.map; int* tmp_row = LN.tmp_row;
     const int n = n_p ? *n_p : n_imm;
     const int tid = threadIdx.x;
     // the last kernel of the loops' device stage: it leaves the counters where the host reads them (no copy to queue behind it)
     // (every thread calls it with the same G: one wave-wide store, i.e. one burst over PCIe instead of twenty single writes)
     auto publish = [&](int G) { if (tid == 0) counts[1] = G; if (counts_host && tid < CN_TOTAL) counts_host[tid] = tid == 1 ? G : counts[tid]; };
-    __shared__ int wtot[16];
-    __shared__ int s_base;
-    __shared__ double s_mean, s_sd3, s_rad;
-    if (tid == 0) s_base = 0;
+    int* wtot = sm.wtot;
+    if (tid == 0) sm.s_base = 0;
     __syncthreads();
     const bool enough = n >= min_pts;                       // VOU:203
     for (int base = 0; base < n; base += 1024) {
         int i = base + tid;
-        bool keep = enough && i < n && flag[i] != 0;
-        int pos = block_compact_pos(keep, wtot, &s_base);
-        if (keep) tmp_idx[pos] = i;
+        int row = i;
+        if (map && i < n) { row = map[i].queryIdx; LN.out_pts4[i] = LN.pts4[row]; }      // the homogeneous points in match order, as triangulatePoints returns them
+        bool keep = enough && i < n && flag[row] != 0;
+        int pos = block_compact_pos(keep, wtot, &sm.s_base);
+        if (keep) { tmp_idx[pos] = i; if (map) tmp_row[pos] = row; }
     }
     __syncthreads();
-    const int ngood = s_base;
+    const int ngood = sm.s_base;
     if (ngood < min_pts || ngood == 0) {                    // VOU:222
         publish(0);
         return;
     }
+    const int* zrow = map ? tmp_row : tmp_idx;              // where the i-th kept point's coordinates are
     // MU:35-56 computes mean and variance from a sum and a sum of squares taken in index order; what leaves this kernel is only WHO
     // passes mean -+ 3 sigma.  Round 3: the two sums are first taken as workgroup tree sums (any order differs from the ordered sums
     // by at most ~2 n u sum|z|, u = 2^-53), the resulting thresholds get a rigorous error radius, and unless some z lies inside that
     // radius of a threshold -- then, or when the variance is not safely positive, the ordered chains below decide -- the set that
     // passes is the ordered sums' set.  (The ordered chains are ~1500 dependent fp64 additions on one lane: 17-24 us of this
     // single-workgroup kernel; UVO_EXTRACT3D_SEQ=1 / the `force_seq` argument always takes them.)
-    __shared__ int s_need_seq;
     {
-        __shared__ double red[3][16];
         double ps = 0, pa = 0, pq = 0;
-        for (int i = tid; i < ngood; i += 1024) { const double z = cam1[3 * tmp_idx[i] + 2]; ps += z; pa += fabs(z); pq += z * z; }
+        for (int i = tid; i < ngood; i += 1024) { const double z = cam1[3 * zrow[i] + 2]; ps += z; pa += fabs(z); pq += z * z; }
         for (int o = 32; o > 0; o >>= 1) { ps += __shfl_down(ps, o); pa += __shfl_down(pa, o); pq += __shfl_down(pq, o); }
-        if ((tid & 63) == 0) { red[0][tid >> 6] = ps; red[1][tid >> 6] = pa; red[2][tid >> 6] = pq; }
+        if ((tid & 63) == 0) { sm.red[0][tid >> 6] = ps; sm.red[1][tid >> 6] = pa; sm.red[2][tid >> 6] = pq; }
         __syncthreads();
         if (tid == 0) {
             double S = 0, A = 0, Q = 0;
-            for (int k = 0; k < 16; k++) { S += red[0][k]; A += red[1][k]; Q += red[2][k]; }
+            for (int k = 0; k < 16; k++) { S += sm.red[0][k]; A += sm.red[1][k]; Q += sm.red[2][k]; }
             const double n = (double)ngood, u = 1.1102230246251565e-16;
             const double mean = S / n, variance = Q / n - mean * mean;
             const double sd3 = 3.0 * sqrt(variance);
@@ -191,26 +202,25 @@ __global__ __launch_bounds__(1024) void k_extract3d_b(Ex3Lanes lanes, int n_imm,
                 const double dsd3 = 3.0 * dvar / sqrt(variance) + 4 * u * sd3;          // d sqrt(v) <= dv / (2 sqrt(v - dv)), rounded up
                 rad = 4 * (dmean + dsd3 + 4 * u * (fabs(mean) + sd3));
             }
-            s_mean = mean; s_sd3 = sd3; s_rad = rad; s_need_seq = safe ? 0 : 1;
+            sm.s_mean = mean; sm.s_sd3 = sd3; sm.s_rad = rad; sm.s_need_seq = safe ? 0 : 1;
         }
         __syncthreads();
-        if (!s_need_seq) {
-            const double hi = s_mean + s_sd3, lo = s_mean - s_sd3, rad = s_rad;
+        if (!sm.s_need_seq) {
+            const double hi = sm.s_mean + sm.s_sd3, lo = sm.s_mean - sm.s_sd3, rad = sm.s_rad;
             bool near = false;
-            for (int i = tid; i < ngood; i += 1024) { const double z = cam1[3 * tmp_idx[i] + 2]; near = near || fabs(z - hi) <= rad || fabs(z - lo) <= rad; }
-            if (near) s_need_seq = 1;                        // (benign race: every writer stores 1)
+            for (int i = tid; i < ngood; i += 1024) { const double z = cam1[3 * zrow[i] + 2]; near = near || fabs(z - hi) <= rad || fabs(z - lo) <= rad; }
+            if (near) sm.s_need_seq = 1;                     // (benign race: every writer stores 1, a late reader skips a scan that could only store 1)
         }
         __syncthreads();
     }
-    if (s_need_seq)
+    if (sm.s_need_seq)
     {   // MU:35-56: sum and sum of squares in index order.  z and z*z are staged through LDS in chunks; the two sequential chains run
         // on two different waves (one lane each), so each issues one fp64 add per element instead of sharing a SIMD's issue slots
-        __shared__ double zbuf[2048], zsq[2048];
-        __shared__ double s_sumsq;
+        double* zbuf = sm.zbuf; double* zsq = sm.zsq;
         double acc = 0.0;                                   // lane 0: the sum; lane 64: the sum of squares
         for (int base = 0; base < ngood; base += 2048) {
             const int cnt = min(2048, ngood - base);
-            for (int i = tid; i < cnt; i += 1024) { const double z = cam1[3 * tmp_idx[base + i] + 2]; zbuf[i] = z; zsq[i] = z * z; }
+            for (int i = tid; i < cnt; i += 1024) { const double z = cam1[3 * zrow[base + i] + 2]; zbuf[i] = z; zsq[i] = z * z; }
             __syncthreads();
             if (tid == 0 || tid == 64) {
                 // the additions are one dependent chain; the LDS reads of the next sixteen operands are issued before the current
@@ -220,35 +230,281 @@ __global__ __launch_bounds__(1024) void k_extract3d_b(Ex3Lanes lanes, int n_imm,
             }
             __syncthreads();
         }
-        if (tid == 64) s_sumsq = acc;
+        if (tid == 64) sm.s_sumsq = acc;
         __syncthreads();
         if (tid == 0) {
-            const double sum = acc, sumsq = s_sumsq;
+            const double sum = acc, sumsq = sm.s_sumsq;
             double mean = sum / ngood;
             double variance = (sumsq / ngood) - (mean * mean);
-            s_mean = mean; s_sd3 = 3.0 * sqrt(variance);
-            s_base = 0;
+            sm.s_mean = mean; sm.s_sd3 = 3.0 * sqrt(variance);
         }
     }
     __syncthreads();
-    if (tid == 0) s_base = 0;
+    if (tid == 0) sm.s_base = 0;
     __syncthreads();
-    const double mean = s_mean, sd3 = s_sd3;
+    const double mean = sm.s_mean, sd3 = sm.s_sd3;
     for (int base = 0; base < ngood; base += 1024) {
         int i = base + tid;
-        bool keep = false; int src = 0; double z = 0;
-        if (i < ngood) { src = tmp_idx[i]; z = cam1[3*src + 2]; keep = (z <= mean + sd3) && (z >= mean - sd3); }
-        int pos = block_compact_pos(keep, wtot, &s_base);
+        bool keep = false; int src = 0, row = 0; double z = 0;
+        if (i < ngood) { src = tmp_idx[i]; row = zrow[i]; z = cam1[3*row + 2]; keep = (z <= mean + sd3) && (z >= mean - sd3); }
+        int pos = block_compact_pos(keep, wtot, &sm.s_base);
         if (keep) {
-            double X = cam1[3*src], Y = cam1[3*src + 1];
+            double X = cam1[3*row], Y = cam1[3*row + 1];
             good_idx[pos] = src;
             good_pts[3*pos] = X; good_pts[3*pos + 1] = Y; good_pts[3*pos + 2] = z;
             opts[3*pos] = (float)X; opts[3*pos + 1] = (float)Y; opts[3*pos + 2] = (float)z;   // solvePnPRansac: opoints -> CV_32F
-            if (xc) ipts[pos] = xc[src];
+            if (map) { const uvo_keypoint k = LN.cL[map[src].trainIdx]; ipts[pos] = uvo_point2f{k.x, k.y}; }
+            else if (xc) ipts[pos] = xc[src];
         }
     }
     __syncthreads();
-    publish(s_base);
+    publish(sm.s_base);
+}
+__global__ __launch_bounds__(1024) void k_extract3d_b(Ex3Lanes lanes, int n_imm, int min_pts, int force_seq)
+{
+    __shared__ Ex3Smem sm;
+    extract3d_block(lanes.l[blockIdx.y], n_imm, min_pts, force_seq, sm);
+}
+
+// ---------------------------------------------------------------- the tail of the stereo loop's stage A in ONE launch (round 4)
+// VO:569-579 (this pair's "after stereo match" set), VO:631 (triangulatePoints) and VO:632 (extract_3Dpoints) were three launches in a
+// row -- gather 4.7 us, triangulation 21.5 us (one dependent fp64 chain per point), extract_3Dpoints 16.4 us (one workgroup) -- and a
+// stage A's length decides the pipeline's cadence almost one to one (tools/probe/gpu.sh sens).  Triangulation and the per-point half of
+// extract_3Dpoints are functions of ONE row of the previous pair's set (its left and right keypoint and the rig), not of the triangular
+// match that selects the row: every pair therefore triangulates the rows of its OWN set here -- for its successor -- while workgroup 0
+// runs extract_3Dpoints on the rows of the previous pair's set that this pair's triangular matches select.  The three roles share
+// nothing inside the launch (the triangulation reads the keypoints through the stereo matches, not the set being gathered).
+struct TailArgs {
+    const uvo_dmatch* m_s; const int* cn; const uvo_keypoint* kL; const uvo_keypoint* kR; const float* dL;       // stereo matches, the detector's lists
+    uvo_keypoint* okL; uvo_keypoint* okR; float* odL; int dim;                                                    // -> this pair's set
+    float4* as_pts4; double* as_cam1; int* as_flag;                                                               // -> its rows, triangulated
+    int tri_blocks, p4_blocks, fused;
+    float4* out_pts4;                                                                                             // triangulatePoints' output, match order (fused form)
+    Ex3Lane ex;
+};
+// The launch's workgroups have to find room NEXT TO another pair's chip-filling kernels (the detection launch leaves 4 KB of a CU's
+// LDS and most of its registers, the descriptor launch a wave slot and 64 registers per SIMD as its workgroups retire), so they are
+// small on every axis: 256 threads, 3.6 KB of LDS, ~100 registers.  As 1024-thread workgroups with 33 KB the same launch took 61 us in
+// the pipeline against 22 us alone.
+static const int kTailThreads = 256;
+static const int kTailTri = 8;            // rows triangulated per workgroup: 8 x 448 bytes of LDS for the 4x4 Jacobi SVDs' operands
+static const int kEx3Passes = 32;         // extract3d_rows addresses kEx3Passes x kTailThreads = 8192 triangular matches; larger contexts: k_extract3d_b
+// extract_3Dpoints of the stereo loop on ONE small workgroup (round 4).  Thread t owns matches t, t + 256, ..; a match's state between
+// the sweeps is one bit (it passed the reprojection test; it passed +-3 sigma), everything else is re-read: three sweeps in chunks of
+// eight (four) passes whose loads are all in flight together -- ~14 memory round trips for 3000 matches, where the any-size kernel
+// (extract3d_block, 1024 threads, both compactions staged through memory) makes two per pass.  The first compaction is never
+// materialised: only its count and the statistics of its members are needed, unless the ordered sums have to decide.
+// Same results: the +-3 sigma set is the ordered sums' set by the argument in extract3d_block (any summation order is within the radius).
+struct Ex3RowsSmem { int cnt[kEx3Passes][kTailThreads / 64]; int s_need_seq; double s_mean, s_sd3, s_rad, s_sumsq; double red[3][kTailThreads / 64]; double zbuf[128], zsq[128]; };
+__device__ __forceinline__ void extract3d_rows(const Ex3Lane& LN, int min_pts, int force_seq, Ex3RowsSmem& sm)
+{
+    constexpr int NT = kTailThreads, NW = NT / 64, R = kEx3Passes, C = 8;
+    static_assert(NW == 4, "one int4 of wave counts per pass");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int n = min(*LN.n_p, R * NT);                      // (the host takes this path only when the context's capacity fits)
+    const int passes = (n + NT - 1) / NT;
+    const uvo_dmatch* __restrict__ map = LN.map; const double* __restrict__ cam1 = LN.cam1; const int* __restrict__ flag = LN.flag;
+    int* counts = LN.counts; int* counts_host = LN.counts_host;
+    auto publish = [&](int G) { if (tid == 0) counts[1] = G; if (counts_host && tid < CN_TOTAL) counts_host[tid] = tid == 1 ? G : counts[tid]; };
+    // per (pass, wave) counts of the matches whose bit is set in `mask` (bit p: match p * NT + tid)
+    auto fill_table = [&](unsigned mask) {
+        __syncthreads();                                     // the table's previous use is over
+#pragma unroll
+        for (int p = 0; p < R; p++) { const unsigned long long bal = __ballot((mask >> p) & 1u); if (lane == 0) sm.cnt[p][wv] = __popcll(bal); }
+        __syncthreads();
+    };
+    // position of this thread's match of pass p in the ordered compaction, given the matches before pass p (`run`, advanced)
+    auto position = [&](int p, bool bit, int& run) {
+        const int4 c = *reinterpret_cast<const int4*>(sm.cnt[p]);
+        const int pos = run + (wv > 0 ? c.x : 0) + (wv > 1 ? c.y : 0) + (wv > 2 ? c.z : 0) + __popcll(__ballot(bit) & below);
+        run += c.x + c.y + c.z + c.w;
+        return pos;
+    };
+    // depths of the matches in `mask`, eight passes in flight: f(p, z)
+    auto for_depths = [&](unsigned mask, auto f) {
+        for (int c0 = 0; c0 < passes; c0 += C) {
+            int row[C]; double z[C];
+#pragma unroll
+            for (int q = 0; q < C; q++) { row[q] = 0; if ((mask >> (c0 + q)) & 1u) row[q] = map[(c0 + q) * NT + tid].queryIdx; }
+#pragma unroll
+            for (int q = 0; q < C; q++) { z[q] = 0; if ((mask >> (c0 + q)) & 1u) z[q] = cam1[3 * row[q] + 2]; }
+#pragma unroll
+            for (int q = 0; q < C; q++) if ((mask >> (c0 + q)) & 1u) f(c0 + q, z[q]);
+        }
+    };
+    const bool enough = n >= min_pts;                        // VOU:203
+    // sweep 1: who passed the reprojection test (VOU:188-221's flag, set where the row was triangulated), their count and tree sums
+    unsigned keep = 0;
+    double ps = 0, pa = 0, pq = 0;
+    for (int c0 = 0; c0 < passes; c0 += C) {
+        int row[C], fl[C]; double z[C];
+#pragma unroll
+        for (int q = 0; q < C; q++) { const int i = (c0 + q) * NT + tid; row[q] = -1; if (i < n) row[q] = map[i].queryIdx; }
+#pragma unroll
+        for (int q = 0; q < C; q++) { fl[q] = 0; z[q] = 0; if (row[q] >= 0) { fl[q] = flag[row[q]]; z[q] = cam1[3 * row[q] + 2]; } }
+#pragma unroll
+        for (int q = 0; q < C; q++) if (enough && fl[q] != 0) { keep |= 1u << (c0 + q); ps += z[q]; pa += fabs(z[q]); pq += z[q] * z[q]; }
+    }
+    int pc = __popc(keep);
+    for (int o = 32; o > 0; o >>= 1) { ps += __shfl_down(ps, o); pa += __shfl_down(pa, o); pq += __shfl_down(pq, o); pc += __shfl_down(pc, o); }
+    if (lane == 0) { sm.red[0][wv] = ps; sm.red[1][wv] = pa; sm.red[2][wv] = pq; sm.cnt[0][wv] = pc; }
+    __syncthreads();
+    int ngood = 0;
+    for (int k = 0; k < NW; k++) ngood += sm.cnt[0][k];
+    if (ngood < min_pts || ngood == 0) {                     // VOU:222
+        publish(0);
+        return;
+    }
+    if (tid == 0) {
+        double S = 0, A = 0, Q = 0;
+        for (int k = 0; k < NW; k++) { S += sm.red[0][k]; A += sm.red[1][k]; Q += sm.red[2][k]; }
+        const double nn = (double)ngood, u = 1.1102230246251565e-16;
+        const double mean = S / nn, variance = Q / nn - mean * mean;
+        const double sd3 = 3.0 * sqrt(variance);
+        const double dS = 8 * nn * u * A, dQ = 8 * nn * u * Q;                        // as in extract3d_block
+        const double dmean = dS / nn + 4 * u * fabs(mean);
+        const double dvar = dQ / nn + 2 * fabs(mean) * dmean + 8 * u * (Q / nn + mean * mean);
+        const bool safe = force_seq == 0 && variance > 0 && variance > 64 * dvar;     // also false for NaN
+        double rad = 0;
+        if (safe) {
+            const double dsd3 = 3.0 * dvar / sqrt(variance) + 4 * u * sd3;
+            rad = 4 * (dmean + dsd3 + 4 * u * (fabs(mean) + sd3));
+        }
+        sm.s_mean = mean; sm.s_sd3 = sd3; sm.s_rad = rad; sm.s_need_seq = safe ? 0 : 1;
+    }
+    __syncthreads();
+    // sweep 2: the +-3 sigma set under the tree sums' thresholds, and whether any depth is too close to one of them to trust it
+    unsigned keep2 = 0;
+    {
+        const double mean = sm.s_mean, sd3 = sm.s_sd3, hi = mean + sd3, lo = mean - sd3, rad = sm.s_rad;
+        bool near = false;
+        for_depths(keep, [&](int p, double z) { near = near || fabs(z - hi) <= rad || fabs(z - lo) <= rad; if (z <= hi && z >= lo) keep2 |= 1u << p; });
+        __syncthreads();                                     // everyone has read thread 0's verdict
+        if (near) sm.s_need_seq = 1;
+        __syncthreads();
+    }
+    if (sm.s_need_seq) {
+        // MU:35-56: the sum and the sum of squares in index order decide.  The members' depths go to scratch (the output buffer, not
+        // yet written) in compaction order and through LDS in chunks; the two chains run on one lane of two different waves.
+        double* zs = LN.good_pts;
+        fill_table(keep);
+        {
+            int run = 0;
+            for (int p = 0; p < passes; p++) {               // (pass by pass: this path is rare)
+                const bool bit = (keep >> p) & 1u;
+                const int pos = position(p, bit, run);
+                if (bit) zs[pos] = cam1[3 * map[p * NT + tid].queryIdx + 2];
+            }
+        }
+        __syncthreads();
+        double acc = 0.0;                                    // thread 0: the sum; thread 64: the sum of squares
+        for (int base = 0; base < ngood; base += 128) {
+            const int cnt = min(128, ngood - base);
+            if (tid < cnt) { const double v = zs[base + tid]; sm.zbuf[tid] = v; sm.zsq[tid] = v * v; }
+            __syncthreads();
+            if (tid == 0 || tid == 64) {
+                const double* src = tid == 0 ? sm.zbuf : sm.zsq;
+                acc = seq_sum_pipelined(acc, cnt, [&](int i) { return src[i]; });
+            }
+            __syncthreads();
+        }
+        if (tid == 64) sm.s_sumsq = acc;
+        __syncthreads();
+        if (tid == 0) {
+            const double mean = acc / ngood;
+            const double variance = (sm.s_sumsq / ngood) - (mean * mean);
+            sm.s_mean = mean; sm.s_sd3 = 3.0 * sqrt(variance);
+        }
+        __syncthreads();
+        const double mean = sm.s_mean, sd3 = sm.s_sd3;
+        keep2 = 0;
+        for_depths(keep, [&](int p, double z) { if ((z <= mean + sd3) && (z >= mean - sd3)) keep2 |= 1u << p; });
+    }
+    // sweep 3: the second compaction and the PnP inputs, four passes in flight
+    fill_table(keep2);
+    int run = 0;
+    for (int c0 = 0; c0 < passes; c0 += 4) {
+        int row[4], train[4]; double X[4], Y[4], Z[4]; float kx[4], ky[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            row[q] = 0; train[q] = 0;
+            if ((keep2 >> (c0 + q)) & 1u) { const int2 m = *reinterpret_cast<const int2*>(map + (c0 + q) * NT + tid); row[q] = m.x; train[q] = m.y; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            X[q] = Y[q] = Z[q] = 0; kx[q] = ky[q] = 0;
+            if ((keep2 >> (c0 + q)) & 1u) {
+                X[q] = cam1[3 * row[q]]; Y[q] = cam1[3 * row[q] + 1]; Z[q] = cam1[3 * row[q] + 2];
+                const uvo_keypoint* k = LN.cL + train[q]; kx[q] = k->x; ky[q] = k->y;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int p = c0 + q;
+            if (p >= passes) break;
+            const bool bit = (keep2 >> p) & 1u;
+            const int pos = position(p, bit, run);
+            if (bit) {
+                LN.good_idx[pos] = p * NT + tid;
+                LN.good_pts[3*pos] = X[q]; LN.good_pts[3*pos + 1] = Y[q]; LN.good_pts[3*pos + 2] = Z[q];
+                LN.opts[3*pos] = (float)X[q]; LN.opts[3*pos + 1] = (float)Y[q]; LN.opts[3*pos + 2] = (float)Z[q];     // solvePnPRansac: opoints -> CV_32F
+                LN.ipts[pos] = uvo_point2f{kx[q], ky[q]};
+            }
+        }
+    }
+    __syncthreads();
+    publish(run);
+}
+__device__ __forceinline__ void tail_gather_rows(const TailArgs& a, int first_row)        // 16 rows per workgroup, sixteen lanes per descriptor row
+{
+    const int meff = a.cn[CN_MEFF];
+    const int row = first_row + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    if (row >= meff) return;
+    const int q = a.m_s[row].queryIdx, t = a.m_s[row].trainIdx;
+    for (int v = sub; v < a.dim / 4; v += 16) reinterpret_cast<float4*>(a.odL + (size_t)row * a.dim)[v] = reinterpret_cast<const float4*>(a.dL + (size_t)q * a.dim)[v];
+    if (sub == 0) { a.okL[row] = a.kL[q]; a.okR[row] = a.kR[t]; }
+}
+// workgroup 0 (when a.fused): extract_3Dpoints; then tri_blocks workgroups of kTriThreads rows to triangulate, p4_blocks that leave
+// triangulatePoints' output in match order for uvo_stereo_get, and the gather of the set
+union TailSmem { Ex3RowsSmem e; double tri[(16 + 16 + 16 + 4 + 4) * kTailTri]; };
+__global__ __launch_bounds__(kTailThreads) void k_stereo_tail(Mat34 P1, Mat34 P2, Cam c1, Cam c2, double tol, TailArgs a, int min_pts, int force_seq)
+{
+    __shared__ TailSmem sm;
+    int b = blockIdx.x;
+    if (a.fused) { if (b == 0) { extract3d_rows(a.ex, min_pts, force_seq, sm.e); return; } b--; }
+    if (b < a.tri_blocks) {
+        const int row = b * kTailTri + threadIdx.x;
+        if (threadIdx.x >= kTailTri || row >= a.cn[CN_MEFF]) return;
+        const uvo_dmatch m = a.m_s[row];
+        const uvo_keypoint l = a.kL[m.queryIdx], r = a.kR[m.trainIdx];
+        const uvo_point2f x1 = {l.x, l.y}, x2 = {r.x, r.y};
+        const float4 X = triangulate_point<kTailTri>(P1, P2, x1, x2, sm.tri);
+        a.as_pts4[row] = X;
+        extract3d_point(X, x1, x2, c1, c2, tol, a.as_cam1, a.as_flag, row);
+        return;
+    }
+    b -= a.tri_blocks;
+    if (b < a.p4_blocks) {
+        const int i = b * kTailThreads + threadIdx.x;
+        if (i < *a.ex.n_p) a.out_pts4[i] = a.ex.pts4[a.ex.map[i].queryIdx];
+        return;
+    }
+    tail_gather_rows(a, (b - a.p4_blocks) * (kTailThreads / 16));
+}
+// the same per-row triangulation for a set that was gathered by other means (the init phase's first set; the second pair of a two-pair launch)
+__global__ __launch_bounds__(kTriThreads) void k_as_triangulate(Mat34 P1, Mat34 P2, Cam c1, Cam c2, double tol, const uvo_keypoint* aL, const uvo_keypoint* aR,
+                                                                const int* n_p, int n_imm, float4* as_pts4, double* as_cam1, int* as_flag)
+{
+    __shared__ double lds[kTriLdsDoubles];
+    const int n = n_p ? *n_p : n_imm;
+    const int row = blockIdx.x * kTriThreads + threadIdx.x;
+    if (row >= n) return;
+    const uvo_keypoint l = aL[row], r = aR[row];
+    const uvo_point2f x1 = {l.x, l.y}, x2 = {r.x, r.y};
+    const float4 X = triangulate_point(P1, P2, x1, x2, lds);
+    as_pts4[row] = X;
+    extract3d_point(X, x1, x2, c1, c2, tol, as_cam1, as_flag, row);
 }
 
 // ---------------------------------------------------------------- PnP RANSAC
@@ -672,6 +928,45 @@ uvo_status pose_triangulate_extract3d(Ctx* c, int slot, const double* P1, const 
     StageTimer t(c, ST_EXTRACT3D);
     Ex3Lanes el; el.l[0] = ex3_lane(c, slot, d_n, counts_host); el.l[1] = c2 ? ex3_lane(c2, slot, c2->d_counts + CN_T, counts_host2) : el.l[0];
     hipLaunchKernelGGL(k_extract3d_b, dim3(1, nl), dim3(1024), 0, c->stream, el, n_max, c->p.MIN_NUM_3DPOINTS, extract3d_force_seq());
+    UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+
+uvo_status pose_stereo_tail(Ctx* a, Ctx* p, int prev, int curr, int slot, const double* P1, const double* P2, const double* R1, const double* t1,
+                            const double* R2, const double* t2, const double* K1, const double* K2, int* counts_host)
+{
+    const int cap = a->cap;
+    Mat34 m1, m2; memcpy(m1.v, P1, sizeof(m1.v)); memcpy(m2.v, P2, sizeof(m2.v));
+    int* cn = a->d_counts;
+    TailArgs ta;
+    ta.m_s = a->d_matches[0]; ta.cn = cn; ta.kL = a->det[0].kps; ta.kR = a->det[1].kps; ta.dL = a->det[0].desc;
+    ta.okL = a->d_as_kpsL[curr]; ta.okR = a->d_as_kpsR[curr]; ta.odL = a->d_as_descL[curr]; ta.dim = a->desc_dim();
+    ta.as_pts4 = a->d_as_pts4[curr]; ta.as_cam1 = a->d_as_cam1[curr]; ta.as_flag = a->d_as_flag[curr];
+    ta.tri_blocks = (cap + kTailTri - 1) / kTailTri;
+    ta.ex = Ex3Lane{ p->d_as_cam1[prev], p->d_as_flag[prev], nullptr, cn + CN_T, a->d_tmp_idx, a->d_good_pts[slot], a->d_good_idx[slot], a->d_opts[slot], a->d_ipts[slot],
+                     cn, counts_host, a->d_matches[1], a->det[0].kps, p->d_as_pts4[prev], a->d_pts4, a->d_tmp_row };
+    // contexts of up to 8192 keypoints: extract_3Dpoints is workgroup 0 of the same launch; larger ones: its any-size kernel first
+    ta.fused = cap <= kEx3Passes * kTailThreads ? 1 : 0;
+    if (ta.fused) { ta.out_pts4 = a->d_pts4; ta.ex.out_pts4 = nullptr; ta.p4_blocks = (cap + kTailThreads - 1) / kTailThreads; }
+    else {
+        ta.out_pts4 = nullptr; ta.p4_blocks = 0;
+        StageTimer t(a, ST_EXTRACT3D);
+        Ex3Lanes el; el.l[0] = el.l[1] = ta.ex;
+        hipLaunchKernelGGL(k_extract3d_b, dim3(1, 1), dim3(1024), 0, a->stream, el, cap, a->p.MIN_NUM_3DPOINTS, extract3d_force_seq());
+    }
+    StageTimer t(a, ST_TRIANGULATE);
+    hipLaunchKernelGGL(k_stereo_tail, dim3(ta.fused + ta.tri_blocks + ta.p4_blocks + (cap + kTailThreads / 16 - 1) / (kTailThreads / 16)), dim3(kTailThreads), 0, a->stream, m1, m2,
+                       make_cam(R1, t1, K1), make_cam(R2, t2, K2), a->p.REPROJECTION_TOLERANCE, ta, a->p.MIN_NUM_3DPOINTS, extract3d_force_seq());
+    UVO_HIP_TRY(a, hipGetLastError());
+    return UVO_OK;
+}
+uvo_status pose_as_triangulate(Ctx* c, hipStream_t st, int buf, const int* d_n, int n_max, const double* P1, const double* P2, const double* R1, const double* t1,
+                               const double* R2, const double* t2, const double* K1, const double* K2)
+{
+    if (n_max <= 0) return UVO_OK;
+    Mat34 m1, m2; memcpy(m1.v, P1, sizeof(m1.v)); memcpy(m2.v, P2, sizeof(m2.v));
+    hipLaunchKernelGGL(k_as_triangulate, dim3((n_max + kTriThreads - 1) / kTriThreads), dim3(kTriThreads), 0, st, m1, m2, make_cam(R1, t1, K1), make_cam(R2, t2, K2),
+                       c->p.REPROJECTION_TOLERANCE, c->d_as_kpsL[buf], c->d_as_kpsR[buf], d_n, n_max, c->d_as_pts4[buf], c->d_as_cam1[buf], c->d_as_flag[buf]);
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }

@@ -976,6 +976,16 @@ __global__ __launch_bounds__(kP23Threads) void k_hessian_nms_all(LanePair lp, in
 }
 
 // debug / parity hook: one det+trace layer written to global planes (rows x cols)
+// Measurement only (tools/probe/gpu.sh sens): a kernel of known duration in the middle of stage A -- one wave ("thin") or three
+// workgroups per CU holding a detection tile's LDS ("fat") -- to read off how the pipeline's cadence follows either kind of time.
+__global__ __launch_bounds__(256) void k_probe_hold(int ticks)
+{
+    extern __shared__ int probe_lds[];
+    if (threadIdx.x == 0) probe_lds[0] = ticks;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
 __global__ void k_hessian_layer_debug(const int32_t* gsum, int w, int h, LayerPat lp, int step, int rows, int cols,
                                       float* det, float* trace)
 {
@@ -2125,6 +2135,13 @@ uvo_status surf_detect_lanes(Ctx* c, Ctx* c2, int nimg, int gate_min_features)
             StageTimer t(c, ST_HESSIAN_O0 + c->p.SURF_OCTAVES_NUMBER - 1);
             hipLaunchKernelGGL(k_hessian_finish, dim3((c->surv_cap + kFinishPerWg - 1) / kFinishPerWg, nlanes), dim3(256), 0, c->stream, lp, static_cast<const OctavePat*>(c->d_octpat), w, h);
             UVO_HIP_TRY(c, hipGetLastError());
+        }
+        static const int probe_thin = getenv("UVO_PROBE_THIN_US") ? atoi(getenv("UVO_PROBE_THIN_US")) : 0, probe_fat = getenv("UVO_PROBE_FAT_US") ? atoi(getenv("UVO_PROBE_FAT_US")) : 0;
+        if (probe_thin > 0) hipLaunchKernelGGL(k_probe_hold, dim3(1), dim3(64), 64, c->stream, probe_thin * 100);           // wall_clock64: 100 MHz
+        if (probe_fat > 0) {
+            static bool once = false;
+            if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_probe_hold), hipFuncAttributeMaxDynamicSharedMemorySize, 53000); once = true; }
+            hipLaunchKernelGGL(k_probe_hold, dim3(768), dim3(256), 53000, c->stream, probe_fat * 100);
         }
     }
     {

@@ -5,6 +5,7 @@
 #include <thread>
 #include <mutex>
 #include <condition_variable>
+#include <atomic>
 #include <vector>
 #include <deque>
 #include <stdint.h>
@@ -105,6 +106,9 @@ struct Ctx {
     uvo_keypoint* d_as_kpsR[2] = {nullptr, nullptr};
     float* d_as_descL[2] = {nullptr, nullptr};
     int* d_as_n = nullptr;                       // [2] counts (device)
+    // the rows of a set, triangulated (triangulatePoints + the per-point half of extract_3Dpoints are functions of a row's two keypoints
+    // and the rig): filled by the pair that builds the set, read by the next pair through its triangular matches (pose.hip: k_stereo_tail)
+    float4* d_as_pts4[2] = {nullptr, nullptr};  double* d_as_cam1[2] = {nullptr, nullptr};  int* d_as_flag[2] = {nullptr, nullptr};
     bool vo_initialized = false;
     std::vector<uvo_dmatch> init_matches;        // results_match_prev (VO:468): survives failed init attempts
     double K_left[9], K_right[9], R_right[9], t_right[3], P_eye_left[12], P_right[12];
@@ -120,6 +124,7 @@ struct Ctx {
     double* d_good_pts[2] = {nullptr, nullptr};  int* d_good_idx[2] = {nullptr, nullptr};     // G x 3, G
     float* d_opts[2] = {nullptr, nullptr};  uvo_point2f* d_ipts[2] = {nullptr, nullptr};      // G x 3 f32 object points, G image points
     int* d_tmp_idx = nullptr;                    // extract_3Dpoints scratch
+    int* d_tmp_row = nullptr;                    // the same, rows of the previous set (k_stereo_tail)
     int* d_counts = nullptr;                     // misc device counters: [0]=T, [1]=G, [2]=n_inliers, ...
     int* h_counts = nullptr;                     // pinned mirror
 
@@ -150,12 +155,18 @@ struct Ctx {
                                                  // submitting thread until the event completed (133 us per pair at C3)
     // How the lane's worker thread waits for the device (env UVO_WORKER_WAIT = spin | block | block-all; default block):
     //   0 spin      -- every wait polls (lowest latency, one busy host thread per waiting worker: up to `depth` per context)
-    //   1 block     -- the long wait for the end of stage A (evA[0], created with hipEventBlockingSync) sleeps on the interrupt; the two
-    //                  short syncs inside the PnP stage poll.  With N ranks on one node this keeps a rank at one spinning submitter
-    //                  + at most max_b polling workers instead of 1 + depth
+    //   1 block     -- the long wait for the end of stage A (evA[0]) SLEEPS ON A TIMER for most of the stage's expected length (a running
+    //                  mean over the context's pairs) and polls the event over the rest; the two short syncs inside the PnP stage poll.
+    //                  With N ranks on one node this keeps a rank at one spinning submitter + at most max_b polling workers instead
+    //                  of 1 + depth.  Until round 4 this wait slept on the event's interrupt (hipEventBlockingSync): about one wait
+    //                  in a hundred then woke 3-4 ms late (pipeline_trace: dev_a_end_to_pnp_begin_ms 3.3 / 4.4 ms against 0.024) --
+    //                  the stall behind round 3's 1990 pairs/s driver record
     //   2 block-all -- the PnP stage's syncs sleep as well (evBlock); for hosts with fewer cores than threads
     int worker_wait = 1;
+    std::atomic<double> stage_a_mean_us{0.0};    // master: hand-over -> end of stage A, running mean (lane workers' timed sleep)
+    double t_handover_us = 0;                    // lane: when the pair's stage A was handed to the worker
     hipEvent_t evBlock = nullptr;                // hipEventBlockingSync marker for host_sync()
+    hipEvent_t evPoll = nullptr;                 // host_sync()'s marker when it polls
     int* h_countsA[2] = {nullptr, nullptr};      // pinned copy of d_counts
     hipEvent_t evAS = nullptr;                   // this lane's "after stereo match" set is written
     int a_overlap = 2;                           // master: stage As (detect .. extract_3Dpoints) allowed side by side (env UVO_A_OVERLAP, 0 = no limit)
@@ -263,6 +274,8 @@ struct Range { explicit Range(const char* name) { range_push(name); } ~Range() {
 
 // Wait on the host for everything queued on `st` so far, the way lane `c`'s worker_wait says (polling or sleeping)
 hipError_t host_sync(Ctx* c, hipStream_t st);
+// hot-path host waits by query loops: never the runtime's sleep on an interrupt (ctx.hip)
+hipError_t poll_event(hipEvent_t ev);
 
 // surf.hip
 uvo_status surf_upload(Ctx* c, int slot, const uint8_t* gray, int w, int h, int stride, int mem);
@@ -290,6 +303,13 @@ uvo_status pose_triangulate_extract3d(Ctx* c, int slot, const double* P1, const 
                                       const double* R2, const double* t2, const double* K1, const double* K2, const int* d_n, int n_max,
                                       int* counts_host = nullptr,      // counts_host: pinned mirror of d_counts written by the last kernel
                                       Ctx* c2 = nullptr, int* counts_host2 = nullptr);   // c2: a second lane's pair in the same launches
+// The tail of the stereo loop's stage A in one launch: lane `a` gathers its "after stereo match" set (buffer curr) and triangulates
+// its rows, and runs extract_3Dpoints on the rows of lane p's set (buffer prev) that its triangular matches select (VO:569-579, 631-632).
+uvo_status pose_stereo_tail(Ctx* a, Ctx* p, int prev, int curr, int slot, const double* P1, const double* P2, const double* R1, const double* t1,
+                            const double* R2, const double* t2, const double* K1, const double* K2, int* counts_host);
+// the rows of lane c's set `buf`, triangulated by a launch of their own (a set gathered by other means)
+uvo_status pose_as_triangulate(Ctx* c, hipStream_t st, int buf, const int* d_n, int n_max, const double* P1, const double* P2, const double* R1, const double* t1,
+                               const double* R2, const double* t2, const double* K1, const double* K2);
 uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, const double* R2, const double* t2,
                           const double* K1, const double* K2, const int* d_n, int n_max);
 uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const double* R, const double* t, const double* K,

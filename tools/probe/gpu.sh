@@ -12,6 +12,7 @@
 #   hess-split <tag>            per-octave detection kernels (UVO_HESSIAN_SPLIT=1) and the merged launch, old build and new
 #   pmc <tag> <kernel pattern> [split]   counter passes (separate --pmc runs: SQ set 1, SQ set 2, FETCH_SIZE, WRITE_SIZE) of a synchronous run
 #   ctx-reuse [pairs]           five contexts in a row, stream pool on and off
+#   sens [steps]                a kernel of known duration added to stage A (one wave / chip-filling): how the cadence follows thin and fat time
 #   stamps                      phases of the detection launch's workgroups (UVO_HESS_STAMPS -> tools/probe/hess_stamps.py)
 #   rates                       issue-rate probe (built by hipcc here if missing)
 #   topo                        what the rank pinning reads on this box
@@ -63,6 +64,9 @@ step() {
              unset UVO_HESSIAN_SPLIT
              for p in sq1 sq2 fetch write; do python tools/probe/pmc_quick.py pmc_${t}_${p} "$pat" 2; done ;;
     ctx-reuse) python tools/probe/ctx_reuse.py ${1:-400} 2>/dev/null | grep pool; UVO_STREAM_POOL=0 python tools/probe/ctx_reuse.py ${1:-400} 2>/dev/null | grep pool ;;
+    sens)    n=${1:-300}; LBL=base brun --steps $n || return 1
+             for us in 20 40; do UVO_PROBE_THIN_US=$us LBL="one wave held +$us us per pair" brun --steps $n; UVO_PROBE_FAT_US=$us LBL="768 LDS-filling blocks +$us us" brun --steps $n; done
+             LBL=base brun --steps $n ;;
     stamps)  UVO_HESS_STAMPS=gpurun_out/${TAG}_hess_stamps.csv python tools/prof_stereo.py 8 > /dev/null 2>&1; python tools/probe/hess_stamps.py gpurun_out/${TAG}_hess_stamps.csv ;;
     rates)   [ -x tools/probe/issue_rate_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probe/issue_rate_probe.hip -o tools/probe/issue_rate_probe || return 1
              tools/probe/issue_rate_probe ;;
