@@ -890,6 +890,7 @@ static uvo_status stereo_init_step(uvo_ctx* c, uvo_stereo_result* out)
     const int nL = c->h_counts[CN_NL], nR = c->h_counts[CN_NR];
     out->n_left = nL; out->n_right = nR;
     c->last_nL = nL; c->last_nR = nR; c->last_M = c->last_T = c->last_G = c->last_ninl = 0;
+    c->kp_hint = nL > nR ? nL : nR;
     if (nL >= p.MIN_NUM_FEATURES && nR >= p.MIN_NUM_FEATURES) {                         // VO:489
         UVO_TRY(match_knn2(c, c->det[0].desc, nullptr, nL, c->det[1].desc, nullptr, nR));
         UVO_TRY(match_ratio_compact(c, nullptr, nL, (float)p.LOWE_RATIO_THRESHOLD, c->d_matches[0], c->d_nmatch, c->cap));
@@ -1312,6 +1313,7 @@ extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_resul
     const int nL = hc[CN_NL], nR = hc[CN_NR], M = hc[CN_M], T = hc[CN_TRAW], G = hc[CN_G];
     out->n_left = nL; out->n_right = nR; out->n_stereo_matches = M; out->n_tri_matches = T; out->n_good3d = G;
     L->last_nL = nL; L->last_nR = nR; L->last_M = M; L->last_T = hc[CN_T]; L->last_G = G; L->last_ninl = 0;
+    c->kp_hint = nL > nR ? nL : nR;
     int valid = 0;
     if (j.ran) {                                                                           // VO:634
         if (j.st != UVO_OK) return fail(c, j.st, j.err.c_str());

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <utility>
 #include <vector>
+#include <string>
 
 namespace uvo {
 
@@ -650,11 +651,19 @@ struct NmsLds { static constexpr int kList = 3 * ((TW - 1) / 2) * ((TH - 1) / 2)
 
 // UVO_HESS_STAMPS=<file> (measurement): wall-clock stamps (100 MHz) of every workgroup's phases in the last detection launch --
 // start, integral tile in LDS, box sums done, end -- with the tile kind, written as CSV when the context goes
+// The stamps exist in the measurement build only (make STAMPS=1 -> lib_ab/libuvo_hip_stamps.so, tools/probe/gpu.sh stamps): reading the
+// pointer costs a scalar load and an s_waitcnt lgkmcnt(0) per stamp, which also drains the LDS reads in flight -- the descriptor launch
+// measured 66 us with its stamps compiled in and switched off, 58 us without them.
+#ifndef UVO_STAMPS
+#define UVO_STAMPS 0
+#endif
 __device__ long long* g_hess_stamps = nullptr;
 __device__ __forceinline__ void hess_stamp(int k, long long v = -1)
 {
+#if UVO_STAMPS
     long long* st = g_hess_stamps;
     if (st && threadIdx.x == 0) st[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + k] = v >= 0 ? v : (long long)wall_clock64();
+#endif
 }
 // the survivor count of a tile starts at zero: called before the barrier that precedes nms_survivors (one barrier less per tile: under
 // three workgroups per CU a barrier costs the wait for the slowest of eight time-sliced waves)
@@ -1233,6 +1242,18 @@ __device__ __forceinline__ void describe_tail(const DescArgs& a, int im, int k, 
 // windows), PX = 2 and PX = 1 for windows up to 127 / 64 pixels so that small windows do not idle three quarters of the lanes.
 // ------------------------------------------------------------------------------------------
 static const int kTapBatch = 16;           // image rows a lane of descriptor64_big has in flight
+// UVO_DESC_STAMPS=<file> (measurement): wall-clock stamps (100 MHz) of the phases of every small-window workgroup of the last descriptor launch
+__device__ long long* g_desc_stamps = nullptr;
+__device__ __forceinline__ void desc_stamp(int im, int k, int slot, long long v = -1)
+{
+#if UVO_STAMPS
+    long long* st = g_desc_stamps;
+    if (st && threadIdx.x == 0) st[((size_t)im * 16384 + (k & 16383)) * 8 + slot] = v >= 0 ? v : (long long)wall_clock64();
+#endif
+}
+// (Round 4, measured and removed: staging a small window's bytes in LDS first -- every load of the workgroup in flight at once -- and
+// running the horizontal pass from there.  Stamps: table + barrier 1.2 us and horizontal pass 5.3 us became staging 4.0 us + LDS pass
+// 3.9 us; the small-window half of the launch alone 30.0 -> 34.3 us.)
 static const int kPatchStride = 448;       // bytes of patch scratch per keypoint (441 used)
 __device__ __forceinline__ int sgpr_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 // a < b ? x : y on scalar registers (the compiler turns the C expression into VALU selects on copies of the operands)
@@ -1394,11 +1415,13 @@ __device__ __forceinline__ ColTask col_task(const AreaTab& ty, int dx, int start
 __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int h, int k, int im)
 {
     const int tid = threadIdx.x;
+    desc_stamp(im, k, 0);
     const uvo_keypoint kp = a.kps[im][k];
     const float size = kp.size;
     const float s = size * 1.2f / 9.0f;
     const int win_size = (int)((20 + 1) * s);
     if (win_size > kSmallWin) return;                  // large windows: descriptor64_big
+    desc_stamp(im, k, 1); desc_stamp(im, k, 6, win_size);
     extern __shared__ __align__(16) unsigned char smem_desc[];
     float* buf = reinterpret_cast<float*>(smem_desc);                 // [21][bp]
     const int bp = (win_size + 3) | 1;                                // odd pitch: the vertical pass walks 21 columns bank-conflict-free (+3: area_column's alignment shift)
@@ -1434,6 +1457,7 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
     } else {
         if (tid < 21) tab[tid] = area_tab(tid, win_size, scale);
         __syncthreads();
+        desc_stamp(im, k, 2);
         // horizontal pass of resizeArea_ (over WIN columns j = image rows), lanes along WIN rows i = image x: wave wv takes the
         // destination columns dx = wv, wv + 4, .. through the shared column core (round 3): a column's taps are the same for
         // every lane, so row clamps, offsets and weights are scalar work and a lane's pixel costs cvt + mul + add.  (Round 2 ran
@@ -1454,6 +1478,7 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
             }
         }
         __syncthreads();
+        desc_stamp(im, k, 3);
         // vertical pass (over WIN rows i)
         for (int o = tid; o < 441; o += 256) {
             int dy = o / 21, dx = o - dy * 21;
@@ -1467,7 +1492,9 @@ __device__ __forceinline__ void describe_keypoint(const DescArgs& a, int w, int 
         }
     }
     __syncthreads();
+    desc_stamp(im, k, 4); if (area_fast) desc_stamp(im, k, 7, 2);
     describe_tail(a, im, k, PATCH);
+    desc_stamp(im, k, 5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1679,9 +1706,8 @@ __global__ __launch_bounds__(256) void k_descriptor_rot(DescArgs a, int w, int h
 
 
 // small windows: one workgroup per keypoint (block bx of nbx of the launch's small-window part)
-__device__ __forceinline__ void descriptor64_small(const DescArgs& a, int w, int h, int bx, int nbx)
+__device__ __forceinline__ void descriptor64_small(const DescArgs& a, int w, int h, int bx, int nbx, int im)
 {
-    const int im = UVO_LANE_IM(blockIdx.y);
     const int n = *a.n[im];
     // one workgroup per keypoint when the grid has max_kpts of them (measured faster than a smaller grid walking the list:
     // the hardware hands the next keypoint to whichever CU frees up); the loop covers smaller grids
@@ -1701,9 +1727,9 @@ __device__ __forceinline__ void descriptor64_small(const DescArgs& a, int w, int
 // outputs, a lane each): the per-task work that does not depend on the window -- parameters, tables, the vertical pass,
 // its 21-of-64 lanes -- is shared by three columns where the LDS allows it.
 static const int kBigRow = 768;            // floats of row buffer per wave of the large-window part (a 739-pixel window + the 8 floats of slack area_column asks for; 3 x 256 for three-column tasks)
-__device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h, uint8_t* __restrict__ patch, int bx, int nbx)
+__device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h, uint8_t* __restrict__ patch, int bx, int nbx, int im)
 {
-    const int im = UVO_LANE_IM(blockIdx.y), lane = threadIdx.x & 63, wv = sgpr_i(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wv = sgpr_i(threadIdx.x >> 6);
     const int nb = a.big_n[im], nl = min(a.big_large[im], nb);        // the sorted list: nl wide windows first
     extern __shared__ __align__(16) unsigned char smem_desc[];        // shared with the small-window part: 4 x kBigRow floats here
     float* bufrow0 = reinterpret_cast<float*>(smem_desc) + wv * kBigRow;
@@ -1734,6 +1760,8 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
         }
         if (t >= ntask) continue;
         const int e = entry_of(t);
+        const bool st_on = UVO_STAMPS && g_desc_stamps != nullptr && lane == 0;
+        if (st_on) { long long* sp = g_desc_stamps + ((size_t)(2 + im) * 16384 + (t & 16383)) * 8; sp[0] = wall_clock64(); sp[6] = par.y & 0xFFFF; sp[7] = (t < nt1 ? 1 : 3) + 10 * (par.y >> 16 != 0); }
         const int ncols = t < nt1 ? 1 : 3, dx0 = t < nt1 ? t - e * 21 : 3 * ((t - nt1) - (e - nl) * 7);
         const int bstride = 256;                              // floats between the column buffers of a three-column task (kTripleWin + 8 <= 256)
         // the task is the same for every lane: scalar registers, so that row clamps, row addresses and tap weights are SALU work
@@ -1833,6 +1861,7 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            if (st_on) g_desc_stamps[((size_t)(2 + im) * 16384 + (t & 16383)) * 8 + 1] = wall_clock64();
             if (lane < 21 * ncols) {                        // vertical passes of the task's columns, 21 lanes each
                 const int d = lane / 21, dy = lane - d * 21;
                 const float* bufrow = bufrow0 + d * bstride + (vec_ok ? (start_x & 3) : 0);      // area_column's alignment shift
@@ -1844,19 +1873,28 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
             }
         }
         __builtin_amdgcn_wave_barrier();
+        if (st_on) g_desc_stamps[((size_t)(2 + im) * 16384 + (t & 16383)) * 8 + 2] = wall_clock64();
     }
 }
 // Both window classes in one launch: blocks [0, nbig) are the persistent waves of the large-window tasks, the rest take one
 // small-window keypoint each.  The large-window part stalls on its per-tap dependency chains, the small-window part on its
 // barriers; resident together they keep the VALU busier than one after the other (and a launch is saved).
 // (8 waves per SIMD: the compiler would settle at 66 VGPRs = 7 waves)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_descriptor64(LanePair lp, int w, int h, int nbig, int part)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_descriptor64(LanePair lp, int w, int h, int nbig, int part, int nim, int order)
 {
-    const LaneArgs& LA = UVO_LANE_OF(lp, blockIdx.y); const DescArgs& a = LA.da; uint8_t* __restrict__ patch = LA.patch;
-    // (large-window blocks first: small-window blocks first measured 78 us, alternating blocks 97 us, against 66-68 us)
+    // The launch is one row of workgroups; `order` says who comes first (the hardware starts workgroups in index order, and with
+    // lifetimes of 4 to 14 us that order decides what is resident together): 0: image by image, each image's large-window waves before
+    // its small-window workgroups (rounds 2-4); 1: every image's large-window waves, then the small-window workgroups image by image;
+    // 2: the same with the small-window workgroups of the images alternating
+    const int nsmall = (int)gridDim.x / nim - nbig;
+    int id = blockIdx.x, yy, bx; bool big;
+    if (order == 0) { yy = id / (nbig + nsmall); bx = id - yy * (nbig + nsmall); big = bx < nbig; if (!big) bx -= nbig; }
+    else if (id < nim * nbig) { yy = id / nbig; bx = id - yy * nbig; big = true; }
+    else { id -= nim * nbig; big = false; if (order == 1) { yy = id / nsmall; bx = id - yy * nsmall; } else { yy = id % nim; bx = id / nim; } }
+    const LaneArgs& LA = UVO_LANE_OF(lp, yy); const DescArgs& a = LA.da; uint8_t* __restrict__ patch = LA.patch;
     // part (UVO_DESC_PART, measurement only -- the other class of keypoints gets no descriptor): 1 = large windows only, 2 = small only
-    if ((int)blockIdx.x < nbig) { if (part != 2) descriptor64_big(a, w, h, patch, blockIdx.x, nbig); }
-    else if (part != 1) descriptor64_small(a, w, h, blockIdx.x - nbig, gridDim.x - nbig);
+    if (big) { if (part != 2) descriptor64_big(a, w, h, patch, bx, nbig, UVO_LANE_IM(yy)); }
+    else if (part != 1) descriptor64_small(a, w, h, bx, nsmall, UVO_LANE_IM(yy));
 }
 __global__ __launch_bounds__(256) void k_descriptor64_big_finish(LanePair lp)
 {
@@ -2098,7 +2136,7 @@ uvo_status surf_detect_lanes(Ctx* c, Ctx* c2, int nimg, int gate_min_features)
             static const size_t lds_pad = getenv("UVO_HESS_LDS") ? (size_t)atoi(getenv("UVO_HESS_LDS")) : 0;      // measurement: fewer blocks per CU
             const size_t lds_launch = lds_pad > lds ? lds_pad : lds;
             if (lds_pad > lds) { static bool once = false; if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_launch); once = true; } }
-            static const char* stamps_path = getenv("UVO_HESS_STAMPS");
+            static const char* stamps_path = UVO_STAMPS ? getenv("UVO_HESS_STAMPS") : nullptr;
             static long long* d_stamps = nullptr; static size_t stamps_n = 0;
             if (stamps_path && c->lane_id == 0 && !c->master) {
                 if (!d_stamps) { stamps_n = (size_t)total * 4 * 8; (void)hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(long long) * stamps_n); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hess_stamps), &d_stamps, sizeof(d_stamps)); }
@@ -2158,7 +2196,41 @@ uvo_status surf_detect_lanes(Ctx* c, Ctx* c2, int nimg, int gate_min_features)
         if (c->p.SURF_UPRIGHT) {
             const int nbig = 1024;                             // 8192 persistent waves for the large-window tasks (512: 80 us, 768..2048: 66-69 us)
             static const int desc_part = getenv("UVO_DESC_PART") ? atoi(getenv("UVO_DESC_PART")) : 0;      // measurement only
-            hipLaunchKernelGGL(k_descriptor64, dim3(nbig + c->cap, nim), dim3(256), lds_small > lds_big ? lds_small : lds_big, c->stream, lp, w, h, nbig, desc_part);
+            static const char* dstamps_path = UVO_STAMPS ? getenv("UVO_DESC_STAMPS") : nullptr;
+            static long long* d_dstamps = nullptr; const size_t dstamps_n = (size_t)4 * 16384 * 8;
+            const bool dstamp = dstamps_path && c->lane_id == 0 && !c->master && nim == 2;
+            if (dstamp) {
+                if (!d_dstamps) { (void)hipMalloc(reinterpret_cast<void**>(&d_dstamps), sizeof(long long) * dstamps_n); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_desc_stamps), &d_dstamps, sizeof(d_dstamps)); }
+                (void)hipMemsetAsync(d_dstamps, 0, sizeof(long long) * dstamps_n, c->stream);
+            }
+            // small-window part: a workgroup per keypoint -- as many as the last pair whose counts reached the host had, plus a quarter
+            // (the workgroups walk the list when there are more: any grid gives the same descriptors); max_kpts of them before that
+            const Ctx* hm = c->master ? c->master : c;
+            static const int fixed_grid = getenv("UVO_DESC_GRID") ? atoi(getenv("UVO_DESC_GRID")) : 0;              // measurement: 0 = by the hint, -1 = max_kpts, n = n
+            int nsmall = hm->kp_hint > 0 ? ((hm->kp_hint + hm->kp_hint / 4 + 255) & ~255) : c->cap;
+            if (fixed_grid != 0) nsmall = fixed_grid < 0 ? c->cap : fixed_grid;
+            nsmall = nsmall < 512 ? 512 : (nsmall > c->cap ? c->cap : nsmall);
+            // order 2 + the hint-sized grid: 57.2 us; image by image on max_kpts workgroups (rounds 2-4): 60.5; large-window waves first,
+            // small-window workgroups image by image: 59.7; 512 / 2048 large-window workgroups per image: 58.1 / 58.9 (tools/probe/desc_order.sh)
+            static const int desc_order = getenv("UVO_DESC_ORDER") ? atoi(getenv("UVO_DESC_ORDER")) : 2;            // measurement
+            static const int nbig_env = getenv("UVO_DESC_NBIG") ? atoi(getenv("UVO_DESC_NBIG")) : 0;
+            const int nbig_l = nbig_env > 0 ? nbig_env : nbig;
+            hipLaunchKernelGGL(k_descriptor64, dim3((nbig_l + nsmall) * nim), dim3(256), lds_small > lds_big ? lds_small : lds_big, c->stream, lp, w, h, nbig_l, desc_part, nim, desc_order);
+            if (dstamp && d_dstamps) {                        // (measurement: synchronous, every launch rewrites the file)
+                std::vector<long long> hs(dstamps_n);
+                (void)hipStreamSynchronize(c->stream);
+                (void)hipMemcpy(hs.data(), d_dstamps, sizeof(long long) * dstamps_n, hipMemcpyDeviceToHost);
+                if (FILE* f = fopen(dstamps_path, "w")) {
+                    fprintf(f, "im,k,t_start,t_kp,t_ready,t_horiz,t_vert,t_end,win,kind\n");
+                    for (int y = 0; y < 2; y++) for (int k = 0; k < 16384; k++) { const long long* r = hs.data() + ((size_t)y * 16384 + k) * 8; if (r[0]) fprintf(f, "%d,%d,%lld,%lld,%lld,%lld,%lld,%lld,%lld,%lld\n", y, k, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]); }
+                    fclose(f);
+                }
+                if (FILE* f = fopen((std::string(dstamps_path) + ".big").c_str(), "w")) {
+                    fprintf(f, "im,task,t_start,t_horiz,t_end,win,kind\n");
+                    for (int y = 0; y < 2; y++) for (int k = 0; k < 16384; k++) { const long long* r = hs.data() + ((size_t)(2 + y) * 16384 + k) * 8; if (r[0] && r[2]) fprintf(f, "%d,%d,%lld,%lld,%lld,%lld,%lld\n", y, k, r[0], r[1], r[2], r[6], r[7]); }
+                    fclose(f);
+                }
+            }
             hipLaunchKernelGGL(k_descriptor64_big_finish, dim3(1024, nim), dim3(256), 0, c->stream, lp);
         } else {
             // orientation assignment, then every descriptor from its rotated window (not the shipped configuration)

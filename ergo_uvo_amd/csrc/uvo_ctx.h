@@ -180,6 +180,9 @@ struct Ctx {
     StagePlan plan;                              // lane: this lane's pair as uvo_stereo_submit planned it
     int stashed_lane = -1;                       // master: lane of the pair that waits for its partner (-1: none)
     std::vector<Ctx*> lanes;                     // master only: lanes[0] == this
+    // keypoints per image of the last pair / frame whose counts reached the host (master; 0: none yet): sizes the descriptor launch's
+    // small-window part -- a grid of max_kpts workgroups spends a sixth of the launch's wave-time on workgroups that find no keypoint
+    int kp_hint = 0;
     Ctx* master = nullptr;                       // children only
     int lane_id = 0;
     int primed_w = 0, primed_h = 0;              // image size this lane's streams and detector tables are ready for (prime_lanes)
