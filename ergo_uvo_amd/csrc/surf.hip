@@ -234,6 +234,11 @@ struct OctavePat {
 };
 
 // resizeHaarPattern (surf.cpp): coordinates cvRound(ratio*c), weight w/((float)(dx2-dx1)*(dy2-dy1))
+// What a detection tile needs of its octave's pattern at run time (the box geometry is compile-time there): by value in the merged
+// launch's arguments.  Read from the pattern table in global memory instead, every field was a scalar load at its first use with an
+// s_waitcnt lgkmcnt(0) behind it -- 117 of them scattered over the kernel, each also draining the LDS reads in flight.
+struct OctDims { struct { int samples_i, samples_j; } L[5]; int rows, cols, nms_margin[3], octave; };
+struct HessDims { OctDims o[4]; };
 static void make_pattern(int size, LayerPat* lp)
 {
     static const int dx_s[3][5]  = { {0, 2, 3, 7, 1}, {3, 2, 6, 7, -2}, {6, 2, 9, 7, 1} };
@@ -492,8 +497,8 @@ __device__ __forceinline__ void static_for(F&& f)
 }
 
 // det plane of layer L (1..3) of a workgroup's TW x TH samples from the integral tile in LDS; 0 where the template does not fit
-template <int O, int L, int TW, int TH, int NT>
-__device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, float* __restrict__ sdet, const OctavePat& op,
+template <int O, int L, int TW, int TH, int NT, class OP>
+__device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, float* __restrict__ sdet, const OP& op,
                                             int px0, int py0, float skip_thr)
 {
     using OC = OctC<O>;
@@ -505,7 +510,7 @@ __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, f
     // tile index of corner (dy, dx) relative to base = &stile[ry*STEP*STEP*PW + rx]
 #define SV(dy, dx) base[((OFFL + (dy)) * STEP + ((OFFL + (dx)) % STEP)) * PW + (OFFL + (dx)) / STEP]
     UVO_HESSIAN_CONSTS(LC);
-    const LayerPat& lp = op.L[L];
+    const auto& lp = op.L[L];
     const int tid = lane_tid();
     // a compile-time trip count (the last pass is guarded): the box arithmetic holds inline assembly, which the compiler treats as
     // convergent and will not unroll behind a run-time remainder
@@ -534,9 +539,9 @@ __device__ __forceinline__ ImgRsrc img_rsrc(const uint8_t* img, int bytes)
 // The same layer from the de-interleaved planes in global memory (octaves 2 and 3: the integral tile of one
 // workgroup would not fit LDS).  Sample (oi, oj) has its top-left at pixel (STEP*oi, STEP*oj); corner (dy, dx) is in
 // plane (dy & 3, dx & 3) at [STEP/4*oi + dy/4][STEP/4*oj + dx/4]: plane and offsets are compile-time, lanes along oj.
-template <int O, int L, int TW, int TH, int NT>
+template <int O, int L, int TW, int TH, int NT, class OP>
 __device__ __forceinline__ void det_layer_p(const int32_t* __restrict__ planes, int pw, int pstride, float* __restrict__ sdet,
-                                            const OctavePat& op, int px0, int py0, float skip_thr)
+                                            const OP& op, int px0, int py0, float skip_thr)
 {
     using OC = OctC<O>;
     constexpr int STEP = OC::STEP, SIZE = OC::size(L), Q = STEP / 4;
@@ -548,7 +553,7 @@ __device__ __forceinline__ void det_layer_p(const int32_t* __restrict__ planes, 
     const ImgRsrc rs = img_rsrc(reinterpret_cast<const uint8_t*>(planes), 16 * pstride * 4);
 #define SVP(dy, dx) (int)__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4 * ((dx) >> 2), 4 * ((((dy) & 3) * 4 + ((dx) & 3)) * pstride + ((dy) >> 2) * pw), 0)
     UVO_HESSIAN_CONSTS(LC);
-    const LayerPat& lp = op.L[L];
+    const auto& lp = op.L[L];
     const int tid = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < (TW * TH + NT - 1) / NT; it++) {
@@ -591,9 +596,9 @@ __device__ __forceinline__ float plane_det(ImgRsrc rs, int voff, int pw, int pst
 #undef SVP
     return det;
 }
-template <int O, int TW, int TH, int NT>
+template <int O, int TW, int TH, int NT, class OP>
 __device__ __forceinline__ void det_layers_p3(const int32_t* __restrict__ planes, int pw, int pstride, float* __restrict__ sdet,
-                                              const OctavePat& op, int px0, int py0, float skip_thr)
+                                              const OP& op, int px0, int py0, float skip_thr)
 {
     using OC = OctC<O>;
     constexpr int Q = OC::STEP / 4;
@@ -608,7 +613,7 @@ __device__ __forceinline__ void det_layers_p3(const int32_t* __restrict__ planes
 #pragma unroll
         for (int l = 0; l < 3; l++) {
             const int m = l == 0 ? OC::margin(1) : l == 1 ? OC::margin(2) : OC::margin(3);
-            const LayerPat& lp = op.L[l + 1];
+            const auto& lp = op.L[l + 1];
             const int oi = py0 + ry - m, oj = px0 + rx - m;
             ok[l] = oi >= 0 && oi < lp.samples_i && oj >= 0 && oj < lp.samples_j;
             voff[l] = ok[l] ? 4 * ((oi * Q) * pw + oj * Q) : 0x7FFFFFF0;      // past the buffer: its loads return 0
@@ -669,8 +674,8 @@ __device__ __forceinline__ void hess_stamp(int k, long long v = -1)
 // three workgroups per CU a barrier costs the wait for the slowest of eight time-sliced waves)
 template <int TW, int TH>
 __device__ __forceinline__ void nms_zero(unsigned* s_list) { if (lane_tid() == 0) reinterpret_cast<int*>(s_list + NmsLds<TW, TH>::kList)[0] = 0; }
-template <int TW, int TH, int NT>
-__device__ __forceinline__ void nms_survivors(const float* __restrict__ sdet, unsigned* __restrict__ s_list, const OctavePat& op, float thr,
+template <int TW, int TH, int NT, class OP>
+__device__ __forceinline__ void nms_survivors(const float* __restrict__ sdet, unsigned* __restrict__ s_list, const OP& op, float thr,
                                               int px0, int py0, int im, const SurvOut& sv)
 {
     const int tid = lane_tid();
@@ -842,8 +847,8 @@ __global__ __launch_bounds__(256) void k_hessian_finish(LanePair lp, const Octav
 }
 
 // One tile of octave 0 or 1 (tile bx, by of image im): the body of k_hessian_nms_c and of the octave-0 blocks of k_hessian_nms_c0_p23
-template <int O, int TW, int TH, int NT>
-__device__ __forceinline__ void hessian_nms_c_tile(const ImgPair& ip, int w, int h, const OctavePat& op, float thr, const SurvOut& sv,
+template <int O, int TW, int TH, int NT, class OP>
+__device__ __forceinline__ void hessian_nms_c_tile(const ImgPair& ip, int w, int h, const OP& op, float thr, const SurvOut& sv,
                                                    int bx, int by, int im, unsigned char* smem)
 {
     using OC = OctC<O>;
@@ -931,21 +936,21 @@ __global__ __launch_bounds__(NT) void k_hessian_nms_p(LanePair lp, int w, int h,
 // neither fills the chip (5120 and 2560 waves); side by side they take about what octave 2 took alone.
 static const int kP23Threads = 512;
 struct P23Grid { int nbx2, nb2, nbx3, nb3; };
-__device__ __forceinline__ void hessian_nms_p23_tile(const ImgPair& ip, const OctavePat& op2, const OctavePat& op3, float thr, const SurvOut& sv,
-                                                     const P23Grid& g, int b, int im, float* sdet, unsigned* s_list)
+template <class OP>
+__device__ __forceinline__ void hessian_nms_p23_tile(const ImgPair& ip, const OP& op2, const OP& op3, float thr, const SurvOut& sv,
+                                                     bool oct3, int bx, int by, int im, float* sdet, unsigned* s_list)
 {
     constexpr int TW2 = 32, TH2 = 16, TW3 = 16, TH3 = 16;
     static_assert(TW3 * TH3 <= TW2 * TH2 && NmsLds<TW3, TH3>::kWords <= NmsLds<TW2, TH2>::kWords, "octave 3 reuses octave 2's LDS");
-    if (b < g.nb2) {
-        const int px0 = (b % g.nbx2) * (TW2 - 2) - 1, py0 = (b / g.nbx2) * (TH2 - 2) - 1;
+    if (!oct3) {
+        const int px0 = bx * (TW2 - 2) - 1, py0 = by * (TH2 - 2) - 1;
         det_layers_p3<2, TW2, TH2, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op2, px0, py0, thr);
         nms_zero<TW2, TH2>(s_list);
         __syncthreads();
         hess_stamp(2);
         nms_survivors<TW2, TH2, kP23Threads>(sdet, s_list, op2, thr, px0, py0, im, sv);
     } else {
-        b -= g.nb2;
-        const int px0 = (b % g.nbx3) * (TW3 - 2) - 1, py0 = (b / g.nbx3) * (TH3 - 2) - 1;
+        const int px0 = bx * (TW3 - 2) - 1, py0 = by * (TH3 - 2) - 1;
         det_layers_p3<3, TW3, TH3, kP23Threads>(ip.planes[im], ip.pw, ip.pstride, sdet, op3, px0, py0, thr);
         nms_zero<TW3, TH3>(s_list);
         __syncthreads();
@@ -966,20 +971,24 @@ struct HessGrid { int nbx0, nb0, nbx1, nb1; P23Grid g; };          // tiles per 
 // turn-over costs per tile -- 93 / 103 / 105 us against 84: a slot bound to a fixed run of tiles loses the balance that "whichever
 // slot frees up takes the next tile" gives; the same lesson as the resident-workgroup queues)
 template <int TW, int TH>
-__global__ __launch_bounds__(kP23Threads) void k_hessian_nms_all(LanePair lp, int w, int h, const OctavePat* __restrict__ ops, float thr,
-                                                                 const uint16_t* __restrict__ order, HessGrid hg)
+__global__ __launch_bounds__(kP23Threads) void k_hessian_nms_all(LanePair lp, int w, int h, HessDims hd, float thr,
+                                                                 const uint32_t* __restrict__ order)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const LaneArgs& LA = UVO_LANE_OF(lp, blockIdx.y); const ImgPair& ip = LA.ip; const SurvOut& sv = LA.sv;
+    const LaneArgs& LA = UVO_LANE_OF(lp, blockIdx.y); const ImgPair& ip = LA.ip;
+    // the survivor list's address, counter and capacity are read here, with the other arguments, rather than by scalar loads of their own
+    // behind the tile's last barriers
+    SurvOut sv = LA.sv;
+    asm volatile("" : "+s"(sv.list), "+s"(sv.count), "+s"(sv.cap));
     const int im = UVO_LANE_IM(blockIdx.y);
     const unsigned e = order[blockIdx.x];
-    const int kind = e >> 14, idx = e & 0x3FFF;
-    hess_stamp(0); hess_stamp(4, kind == 2 ? (idx < hg.g.nb2 ? 2 : 3) : kind);
-    if (kind == 0) hessian_nms_c_tile<0, TW, TH, kP23Threads>(ip, w, h, ops[0], thr, sv, idx % hg.nbx0, idx / hg.nbx0, im, smem);
-    else if (kind == 1) hessian_nms_c_tile<1, 32, kO1TileRows, kP23Threads>(ip, w, h, ops[1], thr, sv, idx % hg.nbx1, idx / hg.nbx1, im, smem);
+    const int kind = e >> 30, bx = e & 0x3FFF, by = (e >> 14) & 0x3FFF;
+    hess_stamp(0); hess_stamp(4, kind);
+    if (kind == 0) hessian_nms_c_tile<0, TW, TH, kP23Threads>(ip, w, h, hd.o[0], thr, sv, bx, by, im, smem);
+    else if (kind == 1) hessian_nms_c_tile<1, 32, kO1TileRows, kP23Threads>(ip, w, h, hd.o[1], thr, sv, bx, by, im, smem);
     else {
         float* sdet = reinterpret_cast<float*>(smem);
-        hessian_nms_p23_tile(ip, ops[2], ops[3], thr, sv, hg.g, idx, im, sdet, reinterpret_cast<unsigned*>(sdet + kP23SdetFloats));
+        hessian_nms_p23_tile(ip, hd.o[2], hd.o[3], thr, sv, kind == 3, bx, by, im, sdet, reinterpret_cast<unsigned*>(sdet + kP23SdetFloats));
     }
     hess_stamp(3);
 }
@@ -2080,9 +2089,18 @@ uvo_status surf_prepare(Ctx* c, int w, int h)
     const int ng[3] = { nb0, nb1, nb23 }, ngroups = total;
     if ((int)c->h_hess_order.size() != ngroups || c->hess_order_key[0] != nb0 || c->hess_order_key[1] != nb1 || c->hess_order_key[2] != nb23) {
         // block b's kind and tile: the i-th tile of a kind with n tiles sits at position (i + 1/2) / n of the launch
-        std::vector<std::pair<double, uint16_t>> pos;
+        // (an entry is the block's octave and its tile's column and row, 2 + 14 + 14 bits: one scalar load at the top of the kernel;
+        // as 16-bit entries -- kind and tile index -- it took a vector load, a wait and two integer divisions before a tile knew its place)
+        std::vector<std::pair<double, uint32_t>> pos;
         pos.reserve((size_t)ngroups);
-        for (int k = 0; k < 3; k++) for (int i = 0; i < ng[k]; i++) pos.emplace_back((i + 0.5) / ng[k] + k * 1e-9, (uint16_t)((k << 14) | i));
+        for (int k = 0; k < 3; k++) for (int i = 0; i < ng[k]; i++) {
+            uint32_t e;
+            if (k == 0) e = (0u << 30) | ((uint32_t)(i / m.nbx0) << 14) | (uint32_t)(i % m.nbx0);
+            else if (k == 1) e = (1u << 30) | ((uint32_t)(i / m.nbx1) << 14) | (uint32_t)(i % m.nbx1);
+            else if (i < m.g.nb2) e = (2u << 30) | ((uint32_t)(i / m.g.nbx2) << 14) | (uint32_t)(i % m.g.nbx2);
+            else e = (3u << 30) | ((uint32_t)((i - m.g.nb2) / m.g.nbx3) << 14) | (uint32_t)((i - m.g.nb2) % m.g.nbx3);
+            pos.emplace_back((i + 0.5) / ng[k] + k * 1e-9, e);
+        }
         std::sort(pos.begin(), pos.end());
         c->h_hess_order.resize((size_t)ngroups);
         for (int b = 0; b < ngroups; b++) c->h_hess_order[(size_t)b] = pos[(size_t)b].second;
@@ -2090,10 +2108,10 @@ uvo_status surf_prepare(Ctx* c, int w, int h)
         if (c->d_hess_order_cap < (size_t)ngroups) {
             if (c->d_hess_order) (void)hipFree(c->d_hess_order);
             c->d_hess_order = nullptr; c->d_hess_order_cap = 0;
-            UVO_HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_hess_order), sizeof(uint16_t) * (size_t)ngroups));
+            UVO_HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_hess_order), sizeof(uint32_t) * (size_t)ngroups));
             c->d_hess_order_cap = (size_t)ngroups;
         }
-        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_hess_order, c->h_hess_order.data(), sizeof(uint16_t) * (size_t)ngroups, hipMemcpyHostToDevice, c->stream));
+        UVO_HIP_TRY(c, hipMemcpyAsync(c->d_hess_order, c->h_hess_order.data(), sizeof(uint32_t) * (size_t)ngroups, hipMemcpyHostToDevice, c->stream));
         UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->hess_order_key[0] = nb0; c->hess_order_key[1] = nb1; c->hess_order_key[2] = nb23;
     }
@@ -2142,8 +2160,14 @@ uvo_status surf_detect_lanes(Ctx* c, Ctx* c2, int nimg, int gate_min_features)
                 if (!d_stamps) { stamps_n = (size_t)total * 4 * 8; (void)hipMalloc(reinterpret_cast<void**>(&d_stamps), sizeof(long long) * stamps_n); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hess_stamps), &d_stamps, sizeof(d_stamps)); }
                 (void)hipMemsetAsync(d_stamps, 0, sizeof(long long) * stamps_n, c->stream);
             }
-            hipLaunchKernelGGL(kern, dim3(total, nim), dim3(kP23Threads), lds_launch, c->stream, lp, w, h, static_cast<const OctavePat*>(c->d_octpat), thr,
-                               c->d_hess_order, hg);
+            HessDims hd;
+            for (int o = 0; o < 4; o++) {
+                OctDims& d = hd.o[o];
+                for (int l = 0; l < 5; l++) { d.L[l].samples_i = ops[o].L[l].samples_i; d.L[l].samples_j = ops[o].L[l].samples_j; }
+                d.rows = ops[o].rows; d.cols = ops[o].cols; d.octave = ops[o].octave;
+                for (int l = 0; l < 3; l++) d.nms_margin[l] = ops[o].nms_margin[l];
+            }
+            hipLaunchKernelGGL(kern, dim3(total, nim), dim3(kP23Threads), lds_launch, c->stream, lp, w, h, hd, thr, c->d_hess_order);
             if (stamps_path && d_stamps && c->lane_id == 0 && !c->master) {        // (measurement: synchronous, every launch rewrites the file)
                 std::vector<long long> hs(stamps_n);
                 (void)hipStreamSynchronize(c->stream);

@@ -79,8 +79,8 @@ struct Ctx {
     Survivor* d_surv = nullptr; int surv_cap = 0; // NMS survivors of a frame (both images, every octave), 4 * cap
     void* d_octpat = nullptr;                    // the four OctavePat of the current image size, for k_hessian_finish
     std::vector<unsigned char> h_octpat;         // what d_octpat holds
-    uint16_t* d_hess_order = nullptr; size_t d_hess_order_cap = 0;       // merged detection launch: kind and tile of every block
-    std::vector<uint16_t> h_hess_order; int hess_order_key[3] = {0, 0, 0};
+    uint32_t* d_hess_order = nullptr; size_t d_hess_order_cap = 0;       // merged detection launch: octave and tile (column, row) of every block
+    std::vector<uint32_t> h_hess_order; int hess_order_key[3] = {0, 0, 0};
     int4* d_big_par = nullptr; int* d_big_n = nullptr;   // [2][cap] (sorted index, win, start_x, start_y) of large-window keypoints in append order, then [2][cap] by descending win; [2] counts
     struct AreaTab* d_area_tabs = nullptr;       // [kMaxWin + 1][21] INTER_AREA resize tables of every descriptor window size (surf_build_area_tables)
     float* d_ori_w = nullptr;                    // 13 x 13 Gaussian weights of the orientation samples (SURF_UPRIGHT = false)
