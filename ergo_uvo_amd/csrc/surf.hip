@@ -846,6 +846,10 @@ __global__ __launch_bounds__(256) void k_hessian_finish(LanePair lp, const Octav
     }
 }
 
+// quads a thread has in flight during the tile fill: the whole tile in one round trip when that takes at most six per thread
+#ifndef UVO_FILL
+#define UVO_FILL(quads, nt) (((quads) + (nt) - 1) / (nt) <= 6 ? ((quads) + (nt) - 1) / (nt) : 4)
+#endif
 // One tile of octave 0 or 1 (tile bx, by of image im): the body of k_hessian_nms_c and of the octave-0 blocks of k_hessian_nms_c0_p23
 template <int O, int TW, int TH, int NT, class OP>
 __device__ __forceinline__ void hessian_nms_c_tile(const ImgPair& ip, int w, int h, const OP& op, float thr, const SurvOut& sv,
@@ -869,7 +873,7 @@ __device__ __forceinline__ void hessian_nms_c_tile(const ImgPair& ip, int w, int
     // sample reads lies inside the image (samples_i/j are defined that way), out-of-image elements are only ever read by
     // masked samples, and the integral buffers carry kSumPad ints of slack on both sides, so the overshoot of the first
     // and last rows stays inside the allocation.
-    constexpr int QPR = OctTile<O, TW>::TWq / 4, kQuads = THs * QPR, kFill = 4, kQ = NT / QPR, kR = NT % QPR;
+    constexpr int QPR = OctTile<O, TW>::TWq / 4, kQuads = THs * QPR, kFill = UVO_FILL(kQuads, NT), kQ = NT / QPR, kR = NT % QPR;
     static_assert(STEP == 1 || STEP == 2, "tile fill handles octaves 0 and 1");
     static_assert(OctTile<O, TW>::TWq < kSumPad && STEP - OC::LO < kSumPad, "integral slack too small for the tile overshoot");
     int fidx = tid, fty = tid / QPR, fq = tid - fty * QPR;           // quad, tile row, quad in row: advanced by NT per step
