@@ -189,15 +189,15 @@ __global__ __launch_bounds__(256) void k_integral_strip_final(LanePair lp, int w
                 for (int k = 0; k < 8; k++) { acc[k] += run; run += packed_px(lo[r], hi[r], k); }
                 int4* rb = reinterpret_cast<int4*>(&rowbuf[rr][8 * tid]);
                 rb[0] = make_int4(acc[0], acc[1], acc[2], acc[3]); rb[1] = make_int4(acc[4], acc[5], acc[6], acc[7]);
-                if (ys <= h && c0 <= w) {
+                if (((r + 1) & 3) != 2 && ys <= h && c0 <= w) {        // (y0 is a multiple of 8: ys & 3 == (r + 1) & 3; planes of rows / columns = 2 (mod 4) are never read: plane_written)
                     // planes: sum column x -> plane (ys & 3, x & 3) at [ys >> 2][x >> 2]; this thread's columns give two adjacent entries per plane
                     int32_t* pl = planes + (size_t)((ys & 3) * 4) * ip.pstride + (size_t)(ys >> 2) * ip.pw + (c0 >> 2);
                     if (c0 + 7 <= w) {
 #pragma unroll
-                        for (int rx = 0; rx < 4; rx++) *reinterpret_cast<int2*>(pl + (size_t)rx * ip.pstride) = make_int2(acc[rx], acc[rx + 4]);   // pw, pstride even: 8-byte aligned
+                        for (int rx = 0; rx < 4; rx++) if (rx != 2) *reinterpret_cast<int2*>(pl + (size_t)rx * ip.pstride) = make_int2(acc[rx], acc[rx + 4]);   // pw, pstride even: 8-byte aligned
                     } else {
 #pragma unroll
-                        for (int k = 0; k < 8; k++) if (c0 + k <= w) pl[(size_t)(k & 3) * ip.pstride + (k >> 2)] = acc[k];
+                        for (int k = 0; k < 8; k++) if ((k & 3) != 2 && c0 + k <= w) pl[(size_t)(k & 3) * ip.pstride + (k >> 2)] = acc[k];
                     }
                 }
             }
@@ -530,6 +530,14 @@ __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, f
 #undef SV
 }
 
+// The box corners of octaves 2 and 3 (filters 27 .. 99 and 51 .. 195 pixels at steps 4 and 8, layers 1 - 3) only ever fall on rows and
+// columns of the integral with index = 0, 1 or 3 (mod 4): nine of the sixteen de-interleaved planes are read, and k_integral_strip_final
+// writes only those (7 MB less per pair).  Every plane read goes through this check at compile time.
+template <int DY, int DX> __device__ __forceinline__ constexpr int plane_written()
+{
+    static_assert((DY & 3) != 2 && (DX & 3) != 2, "this corner lies in a plane that k_integral_strip_final does not write");
+    return 0;
+}
 typedef __amdgpu_buffer_rsrc_t ImgRsrc;
 __device__ __forceinline__ ImgRsrc img_rsrc(const uint8_t* img, int bytes)
 {
@@ -551,7 +559,7 @@ __device__ __forceinline__ void det_layer_p(const int32_t* __restrict__ planes, 
     // (plane and row of the corner: SALU arithmetic on pw / pstride) + the column as the instruction's immediate, instead of a
     // 64-bit flat address (a VGPR pair and a v_lshl_add_u64) per corner.
     const ImgRsrc rs = img_rsrc(reinterpret_cast<const uint8_t*>(planes), 16 * pstride * 4);
-#define SVP(dy, dx) (int)__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4 * ((dx) >> 2), 4 * ((((dy) & 3) * 4 + ((dx) & 3)) * pstride + ((dy) >> 2) * pw), 0)
+#define SVP(dy, dx) (int)__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4 * ((dx) >> 2) + plane_written<(dy), (dx)>(), 4 * ((((dy) & 3) * 4 + ((dx) & 3)) * pstride + ((dy) >> 2) * pw), 0)
     UVO_HESSIAN_CONSTS(LC);
     const auto& lp = op.L[L];
     const int tid = threadIdx.x;
@@ -580,7 +588,7 @@ template <int O, int L>
 __device__ __forceinline__ float plane_pp(ImgRsrc rs, int voff, int pw, int pstride)
 {
     using LC = LayerC<OctC<O>::size(L)>;
-#define SVP(dy, dx) (int)__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4 * ((dx) >> 2), 4 * ((((dy) & 3) * 4 + ((dx) & 3)) * pstride + ((dy) >> 2) * pw), 0)
+#define SVP(dy, dx) (int)__builtin_amdgcn_raw_buffer_load_b32(rs, voff + 4 * ((dx) >> 2) + plane_written<(dy), (dx)>(), 4 * ((((dy) & 3) * 4 + ((dx) & 3)) * pstride + ((dy) >> 2) * pw), 0)
     UVO_HESSIAN_CONSTS(LC);
     float pp;
     UVO_HESSIAN_PP(SVP, pp)
