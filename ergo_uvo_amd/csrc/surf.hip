@@ -1901,7 +1901,10 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
 // small-window keypoint each.  The large-window part stalls on its per-tap dependency chains, the small-window part on its
 // barriers; resident together they keep the VALU busier than one after the other (and a launch is saved).
 // (8 waves per SIMD: the compiler would settle at 66 VGPRs = 7 waves)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_descriptor64(LanePair lp, int w, int h, int nbig, int part, int nim, int order)
+#ifndef UVO_DESC_WAVES
+#define UVO_DESC_WAVES 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVO_DESC_WAVES, 8))) void k_descriptor64(LanePair lp, int w, int h, int nbig, int part, int nim, int order)
 {
     // The launch is one row of workgroups; `order` says who comes first (the hardware starts workgroups in index order, and with
     // lifetimes of 4 to 14 us that order decides what is resident together): 0: image by image, each image's large-window waves before
