@@ -278,7 +278,7 @@ struct TailArgs {
     const uvo_dmatch* m_s; const int* cn; const uvo_keypoint* kL; const uvo_keypoint* kR; const float* dL;       // stereo matches, the detector's lists
     uvo_keypoint* okL; uvo_keypoint* okR; float* odL; int dim;                                                    // -> this pair's set
     float4* as_pts4; double* as_cam1; int* as_flag;                                                               // -> its rows, triangulated
-    int tri_blocks, p4_blocks, fused;
+    int tri_blocks, p4_blocks, gather_blocks, fused;
     float4* out_pts4;                                                                                             // triangulatePoints' output, match order (fused form)
     Ex3Lane ex;
 };
@@ -473,24 +473,30 @@ __global__ __launch_bounds__(kTailThreads) void k_stereo_tail(Mat34 P1, Mat34 P2
     __shared__ TailSmem sm;
     int b = blockIdx.x;
     if (a.fused) { if (b == 0) { extract3d_rows(a.ex, min_pts, force_seq, sm.e); return; } b--; }
+    // (every role walks its rows with the stride of its share of the grid: the host sizes the shares by the last known keypoint
+    // count -- a grid for max_kpts rows is 1500 workgroups of which 400 find work -- and any size gives the same result)
     if (b < a.tri_blocks) {
-        const int row = b * kTailTri + threadIdx.x;
-        if (threadIdx.x >= kTailTri || row >= a.cn[CN_MEFF]) return;
-        const uvo_dmatch m = a.m_s[row];
-        const uvo_keypoint l = a.kL[m.queryIdx], r = a.kR[m.trainIdx];
-        const uvo_point2f x1 = {l.x, l.y}, x2 = {r.x, r.y};
-        const float4 X = triangulate_point<kTailTri>(P1, P2, x1, x2, sm.tri);
-        a.as_pts4[row] = X;
-        extract3d_point(X, x1, x2, c1, c2, tol, a.as_cam1, a.as_flag, row);
+        if (threadIdx.x >= kTailTri) return;
+        const int meff = a.cn[CN_MEFF];
+        for (int row = b * kTailTri + threadIdx.x; row < meff; row += a.tri_blocks * kTailTri) {
+            const uvo_dmatch m = a.m_s[row];
+            const uvo_keypoint l = a.kL[m.queryIdx], r = a.kR[m.trainIdx];
+            const uvo_point2f x1 = {l.x, l.y}, x2 = {r.x, r.y};
+            const float4 X = triangulate_point<kTailTri>(P1, P2, x1, x2, sm.tri);
+            a.as_pts4[row] = X;
+            extract3d_point(X, x1, x2, c1, c2, tol, a.as_cam1, a.as_flag, row);
+        }
         return;
     }
     b -= a.tri_blocks;
     if (b < a.p4_blocks) {
-        const int i = b * kTailThreads + threadIdx.x;
-        if (i < *a.ex.n_p) a.out_pts4[i] = a.ex.pts4[a.ex.map[i].queryIdx];
+        const int T = *a.ex.n_p;
+        for (int i = b * kTailThreads + threadIdx.x; i < T; i += a.p4_blocks * kTailThreads) a.out_pts4[i] = a.ex.pts4[a.ex.map[i].queryIdx];
         return;
     }
-    tail_gather_rows(a, (b - a.p4_blocks) * (kTailThreads / 16));
+    b -= a.p4_blocks;
+    const int meff = a.cn[CN_MEFF];
+    for (int first = b * (kTailThreads / 16); first < meff; first += a.gather_blocks * (kTailThreads / 16)) tail_gather_rows(a, first);
 }
 // the same per-row triangulation for a set that was gathered by other means (the init phase's first set; the second pair of a two-pair launch)
 __global__ __launch_bounds__(kTriThreads) void k_as_triangulate(Mat34 P1, Mat34 P2, Cam c1, Cam c2, double tol, const uvo_keypoint* aL, const uvo_keypoint* aR,
@@ -942,12 +948,17 @@ uvo_status pose_stereo_tail(Ctx* a, Ctx* p, int prev, int curr, int slot, const 
     ta.m_s = a->d_matches[0]; ta.cn = cn; ta.kL = a->det[0].kps; ta.kR = a->det[1].kps; ta.dL = a->det[0].desc;
     ta.okL = a->d_as_kpsL[curr]; ta.okR = a->d_as_kpsR[curr]; ta.odL = a->d_as_descL[curr]; ta.dim = a->desc_dim();
     ta.as_pts4 = a->d_as_pts4[curr]; ta.as_cam1 = a->d_as_cam1[curr]; ta.as_flag = a->d_as_flag[curr];
-    ta.tri_blocks = (cap + kTailTri - 1) / kTailTri;
+    // rows to expect: the keypoints of the last pair whose counts reached the host, plus a quarter (max_kpts before that)
+    const Ctx* hm = a->master ? a->master : a;
+    int rows = hm->kp_hint > 0 ? hm->kp_hint + hm->kp_hint / 4 : cap;
+    rows = rows < 256 ? 256 : (rows > cap ? cap : rows);
+    ta.tri_blocks = (rows + kTailTri - 1) / kTailTri;
+    ta.gather_blocks = (rows + kTailThreads / 16 - 1) / (kTailThreads / 16);
     ta.ex = Ex3Lane{ p->d_as_cam1[prev], p->d_as_flag[prev], nullptr, cn + CN_T, a->d_tmp_idx, a->d_good_pts[slot], a->d_good_idx[slot], a->d_opts[slot], a->d_ipts[slot],
                      cn, counts_host, a->d_matches[1], a->det[0].kps, p->d_as_pts4[prev], a->d_pts4, a->d_tmp_row };
     // contexts of up to 8192 keypoints: extract_3Dpoints is workgroup 0 of the same launch; larger ones: its any-size kernel first
     ta.fused = cap <= kEx3Passes * kTailThreads ? 1 : 0;
-    if (ta.fused) { ta.out_pts4 = a->d_pts4; ta.ex.out_pts4 = nullptr; ta.p4_blocks = (cap + kTailThreads - 1) / kTailThreads; }
+    if (ta.fused) { ta.out_pts4 = a->d_pts4; ta.ex.out_pts4 = nullptr; ta.p4_blocks = (rows + kTailThreads - 1) / kTailThreads; }
     else {
         ta.out_pts4 = nullptr; ta.p4_blocks = 0;
         StageTimer t(a, ST_EXTRACT3D);
@@ -955,7 +966,7 @@ uvo_status pose_stereo_tail(Ctx* a, Ctx* p, int prev, int curr, int slot, const 
         hipLaunchKernelGGL(k_extract3d_b, dim3(1, 1), dim3(1024), 0, a->stream, el, cap, a->p.MIN_NUM_3DPOINTS, extract3d_force_seq());
     }
     StageTimer t(a, ST_TRIANGULATE);
-    hipLaunchKernelGGL(k_stereo_tail, dim3(ta.fused + ta.tri_blocks + ta.p4_blocks + (cap + kTailThreads / 16 - 1) / (kTailThreads / 16)), dim3(kTailThreads), 0, a->stream, m1, m2,
+    hipLaunchKernelGGL(k_stereo_tail, dim3(ta.fused + ta.tri_blocks + ta.p4_blocks + ta.gather_blocks), dim3(kTailThreads), 0, a->stream, m1, m2,
                        make_cam(R1, t1, K1), make_cam(R2, t2, K2), a->p.REPROJECTION_TOLERANCE, ta, a->p.MIN_NUM_3DPOINTS, extract3d_force_seq());
     UVO_HIP_TRY(a, hipGetLastError());
     return UVO_OK;

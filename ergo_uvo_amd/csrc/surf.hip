@@ -1107,11 +1107,13 @@ __global__ __launch_bounds__(256) void k_rank_partial(LanePair lp)
     for (int t_ = blockIdx.x; t_ < ntiles; t_ += gridDim.x) {
         const int i0 = (t_ % nib) * 256, j0 = (t_ / nib) * kSortChunk;
         const int cnt = min(kSortChunk, n - j0);
+        const int me = i0 + tid;
+        uvo_keypoint mykp = {};
+        if (me < n) mykp = a.cand[im][me];                   // (in flight together with the tile's records: one memory round trip, not two)
         for (int t = tid; t < cnt; t += 256) { tile[t] = make_sort_key(a.cand[im][j0 + t]); tile_k1[t] = tile[t].k1; }
         __syncthreads();
-        const int me = i0 + tid;
         if (me < n) {
-            const SortKey mine = make_sort_key(a.cand[im][me]);
+            const SortKey mine = make_sort_key(mykp);
             int rank = 0;
             // the first key (response, size) decides almost every comparison: one 64-bit compare per pair on a dense array of
             // first keys, the full lexicographic comparison only on the rare equal ones

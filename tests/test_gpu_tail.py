@@ -58,7 +58,12 @@ def test_tail_routes_capacities_and_the_oracle():
     scene = synth.Scene(321, 640)
     frames = [synth.stereo_pair(scene, k, 640, 360) for k in range(4)]
     blank = (np.full_like(frames[0][0], 90), np.full_like(frames[0][1], 90))
-    seq = [frames[0], frames[1], frames[2], blank, frames[3], frames[2], frames[1]]       # a gate failure mid-sequence: empty set, VO:727-733
+    # a pair with a few dozen keypoints (a textured patch on a blank image): the launches after it are sized for that count and have to
+    # walk the next, rich pair's rows (the tail's roles and the descriptor launch loop over grids smaller than their work)
+    sparse = tuple(b.copy() for b in blank)
+    for k in (0, 1):
+        sparse[k][100:180, 200:300] = frames[1][k][100:180, 200:300]
+    seq = [frames[0], frames[1], frames[2], blank, frames[3], sparse, frames[2], frames[1]]       # a gate failure mid-sequence: empty set, VO:727-733
     rig = synth.stereo_rig(640)
     base = run(uvo, rig, seq, 4096, False)
     assert sum(f[0][0] for f in base) >= 4
