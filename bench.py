@@ -92,7 +92,7 @@ def self_launch(n: int) -> int:
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                        UVO_RDZV_FILE=os.path.join(tmp, "store"))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                          stdout=None if r == 0 else subprocess.DEVNULL))
+                                          stdout=(_REAL_STDOUT or None) if r == 0 else subprocess.DEVNULL))      # rank 0 prints the line
         # a rank that dies before the rendezvous would leave the others waiting for it: when one fails, the rest are ended (by PID)
         live = list(procs)
         while live:
@@ -161,6 +161,27 @@ def hbm_copy_peak_gbs(torch, seconds: float = 0.05, nbytes: int = 1 << 30) -> fl
     return 2.0 * nbytes * reps / (ms * 1e-3) / 1e9
 
 
+_REAL_STDOUT = None
+
+
+def emit(line: str) -> None:
+    """The contract's one JSON line, on the process's real standard output."""
+    out = _REAL_STDOUT or sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
+def claim_stdout() -> None:
+    """Standard output carries the JSON line and nothing else: everything a library prints there (RCCL's version block at communicator
+    creation, runtime notices) goes to standard error for the rest of the run, the line itself to a duplicate of the original descriptor.
+    (Run as a script only: tests import this module.)"""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,7 +203,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=7, help="the timed region (K steps between two fences) is run this many times in a row; "
                     "`value` is the median block, the first / slowest / fastest are reported beside it")
     ap.add_argument("--no-trace", action="store_true", help="do not record the per-pair pipeline trace (for --steps <= 64 one more, untimed-for-value block runs with it)")
-    ap.add_argument("--trace-all", action="store_true", help="trace every timed block instead (costs the 20-step form ~2.4 %)")
+    ap.add_argument("--trace-all", action="store_true", help="trace every timed block instead (costs the 20-step form ~2.4 %%)")
     ap.add_argument("--timed-only", action="store_true", help="diagnostics: stop after the timed region (no latency / roofline / CPU legs), "
                     "so that a UVO_TRACE file holds the timed pairs")
     ap.add_argument("--dump-records", default=None, help="rank 0 writes the gathered [world, steps, 16] pose records to this .npy")
@@ -376,8 +397,8 @@ def main():
 
     if args.timed_only:
         if rank == 0:
-            print(json.dumps({"value": round(value, 3), "unit": "pairs/s", "steps": args.steps, "warmup": args.warmup, "timed_only": True,
-                              "blocks": n_blocks, "block_values": [round(v, 1) for v in block_values], "collect_gap_ms": collect_gap_ms}), flush=True)
+            emit(json.dumps({"value": round(value, 3), "unit": "pairs/s", "steps": args.steps, "warmup": args.warmup, "timed_only": True,
+                             "blocks": n_blocks, "block_values": [round(v, 1) for v in block_values], "collect_gap_ms": collect_gap_ms}))
         if dist_on:
             multirank.barrier(); dist.destroy_process_group()
         ctx.close()
@@ -580,8 +601,9 @@ def main():
         dist.destroy_process_group()
     ctx.close()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
 
 
 if __name__ == "__main__":
+    claim_stdout()
     main()
