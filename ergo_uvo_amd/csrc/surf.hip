@@ -475,10 +475,43 @@ __device__ __forceinline__ int lane_tid() { int t = threadIdx.x; asm volatile(""
         const float dxy = (float)d;                                                                       \
         det = (pp_in) - 0.81f * dxy * dxy;                                                                \
     }
+// The same with Dy taken only where Dx leaves the product a chance: every box sum is at most 255 x its area, so |dy| <= 510 (+ rounding)
+// and |dx| * 512 <= threshold implies dx * dy <= threshold -- the sample gets kDetBelow exactly as it would have with dy computed.
+// A wave whose 64 samples all fall under that bound skips Dy's eight corners and its double accumulation (LDS tiles only: the plane
+// reads of octaves 2-3 are issued in batches that a branch would split).
+#define UVO_HESSIAN_PP_LAZY(SV, pp_out)                                                                   \
+    {                                                                                                     \
+        const unsigned gx0 = (unsigned)(SV(c7, c0) - SV(c2, c0)), gx3 = sad_u32(SV(c7, c3), SV(c2, c3), kBoxMagic),                       \
+                       gx6 = sad_u32(SV(c7, c6), SV(c2, c6), 2u * kBoxMagic), gx9 = sad_u32(SV(c7, c9), SV(c2, c9), 3u * kBoxMagic);     \
+        static_assert(wx0 == wx2 && wy0 == wy2 && wx0 == wy0 && wx1 == wy1, "the outer boxes of Dx and Dy share one weight");            \
+        const uvo_v2f px02 = UVO_BOX_FMA2(gx3 - gx0, gx9 - gx6, wx0);                                                                     \
+        const float px1 = __builtin_fmaf(__uint_as_float(gx6 - gx3), wx1, -8388608.0f * wx1);                                           \
+        double d = (double)px02.x;                                                                        \
+        d += (double)px1;                                                                                 \
+        d += (double)px02.y;                                                                              \
+        const float dx = (float)d;                                                                        \
+        pp_out = -3.0e38f;                                                                                \
+        if (__builtin_fabsf(dx) * 512.0f > skip_thr) {                                                    \
+            const unsigned gy0 = (unsigned)(SV(c0, c7) - SV(c0, c2)), gy3 = sad_u32(SV(c3, c7), SV(c3, c2), kBoxMagic),                   \
+                           gy6 = sad_u32(SV(c6, c7), SV(c6, c2), 2u * kBoxMagic), gy9 = sad_u32(SV(c9, c7), SV(c9, c2), 3u * kBoxMagic); \
+            const uvo_v2f py02 = UVO_BOX_FMA2(gy3 - gy0, gy9 - gy6, wy0);                                                                 \
+            const float py1 = __builtin_fmaf(__uint_as_float(gy6 - gy3), wy1, -8388608.0f * wy1);                                       \
+            d = (double)py02.x;                                                                           \
+            d += (double)py1;                                                                             \
+            d += (double)py02.y;                                                                          \
+            const float dy = (float)d;                                                                    \
+            pp_out = dx * dy;                                                                             \
+        }                                                                                                 \
+    }
+// Off by default: on the bench's scene (texture everywhere) no wave qualifies and the split costs 0.9 us of the launch (68.5 against
+// 67.6 us); -DUVO_LAZY_DY=1 is for footage with large smooth regions.
+#ifndef UVO_LAZY_DY
+#define UVO_LAZY_DY 0
+#endif
 #define UVO_HESSIAN_DET(SV, det)                                                                          \
     {                                                                                                     \
         float pp_;                                                                                        \
-        UVO_HESSIAN_PP(SV, pp_)                                                                           \
+        if constexpr (UVO_LAZY_DY) UVO_HESSIAN_PP_LAZY(SV, pp_) else UVO_HESSIAN_PP(SV, pp_)              \
         if (!(pp_ > skip_thr)) det = kDetBelow; else UVO_HESSIAN_DXY(SV, pp_, det)                        \
     }
 #define UVO_HESSIAN_CONSTS(LC)                                                                            \
