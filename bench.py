@@ -31,6 +31,10 @@ import os
 # one hardware queue per HIP stream of the pipeline lanes (the ROCm default of 4 makes lanes share queues and
 # serialises them); must be set before the HIP runtime starts
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# numpy / torch size their thread pools by the host's CPU count (256 on the GPU boxes) and their idle threads spin for a while after
+# every parallel region: nothing here needs them, and on a host with a cgroup CPU quota they run the container into the throttle
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
 import sys
 import time
 
@@ -589,9 +593,9 @@ def main():
             "stage_ms": stage_ms, "stage_launches_per_step": stage_calls,
             "cpu_baseline": cpu,
             "host": {"cores_visible": host_cores_all, "cores_of_this_rank": len(my_cores), "pinned": len(my_cores) < host_cores_all and bool(my_cores),
-                     "pin_source": pin.get("source"), "numa_node": pin.get("numa_node"), "gpu_pci": pin.get("pci"), "pin_matches_opened_device": pin.get("pci_match"),
+                     "pin_source": pin.get("source"), "cgroup_cpu_quota": pin.get("cpu_quota"), "numa_node": pin.get("numa_node"), "gpu_pci": pin.get("pci"), "pin_matches_opened_device": pin.get("pci_match"),
                      "numa_nodes_of_ranks": who[:, 4].tolist(), "cores_of_ranks": who[:, 5].tolist(), "gc": "frozen and disabled during the timed blocks",
-                     "threads_per_rank": f"1 submitter (polls) + {args.depth} lane workers (sleep on stage A's event; <= 3 at a time poll inside the PnP stage)",
+                     "threads_per_rank": f"1 submitter (polls) + {args.depth} lane workers (timed sleep + poll for stage A's end; <= 3 at a time poll inside the PnP stage)",
                      "busy_host_threads_rank0": round(busy_threads, 2),
                      "collectives": ("none (single process)" if not dist_on else f"{args.backend}: all_gather_into_tensor of the pose records, all_reduce(MAX) of the time, barriers; {world} rank(s)")},
         }

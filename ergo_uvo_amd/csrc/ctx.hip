@@ -4,6 +4,7 @@
 #include "uvo_ctx.h"
 #include "uvo_epnp.h"
 #include <string.h>
+#include <sched.h>
 #include <atomic>
 #include <math.h>
 #include <float.h>
@@ -159,7 +160,7 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     A(dalloc(&c->d_mpart, 2 * nchunks * cap)); A(dalloc(&c->d_mscratch, 2 * (nchunks + 4))); A(dalloc(&c->d_knn_idx, 2 * cap * 2)); A(dalloc(&c->d_knn_dist, 2 * cap * 2));
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
     A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_tmp_idx, cap)); A(dalloc(&c->d_tmp_row, cap));
-    if (const char* ww = getenv("UVO_WORKER_WAIT")) c->worker_wait = !strcmp(ww, "spin") ? 0 : (!strcmp(ww, "block-all") ? 2 : 1);
+    if (const char* ww = getenv("UVO_WORKER_WAIT")) c->worker_wait = !strcmp(ww, "spin") ? 0 : (!strcmp(ww, "block-all") ? 2 : ((!strcmp(ww, "sleep") || !strcmp(ww, "block")) ? 3 : 1));
     A(hipEventCreateWithFlags(&c->evBlock, hipEventDisableTiming | hipEventBlockingSync));
     A(hipEventCreateWithFlags(&c->evPoll, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
@@ -1212,8 +1213,12 @@ static void run_stage_b(uvo_ctx* L, bool stage_a_ok)
 static bool wait_stage_a(uvo_ctx* L)
 {
     if (L->worker_wait == 2) return hipEventSynchronize(L->evA[0]) == hipSuccess;       // sleeps on the interrupt (hipEventBlockingSync)
-    if (L->worker_wait == 0) return uvo::poll_event(L->evA[0]) == hipSuccess;
     Ctx* m = L->master ? L->master : L;
+    if (L->worker_wait == 1) {                                  // auto: poll when the process may use a CPU per worker (+ submitter + one spare)
+        static const int ncpu = [] { cpu_set_t set; CPU_ZERO(&set); return sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 0; }();
+        if (ncpu >= (int)m->lanes.size() + 2) return uvo::poll_event(L->evA[0]) == hipSuccess;
+    }
+    if (L->worker_wait == 0) return uvo::poll_event(L->evA[0]) == hipSuccess;
     const double t0 = L->t_handover_us, mean = m->stage_a_mean_us.load(std::memory_order_relaxed);
     for (;;) {
         const hipError_t e = hipEventQuery(L->evA[0]);

@@ -153,15 +153,16 @@ struct Ctx {
                                                  // blocks on (hipEventSynchronize), [1] its twin for other lanes' hipStreamWaitEvent -- the runtime holds
                                                  // an event's lock while a host thread waits on it, so a stream wait on the SAME event blocked the
                                                  // submitting thread until the event completed (133 us per pair at C3)
-    // How the lane's worker thread waits for the device (env UVO_WORKER_WAIT = spin | block | block-all; default block):
-    //   0 spin      -- every wait polls (lowest latency, one busy host thread per waiting worker: up to `depth` per context)
-    //   1 block     -- the long wait for the end of stage A (evA[0]) SLEEPS ON A TIMER for most of the stage's expected length (a running
-    //                  mean over the context's pairs) and polls the event over the rest; the two short syncs inside the PnP stage poll.
-    //                  With N ranks on one node this keeps a rank at one spinning submitter + at most max_b polling workers instead
-    //                  of 1 + depth.  Until round 4 this wait slept on the event's interrupt (hipEventBlockingSync): about one wait
-    //                  in a hundred then woke 3-4 ms late (pipeline_trace: dev_a_end_to_pnp_begin_ms 3.3 / 4.4 ms against 0.024) --
-    //                  the stall behind round 3's 1990 pairs/s driver record
-    //   2 block-all -- the PnP stage's syncs sleep as well (evBlock); for hosts with fewer cores than threads
+    // How the lane's worker thread waits for the end of its pair's stage A (env UVO_WORKER_WAIT = spin | sleep | block-all):
+    //   1 auto (default) -- poll (hipEventQuery + pause) when the process may run on at least depth + 2 CPUs, else `sleep`
+    //   0 spin      -- always poll: one busy host thread per waiting worker, up to `depth` per context
+    //   3 sleep     -- sleep ON A TIMER through the first four fifths of a running mean of the stage's length, then poll.  Keeps a rank
+    //                  at one spinning submitter + at most max_b polling workers; on a loaded host a timer sleep was seen to overrun
+    //                  by 8-10 ms about once in 3000 pairs (pipeline_trace: dev_a_end_to_pnp_begin_ms 8.4 ms)
+    //   2 block-all -- every wait, the PnP stage's two short ones included, sleeps on the GPU's interrupt (hipEventBlockingSync,
+    //                  evBlock): for hosts with fewer cores than threads.  Until round 4 the stage-A wait did this by default, and about
+    //                  one such wait in a hundred woke 3-4 ms late -- the stall behind round 3's 1990 pairs/s driver record
+    // Inside the PnP stage the two short syncs poll in every mode but block-all.
     int worker_wait = 1;
     std::atomic<double> stage_a_mean_us{0.0};    // master: hand-over -> end of stage A, running mean (lane workers' timed sleep)
     double t_handover_us = 0;                    // lane: when the pair's stage A was handed to the worker

@@ -1,6 +1,12 @@
 import os
 import sys
 
+# numpy / torch size their thread pools by the host's CPU count (256 on the GPU boxes), and idle pool threads spin after every parallel
+# region: on a box with a cgroup CPU quota (16 there) that runs the container into the throttle -- every thread stopped for the rest
+# of a 100 ms period -- which the rate-comparing GPU tests then see as noise.  Nothing in the tests needs the pools.
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, "4")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

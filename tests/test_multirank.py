@@ -44,7 +44,7 @@ def _worker_body(rank, world, rdzv, q):
         os.environ.pop(k, None)
     sys.path.insert(0, ROOT)
     from ergo_uvo_amd import multirank
-    cores = multirank.pin_rank(rank, world, gpus=[])["cores"]        # no GPU topology on the CPU test host: index slices
+    cores = multirank.pin_rank(rank, world, gpus=[], quota=None)["cores"]        # no GPU topology on the CPU test host: index slices
     r, w = multirank.init("gloo", force=True)
     assert (r, w) == (rank, world)
     recs = _run_stream(rank)
@@ -141,23 +141,39 @@ def test_ranks_are_pinned_to_the_numa_node_of_their_gpu(tmp_path, monkeypatch):
     calls = []
     monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(32)))
     monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cores: calls.append(sorted(cores)))
-    pins = [multirank.pin_rank(r, 8, gpus=gpus) for r in range(8)]
+    pins = [multirank.pin_rank(r, 8, gpus=gpus, quota=None) for r in range(8)]
     assert [p["numa_node"] for p in pins] == [0, 0, 0, 0, 1, 1, 1, 1]
     assert [p["cores"] for p in pins] == [smt(16 * (r // 4))[4 * (r % 4):4 * (r % 4) + 4] for r in range(8)]   # 4 ranks split each node's 16 threads ...
     assert pins[0]["cores"] == [0, 8, 1, 9] and [sorted(p["cores"]) for p in pins] == calls                    # ... into whole cores (both SMT siblings)
     # one rank on a one-card box: the whole node next to the card, not the whole machine
     calls.clear()
-    p = multirank.pin_rank(0, 1, gpus=g1)
+    p = multirank.pin_rank(0, 1, gpus=g1, quota=None)
     assert sorted(p["cores"]) == list(range(16, 32)) and calls == [list(range(16, 32))] and p["pci"] == "0000:55:00.0"
     # five rehearsal ranks sharing the one card split its node
     calls.clear()
-    pins = [multirank.pin_rank(r, 5, share_devices=True, gpus=g1) for r in range(5)]
+    pins = [multirank.pin_rank(r, 5, share_devices=True, gpus=g1, quota=None) for r in range(5)]
     assert [len(p["cores"]) for p in pins] == [3] * 5 and len({c for p in pins for c in p["cores"]}) == 15
     # topology unreadable: index slices as before, and a single rank stays unpinned
     calls.clear()
-    pins = [multirank.pin_rank(r, 4, gpus=[]) for r in range(4)]
+    pins = [multirank.pin_rank(r, 4, gpus=[], quota=None) for r in range(4)]
     assert [p["cores"] for p in pins] == [list(range(8 * r, 8 * r + 8)) for r in range(4)]
-    assert multirank.pin_rank(0, 1, gpus=[])["source"] == "unpinned"
+    assert multirank.pin_rank(0, 1, gpus=[], quota=None)["source"] == "unpinned"
+    # a cgroup CPU quota (container limited to so many CPUs' worth of time): a rank keeps only its share of it -- whole cores first --
+    # so that its busy threads cannot run the container into the throttle; read from cpu.max (v2) or cfs_quota / cfs_period (v1)
+    calls.clear()
+    q = multirank.pin_rank(0, 1, gpus=g1, quota=6.0)
+    assert q["cores"] == smt(16)[:6] and calls == [sorted(smt(16)[:6])] and q["cpu_quota"] == 6.0
+    assert [len(multirank.pin_rank(r, 4, gpus=gpus, quota=10.0)["cores"]) for r in range(4)] == [2, 2, 2, 2]      # 10 // 4, never below two
+    assert len(multirank.pin_rank(0, 1, gpus=[], quota=8.0)["cores"]) == 8
+    cg = tmp_path / "cg"; cg.mkdir()
+    (cg / "cpu.max").write_text("1600000 100000\n")
+    assert multirank.cpu_quota(str(cg)) == 16.0
+    (cg / "cpu.max").write_text("max 100000\n")
+    assert multirank.cpu_quota(str(cg)) is None
+    (cg / "cpu.max").unlink(); (cg / "cpu").mkdir()
+    (cg / "cpu" / "cpu.cfs_quota_us").write_text("250000\n"); (cg / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert multirank.cpu_quota(str(cg)) == 2.5
+    assert multirank.cpu_quota(str(tmp_path / "nowhere")) is None
 
     class Props: pci_domain_id, pci_bus_id, pci_device_id = 0, 0x55, 0
     assert multirank.pin_matches_device(p, Props) is True
