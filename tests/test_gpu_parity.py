@@ -2,6 +2,9 @@
 Bit-exact for integers, keypoints, descriptors, match pairs, masks; poses to 1e-4 rel. Frobenius
 (BASELINE.json north_star), in practice bit-equal.  PARITY vs OpenCV itself is UNPINNED (no OpenCV
 in this environment): what is shown is HIP <-> the oracle's restatement."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -827,38 +830,21 @@ def test_a_later_context_runs_at_the_first_ones_rate():
     """a context created after another one of the same process had been destroyed ran ~10 % below its rate
     (the runtime binds a stream to a hardware queue once; which stream serves which role decides which roles share a pipe of the
     command processor: tools/probe/ctx_reuse.py).  The library parks its streams per role, so the fifth context of a process gets the
-    first one's binding -- pinned here at 5 % (the probe measured 0.99 .. 1.01; create / destroy gave 0.91 .. 0.94, one shared free
-    list 0.87 on every second context)."""
-    import time
-    import torch
-    import ergo_uvo_amd as uvo
-    from ergo_uvo_amd import synth
-    W, H = 1920, 1080
-    scene = synth.Scene(synth.SEEDS["C3"], W)
-    frames = [tuple(torch.from_numpy(a).cuda() for a in synth.stereo_pair(scene, k, W, H)) for k in range(2)]
-    rig = synth.stereo_rig(W)
-    rates = []
-    for it in range(5):
-        c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=6387), 0, W, H, 8192)
-        try:
-            c.stereo_set_depth(6)
-            c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
-            for k in range(2):
-                c.stereo_step(*frames[k], 0.05)
-            best, n = 0.0, 240
-            for rep in range(3):
-                torch.cuda.synchronize()
-                t0 = time.perf_counter(); sub = 0
-                for i in range(n):
-                    while sub < n and sub - i < 6:
-                        c.stereo_submit(*frames[sub & 1]); sub += 1
-                    assert c.stereo_collect(0.05).valid == 1
-                torch.cuda.synchronize()
-                best = max(best, n / (time.perf_counter() - t0))
-            rates.append(best)
-        finally:
-            c.close()
-    assert min(rates[1:]) >= 0.95 * rates[0], rates
+    first one's binding -- pinned here at 5 % (the probe measures 0.99 .. 1.01; create / destroy gave 0.91 .. 0.94, one shared free
+    list 0.87 on every second context).  Measured by the probe itself in a process of its own: inside the test runner the HIP runtime
+    is already up with its default of four hardware queues, the loop is then bound by the host (3000 pairs/s against 4700) and what
+    the comparison sees is the speed of the Python thread, not the streams' binding."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("UVO_STREAM_POOL",)}
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "probe", "ctx_reuse.py"), "240"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    m = re.search(r"contexts 1\.\.5: ([0-9 ]+?) +5th/1st", p.stdout)
+    assert m, p.stdout[-500:]
+    rates = [float(x) for x in m.group(1).split()]
+    assert len(rates) == 5 and min(rates[1:]) >= 0.95 * rates[0], rates
 
 
 @pytest.mark.parametrize("W,H", [(641, 363), (644, 360), (1000, 562)])
