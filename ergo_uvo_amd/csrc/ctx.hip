@@ -965,9 +965,9 @@ static uvo_status prime_lanes(uvo_ctx* c, int w, int h)
         // (event + stream) also set up the runtime's per-thread state
         UVO_HIP_TRY(c, hipEventRecord(l->evA[0], l->stream));
         l->t_handover_us = 0;
-        { std::lock_guard<std::mutex> lk(l->mu); l->job.kind = 2; l->job.state = 1; }
+        { std::lock_guard<std::mutex> lk(l->mu); l->job.kind = 2; l->job.state = 1; l->job_state_a.store(1, std::memory_order_release); }
         l->cv.notify_all();
-        { std::unique_lock<std::mutex> lk(l->mu); l->cv.wait(lk, [&] { return l->job.state == 2; }); l->job.state = 0; }
+        { std::unique_lock<std::mutex> lk(l->mu); l->cv.wait(lk, [&] { return l->job.state == 2; }); l->job.state = 0; l->job_state_a.store(0, std::memory_order_release); }
         l->primed_w = w; l->primed_h = h;
     }
     return UVO_OK;
@@ -1173,7 +1173,7 @@ static uvo_status queue_stage_a(uvo_ctx* c, uvo_ctx* A, uvo_ctx* B)
             L->job.kind = 0;
         } else {   // hand stage B to the lane's worker
             L->t_handover_us = uvo::now_us();
-            { std::lock_guard<std::mutex> lk(L->mu); L->job.kind = 0; L->job.state = 1; }
+            { std::lock_guard<std::mutex> lk(L->mu); L->job.kind = 0; L->job.state = 1; L->job_state_a.store(1, std::memory_order_release); }
             L->cv.notify_all();
         }
     }
@@ -1209,16 +1209,34 @@ static void run_stage_b(uvo_ctx* L, bool stage_a_ok)
         else { j.wrote = r.wrote; j.ok = r.ok; j.ninl = r.ninl; memcpy(j.rvec, r.rvec, sizeof(j.rvec)); memcpy(j.tvec, r.tvec, sizeof(j.tvec)); }
     }
 }
+// Does this context's pipeline poll rather than sleep (uvo_ctx.h: worker_wait)?  auto: when the process may use a CPU per worker.
+static bool pipeline_polls(const Ctx* L)
+{
+    const Ctx* m = L->master ? L->master : L;
+    if (L->worker_wait == 0) return true;
+    if (L->worker_wait != 1) return false;
+    static const int ncpu = [] { cpu_set_t set; CPU_ZERO(&set); return sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 0; }();
+    return ncpu >= (int)m->lanes.size() + 2;
+}
+// A thread about to sleep on a lane's condition variable for job.state == want first polls the state's atomic twin for up to `spin_us`:
+// in a running pipeline the hand-overs (submitter -> worker, worker -> collect) come within a few hundred microseconds, and a
+// thread asleep on a futex was seen to be woken milliseconds late on a loaded host (the last of round 4's stalls: 4 ms holes with
+// every device-side wait already polling).  An idle context's threads still end up asleep.
+static void poll_job_state(uvo_ctx* L, int want, double spin_us)
+{
+    if (!pipeline_polls(L)) return;
+    const double t0 = now_us();
+    while (L->job_state_a.load(std::memory_order_acquire) != want) {          // (a context being destroyed: the spin times out and the condition variable sees `quit`)
+        for (int i = 0; i < 40; i++) __builtin_ia32_pause();
+        if (now_us() - t0 > spin_us) return;
+    }
+}
 // The lane worker's long wait, for the end of its pair's stage A (uvo_ctx.h: worker_wait).
 static bool wait_stage_a(uvo_ctx* L)
 {
     if (L->worker_wait == 2) return hipEventSynchronize(L->evA[0]) == hipSuccess;       // sleeps on the interrupt (hipEventBlockingSync)
     Ctx* m = L->master ? L->master : L;
-    if (L->worker_wait == 1) {                                  // auto: poll when the process may use a CPU per worker (+ submitter + one spare)
-        static const int ncpu = [] { cpu_set_t set; CPU_ZERO(&set); return sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 0; }();
-        if (ncpu >= (int)m->lanes.size() + 2) return uvo::poll_event(L->evA[0]) == hipSuccess;
-    }
-    if (L->worker_wait == 0) return uvo::poll_event(L->evA[0]) == hipSuccess;
+    if (pipeline_polls(L)) return uvo::poll_event(L->evA[0]) == hipSuccess;     // spin, or auto with a CPU per worker (+ submitter + one spare)
     const double t0 = L->t_handover_us, mean = m->stage_a_mean_us.load(std::memory_order_relaxed);
     for (;;) {
         const hipError_t e = hipEventQuery(L->evA[0]);
@@ -1239,6 +1257,7 @@ static void lane_worker(uvo_ctx* L)
     (void)hipSetDevice(L->device);
     std::unique_lock<std::mutex> lk(L->mu);
     for (;;) {
+        if (L->job.state != 1 && !L->quit) { lk.unlock(); poll_job_state(L, 1, 2000.0); lk.lock(); }     // the next pair usually comes within the pipeline's period
         L->cv.wait(lk, [&] { return L->quit || L->job.state == 1; });
         if (L->quit) return;
         lk.unlock();
@@ -1268,6 +1287,7 @@ static void lane_worker(uvo_ctx* L)
         }
         lk.lock();
         L->job.state = 2;
+        L->job_state_a.store(2, std::memory_order_release);
         L->cv.notify_all();
     }
 }
@@ -1302,9 +1322,10 @@ extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_resul
         L->inline_b = false;
         run_stage_b(L, uvo::poll_event(L->evSync) == hipSuccess);
     } else {
+        poll_job_state(L, 2, 5000.0);
         std::unique_lock<std::mutex> lk(L->mu);
         L->cv.wait(lk, [&] { return L->job.state == 2; });
-        L->job.state = 0;
+        L->job.state = 0; L->job_state_a.store(0, std::memory_order_release);
     }
     const Ctx::BJob& j = L->job;
     memset(out, 0, sizeof(*out));
@@ -1793,7 +1814,7 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
     L->t_handover_us = uvo::now_us();
     {
         std::lock_guard<std::mutex> lk(L->mu);
-        L->job.kind = 1; L->job.range = range; L->job.state = 1;
+        L->job.kind = 1; L->job.range = range; L->job.state = 1; L->job_state_a.store(1, std::memory_order_release);
     }
     L->cv.notify_all();
     return UVO_OK;
@@ -1902,9 +1923,10 @@ extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* o
     c->last_lane = li;
     L->pending.used = false;
     {
+        poll_job_state(L, 2, 5000.0);
         std::unique_lock<std::mutex> lk(L->mu);
         L->cv.wait(lk, [&] { return L->job.state == 2; });
-        L->job.state = 0;
+        L->job.state = 0; L->job_state_a.store(0, std::memory_order_release);
     }
     const Ctx::BJob& j = L->job;
     if (j.st != UVO_OK) return fail(c, j.st, j.err.c_str());

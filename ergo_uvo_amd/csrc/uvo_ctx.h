@@ -166,6 +166,7 @@ struct Ctx {
     int worker_wait = 1;
     std::atomic<double> stage_a_mean_us{0.0};    // master: hand-over -> end of stage A, running mean (lane workers' timed sleep)
     double t_handover_us = 0;                    // lane: when the pair's stage A was handed to the worker
+    std::atomic<int> job_state_a{0};             // lane: job.state again, for the threads that poll for it before they sleep on cv (ctx.hip: wait_job_state)
     hipEvent_t evBlock = nullptr;                // hipEventBlockingSync marker for host_sync()
     hipEvent_t evPoll = nullptr;                 // host_sync()'s marker when it polls
     int* h_countsA[2] = {nullptr, nullptr};      // pinned copy of d_counts
