@@ -529,6 +529,18 @@ __device__ __forceinline__ void static_for(F&& f)
     if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
 }
 
+// A corner read from the tile.  As plain loads the compiler pairs corners of one tile row into ds_read2_b32 -- whose two offsets reach
+// 1 KB, three tile rows -- behind a v_add_u32 that forms the pair's base: eight address additions per determinant on the unit that
+// bounds the kernel.  Volatile LDS loads are not paired (each a ds_read_b32 with its 16-bit offset from the sample's one base register):
+// 9 % fewer vector instructions in the octave-0 loop, twice the LDS instructions, 64.5 against 65.0 us -- measured, not kept.
+#ifndef UVO_SV_VOLATILE
+#define UVO_SV_VOLATILE 0
+#endif
+#if UVO_SV_VOLATILE
+#define UVO_SV_LOAD(base, off) (((const volatile __attribute__((address_space(3))) int32_t*)(base))[off])
+#else
+#define UVO_SV_LOAD(base, off) ((base)[off])
+#endif
 // det plane of layer L (1..3) of a workgroup's TW x TH samples from the integral tile in LDS; 0 where the template does not fit
 template <int O, int L, int TW, int TH, int NT, class OP>
 __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, float* __restrict__ sdet, const OP& op,
@@ -541,7 +553,7 @@ __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, f
     constexpr int OFFL = -OC::margin(L) * STEP - OC::LO;          // tile offset of this layer's template origin
     static_assert(OFFL >= 0, "layer origin outside the tile");
     // tile index of corner (dy, dx) relative to base = &stile[ry*STEP*STEP*PW + rx]
-#define SV(dy, dx) base[((OFFL + (dy)) * STEP + ((OFFL + (dx)) % STEP)) * PW + (OFFL + (dx)) / STEP]
+#define SV(dy, dx) UVO_SV_LOAD(base, ((OFFL + (dy)) * STEP + ((OFFL + (dx)) % STEP)) * PW + (OFFL + (dx)) / STEP)
     UVO_HESSIAN_CONSTS(LC);
     const auto& lp = op.L[L];
     const int tid = lane_tid();
