@@ -1353,6 +1353,12 @@ template <> __device__ __forceinline__ unsigned px_load<1>(ImgRsrc rs, int voff,
 template <> __device__ __forceinline__ unsigned px_load<2>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0); }
 template <> __device__ __forceinline__ unsigned px_load<4>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0); }
 
+// (measured, off: the conversion-free form below compiles to v_or_b32_sdwa + v_pk_fma_f32 + v_pk_add_f32 as intended, but holds every
+// loaded word's four floats at once -- 37 registers spilled under this kernel's 64: 90.5 us against 57.2; 76.4 / 66.7 us at seven / six
+// waves per SIMD with 72 / 80 registers, still spilling)
+#ifndef UVO_DESC_FMA
+#define UVO_DESC_FMA 0
+#endif
 template <int PX, int Q>
 struct AreaCol {
     ImgRsrc rs; int w, h1;
@@ -1372,19 +1378,30 @@ struct AreaCol {
 #pragma unroll
         for (int q = 0; q < Q; q++) v[q] = px_load<PX>(rs, voff[q], soff);
     }
+    // (float)pixel * alpha without the byte -> float conversion (v_cvt_f32_ubyte*: 1.7 issue slots on gfx950, tools/probe/issue_rate_probe.hip):
+    // the float whose bits are pixel | 0x4B000000 is 2^23 + pixel, and fma(2^23 + pixel, alpha, -(2^23 alpha)) rounds the exact product
+    // pixel * alpha once -- the same float ((2^23) alpha is exact; pixel = 0 or alpha = +0 give +0 either way; alpha >= 0 always)
+    static __device__ __forceinline__ float px_times(unsigned v, int p, float alpha)
+    {
+#if UVO_DESC_FMA
+        return __builtin_fmaf(__uint_as_float(((v >> (8 * p)) & 255u) | 0x4B000000u), alpha, -8388608.0f * alpha);
+#else
+        return (float)(int)((v >> (8 * p)) & 255u) * alpha;
+#endif
+    }
     __device__ __forceinline__ void first(const unsigned (&v)[Q], float alpha)      // 0.f + v * a == v * a
     {
 #pragma unroll
         for (int q = 0; q < Q; q++)
 #pragma unroll
-            for (int p = 0; p < PX; p++) acc[q][p] = (float)(int)((v[q] >> (8 * p)) & 255u) * alpha;
+            for (int p = 0; p < PX; p++) acc[q][p] = px_times(v[q], p, alpha);
     }
     __device__ __forceinline__ void accum(const unsigned (&v)[Q], float alpha)
     {
 #pragma unroll
         for (int q = 0; q < Q; q++)
 #pragma unroll
-            for (int p = 0; p < PX; p++) acc[q][p] += (float)(int)((v[q] >> (8 * p)) & 255u) * alpha;
+            for (int p = 0; p < PX; p++) acc[q][p] += px_times(v[q], p, alpha);
     }
     // exactly N taps, everything static: N loads go out, then N sums (Q = 1: the columns of windows up to ~250 pixels)
     template <int N> __device__ __forceinline__ void taps_static(const ColTask& t)
