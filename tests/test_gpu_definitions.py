@@ -285,3 +285,47 @@ def test_pnp_ransac_recovers_a_planted_pose(uctx):
     xr = (Yr[:, :2] / Yr[:, 2:]) * np.array([rig.K_left[0, 0], rig.K_left[1, 1]]) + np.array([rig.K_left[0, 2], rig.K_left[1, 2]])
     err = np.linalg.norm(xr - x[inl].astype(np.float32), axis=1)
     assert np.mean(err <= thr) > 0.99 and err.max() < 1.5 * thr            # the inlier set is the best hypothesis', the pose its refit
+
+
+def test_essential_matrix_and_recovered_pose_by_their_definitions(uctx):
+    """findEssentialMat / recoverPose (VO_utility.cpp:134-180): E is an essential matrix (rank 2, two equal singular values:
+    2 E E^T E = tr(E E^T) E), its inliers satisfy the epipolar constraint within the threshold, and the recovered (R, t) is a
+    rotation, a unit translation, and the planted motion."""
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(1280)
+    K = rig.K_left
+    rng = np.random.default_rng(21)
+    n = 600
+    X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.2, 1.2, n), rng.uniform(2.5, 7, n)], 1)
+    R_t = uctx.Rodrigues(np.array([0.02, -0.03, 0.01]))
+    t_t = np.array([0.12, -0.03, 0.05])
+
+    def proj(R, t):
+        Y = X @ R.T + t
+        return (Y[:, :2] / Y[:, 2:]) * np.array([K[0, 0], K[1, 1]]) + np.array([K[0, 2], K[1, 2]])
+    p1 = proj(np.eye(3), np.zeros(3)) + rng.normal(0, 0.2, (n, 2))
+    p2 = proj(R_t, t_t) + rng.normal(0, 0.2, (n, 2))
+    bad = rng.choice(n, 120, replace=False)
+    p2[bad] += rng.uniform(15, 40, (120, 2)) * rng.choice([-1, 1], (120, 2))
+    p1, p2 = p1.astype(np.float32), p2.astype(np.float32)
+    thr = 1.0
+    ok, E, mask = uctx.findEssentialMat(p1, p2, K, method=8, prob=0.999, threshold=thr, max_iters=2000)
+    assert ok
+    E = E / np.linalg.norm(E)
+    sv = np.linalg.svd(E, compute_uv=False)
+    assert sv[2] < 1e-7 and abs(sv[0] - sv[1]) < 1e-7
+    assert np.abs(2 * E @ E.T @ E - np.trace(E @ E.T) * E).max() < 1e-7
+    Ki = np.linalg.inv(K)
+    h1 = np.c_[p1.astype(np.float64), np.ones(n)] @ Ki.T
+    h2 = np.c_[p2.astype(np.float64), np.ones(n)] @ Ki.T
+    # Sampson distance in pixels^2 (focal ~ K[0,0]) of the pairs the mask keeps
+    Ex1, Etx2 = h1 @ E.T, h2 @ E
+    samp = (np.sum(h2 * Ex1, 1) ** 2) / (Ex1[:, 0] ** 2 + Ex1[:, 1] ** 2 + Etx2[:, 0] ** 2 + Etx2[:, 1] ** 2) * K[0, 0] ** 2
+    inl = mask.astype(bool)
+    assert inl.sum() > 0.9 * (n - 120) and not inl[bad].any()
+    assert np.all(samp[inl] <= thr * thr * 1.02)
+    good, R, t, m2 = uctx.recoverPose(E, p1, p2, K, mask)
+    assert abs(np.linalg.det(R) - 1) < 1e-9 and np.abs(R @ R.T - np.eye(3)).max() < 1e-9 and abs(np.linalg.norm(t) - 1) < 1e-9
+    # (the cheirality count also drops points triangulated beyond distanceThresh = 50 baselines: the planted baseline is 0.135 of a unit)
+    assert good == int((m2 > 0).sum()) and good > 0.5 * inl.sum() and not np.any((m2 > 0) & ~inl)
+    assert np.abs(R - R_t).max() < 5e-3 and np.abs(t.ravel() - t_t / np.linalg.norm(t_t)).max() < 5e-2
