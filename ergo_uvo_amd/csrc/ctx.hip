@@ -1216,7 +1216,7 @@ static bool pipeline_polls(const Ctx* L)
     if (L->worker_wait == 0) return true;
     if (L->worker_wait != 1) return false;
     static const int ncpu = [] { cpu_set_t set; CPU_ZERO(&set); return sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 0; }();
-    return ncpu >= (int)m->lanes.size() + 2;
+    return ncpu >= 2 * ((int)m->lanes.size() + 2);        // (logical CPUs: a core per thread -- two ranks of eight busy threads on eight CPUs each ran a 16-CPU container into its throttle: 343 pairs/s)
 }
 // A thread about to sleep on a lane's condition variable for job.state == want first polls the state's atomic twin for up to `spin_us`:
 // in a running pipeline the hand-overs (submitter -> worker, worker -> collect) come within a few hundred microseconds, and a

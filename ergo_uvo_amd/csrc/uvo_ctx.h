@@ -154,7 +154,7 @@ struct Ctx {
                                                  // an event's lock while a host thread waits on it, so a stream wait on the SAME event blocked the
                                                  // submitting thread until the event completed (133 us per pair at C3)
     // How the lane's worker thread waits for the end of its pair's stage A (env UVO_WORKER_WAIT = spin | sleep | block-all):
-    //   1 auto (default) -- poll (hipEventQuery + pause) when the process may run on at least depth + 2 CPUs, else `sleep`
+    //   1 auto (default) -- poll (hipEventQuery + pause) when the process may run on at least 2 (depth + 2) logical CPUs, else `sleep`
     //   0 spin      -- always poll: one busy host thread per waiting worker, up to `depth` per context
     //   3 sleep     -- sleep ON A TIMER through the first four fifths of a running mean of the stage's length, then poll.  Keeps a rank
     //                  at one spinning submitter + at most max_b polling workers; on a loaded host a timer sleep was seen to overrun
