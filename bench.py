@@ -225,7 +225,12 @@ def main():
     # lane workers inherit it (one polling submitter + <= max_b polling PnP workers per rank; the other workers sleep on events)
     host_cores_all = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    pin = {"cores": [], "source": "off"} if args.no_pin else multirank.pin_rank(local_rank, local_world, share_devices=args.share_devices)
+    # UVO_BENCH_PIN=quota: the rank's cores cut to its share of the cgroup CPU quota (measurement: gaps of 2-5 ms on a loaded host)
+    pin = {"cores": [], "source": "off"} if args.no_pin else multirank.pin_rank(local_rank, local_world, share_devices=args.share_devices,
+                                                                                cut_to_quota=os.environ.get("UVO_BENCH_PIN") == "quota")
+    # a rank whose share of the container's CPU quota cannot carry a polling thread per lane lets its lane workers sleep on a timer
+    if pin.get("quota_share") is not None and pin["quota_share"] < args.depth + 3:
+        os.environ.setdefault("UVO_WORKER_WAIT", "sleep")
     my_cores = pin["cores"]
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -593,7 +598,8 @@ def main():
             "stage_ms": stage_ms, "stage_launches_per_step": stage_calls,
             "cpu_baseline": cpu,
             "host": {"cores_visible": host_cores_all, "cores_of_this_rank": len(my_cores), "pinned": len(my_cores) < host_cores_all and bool(my_cores),
-                     "pin_source": pin.get("source"), "cgroup_cpu_quota": pin.get("cpu_quota"), "numa_node": pin.get("numa_node"), "gpu_pci": pin.get("pci"), "pin_matches_opened_device": pin.get("pci_match"),
+                     "pin_source": pin.get("source"), "cgroup_cpu_quota": pin.get("cpu_quota"), "cpu_quota_share_of_this_rank": pin.get("quota_share"),
+                     "worker_wait": os.environ.get("UVO_WORKER_WAIT", "auto"), "numa_node": pin.get("numa_node"), "gpu_pci": pin.get("pci"), "pin_matches_opened_device": pin.get("pci_match"),
                      "numa_nodes_of_ranks": who[:, 4].tolist(), "cores_of_ranks": who[:, 5].tolist(), "gc": "frozen and disabled during the timed blocks",
                      "threads_per_rank": f"1 submitter (polls) + {args.depth} lane workers (timed sleep + poll for stage A's end; <= 3 at a time poll inside the PnP stage)",
                      "busy_host_threads_rank0": round(busy_threads, 2),

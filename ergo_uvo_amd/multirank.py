@@ -112,21 +112,30 @@ def _within_quota(cores: list[int], local_world: int, quota: float | None) -> li
     return cores[:share] if len(cores) > share else cores
 
 
-def pin_rank(local_rank: int, local_world: int, share_devices: bool = False, gpus: list[dict] | None = None, quota: float | None | str = "auto") -> dict:
+def pin_rank(local_rank: int, local_world: int, share_devices: bool = False, gpus: list[dict] | None = None, quota: float | None | str = "auto",
+             cut_to_quota: bool = False) -> dict:
     """Pin this rank -- before its first GPU call, so that the HIP runtime's helper threads and the pipeline's lane workers inherit
     it -- to the host cores NEXT TO ITS GPU: the `local_cpulist` of the device LOCAL_RANK will open (the NUMA node the card hangs
     off, `/sys/bus/pci/devices/<addr>/numa_node`); ranks whose GPUs share a node split that node's cores evenly, in rank order.
     Falls back to an index slice of the allowed cores (rank r of n: cores [r*k, (r+1)*k)) when the topology cannot be read.
-    Returns {"cores", "source", "numa_node", "pci"}.  A rank runs 1 submitting thread (polls) + `depth` lane workers of which at
-    most max_b (3) poll at a time."""
+    Returns {"cores", "source", "numa_node", "pci", "cpu_quota", "quota_share"}.  A rank runs 1 submitting thread + `depth` lane workers,
+    all polling while pairs are in flight.  `cpu_quota` (cgroup) / local_world = `quota_share` is reported, and
+    the cores are cut to it only on request: on a loaded host a rank confined to as many CPUs as it has busy threads was preempted for
+    whole time slices (gaps of 2-5 ms in one 600-pair run of three, none in three with the whole NUMA node to move about in); staying
+    under the quota is a matter of how many threads are busy, not of where they may run."""
     try:
         allowed = sorted(os.sched_getaffinity(0))
     except AttributeError:
         return {"cores": [], "source": "unsupported", "numa_node": None, "pci": None}
     if quota == "auto":
         quota = cpu_quota()
-    out = {"cores": allowed, "source": "unpinned", "numa_node": None, "pci": None, "cpu_quota": quota}
     local_world = max(local_world, 1)
+    share = None if quota is None else quota / local_world
+    out = {"cores": allowed, "source": "unpinned", "numa_node": None, "pci": None, "cpu_quota": quota, "quota_share": share}
+    if not cut_to_quota:
+        quota_cut = None
+    else:
+        quota_cut = quota
     gpus = visible_gpus() if gpus is None else gpus
     if gpus and (share_devices or local_rank < len(gpus)):
         mine = gpus[local_rank % len(gpus)]
@@ -136,17 +145,17 @@ def pin_rank(local_rank: int, local_world: int, share_devices: bool = False, gpu
         k = len(near) // max(len(same), 1)
         if near and k >= 1 and local_rank in same:
             j = same.index(local_rank)
-            cores = _within_quota(near[j * k:(j + 1) * k], local_world, quota)
+            cores = _within_quota(near[j * k:(j + 1) * k], local_world, quota_cut)
             os.sched_setaffinity(0, set(cores))
-            return {"cores": cores, "source": "numa node of the GPU (kfd topology + pci local_cpulist)" + ("" if quota is None else ", cut to the rank's share of the cgroup CPU quota"),
-                    "numa_node": mine["numa_node"], "pci": mine["pci"], "cpu_quota": quota}
+            return {"cores": cores, "source": "numa node of the GPU (kfd topology + pci local_cpulist)" + ("" if quota_cut is None else ", cut to the rank's share of the cgroup CPU quota"),
+                    "numa_node": mine["numa_node"], "pci": mine["pci"], "cpu_quota": quota, "quota_share": share}
     k = len(allowed) // local_world
     if local_world > 1 and k >= 1:
-        cores = _within_quota(allowed[(local_rank % local_world) * k:(local_rank % local_world + 1) * k], local_world, quota)
+        cores = _within_quota(allowed[(local_rank % local_world) * k:(local_rank % local_world + 1) * k], local_world, quota_cut)
         os.sched_setaffinity(0, set(cores))
         out.update(cores=cores, source="index slice of the allowed cores (GPU topology not readable)")
-    elif quota is not None and len(allowed) > max(2, int(quota)):
-        cores = _within_quota(allowed, 1, quota)
+    elif quota_cut is not None and len(allowed) > max(2, int(quota_cut)):
+        cores = _within_quota(allowed, 1, quota_cut)
         os.sched_setaffinity(0, set(cores))
         out.update(cores=cores, source="the first allowed cores, as many as the cgroup CPU quota")
     return out

@@ -159,12 +159,15 @@ def test_ranks_are_pinned_to_the_numa_node_of_their_gpu(tmp_path, monkeypatch):
     assert [p["cores"] for p in pins] == [list(range(8 * r, 8 * r + 8)) for r in range(4)]
     assert multirank.pin_rank(0, 1, gpus=[], quota=None)["source"] == "unpinned"
     # a cgroup CPU quota (container limited to so many CPUs' worth of time): a rank keeps only its share of it -- whole cores first --
-    # so that its busy threads cannot run the container into the throttle; read from cpu.max (v2) or cfs_quota / cfs_period (v1)
+    # (on request: cut_to_quota) so that its busy threads cannot run the container into the throttle; read from cpu.max (v2) or cfs_quota / cfs_period (v1)
     calls.clear()
-    q = multirank.pin_rank(0, 1, gpus=g1, quota=6.0)
+    q = multirank.pin_rank(0, 1, gpus=g1, quota=6.0, cut_to_quota=True)
     assert q["cores"] == smt(16)[:6] and calls == [sorted(smt(16)[:6])] and q["cpu_quota"] == 6.0
-    assert [len(multirank.pin_rank(r, 4, gpus=gpus, quota=10.0)["cores"]) for r in range(4)] == [2, 2, 2, 2]      # 10 // 4, never below two
-    assert len(multirank.pin_rank(0, 1, gpus=[], quota=8.0)["cores"]) == 8
+    assert [len(multirank.pin_rank(r, 4, gpus=gpus, quota=10.0, cut_to_quota=True)["cores"]) for r in range(4)] == [2, 2, 2, 2]      # 10 // 4, never below two
+    assert len(multirank.pin_rank(0, 1, gpus=[], quota=8.0, cut_to_quota=True)["cores"]) == 8
+    # by default the quota is only reported (with the rank's share of it): the rank keeps the cores next to its GPU
+    q = multirank.pin_rank(1, 4, gpus=gpus, quota=10.0)
+    assert len(q["cores"]) == 4 and q["cpu_quota"] == 10.0 and q["quota_share"] == 2.5
     cg = tmp_path / "cg"; cg.mkdir()
     (cg / "cpu.max").write_text("1600000 100000\n")
     assert multirank.cpu_quota(str(cg)) == 16.0
