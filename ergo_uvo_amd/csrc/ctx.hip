@@ -1651,6 +1651,7 @@ extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h
     UVO_TRY(check_cand_overflow(c, 1));
     const int n = c->h_counts[CN_NL];
     out->n_kps = n;
+    c->kp_hint = n;
     c->mono_kps.resize(n);
     if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->mono_kps.data(), c->det[0].kps, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1931,6 +1932,7 @@ extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* o
     const Ctx::BJob& j = L->job;
     if (j.st != UVO_OK) return fail(c, j.st, j.err.c_str());
     *out = j.mres;
+    if (j.mres.n_kps > 0) c->kp_hint = j.mres.n_kps;          // sizes the descriptor launch's small-window grid of the frames to come
     // (uvo_mono_get reads the frame's intermediates from this lane, c->last_lane, until the lane is submitted to again)
     if (j.pose_written) { memcpy(c->mono_R, j.R, sizeof(c->mono_R)); memcpy(c->mono_t, j.t, sizeof(c->mono_t)); }
     if (j.sf_written) c->mono_SF = j.SF;

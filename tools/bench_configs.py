@@ -9,6 +9,8 @@ import json
 import os
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")     # one hardware queue per pipeline stream (see bench.py)
+for _v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):      # no host-sized thread pools under a cgroup CPU quota (see bench.py)
+    os.environ.setdefault(_v, "4")
 import sys
 import time
 
@@ -19,6 +21,8 @@ sys.path.insert(0, ROOT)
 
 
 def main(only=None):
+    from ergo_uvo_amd import multirank
+    multirank.pin_rank(0, 1)                              # the cores next to the GPU, before the runtime's threads exist (as bench.py)
     import torch
     import ergo_uvo_amd as uvo
     from ergo_uvo_amd import synth
