@@ -284,10 +284,15 @@ struct TailArgs {
 };
 // The launch's workgroups have to find room NEXT TO another pair's chip-filling kernels (the detection launch leaves 4 KB of a CU's
 // LDS and most of its registers, the descriptor launch a wave slot and 64 registers per SIMD as its workgroups retire), so they are
-// small on every axis: 256 threads, 3.6 KB of LDS, ~100 registers.  As 1024-thread workgroups with 33 KB the same launch took 61 us in
-// the pipeline against 22 us alone.
+// small where it was measured to matter: 256 threads, ~80 registers.  As 1024-thread workgroups with 33 KB the same launch took 61 us
+// in the pipeline against 22 us alone.
 static const int kTailThreads = 256;
-static const int kTailTri = 8;            // rows triangulated per workgroup: 8 x 448 bytes of LDS for the 4x4 Jacobi SVDs' operands
+// rows triangulated per workgroup (448 bytes of LDS each for the 4x4 Jacobi SVD's operands).  Measured, launch alone / pipeline:
+// 8 rows (3.6 KB, fits beside three detection workgroups): 31.6 us / 4661 pairs/s; 16: 26.0 / 4720; 32: 26.0 / 4731; 64: 23.4 / 4760.
+#ifndef UVO_TAIL_TRI
+#define UVO_TAIL_TRI 64
+#endif
+static const int kTailTri = UVO_TAIL_TRI;
 static const int kEx3Passes = 32;         // extract3d_rows addresses kEx3Passes x kTailThreads = 8192 triangular matches; larger contexts: k_extract3d_b
 // extract_3Dpoints of the stereo loop on ONE small workgroup (round 4).  Thread t owns matches t, t + 256, ..; a match's state between
 // the sweeps is one bit (it passed the reprojection test; it passed +-3 sigma), everything else is re-read: three sweeps in chunks of
@@ -957,7 +962,8 @@ uvo_status pose_stereo_tail(Ctx* a, Ctx* p, int prev, int curr, int slot, const 
     ta.ex = Ex3Lane{ p->d_as_cam1[prev], p->d_as_flag[prev], nullptr, cn + CN_T, a->d_tmp_idx, a->d_good_pts[slot], a->d_good_idx[slot], a->d_opts[slot], a->d_ipts[slot],
                      cn, counts_host, a->d_matches[1], a->det[0].kps, p->d_as_pts4[prev], a->d_pts4, a->d_tmp_row };
     // contexts of up to 8192 keypoints: extract_3Dpoints is workgroup 0 of the same launch; larger ones: its any-size kernel first
-    ta.fused = cap <= kEx3Passes * kTailThreads ? 1 : 0;
+    static const bool split_env = getenv("UVO_TAIL_SPLIT") != nullptr;      // measurement: extract_3Dpoints in its own launch
+    ta.fused = (cap <= kEx3Passes * kTailThreads && !split_env) ? 1 : 0;
     if (ta.fused) { ta.out_pts4 = a->d_pts4; ta.ex.out_pts4 = nullptr; ta.p4_blocks = (rows + kTailThreads - 1) / kTailThreads; }
     else {
         ta.out_pts4 = nullptr; ta.p4_blocks = 0;
