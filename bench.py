@@ -229,8 +229,9 @@ def main():
     pin = {"cores": [], "source": "off"} if args.no_pin else multirank.pin_rank(local_rank, local_world, share_devices=args.share_devices,
                                                                                 cut_to_quota=os.environ.get("UVO_BENCH_PIN") == "quota")
     # a rank whose share of the container's CPU quota cannot carry a polling thread per lane lets its lane workers sleep on a timer
+    # (below four CPUs per rank every wait sleeps on the GPU's interrupt: a handful of busy threads per rank would throttle the container)
     if pin.get("quota_share") is not None and pin["quota_share"] < args.depth + 3:
-        os.environ.setdefault("UVO_WORKER_WAIT", "sleep")
+        os.environ.setdefault("UVO_WORKER_WAIT", "block-all" if pin["quota_share"] < 4 else "sleep")
     my_cores = pin["cores"]
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
