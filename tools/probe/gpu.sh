@@ -68,7 +68,7 @@ step() {
              for us in 20 40; do UVO_PROBE_THIN_US=$us LBL="one wave held +$us us per pair" brun --steps $n; UVO_PROBE_FAT_US=$us LBL="768 LDS-filling blocks +$us us" brun --steps $n; done
              LBL=base brun --steps $n ;;
     stamps)  # the measurement build (make STAMPS=1 BUILD=build_stamps OUT=../lib_ab/libuvo_hip_stamps.so in ergo_uvo_amd/csrc): stamps cost time when compiled in
-             [ -f $PWD/ergo_uvo_amd/lib_ab/libuvo_hip_stamps.so ] || make -C ergo_uvo_amd/csrc -s -j8 STAMPS=1 BUILD=build_stamps OUT=../lib_ab/libuvo_hip_stamps.so || return 1
+             make -C ergo_uvo_amd/csrc -s -j8 STAMPS=1 BUILD=build_stamps OUT=../lib_ab/libuvo_hip_stamps.so || return 1
              UVO_HIP_LIB=$PWD/ergo_uvo_amd/lib_ab/libuvo_hip_stamps.so UVO_HESS_STAMPS=gpurun_out/${TAG}_hess_stamps.csv python tools/prof_stereo.py 8 > /dev/null 2>&1; python tools/probe/hess_stamps.py gpurun_out/${TAG}_hess_stamps.csv
              UVO_HIP_LIB=$PWD/ergo_uvo_amd/lib_ab/libuvo_hip_stamps.so UVO_DESC_STAMPS=gpurun_out/${TAG}_desc_stamps.csv python tools/prof_stereo.py 8 > /dev/null 2>&1; python tools/probe/desc_stamps.py gpurun_out/${TAG}_desc_stamps.csv ;;
     rates)   [ -x tools/probe/issue_rate_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probe/issue_rate_probe.hip -o tools/probe/issue_rate_probe || return 1
