@@ -300,7 +300,8 @@ static const int kEx3Passes = 32;         // extract3d_rows addresses kEx3Passes
 // (extract3d_block, 1024 threads, both compactions staged through memory) makes two per pass.  The first compaction is never
 // materialised: only its count and the statistics of its members are needed, unless the ordered sums have to decide.
 // Same results: the +-3 sigma set is the ordered sums' set by the argument in extract3d_block (any summation order is within the radius).
-struct Ex3RowsSmem { int cnt[kEx3Passes][kTailThreads / 64]; int s_need_seq; double s_mean, s_sd3, s_rad, s_sumsq; double red[3][kTailThreads / 64]; double zbuf[128], zsq[128]; };
+// (16-byte aligned: a pass's four wave counts are read as one int4)
+struct alignas(16) Ex3RowsSmem { int cnt[kEx3Passes][kTailThreads / 64]; int s_need_seq; double s_mean, s_sd3, s_rad, s_sumsq; double red[3][kTailThreads / 64]; double zbuf[128], zsq[128]; };
 __device__ __forceinline__ void extract3d_rows(const Ex3Lane& LN, int min_pts, int force_seq, Ex3RowsSmem& sm)
 {
     constexpr int NT = kTailThreads, NW = NT / 64, R = kEx3Passes, C = 8;
@@ -472,7 +473,7 @@ __device__ __forceinline__ void tail_gather_rows(const TailArgs& a, int first_ro
 }
 // workgroup 0 (when a.fused): extract_3Dpoints; then tri_blocks workgroups of kTriThreads rows to triangulate, p4_blocks that leave
 // triangulatePoints' output in match order for uvo_stereo_get, and the gather of the set
-union TailSmem { Ex3RowsSmem e; double tri[(16 + 16 + 16 + 4 + 4) * kTailTri]; };
+union alignas(16) TailSmem { Ex3RowsSmem e; double tri[(16 + 16 + 16 + 4 + 4) * kTailTri]; };
 __global__ __launch_bounds__(kTailThreads) void k_stereo_tail(Mat34 P1, Mat34 P2, Cam c1, Cam c2, double tol, TailArgs a, int min_pts, int force_seq)
 {
     __shared__ TailSmem sm;
