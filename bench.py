@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group even with one rank, so that --gpus 1 "
                     "runs the N-rank path's collectives (RCCL communicator of one rank)")
     ap.add_argument("--no-pin", action="store_true", help="do not pin the rank to the cores next to its GPU")
+    ap.add_argument("--cpus", type=int, default=0, help="measurement: confine this rank to N logical CPUs (sched_setaffinity before the first GPU "
+                    "call, whole physical cores next to the GPU first) and tell the library that N is its CPU budget")
     ap.add_argument("--blocks", type=int, default=7, help="the timed region (K steps between two fences) is run this many times in a row; "
                     "`value` is the median block, the first / slowest / fastest are reported beside it")
     ap.add_argument("--no-trace", action="store_true", help="do not record the per-pair pipeline trace (for --steps <= 64 one more, untimed-for-value block runs with it)")
@@ -228,10 +230,17 @@ def main():
     # UVO_BENCH_PIN=quota: the rank's cores cut to its share of the cgroup CPU quota (measurement: gaps of 2-5 ms on a loaded host)
     pin = {"cores": [], "source": "off"} if args.no_pin else multirank.pin_rank(local_rank, local_world, share_devices=args.share_devices,
                                                                                 cut_to_quota=os.environ.get("UVO_BENCH_PIN") == "quota")
-    # a rank whose share of the container's CPU quota cannot carry a polling thread per lane lets its lane workers sleep on a timer
-    # (below four CPUs per rank every wait sleeps on the GPU's interrupt: a handful of busy threads per rank would throttle the container)
-    if pin.get("quota_share") is not None and pin["quota_share"] < args.depth + 3:
-        os.environ.setdefault("UVO_WORKER_WAIT", "block-all" if pin["quota_share"] < 4 else "sleep")
+    # The rank's CPU budget = its share of the container's CPU quota (or --cpus): handed to the library (UVO_CPU_BUDGET), which picks
+    # how its host side waits and who drives the PnP stage of pipelined pairs (include/uvo_hip.h: uvo_ctx_host_policy; measured per
+    # budget in profiles/r05_host_budget.json).  With a CPU per lane the lane workers poll; below depth + 3 CPUs the first RANSAC round
+    # runs device-driven and the rank keeps ONE host thread busy -- eight ranks on a 16-CPU quota get 2 CPUs each.
+    if args.cpus > 0:
+        cores = (pin["cores"] or sorted(os.sched_getaffinity(0)))[:args.cpus]
+        os.sched_setaffinity(0, set(cores))
+        pin = dict(pin, cores=cores, source=(pin.get("source") or "") + f", cut to --cpus {args.cpus}")
+        os.environ["UVO_CPU_BUDGET"] = str(args.cpus)
+    elif pin.get("quota_share") is not None:
+        os.environ.setdefault("UVO_CPU_BUDGET", f"{pin['quota_share']:.3f}")
     my_cores = pin["cores"]
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -270,6 +279,7 @@ def main():
     ctx = uvo.Context(params, local_rank, WIDTH, HEIGHT, 8192)
     ctx.stereo_set_depth(args.depth)
     ctx.stereo_set_batch(args.batch)
+    host_policy = ctx.host_policy()
     ctx.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
 
     order = ping_pong(args.frames)
@@ -408,7 +418,10 @@ def main():
     if args.timed_only:
         if rank == 0:
             emit(json.dumps({"value": round(value, 3), "unit": "pairs/s", "steps": args.steps, "warmup": args.warmup, "timed_only": True,
-                             "blocks": n_blocks, "block_values": [round(v, 1) for v in block_values], "collect_gap_ms": collect_gap_ms}))
+                             "blocks": n_blocks, "value_first_block": round(block_values[0], 3), "block_values": [round(v, 1) for v in block_values],
+                             "collect_gap_ms": collect_gap_ms, "busy_host_threads_rank0": round(busy_threads, 2),
+                             "busy_host_threads_all_blocks": [round(v, 2) for v in block_cpu], "host_policy": host_policy,
+                             "cores_of_this_rank": len(my_cores), "valid_steps_all_blocks": [n_valid_all, args.steps * n_blocks]}))
         if dist_on:
             multirank.barrier(); dist.destroy_process_group()
         ctx.close()
@@ -600,9 +613,12 @@ def main():
             "cpu_baseline": cpu,
             "host": {"cores_visible": host_cores_all, "cores_of_this_rank": len(my_cores), "pinned": len(my_cores) < host_cores_all and bool(my_cores),
                      "pin_source": pin.get("source"), "cgroup_cpu_quota": pin.get("cpu_quota"), "cpu_quota_share_of_this_rank": pin.get("quota_share"),
-                     "worker_wait": os.environ.get("UVO_WORKER_WAIT", "auto"), "numa_node": pin.get("numa_node"), "gpu_pci": pin.get("pci"), "pin_matches_opened_device": pin.get("pci_match"),
+                     "worker_wait": os.environ.get("UVO_WORKER_WAIT", "auto"), "stage_b": os.environ.get("UVO_STAGE_B", "auto"), "policy": host_policy,
+                     "cpu_budget_env": os.environ.get("UVO_CPU_BUDGET"), "numa_node": pin.get("numa_node"), "gpu_pci": pin.get("pci"), "pin_matches_opened_device": pin.get("pci_match"),
                      "numa_nodes_of_ranks": who[:, 4].tolist(), "cores_of_ranks": who[:, 5].tolist(), "gc": "frozen and disabled during the timed blocks",
-                     "threads_per_rank": f"1 submitter (polls) + {args.depth} lane workers (timed sleep + poll for stage A's end; <= 3 at a time poll inside the PnP stage)",
+                     "threads_per_rank": ("1 submit / collect thread (polls); the PnP round of a pipelined pair is device-driven, the lane workers sleep"
+                                          if host_policy.get("stage_b") == "device" else
+                                          f"1 submitter (polls) + {args.depth} lane workers ({host_policy.get('wait')} for stage A's end; <= 3 at a time poll inside the PnP stage)"),
                      "busy_host_threads_rank0": round(busy_threads, 2),
                      "collectives": ("none (single process)" if not dist_on else f"{args.backend}: all_gather_into_tensor of the pose records, all_reduce(MAX) of the time, barriers; {world} rank(s)")},
         }

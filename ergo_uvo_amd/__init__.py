@@ -157,6 +157,15 @@ class Context:
         """Advice about the process environment noticed by the library (e.g. GPU_MAX_HW_QUEUES too small for the pipeline depth)."""
         return (self._lib.uvo_ctx_warning(self._h) or b"").decode()
 
+    def host_policy(self) -> dict:
+        """uvo_ctx_host_policy: how the context's host side waits and who drives the PnP stage of pipelined pairs, e.g.
+        {"wait": "poll", "stage_b": "device", "cpu_budget": 2.0, "depth": 6}."""
+        out = {}
+        for kv in (self._lib.uvo_ctx_host_policy(self._h) or b"").decode().split():
+            k, _, v = kv.partition("=")
+            out[k] = float(v) if k == "cpu_budget" else (int(v) if k == "depth" else v)
+        return out
+
     def set_producer_stream(self, stream):
         """Declare the stream that produces device inputs: a raw hipStream_t (int, 0 = the default stream), a torch.cuda.Stream,
         "torch" for torch's current stream at each call, or None to switch the ordering off (inputs must then be complete

@@ -161,8 +161,10 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
     A(dalloc(&c->d_x1, cap)); A(dalloc(&c->d_x2, cap)); A(dalloc(&c->d_xc, cap)); A(dalloc(&c->d_pts4, cap));
     A(dalloc(&c->d_cam1, cap * 3)); A(dalloc(&c->d_flag, cap)); A(dalloc(&c->d_tmp_idx, cap)); A(dalloc(&c->d_tmp_row, cap));
     if (const char* ww = getenv("UVO_WORKER_WAIT")) c->worker_wait = !strcmp(ww, "spin") ? 0 : (!strcmp(ww, "block-all") ? 2 : ((!strcmp(ww, "sleep") || !strcmp(ww, "block")) ? 3 : 1));
+    c->wait_eff.store(c->worker_wait == 0 ? 0 : (c->worker_wait == 2 ? 2 : 1), std::memory_order_relaxed);      // auto: decided by set_depth (apply_wait_policy)
     A(hipEventCreateWithFlags(&c->evBlock, hipEventDisableTiming | hipEventBlockingSync));
     A(hipEventCreateWithFlags(&c->evPoll, hipEventDisableTiming));
+    A(hipEventCreateWithFlags(&c->evB, hipEventDisableTiming | (c->worker_wait == 2 ? hipEventBlockingSync : 0)));
     for (int i = 0; i < 2; i++) {
         A(dalloc(&c->d_good_pts[i], cap * 3)); A(dalloc(&c->d_good_idx[i], cap));
         A(dalloc(&c->d_opts[i], cap * 3)); A(dalloc(&c->d_ipts[i], cap));
@@ -246,6 +248,46 @@ static void write_trace(uvo_ctx* c)
     fclose(f);
 }
 
+// Logical CPUs this process may keep busy: the smallest of its affinity mask, the container's CPU quota (cgroup v2 cpu.max, v1
+// cpu.cfs_quota_us / cpu.cfs_period_us; a process group that runs more busy threads than the quota is throttled -- every thread
+// stopped until the period ends) and UVO_CPU_BUDGET, with which a launcher that knows how many ranks share the quota hands each
+// rank its share (bench.py does).
+static double host_cpu_budget()
+{
+    double b = 1e9;
+    cpu_set_t set; CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) b = CPU_COUNT(&set);
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64]; double per = 0;
+        if (fscanf(f, "%63s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) b = std::min(b, atof(q) / per);
+        fclose(f);
+    } else {
+        double q = -1, per = 0;
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lf", &q) != 1) q = -1; fclose(g); }
+        if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lf", &per) != 1) per = 0; fclose(g); }
+        if (q > 0 && per > 0) b = std::min(b, q / per);
+    }
+    if (const char* e = getenv("UVO_CPU_BUDGET")) { const double v = atof(e); if (v > 0) b = std::min(b, v); }
+    return b;
+}
+// The context's waiting policy for its current depth (uvo_ctx.h: worker_wait, stage_b_mode), stored where the lanes' own threads read
+// it: an atomic per lane -- never the master's lane list, which set_depth rewrites while earlier lanes' workers are running.
+static void apply_wait_policy(uvo_ctx* c)
+{
+    const int depth = (int)c->lanes.size();
+    c->cpu_budget = host_cpu_budget();
+    int eff = c->worker_wait == 0 ? 0 : (c->worker_wait == 2 ? 2 : 1);
+    if (c->worker_wait == 1 && c->cpu_budget >= 2.0 * (depth + 2)) eff = 0;      // (logical CPUs: a core per thread -- two ranks of eight busy threads on eight CPUs each ran a 16-CPU container into its throttle: 343 pairs/s)
+    for (Ctx* l : c->lanes) l->wait_eff.store(eff, std::memory_order_release);
+    if (const char* e = getenv("UVO_STAGE_B")) c->stage_b_mode = !strcmp(e, "device") ? 1 : (!strcmp(e, "worker") ? 0 : -1);
+}
+// does a pipelined pair of this context take the device-driven PnP round (uvo_ctx.h: stage_b_mode)?
+static bool stage_b_on_device(const uvo_ctx* c)
+{
+    if (c->stage_b_mode >= 0) return c->stage_b_mode == 1;
+    return c->cpu_budget < (double)c->lanes.size() + 3.0;                          // no CPU for a worker per lane beside the submitter
+}
+
 static uvo_status set_depth(uvo_ctx* c, int depth)
 {
     if (depth < 1 || depth > Ctx::kMaxDepth) { c->err = "pipeline depth must be 1..16"; return UVO_INVALID_ARG; }
@@ -259,6 +301,7 @@ static uvo_status set_depth(uvo_ctx* c, int depth)
         if (c->trace_on && !l->trace_on && trace_alloc(l) != hipSuccess) { destroy_one(l); c->err = "could not allocate a further pipeline lane"; return UVO_HIP_ERROR; }
         c->lanes.push_back(l);
     }
+    apply_wait_policy(c);
     // the previous pair's "after stereo match" set may live in a lane that no longer exists: restart the sequence
     c->warning.clear();
     {
@@ -386,6 +429,7 @@ static void destroy_one(uvo_ctx* c)
     if (c->evAS) (void)hipEventDestroy(c->evAS);
     if (c->evBlock) (void)hipEventDestroy(c->evBlock);
     if (c->evPoll) (void)hipEventDestroy(c->evPoll);
+    if (c->evB) (void)hipEventDestroy(c->evB);
     if (c->evSync) (void)hipEventDestroy(c->evSync);
     if (c->evProducer) (void)hipEventDestroy(c->evProducer);
     for (auto& r : c->trace) for (int k = 0; k < 6; k++) if (r.ev[k]) (void)hipEventDestroy(r.ev[k]);
@@ -419,6 +463,16 @@ extern "C" uvo_status uvo_ctx_set_producer_stream(uvo_ctx* c, void* hip_stream, 
 }
 extern "C" const char* uvo_ctx_warning(const uvo_ctx* c) { return c ? c->warning.c_str() : ""; }
 extern "C" int uvo_ctx_pending(const uvo_ctx* c) { return c ? c->n_pending : 0; }
+extern "C" const char* uvo_ctx_host_policy(uvo_ctx* c)
+{
+    if (!c) return "";
+    static const char* const wn[3] = { "poll", "timed-sleep+poll", "interrupt" };
+    char buf[160];
+    snprintf(buf, sizeof(buf), "wait=%s stage_b=%s cpu_budget=%.2f depth=%d", wn[c->wait_eff.load() % 3], stage_b_on_device(c) ? "device" : "worker",
+             c->cpu_budget > 1e8 ? -1.0 : c->cpu_budget, (int)c->lanes.size());
+    c->policy_text = buf;
+    return c->policy_text.c_str();
+}
 
 // UVO_MEM_DEVICE inputs: order lane L's next reads after the work queued so far on the declared producer stream
 static uvo_status wait_for_producer(uvo_ctx* m, Ctx* L, int mem)
@@ -454,7 +508,7 @@ hipError_t host_sync(Ctx* c, hipStream_t st)
 {
     // (an event of the lane's own and hipEventQuery -- a load of the signal; hipStreamQuery in a loop cost the 600-step form 6 % and put
     // millisecond gaps back: p99 of the collect gaps 0.95 ms against 0.33)
-    if (c->worker_wait < 2) { const hipError_t e = hipEventRecord(c->evPoll, st); return e == hipSuccess ? poll_event(c->evPoll) : e; }
+    if (c->wait_eff.load(std::memory_order_acquire) != 2) { const hipError_t e = hipEventRecord(c->evPoll, st); return e == hipSuccess ? poll_event(c->evPoll) : e; }     // every mode but block-all
     hipError_t e = hipEventRecord(c->evBlock, st);
     return e == hipSuccess ? hipEventSynchronize(c->evBlock) : e;
 }
@@ -1148,19 +1202,27 @@ static uvo_status queue_stage_a(uvo_ctx* c, uvo_ctx* A, uvo_ctx* B)
     if (B) UVO_HIP_TRY(c, hipEventRecord(B->evA[1], st));
     if (trA) UVO_HIP_TRY(c, hipEventRecord(trA->ev[2], st));
     if (trB) UVO_HIP_TRY(c, hipEventRecord(trB->ev[2], st));
-    // the first RANSAC round, speculatively, on this stream (pose.hip): the worker wakes once, when the pose is there
-    // Taken by the synchronous step only (one pair in flight: 0.80 -> 0.77 ms per pair at C3).  With several pairs in flight the
-    // same kernels queued behind a lane's stage A cost the pipeline a quarter of its rate (4370 -> 3200 pairs/s; 4130 on the
-    // lane's PnP stream behind a stream wait), so pipelined pairs keep the worker-driven stage.  UVO_PNP_SPEC: 0 never,
-    // 1 (default) synchronous steps, 3 / 2 every pair on the lane's stream / its PnP stream (measurement only).
+    // The first RANSAC round without the host (pose.hip: k_pnp_*_spec), in two places:
+    //  * the synchronous step (one pair in flight) queues it on this stream, right behind extract_3Dpoints, and the calling thread
+    //    confirms it (0.80 -> 0.77 ms per pair at C3);
+    //  * a pipelined pair in DEVICE-DRIVEN mode (uvo_ctx.h: stage_b_mode) queues it on the lane's PnP stream behind stage A's event:
+    //    nobody is handed the pair, uvo_stereo_collect confirms the round (or redoes the stage itself).  Queued on the lane's
+    //    stage-A stream instead, the same kernels cost the pipeline a quarter of its rate (round 3: 4370 -> 3200 pairs/s).
+    // UVO_PNP_SPEC=0 switches the round off (the host-driven stage then runs on the calling / collecting thread).
     static const int spec_env = getenv("UVO_PNP_SPEC") ? atoi(getenv("UVO_PNP_SPEC")) : 1;
-    A->spec_queued = !B && (spec_env >= 2 || (spec_env == 1 && A->inline_b)) && !c->timing && p.ITERATIONS_COUNT >= 1;
+    const bool dev_b = !B && !A->inline_b && !c->timing && stage_b_on_device(c);
+    A->dev_b = dev_b;
+    if (B) B->dev_b = false;
+    A->spec_queued = !B && spec_env != 0 && (A->inline_b || dev_b) && !c->timing && p.ITERATIONS_COUNT >= 1;
     if (B) B->spec_queued = false;
     hipStream_t sb = st;
-    if (A->spec_queued && spec_env == 2) { sb = A->pnp_stream; UVO_HIP_TRY(c, hipStreamWaitEvent(sb, A->evA[1], 0)); }
+    if (dev_b) { sb = A->pnp_stream; UVO_HIP_TRY(c, hipStreamWaitEvent(sb, A->evA[1], 0)); }
     if (A->spec_queued) LANE_TRY(pose_pnp_spec_launch(A, sb, c->K_left, p.ITERATIONS_COUNT, (float)p.REPROJECTION_ERROR_THRESHOLD, p.CONFIDENCE, p.MIN_NUM_3DPOINTS));
-    UVO_HIP_TRY(c, hipEventRecord(A->evA[0], sb));                                          // what the lane's worker waits for
-    if (B) UVO_HIP_TRY(c, hipEventRecord(B->evA[0], sb));
+    if (dev_b) UVO_HIP_TRY(c, hipEventRecord(A->evB, sb));                                  // what uvo_stereo_collect waits for
+    else {
+        UVO_HIP_TRY(c, hipEventRecord(A->evA[0], sb));                                      // what the lane's worker waits for
+        if (B) UVO_HIP_TRY(c, hipEventRecord(B->evA[0], sb));
+    }
     if (trA) trA->host_us[2] = uvo::now_us();
     if (trB) trB->host_us[2] = uvo::now_us();
     uvo_ctx* both[2] = { A, B };
@@ -1171,6 +1233,8 @@ static uvo_status queue_stage_a(uvo_ctx* c, uvo_ctx* A, uvo_ctx* B)
             // (no worker wake-up, no condition variable: two thread hand-overs less on the pair's critical path)
             UVO_HIP_TRY(c, hipEventRecord(L->evSync, sb));
             L->job.kind = 0;
+        } else if (L->dev_b) {
+            L->job.kind = 0;                                   // nobody is woken: the round is on the device, collect finishes the pair
         } else {   // hand stage B to the lane's worker
             L->t_handover_us = uvo::now_us();
             { std::lock_guard<std::mutex> lk(L->mu); L->job.kind = 0; L->job.state = 1; L->job_state_a.store(1, std::memory_order_release); }
@@ -1209,15 +1273,8 @@ static void run_stage_b(uvo_ctx* L, bool stage_a_ok)
         else { j.wrote = r.wrote; j.ok = r.ok; j.ninl = r.ninl; memcpy(j.rvec, r.rvec, sizeof(j.rvec)); memcpy(j.tvec, r.tvec, sizeof(j.tvec)); }
     }
 }
-// Does this context's pipeline poll rather than sleep (uvo_ctx.h: worker_wait)?  auto: when the process may use a CPU per worker.
-static bool pipeline_polls(const Ctx* L)
-{
-    const Ctx* m = L->master ? L->master : L;
-    if (L->worker_wait == 0) return true;
-    if (L->worker_wait != 1) return false;
-    static const int ncpu = [] { cpu_set_t set; CPU_ZERO(&set); return sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 0; }();
-    return ncpu >= 2 * ((int)m->lanes.size() + 2);        // (logical CPUs: a core per thread -- two ranks of eight busy threads on eight CPUs each ran a 16-CPU container into its throttle: 343 pairs/s)
-}
+// Does this lane's pipeline poll rather than sleep (uvo_ctx.h: worker_wait; decided per depth by apply_wait_policy)?
+static bool pipeline_polls(const Ctx* L) { return L->wait_eff.load(std::memory_order_acquire) == 0; }
 // A thread about to sleep on a lane's condition variable for job.state == want first polls the state's atomic twin for up to `spin_us`:
 // in a running pipeline the hand-overs (submitter -> worker, worker -> collect) come within a few hundred microseconds, and a
 // thread asleep on a futex was seen to be woken milliseconds late on a loaded host (the last of round 4's stalls: 4 ms holes with
@@ -1234,10 +1291,10 @@ static void poll_job_state(uvo_ctx* L, int want, double spin_us)
 // The lane worker's long wait, for the end of its pair's stage A (uvo_ctx.h: worker_wait).
 static bool wait_stage_a(uvo_ctx* L)
 {
-    if (L->worker_wait == 2) return hipEventSynchronize(L->evA[0]) == hipSuccess;       // sleeps on the interrupt (hipEventBlockingSync)
-    Ctx* m = L->master ? L->master : L;
-    if (pipeline_polls(L)) return uvo::poll_event(L->evA[0]) == hipSuccess;     // spin, or auto with a CPU per worker (+ submitter + one spare)
-    const double t0 = L->t_handover_us, mean = m->stage_a_mean_us.load(std::memory_order_relaxed);
+    const int eff = L->wait_eff.load(std::memory_order_acquire);
+    if (eff == 2) return hipEventSynchronize(L->evA[0]) == hipSuccess;       // sleeps on the interrupt (hipEventBlockingSync)
+    if (eff == 0) return uvo::poll_event(L->evA[0]) == hipSuccess;           // spin, or auto with a CPU per worker (+ submitter + one spare)
+    const double t0 = L->t_handover_us, mean = L->stage_a_mean_us;
     for (;;) {
         const hipError_t e = hipEventQuery(L->evA[0]);
         if (e == hipSuccess) break;
@@ -1248,7 +1305,7 @@ static bool wait_stage_a(uvo_ctx* L)
     }
     if (t0 > 0) {
         const double d = now_us() - t0;
-        m->stage_a_mean_us.store(mean == 0.0 ? d : mean + 0.125 * (d - mean), std::memory_order_relaxed);
+        L->stage_a_mean_us = mean == 0.0 ? d : mean + 0.125 * (d - mean);      // the lane worker's own figure: no other thread touches it
     }
     return true;
 }
@@ -1321,6 +1378,16 @@ extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_resul
     if (L->inline_b) {
         L->inline_b = false;
         run_stage_b(L, uvo::poll_event(L->evSync) == hipSuccess);
+    } else if (L->dev_b) {
+        // device-driven pair: wait for its round on the lane's PnP stream (polling; on the interrupt in block-all mode), confirm it
+        // with the host's own scan, or run the host-driven stage here when the round could not decide the pair
+        L->dev_b = false;
+        Ctx::TraceRec* wtr = (L->trace_on && L->plan.trace_slot >= 0) ? &L->trace[L->plan.trace_slot] : nullptr;
+        if (wtr) wtr->host_us[3] = uvo::now_us();
+        const bool ok = (L->wait_eff.load(std::memory_order_acquire) == 2 ? hipEventSynchronize(L->evB) : uvo::poll_event(L->evB)) == hipSuccess;
+        if (wtr) wtr->host_us[4] = uvo::now_us();
+        run_stage_b(L, ok);
+        if (wtr) wtr->host_us[5] = uvo::now_us();
     } else {
         poll_job_state(L, 2, 5000.0);
         std::unique_lock<std::mutex> lk(L->mu);

@@ -60,7 +60,7 @@ struct Ctx {
     uvo_params p;
     int device = 0, max_w = 0, max_h = 0, cap = 0;
     hipStream_t stream = nullptr;
-    std::string err, warning;
+    std::string err, warning, policy_text;
     hipStream_t producer_stream = nullptr; bool has_producer = false;   // master: uvo_ctx_set_producer_stream
     hipEvent_t evProducer = nullptr;             // this lane's marker on the producer stream
 
@@ -153,18 +153,38 @@ struct Ctx {
                                                  // blocks on (hipEventSynchronize), [1] its twin for other lanes' hipStreamWaitEvent -- the runtime holds
                                                  // an event's lock while a host thread waits on it, so a stream wait on the SAME event blocked the
                                                  // submitting thread until the event completed (133 us per pair at C3)
-    // How the lane's worker thread waits for the end of its pair's stage A (env UVO_WORKER_WAIT = spin | sleep | block-all):
-    //   1 auto (default) -- poll (hipEventQuery + pause) when the process may run on at least 2 (depth + 2) logical CPUs, else `sleep`
-    //   0 spin      -- always poll: one busy host thread per waiting worker, up to `depth` per context
-    //   3 sleep     -- sleep ON A TIMER through the first four fifths of a running mean of the stage's length, then poll.  Keeps a rank
-    //                  at one spinning submitter + at most max_b polling workers; on a loaded host a timer sleep was seen to overrun
-    //                  by 8-10 ms about once in 3000 pairs (pipeline_trace: dev_a_end_to_pnp_begin_ms 8.4 ms)
+    // How the host waits inside a running pipeline (env UVO_WORKER_WAIT = spin | sleep | block-all; default auto):
+    //   1 auto (default) -- `spin` when the process's CPU budget (affinity mask, cgroup quota, UVO_CPU_BUDGET) carries a polling
+    //                  thread per lane (>= 2 (depth + 2) logical CPUs), else `sleep`
+    //   0 spin      -- always poll (hipEventQuery + pause): one busy host thread per waiting worker, up to `depth` per context
+    //   3 sleep     -- the worker's long wait, for the end of its pair's stage A, sleeps ON A TIMER through the first four fifths of a
+    //                  running mean of the stage's length, then polls.  Keeps a rank at one spinning submitter + at most max_b polling
+    //                  workers; on a loaded host a timer sleep was seen to overrun by 8-10 ms about once in 3000 pairs
     //   2 block-all -- every wait, the PnP stage's two short ones included, sleeps on the GPU's interrupt (hipEventBlockingSync,
     //                  evBlock): for hosts with fewer cores than threads.  Until round 4 the stage-A wait did this by default, and about
     //                  one such wait in a hundred woke 3-4 ms late -- the stall behind round 3's 1990 pairs/s driver record
-    // Inside the PnP stage the two short syncs poll in every mode but block-all.
+    // Inside the PnP stage the two short syncs (host_sync) poll in every mode but block-all.
+    // Which thread runs the PnP stage of a pipelined pair is a separate choice: stage_b_mode below.
     int worker_wait = 1;
-    std::atomic<double> stage_a_mean_us{0.0};    // master: hand-over -> end of stage A, running mean (lane workers' timed sleep)
+    // What the lane's threads read instead of walking the master's lane list (which set_depth rewrites while workers run): how this
+    // lane's waits behave -- 0 poll, 1 timed sleep + poll, 2 sleep on the interrupt.  Stored by create_one / set_depth.
+    std::atomic<int> wait_eff{1};
+    // Who drives the PnP stage of a PIPELINED pair (env UVO_STAGE_B = worker | device; default auto):
+    //   0 worker -- the lane's worker thread wakes at the end of stage A, draws the subsets, launches hypotheses + scoring, waits, replays
+    //               the scan, launches mask + refit, waits (two host round trips; `depth` workers + the submitter = 7-9 busy host
+    //               threads per GPU at depth 6 when they poll)
+    //   1 device -- the first RANSAC round (k_pnp_*_spec, pose.hip) is queued on the lane's PnP stream behind stage A's event at submit
+    //               time; nobody is handed the pair.  uvo_stereo_collect waits for the round's event, replays the scan over the counts
+    //               in pinned memory with the host's libm (pose_pnp_spec_accept) and takes the device's pose when it arrives at the
+    //               same winner; otherwise -- the scan needs more than the round's 64 hypotheses, too few inliers for the parallel
+    //               refit, exactly five points -- the COLLECTING thread runs the host-driven stage.  Results are those of the worker
+    //               path by construction; a rank then keeps ONE host thread busy (submit / collect), whatever the depth.
+    //   auto     -- device when the CPU budget cannot carry a polling thread per lane, else worker
+    int stage_b_mode = -1;                       // master: -1 auto, 0 worker, 1 device
+    bool dev_b = false;                          // lane: this lane's pair was queued device-driven (uvo_stereo_collect finishes it)
+    hipEvent_t evB = nullptr;                    // lane: the device-driven round of this lane's pair has finished (on pnp_stream)
+    double cpu_budget = 0;                       // master: logical CPUs this process may keep busy (host_cpu_budget(), ctx.hip)
+    double stage_a_mean_us = 0;                  // lane (its worker's own): hand-over -> end of stage A, running mean (the timed sleep)
     double t_handover_us = 0;                    // lane: when the pair's stage A was handed to the worker
     std::atomic<int> job_state_a{0};             // lane: job.state again, for the threads that poll for it before they sleep on cv (ctx.hip: wait_job_state)
     hipEvent_t evBlock = nullptr;                // hipEventBlockingSync marker for host_sync()

@@ -71,7 +71,7 @@ def visible_gpus(sys_root: str = "/sys", dev_root: str = "/dev", env=None) -> li
         except (OSError, ValueError):
             pass
         gpus.append(g)
-    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES" if env.get("HIP_VISIBLE_DEVICES") not in (None, "") else "CUDA_VISIBLE_DEVICES"):     # HIP honours one of the two, HIP_VISIBLE_DEVICES first
         v = env.get(var)
         if v is None or v == "":
             continue

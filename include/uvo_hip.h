@@ -85,6 +85,13 @@ const char* uvo_ctx_warning(const uvo_ctx* c);
 /* Entries submitted (uvo_stereo_submit / uvo_mono_submit, init pairs included) and not yet collected.  A collect that fails
  * with "nothing submitted" or "wrong kind" leaves it unchanged; every other collect, successful or not, dequeues one. */
 int         uvo_ctx_pending(const uvo_ctx* c);
+/* How this context's host side waits and who drives the PnP stage of pipelined pairs at its current depth, as text:
+ * "wait=poll|timed-sleep+poll|interrupt stage_b=worker|device cpu_budget=<logical CPUs, -1 unlimited> depth=<lanes>".  Decided from
+ * the process's affinity mask, the cgroup CPU quota and the environment (UVO_CPU_BUDGET = this process's share of the quota,
+ * UVO_WORKER_WAIT = spin | sleep | block-all, UVO_STAGE_B = worker | device): with a CPU per lane the lanes' worker threads poll and
+ * run the PnP stage; below that the first RANSAC round runs device-driven and uvo_stereo_collect confirms it, so that a rank keeps
+ * one host thread busy.  Results do not depend on the choice.  Valid until the next call. */
+const char* uvo_ctx_host_policy(uvo_ctx* c);
 
 /* The reference's global FEATURE_DETECTOR (VO_utility.h:25, /vo_params/feature_detector) for the fused steps: "SURF" (default) or
  * "SIFT" -- uvo_stereo_step / submit and uvo_mono_step / submit then take detect_features' SIFT branch (VO_utility.cpp:107-112,

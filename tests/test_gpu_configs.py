@@ -293,6 +293,20 @@ def test_c5_five_ranks_on_one_device_match_single_gpu_streams(tmp_path):
     assert sum(line["host"]["cores_of_ranks"]) <= line["host"]["cores_visible"]         # the five ranks split the card's NUMA node
 
 
+@pytest.mark.parametrize("stream", range(8))
+def test_c5_every_stream_against_the_oracle(oracle, stream):
+    """BASELINE configs[4] under the ORACLE (the self-launched-ranks tests above compare gathered records with a synchronous HIP run of
+    the same stream -- plumbing; this one is the parity check): each of the eight streams (seeds 20250910 + stream), the
+    init pair and four more, synchronously and with six pairs in flight, every intermediate of every pair against oracle.StereoVO bit
+    for bit (keypoints, descriptors, both match lists, points4d, good_idx / good_pts, inlier sets; poses to 1e-4).  One device, one
+    stream after the other, as rank r of the 8-GPU run would see stream r (visual_odometry.h:723-733: nothing is shared between streams)."""
+    from ergo_uvo_amd import synth, multirank
+    import bench
+    want = _run_stereo_config(oracle, multirank.stream_seed(synth.SEEDS["C5"], stream), bench.WIDTH, bench.HEIGHT, bench.MIN_HESSIAN_C3,
+                              [0, 1, 2, 1, 0], cap=8192, depth=6, min_kpts=2000)
+    assert all(o.n_inliers >= 100 for o, _ in want[1:])
+
+
 def test_submit_blocks_for_at_most_a_detector_stage():
     """uvo_stereo_submit paces the pipeline on the calling thread: before it queues a pair's kernels it waits (polling) for the end
     of the stage A submitted two pairs earlier, so a "submit" may hold its caller for up to about one

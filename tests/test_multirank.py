@@ -130,6 +130,10 @@ def test_ranks_are_pinned_to_the_numa_node_of_their_gpu(tmp_path, monkeypatch):
     assert [g["numa_node"] for g in gpus] == [0, 0, 0, 0, 1, 1, 1, 1]
     # HIP_VISIBLE_DEVICES reorders / filters; a container that was handed one card sees only that one
     assert [g["numa_node"] for g in multirank.visible_gpus(str(tmp_path / "sys"), str(tmp_path / "dev"), env={"HIP_VISIBLE_DEVICES": "5,1"})] == [1, 0]
+    # both spellings set (launchers export the pair): HIP honours HIP_VISIBLE_DEVICES alone -- the list is not filtered twice
+    assert [g["numa_node"] for g in multirank.visible_gpus(str(tmp_path / "sys"), str(tmp_path / "dev"), env={"HIP_VISIBLE_DEVICES": "2,3", "CUDA_VISIBLE_DEVICES": "2,3"})] == \
+           [g["numa_node"] for g in multirank.visible_gpus(str(tmp_path / "sys"), str(tmp_path / "dev"), env={"HIP_VISIBLE_DEVICES": "2,3"})]
+    assert len(multirank.visible_gpus(str(tmp_path / "sys"), str(tmp_path / "dev"), env={"CUDA_VISIBLE_DEVICES": "2,3"})) == 2
     assert multirank.visible_gpus(str(tmp_path / "sys"), str(tmp_path / "dev"), env={"ROCR_VISIBLE_DEVICES": "GPU-abc"}) == []
     one = tmp_path / "one"
     _fake_topology(one, hidden=(0, 1, 2, 3, 4, 6, 7))
