@@ -512,7 +512,10 @@ class Context:
     def select_estimation_method(self, pts1, pts2, distance=None) -> bool:
         p1, p2 = _np(pts1, np.float32), _np(pts2, np.float32)
         d = int(self.params.DISTANCE if distance is None else distance)
-        return bool(self._lib.uvo_select_estimation_method(_p(p1), _p(p2), len(p1), d))
+        r = self._lib.uvo_select_estimation_method(_p(p1), _p(p2), len(p1), d)
+        if r < 0:
+            raise MemoryError("uvo_select_estimation_method: no host memory for the median's scratch")
+        return bool(r)
 
     def estimate_relative_pose(self, pts1, pts2, K, use_essential=True, R0=None, t0=None):
         p1, p2, K = _np(pts1, np.float32), _np(pts2, np.float32), _np(K, np.float64)

@@ -17,6 +17,29 @@ using namespace uvo;
 
 struct uvo_ctx : public uvo::Ctx {};
 
+// Nothing leaves the C ABI as a C++ exception ("never throws across the ABI"; the reference's callers, VO_utility.h:96-117,
+// expect a status, and an exception through a C frame is undefined behaviour).  The host side allocates (std::vector staging buffers,
+// std::string messages, std::deque / std::thread at context creation): every extern "C" body is a function-try-block whose handler
+// lands here, and the lane workers catch around their job (lane_worker) -- std::bad_alloc becomes UVO_CAPACITY, anything else
+// UVO_HIP_ERROR, with uvo_last_error set when a context is at hand.
+namespace {
+uvo_status abi_caught(uvo_ctx* c) noexcept
+{
+    uvo_status st = UVO_HIP_ERROR;
+    const char* what = "unexpected C++ exception inside libuvo_hip";
+    static thread_local char text[160];
+    try { throw; }
+    catch (const std::bad_alloc&) { st = UVO_CAPACITY; what = "out of host memory (std::bad_alloc) inside libuvo_hip"; }
+    catch (const std::exception& e) { snprintf(text, sizeof(text), "C++ exception inside libuvo_hip: %s", e.what()); what = text; }
+    catch (...) {}
+    if (c) { try { c->err.assign(what); } catch (...) { c->err.clear(); } }     // (create_one reserves the message's room)
+    return st;
+}
+}  // namespace
+#define UVO_ABI_CATCH(c) catch (...) { return abi_caught(c); }
+#define UVO_ABI_CATCH_RET(c, v) catch (...) { (void)abi_caught(c); return v; }
+#define UVO_ABI_CATCH_VOID(c) catch (...) { (void)abi_caught(c); }
+
 // Every pipeline lane owns two HIP streams; with ROCm's default of four hardware queues the lanes share queues and one lane's
 // detection waits behind another lane's PnP kernels (2010 pairs/s instead of 2830 at depth 6).  The
 // variable is read when the HIP runtime initialises, so it is set when this library is loaded -- before main() when the node
@@ -218,7 +241,8 @@ static uvo_status create_one(const uvo_params* p, int device, int max_w, int max
         hipMemset(c->d_rank, 0, sizeof(int) * cap * 2) != hipSuccess ||
         hipMemset(c->d_counts, 0, sizeof(int) * CN_TOTAL) != hipSuccess) { destroy_one(c); return UVO_HIP_ERROR; }
     if (getenv("UVO_TRACE") && trace_alloc(c) != hipSuccess) { destroy_one(c); return UVO_HIP_ERROR; }
-    c->worker = std::thread(lane_worker, c);
+    try { c->err.reserve(256); c->worker = std::thread(lane_worker, c); }
+    catch (...) { destroy_one(c); return UVO_HIP_ERROR; }
     *out = c;
     return UVO_OK;
 }
@@ -342,7 +366,7 @@ static void precreate_streams(int device)
 }
 
 extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w, int max_h, int max_kpts, uvo_ctx** out)
-{
+try {
     precreate_streams(device);
     uvo_status st = create_one(p, device, max_w, max_h, max_kpts, out);
     if (st != UVO_OK) return st;
@@ -356,26 +380,26 @@ extern "C" uvo_status uvo_ctx_create(const uvo_params* p, int device, int max_w,
     st = set_depth(*out, 2);                      // two pairs in flight by default (uvo_stereo_set_depth changes it)
     if (st != UVO_OK) { uvo_ctx_destroy(*out); *out = nullptr; }
     return st;
-}
+} UVO_ABI_CATCH(nullptr)
 
 extern "C" uvo_status uvo_stereo_set_batch(uvo_ctx* c, int pairs)
-{
+try {
     if (!c) return UVO_INVALID_ARG;
     if (pairs != 1 && pairs != 2) { c->err = "uvo_stereo_set_batch: 1 or 2 pairs per launch set"; return UVO_INVALID_ARG; }
     if (c->n_pending != 0) { c->err = "the launch mode cannot change while pairs are in flight"; return UVO_INVALID_ARG; }
     c->batch = pairs;
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_stereo_set_depth(uvo_ctx* c, int depth)
-{
+try {
     if (!c) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     return set_depth(c, depth);
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" void uvo_ctx_destroy(uvo_ctx* c)
-{
+try {
     if (!c) return;
     if (uvo::g_bdbg && uvo::g_bstat[4].load() > 0) {
         const double n = uvo::g_bstat[4].load();
@@ -390,7 +414,7 @@ extern "C" void uvo_ctx_destroy(uvo_ctx* c)
     for (size_t i = c->lanes.size(); i > 1; i--) destroy_one(static_cast<uvo_ctx*>(c->lanes[i - 1]));
     c->lanes.clear();
     destroy_one(c);
-}
+} UVO_ABI_CATCH_VOID(c)
 
 static void destroy_one(uvo_ctx* c)
 {
@@ -444,7 +468,7 @@ static void destroy_one(uvo_ctx* c)
 extern "C" const char* uvo_last_error(const uvo_ctx* c) { return c ? c->err.c_str() : "null context"; }
 extern "C" void* uvo_ctx_stream(uvo_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" uvo_status uvo_ctx_set_params(uvo_ctx* c, const uvo_params* p)
-{
+try {
     if (!c || !p) return UVO_INVALID_ARG;
     if (c->n_pending != 0) { c->err = "parameters cannot change while pairs are in flight"; return UVO_INVALID_ARG; }
     if (const char* why = unsupported_params(p)) { c->err = why; return UVO_INVALID_ARG; }
@@ -454,17 +478,17 @@ extern "C" uvo_status uvo_ctx_set_params(uvo_ctx* c, const uvo_params* p)
     }
     for (Ctx* l : c->lanes) l->p = *p;
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 extern "C" uvo_status uvo_ctx_set_producer_stream(uvo_ctx* c, void* hip_stream, int enabled)
-{
+try {
     if (!c) return UVO_INVALID_ARG;
     c->producer_stream = static_cast<hipStream_t>(hip_stream); c->has_producer = enabled != 0;
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 extern "C" const char* uvo_ctx_warning(const uvo_ctx* c) { return c ? c->warning.c_str() : ""; }
 extern "C" int uvo_ctx_pending(const uvo_ctx* c) { return c ? c->n_pending : 0; }
 extern "C" const char* uvo_ctx_host_policy(uvo_ctx* c)
-{
+try {
     if (!c) return "";
     static const char* const wn[3] = { "poll", "timed-sleep+poll", "interrupt" };
     char buf[160];
@@ -472,7 +496,7 @@ extern "C" const char* uvo_ctx_host_policy(uvo_ctx* c)
              c->cpu_budget > 1e8 ? -1.0 : c->cpu_budget, (int)c->lanes.size());
     c->policy_text = buf;
     return c->policy_text.c_str();
-}
+} UVO_ABI_CATCH_RET(c, "")
 
 // UVO_MEM_DEVICE inputs: order lane L's next reads after the work queued so far on the declared producer stream
 static uvo_status wait_for_producer(uvo_ctx* m, Ctx* L, int mem)
@@ -539,7 +563,7 @@ static uvo_status detect_dispatch(Ctx* c, int nimg, int gate_min_features = -1)
 }
 
 extern "C" uvo_status uvo_ctx_set_feature_detector(uvo_ctx* c, const char* name)
-{
+try {
     if (!c || !name) return UVO_INVALID_ARG;
     const bool sift = strcmp(name, "SIFT") == 0;
     if (!sift && strcmp(name, "SURF") != 0) return fail(c, UVO_INVALID_ARG, "uvo_ctx_set_feature_detector: \"SURF\" or \"SIFT\" (the AKAZE / ORB detectors are not built)");
@@ -552,11 +576,11 @@ extern "C" uvo_status uvo_ctx_set_feature_detector(uvo_ctx* c, const char* name)
     }
     c->feature_sift = sift ? 1 : 0;
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_surf_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem,
                                       uvo_keypoint* kps, float* desc, int cap, int* n)
-{
+try {
     if (!c || !n) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_surf_detect"));
@@ -573,28 +597,28 @@ extern "C" uvo_status uvo_surf_detect(uvo_ctx* c, const uint8_t* gray, int w, in
     if (desc && cnt) UVO_HIP_TRY(c, hipMemcpyAsync(desc, c->det[0].desc, sizeof(float) * dsize * cnt, hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_sift_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int nfeatures, int n_octave_layers,
                                       double contrast_threshold, double edge_threshold, double sigma, uvo_keypoint* kps, float* desc, int cap, int* n)
-{
+try {
     if (!c || !n || !gray) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_sift_detect"));
     UVO_TRY(wait_for_producer(c, c, mem));
     return sift_detect(c, gray, w, h, stride, mem, nfeatures, n_octave_layers, contrast_threshold, edge_threshold, sigma, kps, desc, cap, n);
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_sift_layer(uvo_ctx* c, int octave, int layer, int dog, float* out, int cap_floats, int* w, int* h)
-{
+try {
     if (!c || !w || !h) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_sift_layer"));
     return sift_layer(c, octave, layer, dog, out, cap_floats, w, h);
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_integral(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int32_t* sum)
-{
+try {
     if (!c || !sum) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_integral"));
@@ -604,14 +628,14 @@ extern "C" uvo_status uvo_integral(uvo_ctx* c, const uint8_t* gray, int w, int h
     UVO_HIP_TRY(c, hipMemcpyAsync(sum, c->d_sum[0], sizeof(int32_t) * (size_t)(w + 1) * (h + 1), hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_hessian_layer(uvo_ctx* c, int octave, int layer, float* det, float* trace)
-{
+try {
     if (!c || !det || !trace) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     return surf_hessian_layer_debug(c, octave, layer, det, trace);
-}
+} UVO_ABI_CATCH(c)
 
 // ------------------------------------------------------------------------------------------ matching
 static uvo_status stage_desc(uvo_ctx* c, int slot, const float* d, int n, int mem, const float** out)
@@ -629,7 +653,7 @@ static uvo_status stage_desc(uvo_ctx* c, int slot, const float* d, int n, int me
 namespace { struct DimScope { uvo_ctx* c; int prev; DimScope(uvo_ctx* c_, int d) : c(c_), prev(c_->match_dim) { if (!prev) c->match_dim = d; } ~DimScope() { c->match_dim = prev; } };
             int surf_dim(const uvo_ctx* c) { return c->p.SURF_EXTENDED ? 128 : 64; } }
 extern "C" uvo_status uvo_match_knn2(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int mem, int* idx, float* dist)
-{
+try {
     if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !idx || !dist) return UVO_INVALID_ARG;
     DimScope surf_rows(c, surf_dim(c));
     (void)hipSetDevice(c->device);
@@ -645,11 +669,11 @@ extern "C" uvo_status uvo_match_knn2(uvo_ctx* c, const float* d1, int n1, const 
     UVO_HIP_TRY(c, hipMemcpyAsync(dist, c->d_knn_dist, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_match_knn2_ratio(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int mem,
                                            float ratio, uvo_dmatch* out, int cap, int* m)
-{
+try {
     if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !out || !m || *m < 0) return UVO_INVALID_ARG;
     DimScope surf_rows(c, surf_dim(c));
     (void)hipSetDevice(c->device);
@@ -668,25 +692,25 @@ extern "C" uvo_status uvo_match_knn2_ratio(uvo_ctx* c, const float* d1, int n1, 
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     *m += cnt;                                       // appended, as VOU:538
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 // match_features' L2 arm for descriptors that are not this context's SURF rows (VO_utility.cpp:525-529 sends "SIFT" -- 128 floats
 // per row whatever SURF_EXTENDED says -- to the same BFMatcher(NORM_L2)): the row width is given per call.
 extern "C" uvo_status uvo_match_knn2_dim(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int dim, int mem, int* idx, float* dist)
-{
+try {
     if (!c) return UVO_INVALID_ARG;
     if (dim != 64 && dim != 128) return fail(c, UVO_INVALID_ARG, "uvo_match_knn2_dim: rows of 64 or 128 floats");
     DimScope ds(c, dim);
     return uvo_match_knn2(c, d1, n1, d2, n2, mem, idx, dist);
-}
+} UVO_ABI_CATCH(c)
 extern "C" uvo_status uvo_match_knn2_ratio_dim(uvo_ctx* c, const float* d1, int n1, const float* d2, int n2, int dim, int mem,
                                                float ratio, uvo_dmatch* out, int cap, int* m)
-{
+try {
     if (!c) return UVO_INVALID_ARG;
     if (dim != 64 && dim != 128) return fail(c, UVO_INVALID_ARG, "uvo_match_knn2_ratio_dim: rows of 64 or 128 floats");
     DimScope ds(c, dim);
     return uvo_match_knn2_ratio(c, d1, n1, d2, n2, mem, ratio, out, cap, m);
-}
+} UVO_ABI_CATCH(c)
 
 // The AKAZE / ORB branch of match_features (VO_utility.cpp:520-524): binary descriptors, Hamming distance
 static uvo_status stage_bytes(uvo_ctx* c, int slot, const uint8_t* d, int n, int bytes, int mem, const uint8_t** out)
@@ -699,7 +723,7 @@ static uvo_status stage_bytes(uvo_ctx* c, int slot, const uint8_t* d, int n, int
     return UVO_OK;
 }
 extern "C" uvo_status uvo_match_knn2_hamming(uvo_ctx* c, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, int mem, int* idx, float* dist)
-{
+try {
     if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !idx || !dist) return UVO_INVALID_ARG;
     if (bytes < 1 || bytes > 64) return fail(c, UVO_INVALID_ARG, "uvo_match_knn2_hamming: descriptor rows of 1..64 bytes");    // before anything is staged
     (void)hipSetDevice(c->device);
@@ -715,10 +739,10 @@ extern "C" uvo_status uvo_match_knn2_hamming(uvo_ctx* c, const uint8_t* d1, int 
     UVO_HIP_TRY(c, hipMemcpyAsync(dist, c->d_knn_dist, sizeof(float) * 2 * n1, hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 extern "C" uvo_status uvo_match_knn2_ratio_hamming(uvo_ctx* c, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, int mem,
                                                    float ratio, uvo_dmatch* out, int cap, int* m)
-{
+try {
     if (!c || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2) || !out || !m || *m < 0) return UVO_INVALID_ARG;
     if (bytes < 1 || bytes > 64) return fail(c, UVO_INVALID_ARG, "uvo_match_knn2_ratio_hamming: descriptor rows of 1..64 bytes");   // before anything is staged
     (void)hipSetDevice(c->device);
@@ -737,12 +761,12 @@ extern "C" uvo_status uvo_match_knn2_ratio_hamming(uvo_ctx* c, const uint8_t* d1
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     *m += cnt;                                       // appended, as VOU:538
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 // ------------------------------------------------------------------------------------------ geometry operators
 extern "C" uvo_status uvo_triangulate_points(uvo_ctx* c, const double* P1, const double* P2,
                                              const uvo_point2f* x1, const uvo_point2f* x2, int n, float* out4xn)
-{
+try {
     if (!c || !P1 || !P2 || n < 0 || (n && (!x1 || !x2 || !out4xn))) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_triangulate_points"));
@@ -756,13 +780,13 @@ extern "C" uvo_status uvo_triangulate_points(uvo_ctx* c, const double* P1, const
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; i++) { out4xn[i] = tmp[i].x; out4xn[n + i] = tmp[i].y; out4xn[2*n + i] = tmp[i].z; out4xn[3*n + i] = tmp[i].w; }
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_extract_3d_points(uvo_ctx* c, const uvo_point2f* k1, const uvo_point2f* k2, int n,
                                             const double* R1, const double* t1, const double* R2, const double* t2,
                                             const double* K1, const double* K2, const float* points4d,
                                             double* pts, int* idx, int* g)
-{
+try {
     if (!c || n < 0 || !g || !R1 || !t1 || !R2 || !t2 || !K1 || !K2 || (n && (!k1 || !k2 || !points4d || !pts || !idx))) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     *g = 0;
@@ -785,23 +809,23 @@ extern "C" uvo_status uvo_extract_3d_points(uvo_ctx* c, const uvo_point2f* k1, c
     }
     *g = G;
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_reproject_errors(uvo_ctx* c, const double* world, int n, const double* R, const double* t,
                                            const double* K, const uvo_point2f* img, double* err)
-{
+try {
     if (!c || n < 0 || !R || !t || !K || (n && (!world || !img || !err))) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_reproject_errors"));
     if (n == 0) return UVO_OK;
     if (n > c->cap) return fail(c, UVO_CAPACITY, "point count exceeds the context's max_kpts");
     return pose_reproject_errors(c, world, n, R, t, K, img, err);
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_solve_pnp_ransac(uvo_ctx* c, const double* obj, const uvo_point2f* img, int n, const double* K,
                                            int iterations_count, float reprojection_error, double confidence,
                                            double* rvec, double* tvec, int* inliers, int* n_inliers, int* ok)
-{
+try {
     if (!c || !obj || !img || !K || !rvec || !tvec || !n_inliers || !ok || n < 0) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_solve_pnp_ransac"));
@@ -821,11 +845,11 @@ extern "C" uvo_status uvo_solve_pnp_ransac(uvo_ctx* c, const double* obj, const 
         UVO_HIP_TRY(c, hipStreamSynchronize(c->pnp_stream));
     }
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 // host fp64; the matrix -> vector direction needs the 3x3 Jacobi SVD
 extern "C" uvo_status uvo_rodrigues(const double* in, int n_in, double* out)
-{
+try {
     if (!in || !out) return UVO_INVALID_ARG;
     if (n_in == 3) { rodrigues_vec2mat(in, out); return UVO_OK; }
     if (n_in == 9) {
@@ -835,7 +859,7 @@ extern "C" uvo_status uvo_rodrigues(const double* in, int n_in, double* out)
         return UVO_OK;
     }
     return UVO_INVALID_ARG;
-}
+} UVO_ABI_CATCH(nullptr)
 
 // ------------------------------------------------------------------------------------------ stereo step
 // VO:569-579: curr_{left,right}_{descr,keypoints}_after_stereo_match by the stereo matches' indices
@@ -894,7 +918,7 @@ __global__ void k_gather_desc_idx(const float* src, int nsrc, const int* idx, in
 }
 
 extern "C" uvo_status uvo_stereo_set_rig(uvo_ctx* c, const double* K_left, const double* K_right, const double* R_right, const double* t_right)
-{
+try {
     if (!c || !K_left || !K_right || !R_right || !t_right) return UVO_INVALID_ARG;
     memcpy(c->K_left, K_left, sizeof(double) * 9); memcpy(c->K_right, K_right, sizeof(double) * 9);
     memcpy(c->R_right, R_right, sizeof(double) * 9); memcpy(c->t_right, t_right, sizeof(double) * 3);
@@ -903,7 +927,7 @@ extern "C" uvo_status uvo_stereo_set_rig(uvo_ctx* c, const double* K_left, const
     projection_matrix(R_right, t_right, K_right, c->P_right);     // VO:462
     c->rig_set = true;
     return uvo_stereo_reset(c);
-}
+} UVO_ABI_CATCH(c)
 
 // collect and drop every entry in flight, stereo pairs and mono frames alike (each collect dequeues its entry even when the pair failed)
 static void drain_in_flight(uvo_ctx* c)
@@ -919,7 +943,7 @@ static void drain_in_flight(uvo_ctx* c)
 }
 
 extern "C" uvo_status uvo_stereo_reset(uvo_ctx* c)
-{
+try {
     if (!c) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     drain_in_flight(c);                                    // results of whatever is still in flight are dropped
@@ -934,7 +958,7 @@ extern "C" uvo_status uvo_stereo_reset(uvo_ctx* c)
     c->n_pending = 0; c->n_submitted = c->n_collected = 0;
     for (int i = 0; i < 3; i++) c->t_prev_curr[i] = c->rvec[i] = c->tvec[i] = 0;
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 // init phase VO:474-520 (first pairs only; host-assisted because results_match_prev accumulates)
 static uvo_status stereo_init_step(uvo_ctx* c, uvo_stereo_result* out)
@@ -1031,7 +1055,7 @@ static uvo_status prime_lanes(uvo_ctx* c, int w, int h)
 // extract_3Dpoints -- all enqueued on the lane's stream without a host sync; the counters are copied to the
 // lane's pinned mirror, an event marks completion and the lane's worker thread takes over for stage B.
 extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, int mem)
-{
+try {
     if (!c || !left || !right) return UVO_INVALID_ARG;
     if (!c->rig_set) return fail(c, UVO_INVALID_ARG, "uvo_stereo_set_rig has not been called");
     const int depth = (int)c->lanes.size();
@@ -1096,7 +1120,7 @@ extern "C" uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const u
     if (S) return queue_stage_a(c, S, L);
     if (may_batch) { c->stashed_lane = li; return UVO_OK; }           // waits for its partner (or for the collect that needs it)
     return queue_stage_a(c, L, nullptr);
-}
+} UVO_ABI_CATCH(c)
 
 // Stage A of one pair (VO:548-632) -- or of two consecutive pairs, lanes A and B, in one set of launches on A's stream: detect,
 // stereo match, triangular match, gathers, triangulation, extract_3Dpoints -- queued without a host sync; the counters land in each
@@ -1334,9 +1358,14 @@ static void lane_worker(uvo_ctx* L)
             m->b_running++;
             g.unlock();
             if (wtr) wtr->host_us[4] = now_us();
-            if (L->job.kind == 1) { const double tb = g_bdbg ? now_us() : 0; run_mono_stage_b(L, stage_a_ok); if (g_bdbg) { g_bstat[1] += now_us() - tb; g_bstat[4] += 1; } }
-            else if (L->job.kind == 2) { hipLaunchKernelGGL(k_prime, dim3(1), dim3(64), 0, L->pnp_stream, L->d_countsB, 1); (void)host_sync(L, L->pnp_stream); }   // prime_lanes
-            else run_stage_b(L, stage_a_ok);
+            try {
+                if (L->job.kind == 1) { const double tb = g_bdbg ? now_us() : 0; run_mono_stage_b(L, stage_a_ok); if (g_bdbg) { g_bstat[1] += now_us() - tb; g_bstat[4] += 1; } }
+                else if (L->job.kind == 2) { hipLaunchKernelGGL(k_prime, dim3(1), dim3(64), 0, L->pnp_stream, L->d_countsB, 1); (void)host_sync(L, L->pnp_stream); }   // prime_lanes
+                else run_stage_b(L, stage_a_ok);
+            } catch (...) {                                                // a worker has no caller to unwind into: the pair fails with a status, its collect reports it
+                L->job.st = abi_caught(L); L->job.ran = 0;
+                try { L->job.err = L->err; } catch (...) { L->job.err.clear(); }
+            }
             if (wtr) wtr->host_us[5] = now_us();
             g.lock();
             m->b_running--;
@@ -1351,7 +1380,7 @@ static void lane_worker(uvo_ctx* L)
 
 // Result of the oldest submitted pair: gates, pose inversion and output (VO:634-717, VO:148-159), in order.
 extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_result* out)
-{
+try {
     if (!c || !out) return UVO_INVALID_ARG;
     if (c->n_pending <= 0) return fail(c, UVO_INVALID_ARG, "uvo_stereo_collect: nothing submitted");
     if (c->inflight[0] == Ctx::kInflightMonoInit || (c->inflight[0] >= 0 && c->lanes[c->inflight[0]]->job.kind != 0))
@@ -1429,11 +1458,11 @@ extern "C" uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_resul
         out->velocity[i] = c->t_prev_curr[i] / dt;                                         // VO:152
     }
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
                                       int mem, double dt, uvo_stereo_result* out)
-{
+try {
     if (!c || !out) return UVO_INVALID_ARG;
     if (c->n_pending != 0) return fail(c, UVO_INVALID_ARG, "uvo_stereo_step: pairs submitted with uvo_stereo_submit are still in flight");
     c->in_sync_step = true;
@@ -1441,10 +1470,10 @@ extern "C" uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uin
     c->in_sync_step = false;
     UVO_TRY(st);
     return uvo_stereo_collect(c, dt, out);
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" int uvo_stereo_get(uvo_ctx* m, const char* what, void* out, int cap_bytes)
-{
+try {
     if (!m || !what || !out) return 0;
     (void)hipSetDevice(m->device);
     const Ctx* c = m->lanes.empty() ? m : m->lanes[m->last_lane];    // the lane of the last collected pair
@@ -1466,7 +1495,7 @@ extern "C" int uvo_stereo_get(uvo_ctx* m, const char* what, void* out, int cap_b
         if (hipMemcpy(out, src, (size_t)count * esz, hipMemcpyDeviceToHost) != hipSuccess) return 0;
     }
     return count;
-}
+} UVO_ABI_CATCH_RET(m, 0)
 
 
 // ------------------------------------------------------------------------------------------ get_image
@@ -1495,7 +1524,7 @@ static void undistort_point_normalised(double u, double v, const double* K, cons
 // viewport (calibration.cpp cvGetOptimalNewCameraMatrix / icvGetRectangles).  Host arithmetic, once per run.
 extern "C" uvo_status uvo_resize_camera_matrix(int original_width, int original_height, int desired_width, double* K, const double* dist4,
                                                double* newK, int* desired_height_out)
-{
+try {
     if (!K || !dist4 || !newK || desired_width <= 0 || original_width <= 0 || original_height <= 0) return UVO_INVALID_ARG;
     const double ratio = (double)original_width / (double)desired_width;
     const int desired_height = (int)(original_height / ratio);
@@ -1527,12 +1556,12 @@ extern "C" uvo_status uvo_resize_camera_matrix(int original_width, int original_
     newK[2] = cx0 * (1 - alpha) + cx1 * alpha;
     newK[5] = cy0 * (1 - alpha) + cy1 * alpha;
     return UVO_OK;
-}
+} UVO_ABI_CATCH(nullptr)
 
 extern "C" uvo_status uvo_get_image(uvo_ctx* c, const uint8_t* rgb, int w, int h, int stride, int mem, const double* K, const double* dist4,
                                     const double* newK, int desired_width, int clahe, int clip_limit, uint8_t* out, int out_mem,
                                     int* out_w, int* out_h)
-{
+try {
     if (!c || !rgb || !K || !dist4 || !newK || !out || !out_w || !out_h) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     const uint8_t* d_res = nullptr;
@@ -1541,12 +1570,12 @@ extern "C" uvo_status uvo_get_image(uvo_ctx* c, const uint8_t* rgb, int w, int h
     UVO_HIP_TRY(c, hipMemcpyAsync(out, d_res, n, out_mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 // ------------------------------------------------------------------------------------------ compressed-image ingest
 extern "C" uvo_status uvo_decode_image(uvo_ctx* c, const uint8_t* data, size_t n, const char* format, uint8_t* out, size_t cap_bytes, int out_mem,
                                        int* w, int* h, int* channels)
-{
+try {
     if (!c || !data || !w || !h || !channels) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_decode_image"));
@@ -1560,9 +1589,9 @@ extern "C" uvo_status uvo_decode_image(uvo_ctx* c, const uint8_t* data, size_t n
     UVO_HIP_TRY(c, hipMemcpyAsync(out, d_res, bytes, out_mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 extern "C" uvo_status uvo_bayer_bggr2bgr(uvo_ctx* c, const uint8_t* bayer, int w, int h, int stride, int mem, uint8_t* out_bgr, int out_mem)
-{
+try {
     if (!c || !bayer || !out_bgr || w <= 0 || h <= 0 || stride < w) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_bayer_bggr2bgr"));
@@ -1572,43 +1601,43 @@ extern "C" uvo_status uvo_bayer_bggr2bgr(uvo_ctx* c, const uint8_t* bayer, int w
     UVO_HIP_TRY(c, hipMemcpyAsync(out_bgr, d_res, (size_t)w * h * 3, out_mem == UVO_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 // ------------------------------------------------------------------------------------------ mono path
 extern "C" uvo_status uvo_find_essential_mat(uvo_ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K, int method,
                                              double prob, double threshold, int max_iters, double* E, uint8_t* mask, int* ok)
-{
+try {
     if (!c || !p1 || !p2 || !K || !E || !mask || !ok || n < 0 || (method != 4 && method != 8)) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     return mono_find_essential(c, p1, p2, n, K, method, prob, threshold, max_iters, E, mask, ok);
-}
+} UVO_ABI_CATCH(c)
 extern "C" uvo_status uvo_recover_pose(uvo_ctx* c, const double* E, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K,
                                        double* R, double* t, uint8_t* mask, int* good)
-{
+try {
     if (!c || !E || !p1 || !p2 || !K || !R || !t || !mask || !good || n < 0) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     return mono_recover_pose(c, E, p1, p2, n, K, R, t, mask, good);
-}
+} UVO_ABI_CATCH(c)
 extern "C" uvo_status uvo_find_homography(uvo_ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, int method, double threshold,
                                           int max_iters, double confidence, double* H, uint8_t* mask, int* ok)
-{
+try {
     if (!c || !p1 || !p2 || !H || !mask || !ok || n < 0 || (method != 4 && method != 8)) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     return mono_find_homography(c, p1, p2, n, method, threshold, max_iters, confidence, H, mask, ok);
-}
+} UVO_ABI_CATCH(c)
 extern "C" uvo_status uvo_decompose_homography_mat(const double* H, const double* K, double* Rs, double* ts, double* ns, int* n_solutions)
-{
+try {
     if (!H || !K || !Rs || !ts || !ns || !n_solutions) return UVO_INVALID_ARG;
     *n_solutions = decompose_homography_mat(H, K, Rs, ts, ns);
     return UVO_OK;
-}
+} UVO_ABI_CATCH(nullptr)
 extern "C" uvo_status uvo_recover_pose_homography(uvo_ctx* c, const double* H, const uvo_point2f* p1, const uvo_point2f* p2, int n,
                                                   const double* K, double* R, double* t, int* max_good)
-{
+try {
     if (!c || !H || !p1 || !p2 || !K || !R || !t || !max_good || n < 0) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     return mono_recover_pose_homography(c, H, p1, p2, n, K, c->p.HOMOGRAPHY_DISTANCE, R, t, max_good);
-}
+} UVO_ABI_CATCH(c)
 
 // MU:65-86 compute_median
 static double compute_median(std::vector<double> v)
@@ -1620,12 +1649,17 @@ static double compute_median(std::vector<double> v)
     return v[size / 2];
 }
 // select_estimation_method (VOU:725-748): 1 = essential, 0 = homography
-extern "C" int uvo_select_estimation_method(const uvo_point2f* k1, const uvo_point2f* k2, int n, int distance)
+static int select_estimation_method(const uvo_point2f* k1, const uvo_point2f* k2, int n, int distance)
 {
     std::vector<double> d(n > 0 ? n : 0);
     for (int i = 0; i < n; i++) { double dx = k1[i].x - k2[i].x, dy = k1[i].y - k2[i].y; d[i] = sqrt(dx * dx + dy * dy); }
     return compute_median(d) < distance ? 0 : 1;
 }
+extern "C" int uvo_select_estimation_method(const uvo_point2f* k1, const uvo_point2f* k2, int n, int distance)
+try {
+    if (n < 0 || (n && (!k1 || !k2))) return -1;
+    return select_estimation_method(k1, k2, n, distance);
+} UVO_ABI_CATCH_RET(nullptr, -1)
 // extract_inliers (VOU:306-329)
 static int extract_inliers(const uvo_point2f* k1, const uvo_point2f* k2, const uint8_t* mask, int n, uvo_point2f* in1, uvo_point2f* in2)
 {
@@ -1637,7 +1671,7 @@ static int extract_inliers(const uvo_point2f* k1, const uvo_point2f* k2, const u
 extern "C" uvo_status uvo_estimate_relative_pose(uvo_ctx* c, const uvo_point2f* k1, const uvo_point2f* k2, int n, const double* K,
                                                  int* use_essential, double* R, double* t, uvo_point2f* in1, uvo_point2f* in2, int* n_in,
                                                  uint8_t* mask, int* success)
-{
+try {
     if (!c || !k1 || !k2 || !K || !use_essential || !R || !t || !in1 || !in2 || !n_in || !mask || !success || n <= 0) return UVO_INVALID_ARG;
     (void)hipSetDevice(c->device);
     Range r_erp("uvo:estimate_relative_pose");
@@ -1675,17 +1709,17 @@ extern "C" uvo_status uvo_estimate_relative_pose(uvo_ctx* c, const uvo_point2f* 
         }
     }
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_mono_set_camera(uvo_ctx* c, const double* K)
-{
+try {
     if (!c || !K) return UVO_INVALID_ARG;
     memcpy(c->mono_K, K, sizeof(c->mono_K));
     c->mono_cam_set = true;
     return uvo_mono_reset(c);
-}
+} UVO_ABI_CATCH(c)
 extern "C" uvo_status uvo_mono_reset(uvo_ctx* c)
-{
+try {
     if (!c) return UVO_INVALID_ARG;
     drain_in_flight(c);                                    // results of whatever is still in flight are dropped
     c->mono_init_results.clear();
@@ -1697,12 +1731,12 @@ extern "C" uvo_status uvo_mono_reset(uvo_ctx* c)
     memcpy(c->mono_R, I, sizeof(I)); c->mono_t[0] = c->mono_t[1] = c->mono_t[2] = 0;
     c->mono_prev_kps.clear(); c->mono_kps.clear(); c->mono_matches.clear(); c->mono_mask.clear(); c->mono_good_pts.clear();
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 // mono loop body, visual_odometry_node::mono_VO (visual_odometry.h:227-245 init, 247-397 main loop, 126-140 output)
 extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h, int stride, int mem, double range, double dt,
                                     uvo_mono_result* out)
-{
+try {
     if (!c || !img || !out) return UVO_INVALID_ARG;
     if (!c->mono_cam_set) return fail(c, UVO_INVALID_ARG, "uvo_mono_set_camera has not been called");
     if (c->mono_pipelined) return fail(c, UVO_INVALID_ARG, "uvo_mono_step after uvo_mono_submit: call uvo_mono_reset first (the previous frame is held by the pipeline)");
@@ -1754,7 +1788,7 @@ extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h
         const uvo_keypoint& a = c->mono_prev_kps[c->mono_matches[i].queryIdx]; const uvo_keypoint& b = c->mono_kps[c->mono_matches[i].trainIdx];
         k1[i] = uvo_point2f{a.x, a.y}; k2[i] = uvo_point2f{b.x, b.y};
     }
-    c->mono_use_essential = uvo_select_estimation_method(k1.data(), k2.data(), M, p.DISTANCE);   // VO:310-317
+    c->mono_use_essential = select_estimation_method(k1.data(), k2.data(), M, p.DISTANCE);   // VO:310-317
     int n_in = 0, success = 0;
     c->mono_mask.assign(M, 0);
     UVO_TRY(uvo_estimate_relative_pose(c, k1.data(), k2.data(), M, c->mono_K, &c->mono_use_essential, c->mono_R, c->mono_t,
@@ -1804,7 +1838,7 @@ extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h
     out->published = 1; out->valid = valid; out->SF = c->mono_SF;
     memcpy(out->R, c->mono_R, sizeof(out->R)); memcpy(out->t, c->mono_t, sizeof(out->t));
     return roll_state();
-}
+} UVO_ABI_CATCH(c)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // mono pipeline (uvo_mono_submit / uvo_mono_collect): the loop body of uvo_mono_step split at the point where the host
@@ -1826,7 +1860,7 @@ __global__ __launch_bounds__(256) void k_gather_mono_pairs(const uvo_dmatch* __r
 }
 
 extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int h, int stride, int mem, double range)
-{
+try {
     if (!c || !img) return UVO_INVALID_ARG;
     if (!c->mono_cam_set) return fail(c, UVO_INVALID_ARG, "uvo_mono_set_camera has not been called");
     const int depth = (int)c->lanes.size();
@@ -1887,7 +1921,7 @@ extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int
     L->cv.notify_all();
     return UVO_OK;
 #undef LANE_TRY
-}
+} UVO_ABI_CATCH(c)
 
 // Stage B of one mono frame on the lane's worker (VO:276-376 after the matching): fills job.mres / pose_written / sf_written
 static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok)
@@ -1921,7 +1955,7 @@ static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok)
     }
     if (!hip_ok(host_sync(L, st))) return;
     if (M < p.MIN_NUM_FEATURES) return;                                                    // VO:299-307
-    int use_essential = uvo_select_estimation_method(k1.data(), k2.data(), M, p.DISTANCE);   // VO:310-317
+    int use_essential = select_estimation_method(k1.data(), k2.data(), M, p.DISTANCE);   // VO:310-317
     int n_in = 0, success = 0;
     L->mono_mask.assign(M, 0);
     // R, t are in/out in the reference (kept when no estimator writes them): run on a sentinel and report whether they were written
@@ -1972,7 +2006,7 @@ static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok)
 }
 
 extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* out)
-{
+try {
     if (!c || !out) return UVO_INVALID_ARG;
     if (c->n_pending <= 0) return fail(c, UVO_INVALID_ARG, "uvo_mono_collect: nothing submitted");
     if (c->inflight[0] == Ctx::kInflightStereoInit || (c->inflight[0] >= 0 && c->lanes[c->inflight[0]]->job.kind != 1))
@@ -2016,10 +2050,10 @@ extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* o
         memcpy(out->R, c->mono_R, sizeof(out->R)); memcpy(out->t, c->mono_t, sizeof(out->t));
     }
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 
 extern "C" int uvo_mono_get(uvo_ctx* c, const char* what, void* out, int cap_bytes)
-{
+try {
     if (!c || !what || !out) return 0;
     const void* src = nullptr; size_t nb = 0; int count = 0;
     std::string w(what);
@@ -2032,13 +2066,13 @@ extern "C" int uvo_mono_get(uvo_ctx* c, const char* what, void* out, int cap_byt
     if (nb > (size_t)cap_bytes) return -count;
     if (nb) memcpy(out, src, nb);
     return count;
-}
+} UVO_ABI_CATCH_RET(c, 0)
 
 // ------------------------------------------------------------------------------------------ pipeline trace
 // The UVO_TRACE machinery through the ABI: device timestamps (hipEvents on the lane's streams) and host timestamps (steady clock) of
 // every pipelined pair's phases, kept in a ring of 256 pairs per lane.
 extern "C" uvo_status uvo_trace_enable(uvo_ctx* c, int on)
-{
+try {
     if (!c) return UVO_INVALID_ARG;
     if (c->n_pending != 0) { c->err = "the pipeline trace cannot change while pairs are in flight"; return UVO_INVALID_ARG; }
     (void)hipSetDevice(c->device);
@@ -2047,9 +2081,9 @@ extern "C" uvo_status uvo_trace_enable(uvo_ctx* c, int on)
         else l->trace_on = false;
     }
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 extern "C" int uvo_trace_read(uvo_ctx* c, uvo_trace_row* rows, int cap)
-{
+try {
     if (!c || (cap > 0 && !rows) || c->n_pending != 0) return -1;
     (void)hipSetDevice(c->device);
     for (Ctx* l : c->lanes) { if (l->stream) (void)hipStreamSynchronize(l->stream); if (l->pnp_stream) (void)hipStreamSynchronize(l->pnp_stream); }
@@ -2072,30 +2106,30 @@ extern "C" int uvo_trace_read(uvo_ctx* c, uvo_trace_row* rows, int cap)
     }
     std::sort(rows, rows + std::min(n, cap), [](const uvo_trace_row& a, const uvo_trace_row& b) { return a.pair < b.pair; });
     return n;
-}
+} UVO_ABI_CATCH_RET(c, -1)
 
 // ------------------------------------------------------------------------------------------ timing
 extern "C" uvo_status uvo_timing_enable(uvo_ctx* c, int on)
-{
+try {
     if (!c) return UVO_INVALID_ARG;
     if (c->n_pending != 0) { c->err = "timing mode cannot change while pairs are in flight"; return UVO_INVALID_ARG; }
     for (Ctx* l : c->lanes) l->timing = on != 0;
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 extern "C" int uvo_timing_count(uvo_ctx*) { return ST_COUNT; }
 extern "C" const char* uvo_timing_name(uvo_ctx*, int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
 extern "C" uvo_status uvo_timing_get(uvo_ctx* c, int i, double* ms, long long* launches)
-{
+try {
     if (!c || i < 0 || i >= ST_COUNT) return UVO_INVALID_ARG;
     double t = 0; long long n = 0;
     for (Ctx* l : c->lanes) { t += l->stage_ms[i]; n += l->stage_n[i]; }
     if (ms) *ms = t;
     if (launches) *launches = n;
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)
 extern "C" uvo_status uvo_timing_reset(uvo_ctx* c)
-{
+try {
     if (!c) return UVO_INVALID_ARG;
     for (Ctx* l : c->lanes) for (int i = 0; i < ST_COUNT; i++) { l->stage_ms[i] = 0; l->stage_n[i] = 0; }
     return UVO_OK;
-}
+} UVO_ABI_CATCH(c)

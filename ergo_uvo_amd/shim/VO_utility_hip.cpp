@@ -5,6 +5,7 @@
 // throws uvo_hip::Error(UVO_NO_DEVICE).  Reference: uvo_libraries/src/VO_utility.cpp (cited as VOU).
 #include "uvo_libraries_hip/VO_utility_hip.h"
 
+#include <new>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -540,5 +541,7 @@ void select_desired_keypoints(const vector<KeyPoint>& keypoints, vector<KeyPoint
 bool select_estimation_method(const vector<Point2f>& keypoints1_conv, const vector<Point2f>& keypoints2_conv)
 {
     require(keypoints1_conv.size() == keypoints2_conv.size(), "select_estimation_method: point counts differ");
-    return uvo_select_estimation_method(pts_of(keypoints1_conv), pts_of(keypoints2_conv), (int)keypoints1_conv.size(), DISTANCE) != 0;
+    const int essential = uvo_select_estimation_method(pts_of(keypoints1_conv), pts_of(keypoints2_conv), (int)keypoints1_conv.size(), DISTANCE);
+    if (essential < 0) throw std::bad_alloc();            // the C entry reports what the reference's std::vector would have thrown
+    return essential != 0;
 }

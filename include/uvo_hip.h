@@ -231,7 +231,8 @@ uvo_status uvo_decompose_homography_mat(const double* H, const double* K, double
 /* recover_pose_homography (VO_utility.h:111 -> VO_utility.cpp:581-624); R, t written only when a candidate wins */
 uvo_status uvo_recover_pose_homography(uvo_ctx* c, const double* H, const uvo_point2f* p1, const uvo_point2f* p2, int n,
                                        const double* K, double* R, double* t, int* max_good);
-/* select_estimation_method (VO_utility.h:116 -> VO_utility.cpp:725-748): 1 = essential, 0 = homography */
+/* select_estimation_method (VO_utility.h:116 -> VO_utility.cpp:725-748): 1 = essential, 0 = homography; -1 = invalid arguments or
+ * no host memory for the median's scratch (the entry has no context to carry a status) */
 int        uvo_select_estimation_method(const uvo_point2f* k1, const uvo_point2f* k2, int n, int distance);
 /* estimate_relative_pose: *use_essential is the reference's global of that name (in/out), R and t are in/out,
  * in1/in2 (capacity n) receive extract_inliers' output, mask the final mask (VO_utility.cpp:157) */
