@@ -329,3 +329,132 @@ def test_essential_matrix_and_recovered_pose_by_their_definitions(uctx):
     # (the cheirality count also drops points triangulated beyond distanceThresh = 50 baselines: the planted baseline is 0.135 of a unit)
     assert good == int((m2 > 0).sum()) and good > 0.5 * inl.sum() and not np.any((m2 > 0) & ~inl)
     assert np.abs(R - R_t).max() < 5e-3 and np.abs(t.ravel() - t_t / np.linalg.norm(t_t)).max() < 5e-2
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Round 5: the three operators whose restatement is the most intricate, against tests/definitions_np.py (numpy float64, written from
+# the published definitions; imports nothing of oracle/): the 64-float descriptor, EPnP inside solvePnPRansac, findHomography's mask.
+
+def _descriptor_ties(img, kp, eps=2e-4):
+    """21 x 21 cells of the keypoint's area-averaged window whose exact average lies within eps of k + 0.5: the 8-bit rounding of such a
+    cell is decided by the resize's own arithmetic (float weights; 2 x 2 blocks round half up), not by the definition."""
+    import definitions_np as D
+    win, n = D.surf_window(img, kp["x"], kp["y"], kp["size"])
+    W = D.area_weights(n, 21)
+    v = W @ win @ W.T
+    return int((np.abs(v - np.floor(v) - 0.5) < eps).sum())
+
+
+@pytest.mark.parametrize("shape,seed,thr,min_kps,min_clean", [((360, 640), 77, 1500, 600, 300), ((1080, 1920), None, 6387, 2800, 1500)])
+def test_surf64_descriptor_against_its_definition(shape, seed, thr, min_kps, min_clean):
+    """VO_utility.cpp:114-119 -> SURF::detectAndCompute, descriptor half: every row of uvo_surf_detect against the numpy statement of
+    the upright 64-float descriptor (window floor(21 * size * 1.2 / 9) clamped to the image, exact area average to 21 x 21 with the
+    8-bit rounding, 20 x 20 Haar differences, sigma = 3.3 Gaussian, 4 x 4 cells, unit length).  Keypoints none of whose 441 cells sits
+    on a rounding tie must agree to 1e-6 per element (float accuracy of a 64-float row); the others -- a grey level either way in a
+    few cells -- to 6e-3, and 97 % of ALL keypoints to 2e-3.  1080p: windows up to several hundred pixels (most above 128)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import definitions_np as D
+    import ergo_uvo_amd as uvo
+    from ergo_uvo_amd import synth
+    h, w = shape
+    img = synth.stereo_pair(synth.Scene(synth.SEEDS["C3"] if seed is None else seed, w), 0, w, h)[0]
+    c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=thr), 0, w, h, 8192)
+    try:
+        kps, desc = c.surf_detect(img)
+    finally:
+        c.close()
+    assert len(kps) >= min_kps
+    err = np.array([np.abs(D.surf64_upright(img, kp["x"], kp["y"], kp["size"]) - desc[k].astype(np.float64)).max() for k, kp in enumerate(kps)])
+    ties = np.array([_descriptor_ties(img, kp) for kp in kps])
+    wins = np.floor(np.float32(21) * (kps["size"] * np.float32(1.2) / np.float32(9))).astype(int)
+    clean = ties == 0
+    assert clean.sum() >= min_clean, clean.sum()
+    assert err[clean].max() <= 1e-6, (err[clean].max(), int(np.argmax(np.where(clean, err, 0))))
+    assert err.max() <= 6e-3 and np.mean(err <= 2e-3) >= 0.97, (err.max(), np.mean(err <= 2e-3))
+    if h >= 1080:
+        big = clean & (wins > 128)
+        assert big.sum() >= 50 and err[big].max() <= 1e-6, (big.sum(), wins.max())
+
+
+def _dyadic_pnp_case(n, seed, R, t, K):
+    """Exactly consistent float32 data for a planted pose: camera-frame depths are powers of two and x / y multiples of Z / 128, K has integer
+    focal lengths, R is a signed permutation (the only rotations with dyadic entries) -- object points, image points and pose are then
+    all exactly representable, so an exact solver must return the pose to rounding error of its own arithmetic."""
+    rng = np.random.default_rng(seed)
+    Z = rng.choice([2.0, 4.0, 8.0], n)
+    Y = np.stack([rng.integers(-64, 65, n) / 64.0 * Z * 0.5, rng.integers(-40, 41, n) / 64.0 * Z * 0.5, Z], 1)
+    X = (Y - t) @ R
+    x = (Y[:, :2] / Y[:, 2:]) * np.array([K[0, 0], K[1, 1]]) + np.array([K[0, 2], K[1, 2]])
+    assert np.array_equal(X.astype(np.float32).astype(np.float64), X) and np.array_equal(x.astype(np.float32).astype(np.float64), x)
+    return X, x.astype(np.float32)
+
+
+def test_epnp_recovers_exact_poses_and_its_refit_is_near_the_least_squares_optimum(uctx):
+    """cv::solvePnPRansac(..., SOLVEPNP_EPNP) (visual_odometry.h:647-648).  (i) Noise-free, exactly representable data: five points (the
+    single solve OpenCV does when npoints == model_points), six (the smallest RANSAC case) and N points -- RANSAC + the refit on all
+    inliers -- recover the planted pose to 1e-9 (observed ~1e-14), every point an inlier.  (ii) Noisy N points: the returned pose's
+    reprojection RMS over its inliers is within 2 % of the RMS after a Levenberg-Marquardt polish of that pose (scipy) -- EPnP is not
+    the maximum-likelihood estimator, but a correct one lands next to it (observed 1.0004 .. 1.004)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import definitions_np as D
+    K = np.array([[700.0, 0, 640], [0, 700, 360], [0, 0, 1]])
+    Rz = np.array([[0., -1, 0], [1, 0, 0], [0, 0, 1]])
+    Rx = np.array([[1., 0, 0], [0, 0, -1], [0, 1, 0]])
+    t = np.array([0.25, -0.125, 0.5])
+    for name, R in (("identity", np.eye(3)), ("90 degrees about z", Rz), ("90 degrees about x", Rx)):
+        for n in (5, 6, 40, 400, 3000):
+            X, x = _dyadic_pnp_case(n, 3 + n, R, t, K)
+            ok, rvec, tvec, inl = uctx.solvePnPRansac(X, x, K)
+            assert ok and len(inl) == n and np.array_equal(inl, np.arange(n)), (name, n, len(inl))
+            assert np.abs(D.rodrigues(rvec) - R).max() <= 1e-9 and np.abs(tvec - t).max() <= 1e-9, (name, n, rvec, tvec)
+    rng = np.random.default_rng(11)
+    for n, noise in ((300, 0.3), (1500, 0.5), (60, 0.2), (3000, 0.4)):
+        X = np.stack([rng.uniform(-2, 2, n), rng.uniform(-1.2, 1.2, n), rng.uniform(2.5, 6, n)], 1).astype(np.float32).astype(np.float64)
+        rv, tt = np.array([0.012, -0.02, 0.007]), np.array([0.04, -0.015, 0.06])
+        x = (D.project(X, rv, tt, K) + rng.normal(0, noise, (n, 2))).astype(np.float32)
+        ok, rvec, tvec, inl = uctx.solvePnPRansac(X, x, K, reprojection_error=8.0)
+        assert ok and len(inl) >= 0.98 * n
+        Xi, xi = X[inl], x[inl].astype(np.float64)
+        rms = D.reprojection_rms(Xi, xi, rvec, tvec, K)
+        rp, tp = D.pose_polish(Xi, xi, rvec, tvec, K)
+        best = D.reprojection_rms(Xi, xi, rp, tp, K)
+        assert best <= rms <= 1.02 * best, (n, noise, rms, best)
+        assert np.abs(rvec - rv).max() < 5e-3 and np.abs(tvec - tt).max() < 2e-2
+
+
+@pytest.mark.parametrize("n,n_out,noise,thr,seed", [(250, 50, 0.3, 1.0, 1), (800, 300, 0.5, 2.0, 2), (60, 10, 0.2, 1.0, 3), (400, 80, 0.05, 0.1, 4), (3000, 900, 0.4, 1.0, 5)])
+def test_find_homography_mask_is_that_of_a_four_point_model_of_the_replayed_stream(uctx, n, n_out, noise, thr, seed):
+    """cv::findHomography(RANSAC) (VO_utility.cpp:152): the mask it returns is the inlier set -- squared reprojection distance <=
+    threshold^2 -- of ONE of the 4-point models RANSAC fits, and RANSAC's subsets are fixed by cv::RNG((uint64)-1).  The stream, the
+    draws (redraw on a duplicate) and the normalised DLT are restated in numpy; the test finds the subset of the stream whose model's
+    inlier set IS the mask (up to pairs within 0.1 % of the threshold), checks that no earlier subset's model had more inliers (RANSAC
+    keeps the first best), and that no planted outlier is in."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import definitions_np as D
+    rng = np.random.default_rng(seed)
+    H0 = np.array([[1.02, 0.03, 12.0], [-0.02, 0.97, -7.0], [2e-5, -1e-5, 1.0]])
+    p = np.stack([rng.uniform(20, 1260, n), rng.uniform(20, 700, n)], 1)
+    ph = np.c_[p, np.ones(n)] @ H0.T
+    q = ph[:, :2] / ph[:, 2:] + rng.normal(0, noise, (n, 2))
+    bad = rng.choice(n, n_out, replace=False)
+    q[bad] += rng.uniform(15, 50, (n_out, 2)) * rng.choice([-1, 1], (n_out, 2))
+    p, q = p.astype(np.float32), q.astype(np.float32)
+    ok, H, mask = uctx.findHomography(p, q, method=8, threshold=thr, max_iters=2000, confidence=0.995)
+    inl = mask.astype(bool)
+    assert ok and not inl[bad].any() and inl.sum() >= 0.5 * (n - n_out)
+    hit, counts = None, []
+    for k, s in enumerate(D.ransac_subsets(n, 4, 400)):
+        Hk = D.homography_dlt(p[s], q[s])
+        e = D.homography_err2(Hk, p, q) if np.all(np.isfinite(Hk)) else np.full(n, np.inf)
+        lo, hi = e <= thr * thr * (1 - 1e-3), e <= thr * thr * (1 + 1e-3)
+        counts.append(int(lo.sum()))
+        if np.all(inl[lo]) and not np.any(inl[~hi]):
+            hit = k
+            break
+    assert hit is not None, "no 4-point model of the first 400 subsets of cv::RNG((uint64)-1) has the returned mask as its inlier set"
+    assert counts[hit] + 2 >= max(counts), (hit, counts[hit], max(counts))           # RANSAC keeps the FIRST model with the most inliers
+    # the refined H (refit on the inliers + LM) explains the inliers at least as well as the 4-point model did
+    assert np.sqrt(D.homography_err2(H / H[2, 2], p[inl], q[inl]).mean()) <= np.sqrt(D.homography_err2(Hk, p[inl], q[inl]).mean()) + 1e-9
