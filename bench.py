@@ -470,13 +470,13 @@ def main():
         # HBM bytes per launch from the committed counter passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of `tools/probe/gpu.sh
         # final`, FETCH_SIZE doubled per MI355X_MICROARCH.md): the newest summary that has the kernel
         # Counters cannot be read from inside this process; the figure is the one of the newest committed counter summary whose
-        # `kernel_source_sha` matches the detector source being run (tools/pmc_summary_r03.py writes it) -- null when the profile
+        # `kernel_source_sha` matches the detector source being run (tools/pmc_summary.py writes it) -- null when the profile
         # predates the kernel, never a stale number.
         traffic, traffic_source = None, None
         try:
             import hashlib
             sha = hashlib.sha256(open(os.path.join(ROOT, "ergo_uvo_amd", "csrc", "surf.hip"), "rb").read()).hexdigest()[:16]
-            for name in ("r04_pmc_stage_kernels.json", "r03_pmc_stage_kernels.json"):
+            for name in ("r05_pmc_stage_kernels.json", "r04_pmc_stage_kernels.json", "r03_pmc_stage_kernels.json"):
                 d = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if d.get("kernel_source_sha", {}).get("surf.hip") == sha:
                     traffic = int(d["kernels"]["hessian_all_octaves"]["hbm_bytes_fetch_x2"])

@@ -18,11 +18,15 @@ EXPORTS = [
     "uvo_ctx_stream", "uvo_ctx_set_params", "uvo_ctx_set_feature_detector", "uvo_ctx_set_producer_stream", "uvo_ctx_warning", "uvo_ctx_pending", "uvo_ctx_host_policy", "uvo_surf_detect", "uvo_sift_detect", "uvo_sift_layer", "uvo_integral", "uvo_hessian_layer",
     "uvo_match_knn2_ratio", "uvo_match_knn2", "uvo_match_knn2_ratio_dim", "uvo_match_knn2_dim", "uvo_match_knn2_ratio_hamming", "uvo_match_knn2_hamming", "uvo_triangulate_points", "uvo_extract_3d_points",
     "uvo_solve_pnp_ransac", "uvo_reproject_errors", "uvo_rodrigues", "uvo_stereo_set_rig", "uvo_stereo_reset", "uvo_stereo_step",
-    "uvo_stereo_set_depth", "uvo_stereo_set_batch", "uvo_stereo_submit", "uvo_stereo_collect",
+    "uvo_stereo_set_depth", "uvo_stereo_submit", "uvo_stereo_collect",
     "uvo_stereo_get", "uvo_find_essential_mat", "uvo_recover_pose", "uvo_find_homography", "uvo_decompose_homography_mat",
     "uvo_recover_pose_homography", "uvo_select_estimation_method", "uvo_estimate_relative_pose", "uvo_mono_set_camera",
     "uvo_mono_reset", "uvo_mono_step", "uvo_mono_submit", "uvo_mono_collect", "uvo_mono_get", "uvo_get_image", "uvo_decode_image", "uvo_bayer_bggr2bgr", "uvo_resize_camera_matrix", "uvo_timing_enable", "uvo_timing_count", "uvo_timing_name", "uvo_timing_get", "uvo_timing_reset", "uvo_trace_enable", "uvo_trace_read",
 ]
+
+
+# exported, but not part of the drop-in ABI (ergo_uvo_amd/csrc/uvo_experimental.h): measurement hooks
+EXPERIMENTAL = ["uvo_stereo_set_batch"]
 
 
 def build(force: bool = False) -> str:
@@ -71,6 +75,6 @@ def lib() -> C.CDLL:
         _lib.uvo_trace_read.restype = C.c_int
         _lib.uvo_trace_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib.uvo_trace_enable.argtypes = [C.c_void_p, C.c_int]
-        for name in EXPORTS:
+        for name in EXPORTS + EXPERIMENTAL:
             getattr(_lib, name)  # fail loudly if the ABI and the header drift apart
     return _lib

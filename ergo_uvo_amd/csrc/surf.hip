@@ -475,43 +475,12 @@ __device__ __forceinline__ int lane_tid() { int t = threadIdx.x; asm volatile(""
         const float dxy = (float)d;                                                                       \
         det = (pp_in) - 0.81f * dxy * dxy;                                                                \
     }
-// The same with Dy taken only where Dx leaves the product a chance: every box sum is at most 255 x its area, so |dy| <= 510 (+ rounding)
-// and |dx| * 512 <= threshold implies dx * dy <= threshold -- the sample gets kDetBelow exactly as it would have with dy computed.
-// A wave whose 64 samples all fall under that bound skips Dy's eight corners and its double accumulation (LDS tiles only: the plane
-// reads of octaves 2-3 are issued in batches that a branch would split).
-#define UVO_HESSIAN_PP_LAZY(SV, pp_out)                                                                   \
-    {                                                                                                     \
-        const unsigned gx0 = (unsigned)(SV(c7, c0) - SV(c2, c0)), gx3 = sad_u32(SV(c7, c3), SV(c2, c3), kBoxMagic),                       \
-                       gx6 = sad_u32(SV(c7, c6), SV(c2, c6), 2u * kBoxMagic), gx9 = sad_u32(SV(c7, c9), SV(c2, c9), 3u * kBoxMagic);     \
-        static_assert(wx0 == wx2 && wy0 == wy2 && wx0 == wy0 && wx1 == wy1, "the outer boxes of Dx and Dy share one weight");            \
-        const uvo_v2f px02 = UVO_BOX_FMA2(gx3 - gx0, gx9 - gx6, wx0);                                                                     \
-        const float px1 = __builtin_fmaf(__uint_as_float(gx6 - gx3), wx1, -8388608.0f * wx1);                                           \
-        double d = (double)px02.x;                                                                        \
-        d += (double)px1;                                                                                 \
-        d += (double)px02.y;                                                                              \
-        const float dx = (float)d;                                                                        \
-        pp_out = -3.0e38f;                                                                                \
-        if (__builtin_fabsf(dx) * 512.0f > skip_thr) {                                                    \
-            const unsigned gy0 = (unsigned)(SV(c0, c7) - SV(c0, c2)), gy3 = sad_u32(SV(c3, c7), SV(c3, c2), kBoxMagic),                   \
-                           gy6 = sad_u32(SV(c6, c7), SV(c6, c2), 2u * kBoxMagic), gy9 = sad_u32(SV(c9, c7), SV(c9, c2), 3u * kBoxMagic); \
-            const uvo_v2f py02 = UVO_BOX_FMA2(gy3 - gy0, gy9 - gy6, wy0);                                                                 \
-            const float py1 = __builtin_fmaf(__uint_as_float(gy6 - gy3), wy1, -8388608.0f * wy1);                                       \
-            d = (double)py02.x;                                                                           \
-            d += (double)py1;                                                                             \
-            d += (double)py02.y;                                                                          \
-            const float dy = (float)d;                                                                    \
-            pp_out = dx * dy;                                                                             \
-        }                                                                                                 \
-    }
-// Off by default: on the bench's scene (texture everywhere) no wave qualifies and the split costs 0.9 us of the launch (68.5 against
-// 67.6 us); -DUVO_LAZY_DY=1 is for footage with large smooth regions.
-#ifndef UVO_LAZY_DY
-#define UVO_LAZY_DY 0
-#endif
+// (A variant that took Dy only where |dx| * 512 > threshold -- a wave whose 64 samples all fall under that bound skips Dy's eight
+// corners -- was measured and removed: on the bench's scene no wave qualifies and the split cost 0.9 us of the launch)
 #define UVO_HESSIAN_DET(SV, det)                                                                          \
     {                                                                                                     \
         float pp_;                                                                                        \
-        if constexpr (UVO_LAZY_DY) UVO_HESSIAN_PP_LAZY(SV, pp_) else UVO_HESSIAN_PP(SV, pp_)              \
+        UVO_HESSIAN_PP(SV, pp_)                                                                           \
         if (!(pp_ > skip_thr)) det = kDetBelow; else UVO_HESSIAN_DXY(SV, pp_, det)                        \
     }
 #define UVO_HESSIAN_CONSTS(LC)                                                                            \
@@ -533,14 +502,7 @@ __device__ __forceinline__ void static_for(F&& f)
 // 1 KB, three tile rows -- behind a v_add_u32 that forms the pair's base: eight address additions per determinant on the unit that
 // bounds the kernel.  Volatile LDS loads are not paired (each a ds_read_b32 with its 16-bit offset from the sample's one base register):
 // 9 % fewer vector instructions in the octave-0 loop, twice the LDS instructions, 64.5 against 65.0 us -- measured, not kept.
-#ifndef UVO_SV_VOLATILE
-#define UVO_SV_VOLATILE 0
-#endif
-#if UVO_SV_VOLATILE
-#define UVO_SV_LOAD(base, off) (((const volatile __attribute__((address_space(3))) int32_t*)(base))[off])
-#else
 #define UVO_SV_LOAD(base, off) ((base)[off])
-#endif
 // det plane of layer L (1..3) of a workgroup's TW x TH samples from the integral tile in LDS; 0 where the template does not fit
 template <int O, int L, int TW, int TH, int NT, class OP>
 __device__ __forceinline__ void det_layer_c(const int32_t* __restrict__ stile, float* __restrict__ sdet, const OP& op,
@@ -725,9 +687,6 @@ __device__ __forceinline__ void hess_stamp(int k, long long v = -1)
 }
 // the survivor count of a tile starts at zero: called before the barrier that precedes nms_survivors (one barrier less per tile: under
 // three workgroups per CU a barrier costs the wait for the slowest of eight time-sliced waves)
-#ifndef UVO_NMS_WAVE_SKIP
-#define UVO_NMS_WAVE_SKIP 1
-#endif
 template <int TW, int TH>
 __device__ __forceinline__ void nms_zero(unsigned* s_list) { if (lane_tid() == 0) reinterpret_cast<int*>(s_list + NmsLds<TW, TH>::kList)[0] = 0; }
 template <int TW, int TH, int NT, class OP>
@@ -760,7 +719,7 @@ __device__ __forceinline__ void nms_survivors(const float* __restrict__ sdet, un
     for (int l = 0; l < 3; l++)
 #pragma unroll
         for (int k = 0; k < ITER; k++) cmax = fmaxf(cmax, col[l][k + 1]);
-    if (!UVO_NMS_WAVE_SKIP || __any(cmax > thr)) {
+    if (__any(cmax > thr)) {
     float m3[3][ITER], m3l[3][ITER], m3r[3][ITER];
 #pragma unroll
     for (int l = 0; l < 3; l++)
@@ -913,9 +872,7 @@ __global__ __launch_bounds__(256) void k_hessian_finish(LanePair lp, const Octav
 }
 
 // quads a thread has in flight during the tile fill: the whole tile in one round trip when that takes at most six per thread
-#ifndef UVO_FILL
 #define UVO_FILL(quads, nt) (((quads) + (nt) - 1) / (nt) <= 6 ? ((quads) + (nt) - 1) / (nt) : 4)
-#endif
 // One tile of octave 0 or 1 (tile bx, by of image im): the body of k_hessian_nms_c and of the octave-0 blocks of k_hessian_nms_c0_p23
 template <int O, int TW, int TH, int NT, class OP>
 __device__ __forceinline__ void hessian_nms_c_tile(const ImgPair& ip, int w, int h, const OP& op, float thr, const SurvOut& sv,
@@ -1353,12 +1310,6 @@ template <> __device__ __forceinline__ unsigned px_load<1>(ImgRsrc rs, int voff,
 template <> __device__ __forceinline__ unsigned px_load<2>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0); }
 template <> __device__ __forceinline__ unsigned px_load<4>(ImgRsrc rs, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0); }
 
-// (measured, off: the conversion-free form below compiles to v_or_b32_sdwa + v_pk_fma_f32 + v_pk_add_f32 as intended, but holds every
-// loaded word's four floats at once -- 37 registers spilled under this kernel's 64: 90.5 us against 57.2; 76.4 / 66.7 us at seven / six
-// waves per SIMD with 72 / 80 registers, still spilling)
-#ifndef UVO_DESC_FMA
-#define UVO_DESC_FMA 0
-#endif
 template <int PX, int Q>
 struct AreaCol {
     ImgRsrc rs; int w, h1;
@@ -1378,17 +1329,10 @@ struct AreaCol {
 #pragma unroll
         for (int q = 0; q < Q; q++) v[q] = px_load<PX>(rs, voff[q], soff);
     }
-    // (float)pixel * alpha without the byte -> float conversion (v_cvt_f32_ubyte*: 1.7 issue slots on gfx950, tools/probe/issue_rate_probe.hip):
-    // the float whose bits are pixel | 0x4B000000 is 2^23 + pixel, and fma(2^23 + pixel, alpha, -(2^23 alpha)) rounds the exact product
-    // pixel * alpha once -- the same float ((2^23) alpha is exact; pixel = 0 or alpha = +0 give +0 either way; alpha >= 0 always)
-    static __device__ __forceinline__ float px_times(unsigned v, int p, float alpha)
-    {
-#if UVO_DESC_FMA
-        return __builtin_fmaf(__uint_as_float(((v >> (8 * p)) & 255u) | 0x4B000000u), alpha, -8388608.0f * alpha);
-#else
-        return (float)(int)((v >> (8 * p)) & 255u) * alpha;
-#endif
-    }
+    // (float)pixel * alpha.  The conversion-free form the detector uses -- fma(bits(pixel | 0x4B000000), alpha, -(2^23 alpha)), v_or_b32_sdwa +
+    // v_pk_fma_f32 -- was measured here and removed: it holds every loaded word's four floats at once, 37 registers spilled under this
+    // kernel's 64, 90.5 us against 57.2.
+    static __device__ __forceinline__ float px_times(unsigned v, int p, float alpha) { return (float)(int)((v >> (8 * p)) & 255u) * alpha; }
     __device__ __forceinline__ void first(const unsigned (&v)[Q], float alpha)      // 0.f + v * a == v * a
     {
 #pragma unroll
@@ -1978,10 +1922,7 @@ __device__ __forceinline__ void descriptor64_big(const DescArgs& a, int w, int h
 // small-window keypoint each.  The large-window part stalls on its per-tap dependency chains, the small-window part on its
 // barriers; resident together they keep the VALU busier than one after the other (and a launch is saved).
 // (8 waves per SIMD: the compiler would settle at 66 VGPRs = 7 waves)
-#ifndef UVO_DESC_WAVES
-#define UVO_DESC_WAVES 8
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(UVO_DESC_WAVES, 8))) void k_descriptor64(LanePair lp, int w, int h, int nbig, int part, int nim, int order)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_descriptor64(LanePair lp, int w, int h, int nbig, int part, int nim, int order)
 {
     // The launch is one row of workgroups; `order` says who comes first (the hardware starts workgroups in index order, and with
     // lifetimes of 4 to 14 us that order decides what is resident together): 0: image by image, each image's large-window waves before

@@ -10,6 +10,7 @@
 #include <deque>
 #include <stdint.h>
 #include "../../include/uvo_hip.h"
+#include "uvo_experimental.h"
 
 namespace uvo {
 

@@ -201,12 +201,6 @@ uvo_status uvo_stereo_step(uvo_ctx* c, const uint8_t* left, const uint8_t* right
  * Pipeline depth: 1..16, default 2 (the stereo loop is fastest at 6, the mono loop at about 14).  Each unit of depth is one more set of device buffers, two more HIP streams and
  * one more host worker thread; changing it restarts nothing unless the lane holding the previous pair is removed. */
 uvo_status uvo_stereo_set_depth(uvo_ctx* c, int depth);
-/* Two-pair launch sets (pairs = 2; 1 restores the default): uvo_stereo_submit holds every first pair of two back until the next one
- * arrives and queues the device work of both -- lanes i and i + 1 of the pipeline -- as ONE launch per kernel (upright SURF with four
- * octaves; any other configuration, the synchronous step and the init pairs go alone).  A pair still waiting for its partner is queued
- * by the uvo_stereo_collect that asks for it, so every submit / collect order works; results are those of single launches, pair for
- * pair.  Not while pairs are in flight.  Batch consumers only: a pair's latency grows by the wait for its partner. */
-uvo_status uvo_stereo_set_batch(uvo_ctx* c, int pairs);
 uvo_status uvo_stereo_submit(uvo_ctx* c, const uint8_t* left, const uint8_t* right, int w, int h, int stride, int mem);
 uvo_status uvo_stereo_collect(uvo_ctx* c, double dt, uvo_stereo_result* out);
 /* intermediates of the pair returned by the last uvo_stereo_step / uvo_stereo_collect, read from its lane (valid until the

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/pmc_sift_* (tools/probe/r03_sift_pmc.sh) -> profiles/r03_pmc_sift_kernels.json: per-launch counter means of the SIFT
+"""gpurun_out/pmc_sift_* (tools/probe/gpu.sh sift-pmc) -> profiles/r03_pmc_sift_kernels.json: per-launch counter means of the SIFT
 kernels on the 1080p frames (for the tiled blur: the octave-0 launch of each radius), HBM bytes per MI355X_MICROARCH.md's recipe
 (FETCH_SIZE / WRITE_SIZE in KiB, separate passes; FETCH doubled for coalesced streams on gfx950, raw kept beside it) and the ratios
 DESIGN.md quotes."""
@@ -65,7 +65,7 @@ for k, v in res.items():
     if v.get("SQ_INSTS_VALU"):
         der["salu_per_valu"] = round(v.get("SQ_INSTS_SALU", 0) / v["SQ_INSTS_VALU"], 3)
     v["derived"] = der
-json.dump({"source": "tools/probe/r03_sift_pmc.sh: rocprofv3 --kernel-trace --pmc <group> -- python3 tools/prof_sift.py 4 (one pass per group)",
+json.dump({"source": "tools/probe/gpu.sh sift-pmc: rocprofv3 --kernel-trace --pmc <group> -- python3 tools/prof_sift.py 4 (one pass per group)",
            "units": "counter means per launch; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles; FETCH_SIZE / WRITE_SIZE in KiB",
            "kernels": res}, open(os.path.join(ROOT, "profiles", "r03_pmc_sift_kernels.json"), "w"), indent=1)
 for k, v in res.items():

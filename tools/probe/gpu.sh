@@ -17,12 +17,16 @@
 #   rates                       issue-rate probe (built by hipcc here if missing)
 #   topo                        what the rank pinning reads on this box
 #   configs                     tools/bench_configs.py
+#   mono <tag>                  rocprofv3 kernel stats of the mono loop at C4 (tools/prof_mono.py contract | 1px), + pipelined rate (tools/probe/mono_pipe.py)
+#   sift <tag>                  the SIFT detector: timing, kernel stats, the stereo loop on SIFT under the profiler
+#   sift-pmc                    counter passes of the SIFT detector (one per group) -> tools/pmc_summary_sift.py
+#   budget [host_budget args]   tools/host_budget.py: {spin, sleep, block-all, device} x {2, 4, 16 CPUs}, both bench forms
 #   final <tag>                 the closing pass of a round: bench (600 steps and the driver's form), kernel stats, counters, configs
-# TAG=<name> prefixes the output files (default r04).
+# TAG=<name> prefixes the output files (default r05).
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-$(dirname $0)/../..}
 mkdir -p gpurun_out
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 OLD=$PWD/ergo_uvo_amd/lib_ab/libuvo_hip_old.so
 line() { python -c "import sys,json,os; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-34s' % os.environ.get('LBL',''), d['value'], d.get('block_values'))"; }
 brun() { python bench.py --blocks 5 --timed-only "$@" 2>/dev/null | LBL="${LBL:-$*}" line; }
@@ -71,12 +75,24 @@ step() {
              make -C ergo_uvo_amd/csrc -s -j8 STAMPS=1 BUILD=build_stamps OUT=../lib_ab/libuvo_hip_stamps.so || return 1
              UVO_HIP_LIB=$PWD/ergo_uvo_amd/lib_ab/libuvo_hip_stamps.so UVO_HESS_STAMPS=gpurun_out/${TAG}_hess_stamps.csv python tools/prof_stereo.py 8 > /dev/null 2>&1; python tools/probe/hess_stamps.py gpurun_out/${TAG}_hess_stamps.csv
              UVO_HIP_LIB=$PWD/ergo_uvo_amd/lib_ab/libuvo_hip_stamps.so UVO_DESC_STAMPS=gpurun_out/${TAG}_desc_stamps.csv python tools/prof_stereo.py 8 > /dev/null 2>&1; python tools/probe/desc_stamps.py gpurun_out/${TAG}_desc_stamps.csv ;;
-    rates)   [ -x tools/probe/issue_rate_probe ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probe/issue_rate_probe.hip -o tools/probe/issue_rate_probe || return 1
+    rates)   [ tools/probe/issue_rate_probe -nt tools/probe/issue_rate_probe.hip ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/probe/issue_rate_probe.hip -o tools/probe/issue_rate_probe || return 1
              tools/probe/issue_rate_probe ;;
     topo)    for n in /sys/class/kfd/kfd/topology/nodes/*; do echo "== $n"; grep -E "simd_count|cpu_cores_count|location_id|domain|drm_render_minor" $n/properties 2>&1; done
              ls -la /dev/dri /dev/kfd 2>&1; nproc; cat /sys/devices/system/node/node*/cpulist 2>&1; env | grep -E "VISIBLE|ROCR|HIP_|GPU_"
              python3 -c "import sys; sys.path.insert(0, '.'); from ergo_uvo_amd import multirank; print(multirank.visible_gpus())" ;;
     configs) python tools/bench_configs.py > gpurun_out/bench_${TAG}_configs.json 2> gpurun_out/bench_${TAG}_configs.err || { tail -5 gpurun_out/bench_${TAG}_configs.err; return 1; }; cat gpurun_out/bench_${TAG}_configs.json ;;
+    mono)    t=${1:-$TAG}
+             for kind in contract 1px; do rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${t}_mono_$kind -- python3 tools/prof_mono.py $kind 32 > gpurun_out/prof_${t}_mono_$kind.log 2>&1 || return 1; tail -1 gpurun_out/prof_${t}_mono_$kind.log; python tools/probe/kstats.py prof_${t}_mono_$kind 22; done
+             python tools/probe/mono_pipe.py 6 2>/dev/null | tail -3; python tools/probe/mono_pipe.py 14 2>/dev/null | tail -3 ;;
+    sift)    t=${1:-$TAG}
+             python3 tools/prof_sift.py 20 --cpu > gpurun_out/${t}_sift_time.log 2>&1 || return 1; cat gpurun_out/${t}_sift_time.log
+             rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${t}_sift -- python3 tools/prof_sift.py 5 > gpurun_out/prof_${t}_sift.log 2>&1 || return 1
+             rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${t}_siftvo -- python3 tools/bench_configs.py SIFTVO > gpurun_out/prof_${t}_siftvo.log 2>&1 || return 1; tail -1 gpurun_out/prof_${t}_siftvo.log ;;
+    sift-pmc) for g in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VALU_CVT SQ_INSTS_VMEM_RD SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS"; do
+               case "$g" in FETCH*) d=fetch ;; WRITE*) d=write ;; SQ_INSTS_VALU*) d=sq1 ;; *) d=sq2 ;; esac
+               rocprofv3 --kernel-trace --pmc $g --output-format csv -d gpurun_out/pmc_sift_$d -- python3 tools/prof_sift.py 4 > gpurun_out/pmc_sift_$d.log 2>&1 || return 1
+             done; python tools/pmc_summary_sift.py ;;
+    budget)  python tools/host_budget.py --out gpurun_out/${TAG}_host_budget.json "$@" ;;
     final)   t=${1:-$TAG}
              python bench.py > gpurun_out/bench_${t}_final.json 2> gpurun_out/bench_${t}_final.err || return 1; tail -c 300 gpurun_out/bench_${t}_final.json; echo
              python bench.py --steps 20 --warmup 5 > gpurun_out/bench_${t}_20steps.json 2> gpurun_out/bench_${t}_20steps.err || return 1
