@@ -1667,6 +1667,47 @@ static int extract_inliers(const uvo_point2f* k1, const uvo_point2f* k2, const u
     for (int i = 0; i < n; i++) if (mask[i] != 0) { in1[k] = k1[i]; in2[k] = k2[i]; k++; }
     return k;
 }
+// One attempt of estimate_relative_pose's loop (VOU:143-156) on host points: the essential or the homography branch; *valid_inliers =
+// countNonZero(mask) after it (VOU:157).  R, t are written when the branch produced a pose.
+static uvo_status estimate_once(uvo_ctx* c, const uvo_point2f* k1, const uvo_point2f* k2, int n, const double* K, int use_essential, double* R, double* t,
+                                uvo_point2f* in1, uvo_point2f* in2, int* n_in, uint8_t* mask, int* valid_inliers)
+{
+    const uvo_params& p = c->p;
+    int ok = 0;
+    memset(mask, 0, n);
+    if (use_essential) {
+        double E[9];
+        UVO_TRY(mono_find_essential(c, k1, k2, n, K, p.ESSENTIAL_OUTLIER_METHOD, p.ESSENTIAL_CONFIDENCE, p.ESSENTIAL_THRESHOLD,
+                                    (int)p.ESSENTIAL_MAX_ITERS, E, mask, &ok));
+        *n_in = extract_inliers(k1, k2, mask, n, in1, in2);
+        int good = 0;
+        if (ok) UVO_TRY(mono_recover_pose(c, E, k1, k2, n, K, R, t, mask, &good));
+        else memset(mask, 0, n);          // OpenCV would throw on the empty E; the attempt simply fails here
+    } else {
+        double H[9];
+        UVO_TRY(mono_find_homography(c, k1, k2, n, p.HOMOGRAPHY_OUTLIER_METHOD, p.HOMOGRAPHY_THRESHOLD, (int)p.HOMOGRAPHY_MAX_ITERS,
+                                     p.HOMOGRAPHY_CONFIDENCE, H, mask, &ok));
+        *n_in = extract_inliers(k1, k2, mask, n, in1, in2);
+        int good = 0;
+        if (ok) UVO_TRY(mono_recover_pose_homography(c, H, k1, k2, n, K, p.HOMOGRAPHY_DISTANCE, R, t, &good));
+    }
+    int v = 0;
+    for (int i = 0; i < n; i++) v += mask[i] != 0;
+    *valid_inliers = v;
+    return UVO_OK;
+}
+// the acceptance test of VOU:157-164
+static bool estimate_accepted(const uvo_params& p, int valid_inliers, int n)
+{
+    const double valid_point_fraction = (double)valid_inliers / n;
+    return valid_point_fraction >= p.VPF_THRESHOLD && valid_inliers >= p.MIN_NUM_INLIERS;
+}
+static const char* bad_outlier_methods(const uvo_params& p)
+{
+    if ((p.ESSENTIAL_OUTLIER_METHOD != 4 && p.ESSENTIAL_OUTLIER_METHOD != 8) || (p.HOMOGRAPHY_OUTLIER_METHOD != 4 && p.HOMOGRAPHY_OUTLIER_METHOD != 8))
+        return "outlier methods must be 4 (LMEDS) or 8 (RANSAC)";
+    return nullptr;
+}
 // estimate_relative_pose (VOU:134-180).  use_essential is the reference's global (in/out); R, t are in/out.
 extern "C" uvo_status uvo_estimate_relative_pose(uvo_ctx* c, const uvo_point2f* k1, const uvo_point2f* k2, int n, const double* K,
                                                  int* use_essential, double* R, double* t, uvo_point2f* in1, uvo_point2f* in2, int* n_in,
@@ -1676,32 +1717,13 @@ try {
     (void)hipSetDevice(c->device);
     Range r_erp("uvo:estimate_relative_pose");
     const uvo_params& p = c->p;
-    if ((p.ESSENTIAL_OUTLIER_METHOD != 4 && p.ESSENTIAL_OUTLIER_METHOD != 8) || (p.HOMOGRAPHY_OUTLIER_METHOD != 4 && p.HOMOGRAPHY_OUTLIER_METHOD != 8))
-        return fail(c, UVO_INVALID_ARG, "outlier methods must be 4 (LMEDS) or 8 (RANSAC)");
+    if (const char* why = bad_outlier_methods(p)) return fail(c, UVO_INVALID_ARG, why);
     bool estimate_completed = false, switch_method = false;
     *success = 0;
     while (!estimate_completed) {
-        int valid_inliers = 0, ok = 0;
-        memset(mask, 0, n);
-        if (*use_essential) {
-            double E[9];
-            UVO_TRY(mono_find_essential(c, k1, k2, n, K, p.ESSENTIAL_OUTLIER_METHOD, p.ESSENTIAL_CONFIDENCE, p.ESSENTIAL_THRESHOLD,
-                                        (int)p.ESSENTIAL_MAX_ITERS, E, mask, &ok));
-            *n_in = extract_inliers(k1, k2, mask, n, in1, in2);
-            int good = 0;
-            if (ok) UVO_TRY(mono_recover_pose(c, E, k1, k2, n, K, R, t, mask, &good));
-            else memset(mask, 0, n);          // OpenCV would throw on the empty E; the attempt simply fails here
-        } else {
-            double H[9];
-            UVO_TRY(mono_find_homography(c, k1, k2, n, p.HOMOGRAPHY_OUTLIER_METHOD, p.HOMOGRAPHY_THRESHOLD, (int)p.HOMOGRAPHY_MAX_ITERS,
-                                         p.HOMOGRAPHY_CONFIDENCE, H, mask, &ok));
-            *n_in = extract_inliers(k1, k2, mask, n, in1, in2);
-            int good = 0;
-            if (ok) UVO_TRY(mono_recover_pose_homography(c, H, k1, k2, n, K, p.HOMOGRAPHY_DISTANCE, R, t, &good));
-        }
-        for (int i = 0; i < n; i++) valid_inliers += mask[i] != 0;
-        double valid_point_fraction = (double)valid_inliers / n;
-        if (valid_point_fraction >= p.VPF_THRESHOLD && valid_inliers >= p.MIN_NUM_INLIERS) { *success = 1; estimate_completed = true; }
+        int valid_inliers = 0;
+        UVO_TRY(estimate_once(c, k1, k2, n, K, *use_essential, R, t, in1, in2, n_in, mask, &valid_inliers));
+        if (estimate_accepted(p, valid_inliers, n)) { *success = 1; estimate_completed = true; }
         else {
             if (switch_method) break;
             switch_method = true;
@@ -1729,115 +1751,8 @@ try {
     c->mono_initialized = false; c->mono_use_essential = 1; c->mono_SF = 1.0; c->mono_n_prev = 0;
     const double I[9] = {1,0,0,0,1,0,0,0,1};
     memcpy(c->mono_R, I, sizeof(I)); c->mono_t[0] = c->mono_t[1] = c->mono_t[2] = 0;
-    c->mono_prev_kps.clear(); c->mono_kps.clear(); c->mono_matches.clear(); c->mono_mask.clear(); c->mono_good_pts.clear();
+    c->mono_mask.clear(); c->mono_good_pts.clear(); c->mono_dev_n = c->mono_dev_M = c->mono_dev_G = 0; c->mono_good_on_host = true; c->mono_matched = false;
     return UVO_OK;
-} UVO_ABI_CATCH(c)
-
-// mono loop body, visual_odometry_node::mono_VO (visual_odometry.h:227-245 init, 247-397 main loop, 126-140 output)
-extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h, int stride, int mem, double range, double dt,
-                                    uvo_mono_result* out)
-try {
-    if (!c || !img || !out) return UVO_INVALID_ARG;
-    if (!c->mono_cam_set) return fail(c, UVO_INVALID_ARG, "uvo_mono_set_camera has not been called");
-    if (c->mono_pipelined) return fail(c, UVO_INVALID_ARG, "uvo_mono_step after uvo_mono_submit: call uvo_mono_reset first (the previous frame is held by the pipeline)");
-    (void)hipSetDevice(c->device);
-    const uvo_params& p = c->p;
-    Range r_step("uvo:mono_step");
-    memset(out, 0, sizeof(*out));
-    c->mono_matches.clear(); c->mono_mask.clear(); c->mono_good_pts.clear();
-    UVO_TRY(wait_for_producer(c, c, mem));
-    UVO_TRY(surf_upload(c, 0, img, w, h, stride, mem));
-    UVO_TRY(detect_dispatch(c, 1));                                                        // VO:238 / VO:274
-    UVO_TRY(read_counts(c));
-    UVO_TRY(check_cand_overflow(c, 1));
-    const int n = c->h_counts[CN_NL];
-    out->n_kps = n;
-    c->kp_hint = n;
-    c->mono_kps.resize(n);
-    if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->mono_kps.data(), c->det[0].kps, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, c->stream));
-    UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    auto roll_state = [&]() -> uvo_status {                                                // VO:279-282 / VO:392-395
-        if (n) UVO_HIP_TRY(c, hipMemcpyAsync(c->d_as_descL[0], c->det[0].desc, sizeof(float) * c->desc_dim() * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
-        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        c->mono_prev_kps = c->mono_kps; c->mono_n_prev = n;
-        return UVO_OK;
-    };
-    if (!c->mono_initialized) {                                                            // VO:227-245
-        UVO_TRY(roll_state());
-        if (n >= p.MIN_NUM_FEATURES) c->mono_initialized = true;
-        return UVO_OK;
-    }
-    out->initialized = 1;
-    if (n < p.MIN_NUM_FEATURES) return roll_state();                                       // VO:276-284
-    // match_features 7-arg (VO:287 -> VOU:551-573)
-    int M = 0;
-    if (c->mono_n_prev > 0 && n > 0) {
-        UVO_TRY(match_knn2(c, c->d_as_descL[0], nullptr, c->mono_n_prev, c->det[0].desc, nullptr, n));
-        UVO_TRY(match_ratio_compact(c, nullptr, c->mono_n_prev, (float)p.LOWE_RATIO_THRESHOLD, c->d_matches[0], c->d_nmatch, c->cap));
-        UVO_TRY(read_counts(c));
-        M = c->h_counts[CN_M];
-        if (M > c->cap) return fail(c, UVO_CAPACITY, "match count exceeds max_kpts");
-        c->mono_matches.resize(M);
-        if (M) UVO_HIP_TRY(c, hipMemcpyAsync(c->mono_matches.data(), c->d_matches[0], sizeof(uvo_dmatch) * M, hipMemcpyDeviceToHost, c->stream));
-        UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    out->n_matches = M;
-    if (M < p.MIN_NUM_FEATURES) return roll_state();                                       // VO:299-307
-    std::vector<uvo_point2f> k1(M), k2(M), in1(M), in2(M);
-    for (int i = 0; i < M; i++) {                                                          // VOU:567-568
-        const uvo_keypoint& a = c->mono_prev_kps[c->mono_matches[i].queryIdx]; const uvo_keypoint& b = c->mono_kps[c->mono_matches[i].trainIdx];
-        k1[i] = uvo_point2f{a.x, a.y}; k2[i] = uvo_point2f{b.x, b.y};
-    }
-    c->mono_use_essential = select_estimation_method(k1.data(), k2.data(), M, p.DISTANCE);   // VO:310-317
-    int n_in = 0, success = 0;
-    c->mono_mask.assign(M, 0);
-    UVO_TRY(uvo_estimate_relative_pose(c, k1.data(), k2.data(), M, c->mono_K, &c->mono_use_essential, c->mono_R, c->mono_t,
-                                       in1.data(), in2.data(), &n_in, c->mono_mask.data(), &success));             // VO:323
-    out->success = success; out->used_essential = c->mono_use_essential; out->n_inliers = n_in;
-    int valid = success ? 1 : 0;                                                           // VO:335-344
-    if (success) {                                                                         // VO:351-376
-        const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
-        double P_prev[12], P_curr[12];
-        projection_matrix(I, z, c->mono_K, P_prev);
-        projection_matrix(c->mono_R, c->mono_t, c->mono_K, P_curr);
-        int G = 0;
-        if (n_in > 0) {
-            UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x1, in1.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, c->stream));
-            UVO_HIP_TRY(c, hipMemcpyAsync(c->d_x2, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, c->stream));
-            UVO_HIP_TRY(c, hipMemcpyAsync(c->d_xc, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, c->stream));
-            UVO_TRY(pose_triangulate_extract3d(c, 0, P_prev, P_curr, I, z, c->mono_R, c->mono_t, c->mono_K, c->mono_K, nullptr, n_in));   // VO:355-356
-            UVO_TRY(read_counts(c));
-            G = c->h_counts[CN_G];
-            c->mono_good_pts.resize((size_t)3 * G);
-            if (G) UVO_HIP_TRY(c, hipMemcpyAsync(c->mono_good_pts.data(), c->d_good_pts[0], sizeof(double) * 3 * G, hipMemcpyDeviceToHost, c->stream));
-            UVO_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        }
-        out->n_good3d = G;
-        if (G < p.MIN_NUM_3DPOINTS) valid = 0;                                             // VO:358
-        else {
-            // convert_3Dpoints_camera (VOU:46-63): the ORIGINAL rows whose transformed z is positive
-            std::vector<double> zs;
-            const double* R = c->mono_R; const double* t = c->mono_t;
-            for (int i = 0; i < G; i++) {
-                const double* q = &c->mono_good_pts[3 * (size_t)i];
-                double zt = (R[6]*q[0] + R[7]*q[1] + R[8]*q[2]) * 1.0 + t[2] * 1.0;
-                if (zt > 0) zs.push_back(q[2]);
-            }
-            out->n_front = (int)zs.size();
-            if (!zs.empty()) c->mono_SF = (float)range / compute_median(zs);               // compute_scale_factor (VOU:23-38)
-            else valid = 0;
-        }
-    }
-    // mono_output_computation (VO:126-140): -SF * R^T * t / dt as one gemm with alpha = (-SF) * (1/dt)
-    double alpha = (-c->mono_SF) * (1.0 / dt);
-    for (int i = 0; i < 3; i++) {
-        double acc = 0;
-        for (int k = 0; k < 3; k++) acc += c->mono_R[k*3 + i] * c->mono_t[k];
-        out->velocity[i] = acc * alpha;
-    }
-    out->published = 1; out->valid = valid; out->SF = c->mono_SF;
-    memcpy(out->R, c->mono_R, sizeof(out->R)); memcpy(out->t, c->mono_t, sizeof(out->t));
-    return roll_state();
 } UVO_ABI_CATCH(c)
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1858,6 +1773,195 @@ __global__ __launch_bounds__(256) void k_gather_mono_pairs(const uvo_dmatch* __r
     const uvo_keypoint a = prev_kps[m[i].queryIdx], b = kps[m[i].trainIdx];              // VOU:567-568
     x1[i] = uvo_point2f{a.x, a.y}; x2[i] = uvo_point2f{b.x, b.y};
 }
+
+// Stage B of one mono frame (VO:276-376 after the matching) on lane L's buffers and stream -- the lane's worker for a pipelined frame,
+// the calling thread for uvo_mono_step: fills job.mres / pose_written / sf_written.  The matched points are on the device (d_x1 / d_x2,
+// mirrored in pinned memory by k_mono_prep together with select_estimation_method's decision).  A frame whose method is the essential
+// matrix takes the device-resident chain (mono.hip: mono_essential_resident, two host syncs); homography-first frames and second
+// attempts (VOU:165-178) take the host-pointer operators on the pinned mirrors.  Keypoints, matches and good points are NOT copied to the
+// host: uvo_mono_get reads them from the lane's buffers when asked.
+static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok)
+{
+    Ctx::BJob& j = L->job;
+    const Ctx* m = L->master ? L->master : L;
+    const uvo_params& p = L->p;
+    j.st = UVO_OK; j.err.clear(); j.pose_written = j.sf_written = false;
+    memset(&j.mres, 0, sizeof(j.mres));
+    L->mono_mask.clear(); L->mono_good_pts.clear();
+    L->mono_dev_n = L->mono_dev_M = L->mono_dev_G = 0; L->mono_good_on_host = false;
+    if (!stage_a_ok) { j.st = UVO_HIP_ERROR; j.err = "stage A of the frame failed"; return; }
+    Range r_b("uvo:mono estimate_relative_pose + triangulation + scale");
+    auto hip_ok = [&](hipError_t e) { if (e != hipSuccess && j.st == UVO_OK) { j.st = UVO_HIP_ERROR; j.err = hipGetErrorString(e); } return e == hipSuccess; };
+    const int* hc = L->h_countsA[0];
+    const int cap = L->cap;
+    if (hc[CN_CAND0] > cap) { j.st = UVO_CAPACITY; j.err = "SURF found more keypoints than the context's max_kpts; results would be order-dependent"; return; }
+    if (hc[CN_ORI_DROP] != 0) { j.st = UVO_INVALID_ARG; j.err = "SURF orientation: a keypoint had no gradient sample inside the image; OpenCV drops such keypoints, which this build does not do"; return; }
+    const int n = hc[CN_NL], M = L->mono_matched ? hc[CN_M] : 0;
+    j.mres.initialized = 1; j.mres.n_kps = n;
+    L->mono_dev_n = n;
+    hipStream_t st = L->stream;
+    if (n < p.MIN_NUM_FEATURES) return;                                                    // VO:276-284
+    if (M > cap) { j.st = UVO_CAPACITY; j.err = "match count exceeds max_kpts"; return; }
+    j.mres.n_matches = M; L->mono_dev_M = M;
+    if (M < p.MIN_NUM_FEATURES) return;                                                    // VO:299-307
+    if (const char* why = bad_outlier_methods(p)) { j.st = UVO_INVALID_ARG; j.err = why; return; }
+    const uvo_point2f *k1 = nullptr, *k2 = nullptr;
+    int use_essential = mono_prep_method(L, M, &k1, &k2);                                  // VO:310-317 (select_estimation_method, on the device)
+    if (use_essential < 0) { j.st = UVO_HIP_ERROR; j.err = "mono pose stage: select_estimation_method's kernel did not report"; return; }
+    L->mono_mask.assign(M, 0);
+    // R, t are in/out in the reference (kept when no estimator writes them): run on a sentinel and report whether they were written
+    double R[9], t[3];
+    const double kSentinel = -7.0e300;
+    for (int i = 0; i < 9; i++) R[i] = kSentinel;
+    for (int i = 0; i < 3; i++) t[i] = kSentinel;
+    int n_in = 0, success = 0;
+    bool resident = false;                       // the accepted estimate came from the device-resident chain: triangulation and scale are done
+    MonoResident mr;
+    std::vector<uvo_point2f> in1, in2;           // extract_inliers' output of a host-pointer attempt
+    for (int attempt = 0; attempt < 2 && !success; attempt++) {                            // estimate_relative_pose (VOU:134-180)
+        int valid_inliers = 0;
+        if (use_essential && attempt == 0) {
+            j.st = mono_essential_resident(L, M, m->mono_K, p.ESSENTIAL_OUTLIER_METHOD, p.ESSENTIAL_CONFIDENCE, p.ESSENTIAL_THRESHOLD, (int)p.ESSENTIAL_MAX_ITERS, &mr);
+            if (j.st != UVO_OK) { j.err = L->err; return; }
+            n_in = mr.n_in;
+            if (mr.ok) { memcpy(R, mr.R, sizeof(R)); memcpy(t, mr.t, sizeof(t)); memcpy(L->mono_mask.data(), mr.mask, (size_t)M); valid_inliers = mr.valid_inliers; }
+            else memset(L->mono_mask.data(), 0, (size_t)M);
+            resident = true;
+        } else {
+            in1.resize(M); in2.resize(M);
+            j.st = estimate_once(L, k1, k2, M, m->mono_K, use_essential, R, t, in1.data(), in2.data(), &n_in, L->mono_mask.data(), &valid_inliers);
+            if (j.st != UVO_OK) { j.err = L->err; return; }
+            resident = false;
+        }
+        if (estimate_accepted(p, valid_inliers, M)) success = 1;
+        else if (attempt == 0) use_essential = !use_essential;                             // VOU:165-178: the other method, once
+    }
+    j.pose_written = R[0] != kSentinel;
+    if (j.pose_written) { memcpy(j.R, R, sizeof(R)); memcpy(j.t, t, sizeof(t)); }
+    j.mres.success = success; j.mres.used_essential = use_essential; j.mres.n_inliers = n_in;
+    j.mres.published = 1;
+    int valid = success ? 1 : 0;                                                           // VO:335-344
+    if (success) {                                                                         // VO:351-376 (success implies the pose was written)
+        int G = 0, n_front = 0;
+        std::vector<double> zs;
+        if (resident) {                                                                    // triangulated, filtered and projected on the device already
+            G = mr.G; n_front = mr.n_front;
+            L->mono_dev_G = G;
+            zs.assign(mr.zs, mr.zs + n_front);
+        } else {
+            const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
+            double P_prev[12], P_curr[12];
+            projection_matrix(I, z, m->mono_K, P_prev);
+            projection_matrix(R, t, m->mono_K, P_curr);
+            if (n_in > 0) {
+                if (!hip_ok(hipMemcpyAsync(L->d_x1, in1.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, st))) return;
+                if (!hip_ok(hipMemcpyAsync(L->d_x2, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, st))) return;
+                if (!hip_ok(hipMemcpyAsync(L->d_xc, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, st))) return;
+                if ((j.st = pose_triangulate_extract3d(L, 0, P_prev, P_curr, I, z, R, t, m->mono_K, m->mono_K, nullptr, n_in)) != UVO_OK) { j.err = L->err; return; }   // VO:355-356
+                if ((j.st = read_counts(L)) != UVO_OK) { j.err = L->err; return; }
+                G = L->h_counts[CN_G];
+                L->mono_good_pts.resize((size_t)3 * G);
+                if (G && !hip_ok(hipMemcpyAsync(L->mono_good_pts.data(), L->d_good_pts[0], sizeof(double) * 3 * G, hipMemcpyDeviceToHost, st))) return;
+                if (!hip_ok(host_sync(L, st))) return;
+            }
+            L->mono_good_on_host = true;
+            for (int i = 0; i < G; i++) {                                                  // convert_3Dpoints_camera (VOU:46-63)
+                const double* q = &L->mono_good_pts[3 * (size_t)i];
+                double zt = (R[6]*q[0] + R[7]*q[1] + R[8]*q[2]) * 1.0 + t[2] * 1.0;
+                if (zt > 0) zs.push_back(q[2]);
+            }
+            n_front = (int)zs.size();
+        }
+        j.mres.n_good3d = G;
+        if (G < p.MIN_NUM_3DPOINTS) valid = 0;                                             // VO:358
+        else {
+            j.mres.n_front = n_front;
+            if (!zs.empty()) { j.SF = (float)j.range / compute_median(zs); j.sf_written = true; }   // compute_scale_factor (VOU:23-38)
+            else valid = 0;
+        }
+    } else L->mono_good_on_host = true;                                                    // (no good points: the empty host vector is the answer)
+    j.mres.valid = valid;
+}
+// What uvo_mono_collect / uvo_mono_step apply, in frame order, from a finished stage B: R, t (kept when no estimator wrote them), the
+// scale factor, the reference's `use_essential`, and the published velocity (mono_output_computation, VO:126-140)
+static void apply_mono_result(uvo_ctx* c, const Ctx::BJob& j, double dt, uvo_mono_result* out)
+{
+    *out = j.mres;
+    if (j.mres.n_kps > 0) c->kp_hint = j.mres.n_kps;          // sizes the descriptor launch's small-window grid of the frames to come
+    if (j.pose_written) { memcpy(c->mono_R, j.R, sizeof(c->mono_R)); memcpy(c->mono_t, j.t, sizeof(c->mono_t)); }
+    if (j.sf_written) c->mono_SF = j.SF;
+    c->mono_use_essential = j.mres.published ? j.mres.used_essential : c->mono_use_essential;
+    if (j.mres.published) {
+        // -SF * R^T * t / dt as one gemm with alpha = (-SF) * (1/dt)
+        double alpha = (-c->mono_SF) * (1.0 / dt);
+        for (int i = 0; i < 3; i++) {
+            double acc = 0;
+            for (int k = 0; k < 3; k++) acc += c->mono_R[k*3 + i] * c->mono_t[k];
+            out->velocity[i] = acc * alpha;
+        }
+        out->SF = c->mono_SF;
+        memcpy(out->R, c->mono_R, sizeof(out->R)); memcpy(out->t, c->mono_t, sizeof(out->t));
+    }
+}
+
+// mono loop body, visual_odometry_node::mono_VO (visual_odometry.h:227-245 init, 247-397 main loop, 126-140 output), one frame at a
+// time on lane 0: the previous frame's keypoints and descriptors are rolled into d_as_kpsL[0] / d_as_descL[0] (VO:279-282 / 392-395).
+// Detection, matching, the point gather and select_estimation_method's kernel are queued without a host sync; the counts are read
+// once, then the pose stage runs on the calling thread (run_mono_stage_b).
+extern "C" uvo_status uvo_mono_step(uvo_ctx* c, const uint8_t* img, int w, int h, int stride, int mem, double range, double dt,
+                                    uvo_mono_result* out)
+try {
+    if (!c || !img || !out) return UVO_INVALID_ARG;
+    if (!c->mono_cam_set) return fail(c, UVO_INVALID_ARG, "uvo_mono_set_camera has not been called");
+    if (c->mono_pipelined) return fail(c, UVO_INVALID_ARG, "uvo_mono_step after uvo_mono_submit: call uvo_mono_reset first (the previous frame is held by the pipeline)");
+    (void)hipSetDevice(c->device);
+    const uvo_params& p = c->p;
+    Range r_step("uvo:mono_step");
+    memset(out, 0, sizeof(*out));
+    c->mono_mask.clear(); c->mono_good_pts.clear();
+    c->mono_dev_n = c->mono_dev_M = c->mono_dev_G = 0; c->mono_good_on_host = true;
+    UVO_TRY(wait_for_producer(c, c, mem));
+    UVO_TRY(surf_upload(c, 0, img, w, h, stride, mem));
+    UVO_TRY(detect_dispatch(c, 1));                                                        // VO:238 / VO:274
+    // match_features 7-arg (VO:287 -> VOU:551-573) against the rolled previous frame: query = previous, train = this frame (its count
+    // stays on the device), ratio test, the matched point pairs, select_estimation_method -- whether the gates let the frame use them
+    // is decided below, from the counts
+    c->mono_matched = c->mono_initialized && c->mono_n_prev > 0;
+    if (c->mono_matched) {
+        UVO_TRY(match_knn2(c, c->d_as_descL[0], nullptr, c->mono_n_prev, c->det[0].desc, c->det[0].n, c->cap));
+        UVO_TRY(match_ratio_compact(c, nullptr, c->mono_n_prev, (float)p.LOWE_RATIO_THRESHOLD, c->d_matches[0], c->d_nmatch, c->cap));
+        hipLaunchKernelGGL(k_gather_mono_pairs, dim3((c->cap + 255) / 256), dim3(256), 0, c->stream, c->d_matches[0], c->d_counts + CN_M, c->cap,
+                           c->d_as_kpsL[0], c->det[0].kps, c->d_x1, c->d_x2);
+        UVO_HIP_TRY(c, hipGetLastError());
+        UVO_TRY(mono_prep_launch(c, c->stream, c->mono_K, p.DISTANCE));
+    }
+    UVO_HIP_TRY(c, hipMemcpyAsync(c->h_countsA[0], c->d_counts, sizeof(int) * CN_TOTAL, hipMemcpyDeviceToHost, c->stream));
+    UVO_HIP_TRY(c, host_sync(c, c->stream));
+    memcpy(c->h_counts, c->h_countsA[0], sizeof(int) * CN_TOTAL);
+    UVO_TRY(check_cand_overflow(c, 1));
+    const int n = c->h_counts[CN_NL];
+    out->n_kps = n;
+    c->kp_hint = n;
+    c->mono_dev_n = n;
+    auto roll_state = [&]() -> uvo_status {                                                // VO:279-282 / VO:392-395 (stream-ordered: the next frame's kernels follow)
+        if (n) {
+            UVO_HIP_TRY(c, hipMemcpyAsync(c->d_as_descL[0], c->det[0].desc, sizeof(float) * c->desc_dim() * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+            UVO_HIP_TRY(c, hipMemcpyAsync(c->d_as_kpsL[0], c->det[0].kps, sizeof(uvo_keypoint) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+        }
+        c->mono_n_prev = n;
+        return UVO_OK;
+    };
+    if (!c->mono_initialized) {                                                            // VO:227-245
+        UVO_TRY(roll_state());
+        if (n >= p.MIN_NUM_FEATURES) c->mono_initialized = true;
+        return UVO_OK;
+    }
+    c->job.kind = 1; c->job.range = range;
+    run_mono_stage_b(c, true);                                                             // VO:276-376
+    if (c->job.st != UVO_OK) { const uvo_status st_ = c->job.st; c->err = c->job.err; return st_; }
+    apply_mono_result(c, c->job, dt, out);
+    return roll_state();
+} UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_mono_submit(uvo_ctx* c, const uint8_t* img, int w, int h, int stride, int mem, double range)
 try {
@@ -1907,6 +2011,8 @@ try {
     hipLaunchKernelGGL(k_gather_mono_pairs, dim3((cap + 255) / 256), dim3(256), 0, st, L->d_matches[0], cn + CN_M, cap,
                        P->det[0].kps, L->det[0].kps, L->d_x1, L->d_x2);
     UVO_HIP_TRY(c, hipGetLastError());
+    LANE_TRY(mono_prep_launch(L, st, c->mono_K, p.DISTANCE));                              // normalised points, select_estimation_method, pinned mirrors
+    L->mono_matched = true;
     if (P != L) { UVO_HIP_TRY(c, hipEventRecord(P->evPrevRead, st)); P->prev_read_pending = true; }
     UVO_HIP_TRY(c, hipMemcpyAsync(L->h_countsA[0], L->d_counts, sizeof(int) * CN_TOTAL, hipMemcpyDeviceToHost, st));
     UVO_HIP_TRY(c, hipEventRecord(L->evA[0], st));
@@ -1922,88 +2028,6 @@ try {
     return UVO_OK;
 #undef LANE_TRY
 } UVO_ABI_CATCH(c)
-
-// Stage B of one mono frame on the lane's worker (VO:276-376 after the matching): fills job.mres / pose_written / sf_written
-static void run_mono_stage_b(uvo_ctx* L, bool stage_a_ok)
-{
-    Ctx::BJob& j = L->job;
-    const Ctx* m = L->master ? L->master : L;
-    const uvo_params& p = L->p;
-    j.st = UVO_OK; j.err.clear(); j.pose_written = j.sf_written = false;
-    memset(&j.mres, 0, sizeof(j.mres));
-    L->mono_matches.clear(); L->mono_mask.clear(); L->mono_good_pts.clear(); L->mono_kps.clear();
-    if (!stage_a_ok) { j.st = UVO_HIP_ERROR; j.err = "stage A of the frame failed"; return; }
-    Range r_b("uvo:mono estimate_relative_pose + triangulation + scale");
-    auto hip_ok = [&](hipError_t e) { if (e != hipSuccess && j.st == UVO_OK) { j.st = UVO_HIP_ERROR; j.err = hipGetErrorString(e); } return e == hipSuccess; };
-    const int* hc = L->h_countsA[0];
-    const int cap = L->cap;
-    if (hc[CN_CAND0] > cap) { j.st = UVO_CAPACITY; j.err = "SURF found more keypoints than the context's max_kpts; results would be order-dependent"; return; }
-    const int n = hc[CN_NL], M = hc[CN_M];
-    j.mres.initialized = 1; j.mres.n_kps = n;
-    hipStream_t st = L->stream;
-    L->mono_kps.resize(n);
-    if (n && !hip_ok(hipMemcpyAsync(L->mono_kps.data(), L->det[0].kps, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, st))) return;
-    if (n < p.MIN_NUM_FEATURES) { (void)hip_ok(host_sync(L, st)); return; }       // VO:276-284
-    if (M > cap) { j.st = UVO_CAPACITY; j.err = "match count exceeds max_kpts"; return; }
-    j.mres.n_matches = M;
-    L->mono_matches.resize(M);
-    std::vector<uvo_point2f> k1(M), k2(M), in1(M), in2(M);
-    if (M) {
-        if (!hip_ok(hipMemcpyAsync(L->mono_matches.data(), L->d_matches[0], sizeof(uvo_dmatch) * M, hipMemcpyDeviceToHost, st))) return;
-        if (!hip_ok(hipMemcpyAsync(k1.data(), L->d_x1, sizeof(uvo_point2f) * M, hipMemcpyDeviceToHost, st))) return;
-        if (!hip_ok(hipMemcpyAsync(k2.data(), L->d_x2, sizeof(uvo_point2f) * M, hipMemcpyDeviceToHost, st))) return;
-    }
-    if (!hip_ok(host_sync(L, st))) return;
-    if (M < p.MIN_NUM_FEATURES) return;                                                    // VO:299-307
-    int use_essential = select_estimation_method(k1.data(), k2.data(), M, p.DISTANCE);   // VO:310-317
-    int n_in = 0, success = 0;
-    L->mono_mask.assign(M, 0);
-    // R, t are in/out in the reference (kept when no estimator writes them): run on a sentinel and report whether they were written
-    double R[9], t[3];
-    const double kSentinel = -7.0e300;
-    for (int i = 0; i < 9; i++) R[i] = kSentinel;
-    for (int i = 0; i < 3; i++) t[i] = kSentinel;
-    j.st = uvo_estimate_relative_pose(L, k1.data(), k2.data(), M, m->mono_K, &use_essential, R, t, in1.data(), in2.data(), &n_in,
-                                      L->mono_mask.data(), &success);                      // VO:323
-    if (j.st != UVO_OK) { j.err = L->err; return; }
-    j.pose_written = R[0] != kSentinel;
-    if (j.pose_written) { memcpy(j.R, R, sizeof(R)); memcpy(j.t, t, sizeof(t)); }
-    j.mres.success = success; j.mres.used_essential = use_essential; j.mres.n_inliers = n_in;
-    j.mres.published = 1;
-    int valid = success ? 1 : 0;                                                           // VO:335-344
-    if (success) {                                                                         // VO:351-376 (success implies the pose was written)
-        const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
-        double P_prev[12], P_curr[12];
-        projection_matrix(I, z, m->mono_K, P_prev);
-        projection_matrix(R, t, m->mono_K, P_curr);
-        int G = 0;
-        if (n_in > 0) {
-            if (!hip_ok(hipMemcpyAsync(L->d_x1, in1.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, st))) return;
-            if (!hip_ok(hipMemcpyAsync(L->d_x2, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, st))) return;
-            if (!hip_ok(hipMemcpyAsync(L->d_xc, in2.data(), sizeof(uvo_point2f) * n_in, hipMemcpyHostToDevice, st))) return;
-            if ((j.st = pose_triangulate_extract3d(L, 0, P_prev, P_curr, I, z, R, t, m->mono_K, m->mono_K, nullptr, n_in)) != UVO_OK) { j.err = L->err; return; }   // VO:355-356
-            if ((j.st = read_counts(L)) != UVO_OK) { j.err = L->err; return; }
-            G = L->h_counts[CN_G];
-            L->mono_good_pts.resize((size_t)3 * G);
-            if (G && !hip_ok(hipMemcpyAsync(L->mono_good_pts.data(), L->d_good_pts[0], sizeof(double) * 3 * G, hipMemcpyDeviceToHost, st))) return;
-            if (!hip_ok(host_sync(L, st))) return;
-        }
-        j.mres.n_good3d = G;
-        if (G < p.MIN_NUM_3DPOINTS) valid = 0;                                             // VO:358
-        else {
-            std::vector<double> zs;                                                        // convert_3Dpoints_camera (VOU:46-63)
-            for (int i = 0; i < G; i++) {
-                const double* q = &L->mono_good_pts[3 * (size_t)i];
-                double zt = (R[6]*q[0] + R[7]*q[1] + R[8]*q[2]) * 1.0 + t[2] * 1.0;
-                if (zt > 0) zs.push_back(q[2]);
-            }
-            j.mres.n_front = (int)zs.size();
-            if (!zs.empty()) { j.SF = (float)j.range / compute_median(zs); j.sf_written = true; }   // compute_scale_factor (VOU:23-38)
-            else valid = 0;
-        }
-    }
-    j.mres.valid = valid;
-}
 
 extern "C" uvo_status uvo_mono_collect(uvo_ctx* c, double dt, uvo_mono_result* out)
 try {
@@ -2032,39 +2056,34 @@ try {
     }
     const Ctx::BJob& j = L->job;
     if (j.st != UVO_OK) return fail(c, j.st, j.err.c_str());
-    *out = j.mres;
-    if (j.mres.n_kps > 0) c->kp_hint = j.mres.n_kps;          // sizes the descriptor launch's small-window grid of the frames to come
     // (uvo_mono_get reads the frame's intermediates from this lane, c->last_lane, until the lane is submitted to again)
-    if (j.pose_written) { memcpy(c->mono_R, j.R, sizeof(c->mono_R)); memcpy(c->mono_t, j.t, sizeof(c->mono_t)); }
-    if (j.sf_written) c->mono_SF = j.SF;
-    c->mono_use_essential = j.mres.published ? j.mres.used_essential : c->mono_use_essential;
-    if (j.mres.published) {
-        // mono_output_computation (VO:126-140): -SF * R^T * t / dt as one gemm with alpha = (-SF) * (1/dt)
-        double alpha = (-c->mono_SF) * (1.0 / dt);
-        for (int i = 0; i < 3; i++) {
-            double acc = 0;
-            for (int k = 0; k < 3; k++) acc += c->mono_R[k*3 + i] * c->mono_t[k];
-            out->velocity[i] = acc * alpha;
-        }
-        out->SF = c->mono_SF;
-        memcpy(out->R, c->mono_R, sizeof(out->R)); memcpy(out->t, c->mono_t, sizeof(out->t));
-    }
+    apply_mono_result(c, j, dt, out);
     return UVO_OK;
 } UVO_ABI_CATCH(c)
 
+// last frame's intermediates.  Keypoints, matches and (after the device-resident pose chain) the good points live in the frame's lane
+// until that lane is submitted to again: they are copied out here, when asked for, not once per frame.
 extern "C" int uvo_mono_get(uvo_ctx* c, const char* what, void* out, int cap_bytes)
 try {
     if (!c || !what || !out) return 0;
-    const void* src = nullptr; size_t nb = 0; int count = 0;
+    (void)hipSetDevice(c->device);
+    const void* src = nullptr; size_t nb = 0; int count = 0; bool on_device = false;
     std::string w(what);
     const Ctx* f = c->mono_pipelined ? c->lanes[c->last_lane] : c;       // the lane of the last collected frame
-    if (w == "kps") { src = f->mono_kps.data(); count = (int)f->mono_kps.size(); nb = (size_t)count * sizeof(uvo_keypoint); }
-    else if (w == "matches") { src = f->mono_matches.data(); count = (int)f->mono_matches.size(); nb = (size_t)count * sizeof(uvo_dmatch); }
+    if (w == "kps") { src = f->det[0].kps; count = f->mono_dev_n; nb = (size_t)count * sizeof(uvo_keypoint); on_device = true; }
+    else if (w == "matches") { src = f->d_matches[0]; count = f->mono_dev_M; nb = (size_t)count * sizeof(uvo_dmatch); on_device = true; }
     else if (w == "mask") { src = f->mono_mask.data(); count = (int)f->mono_mask.size(); nb = (size_t)count; }
-    else if (w == "good_pts") { src = f->mono_good_pts.data(); count = (int)f->mono_good_pts.size() / 3; nb = (size_t)count * 3 * sizeof(double); }
+    else if (w == "good_pts") {
+        if (f->mono_good_on_host) { src = f->mono_good_pts.data(); count = (int)f->mono_good_pts.size() / 3; }
+        else { src = f->d_good_pts[0]; count = f->mono_dev_G; on_device = true; }
+        nb = (size_t)count * 3 * sizeof(double);
+    }
     else return 0;
     if (nb > (size_t)cap_bytes) return -count;
-    if (nb) memcpy(out, src, nb);
+    if (nb) {
+        if (on_device) { if (hipMemcpy(out, src, nb, hipMemcpyDeviceToHost) != hipSuccess) return 0; }
+        else memcpy(out, src, nb);
+    }
     return count;
 } UVO_ABI_CATCH_RET(c, 0)
 

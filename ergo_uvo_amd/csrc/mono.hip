@@ -421,11 +421,12 @@ __device__ void block_sort_median(float* s_err, int n, int npow2, double* out)
 }
 
 __global__ __launch_bounds__(256) void k_e_score(const double* q1, const double* q2, int n, const double* models, const int* nmodels,
-                                                 int mode, float thr2, int npow2, int* counts, double* medians)
+                                                 int mode, float thr2, int npow2, int* counts, double* medians, int* nmodels_host = nullptr)
 {
     extern __shared__ float s_err[];
     __shared__ int s_cnt;
     const int m = blockIdx.x, hyp = blockIdx.y, tid = threadIdx.x;
+    if (m == 0 && tid == 0 && nmodels_host) nmodels_host[hyp] = nmodels[hyp];       // (counts / medians may be pinned host memory too: the host's scan reads them without a copy)
     if (m >= nmodels[hyp]) return;
     double E[9];
     for (int k = 0; k < 9; k++) E[k] = models[(size_t)hyp * 90 + m * 9 + k];
@@ -570,6 +571,13 @@ struct MonoWs {                       // device workspace of the mono stage, own
     Pinned<float> h_src, h_dst;                    // pixel points on their way to src / dst
     Pinned<uint8_t> h_mask;                        // masks in both directions
     Pinned<int> h_good;                            // recoverPose's four counts
+    // the loop's pose stage with its points resident on the device (mono_essential_resident)
+    uvo_point2f *in1 = nullptr, *in2 = nullptr;    // extract_inliers' output (cap each)
+    int* pick = nullptr;                           // [0] best candidate of recoverPose, [1] n_in
+    Pinned<uvo_point2f> h_x1, h_x2;                // the frame's matched points, mirrored by k_mono_prep
+    Pinned<int> h_prep;                            // k_mono_prep: [0] use_essential of select_estimation_method, [1] M it saw
+    Pinned<int> h_pick;                            // k_mono_pick: best, good[4], n_in, valid inliers; k_mono_scale: G, n_front
+    Pinned<double> h_zs;                           // z of the points convert_3Dpoints_camera keeps (cap)
 };
 
 void mono_ws_free(Ctx* c);
@@ -586,12 +594,15 @@ static MonoWs* mono_ws(Ctx* c)
               hipMalloc((void**)&w->counts, sizeof(int) * kMaxHyp * 10) == hipSuccess &&
               hipMalloc((void**)&w->medians, sizeof(double) * kMaxHyp * 10) == hipSuccess &&
               hipMalloc((void**)&w->masks, 5 * cap) == hipSuccess && hipMalloc((void**)&w->good, sizeof(int) * 4) == hipSuccess &&
-              hipMalloc((void**)&w->best, sizeof(double) * 9) == hipSuccess;
+              hipMalloc((void**)&w->best, sizeof(double) * 9) == hipSuccess &&
+              hipMalloc((void**)&w->in1, sizeof(uvo_point2f) * cap) == hipSuccess && hipMalloc((void**)&w->in2, sizeof(uvo_point2f) * cap) == hipSuccess &&
+              hipMalloc((void**)&w->pick, sizeof(int) * 4) == hipSuccess;
     if (!ok) { delete w; return nullptr; }
     ok = w->h_subsets.resize(kMaxHyp * 5) && w->h_nmodels.resize(kMaxHyp) && w->h_counts.resize(kMaxHyp * 10) &&
          w->h_medians.resize(kMaxHyp * 10) && w->h_models.resize((size_t)kMaxHyp * 90) &&
          w->h_q1.resize(2 * cap + 2) && w->h_q2.resize(2 * cap + 2) && w->h_src.resize(2 * cap) && w->h_dst.resize(2 * cap) &&
-         w->h_mask.resize(cap) && w->h_good.resize(4);
+         w->h_mask.resize(cap) && w->h_good.resize(4) && w->h_x1.resize(cap) && w->h_x2.resize(cap) && w->h_prep.resize(4) && w->h_pick.resize(16) &&
+         w->h_zs.resize(cap);
     if (!ok) { c->mono_ws = w; mono_ws_free(c); return nullptr; }
     c->mono_ws = w;
     return w;
@@ -600,10 +611,11 @@ void mono_ws_free(Ctx* c)
 {
     MonoWs* w = static_cast<MonoWs*>(c->mono_ws);
     if (!w) return;
-    void* ptrs[] = { w->q1, w->q2, w->src, w->dst, w->subsets, w->models, w->nmodels, w->counts, w->medians, w->masks, w->good, w->best };
+    void* ptrs[] = { w->q1, w->q2, w->src, w->dst, w->subsets, w->models, w->nmodels, w->counts, w->medians, w->masks, w->good, w->best, w->in1, w->in2, w->pick };
     for (void* p : ptrs) (void)hipFree(p);
     w->h_subsets.release(); w->h_nmodels.release(); w->h_counts.release(); w->h_medians.release(); w->h_models.release();
     w->h_q1.release(); w->h_q2.release(); w->h_src.release(); w->h_dst.release(); w->h_mask.release(); w->h_good.release();
+    w->h_x1.release(); w->h_x2.release(); w->h_prep.release(); w->h_pick.release(); w->h_zs.release();
     delete w;
     c->mono_ws = nullptr;
 }
@@ -1262,6 +1274,254 @@ uvo_status mono_recover_pose_homography(Ctx* c, const double* H, const uvo_point
         for (int k = 0; k < 3; k++) t[k] = tb[k] * inv;
     }
     *max_good_out = max_good;
+    return UVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// The mono loop's pose stage with its points RESIDENT ON THE DEVICE (round 5).  Until round 4 the lane's worker copied the M matches
+// and both point lists to the host, called the host-pointer operator (which uploaded them again, twice: findEssentialMat and
+// recoverPose each normalised on the host), downloaded the mask, compacted the inliers on the host and uploaded them three more times
+// for the triangulation -- eight host syncs per frame.  Here:
+//   k_mono_prep     (tail of the frame's stage A) normalised points q1, q2 (findEssentialMat: (p - c) / f in double) from the matched
+//                   points the gather kernel left in d_x1 / d_x2; select_estimation_method's decision "median displacement < DISTANCE"
+//                   from one count and the two values next to the threshold (VO_utility.cpp:725-748, math_utility.cpp:65-86: exactly
+//                   the comparison the sorted median would give); the points mirrored into pinned memory for the host-side pieces
+//                   that want them (checkSubset of the homography sampler, its refit)
+//   essential first (the frame's method is E): subsets by the host's cv::RNG replay (no points needed) read from pinned memory,
+//                   k_fivepoint_hyp + k_e_score with counts / medians written straight into pinned memory -- ONE host sync -- the
+//                   host's scan, then without another sync: k_model_mask, recoverPose's four candidates (decomposeEssentialMat on
+//                   the host from the mirrored model), k_mono_pick (the winning candidate by recoverPose's >= chain, extract_inliers
+//                   as an ordered compaction, the valid-inlier count), triangulatePoints + extract_3Dpoints on the compacted pairs
+//                   with the candidate chosen ON THE DEVICE, convert_3Dpoints_camera's z list -- the SECOND and last host sync.
+// Two syncs instead of eight; nothing is uploaded.  Frames whose first method is the homography, and second attempts after a failed
+// acceptance test (VO_utility.cpp:165-178), take the host-pointer operators as before, on the pinned mirrors.  Same kernels, same
+// operands, same order: the results are those of the host-pointer path bit for bit (tests/test_gpu_parity.py, test_gpu_configs.py).
+// ------------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_mono_prep(const uvo_point2f* __restrict__ x1, const uvo_point2f* __restrict__ x2, const int* __restrict__ count, int cap,
+                                                    double ax, double bx, double ay, double by, int distance,
+                                                    double* __restrict__ q1, double* __restrict__ q2, uvo_point2f* __restrict__ h_x1, uvo_point2f* __restrict__ h_x2,
+                                                    int* __restrict__ h_prep)
+{
+    const int tid = threadIdx.x, M = min(*count, cap);
+    const double D = (double)distance;
+    int lt = 0; double max_lt = -1.0, min_ge = DBL_MAX;
+    for (int i = tid; i < M; i += 1024) {
+        const uvo_point2f a = x1[i], b = x2[i];
+        q1[2*i] = a.x * ax + bx; q1[2*i + 1] = a.y * ay + by;
+        q2[2*i] = b.x * ax + bx; q2[2*i + 1] = b.y * ay + by;
+        h_x1[i] = a; h_x2[i] = b;
+        const double dx = a.x - b.x, dy = a.y - b.y;                 // float differences, as VO_utility.cpp:733-734
+        const double d = sqrt(dx * dx + dy * dy);
+        if (d < D) { lt++; max_lt = d > max_lt ? d : max_lt; } else min_ge = d < min_ge ? d : min_ge;
+    }
+    __shared__ int s_lt[16]; __shared__ double s_max[16], s_min[16];
+    for (int o = 32; o > 0; o >>= 1) {
+        lt += __shfl_down(lt, o);
+        const double m1 = __shfl_down(max_lt, o), m2 = __shfl_down(min_ge, o);
+        max_lt = m1 > max_lt ? m1 : max_lt; min_ge = m2 < min_ge ? m2 : min_ge;
+    }
+    if ((tid & 63) == 0) { s_lt[tid >> 6] = lt; s_max[tid >> 6] = max_lt; s_min[tid >> 6] = min_ge; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < 16; k++) { lt += s_lt[k]; max_lt = s_max[k] > max_lt ? s_max[k] : max_lt; min_ge = s_min[k] < min_ge ? s_min[k] : min_ge; }
+        // compute_median (math_utility.cpp:65-86) of the M distances against DISTANCE, without sorting them: the sorted vector has its
+        // first `lt` entries below D.  Odd M: v[M/2] < D iff lt > M/2.  Even M: (v[mid-1] + v[mid]) / 2.0 with mid = M/2 -- both below
+        // D (lt > mid), both at or above it (lt < mid), or exactly the two values either side of D (lt == mid).
+        bool below;
+        const int mid = M / 2;
+        if (M == 0) below = 0.0 < D;                                  // compute_median of an empty vector returns 0.0
+        else if (M & 1) below = lt > mid;
+        else below = lt > mid ? true : (lt < mid ? false : (max_lt + min_ge) / 2.0 < D);
+        h_prep[1] = M;
+        __threadfence_system();
+        h_prep[0] = below ? 0 : 1;                                    // select_estimation_method: true = essential
+    }
+}
+uvo_status mono_prep_launch(Ctx* c, hipStream_t st, const double* K, int distance)
+{
+    MonoWs* w = mono_ws(c);
+    if (!w) { c->err = "mono workspace allocation failed"; return UVO_HIP_ERROR; }
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double ax = 1. / fx, bx = -cx * ax, ay = 1. / fy, by = -cy * ay;
+    w->h_prep[0] = -1;
+    hipLaunchKernelGGL(k_mono_prep, dim3(1), dim3(1024), 0, st, c->d_x1, c->d_x2, c->d_counts + CN_M, c->cap, ax, bx, ay, by, distance,
+                       w->q1, w->q2, w->h_x1.data(), w->h_x2.data(), w->h_prep.data());
+    UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+int mono_prep_method(Ctx* c, int M, const uvo_point2f** k1, const uvo_point2f** k2)
+{
+    MonoWs* w = static_cast<MonoWs*>(c->mono_ws);
+    *k1 = w->h_x1.data(); *k2 = w->h_x2.data();
+    return (w->h_prep[1] == M) ? w->h_prep[0] : -1;
+}
+
+// device -> pinned mirror of a few KB (a copy command costs the stage ~10 us; this is a kernel among kernels)
+__global__ __launch_bounds__(256) void k_mirror_words(const int* __restrict__ src, int* __restrict__ dst, int n)
+{
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+}
+
+struct PoseRt { double R[4][9], t[4][3]; };
+// recoverPose's choice among its four candidates (the >= chain of five-point.cpp: the first of the best), extract_inliers
+// (VO_utility.cpp:306-329) on findEssentialMat's mask as an ordered compaction, and the count of the winning candidate's mask
+__global__ __launch_bounds__(1024) void k_mono_pick(const uvo_point2f* __restrict__ x1, const uvo_point2f* __restrict__ x2, int n, const uint8_t* __restrict__ emask,
+                                                    const uint8_t* __restrict__ masks, const int* __restrict__ good, uvo_point2f* __restrict__ in1, uvo_point2f* __restrict__ in2,
+                                                    int* __restrict__ pick, int* __restrict__ h_pick, uint8_t* __restrict__ h_mask)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __shared__ int wtot[16], s_base, s_valid;
+    int best;
+    const int g0 = good[0], g1 = good[1], g2 = good[2], g3 = good[3];
+    if (g0 >= g1 && g0 >= g2 && g0 >= g3) best = 0;
+    else if (g1 >= g0 && g1 >= g2 && g1 >= g3) best = 1;
+    else if (g2 >= g0 && g2 >= g1 && g2 >= g3) best = 2;
+    else best = 3;
+    if (tid == 0) { s_base = 0; s_valid = 0; }
+    __syncthreads();
+    int valid = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const bool keep = i < n && emask[i] != 0;
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wtot[wv] = __popcll(bal);
+        __syncthreads();
+        int off = s_base;
+        for (int k = 0; k < wv; k++) off += wtot[k];
+        if (keep) { in1[off + before] = x1[i]; in2[off + before] = x2[i]; }
+        __syncthreads();
+        if (tid == 0) { int tot = 0; for (int k = 0; k < 16; k++) tot += wtot[k]; s_base += tot; }
+        if (i < n) { const uint8_t m = masks[(size_t)best * n + i]; h_mask[i] = m; valid += m != 0; }
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) valid += __shfl_down(valid, o);
+    if (lane == 0) atomicAdd(&s_valid, valid);
+    __syncthreads();
+    if (tid == 0) {
+        pick[0] = best; pick[1] = s_base;
+        h_pick[0] = best; h_pick[1] = g0; h_pick[2] = g1; h_pick[3] = g2; h_pick[4] = g3; h_pick[5] = s_base; h_pick[6] = s_valid;
+    }
+}
+// convert_3Dpoints_camera (VO_utility.cpp:46-63) for compute_scale_factor: the z of every good point whose z under the recovered pose
+// is positive, into pinned memory (the host takes the median: (float)range / median, VO_utility.cpp:23-38)
+__global__ __launch_bounds__(1024) void k_mono_scale(PoseRt rt, const int* __restrict__ pick, const double* __restrict__ good_pts, const int* __restrict__ G_p,
+                                                     double* __restrict__ h_zs, int* __restrict__ h_pick)
+{
+    const int tid = threadIdx.x, best = pick[0], G = *G_p;
+    const double* R = rt.R[best]; const double* t = rt.t[best];
+    __shared__ int s_n;
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    for (int i = tid; i < G; i += 1024) {
+        const double* q = good_pts + 3 * (size_t)i;
+        const double zt = (R[6]*q[0] + R[7]*q[1] + R[8]*q[2]) * 1.0 + t[2] * 1.0;
+        if (zt > 0) h_zs[atomicAdd(&s_n, 1)] = q[2];                  // (the order does not reach the median)
+    }
+    __syncthreads();
+    if (tid == 0) { h_pick[7] = G; h_pick[8] = s_n; __threadfence_system(); h_pick[9] = 1; }
+}
+
+// findEssentialMat + recoverPose + triangulatePoints + extract_3Dpoints + convert_3Dpoints_camera on the n matched points k_mono_prep
+// left on the device; two host syncs.  out->ok = findEssentialMat produced a model (LMedS: with >= 5 inliers).
+uvo_status mono_essential_resident(Ctx* c, int n, const double* K, int method, double prob, double threshold, int maxIters, MonoResident* out)
+{
+    memset(out, 0, sizeof(*out));
+    MonoWs* w = mono_ws(c);
+    if (!w) { c->err = "mono workspace allocation failed"; return UVO_HIP_ERROR; }
+    if (n > c->cap) { c->err = "point count exceeds the context's max_kpts"; return UVO_CAPACITY; }
+    const int modelPoints = 5;
+    out->mask = w->h_mask.data(); out->zs = w->h_zs.data();
+    if (n < modelPoints) { memset(w->h_mask.data(), 0, (size_t)(n > 0 ? n : 0)); return UVO_OK; }
+    const double fx = K[0], fy = K[4];
+    threshold /= (fx + fy) / 2;
+    hipStream_t st = c->stream;
+    const bool lmeds = method != 8;
+    int niters;
+    if (n == modelPoints) niters = 1;
+    else if (lmeds) { niters = ransac_update_num_iters(prob, 0.45, modelPoints, maxIters); niters = niters > 3 ? niters : 3; }
+    else niters = maxIters > 1 ? maxIters : 1;
+    if (niters > kMaxHyp) { c->err = "max_iters exceeds the compiled hypothesis capacity (2048)"; return UVO_CAPACITY; }
+    bool failed_first = false;
+    int nsub;
+    if (n == modelPoints) { for (int i = 0; i < 5; i++) w->h_subsets[i] = i; nsub = 1; }
+    else nsub = make_subsets(w->h_subsets.data(), niters, modelPoints, n, lmeds ? 1000 : 10000, nullptr, nullptr, &failed_first);
+    const int kFirstRound = 128;
+    const int first = (!lmeds && n != modelPoints && nsub > kFirstRound) ? kFirstRound : nsub;
+    const int npow2 = next_pow2(n);
+    const float thr2 = (float)(threshold * threshold);
+    // round(s) of hypotheses: subsets read from pinned memory, counts / medians / model counts written to it, the models mirrored
+    auto round = [&](int from, int cnt) -> uvo_status {
+        hipLaunchKernelGGL(k_fivepoint_hyp, dim3((cnt + kFpPerWg - 1) / kFpPerWg), dim3(64), 0, st, w->q1, w->q2, w->h_subsets.data() + (size_t)5 * from, cnt,
+                           w->models + (size_t)90 * from, w->nmodels + from);
+        if (n != modelPoints)
+            hipLaunchKernelGGL(k_e_score, dim3(10, cnt), dim3(256), lmeds ? sizeof(float) * npow2 : 0, st, w->q1, w->q2, n, w->models + (size_t)90 * from, w->nmodels + from,
+                               lmeds ? 1 : 0, thr2, npow2, w->h_counts.data() + (size_t)10 * from, w->h_medians.data() + (size_t)10 * from, w->h_nmodels.data() + from);
+        else hipLaunchKernelGGL(k_mirror_words, dim3(1), dim3(256), 0, st, w->nmodels, w->h_nmodels.data(), 1);
+        hipLaunchKernelGGL(k_mirror_words, dim3(std::min(64, (cnt * 180 + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const int*>(w->models + (size_t)90 * from),
+                           reinterpret_cast<int*>(w->h_models.data() + (size_t)90 * from), cnt * 180);
+        UVO_HIP_TRY(c, hipGetLastError());
+        UVO_HIP_TRY(c, host_sync(c, st));
+        return UVO_OK;
+    };
+    UVO_TRY(round(0, first));
+    Winner win;
+    double final_thr = threshold;
+    if (n == modelPoints) {
+        if (w->h_nmodels[0] <= 0) { memset(w->h_mask.data(), 0, (size_t)n); return UVO_OK; }
+        win.hyp = 0; win.model = 0;
+        final_thr = DBL_MAX;                                         // every point an inlier (RANSACPointSetRegistrator::run, count == modelPoints)
+    } else if (lmeds) win = replay_lmeds(w->h_nmodels.data(), w->h_medians.data(), 10, nsub);
+    else {
+        int settled = niters;
+        win = replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 10, first, niters, n, modelPoints, prob, &settled);
+        if (first < nsub && settled > first) {
+            UVO_TRY(round(first, nsub - first));
+            win = replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 10, nsub, niters, n, modelPoints, prob);
+        }
+    }
+    if (win.hyp < 0) { memset(w->h_mask.data(), 0, (size_t)n); return UVO_OK; }
+    if (lmeds && n != modelPoints) {
+        const double sigma = 2.5 * 1.4826 * (1 + 5. / (n - modelPoints)) * sqrt(win.min_median);
+        final_thr = sigma > 0.001 ? sigma : 0.001;
+    }
+    const double* E = w->h_models.data() + (size_t)win.hyp * 90 + win.model * 9;
+    memcpy(out->E, E, sizeof(out->E));
+    uint8_t* emask = w->masks + 4 * (size_t)c->cap;
+    if (n == modelPoints) UVO_HIP_TRY(c, hipMemsetAsync(emask, 1, n, st));
+    else hipLaunchKernelGGL(k_model_mask, dim3((n + 255) / 256), dim3(256), 0, st, 0, w->q1, w->q2, nullptr, nullptr, n,
+                            w->models + (size_t)win.hyp * 90 + win.model * 9, (float)(final_thr * final_thr), emask);
+    // recoverPose: the four candidates of decomposeEssentialMat, cheirality counts on the device
+    double R1[9], R2[9], tt[3];
+    decompose_essential(E, R1, R2, tt);
+    const double* Rc[4] = { R1, R2, R1, R2 };
+    const double sg[4] = { 1, 1, -1, -1 };
+    PoseCands pc; PoseRt rt;
+    for (int cnd = 0; cnd < 4; cnd++) {
+        for (int i = 0; i < 3; i++) { pc.P[cnd][i*4] = Rc[cnd][i*3]; pc.P[cnd][i*4+1] = Rc[cnd][i*3+1]; pc.P[cnd][i*4+2] = Rc[cnd][i*3+2]; pc.P[cnd][i*4+3] = sg[cnd] * tt[i]; }
+        memcpy(rt.R[cnd], Rc[cnd], sizeof(double) * 9);
+        for (int i = 0; i < 3; i++) rt.t[cnd][i] = sg[cnd] * tt[i];
+    }
+    UVO_HIP_TRY(c, hipMemsetAsync(w->good, 0, sizeof(int) * 4, st));
+    hipLaunchKernelGGL(k_recover_pose, dim3((n + kRpThreads - 1) / kRpThreads, 4), dim3(kRpThreads), 0, st, w->q1, w->q2, n, pc, emask, w->masks, w->good);
+    w->h_pick[9] = 0;
+    hipLaunchKernelGGL(k_mono_pick, dim3(1), dim3(1024), 0, st, c->d_x1, c->d_x2, n, emask, w->masks, w->good, w->in1, w->in2, w->pick, w->h_pick.data(), w->h_mask.data());
+    UVO_HIP_TRY(c, hipGetLastError());
+    // triangulatePoints + extract_3Dpoints (visual_odometry.h:355-356) on the inlier pairs, under the candidate k_mono_pick chose
+    const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
+    double P_prev[12], P_cand[4][12];
+    projection_matrix(I, z, K, P_prev);
+    for (int cnd = 0; cnd < 4; cnd++) projection_matrix(rt.R[cnd], rt.t[cnd], K, P_cand[cnd]);
+    UVO_TRY(pose_triangulate_extract3d_pick(c, P_prev, &P_cand[0][0], &rt.R[0][0], &rt.t[0][0], K, w->pick, w->in1, w->in2, w->pick + 1, n));
+    hipLaunchKernelGGL(k_mono_scale, dim3(1), dim3(1024), 0, st, rt, w->pick, c->d_good_pts[0], c->d_counts + CN_G, w->h_zs.data(), w->h_pick.data());
+    UVO_HIP_TRY(c, hipGetLastError());
+    UVO_HIP_TRY(c, host_sync(c, st));
+    if (w->h_pick[9] != 1) { c->err = "mono pose stage: the device chain did not report"; return UVO_HIP_ERROR; }
+    const int best = w->h_pick[0];
+    out->n_in = w->h_pick[5]; out->valid_inliers = w->h_pick[6]; out->good = w->h_pick[1 + best];
+    out->G = w->h_pick[7]; out->n_front = w->h_pick[8];
+    out->ok = lmeds && n != modelPoints ? (out->n_in >= modelPoints) : 1;
+    memcpy(out->R, rt.R[best], sizeof(out->R)); memcpy(out->t, rt.t[best], sizeof(out->t));
     return UVO_OK;
 }
 

@@ -102,6 +102,22 @@ __global__ __launch_bounds__(kTriThreads) void k_triangulate(Mat34 P1, Mat34 P2,
     if (FILTER) extract3d_point(X, x1[i], x2[i], c1, c2, tol, cam1, flag, i);
 }
 
+// The mono loop's triangulation (visual_odometry.h:355-356) under a second camera that a kernel chose: recoverPose's four candidates
+// travel by value, the index of the winner is read from device memory (mono.hip: k_mono_pick), so the launch can be queued before the
+// host knows which candidate won.
+struct PoseChoice { Mat34 P2[4]; Cam c2[4]; };
+__global__ __launch_bounds__(kTriThreads) void k_triangulate_pick(Mat34 P1, PoseChoice pc, const int* __restrict__ best_p, TriLane LN, Cam c1, double tol)
+{
+    const int n = *LN.n_p;
+    const int i = blockIdx.x * kTriThreads + threadIdx.x;
+    __shared__ double lds[kTriLdsDoubles];
+    if (i >= n) return;
+    const int b = *best_p & 3;
+    const float4 X = triangulate_point(P1, pc.P2[b], LN.x1[i], LN.x2[i], lds);
+    LN.out[i] = X;
+    extract3d_point(X, LN.x1[i], LN.x2[i], c1, pc.c2[b], tol, LN.cam1, LN.flag, i);
+}
+
 // ---------------------------------------------------------------- extract_3Dpoints
 // stage A on caller-provided homogeneous points (uvo_extract_3d_points)
 __global__ __launch_bounds__(256) void k_extract3d_a(const float4* pts4, const uvo_point2f* k1, const uvo_point2f* k2,
@@ -940,6 +956,29 @@ uvo_status pose_triangulate_extract3d(Ctx* c, int slot, const double* P1, const 
     StageTimer t(c, ST_EXTRACT3D);
     Ex3Lanes el; el.l[0] = ex3_lane(c, slot, d_n, counts_host); el.l[1] = c2 ? ex3_lane(c2, slot, c2->d_counts + CN_T, counts_host2) : el.l[0];
     hipLaunchKernelGGL(k_extract3d_b, dim3(1, nl), dim3(1024), 0, c->stream, el, n_max, c->p.MIN_NUM_3DPOINTS, extract3d_force_seq());
+    UVO_HIP_TRY(c, hipGetLastError());
+    return UVO_OK;
+}
+
+// triangulatePoints + extract_3Dpoints on the n (device count, at most n_max) point pairs d_in1 / d_in2 with the first camera K [I | 0] and the
+// second one candidate *d_best of four (P2x4: 4 x 12, Rx4: 4 x 9, tx4: 4 x 3); outputs as pose_triangulate_extract3d (slot 0)
+uvo_status pose_triangulate_extract3d_pick(Ctx* c, const double* P1, const double* P2x4, const double* Rx4, const double* tx4, const double* K,
+                                           const int* d_best, const uvo_point2f* d_in1, const uvo_point2f* d_in2, const int* d_n, int n_max)
+{
+    const double I[9] = {1,0,0,0,1,0,0,0,1}, z[3] = {0,0,0};
+    if (n_max > 0) {
+        Mat34 a; memcpy(a.v, P1, sizeof(a.v));
+        PoseChoice pc;
+        for (int k = 0; k < 4; k++) { memcpy(pc.P2[k].v, P2x4 + 12 * k, sizeof(pc.P2[k].v)); pc.c2[k] = make_cam(Rx4 + 9 * k, tx4 + 3 * k, K); }
+        StageTimer t(c, ST_TRIANGULATE);
+        const TriLane ln{ d_in1, d_in2, d_n, c->d_pts4, c->d_cam1, c->d_flag };
+        hipLaunchKernelGGL(k_triangulate_pick, dim3((n_max + kTriThreads - 1) / kTriThreads), dim3(kTriThreads), 0, c->stream, a, pc, d_best, ln, make_cam(I, z, K), c->p.REPROJECTION_TOLERANCE);
+    }
+    StageTimer t(c, ST_EXTRACT3D);
+    Ex3Lane e = ex3_lane(c, 0, d_n, nullptr);
+    e.xc = d_in2;
+    Ex3Lanes el; el.l[0] = el.l[1] = e;
+    hipLaunchKernelGGL(k_extract3d_b, dim3(1, 1), dim3(1024), 0, c->stream, el, n_max, c->p.MIN_NUM_3DPOINTS, extract3d_force_seq());
     UVO_HIP_TRY(c, hipGetLastError());
     return UVO_OK;
 }

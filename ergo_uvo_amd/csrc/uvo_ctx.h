@@ -251,11 +251,14 @@ struct Ctx {
     double mono_K[9]; bool mono_cam_set = false, mono_initialized = false, mono_pipelined = false;
     int mono_use_essential = 1;                  // the reference's global `use_essential` (VOH:89)
     double mono_R[9] = {1,0,0,0,1,0,0,0,1}, mono_t[3] = {0,0,0}, mono_SF = 1.0;
-    std::vector<uvo_keypoint> mono_prev_kps, mono_kps;   // host copies (prev frame / last frame)
+    // the last frame's intermediates for uvo_mono_get: keypoints (det[0].kps), matches (d_matches[0]) and, after the device-resident pose
+    // chain, the good points (d_good_pts[0]) stay in the lane's device buffers -- counts here -- until someone asks
+    int mono_dev_n = 0, mono_dev_M = 0, mono_dev_G = 0; bool mono_good_on_host = true;
+    bool mono_matched = false;                   // this lane's frame was matched against a previous one (CN_M is this frame's)
     int mono_n_prev = 0;                         // rows of the prev descriptors kept in d_as_descL[0]
     std::deque<uvo_mono_result> mono_init_results;   // uvo_mono_submit: results of the synchronous init frames awaiting their collect
     std::deque<uvo_stereo_result> stereo_init_results;   // uvo_stereo_submit: the same for the stereo init pairs (VO:474-520)
-    std::vector<uvo_dmatch> mono_matches; std::vector<uint8_t> mono_mask; std::vector<double> mono_good_pts;
+    std::vector<uint8_t> mono_mask; std::vector<double> mono_good_pts;
 
     // ---- UVO_TRACE=<file>: device timestamps of every pipelined pair's phases (hipEvents with timing), written as CSV by
     // uvo_ctx_destroy: pair, lane, A begin, detection end, A end, B begin, B hypotheses scored, B end (ms since the first) ----
@@ -336,6 +339,8 @@ uvo_status pose_stereo_tail(Ctx* a, Ctx* p, int prev, int curr, int slot, const 
 // the rows of lane c's set `buf`, triangulated by a launch of their own (a set gathered by other means)
 uvo_status pose_as_triangulate(Ctx* c, hipStream_t st, int buf, const int* d_n, int n_max, const double* P1, const double* P2, const double* R1, const double* t1,
                                const double* R2, const double* t2, const double* K1, const double* K2);
+uvo_status pose_triangulate_extract3d_pick(Ctx* c, const double* P1, const double* P2x4, const double* Rx4, const double* tx4, const double* K,
+                                           const int* d_best, const uvo_point2f* d_in1, const uvo_point2f* d_in2, const int* d_n, int n_max);
 uvo_status pose_extract3d(Ctx* c, int slot, const double* R1, const double* t1, const double* R2, const double* t2,
                           const double* K1, const double* K2, const int* d_n, int n_max);
 uvo_status pose_reproject_errors(Ctx* c, const double* world, int n, const double* R, const double* t, const double* K,
@@ -373,6 +378,11 @@ uvo_status mono_recover_pose(Ctx* c, const double* E, const uvo_point2f* p1, con
 uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f* p2, int n, int method, double thr, int maxIters,
                                 double confidence, double* H, uint8_t* mask, int* ok);
 int decompose_homography_mat(const double* H, const double* K, double* Rs, double* ts, double* ns);
+// the mono loop's pose stage on the matched points left on the device (mono.hip, "RESIDENT ON THE DEVICE")
+struct MonoResident { int ok, n_in, valid_inliers, good, G, n_front; double E[9], R[9], t[3]; const uint8_t* mask; const double* zs; };   // mask, zs: pinned, valid until the lane's next frame
+uvo_status mono_prep_launch(Ctx* c, hipStream_t st, const double* K, int distance);
+int mono_prep_method(Ctx* c, int M, const uvo_point2f** k1, const uvo_point2f** k2);      // select_estimation_method's result (1 essential, 0 homography, -1 not reported) + the pinned point mirrors
+uvo_status mono_essential_resident(Ctx* c, int n, const double* K, int method, double prob, double threshold, int maxIters, MonoResident* out);
 uvo_status mono_recover_pose_homography(Ctx* c, const double* H, const uvo_point2f* p1, const uvo_point2f* p2, int n, const double* K,
                                         double HOMOGRAPHY_DISTANCE, double* R, double* t, int* max_good);
 void projection_matrix(const double* R, const double* t, const double* K, double* P);

@@ -15,13 +15,16 @@
 #include <vector>
 #include "uvo_hip.h"
 
+#include <pthread.h>
 static std::atomic<size_t> g_fail_size{0};       // allocations of exactly this many bytes throw while armed (0 = off)
+static std::atomic<int> g_fail_other_threads{0}; // 1: only on threads other than main (a lane worker's allocation is the target)
 static std::atomic<long> g_thrown{0};
+static pthread_t g_main_thread;
 
 static void* alloc_or_throw(size_t n)
 {
     const size_t f = g_fail_size.load(std::memory_order_relaxed);
-    if (f != 0 && n == f) { g_thrown.fetch_add(1); throw std::bad_alloc(); }
+    if (f != 0 && n == f && (!g_fail_other_threads.load(std::memory_order_relaxed) || !pthread_equal(pthread_self(), g_main_thread))) { g_thrown.fetch_add(1); throw std::bad_alloc(); }
     void* p = malloc(n ? n : 1);
     if (!p) throw std::bad_alloc();
     return p;
@@ -101,7 +104,8 @@ static int with_gpu(const char* p0, const char* p1, int w, int h)
     CHECK(strstr(uvo_last_error(c), "out of host memory") != nullptr, "uvo_last_error: '%s'", uvo_last_error(c));
     CHECK(uvo_triangulate_points(c, P1, P2, x1.data(), x2.data(), n, out4.data()) == UVO_OK, "%s", uvo_last_error(c));
     CHECK(memcmp(out4.data(), ref4.data(), sizeof(float) * out4.size()) == 0, "the operator's result changed after the failed call");
-    // ---- a lane WORKER's allocation: the pose stage of a pipelined mono frame copies its M matches into std::vectors ----
+    // ---- a lane WORKER's allocation: the pose stage of a pipelined mono frame sizes its mask (std::vector<uint8_t>, M bytes) on the lane's
+    // worker thread (ctx.hip: run_mono_stage_b); armed for threads other than this one only ----
     const double K[9] = {500, 0, w * 0.5, 0, 500, h * 0.5, 0, 0, 1};
     CHECK(uvo_mono_set_camera(c, K) == UVO_OK, "%s", uvo_last_error(c));
     uvo_mono_result r0, r1;
@@ -113,10 +117,11 @@ static int with_gpu(const char* p0, const char* p1, int w, int h)
     uvo_mono_result q;
     CHECK(uvo_mono_collect(c, 0.2, &q) == UVO_OK, "%s", uvo_last_error(c));
     before = g_thrown.load();
-    g_fail_size = sizeof(uvo_point2f) * (size_t)r1.n_matches;       // the worker's std::vector<uvo_point2f> k1(M) (ctx.hip: run_mono_stage_b)
+    g_fail_other_threads = 1;
+    g_fail_size = (size_t)r1.n_matches;                             // the worker's L->mono_mask.assign(M, 0)
     st = uvo_mono_submit(c, img1.data(), w, h, w, UVO_MEM_HOST, 4.0);
     uvo_status st2 = st == UVO_OK ? uvo_mono_collect(c, 0.2, &q) : st;
-    g_fail_size = 0;
+    g_fail_size = 0; g_fail_other_threads = 0;
     CHECK(st == UVO_OK, "submit: %s", uvo_last_error(c));
     CHECK(g_thrown.load() >= before + 1, "the worker's armed allocation was not reached");
     CHECK(st2 == UVO_CAPACITY, "a worker's bad_alloc must fail the frame with UVO_CAPACITY, got %d (%s)", (int)st2, uvo_last_error(c));
@@ -131,6 +136,7 @@ static int with_gpu(const char* p0, const char* p1, int w, int h)
 
 int main(int argc, char** argv)
 {
+    g_main_thread = pthread_self();
     if (argc >= 2 && !strcmp(argv[1], "host")) return host_only();
     if (argc == 6 && !strcmp(argv[1], "gpu")) { const int rc = host_only(); return rc ? rc : with_gpu(argv[2], argv[3], atoi(argv[4]), atoi(argv[5])); }
     fprintf(stderr, "usage: abi_nothrow host | gpu <img0.raw> <img1.raw> <w> <h>\n");

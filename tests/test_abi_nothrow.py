@@ -19,7 +19,7 @@ def _build(tmp_path):
     exe = str(tmp_path / "abi_nothrow")
     libdir = os.path.join(ROOT, "ergo_uvo_amd", "lib")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "abi_nothrow.cpp"),
-                           "-o", exe, "-L", libdir, "-luvo_hip", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined"])
+                           "-o", exe, "-L", libdir, "-luvo_hip", f"-Wl,-rpath,{libdir}", "-Wl,--allow-shlib-undefined", "-pthread"])
     return exe
 
 

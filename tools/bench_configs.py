@@ -119,24 +119,25 @@ def main(only=None):
             out[key] = {"note": note, "kpts": r.n_kps, "matches": r.n_matches, "valid": nv, "success": ns, "essential_used": ne,
                         "frames_per_s": round(steps / (time.perf_counter() - t0), 1)}
             # per-stage time of the pose kernels when whole rounds of hypotheses run (HIP events; synchronous frames)
-            # the same frames through uvo_mono_submit / uvo_mono_collect, fourteen in flight (the mono pose stage is long and thin)
-            ctx.mono_reset()
-            depth = 14
-            ctx.stereo_set_depth(depth)
-            steps = 600
-            sub = 0
-            for i in range(24):
-                while sub < 24 and sub - i < depth:
-                    ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
-                r = ctx.mono_collect(0.2)
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            nv = 0
-            sub = 0
-            for i in range(steps):
-                while sub < steps and sub - i < depth:
-                    ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
-                nv += ctx.mono_collect(0.2).valid
-            out[key].update({"frames_per_s_pipelined": round(steps / (time.perf_counter() - t0), 1), "valid_pipelined": nv, "pipelined_steps": steps})
+            # the same frames through uvo_mono_submit / uvo_mono_collect, six and fourteen in flight
+            for depth in (6, 14):
+                ctx.mono_reset()
+                ctx.stereo_set_depth(depth)
+                steps = 600
+                sub = 0
+                for i in range(24):
+                    while sub < 24 and sub - i < depth:
+                        ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
+                    r = ctx.mono_collect(0.2)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                nv = 0
+                sub = 0
+                for i in range(steps):
+                    while sub < steps and sub - i < depth:
+                        ctx.mono_submit(dmono[order[sub % len(order)]], rng); sub += 1
+                    nv += ctx.mono_collect(0.2).valid
+                tag = "" if depth == 14 else "_depth%d" % depth
+                out[key].update({"frames_per_s_pipelined" + tag: round(steps / (time.perf_counter() - t0), 1), "valid_pipelined" + tag: nv, "pipelined_steps": steps})
             ctx.close()
 
         # the contract's parameters (the shipped mono column with methods = 8): 0.1 / 0.1 / 0.1 px
