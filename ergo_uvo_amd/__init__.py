@@ -182,9 +182,14 @@ class Context:
             self._check(self._lib.uvo_ctx_set_producer_stream(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream or None), 1))
 
     def set_feature_detector(self, name: str):
-        """The reference's global FEATURE_DETECTOR for the fused steps: "SURF" (default) or "SIFT"."""
+        """The reference's global FEATURE_DETECTOR: "SURF" (default) or "SIFT" for the fused steps and detect_features; "AKAZE" for
+        detect_features / match_features alone (the fused steps refuse it)."""
+        if name == "AKAZE":
+            self._feature_akaze, self._feature_sift = True, False
+            return
         self._check(self._lib.uvo_ctx_set_feature_detector(self._h, name.encode()))
         self._feature_sift = name == "SIFT"
+        self._feature_akaze = False
 
     def set_params(self, params: Params):
         self.params = params
@@ -194,9 +199,31 @@ class Context:
     def detect_features(self, img):
         """detect_features(img, keypoints, descriptors): the SURF branch (VO_utility.cpp:114-119), or the SIFT branch (VO_utility.cpp:107-112)
         when set_feature_detector("SIFT") was called -- the reference switches on its global FEATURE_DETECTOR."""
+        if getattr(self, "_feature_akaze", False):
+            return self.akaze_detect(img)                  # VO_utility.cpp:93-98
         if getattr(self, "_feature_sift", False):
             return self.sift_detect(img)
         return self.surf_detect(img)
+
+    def akaze_detect(self, img, cap=None):
+        """detect_features, FEATURE_DETECTOR == "AKAZE" (VO_utility.cpp:93-98): AKAZE::create()->detectAndCompute.
+        Returns (keypoints, n x 61 uint8 M-LDB descriptors) -- rows for match_features_hamming."""
+        h, w = img.shape[-2], img.shape[-1]
+        p, mem, keep = _ptr_mem(img, np.uint8)
+        cap = int(cap if cap is not None else self.max_kpts)
+        n = C.c_int(0)
+        kps = np.empty(cap, KP_DTYPE)
+        desc = np.empty((cap, 61), np.uint8)
+        self._order_after_producer(img)
+        self._check(self._lib.uvo_akaze_detect(self._h, p, w, h, w, mem, _p(kps), _p(desc), cap, C.byref(n)))
+        return kps[:n.value], desc[:n.value]
+
+    def akaze_plane(self, level: int, what: int):
+        """Test hook: plane `what` (0 Lt, 1 Lsmooth, 2 Lx, 3 Ly, 4 Ldet) of evolution level `level` of the last akaze_detect."""
+        w, h = C.c_int(0), C.c_int(0)
+        out = np.empty(self.max_w * self.max_h, np.float32)
+        self._check(self._lib.uvo_akaze_plane(self._h, int(level), int(what), _p(out), out.size, C.byref(w), C.byref(h)))
+        return out[:w.value * h.value].reshape(h.value, w.value).copy()
 
     def surf_detect(self, img):
         """uvo_surf_detect: the SURF operator itself (64- or, with SURF_EXTENDED, 128-float rows), whatever set_feature_detector says."""

@@ -246,6 +246,7 @@ struct Ctx {
     void* mono_ws = nullptr;                     // MonoWs*, allocated on first use
     void* pre_ws = nullptr;                      // PreWs* (get_image), allocated on first use
     void* codec_ws = nullptr;                    // CodecWs* (uvo_decode_image), allocated on first use
+    void* akaze_ws = nullptr;                    // AkazeWs* (uvo_akaze_detect), allocated on first use per image size
     void* sift_ws[2] = {nullptr, nullptr};       // SiftWs* per image slot (uvo_sift_detect uses slot 0), allocated on first use
     int feature_sift = 0;                        // the reference's global FEATURE_DETECTOR == "SIFT" (uvo_ctx_set_feature_detector); read from the master context
     double mono_K[9]; bool mono_cam_set = false, mono_initialized = false, mono_pipelined = false;
@@ -364,6 +365,10 @@ uvo_status codec_peek(Ctx* c, const uint8_t* data, size_t n, int bayer, int* w, 
 uvo_status codec_bayer(Ctx* c, const uint8_t* bayer, int w, int h, int stride, int mem, const uint8_t** d_out);
 // sift.hip
 void sift_ws_free(Ctx* c);
+// akaze.hip
+void akaze_ws_free(Ctx* c);
+uvo_status akaze_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, uvo_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+uvo_status akaze_plane(Ctx* c, int level, int what, float* out, int cap_floats, int* ow, int* oh);
 uvo_status sift_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int nfeatures, int nL, double contrastThreshold,
                        double edgeThreshold, double sigma, uvo_keypoint* kps, float* desc, int cap, int* n_out);
 uvo_status sift_layer(Ctx* c, int octave, int layer, int dog, float* out, int cap_floats, int* ow, int* oh);

@@ -296,14 +296,28 @@ Mat get_image(const Mat& current_img, const Mat& cameraMatrix, const Mat& distor
     return out;
 }
 
-// VOU:91-126: the "SURF" branch (SURF::create(...)->detectAndCompute) and the "SIFT" branch (SIFT::create(10000, 3, 0.03, 10, 1.6)->
-// detectAndCompute, VOU:107-112).  "AKAZE" / "ORB" are not served (their detectors are not built).
+// VOU:91-126: the "SURF" branch (SURF::create(...)->detectAndCompute), the "SIFT" branch (SIFT::create(10000, 3, 0.03, 10, 1.6)->
+// detectAndCompute, VOU:107-112) and the "AKAZE" branch (AKAZE::create()->detectAndCompute, VOU:93-98: CV_8U rows of 61 bytes).
+// "ORB" is not served (its learned sampling pattern cannot be restated).
 void detect_features(Mat img, vector<KeyPoint>& keypoints, Mat& descriptors)
 {
-    const bool sift = FEATURE_DETECTOR == "SIFT";
-    if (!sift && FEATURE_DETECTOR != "SURF") throw uvo_hip::Error(UVO_INVALID_ARG, "detect_features: FEATURE_DETECTOR must be \"SURF\" or \"SIFT\"");
+    const bool sift = FEATURE_DETECTOR == "SIFT", akaze = FEATURE_DETECTOR == "AKAZE";
+    if (!sift && !akaze && FEATURE_DETECTOR != "SURF") throw uvo_hip::Error(UVO_INVALID_ARG, "detect_features: FEATURE_DETECTOR must be \"SURF\", \"SIFT\" or \"AKAZE\"");
     require(!img.empty() && img.type() == CV_8UC1, "detect_features: CV_8UC1 image expected");
     uvo_ctx* c = ctx_now();
+    if (akaze) {
+        const int cap = g.max_kpts;
+        vector<uvo_keypoint> kps((size_t)cap);
+        vector<uint8_t> desc((size_t)cap * 61);
+        int n = 0;
+        const int stride = img.rows > 1 ? (int)(img.ptr<uint8_t>(1) - img.ptr<uint8_t>(0)) : img.cols;
+        SHIM_TRY(uvo_akaze_detect(c, img.ptr<uint8_t>(0), img.cols, img.rows, stride, UVO_MEM_HOST, kps.data(), desc.data(), cap, &n), "uvo_akaze_detect");
+        keypoints.resize((size_t)n);
+        if (n) memcpy(static_cast<void*>(keypoints.data()), kps.data(), sizeof(uvo_keypoint) * n);
+        descriptors.create(n, 61, CV_8UC1);                                  // AKAZE::descriptorType() == CV_8U, descriptorSize() == 61
+        for (int i = 0; i < n; i++) memcpy(descriptors.ptr<uint8_t>(i), desc.data() + (size_t)i * 61, 61);
+        return;
+    }
     const int cap = sift ? std::max(g.max_kpts, 10000) + 1024 : g.max_kpts;       // retainBest(10000) bounds SIFT's output, ties at the cut aside (room for them)
     vector<uvo_keypoint> kps((size_t)cap);
     const int dsize = sift ? 128 : (SURF_EXTENDED ? 128 : 64);             // descriptorSize()

@@ -116,6 +116,16 @@ uvo_status uvo_surf_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int st
  * `octave`.  A standalone operator: the stereo / mono steps of this library run on SURF (the shipped parameter files). */
 uvo_status uvo_sift_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, int nfeatures, int n_octave_layers,
                            double contrast_threshold, double edge_threshold, double sigma, uvo_keypoint* kps, float* desc, int cap, int* n);
+/* detect_features, FEATURE_DETECTOR == "AKAZE" (VO_utility.cpp:93-98): AKAZE::create()->detectAndCompute(img, noArray(), keypoints,
+ * descriptors) -- DESCRIPTOR_MLDB at full length (486 bits: rows of 61 bytes, for uvo_match_knn2_ratio_hamming), 3 channels, threshold
+ * 0.001, 4 octaves of 4 sublevels, DIFF_PM_G2.  Keypoints in OpenCV's order (evolution level by level, row-major), `size` the diameter,
+ * `angle` in degrees, `class_id` the evolution level.  The non-linear scale space, the Hessian response, orientation and descriptors run
+ * on the device; the sequential duplicate suppression of Find_Scale_Space_Extrema runs on the host over the candidate list.  A
+ * standalone operator: the fused stereo / mono steps run on SURF or SIFT. */
+uvo_status uvo_akaze_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, uvo_keypoint* kps, uint8_t* desc, int cap, int* n);
+/* test hook: plane `what` (0 Lt, 1 Lsmooth, 2 Lx, 3 Ly -- the multiscale derivatives --, 4 Ldet) of evolution level `level` of the last
+ * uvo_akaze_detect, row-major floats to a host buffer */
+uvo_status uvo_akaze_plane(uvo_ctx* c, int level, int what, float* out, int cap_floats, int* w, int* h);
 /* test hook: Gaussian (dog = 0, layers 0 .. n_octave_layers + 2) or difference (dog = 1, layers 0 .. n_octave_layers + 1) layer of
  * octave `octave` (0 = the doubled image) of the last uvo_sift_detect, row-major floats to a host buffer; out = NULL reports the size */
 uvo_status uvo_sift_layer(uvo_ctx* c, int octave, int layer, int dog, float* out, int cap_floats, int* w, int* h);

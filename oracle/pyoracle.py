@@ -555,3 +555,76 @@ def bayer_bggr2bgr(bayer: np.ndarray) -> np.ndarray:
     out = np.empty((h, w, 3), np.uint8)
     lib().orc_bayer_bggr2bgr(_p(bayer), w, h, w, _p(out))
     return out
+
+
+# ---------------------------------------------------------------------------------------------- AKAZE (o_akaze.c)
+AKAZE_DESC_BYTES = 61
+
+
+def akaze_detect(img: np.ndarray, cap=1 << 16, descriptors=True):
+    """AKAZE::create()->detectAndCompute (VO_utility.cpp:93-98), restated: (keypoints, n x 61 uint8 M-LDB descriptors)."""
+    img = _c(img, np.uint8)
+    h, w = img.shape
+    kps = np.zeros(cap, KP_DTYPE)
+    desc = np.zeros((cap, AKAZE_DESC_BYTES), np.uint8) if descriptors else None
+    f = lib().orc_akaze_detect_and_compute
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    n = f(_p(img), w, h, w, _p(kps), _p(desc) if descriptors else None, cap)
+    if n < 0:
+        raise ValueError(f"akaze_detect: capacity {cap} too small for {-n} keypoints")
+    return kps[:n].copy(), (desc[:n].copy() if descriptors else None)
+
+
+def akaze_fed_tau(T: float, tau_max: float = 0.25) -> np.ndarray:
+    tau = np.zeros(256, np.float32)
+    f = lib().orc_akaze_fed_tau
+    f.argtypes = [C.c_float, C.c_float, C.c_void_p]
+    n = f(C.c_float(T), C.c_float(tau_max), _p(tau))
+    return tau[:n].copy()
+
+
+def akaze_levels(w: int, h: int):
+    """-> (array [n][6]: w, h, octave, sigma_size, border, FED steps into the level; esigma [n])"""
+    out = np.zeros((16, 6), np.int32); es = np.zeros(16, np.float32)
+    f = lib().orc_akaze_levels
+    f.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    n = f(int(w), int(h), _p(out), _p(es))
+    return out[:n].copy(), es[:n].copy()
+
+
+def akaze_plane(img: np.ndarray, level: int, what: int):
+    """what: 0 Lt, 1 Lsmooth, 2 Lx, 3 Ly (multiscale derivatives), 4 Ldet of evolution level `level` -> (plane, kcontrast)"""
+    img = _c(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros(h * w, np.float32)
+    ow, oh, kc = C.c_int(0), C.c_int(0), C.c_float(0)
+    f = lib().orc_akaze_plane
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    n = f(_p(img), w, h, w, int(level), int(what), _p(out), C.byref(ow), C.byref(oh), C.byref(kc))
+    if n == 0:
+        raise ValueError("akaze_plane: no such level")
+    return out[:n].reshape(oh.value, ow.value).copy(), kc.value
+
+
+def akaze_scharr(src: np.ndarray, xorder: bool) -> np.ndarray:
+    src = _c(src, np.float32); out = np.zeros_like(src)
+    f = lib().orc_akaze_scharr
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    f(_p(src), src.shape[1], src.shape[0], int(bool(xorder)), _p(out))
+    return out
+
+
+def akaze_pm_g2(lx: np.ndarray, ly: np.ndarray, k: float) -> np.ndarray:
+    lx, ly = _c(lx, np.float32), _c(ly, np.float32); out = np.zeros_like(lx)
+    f = lib().orc_akaze_pm_g2
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    f(_p(lx), _p(ly), lx.size, C.c_float(k), _p(out))
+    return out
+
+
+def akaze_nld_step(lt: np.ndarray, lf: np.ndarray, step: float) -> np.ndarray:
+    lt, lf = _c(lt, np.float32), _c(lf, np.float32); out = np.zeros_like(lt)
+    f = lib().orc_akaze_nld_step
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
+    f(_p(lt), _p(lf), lt.shape[1], lt.shape[0], C.c_float(step), _p(out))
+    return out

@@ -156,6 +156,15 @@ orc_stereo* orc_stereo_create(const orc_vo_params* p, const double* K_left, cons
                               const double* R_right, const double* t_right, int max_kpts);
 void        orc_stereo_destroy(orc_stereo* s);
 void        orc_stereo_use_sift(orc_stereo* s, int on);    /* FEATURE_DETECTOR = "SIFT" instead of "SURF" (detect_features VOU:107-112, match_features VOU:525-529) */
+/* o_akaze.c: AKAZE::create()->detectAndCompute (VO_utility.cpp:93-98); desc: cap x 61 bytes (M-LDB, 486 bits) or NULL; -(count) if cap is too small */
+int         orc_akaze_detect_and_compute(const uint8_t* img, int w, int h, int stride, orc_keypoint* kps, uint8_t* desc, int cap);
+int         orc_akaze_fed_tau(float T, float tau_max, float* tau /* >= 256 */);
+int         orc_akaze_levels(int img_w, int img_h, int* out /* [n][6]: w, h, octave, sigma_size, border, nsteps */, float* esigma);
+int         orc_akaze_plane(const uint8_t* img, int w, int h, int stride, int level, int what /* 0 Lt, 1 Lsmooth, 2 Lx, 3 Ly, 4 Ldet */, float* out,
+                            int* ow, int* oh, float* kcontrast);
+void        orc_akaze_scharr(const float* src, int w, int h, int xorder, float* dst);
+void        orc_akaze_pm_g2(const float* lx, const float* ly, int n, float k, float* dst);
+void        orc_akaze_nld_step(const float* lt, const float* lf, int w, int h, float step_size, float* out);
 /* o_sift.c: SIFT::create(nfeatures, nOctaveLayers, contrastThreshold, edgeThreshold, sigma)->detectAndCompute; desc: cap x 128 floats or NULL */
 int         orc_sift_detect_and_compute(const uint8_t* img, int w, int h, int stride, int nfeatures, int nOctaveLayers, double contrastThreshold,
                                         double edgeThreshold, double sigma, orc_keypoint* kps, float* desc, int cap);

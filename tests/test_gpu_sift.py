@@ -154,12 +154,13 @@ def _shim_detect(tmp_path, img, name, min_hessian=1500):
     raw = outp.read_bytes()
     n, cols = struct.unpack("<ii", raw[:8])
     kps = np.frombuffer(raw[8:8 + 28 * n], KP_DTYPE)
-    desc = np.frombuffer(raw[8 + 28 * n:], np.float32).reshape(n, cols)
+    body = raw[8 + 28 * n:]
+    desc = np.frombuffer(body, np.uint8).reshape(n, cols) if len(body) == n * cols else np.frombuffer(body, np.float32).reshape(n, cols)   # AKAZE rows are bytes
     return 0, kps, desc
 
 
 def test_shim_detect_features_sift_and_surf_branches(tmp_path, oracle):
-    """detect_features(img, keypoints, descriptors) with FEATURE_DETECTOR = "SIFT" / "SURF" through the C++ surface; "AKAZE" is refused."""
+    """detect_features(img, keypoints, descriptors) with FEATURE_DETECTOR = "SIFT" / "SURF" through the C++ surface; "ORB" is refused."""
     img = scene_image(640, 360, 17)
     rc, kps, desc = _shim_detect(tmp_path, img, "SIFT")
     assert rc == 0, kps
@@ -167,8 +168,8 @@ def test_shim_detect_features_sift_and_surf_branches(tmp_path, oracle):
     assert desc.shape[1] == 128 and same(kps, ko) and same(desc, do)
     rc, kps, desc = _shim_detect(tmp_path, img, "SURF")
     assert rc == 0 and desc.shape[1] == 64 and len(kps) > 100
-    rc, err, _ = _shim_detect(tmp_path, img, "AKAZE")
-    assert rc == 4 and "FEATURE_DETECTOR" in err
+    rc, err, _ = _shim_detect(tmp_path, img, "ORB")
+    assert rc == 4 and "FEATURE_DETECTOR" in err                     # (the "AKAZE" branch: tests/test_gpu_akaze.py)
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
