@@ -112,6 +112,7 @@ class Context:
         self._lib = _lib.lib()
         self.params = params
         self.max_kpts = max_kpts
+        self.max_w, self.max_h = max_w, max_h
         h = C.c_void_p()
         st = self._lib.uvo_ctx_create(C.byref(params), device, max_w, max_h, max_kpts, C.byref(h))
         if st != 0:
