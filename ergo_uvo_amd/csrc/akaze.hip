@@ -3,7 +3,7 @@
 // DESCRIPTOR_MLDB, full length (486 bits = 61 bytes), 3 channels, threshold 0.001f, 4 octaves x 4 sublevels, DIFF_PM_G2 -- after
 // Alcantarilla, Nuevo, Bartoli, "Fast explicit diffusion for accelerated features in nonlinear scale spaces" (BMVC 2013) in the form
 // of OpenCV 4.5's features2d/src/kaze/AKAZEFeatures.cpp as far as it can be recalled (PARITY UNPINNED; the float operation order is
-// the scalar one of imgproc's separable filters, shared with oracle/o_akaze.c -- which only tests/ load).
+// the scalar one of imgproc's separable filters).
 //
 // Everything that touches pixels runs on the device, one launch per pass (HBM-bound stencils over float planes, coalesced rows):
 //   k_ak_u8_to_f32                 the image in [0, 1]
