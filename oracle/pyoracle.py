@@ -628,3 +628,139 @@ def akaze_nld_step(lt: np.ndarray, lf: np.ndarray, step: float) -> np.ndarray:
     f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]
     f(_p(lt), _p(lf), lt.shape[1], lt.shape[0], C.c_float(step), _p(out))
     return out
+
+
+# ---------------------------------------------------------------------------------------------- ORB (o_orb.c)
+ORB_DESC_BYTES = 32
+# ORB::create(10000, 1.2, 8, 31, 0, 2, ORB::HARRIS_SCORE, 31, 10), VO_utility.cpp:103
+ORB_REFERENCE = dict(nfeatures=10000, scaleFactor=1.2, nlevels=8, edgeThreshold=31, firstLevel=0, patchSize=31, fastThreshold=10)
+
+
+def orb_random_pattern(patch_size=31, npoints=512) -> np.ndarray:
+    """orb.cpp makeRandomPattern: the (npoints, 2) int32 table OpenCV draws for patch sizes other than 31 (cv::RNG(0x34985739))."""
+    out = np.zeros((npoints, 2), np.int32)
+    f = lib().orc_orb_random_pattern
+    f.argtypes = [C.c_int, C.c_void_p, C.c_int]
+    f(int(patch_size), _p(out), int(npoints))
+    return out
+
+
+def orb_levels(w, h, nfeatures=10000, scaleFactor=1.2, nlevels=8, edgeThreshold=31, firstLevel=0, patchSize=31):
+    """-> (border, [(w, h, features wanted)] per level, scales)"""
+    out = np.zeros((nlevels, 3), np.int32); sc = np.zeros(nlevels, np.float32)
+    f = lib().orc_orb_levels
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    b = f(w, h, nfeatures, C.c_float(scaleFactor), nlevels, edgeThreshold, firstLevel, patchSize, _p(out), _p(sc))
+    return b, out, sc
+
+
+def orb_detect(img: np.ndarray, pattern=None, cap=1 << 16, nfeatures=10000, scaleFactor=1.2, nlevels=8, edgeThreshold=31, firstLevel=0,
+               patchSize=31, fastThreshold=10):
+    """ORB::create(...)->detectAndCompute (VO_utility.cpp:100-105), restated: (keypoints, n x 32 uint8 rBRIEF rows or None without a pattern)."""
+    img = _c(img, np.uint8)
+    h, w = img.shape
+    kps = np.zeros(cap, KP_DTYPE)
+    pat = None if pattern is None else _c(np.asarray(pattern).reshape(-1), np.int32)
+    if pat is not None and pat.size != 1024:
+        raise ValueError("orb_detect: the pattern is 256 x (x0, y0, x1, y1)")
+    desc = np.zeros((cap, ORB_DESC_BYTES), np.uint8) if pat is not None else None
+    f = lib().orc_orb_detect_and_compute
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    n = f(_p(img), w, h, w, nfeatures, C.c_float(scaleFactor), nlevels, edgeThreshold, firstLevel, patchSize, fastThreshold,
+          _p(pat) if pat is not None else None, _p(kps), _p(desc) if desc is not None else None, cap)
+    if n < 0:
+        raise ValueError(f"orb_detect: capacity {cap} too small for {-n} keypoints")
+    return kps[:n].copy(), (desc[:n].copy() if desc is not None else None)
+
+
+def resize_linear_exact(src: np.ndarray, dw: int, dh: int) -> np.ndarray:
+    src = _c(src, np.uint8); out = np.zeros((dh, dw), np.uint8)
+    f = lib().orc_resize_linear_exact_u8
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    f(_p(src), src.shape[1], src.shape[0], src.shape[1], _p(out), dw, dh, dw)
+    return out
+
+
+def fast_scores(img: np.ndarray, threshold: int) -> np.ndarray:
+    img = _c(img, np.uint8); out = np.zeros_like(img)
+    f = lib().orc_fast_scores
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    f(_p(img), img.shape[1], img.shape[0], img.shape[1], int(threshold), _p(out))
+    return out
+
+
+def fast_detect(img: np.ndarray, threshold: int, cap=1 << 18) -> np.ndarray:
+    img = _c(img, np.uint8); kps = np.zeros(cap, KP_DTYPE)
+    f = lib().orc_fast_detect
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    n = f(_p(img), img.shape[1], img.shape[0], img.shape[1], int(threshold), _p(kps), cap)
+    if n < 0:
+        raise ValueError("fast_detect: capacity")
+    return kps[:n].copy()
+
+
+def retain_best(responses: np.ndarray, n_points: int) -> np.ndarray:
+    """KeyPointsFilter::retainBest on a vector with these responses: the surviving old indices in their new order."""
+    r = _c(responses, np.float32); perm = np.zeros(max(r.size, 1), np.int32)
+    f = lib().orc_retain_best
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    m = f(_p(r), r.size, int(n_points), _p(perm))
+    return perm[:m].copy()
+
+
+def orb_harris(img: np.ndarray, x: int, y: int) -> float:
+    img = _c(img, np.uint8)
+    f = lib().orc_orb_harris
+    f.restype = C.c_float; f.argtypes = [C.c_void_p, C.c_int]
+    return f(C.c_void_p(img.ctypes.data + y * img.shape[1] + x), img.shape[1])
+
+
+def orb_umax(half=15) -> np.ndarray:
+    u = np.zeros(half + 2, np.int32)
+    f = lib().orc_orb_umax
+    f.argtypes = [C.c_int, C.c_void_p]
+    f(half, _p(u))
+    return u
+
+
+def orb_ic_angle(img: np.ndarray, x: int, y: int, half=15) -> float:
+    img = _c(img, np.uint8); u = orb_umax(half)
+    f = lib().orc_orb_ic_angle
+    f.restype = C.c_float; f.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    return f(C.c_void_p(img.ctypes.data + y * img.shape[1] + x), img.shape[1], _p(u), half)
+
+
+def orb_blur_kernel() -> np.ndarray:
+    k = np.zeros(7, np.int32)
+    f = lib().orc_orb_blur_kernel
+    f.argtypes = [C.c_void_p]
+    f(_p(k))
+    return k
+
+
+def orb_blur(img: np.ndarray) -> np.ndarray:
+    img = _c(img, np.uint8); out = np.zeros_like(img)
+    f = lib().orc_orb_blur_u8
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    f(_p(img), img.shape[1], img.shape[0], _p(out))
+    return out
+
+
+def orb_describe(img: np.ndarray, x: int, y: int, angle_deg: float, pattern) -> np.ndarray:
+    img = _c(img, np.uint8); pat = _c(np.asarray(pattern).reshape(-1), np.int32); out = np.zeros(32, np.uint8)
+    f = lib().orc_orb_describe
+    f.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    f(C.c_void_p(img.ctypes.data + y * img.shape[1] + x), img.shape[1], C.c_float(angle_deg), _p(pat), _p(out))
+    return out
+
+
+def orb_level_image(img: np.ndarray, level: int, blurred=False, scaleFactor=1.2, nlevels=8) -> np.ndarray:
+    img = _c(img, np.uint8); h, w = img.shape
+    out = np.zeros(h * w, np.uint8); ow, oh = C.c_int(0), C.c_int(0)
+    f = lib().orc_orb_level_image
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    rc = f(_p(img), w, h, w, C.c_float(scaleFactor), nlevels, int(level), int(bool(blurred)), _p(out), out.size, C.byref(ow), C.byref(oh))
+    if rc != 0:
+        raise ValueError("orb_level_image")
+    return out[:ow.value * oh.value].reshape(oh.value, ow.value).copy()

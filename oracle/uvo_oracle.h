@@ -156,6 +156,25 @@ orc_stereo* orc_stereo_create(const orc_vo_params* p, const double* K_left, cons
                               const double* R_right, const double* t_right, int max_kpts);
 void        orc_stereo_destroy(orc_stereo* s);
 void        orc_stereo_use_sift(orc_stereo* s, int on);    /* FEATURE_DETECTOR = "SIFT" instead of "SURF" (detect_features VOU:107-112, match_features VOU:525-529) */
+/* o_orb.c: ORB::create(nfeatures, scaleFactor, nlevels, edgeThreshold, 0, 2, HARRIS_SCORE, patchSize, fastThreshold)->detectAndCompute
+ * (VO_utility.cpp:100-105).  pattern: 1024 ints in the layout of OpenCV's bit_pattern_31_ (x0, y0, x1, y1 per bit) or NULL (keypoints
+ * only); desc: cap x 32 bytes; -(count) if cap is too small */
+int         orc_orb_detect_and_compute(const uint8_t* img, int w, int h, int stride, int nfeatures, float scaleFactor, int nlevels, int edgeThreshold,
+                                       int firstLevel, int patchSize, int fastThreshold, const int* pattern, orc_keypoint* kps, uint8_t* desc, int cap);
+int         orc_orb_levels(int img_w, int img_h, int nfeatures, float scaleFactor, int nlevels, int edgeThreshold, int firstLevel, int patchSize,
+                           int* out /* [nlevels][3]: w, h, features wanted */, float* scale);
+void        orc_resize_linear_exact_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh, int dstride);
+void        orc_fast_scores(const uint8_t* img, int w, int h, int stride, int threshold, uint8_t* score);
+int         orc_fast_detect(const uint8_t* img, int w, int h, int stride, int threshold, orc_keypoint* kps, int cap);
+int         orc_retain_best(const float* responses, int n, int n_points, int* perm);
+float       orc_orb_harris(const uint8_t* center, int step);
+void        orc_orb_umax(int halfPatchSize, int* umax);
+float       orc_orb_ic_angle(const uint8_t* center, int step, const int* umax, int half_k);
+void        orc_orb_blur_kernel(int* k7);
+void        orc_orb_blur_u8(const uint8_t* src, int w, int h, uint8_t* dst);
+void        orc_orb_random_pattern(int patchSize, int* pattern, int npoints);
+void        orc_orb_describe(const uint8_t* center, int step, float angle_deg, const int* pattern, uint8_t* desc);
+int         orc_orb_level_image(const uint8_t* img, int w, int h, int stride, float scaleFactor, int nlevels, int level, int blurred, uint8_t* out, int cap, int* ow, int* oh);
 /* o_akaze.c: AKAZE::create()->detectAndCompute (VO_utility.cpp:93-98); desc: cap x 61 bytes (M-LDB, 486 bits) or NULL; -(count) if cap is too small */
 int         orc_akaze_detect_and_compute(const uint8_t* img, int w, int h, int stride, orc_keypoint* kps, uint8_t* desc, int cap);
 int         orc_akaze_fed_tau(float T, float tau_max, float* tau /* >= 256 */);
