@@ -185,12 +185,12 @@ class Context:
     def set_feature_detector(self, name: str):
         """The reference's global FEATURE_DETECTOR: "SURF" (default) or "SIFT" for the fused steps and detect_features; "AKAZE" for
         detect_features / match_features alone (the fused steps refuse it)."""
-        if name == "AKAZE":
-            self._feature_akaze, self._feature_sift = True, False
+        if name in ("AKAZE", "ORB"):
+            self._feature_akaze, self._feature_orb, self._feature_sift = name == "AKAZE", name == "ORB", False
             return
         self._check(self._lib.uvo_ctx_set_feature_detector(self._h, name.encode()))
         self._feature_sift = name == "SIFT"
-        self._feature_akaze = False
+        self._feature_akaze = self._feature_orb = False
 
     def set_params(self, params: Params):
         self.params = params
@@ -202,6 +202,8 @@ class Context:
         when set_feature_detector("SIFT") was called -- the reference switches on its global FEATURE_DETECTOR."""
         if getattr(self, "_feature_akaze", False):
             return self.akaze_detect(img)                  # VO_utility.cpp:93-98
+        if getattr(self, "_feature_orb", False):
+            return self.orb_detect(img)                    # VO_utility.cpp:100-105
         if getattr(self, "_feature_sift", False):
             return self.sift_detect(img)
         return self.surf_detect(img)
@@ -224,6 +226,43 @@ class Context:
         w, h = C.c_int(0), C.c_int(0)
         out = np.empty(self.max_w * self.max_h, np.float32)
         self._check(self._lib.uvo_akaze_plane(self._h, int(level), int(what), _p(out), out.size, C.byref(w), C.byref(h)))
+        return out[:w.value * h.value].reshape(h.value, w.value).copy()
+
+    def orb_configure(self, nfeatures=10000, scaleFactor=1.2, nlevels=8, edgeThreshold=31, patchSize=31, fastThreshold=10):
+        """The arguments of ORB::create the reference passes (VO_utility.cpp:103) are the defaults; firstLevel 0, WTA_K 2, HARRIS_SCORE are fixed."""
+        f = self._lib.uvo_orb_configure
+        f.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int]
+        self._check(f(self._h, int(nfeatures), float(scaleFactor), int(nlevels), int(edgeThreshold), int(patchSize), int(fastThreshold)))
+
+    def orb_set_pattern(self, pattern):
+        """The rBRIEF sampling table in OpenCV's bit_pattern_31_ layout (256 x (x0, y0, x1, y1)); None forgets it."""
+        if pattern is None:
+            self._check(self._lib.uvo_orb_set_pattern(self._h, None))
+            return
+        pat = np.ascontiguousarray(np.asarray(pattern).reshape(-1), np.int32)
+        if pat.size != 1024:
+            raise ValueError("orb_set_pattern: 256 x (x0, y0, x1, y1)")
+        self._check(self._lib.uvo_orb_set_pattern(self._h, _p(pat)))
+
+    def orb_detect(self, img, cap=None, descriptors=True):
+        """detect_features, FEATURE_DETECTOR == "ORB" (VO_utility.cpp:100-105): ORB::create(10000, 1.2, 8, 31, 0, 2, HARRIS_SCORE, 31, 10)
+        ->detectAndCompute.  Returns (keypoints, n x 32 uint8 rBRIEF rows) -- rows for match_features_hamming; descriptors need
+        orb_set_pattern (descriptors=False: keypoints only)."""
+        h, w = img.shape[-2], img.shape[-1]
+        p, mem, keep = _ptr_mem(img, np.uint8)
+        cap = int(cap if cap is not None else self.max_kpts)
+        n = C.c_int(0)
+        kps = np.empty(cap, KP_DTYPE)
+        desc = np.empty((cap, 32), np.uint8) if descriptors else None
+        self._order_after_producer(img)
+        self._check(self._lib.uvo_orb_detect(self._h, p, w, h, w, mem, _p(kps), _p(desc) if descriptors else None, cap, C.byref(n)))
+        return kps[:n.value], (desc[:n.value] if descriptors else None)
+
+    def orb_plane(self, level: int, what: int):
+        """Test hook: level `level` of the last orb_detect: what = 0 the resized image, 1 its blurred copy, 2 the FAST score map."""
+        w, h = C.c_int(0), C.c_int(0)
+        out = np.empty(self.max_w * self.max_h, np.uint8)
+        self._check(self._lib.uvo_orb_plane(self._h, int(level), int(what), _p(out), out.size, C.byref(w), C.byref(h)))
         return out[:w.value * h.value].reshape(h.value, w.value).copy()
 
     def surf_detect(self, img):

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("UVO_HIP_LIB") or os.path.join(_HERE, "lib", "libuvo_h
 
 EXPORTS = [
     "uvo_params_default_stereo", "uvo_params_default_mono", "uvo_ctx_create", "uvo_ctx_destroy", "uvo_last_error",
-    "uvo_ctx_stream", "uvo_ctx_set_params", "uvo_ctx_set_feature_detector", "uvo_ctx_set_producer_stream", "uvo_ctx_warning", "uvo_ctx_pending", "uvo_ctx_host_policy", "uvo_surf_detect", "uvo_sift_detect", "uvo_sift_layer", "uvo_akaze_detect", "uvo_akaze_plane", "uvo_integral", "uvo_hessian_layer",
+    "uvo_ctx_stream", "uvo_ctx_set_params", "uvo_ctx_set_feature_detector", "uvo_ctx_set_producer_stream", "uvo_ctx_warning", "uvo_ctx_pending", "uvo_ctx_host_policy", "uvo_surf_detect", "uvo_sift_detect", "uvo_sift_layer", "uvo_akaze_detect", "uvo_akaze_plane", "uvo_orb_configure", "uvo_orb_set_pattern", "uvo_orb_detect", "uvo_orb_plane", "uvo_integral", "uvo_hessian_layer",
     "uvo_match_knn2_ratio", "uvo_match_knn2", "uvo_match_knn2_ratio_dim", "uvo_match_knn2_dim", "uvo_match_knn2_ratio_hamming", "uvo_match_knn2_hamming", "uvo_triangulate_points", "uvo_extract_3d_points",
     "uvo_solve_pnp_ransac", "uvo_reproject_errors", "uvo_rodrigues", "uvo_stereo_set_rig", "uvo_stereo_reset", "uvo_stereo_step",
     "uvo_stereo_set_depth", "uvo_stereo_submit", "uvo_stereo_collect",

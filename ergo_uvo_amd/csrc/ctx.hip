@@ -438,6 +438,7 @@ static void destroy_one(uvo_ctx* c)
     codec_ws_free(c);
     sift_ws_free(c);
     akaze_ws_free(c);
+    orb_ws_free(c);
     void* ptrs[] = { c->d_hess_order, c->d_surv, c->d_octpat, c->d_colpart, c->d_DW, c->d_rank, c->d_big_par, c->d_big_patch, c->d_area_tabs, c->d_area_iscale, c->d_ori_w, c->d_mpart, c->d_mscratch, c->d_knn_idx, c->d_knn_dist, c->d_x1, c->d_x2, c->d_xc, c->d_pts4, c->d_cam1,
                      c->d_flag, c->d_tmp_idx, c->d_tmp_row, c->d_good_pts[0], c->d_good_pts[1], c->d_good_idx[0], c->d_good_idx[1], c->d_opts[0], c->d_opts[1],
                      c->d_ipts[0], c->d_ipts[1], c->d_counts, c->d_countsB, c->d_subsets, c->d_models,
@@ -567,7 +568,7 @@ extern "C" uvo_status uvo_ctx_set_feature_detector(uvo_ctx* c, const char* name)
 try {
     if (!c || !name) return UVO_INVALID_ARG;
     const bool sift = strcmp(name, "SIFT") == 0;
-    if (!sift && strcmp(name, "SURF") != 0) return fail(c, UVO_INVALID_ARG, "uvo_ctx_set_feature_detector: the fused steps run on \"SURF\" or \"SIFT\" (AKAZE is the operator uvo_akaze_detect + the Hamming matcher; ORB is not built)");
+    if (!sift && strcmp(name, "SURF") != 0) return fail(c, UVO_INVALID_ARG, "uvo_ctx_set_feature_detector: the fused steps run on \"SURF\" or \"SIFT\" (AKAZE and ORB are the operators uvo_akaze_detect / uvo_orb_detect + the Hamming matcher)");
     if (c->n_pending != 0) return fail(c, UVO_INVALID_ARG, "the feature detector cannot change while pairs are in flight");
     if ((sift ? 1 : 0) != c->feature_sift && (c->vo_initialized || c->mono_initialized))
         return fail(c, UVO_INVALID_ARG, "the feature detector changes the descriptors: the previous frame's set held by the running VO loop would not match (uvo_stereo_reset / uvo_mono_reset first)");
@@ -625,6 +626,38 @@ try {
     (void)hipSetDevice(c->device);
     UVO_TRY(need_idle(c, "uvo_akaze_plane"));
     return akaze_plane(c, level, what, out, cap_floats, w, h);
+} UVO_ABI_CATCH(c)
+
+// detect_features' ORB branch (VO_utility.cpp:100-105): ORB::create(10000, 1.2, 8, 31, 0, 2, HARRIS_SCORE, 31, 10)->detectAndCompute; 32-byte rBRIEF
+// rows for the Hamming matcher.  The sampling table (OpenCV's bit_pattern_31_) is the caller's: uvo_orb_set_pattern.
+extern "C" uvo_status uvo_orb_configure(uvo_ctx* c, int nfeatures, float scale_factor, int nlevels, int edge_threshold, int patch_size, int fast_threshold)
+try {
+    if (!c) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_orb_configure"));
+    return orb_configure(c, nfeatures, scale_factor, nlevels, edge_threshold, patch_size, fast_threshold);
+} UVO_ABI_CATCH(c)
+extern "C" uvo_status uvo_orb_set_pattern(uvo_ctx* c, const int* pattern)
+try {
+    if (!c) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_orb_set_pattern"));
+    return orb_set_pattern(c, pattern);
+} UVO_ABI_CATCH(c)
+extern "C" uvo_status uvo_orb_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, uvo_keypoint* kps, uint8_t* desc, int cap, int* n)
+try {
+    if (!c || !n || !gray) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_orb_detect"));
+    UVO_TRY(wait_for_producer(c, c, mem));
+    return orb_detect(c, gray, w, h, stride, mem, kps, desc, cap, n);
+} UVO_ABI_CATCH(c)
+extern "C" uvo_status uvo_orb_plane(uvo_ctx* c, int level, int what, uint8_t* out, int cap_bytes, int* w, int* h)
+try {
+    if (!c || !out || !w || !h) return UVO_INVALID_ARG;
+    (void)hipSetDevice(c->device);
+    UVO_TRY(need_idle(c, "uvo_orb_plane"));
+    return orb_level_plane(c, level, what, out, cap_bytes, w, h);
 } UVO_ABI_CATCH(c)
 
 extern "C" uvo_status uvo_sift_layer(uvo_ctx* c, int octave, int layer, int dog, float* out, int cap_floats, int* w, int* h)

@@ -246,6 +246,7 @@ struct Ctx {
     void* mono_ws = nullptr;                     // MonoWs*, allocated on first use
     void* pre_ws = nullptr;                      // PreWs* (get_image), allocated on first use
     void* codec_ws = nullptr;                    // CodecWs* (uvo_decode_image), allocated on first use
+    void* orb_ws = nullptr;                      // OrbWs* (uvo_orb_detect): parameters, sampling table, buffers of the last image size
     void* akaze_ws = nullptr;                    // AkazeWs* (uvo_akaze_detect), allocated on first use per image size
     void* sift_ws[2] = {nullptr, nullptr};       // SiftWs* per image slot (uvo_sift_detect uses slot 0), allocated on first use
     int feature_sift = 0;                        // the reference's global FEATURE_DETECTOR == "SIFT" (uvo_ctx_set_feature_detector); read from the master context
@@ -365,6 +366,12 @@ uvo_status codec_peek(Ctx* c, const uint8_t* data, size_t n, int bayer, int* w, 
 uvo_status codec_bayer(Ctx* c, const uint8_t* bayer, int w, int h, int stride, int mem, const uint8_t** d_out);
 // sift.hip
 void sift_ws_free(Ctx* c);
+// orb.hip
+void orb_ws_free(Ctx* c);
+uvo_status orb_configure(Ctx* c, int nfeatures, float scaleFactor, int nlevels, int edgeThreshold, int patchSize, int fastThreshold);
+uvo_status orb_set_pattern(Ctx* c, const int* pattern);
+uvo_status orb_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, uvo_keypoint* kps, uint8_t* desc, int cap, int* n_out);
+uvo_status orb_level_plane(Ctx* c, int level, int what, uint8_t* out, int cap_bytes, int* ow, int* oh);
 // akaze.hip
 void akaze_ws_free(Ctx* c);
 uvo_status akaze_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, uvo_keypoint* kps, uint8_t* desc, int cap, int* n_out);

@@ -70,6 +70,8 @@ struct State {
     uvo_ctx* ctx = nullptr;
     uvo_params applied;
     int device = 0, max_w = 1920, max_h = 1200, max_kpts = 8192;
+    std::vector<int> orb_pattern;                 // OpenCV's bit_pattern_31_ (set_orb_pattern / UVO_ORB_PATTERN_FILE); empty = not supplied
+    bool orb_pattern_sent = false;                // ... and handed to the current context
 } g;
 
 [[noreturn]] void raise(uvo_status st, const char* where)
@@ -147,6 +149,13 @@ void shutdown()
 {
     std::lock_guard<std::mutex> lk(g.mu);
     if (g.ctx) { uvo_ctx_destroy(g.ctx); g.ctx = nullptr; }
+    g.orb_pattern_sent = false;
+}
+void set_orb_pattern(const int* pattern1024)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (pattern1024) g.orb_pattern.assign(pattern1024, pattern1024 + 1024); else g.orb_pattern.clear();
+    g.orb_pattern_sent = false;
 }
 
 void triangulatePoints(const Mat& P1, const Mat& P2, const vector<Point2f>& x1, const vector<Point2f>& x2, Mat& points4D)
@@ -298,13 +307,45 @@ Mat get_image(const Mat& current_img, const Mat& cameraMatrix, const Mat& distor
 
 // VOU:91-126: the "SURF" branch (SURF::create(...)->detectAndCompute), the "SIFT" branch (SIFT::create(10000, 3, 0.03, 10, 1.6)->
 // detectAndCompute, VOU:107-112) and the "AKAZE" branch (AKAZE::create()->detectAndCompute, VOU:93-98: CV_8U rows of 61 bytes).
-// "ORB" is not served (its learned sampling pattern cannot be restated).
+// The "ORB" branch (ORB::create(10000, 1.2, 8, 31, 0, 2, ORB::HARRIS_SCORE, 31, 10)->detectAndCompute, VOU:100-105: CV_8U rows of 32 bytes)
+// needs OpenCV's learned sampling table bit_pattern_31_, which cannot be restated: uvo_hip::set_orb_pattern(table) or a text file of its
+// 1024 integers named by UVO_ORB_PATTERN_FILE; without one the branch throws and says so.
+static void orb_pattern_to(uvo_ctx* c)
+{
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (g.orb_pattern.empty())
+        if (const char* path = getenv("UVO_ORB_PATTERN_FILE"))
+            if (FILE* f = fopen(path, "r")) {
+                std::vector<int> v; int x; char sep;
+                while (fscanf(f, " %d", &x) == 1) { v.push_back(x); if (fscanf(f, " %c", &sep) == 1 && sep != ',' && sep != ';') ungetc(sep, f); }
+                fclose(f);
+                if (v.size() == 1024) g.orb_pattern = v;
+            }
+    if (g.orb_pattern.size() != 1024)
+        throw uvo_hip::Error(UVO_INVALID_ARG, "detect_features: FEATURE_DETECTOR \"ORB\" needs OpenCV's sampling table bit_pattern_31_ (features2d/src/orb.cpp, 1024 integers): "
+                                              "uvo_hip::set_orb_pattern(table) or UVO_ORB_PATTERN_FILE=<text file of the integers>");
+    if (!g.orb_pattern_sent) { SHIM_TRY(uvo_orb_set_pattern(c, g.orb_pattern.data()), "uvo_orb_set_pattern"); g.orb_pattern_sent = true; }
+}
 void detect_features(Mat img, vector<KeyPoint>& keypoints, Mat& descriptors)
 {
-    const bool sift = FEATURE_DETECTOR == "SIFT", akaze = FEATURE_DETECTOR == "AKAZE";
-    if (!sift && !akaze && FEATURE_DETECTOR != "SURF") throw uvo_hip::Error(UVO_INVALID_ARG, "detect_features: FEATURE_DETECTOR must be \"SURF\", \"SIFT\" or \"AKAZE\"");
+    const bool sift = FEATURE_DETECTOR == "SIFT", akaze = FEATURE_DETECTOR == "AKAZE", orb = FEATURE_DETECTOR == "ORB";
+    if (!sift && !akaze && !orb && FEATURE_DETECTOR != "SURF") throw uvo_hip::Error(UVO_INVALID_ARG, "detect_features: FEATURE_DETECTOR must be \"SURF\", \"SIFT\", \"AKAZE\" or \"ORB\"");   // VOU:121-124: "WRONG SELECTION OF DETECTOR"
     require(!img.empty() && img.type() == CV_8UC1, "detect_features: CV_8UC1 image expected");
     uvo_ctx* c = ctx_now();
+    if (orb) {
+        orb_pattern_to(c);
+        const int cap = std::max(g.max_kpts, 10000 + 2048);                     // retainBest(10000 in all) bounds the output, ties at the cuts aside
+        vector<uvo_keypoint> kps((size_t)cap);
+        vector<uint8_t> desc((size_t)cap * 32);
+        int n = 0;
+        const int stride = img.rows > 1 ? (int)(img.ptr<uint8_t>(1) - img.ptr<uint8_t>(0)) : img.cols;
+        SHIM_TRY(uvo_orb_detect(c, img.ptr<uint8_t>(0), img.cols, img.rows, stride, UVO_MEM_HOST, kps.data(), desc.data(), cap, &n), "uvo_orb_detect");
+        keypoints.resize((size_t)n);
+        if (n) memcpy(static_cast<void*>(keypoints.data()), kps.data(), sizeof(uvo_keypoint) * n);
+        descriptors.create(n, 32, CV_8UC1);                                  // ORB::descriptorType() == CV_8U, descriptorSize() == 32
+        for (int i = 0; i < n; i++) memcpy(descriptors.ptr<uint8_t>(i), desc.data() + (size_t)i * 32, 32);
+        return;
+    }
     if (akaze) {
         const int cap = g.max_kpts;
         vector<uvo_keypoint> kps((size_t)cap);

@@ -126,6 +126,26 @@ uvo_status uvo_akaze_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int s
 /* test hook: plane `what` (0 Lt, 1 Lsmooth, 2 Lx, 3 Ly -- the multiscale derivatives --, 4 Ldet) of evolution level `level` of the last
  * uvo_akaze_detect, row-major floats to a host buffer */
 uvo_status uvo_akaze_plane(uvo_ctx* c, int level, int what, float* out, int cap_floats, int* w, int* h);
+/* detect_features, FEATURE_DETECTOR == "ORB" (VO_utility.cpp:100-105):
+ *     ORB::create(10000, 1.2, 8, 31, 0, 2, ORB::HARRIS_SCORE, 31, 10)->detectAndCompute(img, noArray(), keypoints, descriptors)
+ * -- those arguments are the context's defaults (firstLevel 0, WTA_K 2 and HARRIS_SCORE are fixed); uvo_orb_configure changes the
+ * others.  Rows of 32 bytes for uvo_match_knn2_ratio_hamming.  Keypoints in OpenCV's order: level by level, within a level the order
+ * KeyPointsFilter::retainBest (libstdc++'s std::nth_element + std::partition) leaves; `size` = patchSize x 1.2^level, `angle` in
+ * degrees (intensity centroid), `response` the Harris measure, `octave` the level.  Pyramid (INTER_LINEAR_EXACT), FAST-9/16 scores and
+ * maxima, Harris responses, angles, the 7 x 7 blur and the descriptors run on the device; the two retainBest rankings per level run
+ * on the host over the response arrays.
+ * THE SAMPLING TABLE IS THE CALLER'S: with patchSize 31 OpenCV reads its 256 test pairs from `bit_pattern_31_` (orb.cpp: 1024 integers
+ * learned offline), which this library cannot restate and the reference does not hold.  uvo_orb_set_pattern takes it in OpenCV's own
+ * layout -- x0, y0, x1, y1 per descriptor bit, |coordinate| <= patchSize / 2 -- and keeps it for the context (NULL forgets it).  Without a
+ * table uvo_orb_detect returns keypoints only (desc = NULL) and refuses descriptors with UVO_INVALID_ARG.  (For patch sizes other than
+ * 31 OpenCV draws the table itself with cv::RNG(0x34985739): INTEGRATION.md shows the eight lines.)
+ * A standalone operator: the fused stereo / mono steps run on SURF or SIFT. */
+uvo_status uvo_orb_configure(uvo_ctx* c, int nfeatures, float scale_factor, int nlevels, int edge_threshold, int patch_size, int fast_threshold);
+uvo_status uvo_orb_set_pattern(uvo_ctx* c, const int* pattern /* 1024 ints or NULL */);
+uvo_status uvo_orb_detect(uvo_ctx* c, const uint8_t* gray, int w, int h, int stride, int mem, uvo_keypoint* kps, uint8_t* desc, int cap, int* n);
+/* test hook: level `level` of the last uvo_orb_detect as bytes to a host buffer: what = 0 the resized image (levels >= 1), 1 its blurred
+ * copy (after a call with descriptors), 2 its FAST score map (0 = no corner) */
+uvo_status uvo_orb_plane(uvo_ctx* c, int level, int what, uint8_t* out, int cap_bytes, int* w, int* h);
 /* test hook: Gaussian (dog = 0, layers 0 .. n_octave_layers + 2) or difference (dog = 1, layers 0 .. n_octave_layers + 1) layer of
  * octave `octave` (0 = the doubled image) of the last uvo_sift_detect, row-major floats to a host buffer; out = NULL reports the size */
 uvo_status uvo_sift_layer(uvo_ctx* c, int octave, int layer, int dog, float* out, int cap_floats, int* w, int* h);
@@ -151,7 +171,7 @@ uvo_status uvo_match_knn2_dim(uvo_ctx* c, const float* d1, int n1, const float* 
 
 /* The AKAZE / ORB branch of the same function (VO_utility.cpp:520-524): BFMatcher(NORM_HAMMING).knnMatch k=2 + Lowe ratio on binary
  * descriptors of `bytes` bytes per row (1..64: ORB 32, AKAZE 61), u8, `mem`.  DMatch::distance = the number of differing bits.
- * (The detectors of that branch are not provided: descriptors come from the caller's own AKAZE / ORB.) */
+ * (Rows from uvo_akaze_detect / uvo_orb_detect, or from the caller's own detector.) */
 uvo_status uvo_match_knn2_ratio_hamming(uvo_ctx* c, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, int mem,
                                         float ratio, uvo_dmatch* out, int cap, int* m);
 uvo_status uvo_match_knn2_hamming(uvo_ctx* c, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int bytes, int mem,

@@ -8,8 +8,9 @@
 // Differences a maintainer should know about:
 //   * the parameter globals are DECLARED here and DEFINED once in the library (the reference defines them in its
 //     header); get_VO_parameters() keeps assigning to them as before, every call below reads their current value;
-//   * FEATURE_DETECTOR must be "SURF" or "SIFT" for detect_features (the AKAZE / ORB detectors are not built; match_features
-//     serves all four names);
+//   * detect_features serves all four names of FEATURE_DETECTOR; "ORB" needs OpenCV's learned sampling table bit_pattern_31_
+//     (features2d/src/orb.cpp), which this library cannot restate: uvo_hip::set_orb_pattern(table), or the environment variable
+//     UVO_ORB_PATTERN_FILE naming a text file of its 1024 integers -- without it the ORB branch throws and says so;
 //   * OpenCV errors become uvo_hip::Error (a std::runtime_error) carrying the library's message;
 //   * the cv:: calls the stereo/mono loops make directly (triangulatePoints, solvePnPRansac, Rodrigues) have
 //     same-signature replacements in namespace uvo_hip.
@@ -83,6 +84,8 @@ struct Error : std::runtime_error { uvo_status status; Error(uvo_status s, const
 void     configure(int device, int max_w, int max_h, int max_kpts);
 uvo_ctx* context();
 void     shutdown();
+// OpenCV's bit_pattern_31_ for the "ORB" branch of detect_features: 1024 ints, x0, y0, x1, y1 per descriptor bit (nullptr forgets it)
+void     set_orb_pattern(const int* pattern1024);
 
 // Replacements for the cv:: functions the node loops call directly (visual_odometry.h:355, 631, 647-648, 673).
 void triangulatePoints(const uvocv::Mat& projMatr1, const uvocv::Mat& projMatr2, const std::vector<uvocv::Point2f>& projPoints1,

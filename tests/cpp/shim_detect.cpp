@@ -2,7 +2,7 @@
 // detector picked by the FEATURE_DETECTOR global as the reference does ("SURF": VOU:114-119, "SIFT": VOU:107-112).
 //   usage: shim_detect <input.bin> <output.bin>
 //   input : int32 w, h, min_hessian; char name[8] (zero padded); h x w bytes
-//   output: int32 n, descriptor columns; n x KeyPoint (28 bytes); n x columns f32 (SURF, SIFT) or n x columns bytes (AKAZE)
+//   output: int32 n, descriptor columns; n x KeyPoint (28 bytes); n x columns f32 (SURF, SIFT) or n x columns bytes (AKAZE, ORB -- the latter with UVO_ORB_PATTERN_FILE set)
 //   exit 4 when detect_features throws for the name (an unserved detector)
 #include <cstdio>
 #include <cstring>
@@ -34,7 +34,7 @@ int main(int argc, char** argv)
         fwrite(&n, sizeof(int), 1, o); fwrite(&cols, sizeof(int), 1, o);
         static_assert(sizeof(KeyPoint) == 28, "KeyPoint POD");
         if (n) fwrite(static_cast<const void*>(kps.data()), sizeof(KeyPoint), (size_t)n, o);
-        if (desc.type() == CV_8UC1) for (int i = 0; i < n; i++) fwrite(desc.ptr<unsigned char>(i), 1, (size_t)cols, o);      // AKAZE: 61-byte rows
+        if (desc.type() == CV_8UC1) for (int i = 0; i < n; i++) fwrite(desc.ptr<unsigned char>(i), 1, (size_t)cols, o);      // AKAZE: 61-byte rows, ORB: 32
         else for (int i = 0; i < n; i++) fwrite(desc.ptr<float>(i), sizeof(float), (size_t)cols, o);
         fclose(o);
     } catch (const uvo_hip::Error& e) {
