@@ -10,7 +10,7 @@
 // SURVEY.md 2.3 (K5, K6) plans.
 //   k_fivepoint_hyp : four 5-point hypotheses per wave (Nister/Stewenius as in OpenCV's five-point.cpp)
 //   k_e_score       : Sampson error of every (hypothesis, model) over all matches -> inlier count or median
-//   k_h_hyp         : one normalised-DLT homography per thread (9x9 Jacobi eigen in LDS)
+//   k_h_hyp         : normalised-DLT homographies, sixteen lanes per hypothesis (9x9 Jacobi eigen: pivot search, rotations and index rescans across the lanes)
 //   k_h_score       : reprojection error -> inlier count or median
 //   k_model_mask    : mask of the winning model
 //   k_recover_pose  : cheirality test of the 4 (R,t) candidates
@@ -146,6 +146,10 @@ __device__ __forceinline__ cplx dk_sweep(const cplx p, const double* cr, double 
 // 300 sweeps, or fewer when exact: OpenCV stops when the largest correction is <= 0; and once a full sweep leaves
 // every root bitwise unchanged all later sweeps recompute the same corrections, so stopping there gives the
 // result of the full 300 iterations.  The four rows of the wave stop independently (`live`).
+// (Round 5 looked for more exits of that kind -- a sweep is a function of the ten roots alone, so a state that recurs bit for bit
+// makes the sequence periodic and the state after sweep 300 computable: with Brent's one-saved-state scheme two hypotheses in
+// three do recur, with periods from 2 to 126, but a third wander on without recurring inside 300 sweeps, and the launch lasts as long
+// as its slowest hypothesis: 912 us with the test against 879 without.  DESIGN.md section 9.)
 template <int NC>
 __device__ __forceinline__ cplx dk_sweeps(cplx z, const double* cr, double cn, int n, int l, int row)
 {
@@ -449,26 +453,168 @@ __global__ __launch_bounds__(256) void k_e_score(const double* q1, const double*
     }
 }
 
-static const int kHHypThreads = 32;
-__global__ __launch_bounds__(kHHypThreads) void k_h_hyp(const float* src, const float* dst, const int* subsets, int nhyp,
-                                                        double* models /* nhyp x 9 */, int* nmodels)
+// HomographyEstimatorCallback::runKernel for one 4-point subset, SIXTEEN LANES PER HYPOTHESIS (one DPP row; four hypotheses per wave).
+// Until round 5 a thread solved a hypothesis alone: the 9 x 9 Jacobi eigen-solver (JacobiImpl_: ~150 rotations, each a pivot search over
+// 16 candidates, two hypots, ~25 two-element rotations and four index rescans, every operand an LDS round trip) kept a lane busy for
+// 0.70 ms.  Nothing in it is sequential except the rotations themselves:
+//   * the pivot search "first largest |a| among A[i][indR[i]] (i = 0..7), then A[indC[i]][i] (i = 1..8)" is an arg-max over 16 candidates
+//     with ties to the earlier one -- one candidate per lane, four rotate-and-compare steps inside the row;
+//   * the rotation touches element pairs that are independent of each other: lane i < 9 takes the pair of A that carries index i and
+//     the pair (V[k][i], V[l][i]);
+//   * indR / indC are rescanned for the two pivot rows only (as OpenCV does -- the stale entries of other rows are part of the
+//     algorithm): four arg-maxes over <= 8 lanes, ties to the lower index.
+// Every floating-point operation and comparison is the scalar loop's (uvo_mono.h: jacobi_eigen, homography_kernel: the oracle's and
+// the host refit's); only independent work moved to other lanes.  The rows of a wave stop independently (`live`).
+static const int kHPerWg = 4;
+template <int D>
+__device__ __forceinline__ double row_ror_d(double v)
 {
-    __shared__ double lds[171 * kHHypThreads];
-    __shared__ int ilds[18 * kHHypThreads];
-    const int hyp = blockIdx.x * kHHypThreads + threadIdx.x;
-    if (hyp >= nhyp) return;
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x120 + D, 0xf, 0xf, false);
+    u.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x120 + D, 0xf, 0xf, false);
+    return u.d;
+}
+template <int D>
+__device__ __forceinline__ int row_ror_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x120 + D, 0xf, 0xf, false); }
+// all 16 lanes of the row end with the largest v and, among equal v, the smallest c
+__device__ __forceinline__ void row_argmax16(double& v, int& c)
+{
+#define UVO_AM_STEP(D) { const double ov = row_ror_d<D>(v); const int oc = row_ror_i<D>(c); if (ov > v || (ov == v && oc < c)) { v = ov; c = oc; } }
+    UVO_AM_STEP(1) UVO_AM_STEP(2) UVO_AM_STEP(4) UVO_AM_STEP(8)
+#undef UVO_AM_STEP
+}
+__global__ __launch_bounds__(64) void k_h_hyp(const float* src, const float* dst, const int* subsets, int nhyp,
+                                              double* models /* nhyp x 9 */, int* nmodels)
+{
+    constexpr int n = 9;
+    __shared__ double s_A[kHPerWg][81], s_V[kHPerWg][81], s_W[kHPerWg][9];
+    __shared__ int s_indR[kHPerWg][9], s_indC[kHPerWg][9];
+    const int row = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int hyp_raw = blockIdx.x * kHPerWg + row;
+    const bool real = hyp_raw < nhyp;                               // a ragged tail recomputes the last hypothesis, writes nothing
+    const int hyp = real ? hyp_raw : nhyp - 1;
+    double* A = s_A[row]; double* V = s_V[row]; double* W = s_W[row];
+    int* indR = s_indR[row]; int* indC = s_indC[row];
     float M[8], m[8];
     for (int i = 0; i < 4; i++) {
-        int id = subsets[hyp * 4 + i];
+        const int id = subsets[hyp * 4 + i];
         M[2*i] = src[2*id]; M[2*i+1] = src[2*id+1]; m[2*i] = dst[2*id]; m[2*i+1] = dst[2*id+1];
     }
-    using A = SArr<kHHypThreads>;
-    struct IArr { int* p; __device__ int& operator[](int i) const { return p[i * kHHypThreads]; } __device__ IArr operator+(int o) const { return IArr{p + o * kHHypThreads}; } };
-    A base{lds + threadIdx.x};
-    double H[9];
-    int ok = homography_kernel(M, m, 4, H, base, base + 81, base + 90, IArr{ilds + threadIdx.x});
-    nmodels[hyp] = ok;
-    if (ok) for (int k = 0; k < 9; k++) models[(size_t)hyp * 9 + k] = H[k];
+    // ---- normalisation (every lane the same scalars) ----
+    const int count = 4;
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+    for (int i = 0; i < count; i++) { cmx += m[2*i]; cmy += m[2*i+1]; cMx += M[2*i]; cMy += M[2*i+1]; }
+    cmx /= count; cmy /= count; cMx /= count; cMy /= count;
+    for (int i = 0; i < count; i++) {
+        smx += fabs(m[2*i] - cmx); smy += fabs(m[2*i+1] - cmy);
+        sMx += fabs(M[2*i] - cMx); sMy += fabs(M[2*i+1] - cMy);
+    }
+    const bool degenerate = fabs(smx) < DBL_EPSILON || fabs(smy) < DBL_EPSILON || fabs(sMx) < DBL_EPSILON || fabs(sMy) < DBL_EPSILON;
+    smx = count/smx; smy = count/smy; sMx = count/sMx; sMy = count/sMy;
+    // ---- L^T L: the rows Lx, Ly of the four points into V (scratch until the solver initialises it), then entry (j, k >= j) = the sum over
+    // the points in their order, 45 entries over the lanes ----
+    if (l < count) {
+        const int i = l;
+        const double x = (m[2*i] - cmx)*smx, y = (m[2*i+1] - cmy)*smy;
+        const double X = (M[2*i] - cMx)*sMx, Y = (M[2*i+1] - cMy)*sMy;
+        const double Lx[9] = { X, Y, 1, 0, 0, 0, -x*X, -x*Y, -x };
+        const double Ly[9] = { 0, 0, 0, X, Y, 1, -y*X, -y*Y, -y };
+        for (int j = 0; j < 9; j++) { V[i*18 + j] = Lx[j]; V[i*18 + 9 + j] = Ly[j]; }
+    }
+    __syncthreads();
+    for (int e = l; e < 81; e += 16) {
+        const int j = e / 9, k = e - 9 * j;
+        if (k < j) continue;
+        double acc = 0;
+        for (int i = 0; i < count; i++) acc += V[i*18 + j]*V[i*18 + k] + V[i*18 + 9 + j]*V[i*18 + 9 + k];
+        A[j*9 + k] = acc; A[k*9 + j] = acc;
+    }
+    __syncthreads();
+    // ---- JacobiImpl_<double>(A, 9, W, V) ----
+    const double eps = DBL_EPSILON;
+    for (int e = l; e < 81; e += 16) V[e] = (e % 10) == 0 ? 1.0 : 0.0;
+    if (l < n) {
+        const int k = l;
+        W[k] = A[(n + 1)*k];
+        if (k < n - 1) { int mi = k + 1; double mv = fabs(A[n*k + mi]); for (int i = k + 2; i < n; i++) { const double val = fabs(A[n*k + i]); if (mv < val) mv = val, mi = i; } indR[k] = mi; }
+        if (k > 0) { int mi = 0; double mv = fabs(A[k]); for (int i = 1; i < k; i++) { const double val = fabs(A[n*i + k]); if (mv < val) mv = val, mi = i; } indC[k] = mi; }
+    }
+    __syncthreads();
+    bool live = !degenerate;                                        // (a degenerate subset returns before the solver in the reference: no model)
+#pragma unroll 1
+    for (int iters = 0; iters < n*n*30; iters++) {
+        // the pivot: candidate l < 8 is A[l][indR[l]], candidate l >= 8 is A[indC[l - 7]][l - 7]
+        int ck, cl;
+        if (l < 8) { ck = l; cl = indR[l]; } else { cl = l - 7; ck = indC[cl]; }
+        double val = fabs(A[n*ck + cl]);
+        int c = l;
+        row_argmax16(val, c);
+        int k, pl;
+        if (c < 8) { k = c; pl = indR[c]; } else { pl = c - 7; k = indC[pl]; }
+        const double p = A[n*k + pl];
+        live = live && !(fabs(p) <= eps);
+        if (!__any(live)) break;
+        const double Wk = W[k], Wl = W[pl];
+        const double y = (Wl - Wk)*0.5;
+        double t = fabs(y) + det_hypot(p, y);
+        double s = det_hypot(p, t);
+        const double cc = t/s;
+        s = p/s; t = (p/t)*p;
+        if (y < 0) s = -s, t = -t;
+        // the element pairs lane l rotates
+        int a_i0 = -1, a_i1 = -1;
+        if (l < n && l != k && l != pl) {
+            if (l < k) { a_i0 = n*l + k; a_i1 = n*l + pl; }
+            else if (l < pl) { a_i0 = n*k + l; a_i1 = n*l + pl; }
+            else { a_i0 = n*k + l; a_i1 = n*pl + l; }
+        }
+        double a0 = 0, b0 = 0, v0 = 0, v1 = 0;
+        if (a_i0 >= 0) { a0 = A[a_i0]; b0 = A[a_i1]; }
+        if (l < n) { v0 = V[n*k + l]; v1 = V[n*pl + l]; }
+        __syncthreads();                                            // every lane holds what it reads of the old matrix
+        if (live) {
+            if (l == 0) { A[n*k + pl] = 0; W[k] = Wk - t; W[pl] = Wl + t; }
+            if (a_i0 >= 0) { A[a_i0] = a0*cc - b0*s; A[a_i1] = a0*s + b0*cc; }
+            if (l < n) { V[n*k + l] = v0*cc - v1*s; V[n*pl + l] = v0*s + v1*cc; }
+        }
+        __syncthreads();
+        // indR / indC of the two pivot rows from the rotated matrix
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int idx = j == 0 ? k : pl;
+            double vr = -1.0, vc = -1.0;
+            int ir = l, ic = l;
+            if (l < n && l > idx) vr = fabs(A[n*idx + l]);
+            if (l < idx) vc = fabs(A[n*l + idx]);
+            row_argmax16(vr, ir);
+            row_argmax16(vc, ic);
+            if (live && l == 0) { if (idx < n - 1) indR[idx] = ir; if (idx > 0) indC[idx] = ic; }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    // ---- the eigenvalue sort (selection sort, first largest wins; rows of V swapped with it): which row ends up last; then de-normalise ----
+    if (l == 0 && real) {
+        int perm[9];
+        double w[9];
+        for (int i = 0; i < n; i++) { perm[i] = i; w[i] = W[i]; }
+        for (int k = 0; k < n - 1; k++) {
+            int mi = k;
+            for (int i = k + 1; i < n; i++) if (w[mi] < w[i]) mi = i;
+            if (k != mi) { const double t = w[mi]; w[mi] = w[k]; w[k] = t; const int q = perm[mi]; perm[mi] = perm[k]; perm[k] = q; }
+        }
+        const double* H0 = V + 9 * perm[8];
+        const double invHnorm[9] = { 1./smx, 0, cmx, 0, 1./smy, cmy, 0, 0, 1 };
+        const double Hnorm2[9] = { sMx, 0, -cMx*sMx, 0, sMy, -cMy*sMy, 0, 0, 1 };
+        double Ht[9], H1[9];
+        for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++)
+            Ht[r*3 + q] = invHnorm[r*3]*H0[q] + invHnorm[r*3+1]*H0[3 + q] + invHnorm[r*3+2]*H0[6 + q];
+        for (int r = 0; r < 3; r++) for (int q = 0; q < 3; q++)
+            H1[r*3 + q] = Ht[r*3]*Hnorm2[q] + Ht[r*3+1]*Hnorm2[3 + q] + Ht[r*3+2]*Hnorm2[6 + q];
+        const double sc = 1./H1[8];
+        nmodels[hyp] = degenerate ? 0 : 1;
+        if (!degenerate) for (int q = 0; q < 9; q++) models[(size_t)hyp * 9 + q] = H1[q]*sc;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_h_score(const float* src, const float* dst, int n, const double* models, const int* nmodels,
@@ -1060,7 +1206,7 @@ uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f
             // RANSAC in rounds, as mono_find_essential: the first kFirstRound subsets, the rest only if the adaptive count reaches past them
             const int kFirstRound = 128;
             const int first = (!lmeds && nsub > kFirstRound) ? kFirstRound : nsub;
-            hipLaunchKernelGGL(k_h_hyp, dim3((first + kHHypThreads - 1) / kHHypThreads), dim3(kHHypThreads), 0, st, w->src, w->dst, w->subsets, first,
+            hipLaunchKernelGGL(k_h_hyp, dim3((first + kHPerWg - 1) / kHPerWg), dim3(64), 0, st, w->src, w->dst, w->subsets, first,
                                w->models, w->nmodels);
             const int npow2 = next_pow2(n);
             const float thr2 = (float)(thr * thr);
@@ -1078,7 +1224,7 @@ uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f
                 win = replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 1, first, niters, n, modelPoints, confidence, &settled);
                 if (first < nsub && settled > first) {
                     const int rest = nsub - first;
-                    hipLaunchKernelGGL(k_h_hyp, dim3((rest + kHHypThreads - 1) / kHHypThreads), dim3(kHHypThreads), 0, st, w->src, w->dst,
+                    hipLaunchKernelGGL(k_h_hyp, dim3((rest + kHPerWg - 1) / kHPerWg), dim3(64), 0, st, w->src, w->dst,
                                        w->subsets + (size_t)4 * first, rest, w->models + (size_t)9 * first, w->nmodels + first);
                     hipLaunchKernelGGL(k_h_score, dim3(rest), dim3(256), 0, st, w->src, w->dst, n, w->models + (size_t)9 * first, w->nmodels + first,
                                        0, thr2, npow2, w->counts + first, w->medians + first);

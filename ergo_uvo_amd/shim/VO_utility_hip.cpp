@@ -435,6 +435,15 @@ void match_features(vector<KeyPoint> keypoints1, vector<KeyPoint> keypoints2, Ma
                     vector<Point2f>& keypoints1_conv, vector<Point2f>& keypoints2_conv)
 {
     const size_t base = matches.size();
+    if ((!descriptors1.empty() && descriptors1.type() == CV_8UC1) || (!descriptors2.empty() && descriptors2.type() == CV_8UC1)) {
+        // VOU:555-556 applies BFMatcher(NORM_L2) to AKAZE / ORB rows as well: for CV_8U rows OpenCV sums the squared byte differences in
+        // integers and takes the float square root.  Every such sum is below 2^24, so the float matcher on the bytes widened to float
+        // (rows padded with zeros to 64 columns: equal in both sets, no contribution) gives the same distances bit for bit.
+        require(descriptors1.empty() || (descriptors1.type() == CV_8UC1 && descriptors1.cols <= 64), "match_features: CV_8U descriptors of at most 64 bytes expected");
+        require(descriptors2.empty() || (descriptors2.type() == CV_8UC1 && (descriptors1.empty() || descriptors2.cols == descriptors1.cols)), "match_features: CV_8U descriptors with equal widths expected");
+        auto widen = [](const Mat& d) { Mat f; f.create(d.rows, 64, CV_32FC1); for (int i = 0; i < d.rows; i++) { float* o = f.ptr<float>(i); const uint8_t* b = d.ptr<uint8_t>(i); for (int k = 0; k < 64; k++) o[k] = k < d.cols ? (float)b[k] : 0.f; } return f; };
+        match_impl(widen(descriptors1), widen(descriptors2), matches, 64);
+    } else
     match_impl(descriptors1, descriptors2, matches, descriptors1.empty() ? (SURF_EXTENDED ? 128 : 64) : descriptors1.cols);     // VOU:551-552: NORM_L2 whatever the detector
     for (size_t i = base; i < matches.size(); i++) {
         keypoints1_conv.push_back(keypoints1.at((size_t)matches[i].queryIdx).pt);      // query is keypoints1
@@ -575,10 +584,11 @@ int recover_pose_homography(Mat H, vector<Point2f> inliers1, vector<Point2f> inl
 void select_desired_descriptors(const Mat& descriptors, Mat& descriptors_desired, const Mat& indexes)
 {
     descriptors_desired.create(indexes.rows, descriptors.cols, descriptors.type());
-    require(descriptors.type() == CV_32FC1, "select_desired_descriptors: CV_32F descriptors expected");
+    require(descriptors.type() == CV_32FC1 || descriptors.type() == CV_8UC1, "select_desired_descriptors: CV_32F (SURF, SIFT) or CV_8U (AKAZE, ORB) descriptors expected");
+    const size_t row_bytes = (size_t)descriptors.cols * descriptors.elemSize();                 // descriptors.row(idx).copyTo(...): whatever the type
     for (int i = 0; i < indexes.rows; i++) {
         int idx = indexes.at<int>(i, 0);
-        if (idx >= 0 && idx < descriptors.rows) memcpy(descriptors_desired.ptr<float>(i), descriptors.ptr<float>(idx), sizeof(float) * descriptors.cols);
+        if (idx >= 0 && idx < descriptors.rows) memcpy(descriptors_desired.ptr<uint8_t>(i), descriptors.ptr<uint8_t>(idx), row_bytes);
     }
 }
 

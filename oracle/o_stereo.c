@@ -29,9 +29,16 @@ struct orc_stereo {
     float* points4D; int nT;
     double* good_pts; int* good_idx; int G;
     int* inliers; int n_inl;
-    int use_sift;              /* FEATURE_DETECTOR == "SIFT" (the reference's global, VOH:25) */
+    int detector;              /* the reference's global FEATURE_DETECTOR (VOH:25): 0 "SURF", 1 "SIFT", 2 "AKAZE", 3 "ORB" */
+    int orb_pattern[1024];     /* "ORB": the sampling table, OpenCV's bit_pattern_31_ layout (o_orb.c: an input) */
 };
-void orc_stereo_use_sift(orc_stereo* s, int on) { s->use_sift = on; }
+void orc_stereo_use_sift(orc_stereo* s, int on) { s->detector = on ? 1 : 0; }
+/* detector 0..3 as above; pattern: 1024 ints for "ORB" (ignored otherwise) */
+void orc_stereo_use_detector(orc_stereo* s, int detector, const int* pattern)
+{
+    s->detector = detector;
+    if (detector == 3 && pattern) memcpy(s->orb_pattern, pattern, sizeof(s->orb_pattern));
+}
 
 /* VOU:9-15 compute_projection_matrix: K * [R|t] ([UPSTREAM] gemm small-matrix case, len 3) */
 static void compute_projection_matrix(const double* R, const double* t, const double* K, double* P)
@@ -75,7 +82,15 @@ void orc_stereo_destroy(orc_stereo* s)
 
 static int detect(orc_stereo* s, const uint8_t* img, int w, int h, int stride, orc_keypoint* kps, float* desc)
 {
-    if (s->use_sift) {          /* VOU:107-112: SIFT::create(10000, 3, 0.03, 10, 1.6)->detectAndCompute */
+    if (s->detector == 2) {     /* VOU:93-98: AKAZE::create()->detectAndCompute; rows of 61 bytes */
+        int n = orc_akaze_detect_and_compute(img, w, h, stride, kps, (uint8_t*)desc, s->cap);
+        return n < 0 ? s->cap : n;
+    }
+    if (s->detector == 3) {     /* VOU:100-105: ORB::create(10000, 1.2, 8, 31, 0, 2, ORB::HARRIS_SCORE, 31, 10)->detectAndCompute; rows of 32 bytes */
+        int n = orc_orb_detect_and_compute(img, w, h, stride, 10000, 1.2f, 8, 31, 0, 31, 10, s->orb_pattern, kps, (uint8_t*)desc, s->cap);
+        return n < 0 ? s->cap : n;
+    }
+    if (s->detector == 1) {          /* VOU:107-112: SIFT::create(10000, 3, 0.03, 10, 1.6)->detectAndCompute */
         int n = orc_sift_detect_and_compute(img, w, h, stride, 10000, 3, 0.03, 10, 1.6, kps, desc, s->cap);
         return n < 0 ? s->cap : n;
     }
@@ -93,15 +108,23 @@ static int gather_keypoints(const orc_keypoint* src, int nsrc, const int* idx, i
     for (int i = 0; i < nidx; i++) if (idx[i] >= 0 && idx[i] < nsrc) dst[k++] = src[idx[i]];
     return k;
 }
-static void gather_descriptors(const float* src, int nsrc, const int* idx, int nidx, float* dst, int dim)
+static void gather_descriptors(const float* src_, int nsrc, const int* idx, int nidx, float* dst_, int row_bytes)
 {
+    const uint8_t* src = (const uint8_t*)src_; uint8_t* dst = (uint8_t*)dst_;   /* descriptors.row(idx).copyTo(...): CV_32F or CV_8U rows alike */
     for (int i = 0; i < nidx; i++) {
-        if (idx[i] >= 0 && idx[i] < nsrc) memcpy(dst + (size_t)i*dim, src + (size_t)idx[i]*dim, sizeof(float)*dim);
-        else memset(dst + (size_t)i*dim, 0, sizeof(float)*dim);   /* reference leaves the row uninitialised */
+        if (idx[i] >= 0 && idx[i] < nsrc) memcpy(dst + (size_t)i*row_bytes, src + (size_t)idx[i]*row_bytes, (size_t)row_bytes);
+        else memset(dst + (size_t)i*row_bytes, 0, (size_t)row_bytes);   /* reference leaves the row uninitialised */
     }
 }
-/* SURF::descriptorSize(): 64, or 128 with `extended` */
-static int desc_dim(const orc_stereo* s) { return s->use_sift || s->p.SURF_EXTENDED ? 128 : 64; }
+/* descriptorSize() in elements: SURF 64 (128 with `extended`), SIFT 128 floats; AKAZE 61, ORB 32 bytes */
+static int desc_dim(const orc_stereo* s) { return s->detector == 2 ? 61 : s->detector == 3 ? 32 : (s->detector == 1 || s->p.SURF_EXTENDED ? 128 : 64); }
+static int desc_row_bytes(const orc_stereo* s) { return s->detector >= 2 ? desc_dim(s) : desc_dim(s) * (int)sizeof(float); }
+/* match_features (VOU:515-543): BFMatcher(NORM_HAMMING) for "AKAZE" / "ORB", BFMatcher(NORM_L2) for "SURF" / "SIFT", then the ratio test */
+static void match(const orc_stereo* s, const float* d1, int n1, const float* d2, int n2, orc_dmatch* out, int cap, int* m)
+{
+    if (s->detector >= 2) orc_match_knn2_ratio_hamming((const uint8_t*)d1, n1, (const uint8_t*)d2, n2, desc_dim(s), (float)s->p.LOWE_RATIO_THRESHOLD, out, cap, m);
+    else orc_match_knn2_ratio(d1, n1, d2, n2, desc_dim(s), (float)s->p.LOWE_RATIO_THRESHOLD, out, cap, m);
+}
 
 int orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* right, int w, int h, int stride,
                     double dt, orc_stereo_result* out)
@@ -118,14 +141,13 @@ int orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* right, in
     if (!s->vo_initialized) {
         /* ---- VO:474-520 ---- */
         if (s->nL >= p->MIN_NUM_FEATURES && s->nR >= p->MIN_NUM_FEATURES) {
-            orc_match_knn2_ratio(s->descL, s->nL, s->descR, s->nR, desc_dim(s), (float)p->LOWE_RATIO_THRESHOLD,
-                                 s->results_match_prev, s->cap * 4, &s->n_match_prev);
+            match(s, s->descL, s->nL, s->descR, s->nR, s->results_match_prev, s->cap * 4, &s->n_match_prev);
             if (s->n_match_prev > p->MIN_NUM_FEATURES) s->vo_initialized = 1;
         }
         out->n_stereo_matches = s->n_match_prev;
         if (s->vo_initialized) {
             for (int i = 0; i < s->n_match_prev; i++) { ia[i] = s->results_match_prev[i].queryIdx; ib[i] = s->results_match_prev[i].trainIdx; }
-            gather_descriptors(s->descL, s->nL, ia, s->n_match_prev, s->prevL_desc_as, desc_dim(s)); s->n_prevL_desc_as = s->n_match_prev;
+            gather_descriptors(s->descL, s->nL, ia, s->n_match_prev, s->prevL_desc_as, desc_row_bytes(s)); s->n_prevL_desc_as = s->n_match_prev;
             s->n_prevL_as = gather_keypoints(s->kpsL, s->nL, ia, s->n_match_prev, s->prevL_kps_as);
             s->n_prevR_as = gather_keypoints(s->kpsR, s->nR, ib, s->n_match_prev, s->prevR_kps_as);
             memcpy(s->m_curr, s->results_match_prev, sizeof(orc_dmatch) * (size_t)(s->n_match_prev < s->cap ? s->n_match_prev : s->cap));
@@ -142,12 +164,11 @@ int orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* right, in
     orc_keypoint* currL_kps_as = (orc_keypoint*)malloc(sizeof(orc_keypoint) * (size_t)s->cap);
     orc_keypoint* currR_kps_as = (orc_keypoint*)malloc(sizeof(orc_keypoint) * (size_t)s->cap);
     float* currL_desc_as = (float*)malloc(sizeof(float) * 128 * (size_t)s->cap);
-    const int dim = desc_dim(s);
+    const int dim = desc_row_bytes(s);
     int n_currL_as = 0, n_currR_as = 0, n_currL_desc_as = 0;
 
     if (s->nL >= p->MIN_NUM_FEATURES && s->nR >= p->MIN_NUM_FEATURES) {                     /* VO:556 */
-        orc_match_knn2_ratio(s->descL, s->nL, s->descR, s->nR, desc_dim(s), (float)p->LOWE_RATIO_THRESHOLD,
-                             s->m_curr, s->cap, &s->n_m_curr);                              /* VO:558 */
+        match(s, s->descL, s->nL, s->descR, s->nR, s->m_curr, s->cap, &s->n_m_curr);         /* VO:558 */
         if (s->n_m_curr > p->MIN_NUM_FEATURES) {                                             /* VO:567 */
             for (int i = 0; i < s->n_m_curr; i++) { ia[i] = s->m_curr[i].queryIdx; ib[i] = s->m_curr[i].trainIdx; }
             gather_descriptors(s->descL, s->nL, ia, s->n_m_curr, currL_desc_as, dim); n_currL_desc_as = s->n_m_curr;   /* VO:576 */
@@ -155,8 +176,7 @@ int orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* right, in
             n_currR_as = gather_keypoints(s->kpsR, s->nR, ib, s->n_m_curr, currR_kps_as);                         /* VO:579 */
 
             /* triangular matching VO:592 */
-            orc_match_knn2_ratio(s->prevL_desc_as, s->n_prevL_desc_as, s->descL, s->nL, desc_dim(s), (float)p->LOWE_RATIO_THRESHOLD,
-                                 s->m_pc, s->cap * 4, &s->n_m_pc);
+            match(s, s->prevL_desc_as, s->n_prevL_desc_as, s->descL, s->nL, s->m_pc, s->cap * 4, &s->n_m_pc);
             int T = s->n_m_pc;
             for (int i = 0; i < T; i++) { ia[i] = s->m_pc[i].queryIdx; ib[i] = s->m_pc[i].trainIdx; }
             orc_keypoint* pl = (orc_keypoint*)malloc(sizeof(orc_keypoint) * (size_t)(T + 1));
@@ -207,7 +227,7 @@ int orc_stereo_step(orc_stereo* s, const uint8_t* left, const uint8_t* right, in
     /* state carry VO:727-733 (happens on failure too, with possibly empty sets) */
     memcpy(s->prevL_kps_as, currL_kps_as, sizeof(orc_keypoint) * (size_t)n_currL_as); s->n_prevL_as = n_currL_as;
     memcpy(s->prevR_kps_as, currR_kps_as, sizeof(orc_keypoint) * (size_t)n_currR_as); s->n_prevR_as = n_currR_as;
-    memcpy(s->prevL_desc_as, currL_desc_as, sizeof(float) * dim * (size_t)n_currL_desc_as); s->n_prevL_desc_as = n_currL_desc_as;
+    memcpy(s->prevL_desc_as, currL_desc_as, (size_t)dim * (size_t)n_currL_desc_as); s->n_prevL_desc_as = n_currL_desc_as;
     free(currL_kps_as); free(currR_kps_as); free(currL_desc_as); free(ia); free(ib);
     return 0;
 }
@@ -218,8 +238,8 @@ int orc_stereo_get(orc_stereo* s, const char* what, void* out, int cap_bytes)
 #define CASE(name, ptr, cnt, esz) if (!strcmp(what, name)) { src = (ptr); count = (cnt); nb = (size_t)(cnt) * (esz); }
     CASE("kps_left", s->kpsL, s->nL, sizeof(orc_keypoint))
     CASE("kps_right", s->kpsR, s->nR, sizeof(orc_keypoint))
-    CASE("desc_left", s->descL, s->nL, desc_dim(s)*sizeof(float))
-    CASE("desc_right", s->descR, s->nR, desc_dim(s)*sizeof(float))
+    CASE("desc_left", s->descL, s->nL, desc_row_bytes(s))
+    CASE("desc_right", s->descR, s->nR, desc_row_bytes(s))
     CASE("matches_stereo", s->m_curr, s->n_m_curr, sizeof(orc_dmatch))
     CASE("matches_tri", s->m_pc, s->n_m_pc, sizeof(orc_dmatch))
     CASE("points4d", s->points4D, s->nT, 4*sizeof(float))

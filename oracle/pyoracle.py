@@ -269,6 +269,20 @@ class StereoVO:
         lib().orc_stereo_use_sift.argtypes = [C.c_void_p, C.c_int]
         lib().orc_stereo_use_sift(self.h, int(bool(on)))
         self.dim = 128 if on else (128 if self._extended else 64)
+        self._desc_dtype = None
+
+    def use_detector(self, name: str, orb_pattern=None):
+        """The reference's global FEATURE_DETECTOR for this loop: "SURF", "SIFT", "AKAZE" (61-byte rows, Hamming matcher) or "ORB" (32-byte
+        rows, Hamming; orb_pattern = the sampling table, 256 x (x0, y0, x1, y1))."""
+        det = ("SURF", "SIFT", "AKAZE", "ORB").index(name)
+        pat = None
+        if det == 3:
+            pat = _c(np.asarray(orb_pattern).reshape(-1), np.int32)
+            assert pat.size == 1024
+        lib().orc_stereo_use_detector.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib().orc_stereo_use_detector(self.h, det, _p(pat) if pat is not None else None)
+        self._desc_dtype = {0: np.dtype(("f4", 128 if self._extended else 64)), 1: np.dtype(("f4", 128)), 2: np.dtype(("u1", 61)), 3: np.dtype(("u1", 32))}[det]
+        self.dim = self._desc_dtype.shape[0]
 
     def step(self, left, right, dt=0.05) -> StereoResult:
         left = _c(left, np.uint8); right = _c(right, np.uint8)
@@ -278,8 +292,9 @@ class StereoVO:
         return r
 
     def get(self, what: str):
-        spec = {"kps_left": KP_DTYPE, "kps_right": KP_DTYPE, "desc_left": np.dtype(("f4", self.dim)),
-                "desc_right": np.dtype(("f4", self.dim)), "matches_stereo": DM_DTYPE, "matches_tri": DM_DTYPE,
+        dd = getattr(self, "_desc_dtype", None) or np.dtype(("f4", self.dim))
+        spec = {"kps_left": KP_DTYPE, "kps_right": KP_DTYPE, "desc_left": dd,
+                "desc_right": dd, "matches_stereo": DM_DTYPE, "matches_tri": DM_DTYPE,
                 "points4d": np.dtype(("f4", 4)), "good_pts": np.dtype(("f8", 3)), "good_idx": np.dtype("i4"),
                 "inliers": np.dtype("i4")}[what]
         buf = np.zeros(self.cap * 4, spec)

@@ -155,6 +155,7 @@ typedef struct {
 orc_stereo* orc_stereo_create(const orc_vo_params* p, const double* K_left, const double* K_right,
                               const double* R_right, const double* t_right, int max_kpts);
 void        orc_stereo_destroy(orc_stereo* s);
+void        orc_stereo_use_detector(orc_stereo* s, int detector /* 0 "SURF", 1 "SIFT", 2 "AKAZE", 3 "ORB" */, const int* orb_pattern /* 1024 ints for "ORB" */);
 void        orc_stereo_use_sift(orc_stereo* s, int on);    /* FEATURE_DETECTOR = "SIFT" instead of "SURF" (detect_features VOU:107-112, match_features VOU:525-529) */
 /* o_orb.c: ORB::create(nfeatures, scaleFactor, nlevels, edgeThreshold, 0, 2, HARRIS_SCORE, patchSize, fastThreshold)->detectAndCompute
  * (VO_utility.cpp:100-105).  pattern: 1024 ints in the layout of OpenCV's bit_pattern_31_ (x0, y0, x1, y1 per bit) or NULL (keypoints

@@ -3,6 +3,7 @@
 //   usage: shim_match_binary <input.bin> <output.bin>
 //   input : int32 n1, n2, bytes; f32 ratio; n1 x bytes u8; n2 x bytes u8
 //           bytes < 0: the "SIFT" arm of the L2 branch instead (VO_utility.cpp:525-529): FEATURE_DETECTOR = "SIFT", rows of -bytes f32
+//           n1 < 0   : -n1 query rows through the SEVEN-argument overload (VO_utility.cpp:551-573), which applies NORM_L2 to the u8 rows
 //   output: int32 m; m x (queryIdx, trainIdx i32, distance f32)
 #include <cstdio>
 #include <vector>
@@ -16,7 +17,8 @@ int main(int argc, char** argv)
     if (!f) return 2;
     int hdr[3]; float ratio;
     if (fread(hdr, sizeof(int), 3, f) != 3 || fread(&ratio, sizeof(float), 1, f) != 1) return 2;
-    const int n1 = hdr[0], n2 = hdr[1];
+    const bool seven = hdr[0] < 0;
+    const int n1 = seven ? -hdr[0] : hdr[0], n2 = hdr[1];
     const bool sift = hdr[2] < 0;
     const int nb = sift ? -hdr[2] : hdr[2];
     Mat d1(n1, nb, sift ? CV_32FC1 : CV_8UC1), d2(n2, nb, sift ? CV_32FC1 : CV_8UC1);
@@ -30,8 +32,15 @@ int main(int argc, char** argv)
         std::vector<KeyPoint> k1((size_t)n1), k2((size_t)n2);
         std::vector<DMatch> matches(1);                       // one stale entry: the reference appends (VOU:538)
         matches[0].queryIdx = -7;
-        match_features(k1, k2, d1, d2, matches);
+        std::vector<Point2f> c1, c2;
+        for (int i = 0; i < n1; i++) k1[(size_t)i].pt.x = (float)i;
+        for (int i = 0; i < n2; i++) k2[(size_t)i].pt.x = (float)(1000000 + i);
+        if (seven) match_features(k1, k2, d1, d2, matches, c1, c2); else match_features(k1, k2, d1, d2, matches);
         if (matches.empty() || matches[0].queryIdx != -7) return 3;
+        if (seven) {                                          // the converted points of the appended matches (VOU:566-567)
+            if (c1.size() + 1 != matches.size() || c2.size() != c1.size()) return 3;
+            for (size_t i = 0; i < c1.size(); i++) if (c1[i].x != (float)matches[i + 1].queryIdx || c2[i].x != (float)(1000000 + matches[i + 1].trainIdx)) return 3;
+        }
         FILE* o = fopen(argv[2], "wb");
         const int m = (int)matches.size() - 1;
         fwrite(&m, sizeof(int), 1, o);

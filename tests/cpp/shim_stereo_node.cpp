@@ -4,7 +4,7 @@
 // record bit for bit with the CPU oracle's stereo state machine.
 //
 //   usage: shim_stereo_node <input.bin> <output.bin>
-//   input : int32 W, H, nframes, min_hessian (< 0: FEATURE_DETECTOR = "SIFT"); f64 K_left[9], K_right[9], R_right[9], t_right[3]; then nframes x (L, R) u8
+//   input : int32 W, H, nframes, min_hessian (-1 / -2 / -3: FEATURE_DETECTOR = "SIFT" / "AKAZE" / "ORB"); f64 K_left[9], K_right[9], R_right[9], t_right[3]; then nframes x (L, R) u8
 //   output: per frame 8 x int32 (valid, initialized, nL, nR, n_stereo, n_tri, G, n_inliers) + 9 x f64 (rvec, tvec, t_prev_curr)
 #include <cstdio>
 #include <cstdlib>
@@ -26,13 +26,15 @@ int main(int argc, char** argv)
     int hdr[4]; double cam[30];
     if (fread(hdr, sizeof(int), 4, f) != 4 || fread(cam, sizeof(double), 30, f) != 30) { fprintf(stderr, "short header\n"); return 2; }
     const int W = hdr[0], H = hdr[1], nframes = hdr[2];
-    if (hdr[3] < 0) FEATURE_DETECTOR = "SIFT";                        // min_hessian < 0: the loop on SIFT features (VOU:107-112, 525-529)
+    if (hdr[3] == -1) FEATURE_DETECTOR = "SIFT";                      // min_hessian < 0: the loop on another detector's features -- SIFT (VOU:107-112, 525-529),
+    else if (hdr[3] == -2) FEATURE_DETECTOR = "AKAZE";               // AKAZE (VOU:93-98) or ORB (VOU:100-105; the sampling table from UVO_ORB_PATTERN_FILE), both
+    else if (hdr[3] == -3) FEATURE_DETECTOR = "ORB";                 // through match_features' Hamming branch (VOU:520-524)
     else SURF_MIN_HESSIAN = hdr[3];                                 // get_VO_parameters would set the globals
     Mat K_left = mat64(cam, 3, 3), K_right = mat64(cam + 9, 3, 3), R_right = mat64(cam + 18, 3, 3), t_right = mat64(cam + 27, 3, 1);
     Mat R_eye = Mat::eye(3, 3, CV_64FC1), t_zeros = Mat::zeros(3, 1, CV_64FC1), distCoeffs;
     Mat P_eye_left = compute_projection_matrix(R_eye, t_zeros, K_left);            // VO:460
     Mat P_right = compute_projection_matrix(R_right, t_right, K_right);            // VO:462
-    uvo_hip::configure(0, W, H, 8192);
+    uvo_hip::configure(0, W, H, hdr[3] == -3 ? 16384 : 8192);        // ORB::create(10000, ...) returns up to 10000 keypoints (and ties)
 
     FILE* out = fopen(argv[2], "wb");
     if (!out) { perror("output"); return 2; }

@@ -151,6 +151,46 @@ def test_stereo_node_loop_on_sift_features_through_the_shim_matches_oracle(oracl
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("detector,code", [("AKAZE", -2), ("ORB", -3)])
+def test_stereo_node_loop_on_binary_features_through_the_shim_matches_oracle(oracle, scene_small, tmp_path, detector, code):
+    """FEATURE_DETECTOR = "AKAZE" / "ORB": the same node loop on binary descriptors -- detect_features' AKAZE / ORB branches
+    (VO_utility.cpp:93-105), match_features' Hamming branch (VO_utility.cpp:520-524), select_desired_descriptors on CV_8U rows
+    (VO_utility.cpp:683-696 copies rows of any type) -- against the oracle's state machine switched to the same detector.  ORB's sampling
+    table (an input: OpenCV's bit_pattern_31_ cannot be restated) is the one OpenCV's makeRandomPattern draws, read by the C++ surface from
+    UVO_ORB_PATTERN_FILE."""
+    from ergo_uvo_amd import synth
+    _build()
+    rig = synth.stereo_rig(640)
+    seq = [scene_small[k] for k in (0, 1, 2, 1)]
+    H, W = seq[0][0].shape
+    inp, outp, patf = tmp_path / "in.bin", tmp_path / "out.bin", tmp_path / "bit_pattern_31.txt"
+    pat = oracle.orb_random_pattern()
+    patf.write_text(",\n".join(", ".join(str(int(v)) for v in row) for row in pat.reshape(256, 4)) + "\n")
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<4i", W, H, len(seq), code))
+        for m in (rig.K_left, rig.K_right, rig.R_right, rig.t_right):
+            f.write(np.ascontiguousarray(m, np.float64).tobytes())
+        for L, R in seq:
+            f.write(np.ascontiguousarray(L).tobytes()); f.write(np.ascontiguousarray(R).tobytes())
+    res = subprocess.run([DRIVER, str(inp), str(outp)], capture_output=True, text=True, timeout=300, env=dict(os.environ, UVO_ORB_PATTERN_FILE=str(patf)))
+    assert res.returncode == 0, res.stderr
+    rec = np.fromfile(outp, np.dtype([("i", "<i4", 8), ("d", "<f8", 9)]))
+    assert len(rec) == len(seq)
+    ovo = oracle.StereoVO(oracle.stereo_params(1500), rig.K_left, rig.K_right, rig.R_right, rig.t_right, max_kpts=16384)
+    ovo.use_detector(detector, pat)
+    nvalid = 0
+    for k, (L, R) in enumerate(seq):
+        o = ovo.step(L, R, 0.05)
+        want = [o.valid, o.initialized, o.n_left, o.n_right, o.n_stereo_matches, o.n_tri_matches, o.n_good3d, o.n_inliers]
+        assert list(rec["i"][k]) == want, (k, list(rec["i"][k]), want)
+        d = np.array(list(o.rvec) + list(o.tvec) + list(o.t_prev_curr))
+        for a, b in zip(rec["d"][k].reshape(3, 3), d.reshape(3, 3)):
+            assert np.linalg.norm(a - b) <= 1e-4 * max(np.linalg.norm(b), 1e-12), (k, rec["d"][k], d)
+        nvalid += o.valid
+    assert nvalid == len(seq) - 1 and rec["i"][-1][7] > (500 if detector == "AKAZE" else 1500)      # valid poses, hundreds of PnP inliers
+
+
+@pytest.mark.gpu
 def test_get_image_through_the_shim_matches_oracle(oracle, tmp_path):
     _build()
     rng = np.random.default_rng(9)
@@ -231,6 +271,37 @@ def test_shim_match_features_hamming_branch(oracle, tmp_path):
     om = oracle.match_hamming(a, b, ratio)
     assert m == len(om) >= 200
     assert np.array_equal(rec["q"], om["queryIdx"]) and np.array_equal(rec["t"], om["trainIdx"]) and np.array_equal(rec["d"], om["distance"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb", [61, 32])
+def test_shim_seven_argument_match_features_applies_l2_to_binary_rows(tmp_path, nb):
+    """VO_utility.cpp:551-573: the mono loop's match_features overload constructs BFMatcher(NORM_L2) whatever FEATURE_DETECTOR says; on the
+    CV_8U rows of AKAZE (61 bytes) / ORB (32) OpenCV sums squared byte differences in integers and takes the float square root.  Against a
+    numpy integer brute force (no oracle): 2 nearest with ties to the lower train index, d0 < ratio * d1 in float."""
+    _build()
+    rng = np.random.default_rng(6)
+    n1, n2, ratio = 500, 700, 0.9
+    a = rng.integers(0, 256, (n1, nb), dtype=np.uint8); b = rng.integers(0, 256, (n2, nb), dtype=np.uint8)
+    a[:150] = b[100:250]; a[:150, 3] ^= 0x05                                  # near copies: clear winners
+    b[600:620] = b[100:120]                                                   # duplicated train rows: ties
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    inp.write_bytes(struct.pack("<iiif", -n1, n2, nb, ratio) + a.tobytes() + b.tobytes())
+    res = subprocess.run([os.path.join(ROOT, "tests", "cpp", "build", "shim_match_binary"), str(inp), str(outp)], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr
+    raw = outp.read_bytes()
+    m = struct.unpack("<i", raw[:4])[0]
+    rec = np.frombuffer(raw[4:], np.dtype([("q", "<i4"), ("t", "<i4"), ("d", "<f4")]))
+    d2 = ((a[:, None, :].astype(np.int64) - b[None, :, :].astype(np.int64)) ** 2).sum(axis=2)
+    order = np.argsort(d2, axis=1, kind="stable")[:, :2]                      # stable: the lower train index first among equals
+    want = []
+    for q in range(n1):
+        f0 = np.sqrt(np.float32(d2[q, order[q, 0]])); f1 = np.sqrt(np.float32(d2[q, order[q, 1]]))
+        if f0 < np.float32(ratio) * f1:
+            want.append((q, int(order[q, 0]), f0))
+    assert m == len(want) >= 120                                              # the 130 near copies whose train row is not duplicated, and a few more
+    assert [(int(r["q"]), int(r["t"])) for r in rec] == [(q, t) for q, t, _ in want]
+    assert np.array_equal(rec["d"], np.array([d for _, _, d in want], np.float32))
 
 
 def sift_like_rows(rng, n, base=None, noise=6.0):

@@ -20,6 +20,7 @@
 #   mono <tag>                  rocprofv3 kernel stats of the mono loop at C4 (tools/prof_mono.py contract | 1px), + pipelined rate (tools/probe/mono_pipe.py)
 #   sift <tag>                  the SIFT detector: timing, kernel stats, the stereo loop on SIFT under the profiler
 #   sift-pmc                    counter passes of the SIFT detector (one per group) -> tools/pmc_summary_sift.py
+#   binary <tag>                the AKAZE and ORB detectors: timing (CPU oracle beside it), kernel stats of each
 #   budget [host_budget args]   tools/host_budget.py: {spin, sleep, block-all, device} x {2, 4, 16 CPUs}, both bench forms
 #   final <tag>                 the closing pass of a round: bench (600 steps and the driver's form), kernel stats, counters, configs
 # TAG=<name> prefixes the output files (default r05).
@@ -92,6 +93,9 @@ step() {
                case "$g" in FETCH*) d=fetch ;; WRITE*) d=write ;; SQ_INSTS_VALU*) d=sq1 ;; *) d=sq2 ;; esac
                rocprofv3 --kernel-trace --pmc $g --output-format csv -d gpurun_out/pmc_sift_$d -- python3 tools/prof_sift.py 4 > gpurun_out/pmc_sift_$d.log 2>&1 || return 1
              done; python tools/pmc_summary_sift.py ;;
+    binary)  t=${1:-$TAG}
+             python3 tools/prof_binary.py both 20 --cpu > gpurun_out/${t}_binary_time.log 2>&1 || { tail -5 gpurun_out/${t}_binary_time.log; return 1; }; cat gpurun_out/${t}_binary_time.log
+             for d in akaze orb; do rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${t}_$d -- python3 tools/prof_binary.py $d 5 > gpurun_out/prof_${t}_$d.log 2>&1 || return 1; echo "== $d"; python tools/probe/kstats.py prof_${t}_$d 24; done ;;
     budget)  python tools/host_budget.py --out gpurun_out/${TAG}_host_budget.json "$@" ;;
     final)   t=${1:-$TAG}
              python bench.py > gpurun_out/bench_${t}_final.json 2> gpurun_out/bench_${t}_final.err || return 1; tail -c 300 gpurun_out/bench_${t}_final.json; echo
