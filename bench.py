@@ -113,6 +113,56 @@ def self_launch(n: int) -> int:
     return rc
 
 
+def measure_hbm_traffic(pattern: str = "k_hessian_nms_all", steps: int = 6, timeout_s: float = 150.0):
+    """HBM bytes per launch of the roofline kernel FROM THE COUNTERS, in this run: two `rocprofv3 --kernel-trace --pmc <counter>` child
+    passes (FETCH_SIZE, then WRITE_SIZE -- separate runs, and the gfx950 reading of MI355X_MICROARCH.md: both count KiB, FETCH_SIZE is
+    doubled) of tools/prof_stereo.py, the same C3 stereo step the roofline leg times.  Must be called BEFORE this process touches the
+    GPU (the children are ordinary child processes; nothing here execs).  -> (bytes per launch or None, details)."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, {"skipped": "rocprofv3 not on PATH"}
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR")):
+        return None, {"skipped": "this process runs under a profiler already"}
+    per_counter, details = {}, {"command": "rocprofv3 --kernel-trace --pmc <counter> --output-format csv -- python3 tools/prof_stereo.py %d" % steps}
+    tmp = tempfile.mkdtemp(prefix="uvo_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "tools", "prof_stereo.py"), str(steps)]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)                   # the group this call started, nothing else
+                p.wait()
+                return None, dict(details, skipped=f"the {counter} pass did not finish in {timeout_s:.0f} s")
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if rc != 0 or not files:
+                return None, dict(details, skipped=f"the {counter} pass failed (rc {rc})")
+            per, order = {}, []
+            for r in csv.DictReader(open(files[0])):
+                if pattern not in r["Kernel_Name"] or r["Counter_Name"] != counter:
+                    continue
+                k = r["Dispatch_Id"]
+                if k not in per:
+                    per[k] = 0.0; order.append(k)
+                per[k] += float(r["Counter_Value"])                # one row per XCD: the launch's total is their sum
+            vals = [per[k] for k in order[2:]]                      # the first launches of a context warm caches and clocks
+            if not vals:
+                return None, dict(details, skipped=f"no {pattern} launch in the {counter} pass")
+            per_counter[counter] = sum(vals) / len(vals)
+            details[counter + "_KiB_per_launch"] = round(per_counter[counter], 1)
+            details["launches_averaged"] = len(vals)
+    except Exception as e:                                          # a counter pass is evidence, never a reason for the bench to fail
+        return None, dict(details, skipped=f"{type(e).__name__}: {e}")
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    nbytes = int((2.0 * per_counter["FETCH_SIZE"] + per_counter["WRITE_SIZE"]) * 1024.0)
+    details["how"] = "(2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, counters summed over the XCDs, separate passes, measured in this run before the timed region"
+    return nbytes, details
+
+
 def summarise_trace(tr) -> dict:
     """uvo_trace_read's rows (every pipelined pair of the timed blocks) -> the figures that locate a stall: device durations of a
     pair's stage A (detect .. extract_3Dpoints) and PnP stage, the device-side gap between them, the cadence of stage-A ends, and
@@ -132,6 +182,7 @@ def summarise_trace(tr) -> dict:
            "dev_pnp_stage_ms": stats(dev[b, 5] - dev[b, 3], pair[b]), "dev_a_end_to_pnp_begin_ms": stats(dev[b, 3] - dev[b, 2], pair[b]),
            "dev_pair_latency_ms": stats(dev[b, 5] - dev[b, 0], pair[b]),
            "dev_a_end_cadence_ms": stats(np.diff(dev[:, 2]), pair[1:]),
+           "dev_detection_launch_ms": (stats((dev[:, 7] - dev[:, 6])[dev[:, 6] >= 0], pair[dev[:, 6] >= 0]) if dev.shape[1] > 7 else None),
            "host_pacing_wait_ms": stats(host[:, 1] - host[:, 0], pair), "host_submit_call_ms": stats(host[:, 2] - host[:, 0], pair),
            "host_pnp_slot_wait_ms": stats(host[b, 4] - host[b, 3], pair[b]), "host_stage_b_ms": stats(host[b, 5] - host[b, 4], pair[b]),
            "per_lane_p50_ms": {int(l): {"stage_a": round(float(np.median((dev[:, 2] - dev[:, 0])[tr["lane"] == l])), 4),
@@ -198,6 +249,8 @@ def main():
                     help="pairs per launch set (uvo_stereo_set_batch): 2 = consecutive pairs of the stream are queued two at a time")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU-oracle baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 counter passes behind roofline.traffic (rank 0 at N = 1 runs them "
+                    "before its first GPU call, ~40 s; without them the figure of the newest matching committed counter summary is reported)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="collective backend of the pose-record gather "
                     "(nccl = RCCL; gloo only for rehearsing N ranks on fewer devices)")
     ap.add_argument("--share-devices", action="store_true", help="rehearsal: ranks may share a device (LOCAL_RANK modulo the device count)")
@@ -216,6 +269,12 @@ def main():
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
+
+    # roofline.traffic from the counters, measured in this run: child passes, before this process touches the GPU (rank 0 at N = 1, the
+    # run that also carries the CPU baseline)
+    pmc_traffic, pmc_details = None, {"skipped": "not requested for this form (--no-pmc / --no-cpu-baseline / --timed-only / N > 1)"}
+    if args.gpus == 1 and "WORLD_SIZE" not in os.environ and not (args.no_pmc or args.no_cpu_baseline or args.timed_only or args.force_dist):
+        pmc_traffic, pmc_details = measure_hbm_traffic()
 
     import torch
     import torch.distributed as dist
@@ -399,6 +458,7 @@ def main():
                       "argmax": {"block": worst[1], "step": worst[2]}, "first_of_block_p50": round(sorted(g[0] for g in gaps if g[2] == 0)[n_blocks // 2], 4),
                       "what": "host clock between consecutive uvo_stereo_collect returns over all blocks; the first gap of a block is the pipeline fill"}
     trace_summary = None
+    det_pipelined_ms = None                                                # the detection launch's duration with other pairs' kernels beside it
     if trace_on:
         if not args.trace_all:                                             # the diagnostic block: same shape, traced, not part of `value`
             ctx.trace_enable(True)
@@ -411,6 +471,16 @@ def main():
         trace_summary["traced"] = "every timed block" if args.trace_all else "one more block after the timed ones (not part of `value`)"
         if not args.trace_all:
             trace_summary["traced_block_value"] = round(total_pairs / dt_t, 3)
+        if trace_summary.get("dev_detection_launch_ms"):
+            det_pipelined_ms = trace_summary["dev_detection_launch_ms"]["p50"]
+    elif not args.no_trace and not args.timed_only:                        # long blocks: one traced block of 64 pairs for the pipelined launch duration alone
+        ctx.trace_enable(True)
+        res_t = (uvo.StereoResult * 64)()
+        timed_block(64, res_t, [0.0] * 65)
+        tr = ctx.trace_read()
+        ctx.trace_enable(False)
+        d = summarise_trace(tr).get("dev_detection_launch_ms")
+        det_pipelined_ms = d["p50"] if d else None
 
     if rank == 0 and args.dump_records:
         np.save(args.dump_records, allrec.cpu().numpy())
@@ -467,23 +537,24 @@ def main():
         avg_ms = ms / max(n, 1)
         alg_bytes = algorithmic_bytes_hessian_launch(WIDTH, HEIGHT, 2)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed counter passes (separate --pmc FETCH_SIZE / WRITE_SIZE runs of `tools/probe/gpu.sh
-        # final`, FETCH_SIZE doubled per MI355X_MICROARCH.md): the newest summary that has the kernel
-        # Counters cannot be read from inside this process; the figure is the one of the newest committed counter summary whose
-        # `kernel_source_sha` matches the detector source being run (tools/pmc_summary.py writes it) -- null when the profile
-        # predates the kernel, never a stale number.
+        # HBM bytes per launch from the counters: the two child passes run at the top of main() (measure_hbm_traffic) ...
         traffic, traffic_source = None, None
-        try:
-            import hashlib
-            sha = hashlib.sha256(open(os.path.join(ROOT, "ergo_uvo_amd", "csrc", "surf.hip"), "rb").read()).hexdigest()[:16]
-            for name in ("r05_pmc_stage_kernels.json", "r04_pmc_stage_kernels.json", "r03_pmc_stage_kernels.json"):
-                d = json.load(open(os.path.join(ROOT, "profiles", name)))
-                if d.get("kernel_source_sha", {}).get("surf.hip") == sha:
-                    traffic = int(d["kernels"]["hessian_all_octaves"]["hbm_bytes_fetch_x2"])
-                    traffic_source = f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; surf.hip sha256 {sha})"
-                    break
-        except Exception:
-            pass
+        if pmc_traffic is not None:
+            traffic, traffic_source = pmc_traffic, "measured in this run: " + pmc_details["how"]
+        else:
+            # ... or, when the counter passes were not run here, the figure of the newest committed counter summary whose
+            # `kernel_source_sha` matches the detector source being run (tools/pmc_summary.py) -- null when none does, never a stale number
+            try:
+                import hashlib
+                sha = hashlib.sha256(open(os.path.join(ROOT, "ergo_uvo_amd", "csrc", "surf.hip"), "rb").read()).hexdigest()[:16]
+                for name in ("r05_pmc_stage_kernels.json", "r04_pmc_stage_kernels.json", "r03_pmc_stage_kernels.json"):
+                    d = json.load(open(os.path.join(ROOT, "profiles", name)))
+                    if d.get("kernel_source_sha", {}).get("surf.hip") == sha:
+                        traffic = int(d["kernels"]["hessian_all_octaves"]["hbm_bytes_fetch_x2"])
+                        traffic_source = f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; surf.hip sha256 {sha}); not measured in this run: {pmc_details.get('skipped')}"
+                        break
+            except Exception:
+                pass
         # the all-pairs contraction of the matcher against the f32 MFMA peak (F = 2 Nq Nt 64 per call)
         mm_ms, mm_n = tm["match_top2"]
         f_pair = 2.0 * 64 * (rl.n_left * rl.n_right + rl.n_stereo_matches * rl.n_left)
@@ -592,10 +663,14 @@ def main():
             "value_h2d_inclusive": None if h2d_value is None else round(h2d_value, 3),
             "roofline": {"bound": "hbm", "kernel": "k_hessian_nms_all (the four octaves, 3 middle layers each, 2 images per launch)",
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source, "traffic_counters": pmc_details,
                          "peak_measured": round(hbm_measured, 1), "frac_of_measured": round(achieved / hbm_measured, 5),
                          "peak_measured_what": "device-to-device copy of 1 GiB on this GPU at bench start, read + write bytes per second",
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5)},
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(avg_ms, 5),
+                         "frac_pipelined": (None if not det_pipelined_ms else round(alg_bytes / (det_pipelined_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)),
+                         "pipelined_launch_ms": det_pipelined_ms,
+                         "frac_is": "the launch alone on the chip (synchronous steps, HIP events around the stage); frac_pipelined: the same launch "
+                                    "inside the pipeline `value` is timed in, other pairs' kernels beside it (median over a traced block, uvo_trace_row::dev_ms[6..7])"},
             "roofline_desc": {"bound": "hbm", "kernel": "descriptor stage of a pair (k_big_sort, k_descriptor64: small- and large-window blocks in one launch, k_descriptor64_big_finish)",
                               "achieved": round(desc_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(desc_gbs / HBM_PEAK_GBS, 6),
                               "algorithmic_bytes_per_pair": b_desc, "stage_ms_per_pair": round(d_ms, 5)},

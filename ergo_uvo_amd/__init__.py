@@ -102,7 +102,7 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-TRACE_DTYPE = np.dtype([("pair", "i8"), ("lane", "i4"), ("b_used", "i4"), ("dev_ms", "f4", 6), ("host_ms", "f8", 6)], align=True)   # uvo_trace_row
+TRACE_DTYPE = np.dtype([("pair", "i8"), ("lane", "i4"), ("b_used", "i4"), ("dev_ms", "f4", 8), ("host_ms", "f8", 6)], align=True)   # uvo_trace_row
 
 
 class Context:

@@ -96,7 +96,7 @@ static hipError_t trace_alloc(Ctx* c)
 {
     if (c->trace.empty()) {
         c->trace.resize(Ctx::kTraceRing);
-        for (auto& r : c->trace) for (int k = 0; k < 6; k++) { hipError_t e = hipEventCreate(&r.ev[k]); if (e != hipSuccess) return e; }
+        for (auto& r : c->trace) for (int k = 0; k < 8; k++) { hipError_t e = hipEventCreate(&r.ev[k]); if (e != hipSuccess) return e; }
     }
     c->trace_on = true;
     return hipSuccess;
@@ -458,7 +458,7 @@ static void destroy_one(uvo_ctx* c)
     if (c->evB) (void)hipEventDestroy(c->evB);
     if (c->evSync) (void)hipEventDestroy(c->evSync);
     if (c->evProducer) (void)hipEventDestroy(c->evProducer);
-    for (auto& r : c->trace) for (int k = 0; k < 6; k++) if (r.ev[k]) (void)hipEventDestroy(r.ev[k]);
+    for (auto& r : c->trace) for (int k = 0; k < 8; k++) if (r.ev[k]) (void)hipEventDestroy(r.ev[k]);
     if (c->evDet) (void)hipEventDestroy(c->evDet);
     if (c->evPrevRead) (void)hipEventDestroy(c->evPrevRead);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1143,7 +1143,7 @@ try {
         L->trace_cur = (int)(L->trace_count++ % Ctx::kTraceRing);
         pl.trace_slot = L->trace_cur;
         Ctx::TraceRec* tr = &L->trace[L->trace_cur];
-        tr->pair = c->n_submitted; tr->b_used = false;
+        tr->pair = c->n_submitted; tr->b_used = false; tr->det_marked = false;
         for (double& v : tr->host_us) v = 0;
         tr->host_us[0] = uvo::now_us();
     }
@@ -2171,6 +2171,7 @@ try {
                 if (k < 3 || r.b_used) (void)hipEventElapsedTime(&w.dev_ms[k], ref, r.ev[k]);
                 w.host_ms[k] = r.host_us[k] > 0 ? (r.host_us[k] - ref_host) * 1e-3 : -1.0;
             }
+            for (int k = 6; k < 8; k++) { w.dev_ms[k] = -1.f; if (r.det_marked) (void)hipEventElapsedTime(&w.dev_ms[k], ref, r.ev[k]); }
         }
         n++;
     }

@@ -463,8 +463,8 @@ __global__ __launch_bounds__(256) void k_e_score(const double* q1, const double*
 //     the pair (V[k][i], V[l][i]);
 //   * indR / indC are rescanned for the two pivot rows only (as OpenCV does -- the stale entries of other rows are part of the
 //     algorithm): four arg-maxes over <= 8 lanes, ties to the lower index.
-// Every floating-point operation and comparison is the scalar loop's (uvo_mono.h: jacobi_eigen, homography_kernel: the oracle's and
-// the host refit's); only independent work moved to other lanes.  The rows of a wave stop independently (`live`).
+// Every floating-point operation and comparison is the scalar loop's (uvo_mono.h: jacobi_eigen, homography_kernel -- what the host
+// refit runs); only independent work moved to other lanes.  The rows of a wave stop independently (`live`).
 static const int kHPerWg = 4;
 template <int D>
 __device__ __forceinline__ double row_ror_d(double v)

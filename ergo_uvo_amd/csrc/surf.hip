@@ -2200,7 +2200,10 @@ uvo_status surf_detect_lanes(Ctx* c, Ctx* c2, int nimg, int gate_min_features)
                 d.rows = ops[o].rows; d.cols = ops[o].cols; d.octave = ops[o].octave;
                 for (int l = 0; l < 3; l++) d.nms_margin[l] = ops[o].nms_margin[l];
             }
+            Ctx::TraceRec* trh = (c->trace_on && c->trace_cur >= 0) ? &c->trace[c->trace_cur] : nullptr;      // uvo_trace_row::dev_ms[6], [7]
+            if (trh) (void)hipEventRecord(trh->ev[6], c->stream);
             hipLaunchKernelGGL(kern, dim3(total, nim), dim3(kP23Threads), lds_launch, c->stream, lp, w, h, hd, thr, c->d_hess_order);
+            if (trh) { (void)hipEventRecord(trh->ev[7], c->stream); trh->det_marked = true; }
             if (stamps_path && d_stamps && c->lane_id == 0 && !c->master) {        // (measurement: synchronous, every launch rewrites the file)
                 std::vector<long long> hs(stamps_n);
                 (void)hipStreamSynchronize(c->stream);

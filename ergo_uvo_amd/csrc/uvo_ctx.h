@@ -265,7 +265,7 @@ struct Ctx {
     // ---- UVO_TRACE=<file>: device timestamps of every pipelined pair's phases (hipEvents with timing), written as CSV by
     // uvo_ctx_destroy: pair, lane, A begin, detection end, A end, B begin, B hypotheses scored, B end (ms since the first) ----
     static const int kTraceRing = 256;
-    struct TraceRec { long long pair = -1; hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool b_used = false;
+    struct TraceRec { long long pair = -1; hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; bool b_used = false, det_marked = false;   // [6], [7]: around the detection launch (k_hessian_nms_all), recorded when det_marked
                       double host_us[6] = {0, 0, 0, 0, 0, 0}; };     // steady clock: submit entered, pacing wait over, submit returned, worker past stage A's event,
                                                                     // worker holds a PnP slot, stage B done
     std::vector<TraceRec> trace; int trace_cur = -1; long long trace_count = 0;

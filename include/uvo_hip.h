@@ -334,8 +334,9 @@ uvo_status uvo_timing_reset(uvo_ctx* c);
  * (VO:548-632), PnP stage begins, hypotheses scored, PnP stage done (VO:647-648) -- in ms after the first traced pair's stage-A
  * begin; the last three are -1 when the pair's gates skipped solvePnPRansac.  host_ms: the submitting thread entered
  * uvo_stereo_submit, its pacing wait ended, it returned; the lane's worker saw stage A's end, got a PnP slot, finished -- steady
- * clock, ms after the first traced pair's submit (-1: not reached).  The ring keeps the last 256 pairs per lane. */
-typedef struct uvo_trace_row { long long pair; int lane; int b_used; float dev_ms[6]; double host_ms[6]; } uvo_trace_row;
+ * clock, ms after the first traced pair's submit (-1: not reached).  dev_ms[6], [7]: begin and end of the pair's detection launch
+ * (k_hessian_nms_all; bench.py's roofline.frac_pipelined).  The ring keeps the last 256 pairs per lane. */
+typedef struct uvo_trace_row { long long pair; int lane; int b_used; float dev_ms[8]; double host_ms[6]; } uvo_trace_row;
 uvo_status uvo_trace_enable(uvo_ctx* c, int on);           /* not while pairs are in flight; enabling clears the ring */
 int        uvo_trace_read(uvo_ctx* c, uvo_trace_row* rows, int cap);   /* waits for the device; rows sorted by pair; returns the
                                                                          number of traced pairs (may exceed cap), -1 on misuse */

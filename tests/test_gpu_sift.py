@@ -271,7 +271,9 @@ def test_feature_detector_switch_refusals(scene_small):
     c = uvo.Context(uvo.Params.stereo(SURF_MIN_HESSIAN=1500), 0, 640, 360, 1024)       # room for 1024 keypoints: SIFT finds ~1500 here
     try:
         with pytest.raises(uvo.UvoError, match="SURF.*SIFT"):
-            c.set_feature_detector("ORB")
+            c.set_feature_detector("BRISK")                                             # not one of the reference's four names
+        with pytest.raises(uvo.UvoError, match="SURF.*SIFT"):
+            c._check(c._lib.uvo_ctx_set_feature_detector(c._h, b"ORB"))                 # AKAZE / ORB are operators: the FUSED steps run on SURF or SIFT
         c.stereo_set_rig(rig.K_left, rig.K_right, rig.R_right, rig.t_right)
         c.set_feature_detector("SIFT")
         with pytest.raises(uvo.UvoError, match="max_kpts"):
