@@ -80,6 +80,28 @@ def test_oracle_sift(cvfix, inputs, oracle):
     assert np.array_equal(m["distance"].view(np.uint32), cvfix["sift_ratio_dist"].view(np.uint32))
 
 
+def test_oracle_akaze_and_orb(cvfix, inputs, oracle):
+    """detect_features' AKAZE / ORB branches (VOU:93-105) and match_features' Hamming arm (VOU:520-524) as the real cv::AKAZE / cv::ORB /
+    BFMatcher(NORM_HAMMING) gave them.  ORB's descriptors need the fixture's `orb_pattern` (the dumper's optional third argument: the
+    bit_pattern_31_ of the OpenCV that produced it); without it the keypoints are compared alone."""
+    if "akaze_left0_desc" not in cvfix.files:
+        pytest.skip("the fixture predates the AKAZE / ORB branches of tools/opencv_oracle/opencv_oracle.cpp")
+    for name in ("left0", "right0"):
+        k, d = oracle.akaze_detect(inputs[name], cap=1 << 17)
+        _same_kps(k, cvfix, f"akaze_{name}_kps")
+        assert np.array_equal(d, cvfix[f"akaze_{name}_desc"])
+    m = oracle.match_hamming(cvfix["akaze_left0_desc"], cvfix["akaze_right0_desc"], float(inputs["lowe_ratio"]))
+    assert np.array_equal(np.c_[m["queryIdx"], m["trainIdx"]], cvfix["akaze_ratio_matches"]) and np.array_equal(m["distance"], cvfix["akaze_ratio_dist"])
+    pat = cvfix["orb_pattern"] if "orb_pattern" in cvfix.files else None
+    for name in ("left0", "right0"):
+        k, d = oracle.orb_detect(inputs[name], pat)
+        _same_kps(k, cvfix, f"orb_{name}_kps")
+        if pat is not None:
+            assert np.array_equal(d, cvfix[f"orb_{name}_desc"])
+    m = oracle.match_hamming(cvfix["orb_left0_desc"], cvfix["orb_right0_desc"], float(inputs["lowe_ratio"]))
+    assert np.array_equal(np.c_[m["queryIdx"], m["trainIdx"]], cvfix["orb_ratio_matches"]) and np.array_equal(m["distance"], cvfix["orb_ratio_dist"])
+
+
 def test_oracle_matcher(cvfix, inputs, oracle):
     d1, d2 = cvfix["surf_left0_desc"], cvfix["surf_right0_desc"]
     idx, dist = oracle.knn2(d1, d2)
@@ -144,6 +166,18 @@ def test_hip_against_opencv(cvfix, inputs):
                 k, d = c.sift_detect(inputs[name])
                 _same_kps(k, cvfix, f"sift_{name}_kps")
                 assert np.array_equal(d, cvfix[f"sift_{name}_desc"])
+        if "akaze_left0_desc" in cvfix.files:
+            if "orb_pattern" in cvfix.files:
+                c.orb_set_pattern(cvfix["orb_pattern"])
+            for name in ("left0", "right0"):
+                k, d = c.akaze_detect(inputs[name], cap=1 << 16)
+                _same_kps(k, cvfix, f"akaze_{name}_kps")
+                assert np.array_equal(d, cvfix[f"akaze_{name}_desc"])
+                k, d = c.orb_detect(inputs[name], cap=1 << 16, descriptors="orb_pattern" in cvfix.files)
+                _same_kps(k, cvfix, f"orb_{name}_kps")
+                assert d is None or np.array_equal(d, cvfix[f"orb_{name}_desc"])
+            m = c.match_features_hamming(cvfix["akaze_left0_desc"], cvfix["akaze_right0_desc"], float(inputs["lowe_ratio"]))
+            assert np.array_equal(np.stack([m["queryIdx"], m["trainIdx"]], 1), cvfix["akaze_ratio_matches"])
         idx, dist = c.knn_match(cvfix["surf_left0_desc"], cvfix["surf_right0_desc"])
         assert np.array_equal(idx, cvfix["knn_idx"]) and np.array_equal(dist.view(np.uint32), cvfix["knn_dist"].view(np.uint32))
         m = c.match_features(cvfix["surf_left0_desc"], cvfix["surf_right0_desc"], float(inputs["lowe_ratio"]))

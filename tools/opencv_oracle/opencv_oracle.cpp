@@ -5,8 +5,10 @@
 // party with OpenCV 4.5 + contrib does:
 //     python tools/opencv_oracle/make_inputs.py /tmp/uvo_inputs.npz            # deterministic inputs (numpy only)
 //     g++ -O2 -std=c++17 tools/opencv_oracle/opencv_oracle.cpp -o opencv_oracle $(pkg-config --cflags --libs opencv4)
-//     ./opencv_oracle /tmp/uvo_inputs.npz tests/golden/opencv_fixture.npz
-//     python -m pytest tests/test_opencv_fixture.py            # oracle vs OpenCV (CPU), HIP vs OpenCV (-m gpu)
+//     ./opencv_oracle /tmp/uvo_inputs.npz tests/golden/opencv_fixture.npz [bit_pattern_31.txt]
+// (the optional third argument: a text file with the 1024 integers between the braces of `static int bit_pattern_31_[256*4]` in
+//  modules/features2d/src/orb.cpp of the OpenCV tree that was built, comments removed -- stored in the fixture so that ORB's
+//  DESCRIPTORS can be compared as well; without it the ORB keypoints are compared alone)
 // Every OpenCV call below has the argument shapes of the reference's call site, cited next to it
 // (VOU = uvo_libraries/src/VO_utility.cpp, VO = uvo/include/visual_odometry.h of the reference).
 #include <opencv2/opencv.hpp>
@@ -55,7 +57,7 @@ static void put_keypoints(npz::File& out, const std::string& key, const std::vec
 
 int main(int argc, char** argv)
 {
-    if (argc != 3) { fprintf(stderr, "usage: %s inputs.npz fixture.npz\n", argv[0]); return 2; }
+    if (argc != 3 && argc != 4) { fprintf(stderr, "usage: %s inputs.npz fixture.npz [bit_pattern_31.txt]\n", argv[0]); return 2; }
     const npz::File in = npz::load(argv[1]);
     npz::File out;
     {
@@ -98,6 +100,37 @@ int main(int argc, char** argv)
             }
         out["sift_ratio_matches"] = npz::make(good.data(), { good.size() / 2, 2 });
         out["sift_ratio_dist"] = npz::make(gd.data(), { gd.size() });
+    }
+    // ---------------- detect_features, AKAZE branch: VOU:93-98, ORB branch: VOU:100-105; match_features' Hamming arm: VOU:520-524 ----------------
+    {
+        const float ratio = (float)scalar(in, "lowe_ratio");
+        for (int which = 0; which < 2; which++) {
+            const std::string tag = which == 0 ? "akaze_" : "orb_";
+            Mat bdesc[2]; std::vector<KeyPoint> bkps[2];
+            for (int k = 0; k < 2; k++) {
+                Mat img = mat_u8(in.at(names[k]));
+                if (which == 0) { Ptr<AKAZE> detector = AKAZE::create(); detector->detectAndCompute(img, noArray(), bkps[k], bdesc[k]); }
+                else { Ptr<ORB> detector = ORB::create(10000, 1.2, 8, 31, 0, 2, ORB::HARRIS_SCORE, 31, 10); detector->detectAndCompute(img, noArray(), bkps[k], bdesc[k]); }
+                put_keypoints(out, tag + names[k] + "_kps", bkps[k]);
+                out[tag + names[k] + "_desc"] = from_mat(bdesc[k].empty() ? Mat(0, which == 0 ? 61 : 32, CV_8U) : bdesc[k]);
+            }
+            BFMatcher matcher(NORM_HAMMING, false);                                                          // VOU:522
+            std::vector<std::vector<DMatch>> knn;
+            if (!bdesc[0].empty() && !bdesc[1].empty()) matcher.knnMatch(bdesc[0], bdesc[1], knn, 2);
+            std::vector<int32_t> good; std::vector<float> gd;
+            for (size_t i = 0; i < knn.size(); i++)
+                if (knn[i].size() >= 2 && knn[i][0].distance < ratio * knn[i][1].distance) {
+                    good.push_back(knn[i][0].queryIdx); good.push_back(knn[i][0].trainIdx); gd.push_back(knn[i][0].distance);
+                }
+            out[tag + "ratio_matches"] = npz::make(good.data(), { good.size() / 2, 2 });
+            out[tag + "ratio_dist"] = npz::make(gd.data(), { gd.size() });
+        }
+        if (argc == 4) {                                                                                     // the sampling table this OpenCV was built with
+            std::vector<int32_t> pat; int v;
+            if (FILE* f = fopen(argv[3], "r")) { while (fscanf(f, " %d", &v) == 1) { pat.push_back(v); int ch; while ((ch = fgetc(f)) != EOF && (ch == ',' || ch == ' ' || ch == '\n' || ch == '\r' || ch == '\t' || ch == ';')) {} if (ch != EOF) ungetc(ch, f); } fclose(f); }
+            if (pat.size() != 1024) { fprintf(stderr, "%s: expected the 1024 integers of bit_pattern_31_, found %zu\n", argv[3], pat.size()); return 2; }
+            out["orb_pattern"] = npz::make(pat.data(), { 256, 4 });
+        }
     }
     // ---------------- match_features: VOU:515-543 (BFMatcher(NORM_L2).knnMatch k = 2, ratio test) ----------------
     {
