@@ -31,9 +31,10 @@
 
 namespace uvo {
 
+double now_us();                                                  // pose.hip / ctx.hip: steady clock, microseconds
 static const int kAkMaxLevels = 16, kAkDescBytes = 61, kAkCandCap = 1 << 18;
 struct AkLevel { int w, h, octave, sublevel, sigma_size, border, nsteps; float esigma, etime, octave_ratio; float tau[64]; };
-struct AkCand { int x, y; float v[9]; int pad; };             // a strict maximum and its 3 x 3 neighbourhood (row-major, v[4] = the maximum)
+struct AkCand { int x, y; float v[9]; int pad; };             // a strict maximum and its 3 x 3 neighbourhood (row-major, v[4] = the maximum); pad = its evolution level
 struct AkTab { int si; float alpha; };
 
 struct AkazeWs {
@@ -47,9 +48,12 @@ struct AkazeWs {
     AkCand* cand = nullptr; int* cand_n = nullptr;            // candidates of one level (device), count
     AkCand* h_cand = nullptr; int* h_hist = nullptr;          // pinned
     uvo_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; // outputs (cap)
-    AkTab* xtab = nullptr; AkTab* ytab = nullptr; int* xofs = nullptr; int* yofs = nullptr;       // general INTER_AREA tables of one octave change
+    AkTab* xtab[kAkMaxLevels] = {nullptr}; AkTab* ytab[kAkMaxLevels] = {nullptr}; int* xofs[kAkMaxLevels] = {nullptr}; int* yofs[kAkMaxLevels] = {nullptr};   // general INTER_AREA tables of the octave changes that are not exact halvings (built with the workspace)
+    float* d_kc = nullptr; float* h_kc = nullptr;             // compute_kcontrast's result: pinned source, device copy the conductance kernels read
+    hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; // the launch chain from the first evolution step to the last level's candidates, captured once per image size
     std::vector<uint8_t> mask[kAkMaxLevels]; std::vector<float> val[kAkMaxLevels];               // host: keypoint mask and Ldet at candidates
     std::vector<std::vector<AkCand>> cands;
+    std::vector<uint64_t> keys;                               // host: sort keys of the candidate list
 };
 
 // ---- fed.cpp: fed_tau_by_process_time(T, 1, 0.25f, true, tau) ----
@@ -213,10 +217,14 @@ __global__ __launch_bounds__(256) void k_ak_gradhist(const float* __restrict__ l
     __syncthreads();
     for (int i = threadIdx.x; i < nbins; i += 256) if (s_h[i]) atomicAdd(&hist[1 + i], s_h[i]);
 }
-__global__ __launch_bounds__(256) void k_ak_pm_g2(const float* __restrict__ lx, const float* __restrict__ ly, int n, float k, float* __restrict__ dst)
+// (kcontrast of the frame from device memory -- the launch is part of a captured graph --, x 0.75f once per octave change as
+// Create_Nonlinear_Scale_Space does)
+__global__ __launch_bounds__(256) void k_ak_pm_g2(const float* __restrict__ lx, const float* __restrict__ ly, int n, const float* __restrict__ kc, int octave, float* __restrict__ dst)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    float k = *kc;
+    for (int o = 0; o < octave; o++) k *= 0.75f;
     const float k2inv = 1.0f / (k * k);
     dst[i] = 1.0f / (1.0f + ((lx[i] * lx[i] + ly[i] * ly[i]) * k2inv));
 }
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(256) void k_ak_det(const float* __restrict__ lxx, c
     if (i < n) dst[i] = (lxx[i] * lyy[i] - lxy[i] * lxy[i]) * sig4;
 }
 // FindKeypointsSameScale's parallel half: strict maxima of the 3 x 3 neighbourhood above the threshold inside [border, size - border)
-__global__ __launch_bounds__(256) void k_ak_candidates(const float* __restrict__ ldet, int w, int h, int border, float thr, AkCand* __restrict__ out, int* __restrict__ count, int cap)
+__global__ __launch_bounds__(256) void k_ak_candidates(const float* __restrict__ ldet, int w, int h, int border, float thr, int level, AkCand* __restrict__ out, int* __restrict__ count, int cap)
 {
     const int x = border + blockIdx.x * 256 + threadIdx.x, y = border + blockIdx.y;
     if (x >= w - border || y >= h - border) return;
@@ -283,7 +291,7 @@ __global__ __launch_bounds__(256) void k_ak_candidates(const float* __restrict__
     const int slot = atomicAdd(count, 1);
     if (slot >= cap) return;
     AkCand c;
-    c.x = x; c.y = y; c.pad = 0;
+    c.x = x; c.y = y; c.pad = level;
     c.v[0] = prev[x - 1]; c.v[1] = prev[x]; c.v[2] = prev[x + 1]; c.v[3] = curr[x - 1]; c.v[4] = value; c.v[5] = curr[x + 1];
     c.v[6] = next[x - 1]; c.v[7] = next[x]; c.v[8] = next[x + 1];
     out[slot] = c;
@@ -456,11 +464,15 @@ void akaze_ws_free(Ctx* c)
     for (int i = 0; i < kAkMaxLevels; i++) { (void)hipFree(s->Lt[i]); (void)hipFree(s->Lsmooth[i]); (void)hipFree(s->Lx[i]); (void)hipFree(s->Ly[i]); (void)hipFree(s->Ldet[i]); }
     for (float* p : s->s) (void)hipFree(p);
     (void)hipFree(s->img); (void)hipFree(s->img8); (void)hipFree(s->hist); (void)hipFree(s->cand); (void)hipFree(s->cand_n); (void)hipFree(s->d_kps); (void)hipFree(s->d_desc);
-    (void)hipFree(s->xtab); (void)hipFree(s->ytab); (void)hipFree(s->xofs); (void)hipFree(s->yofs);
+    for (int i = 0; i < kAkMaxLevels; i++) { (void)hipFree(s->xtab[i]); (void)hipFree(s->ytab[i]); (void)hipFree(s->xofs[i]); (void)hipFree(s->yofs[i]); }
+    if (s->exec) (void)hipGraphExecDestroy(s->exec);
+    if (s->graph) (void)hipGraphDestroy(s->graph);
+    (void)hipFree(s->d_kc); (void)hipHostFree(s->h_kc);
     (void)hipHostFree(s->h_cand); (void)hipHostFree(s->h_hist);
     delete s;
     c->akaze_ws = nullptr;
 }
+static void area_tab(int ssize, int dsize, double scale, std::vector<AkTab>* tab, std::vector<int>* ofs);
 static AkazeWs* akaze_ws(Ctx* c, int w, int h)
 {
     AkazeWs* s = static_cast<AkazeWs*>(c->akaze_ws);
@@ -483,9 +495,23 @@ static AkazeWs* akaze_ws(Ctx* c, int w, int h)
     ok = ok && hipMalloc(reinterpret_cast<void**>(&s->img8), npx) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&s->hist), sizeof(int) * 512) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&s->cand), sizeof(AkCand) * kAkCandCap) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&s->cand_n), sizeof(int) * kAkMaxLevels) == hipSuccess &&
          hipMalloc(reinterpret_cast<void**>(&s->d_kps), sizeof(uvo_keypoint) * (size_t)s->cap) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&s->d_desc), (size_t)kAkDescBytes * s->cap) == hipSuccess &&
-         hipMalloc(reinterpret_cast<void**>(&s->xtab), sizeof(AkTab) * 2 * (size_t)(w + 2)) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&s->ytab), sizeof(AkTab) * 2 * (size_t)(h + 2)) == hipSuccess &&
-         hipMalloc(reinterpret_cast<void**>(&s->xofs), sizeof(int) * (size_t)(w + 2)) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&s->yofs), sizeof(int) * (size_t)(h + 2)) == hipSuccess &&
+         hipMalloc(reinterpret_cast<void**>(&s->d_kc), sizeof(float)) == hipSuccess && hipHostMalloc(reinterpret_cast<void**>(&s->h_kc), sizeof(float)) == hipSuccess &&
          hipHostMalloc(reinterpret_cast<void**>(&s->h_cand), sizeof(AkCand) * kAkCandCap) == hipSuccess && hipHostMalloc(reinterpret_cast<void**>(&s->h_hist), sizeof(int) * 512) == hipSuccess;
+    // resize(Lt[i - 1], Lt[i], INTER_AREA) at an octave change: exact halving has a kernel of its own; other size ratios (odd sizes) take
+    // resizeArea_'s tables, which depend on the sizes alone
+    for (int i = 1; i < s->n && ok; i++) {
+        if (!(s->lv[i].octave > s->lv[i - 1].octave)) continue;
+        const int lw = s->lv[i].w, lh = s->lv[i].h, sw = s->lv[i - 1].w, sh = s->lv[i - 1].h;
+        const double scale_x = 1. / ((double)lw / sw), scale_y = 1. / ((double)lh / sh);
+        const int isx = cv_round_d(scale_x), isy = cv_round_d(scale_y);
+        if (fabs(scale_x - isx) < DBL_EPSILON && fabs(scale_y - isy) < DBL_EPSILON && isx == 2 && isy == 2) continue;
+        std::vector<AkTab> xt, yt; std::vector<int> xo, yo;
+        area_tab(sw, lw, scale_x, &xt, &xo); area_tab(sh, lh, scale_y, &yt, &yo);
+        ok = hipMalloc(reinterpret_cast<void**>(&s->xtab[i]), sizeof(AkTab) * (xt.size() + 1)) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&s->ytab[i]), sizeof(AkTab) * (yt.size() + 1)) == hipSuccess &&
+             hipMalloc(reinterpret_cast<void**>(&s->xofs[i]), sizeof(int) * xo.size()) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&s->yofs[i]), sizeof(int) * yo.size()) == hipSuccess &&
+             hipMemcpy(s->xtab[i], xt.data(), sizeof(AkTab) * xt.size(), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(s->ytab[i], yt.data(), sizeof(AkTab) * yt.size(), hipMemcpyHostToDevice) == hipSuccess &&
+             hipMemcpy(s->xofs[i], xo.data(), sizeof(int) * xo.size(), hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(s->yofs[i], yo.data(), sizeof(int) * yo.size(), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (!ok) { akaze_ws_free(c); return nullptr; }
     s->cands.resize(kAkMaxLevels);
     return s;
@@ -519,14 +545,15 @@ static void area_tab(int ssize, int dsize, double scale, std::vector<AkTab>* tab
 // find_neighbor_point (AKAZEFeatures.cpp): a keypoint of `mask` within search_radius (L2) of (x, y), scanning the square window row-major
 static bool find_neighbor_point(int x, int y, const std::vector<uint8_t>& mask, int cols, int rows, int search_radius, int* idx)
 {
-    for (int i = y - search_radius; i < y + search_radius; ++i) {
-        if (i < 0 || i >= rows) continue;
+    // (the marks are sparse: eight mask bytes are tested at a time and only a non-zero word is walked byte by byte, in the same order)
+    const int j0 = std::max(x - search_radius, 0), j1 = std::min(x + search_radius, cols), r2 = search_radius * search_radius;
+    for (int i = std::max(y - search_radius, 0); i < std::min(y + search_radius, rows); ++i) {
         const uint8_t* curr = mask.data() + (size_t)i * cols;
-        for (int j = x - search_radius; j < x + search_radius; ++j) {
-            if (j < 0 || j >= cols) continue;
-            if (curr[j] == 0) continue;
-            const int dx = j - x, dy = i - y;
-            if (dx * dx + dy * dy <= search_radius * search_radius) { *idx = i * cols + j; return true; }
+        const int dy = i - y;
+        for (int j = j0; j < j1;) {
+            if (j1 - j >= 8) { uint64_t wd; memcpy(&wd, curr + j, 8); if (wd == 0) { j += 8; continue; } }
+            if (curr[j] != 0) { const int dx = j - x; if (dx * dx + dy * dy <= r2) { *idx = i * cols + j; return true; } }
+            ++j;
         }
     }
     return false;
@@ -541,6 +568,10 @@ uvo_status akaze_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, i
     hipStream_t st = c->stream;
     const dim3 blk(256);
     auto grid = [](int ww, int hh) { return dim3((ww + 255) / 256, hh); };
+    static const bool dbg = getenv("UVO_DBG_PHASE") != nullptr;                                            // host wall clock of the call's phases
+    double tph[8] = {0}; int nph = 0;
+    auto stamp = [&]() { if (dbg && nph < 8) tph[nph++] = uvo::now_us(); };
+    stamp();
     // ---- Create_Nonlinear_Scale_Space ----
     const uint8_t* d_img8 = gray;
     int d_stride = stride;
@@ -552,6 +583,8 @@ uvo_status akaze_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, i
     AkKernel k9, k5;
     { int ks = cv_ceil_d((double)(2.0f * (1.0f + (1.6f - 0.8f) / (0.3f)))); ks |= 1; gauss_kernel(ks, (double)1.6f, &k9); }
     gauss_kernel(5, (double)1.0f, &k5);
+    // last frame's keypoint marks (the masks are whole planes: clearing the few thousand marked entries, not 11 MB of planes per frame)
+    for (int i = 0; i < s->n; i++) { for (const AkCand& cd : s->cands[i]) s->mask[i][(size_t)cd.y * s->lv[i].w + cd.x] = 0; s->cands[i].clear(); }
     hipLaunchKernelGGL(k_ak_blur_rows, grid(w, h), blk, 0, st, s->img, w, h, k9, s->s[0]);
     hipLaunchKernelGGL(k_ak_blur_cols, grid(w, h), blk, 0, st, s->s[0], w, h, k9, s->Lsmooth[0]);
     UVO_HIP_TRY(c, hipMemcpyAsync(s->Lt[0], s->Lsmooth[0], sizeof(float) * (size_t)w * h, hipMemcpyDeviceToDevice, st));
@@ -582,71 +615,85 @@ uvo_status akaze_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, i
             }
         }
     }
-    for (int i = 1; i < s->n; i++) {
-        const AkLevel& lv = s->lv[i];
-        const int lw = lv.w, lh = lv.h;
-        if (lv.octave > s->lv[i - 1].octave) {
-            const int sw = s->lv[i - 1].w, sh = s->lv[i - 1].h;
-            const double scale_x = 1. / ((double)lw / sw), scale_y = 1. / ((double)lh / sh);
-            const int isx = cv_round_d(scale_x), isy = cv_round_d(scale_y);
-            if (fabs(scale_x - isx) < DBL_EPSILON && fabs(scale_y - isy) < DBL_EPSILON && isx == 2 && isy == 2)
-                hipLaunchKernelGGL(k_ak_half, grid(lw, lh), blk, 0, st, s->Lt[i - 1], sw, lw, lh, s->Lt[i]);
-            else {
-                std::vector<AkTab> xt, yt; std::vector<int> xo, yo;
-                area_tab(sw, lw, scale_x, &xt, &xo); area_tab(sh, lh, scale_y, &yt, &yo);
-                UVO_HIP_TRY(c, hipMemcpyAsync(s->xtab, xt.data(), sizeof(AkTab) * xt.size(), hipMemcpyHostToDevice, st));
-                UVO_HIP_TRY(c, hipMemcpyAsync(s->ytab, yt.data(), sizeof(AkTab) * yt.size(), hipMemcpyHostToDevice, st));
-                UVO_HIP_TRY(c, hipMemcpyAsync(s->xofs, xo.data(), sizeof(int) * xo.size(), hipMemcpyHostToDevice, st));
-                UVO_HIP_TRY(c, hipMemcpyAsync(s->yofs, yo.data(), sizeof(int) * yo.size(), hipMemcpyHostToDevice, st));
-                hipLaunchKernelGGL(k_ak_area, grid(lw, lh), blk, 0, st, s->Lt[i - 1], sw, lw, lh, s->xtab, s->xofs, s->ytab, s->yofs, s->Lt[i]);
-                UVO_HIP_TRY(c, hipStreamSynchronize(st));          // (the tables are host vectors of this scope)
+    stamp();
+    *s->h_kc = kcontrast;
+    UVO_HIP_TRY(c, hipMemcpyAsync(s->d_kc, s->h_kc, sizeof(float), hipMemcpyHostToDevice, st));
+    // ---- the evolution (levels 1 ..), Compute_Determinant_Hessian_Response and the candidates of every level: ~600 small launches (166 FED
+    // steps, 80 derivative passes at 1080p) whose arguments depend on the image SIZE only -- captured once per workspace as a HIP graph
+    // and replayed with one call per frame.  Measured: the chain is bound by the DEVICE (600 kernels of 3-6 us back to back: 3.2 ms at
+    // 1080p either way; whole call 1.46 ms as a graph against 1.56 ms launch by launch at 640 x 360, level at 1080p); what the graph
+    // buys is the host thread, idle instead of issuing launches for 3 ms. ----
+    auto record = [&]() -> uvo_status {
+        for (int i = 1; i < s->n; i++) {
+            const AkLevel& lv = s->lv[i];
+            const int lw = lv.w, lh = lv.h;
+            if (lv.octave > s->lv[i - 1].octave) {
+                const int sw = s->lv[i - 1].w;
+                if (!s->xtab[i]) hipLaunchKernelGGL(k_ak_half, grid(lw, lh), blk, 0, st, s->Lt[i - 1], sw, lw, lh, s->Lt[i]);
+                else hipLaunchKernelGGL(k_ak_area, grid(lw, lh), blk, 0, st, s->Lt[i - 1], sw, lw, lh, s->xtab[i], s->xofs[i], s->ytab[i], s->yofs[i], s->Lt[i]);
+            } else UVO_HIP_TRY(c, hipMemcpyAsync(s->Lt[i], s->Lt[i - 1], sizeof(float) * (size_t)lw * lh, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(k_ak_blur_rows, grid(lw, lh), blk, 0, st, s->Lt[i], lw, lh, k5, s->s[0]);
+            hipLaunchKernelGGL(k_ak_blur_cols, grid(lw, lh), blk, 0, st, s->s[0], lw, lh, k5, s->Lsmooth[i]);
+            hipLaunchKernelGGL(k_ak_scharr, grid(lw, lh), blk, 0, st, s->Lsmooth[i], lw, lh, 1, s->s[0]);
+            hipLaunchKernelGGL(k_ak_scharr, grid(lw, lh), blk, 0, st, s->Lsmooth[i], lw, lh, 0, s->s[1]);
+            hipLaunchKernelGGL(k_ak_pm_g2, dim3((lw * lh + 255) / 256), blk, 0, st, s->s[0], s->s[1], lw * lh, s->d_kc, lv.octave, s->s[2]);
+            // Fast Explicit Diffusion: the cycle's steps, ping-pong between Lt[i] and a scratch plane
+            float* cur = s->Lt[i]; float* nxt = s->s[3];
+            for (int j = 0; j < lv.nsteps; j++) {
+                hipLaunchKernelGGL(k_ak_nld_step, grid(lw, lh), blk, 0, st, cur, s->s[2], lw, lh, lv.tau[j] * 0.5f, nxt);
+                std::swap(cur, nxt);
             }
-            kcontrast *= 0.75f;
-        } else UVO_HIP_TRY(c, hipMemcpyAsync(s->Lt[i], s->Lt[i - 1], sizeof(float) * (size_t)lw * lh, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_ak_blur_rows, grid(lw, lh), blk, 0, st, s->Lt[i], lw, lh, k5, s->s[0]);
-        hipLaunchKernelGGL(k_ak_blur_cols, grid(lw, lh), blk, 0, st, s->s[0], lw, lh, k5, s->Lsmooth[i]);
-        hipLaunchKernelGGL(k_ak_scharr, grid(lw, lh), blk, 0, st, s->Lsmooth[i], lw, lh, 1, s->s[0]);
-        hipLaunchKernelGGL(k_ak_scharr, grid(lw, lh), blk, 0, st, s->Lsmooth[i], lw, lh, 0, s->s[1]);
-        hipLaunchKernelGGL(k_ak_pm_g2, dim3((lw * lh + 255) / 256), blk, 0, st, s->s[0], s->s[1], lw * lh, kcontrast, s->s[2]);
-        // Fast Explicit Diffusion: the cycle's steps, ping-pong between Lt[i] and a scratch plane
-        float* cur = s->Lt[i]; float* nxt = s->s[3];
-        for (int j = 0; j < lv.nsteps; j++) {
-            hipLaunchKernelGGL(k_ak_nld_step, grid(lw, lh), blk, 0, st, cur, s->s[2], lw, lh, lv.tau[j] * 0.5f, nxt);
-            std::swap(cur, nxt);
+            if (cur != s->Lt[i]) UVO_HIP_TRY(c, hipMemcpyAsync(s->Lt[i], cur, sizeof(float) * (size_t)lw * lh, hipMemcpyDeviceToDevice, st));
         }
-        if (cur != s->Lt[i]) UVO_HIP_TRY(c, hipMemcpyAsync(s->Lt[i], cur, sizeof(float) * (size_t)lw * lh, hipMemcpyDeviceToDevice, st));
-    }
-    // ---- Compute_Determinant_Hessian_Response + the candidates of every level ----
-    UVO_HIP_TRY(c, hipMemsetAsync(s->cand_n, 0, sizeof(int) * kAkMaxLevels, st));
-    int cand_count[kAkMaxLevels];
-    for (int i = 0; i < s->n; i++) {
-        const AkLevel& lv = s->lv[i];
-        const int lw = lv.w, lh = lv.h, r = lv.sigma_size;
-        hipLaunchKernelGGL(k_ak_sep_deriv, grid(lw, lh), blk, 0, st, s->Lsmooth[i], lw, lh, 1, r, s->Lx[i]);
-        hipLaunchKernelGGL(k_ak_sep_deriv, grid(lw, lh), blk, 0, st, s->Lx[i], lw, lh, 1, r, s->s[0]);        // Lxx
-        hipLaunchKernelGGL(k_ak_sep_deriv, grid(lw, lh), blk, 0, st, s->Lx[i], lw, lh, 0, r, s->s[1]);        // Lxy
-        hipLaunchKernelGGL(k_ak_sep_deriv, grid(lw, lh), blk, 0, st, s->Lsmooth[i], lw, lh, 0, r, s->Ly[i]);
-        hipLaunchKernelGGL(k_ak_sep_deriv, grid(lw, lh), blk, 0, st, s->Ly[i], lw, lh, 0, r, s->s[2]);        // Lyy
-        hipLaunchKernelGGL(k_ak_det, dim3((lw * lh + 255) / 256), blk, 0, st, s->s[0], s->s[1], s->s[2], lw * lh, (float)(r * r * r * r), s->Ldet[i]);
-        s->cands[i].clear();
-        cand_count[i] = 0;
-        if (lv.border + 1 >= lh || lw - 2 * lv.border <= 0 || lh - 2 * lv.border <= 0) continue;              // "if border is too big we shouldn't search any keypoints"
-        hipLaunchKernelGGL(k_ak_candidates, grid(lw - 2 * lv.border, lh - 2 * lv.border), blk, 0, st, s->Ldet[i], lw, lh, lv.border, 0.001f, s->cand, s->cand_n + i, kAkCandCap);
-        UVO_HIP_TRY(c, hipMemcpyAsync(&cand_count[i], s->cand_n + i, sizeof(int), hipMemcpyDeviceToHost, st));
+        UVO_HIP_TRY(c, hipMemsetAsync(s->cand_n, 0, sizeof(int) * kAkMaxLevels, st));
+        for (int i = 0; i < s->n; i++) {
+            const AkLevel& lv = s->lv[i];
+            const int lw = lv.w, lh = lv.h, r = lv.sigma_size;
+            hipLaunchKernelGGL(k_ak_sep_deriv, grid(lw, lh), blk, 0, st, s->Lsmooth[i], lw, lh, 1, r, s->Lx[i]);
+            hipLaunchKernelGGL(k_ak_sep_deriv, grid(lw, lh), blk, 0, st, s->Lx[i], lw, lh, 1, r, s->s[0]);        // Lxx
+            hipLaunchKernelGGL(k_ak_sep_deriv, grid(lw, lh), blk, 0, st, s->Lx[i], lw, lh, 0, r, s->s[1]);        // Lxy
+            hipLaunchKernelGGL(k_ak_sep_deriv, grid(lw, lh), blk, 0, st, s->Lsmooth[i], lw, lh, 0, r, s->Ly[i]);
+            hipLaunchKernelGGL(k_ak_sep_deriv, grid(lw, lh), blk, 0, st, s->Ly[i], lw, lh, 0, r, s->s[2]);        // Lyy
+            hipLaunchKernelGGL(k_ak_det, dim3((lw * lh + 255) / 256), blk, 0, st, s->s[0], s->s[1], s->s[2], lw * lh, (float)(r * r * r * r), s->Ldet[i]);
+            if (lv.border + 1 >= lh || lw - 2 * lv.border <= 0 || lh - 2 * lv.border <= 0) continue;              // "if border is too big we shouldn't search any keypoints"
+            // every level appends to one list (the record carries its level); cand_n[0] counts them all
+            hipLaunchKernelGGL(k_ak_candidates, grid(lw - 2 * lv.border, lh - 2 * lv.border), blk, 0, st, s->Ldet[i], lw, lh, lv.border, 0.001f, i, s->cand, s->cand_n, kAkCandCap);
+        }
+        return UVO_OK;
+    };
+    static const bool use_graph = !(getenv("UVO_AKAZE_GRAPH") && atoi(getenv("UVO_AKAZE_GRAPH")) == 0);      // UVO_AKAZE_GRAPH=0: launch by launch (measurement)
+    if (use_graph) {
+        if (!s->exec) {
+            UVO_HIP_TRY(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            const uvo_status rs = record();
+            hipGraph_t g = nullptr;
+            const hipError_t ee = hipStreamEndCapture(st, &g);
+            if (rs != UVO_OK || ee != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); if (rs == UVO_OK) c->err = std::string("AKAZE: graph capture: ") + hipGetErrorString(ee); return rs != UVO_OK ? rs : UVO_HIP_ERROR; }
+            s->graph = g;
+            UVO_HIP_TRY(c, hipGraphInstantiate(&s->exec, s->graph, nullptr, nullptr, 0));
+        }
+        UVO_HIP_TRY(c, hipGraphLaunch(s->exec, st));
+    } else UVO_TRY(record());
+    int n_cand = 0;
+    UVO_HIP_TRY(c, hipMemcpyAsync(s->h_hist, s->cand_n, sizeof(int), hipMemcpyDeviceToHost, st));
+    UVO_HIP_TRY(c, hipStreamSynchronize(st));
+    n_cand = s->h_hist[0];
+    if (n_cand > kAkCandCap) { c->err = "AKAZE: more local maxima than the candidate list holds"; return UVO_CAPACITY; }
+    if (n_cand) {
+        UVO_HIP_TRY(c, hipMemcpyAsync(s->h_cand, s->cand, sizeof(AkCand) * n_cand, hipMemcpyDeviceToHost, st));
         UVO_HIP_TRY(c, hipStreamSynchronize(st));
-        if (cand_count[i] > kAkCandCap) { c->err = "AKAZE: more local maxima in one level than the candidate list holds"; return UVO_CAPACITY; }
-        if (cand_count[i]) {
-            UVO_HIP_TRY(c, hipMemcpyAsync(s->h_cand, s->cand, sizeof(AkCand) * cand_count[i], hipMemcpyDeviceToHost, st));
-            UVO_HIP_TRY(c, hipStreamSynchronize(st));
-            s->cands[i].assign(s->h_cand, s->h_cand + cand_count[i]);
-            std::sort(s->cands[i].begin(), s->cands[i].end(), [](const AkCand& a, const AkCand& b) { return a.y != b.y ? a.y < b.y : a.x < b.x; });      // row-major, as the scan visits them
-        }
+        // level by level, row-major inside a level -- the order the scans visit them: one sort of 64-bit keys (level, y, x, list position)
+        std::vector<uint64_t>& keys = s->keys;
+        keys.resize((size_t)n_cand);
+        for (int q = 0; q < n_cand; q++) { const AkCand& cd = s->h_cand[q]; keys[(size_t)q] = ((uint64_t)cd.pad << 58) | ((uint64_t)cd.y << 40) | ((uint64_t)cd.x << 22) | (uint64_t)q; }
+        std::sort(keys.begin(), keys.end());
+        for (int q = 0; q < n_cand; q++) { const AkCand& cd = s->h_cand[keys[(size_t)q] & 0x3fffffu]; s->cands[cd.pad].push_back(cd); }
     }
     UVO_HIP_TRY(c, hipGetLastError());
+    stamp();
     // ---- FindKeypointsSameScale's sequential half, Find_Scale_Space_Extrema's two sweeps (host, candidate lists) ----
     for (int i = 0; i < s->n; i++) {
         const AkLevel& lv = s->lv[i];
-        std::fill(s->mask[i].begin(), s->mask[i].end(), (uint8_t)0);
         for (const AkCand& cd : s->cands[i]) {
             const float value = cd.v[4];
             s->val[i][(size_t)cd.y * lv.w + cd.x] = value;
@@ -710,6 +757,7 @@ uvo_status akaze_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, i
     }
     const int n = (int)out.size();
     *n_out = n;
+    stamp();
     if (n > s->cap) { c->err = "AKAZE found more keypoints than the context's max_kpts"; return UVO_CAPACITY; }
     if ((kps || desc) && n > cap) { c->err = "uvo_akaze_detect: output capacity too small"; return UVO_CAPACITY; }
     if (n == 0) return UVO_OK;
@@ -724,6 +772,9 @@ uvo_status akaze_detect(Ctx* c, const uint8_t* gray, int w, int h, int stride, i
     if (kps) UVO_HIP_TRY(c, hipMemcpyAsync(kps, s->d_kps, sizeof(uvo_keypoint) * n, hipMemcpyDeviceToHost, st));
     if (desc) UVO_HIP_TRY(c, hipMemcpyAsync(desc, s->d_desc, (size_t)kAkDescBytes * n, hipMemcpyDeviceToHost, st));
     UVO_HIP_TRY(c, hipStreamSynchronize(st));
+    stamp();
+    if (dbg && nph == 5) fprintf(stderr, "[uvo] akaze phases (ms): contrast %.3f | evolution + responses + candidates (%d) %.3f | host suppression + refinement %.3f | orientation + M-LDB + copies (%d keypoints) %.3f\n",
+                                 (tph[1] - tph[0]) * 1e-3, n_cand, (tph[2] - tph[1]) * 1e-3, (tph[3] - tph[2]) * 1e-3, n, (tph[4] - tph[3]) * 1e-3);
     return UVO_OK;
 }
 // intermediates for the parity tests: what = 0 Lt, 1 Lsmooth, 2 Lx, 3 Ly, 4 Ldet of `level` after the last akaze_detect
