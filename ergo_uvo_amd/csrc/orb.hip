@@ -265,8 +265,9 @@ __global__ __launch_bounds__(256) void k_orb_blur(const uint8_t* __restrict__ sr
 // computeOrbDescriptors, WTA_K 2: lane = descriptor byte; bit b = I(p[16 byte + 2 b]) < I(p[16 byte + 2 b + 1]) on the blurred level
 __global__ __launch_bounds__(256) void k_orb_describe(OrbLevels L, const int8_t* __restrict__ pattern, const uvo_keypoint* __restrict__ kps, int n, uint8_t* __restrict__ desc)
 {
-    __shared__ int8_t pat[1024];
-    reinterpret_cast<int*>(pat)[threadIdx.x] = reinterpret_cast<const int*>(pattern)[threadIdx.x];
+    __shared__ int pat32[256];                                      // the table's 1024 signed bytes, copied a word per thread
+    pat32[threadIdx.x] = reinterpret_cast<const int*>(pattern)[threadIdx.x];
+    const int8_t* pat = reinterpret_cast<const int8_t*>(pat32);
     __syncthreads();
     const int i = blockIdx.x * 8 + (threadIdx.x >> 5), lane = threadIdx.x & 31;
     if (i >= n) return;

@@ -155,7 +155,8 @@ double orc_compute_scale_factor(float distance, const double* pts_nx3, int n)
 struct orc_mono {
     orc_vo_params p;
     double K[9];
-    int cap, vo_initialized, use_essential, use_sift;      /* use_sift: FEATURE_DETECTOR == "SIFT" (VOH:25) */
+    int cap, vo_initialized, use_essential, detector;      /* detector: the reference's global FEATURE_DETECTOR (VOH:25): 0 "SURF", 1 "SIFT", 2 "AKAZE", 3 "ORB" */
+    int orb_pattern[1024];                                  /* "ORB": the sampling table (o_orb.c: an input) */
     orc_keypoint* prev_kps; float* prev_desc; int n_prev;
     double R[9], t[3], SF;
     /* last-step intermediates */
@@ -185,7 +186,12 @@ void orc_mono_destroy(orc_mono* s)
     free(s->prev_kps); free(s->prev_desc); free(s->kps); free(s->desc); free(s->matches); free(s->mask); free(s->good_pts); free(s);
 }
 
-void orc_mono_use_sift(orc_mono* s, int on) { s->use_sift = on; }
+void orc_mono_use_sift(orc_mono* s, int on) { s->detector = on ? 1 : 0; }
+void orc_mono_use_detector(orc_mono* s, int detector, const int* pattern)
+{
+    s->detector = detector;
+    if (detector == 3 && pattern) memcpy(s->orb_pattern, pattern, sizeof(s->orb_pattern));
+}
 
 int orc_mono_step(orc_mono* s, const uint8_t* img, int w, int h, int stride, double range, double dt, orc_mono_result* out)
 {
@@ -193,9 +199,21 @@ int orc_mono_step(orc_mono* s, const uint8_t* img, int w, int h, int stride, dou
     memset(out, 0, sizeof(*out));
     s->n_matches = s->n_inl = s->G = 0;
     orc_surf_params sp = { (double)p->SURF_MIN_HESSIAN, p->SURF_OCTAVES_NUMBER, p->SURF_OCTAVES_LAYERS, p->SURF_EXTENDED, p->SURF_UPRIGHT };
-    const int ddim = s->use_sift || p->SURF_EXTENDED ? 128 : 64;
-    int n = s->use_sift ? orc_sift_detect_and_compute(img, w, h, stride, 10000, 3, 0.03, 10, 1.6, s->kps, s->desc, s->cap)      /* VOU:107-112 */
-                        : orc_surf_detect_and_compute(img, w, h, stride, &sp, s->kps, s->desc, s->cap);
+    const int ddim = s->detector == 2 ? 61 : s->detector == 3 ? 32 : (s->detector == 1 || p->SURF_EXTENDED ? 128 : 64);
+    int n;
+    if (s->detector >= 2) {
+        /* VOU:93-105: CV_8U rows.  The mono loop's match_features overload (VOU:551-573) constructs BFMatcher(NORM_L2) whatever the detector:
+         * on CV_8U rows OpenCV sums the squared byte differences in integers and takes the float square root -- every sum is below 2^24,
+         * so the float matcher on the bytes widened to float returns the same distances; the rows are kept widened */
+        uint8_t* b = (uint8_t*)malloc((size_t)s->cap * 64);
+        n = s->detector == 2 ? orc_akaze_detect_and_compute(img, w, h, stride, s->kps, b, s->cap)
+                             : orc_orb_detect_and_compute(img, w, h, stride, 10000, 1.2f, 8, 31, 0, 31, 10, s->orb_pattern, s->kps, b, s->cap);
+        const int nn = n < 0 ? s->cap : n;
+        for (size_t i = 0; i < (size_t)nn * ddim; i++) s->desc[i] = (float)b[i];
+        free(b);
+    } else
+    n = s->detector == 1 ? orc_sift_detect_and_compute(img, w, h, stride, 10000, 3, 0.03, 10, 1.6, s->kps, s->desc, s->cap)      /* VOU:107-112 */
+                         : orc_surf_detect_and_compute(img, w, h, stride, &sp, s->kps, s->desc, s->cap);
     if (n < 0) n = s->cap;
     s->n_kps = n; out->n_kps = n;
     if (!s->vo_initialized) {                                            /* VO:227-245 */

@@ -422,6 +422,13 @@ class MonoVO:
         lib().orc_mono_use_sift.argtypes = [C.c_void_p, C.c_int]
         lib().orc_mono_use_sift(self.h, int(bool(on)))
 
+    def use_detector(self, name: str, orb_pattern=None):
+        """FEATURE_DETECTOR for the mono loop: "SURF", "SIFT", "AKAZE" or "ORB" (orb_pattern = the sampling table, 256 x (x0, y0, x1, y1))."""
+        det = ("SURF", "SIFT", "AKAZE", "ORB").index(name)
+        pat = _c(np.asarray(orb_pattern).reshape(-1), np.int32) if det == 3 else None
+        lib().orc_mono_use_detector.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib().orc_mono_use_detector(self.h, det, _p(pat) if pat is not None else None)
+
     def step(self, img, rng=1.0, dt=0.05) -> MonoResult:
         img = _c(img, np.uint8)
         h, w = img.shape

@@ -226,6 +226,7 @@ typedef struct {
 orc_mono* orc_mono_create(const orc_vo_params* p, const double* K, int max_kpts);
 void      orc_mono_destroy(orc_mono* s);
 void      orc_mono_use_sift(orc_mono* s, int on);       /* FEATURE_DETECTOR = "SIFT" */
+void        orc_mono_use_detector(orc_mono* s, int detector /* 0 "SURF", 1 "SIFT", 2 "AKAZE", 3 "ORB" */, const int* orb_pattern /* 1024 ints for "ORB" */);
 int       orc_mono_step(orc_mono* s, const uint8_t* img, int w, int h, int stride, double range, double dt, orc_mono_result* out);
 int       orc_mono_get(orc_mono* s, const char* what, void* out, int cap_bytes);
 

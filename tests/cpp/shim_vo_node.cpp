@@ -6,6 +6,7 @@
 //   out.bin   : per frame int32 x 6 (published, valid, n_kps, n_matches, n_inliers, n_good3d) + f64 x 4 (v[3], stamp)
 //   --config-only as first argument: load the YAML files, print the globals as "NAME value" lines, touch no GPU.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "uvo_libraries_hip/visual_odometry_hip.h"
@@ -56,7 +57,8 @@ int main(int argc, char** argv)
         int hdr[3];
         if (fread(hdr, sizeof(int), 3, f) != 3) { fprintf(stderr, "short header\n"); return 2; }
         const int W = hdr[0], H = hdr[1], n = hdr[2];
-        uvo_hip::configure(0, W > 640 ? W : 640, H > 480 ? H : 480, 8192);
+        const int max_kpts = getenv("UVO_TEST_MAX_KPTS") ? atoi(getenv("UVO_TEST_MAX_KPTS")) : 8192;       // (ORB::create(10000, ...) returns more than 8192 keypoints)
+        uvo_hip::configure(0, W > 640 ? W : 640, H > 480 ? H : 480, max_kpts);
         uvo_hip::visual_odometry_core node(mode, tree, argv[2]);
         FILE* out = fopen(argv[4], "wb");
         if (!out) { perror("out"); return 2; }

@@ -228,7 +228,7 @@ def _rgb(gray):
     return np.repeat(gray[..., None], 3, axis=2)
 
 
-def _run_node(tmp_path, mode, cam, frames, params, intr):
+def _run_node(tmp_path, mode, cam, frames, params, intr, env=None):
     _build()
     inp, outp, pf, cf = tmp_path / "frames.bin", tmp_path / "out.bin", tmp_path / "params.yaml", tmp_path / "intr.yaml"
     pf.write_text(params); cf.write_text(intr)
@@ -239,7 +239,7 @@ def _run_node(tmp_path, mode, cam, frames, params, intr):
             f.write(struct.pack("<2d", stamp, rng))
             for im in imgs:
                 f.write(np.ascontiguousarray(im).tobytes())
-    res = subprocess.run([DRIVER, mode, cam, str(inp), str(outp), str(pf), str(cf)], capture_output=True, text=True, timeout=600)
+    res = subprocess.run([DRIVER, mode, cam, str(inp), str(outp), str(pf), str(cf)], capture_output=True, text=True, timeout=600, env=dict(os.environ, **(env or {})))
     assert res.returncode == 0, res.stderr
     return np.fromfile(outp, np.dtype([("i", "<i4", 6), ("d", "<f8", 4)]))
 
@@ -285,6 +285,70 @@ def test_mono_node_loop_matches_oracle(oracle, tmp_path):
             v, ov = r["d"][:3], np.array(list(o.velocity))
             assert np.linalg.norm(v - ov) <= 1e-4 * np.linalg.norm(ov), (i, v, ov)
     assert n_pub == len(ks) - 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("detector", ["AKAZE", "ORB"])
+def test_mono_node_loop_on_binary_features_matches_oracle(oracle, tmp_path, detector):
+    """`feature_detector: 'AKAZE'` / `'ORB'` in the node's YAML (uvo/config/mono_VO_parameters.yaml:19): the unchanged mono loop on the other two
+    branches of detect_features (VO_utility.cpp:93-105) -- CV_8U rows through the 7-argument match_features, which applies NORM_L2 to them
+    (VO_utility.cpp:555) -- against the oracle's state machine switched to the same detector.  ORB's table: OpenCV's makeRandomPattern
+    (the learned bit_pattern_31_ is the integrator's to supply), read from UVO_ORB_PATTERN_FILE."""
+    from ergo_uvo_amd import synth
+    W, H = 640, 480
+    scene = synth.Scene(synth.SEEDS["C1"], W)
+    rig = synth.stereo_rig(W)
+    ks = [0, 2, 4, 4.25, 6]
+    grays = [synth.mono_frame(scene, k, W, H) for k in ks]
+    R0, C0 = synth.camera_pose(0)
+    rng = scene.depth_at_center(C0, R0)
+    frames = [(1.0 + 0.2 * i, rng, _rgb(g)) for i, g in enumerate(grays)]
+    pat = oracle.orb_random_pattern()
+    patf = tmp_path / "bit_pattern_31.txt"
+    patf.write_text(" ".join(str(int(v)) for v in pat.reshape(-1)) + "\n")
+    rec = _run_node(tmp_path, "mono", "frontal_camera", frames, MONO_PARAMS.replace("'SURF'", f"'{detector}'"), _intr_yaml(rig.K_left), env={"UVO_ORB_PATTERN_FILE": str(patf), "UVO_TEST_MAX_KPTS": "16384"})
+    Ks, newK, _ = oracle.resize_camera_matrix(W, H, 640, rig.K_left, np.zeros(4))
+    ovo = oracle.MonoVO(oracle.mono_params(), newK, max_kpts=16384)
+    ovo.use_detector(detector, pat)
+    n_valid = 0
+    for i, g in enumerate(grays):
+        pre = oracle.get_image(_rgb(g), 640, Ks, np.zeros(4), newK, True, 3)
+        o = ovo.step(pre, rng, 0.2)
+        r = rec[i]
+        assert (r["i"][0], r["i"][2]) == (o.published, o.n_kps), (i, list(r["i"]))
+        if o.published:
+            assert (r["i"][1], r["i"][3], r["i"][4], r["i"][5]) == (o.valid, o.n_matches, o.n_inliers, o.n_good3d), (i, list(r["i"]))
+            v, ov = r["d"][:3], np.array(list(o.velocity))
+            assert np.linalg.norm(v - ov) <= 1e-4 * np.linalg.norm(ov), (i, v, ov)
+            n_valid += o.valid
+    assert n_valid == len(ks) - 1
+
+
+@pytest.mark.gpu
+def test_stereo_node_loop_on_akaze_matches_oracle(oracle, scene_small, tmp_path):
+    """`feature_detector: 'AKAZE'` for the stereo node class: get_image, detect_features' AKAZE branch, the Hamming matcher, the loop unchanged."""
+    from ergo_uvo_amd import synth
+    rig = synth.stereo_rig(640)
+    seq = [scene_small[k] for k in (0, 1, 2, 1)]
+    frames = [(2.0 + 0.05 * i, 0.0, _rgb(L), _rgb(R)) for i, (L, R) in enumerate(seq)]
+    rec = _run_node(tmp_path, "stereo", "frontal_camera", frames, STEREO_PARAMS.replace("'SURF'", "'AKAZE'"), _intr_yaml(rig.K_left, stereo=(rig.K_right, rig.R_right, rig.t_right)))
+    KsL, newKL, _ = oracle.resize_camera_matrix(640, 360, 640, rig.K_left, np.zeros(4))
+    KsR, newKR, _ = oracle.resize_camera_matrix(640, 360, 640, rig.K_right, np.zeros(4))
+    ovo = oracle.StereoVO(oracle.stereo_params(1500), newKL, newKR, rig.R_right, rig.t_right)
+    ovo.use_detector("AKAZE")
+    n_valid = 0
+    for i, (L, R) in enumerate(seq):
+        pl = oracle.get_image(_rgb(L), 640, KsL, np.zeros(4), newKL, True, 8)
+        pr = oracle.get_image(_rgb(R), 640, KsR, np.zeros(4), newKR, True, 8)
+        o = ovo.step(pl, pr, 0.05)
+        r = rec[i]
+        assert r["i"][0] == o.initialized and r["i"][2] == o.n_left, (i, list(r["i"]))
+        if o.initialized:
+            assert (r["i"][1], r["i"][3], r["i"][4], r["i"][5]) == (o.valid, o.n_tri_matches, o.n_inliers, o.n_good3d), (i, list(r["i"]))
+            v, ov = r["d"][:3], np.array(list(o.velocity))
+            assert np.linalg.norm(v - ov) <= 1e-4 * max(np.linalg.norm(ov), 1e-300), (i, v, ov)
+            n_valid += o.valid
+    assert n_valid == len(seq) - 1
 
 
 @pytest.mark.gpu
