@@ -2,6 +2,7 @@
 // fused stereo step (visual_odometry_node::stereo_VO, visual_odometry.h:474-739) with every
 // intermediate kept in HBM.
 #include "uvo_ctx.h"
+#include <pthread.h>
 #include "uvo_epnp.h"
 #include <string.h>
 #include <sched.h>
@@ -1386,6 +1387,7 @@ static bool wait_stage_a(uvo_ctx* L)
 }
 static void lane_worker(uvo_ctx* L)
 {
+    { char nm[16]; snprintf(nm, sizeof(nm), "uvo-lane%d", L->lane_id); (void)pthread_setname_np(pthread_self(), nm); }      // (top, /proc/<pid>/task/*/comm: tools/probe/thread_cpu.py)
     (void)hipSetDevice(L->device);
     std::unique_lock<std::mutex> lk(L->mu);
     for (;;) {
