@@ -37,6 +37,28 @@ CHILD = textwrap.dedent(r"""
     orc.sift_detect(np.random.default_rng(5).integers(0, 256, (64, 90), dtype=np.uint8), nfeatures=0, n_octave_layers=2, sigma=1.2)
     orc.sift_gauss_layer(frames[0][0][:40, :56].copy(), 3, 5)
     orc.knn2(desc[:1], desc2[:1])
+    # AKAZE (o_akaze.c) and ORB (o_orb.c): odd sizes (the general resize tables), images too small for the upper levels, a cut list whose
+    # rankings run through the nth_element replay, keypoints only (no sampling table)
+    ka, da = orc.akaze_detect(frames[0][0])
+    assert len(ka) > 50 and da.shape == (len(ka), 61)
+    orc.akaze_detect(frames[0][0][:131, :203].copy())
+    orc.akaze_detect(frames[0][0][:40, :56].copy())
+    pat = orc.orb_random_pattern()
+    ko, do_ = orc.orb_detect(frames[0][0], pat)
+    assert len(ko) > 500 and do_.shape == (len(ko), 32)
+    orc.orb_detect(frames[0][0][:131, :203].copy(), pat, nfeatures=60)
+    orc.orb_detect(frames[0][0][:70, :90].copy(), None)
+    orc.orb_detect(frames[0][0], pat, nfeatures=300, scaleFactor=1.5, nlevels=3, edgeThreshold=40, fastThreshold=30)
+    orc.match_hamming(do_[:200], do_[100:400], 0.8)
+    for det in ("AKAZE", "ORB"):
+        vb = orc.StereoVO(orc.stereo_params(400), rig.K_left, rig.K_right, rig.R_right, rig.t_right, max_kpts=16384)
+        vb.use_detector(det, pat)
+        for l, r in frames[:2]:
+            vb.step(l, r, 0.05)
+        mb = orc.MonoVO(orc.mono_params(400, 8), rig.K_left, max_kpts=16384)
+        mb.use_detector(det, pat)
+        for k in range(2):
+            mb.step(synth.mono_frame(scene, k, W, H), 4.0, 0.05)
     vo = orc.StereoVO(orc.stereo_params(400), rig.K_left, rig.K_right, rig.R_right, rig.t_right)
     for l, r in frames:
         vo.step(l, r, 0.05)
