@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -37,3 +38,23 @@ def test_dumper_source_cites_the_reference_call_sites():
     for needle in ("xfeatures2d::SURF::create", "knnMatch", "triangulatePoints", "solvePnPRansac", "findEssentialMat", "recoverPose",
                    "findHomography", "decomposeHomographyMat", "getOptimalNewCameraMatrix", "INTER_AREA", "createCLAHE", "VOU:", "VO:"):
         assert needle in text, needle
+
+
+def test_orb_pattern_extractor_reads_an_annotated_initialiser(tmp_path):
+    """tools/orb_pattern_from_opencv_source.py on a stand-in source file (seeded integers -- not OpenCV's table -- in orb.cpp's layout, with
+    its block and line comments): 1024 integers come back in order, in the text format the C++ surface parses; a short table is refused."""
+    import importlib.util, random
+    spec = importlib.util.spec_from_file_location("orbpat", os.path.join(ROOT, "tools", "orb_pattern_from_opencv_source.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    rnd = random.Random(5)
+    vals = [rnd.randint(-13, 13) for _ in range(1024)]
+    lines = [f"    {vals[4*k]},{vals[4*k+1]}, {vals[4*k+2]},{vals[4*k+3]} /*mean (0.{k}), correlation ({k % 7})*/," for k in range(256)]
+    src = "static int other_[4] = { 1, 2, 3, 4 };\nstatic int bit_pattern_31_[256*4] =\n{\n" + "\n".join(lines) + "  // the end\n};\nstatic void f() { int x[2] = {5, 6}; }\n"
+    cpp, out = tmp_path / "orb.cpp", tmp_path / "pattern.txt"
+    cpp.write_text(src)
+    assert m.extract(src) == vals
+    assert m.main(["x", str(cpp), str(out)]) == 0
+    back = [int(v) for v in out.read_text().replace(",", " ").split()]
+    assert back == vals
+    with pytest.raises(ValueError):
+        m.extract(src.replace(lines[7] + "\n", ""))
