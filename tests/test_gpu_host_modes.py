@@ -117,8 +117,10 @@ def test_every_host_mode_returns_the_synchronous_steps_results(cases, want, labe
 
 
 def test_a_device_driven_rank_keeps_about_one_host_thread_busy():
-    """What the mode is for: at C3 with six pairs in flight the process burns at most ~1.5 CPU seconds per second with the PnP round on
-    the device (one polling submit / collect thread + the runtime's helpers), against 7-9 when every lane's worker polls."""
+    """What the mode is for: at C3 with six pairs in flight the process burns about two CPU seconds per second with the PnP round on the
+    device -- the polling submit / collect thread and one thread of the HIP runtime that the pipeline's completion signals keep awake
+    (tools/probe/thread_cpu.py: 0.99 + 0.96; the lane workers sleep) -- against 7-9 when every lane's worker polls.  The bound leaves
+    room for the runtime's other helpers (1.95-2.04 observed)."""
     import time
     import torch
     import ergo_uvo_amd as uvo
@@ -155,5 +157,5 @@ def test_a_device_driven_rank_keeps_about_one_host_thread_busy():
         for k, v in saved.items():
             if v is not None:
                 os.environ[k] = v
-    assert busy["device"] <= 2.0, busy
+    assert busy["device"] <= 2.4, busy
     assert busy["worker"] >= busy["device"] + 1.0, busy
