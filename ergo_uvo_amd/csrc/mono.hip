@@ -711,6 +711,8 @@ struct MonoWs {                       // device workspace of the mono stage, own
     uint8_t* masks = nullptr;                      // 5 x cap
     int* good = nullptr;                           // 4
     double* best = nullptr;                        // 9
+    bool h_one_round = false;                      // findHomography's RANSAC: the last scan went on past the first round's hypotheses, so the next
+                                                   // call solves them all in one launch (a launch takes 0.35 ms whether it carries 128 or 2000)
     Pinned<int> h_subsets, h_nmodels, h_counts;
     Pinned<double> h_medians, h_models;
     Pinned<double> h_q1, h_q2;                     // normalised points on their way to q1 / q2
@@ -1204,8 +1206,10 @@ uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f
             UVO_HIP_TRY(c, hipMemcpyAsync(w->dst, dst.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
             UVO_HIP_TRY(c, hipMemcpyAsync(w->subsets, w->h_subsets.data(), sizeof(int) * 4 * nsub, hipMemcpyHostToDevice, st));
             // RANSAC in rounds, as mono_find_essential: the first kFirstRound subsets, the rest only if the adaptive count reaches past them
+            // (at the shipped 0.1-px threshold the scan of a low-inlier frame never settles inside the first round, and the second launch
+            //  costs the frame another 0.35 ms and a synchronisation: the workspace remembers what the last scan needed)
             const int kFirstRound = 128;
-            const int first = (!lmeds && nsub > kFirstRound) ? kFirstRound : nsub;
+            const int first = (!lmeds && nsub > kFirstRound && !w->h_one_round) ? kFirstRound : nsub;
             hipLaunchKernelGGL(k_h_hyp, dim3((first + kHPerWg - 1) / kHPerWg), dim3(64), 0, st, w->src, w->dst, w->subsets, first,
                                w->models, w->nmodels);
             const int npow2 = next_pow2(n);
@@ -1222,6 +1226,7 @@ uvo_status mono_find_homography(Ctx* c, const uvo_point2f* p1, const uvo_point2f
             else {
                 int settled = niters;
                 win = replay_ransac(w->h_nmodels.data(), w->h_counts.data(), 1, first, niters, n, modelPoints, confidence, &settled);
+                if (nsub > kFirstRound) w->h_one_round = settled > kFirstRound;          // the scan's result is the same either way
                 if (first < nsub && settled > first) {
                     const int rest = nsub - first;
                     hipLaunchKernelGGL(k_h_hyp, dim3((rest + kHPerWg - 1) / kHPerWg), dim3(64), 0, st, w->src, w->dst,
